@@ -1,0 +1,185 @@
+/*
+ * nohuman_engine.h -- C ABI of libnohuman_engine.so, the MI355X (gfx950) in-process replacement
+ * for the `kraken2` subprocess that nohuman spawns.
+ *
+ * What it replaces in the reference (file:line under /root/reference):
+ *   - the process boundary  CommandRunner::run -> Command::new("kraken2").args(..).output()
+ *     (src/lib.rs:22-48) called once, blocking, from main() (src/main.rs:270);
+ *   - the information carried by the argv built at src/main.rs:210-267
+ *     (--threads, --db, --output, --confidence, --report, --paired,
+ *      --classified-out | --unclassified-out, input paths);
+ *   - the three integers scraped from kraken2's stderr by parse_kraken_stderr
+ *     (src/lib.rs:61-97), which the engine returns directly in nh_stats;
+ *   - the dependency check CommandRunner::is_executable (src/lib.rs:50-57) -> nh_probe;
+ *   - the database directory contract validate_db_directory (src/lib.rs:119-141) -> nh_open.
+ *
+ * Conventions: every function returns 0 on success or a negative nh_status; nothing throws or
+ * aborts across the ABI; the caller owns every buffer it passes; the engine handle is opaque and
+ * only created/destroyed by nh_open... / nh_close; nh_last_error() is a thread-local string valid
+ * until the next call on that thread.  There is NO CPU fallback: without a usable gfx950 device
+ * nh_open / nh_probe fail with NH_EDEVICE.
+ */
+#ifndef NOHUMAN_ENGINE_H
+#define NOHUMAN_ENGINE_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define NH_ABI_VERSION 1
+
+typedef enum {
+    NH_OK = 0,
+    NH_EINVAL = -1,   /* bad argument */
+    NH_EIO = -2,      /* file could not be read / written */
+    NH_EDB = -3,      /* malformed or unsupported database (e.g. protein DB) */
+    NH_EDEVICE = -4,  /* no usable gfx950 device, HIP error */
+    NH_EOOM = -5,     /* host or device allocation failed */
+    NH_ECAPACITY = -6 /* an internal per-fragment capacity was exceeded (reported, never silent) */
+} nh_status;
+
+typedef struct nh_engine nh_engine;
+
+/* One record per fragment (read or read pair).  16 bytes; the "result record" of the roofline
+ * formula in BASELINE.md section 4.  Replaces the C/U column, the taxid column and the hit list
+ * totals of kraken2's per-read output line. */
+typedef struct {
+    uint32_t call;        /* internal taxon id of the call; 0 = unclassified (kept by nohuman) */
+    uint32_t total_kmers; /* k-mers of both mates, ambiguous ones included (confidence denominator) */
+    uint32_t clade_hits;  /* k-mer hits in the clade rooted at `call` (confidence numerator) */
+    uint32_t hit_groups;  /* kraken2 minimizer_hit_groups */
+} nh_result;
+
+/* per-k-mer taxa list markers (the "A:n" and "|:|" items of kraken2's hit list) */
+#define NH_TAXON_AMBIGUOUS 0xFFFFFFFFu
+#define NH_TAXON_MATE_BORDER 0xFFFFFFFEu
+
+/* Replaces the three summary lines of kraken2's stderr (src/lib.rs:67-89). */
+typedef struct {
+    uint64_t total_sequences; /* fragments processed */
+    uint64_t classified;      /* "sequences classified" == human for nohuman */
+    uint64_t unclassified;
+    uint64_t total_bases;
+    uint64_t table_lookups;   /* D of the roofline formula, summed */
+    double seconds;           /* classify wall time, database load excluded (as kraken2's timer) */
+} nh_stats;
+
+typedef struct {
+    uint64_t k, l, spaced_seed_mask, toggle_mask, minimum_acceptable_hash_value;
+    int32_t revcom_version, dna_db;
+    uint64_t capacity, size, key_bits, value_bits;
+    uint64_t node_count;
+    int32_t device;
+    int32_t reserved;
+} nh_db_info;
+
+/* Behaviour switches; defaults reproduce kraken2 as nohuman invokes it (src/main.rs:215-224:
+ * no --minimum-hit-groups, no --quick, no quality masking). */
+typedef struct {
+    uint32_t minimum_hit_groups; /* default 2 */
+    int32_t linear_probing;      /* default 1 (kraken2 builds with -DLINEAR_PROBING) */
+    int32_t reset_per_mate;      /* default 1 (last minimizer/taxon reset for each mate) */
+    int32_t reserved;
+} nh_options;
+
+/* flags of nh_classify_* */
+#define NH_FLAG_PAIRED 1u /* sequences 2f and 2f+1 are the mates of fragment f (--paired) */
+
+const char *nh_last_error(void);
+int nh_abi_version(void);
+
+/* 0 if a gfx950 device is usable; msg receives a one-line description either way.
+ * Replaces CommandRunner::is_executable (src/lib.rs:50-57), used by `nohuman --check`. */
+int nh_probe(char *msg, size_t msg_len);
+int nh_device_count(int *count);
+
+/* Load <db_dir>/{hash,opts,taxo}.k2d -- or <db_dir>/db/... (src/lib.rs:119-141) -- into the HBM
+ * of `device`.  Replaces kraken2's "Loading database information..." phase. */
+int nh_open(const char *db_dir, int device, nh_engine **out);
+/* Same from in-memory images of the three files (borrowed for the duration of the call). */
+int nh_open_images(const void *opts, size_t opts_len, const void *taxo, size_t taxo_len,
+                   const void *hash, size_t hash_len, int device, nh_engine **out);
+/* Bench/test support: a database whose hash table is generated directly in HBM (n_keys pseudo-
+ * random minimizers inserted with kraken2's CompareAndSet linear-probing rule; every value is the
+ * deepest node of a `depth`-node chain taxonomy).  Stands in for HPRC.r2, which cannot be
+ * downloaded on the build or GPU boxes. */
+int nh_open_synthetic(uint64_t capacity, uint64_t n_keys, uint32_t depth, uint64_t seed, int device,
+                      nh_engine **out);
+int nh_close(nh_engine *e);
+
+int nh_db_info_get(const nh_engine *e, nh_db_info *info);
+int nh_options_get(const nh_engine *e, nh_options *o);
+int nh_options_set(nh_engine *e, const nh_options *o);
+/* internal taxon id -> external (NCBI) id, as printed in kraken2's output / "kraken:taxid|N" */
+int nh_taxon_external(const nh_engine *e, uint32_t internal, uint64_t *external);
+/* copies of the database images back to the host (tests and the bench's CPU-baseline leg) */
+int nh_table_download(const nh_engine *e, uint32_t *cells, uint64_t n_cells);
+int nh_taxonomy_image(const nh_engine *e, void *buf, size_t cap, size_t *len);
+int nh_opts_image(const nh_engine *e, void *buf, size_t cap, size_t *len);
+
+/*
+ * Classify one batch held in HOST memory; blocking.  Replaces kraken2's per-block loop
+ * (classify.cc ProcessFiles/ClassifySequence) for the reads of one batch.
+ *   bases        concatenated sequence bytes exactly as in the FASTQ/FASTA sequence lines
+ *   seq_offsets  n_seq+1 offsets into bases; n_seq = n_frag * (paired ? 2 : 1)
+ *   confidence   the f64 value kraken2 would parse from --confidence (src/main.rs:213)
+ *   results      n_frag records
+ *   kmer_taxa / kmer_taxa_offsets (both NULL or both set): per-k-mer internal taxon ids with the
+ *                two markers above -- the material of the `-k` hit list.
+ *                kmer_taxa_offsets[f] = sum over fragments < f of (k-mers of both mates + paired);
+ *                the caller sizes kmer_taxa with nh_kmer_taxa_entries.
+ */
+int nh_classify_batch(nh_engine *e, const uint8_t *bases, const uint64_t *seq_offsets,
+                      uint64_t n_frag, uint32_t flags, double confidence, nh_result *results,
+                      uint32_t *kmer_taxa, uint64_t *kmer_taxa_offsets, uint64_t kmer_taxa_cap);
+uint64_t nh_kmer_taxa_entries(const nh_engine *e, const uint64_t *seq_offsets, uint64_t n_frag,
+                              uint32_t flags);
+
+/*
+ * Same with every buffer already resident in the engine device's HBM; asynchronous on `stream`
+ * (a hipStream_t, NULL = the default stream).  d_bases must be 4-byte aligned and readable for
+ * 8 bytes past the last base.  d_kmer_taxa / d_kmer_taxa_offsets may be NULL.  d_counters (may be
+ * NULL) points at 4 uint64 accumulators {fragments, classified, bases, table_lookups} that the
+ * kernel adds to.  This is the entry the roofline number of bench.py is measured on.
+ */
+int nh_classify_batch_device(nh_engine *e, const void *d_bases, const void *d_seq_offsets,
+                             uint64_t n_frag, uint32_t flags, double confidence, void *d_results,
+                             void *d_kmer_taxa, const void *d_kmer_taxa_offsets, void *d_counters,
+                             void *stream);
+
+/* running totals over every nh_classify_batch* call on this engine since open / reset */
+int nh_stats_get(nh_engine *e, nh_stats *s);
+int nh_stats_reset(nh_engine *e);
+
+/*
+ * Whole-run entry: the information of the argv at src/main.rs:210-267, outputs written
+ * UNCOMPRESSED to the given paths exactly where kraken2 would write kraken_out.fq /
+ * kraken_out_1.fq + kraken_out_2.fq (src/main.rs:252-256,308-309,333), so nohuman's compress stage
+ * (src/main.rs:342-368) is untouched.
+ */
+typedef struct {
+    const char *db_dir;        /* --db */
+    const char *in1;           /* first input (plain or gzip FASTQ/FASTA) */
+    const char *in2;           /* second input or NULL (--paired when set) */
+    const char *out1;          /* kraken_out.fq / kraken_out_1.fq */
+    const char *out2;          /* kraken_out_2.fq or NULL */
+    const char *kraken_output; /* --output; NULL or "/dev/null" = none */
+    const char *report;        /* --report; NULL = none */
+    double confidence;         /* --confidence */
+    uint32_t threads;          /* --threads: host reader/writer workers */
+    int32_t keep_human;        /* 0: --unclassified-out (default), 1: --classified-out (-H) */
+    int32_t n_devices;         /* 0 = all visible devices */
+    const int32_t *device_ids; /* NULL = 0..n_devices-1 */
+} nh_run_args;
+
+int nh_run(const nh_run_args *args, nh_stats *stats);
+/* nh_run on an already opened engine (single device) */
+int nh_run_engine(nh_engine *e, const nh_run_args *args, nh_stats *stats);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* NOHUMAN_ENGINE_H */

@@ -1,0 +1,44 @@
+// nh_device.h -- device-side parameter block shared by the gfx950 kernels and the host launcher.
+#pragma once
+#include <stdint.h>
+
+namespace nh {
+
+// Everything a classify wave needs to know about the database, passed by value as a kernel
+// argument (lives in SGPRs / the kernarg segment; no global loads for it).
+struct DevDB {
+    const uint32_t *table;  // hash.k2d cells, capacity entries (+ padding to a multiple of 4, +4)
+    uint64_t capacity;
+    uint64_t cap_magic;     // floor((2^64 - 1) / capacity): exact `hc % capacity` without a divide
+    const uint32_t *parent; // taxonomy: internal parent ids [node_count]
+    uint32_t node_count;
+    uint32_t value_bits;
+    uint32_t vmask;
+    uint32_t k, l;
+    uint32_t window;        // k - l
+    uint64_t lmer_mask;     // low 2l bits
+    uint64_t spaced_mask;   // spaced_seed_mask, or ~0 when the DB has none
+    uint64_t toggle;        // toggle_mask & lmer_mask
+    uint64_t min_hash;      // minimum_acceptable_hash_value
+    int32_t revcom_version;
+    int32_t linear_probing;
+    int32_t reset_per_mate;
+    uint32_t min_hit_groups;
+};
+
+// per-launch device counters (uint64 each)
+enum { CNT_FRAGMENTS = 0, CNT_CLASSIFIED = 1, CNT_BASES = 2, CNT_LOOKUPS = 3, CNT_N = 4 };
+
+struct Result {
+    uint32_t call, total_kmers, clade_hits, hit_groups;
+};
+
+constexpr uint32_t TAXON_AMBIGUOUS = 0xFFFFFFFFu;
+constexpr uint32_t TAXON_MATE_BORDER = 0xFFFFFFFEu;
+
+constexpr int WAVE = 64;
+constexpr int WAVES_PER_BLOCK = 4;
+constexpr int TL = 128;      // l-mers per tile (2 per lane)
+constexpr int LIST_CAP = 64; // distinct taxa per fragment held in LDS
+
+}  // namespace nh

@@ -1,0 +1,699 @@
+// nh_engine.hip -- host side of libnohuman_engine.so: database images -> HBM, batch staging,
+// and the extern "C" ABI declared in include/nohuman_engine.h.
+//
+// Reference units replaced (file:line under /root/reference): the kraken2 process boundary
+// src/lib.rs:22-48 / src/main.rs:270; DB directory contract src/lib.rs:119-141; the kraken2 units
+// behind it are external (pinned Dockerfile:15,35-38) and specified in SURVEY.md Appendix A.
+// No CPU fallback exists in this file: without a HIP device every entry fails with NH_EDEVICE.
+#include <hip/hip_runtime.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <sys/stat.h>
+
+#include <chrono>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "nh_device.h"
+#include "nh_internal.h"
+#include "nohuman_engine.h"
+
+namespace nh {
+
+thread_local std::string g_last_error;
+
+int set_error(int code, const char *fmt, ...) {
+    char buf[1024];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    g_last_error = buf;
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                        \
+    do {                                                                                     \
+        hipError_t _e = (expr);                                                              \
+        if (_e != hipSuccess)                                                                \
+            return set_error(_e == hipErrorOutOfMemory ? NH_EOOM : NH_EDEVICE, "%s: %s", #expr, \
+                             hipGetErrorString(_e));                                         \
+    } while (0)
+
+static uint64_t rd64(const uint8_t *p) {
+    uint64_t v;
+    memcpy(&v, p, 8);
+    return v;
+}
+
+static int check_device(int device) {
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0)
+        return set_error(NH_EDEVICE, "no HIP device available (%s)",
+                         e == hipSuccess ? "count 0" : hipGetErrorString(e));
+    if (device < 0 || device >= n)
+        return set_error(NH_EDEVICE, "device %d out of range (have %d)", device, n);
+    hipDeviceProp_t prop;
+    HIP_TRY(hipGetDeviceProperties(&prop, device));
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+        return set_error(NH_EDEVICE, "device %d is %s; this library is built for gfx950 only",
+                         device, prop.gcnArchName);
+    return NH_OK;
+}
+
+static int parse_opts(Engine *e, const void *opts, size_t opts_len) {
+    uint8_t ob[64];
+    memset(ob, 0, sizeof ob);
+    memcpy(ob, opts, opts_len < 64 ? opts_len : 64);
+    e->opts_image.assign((const uint8_t *)opts, (const uint8_t *)opts + opts_len);
+    nh_db_info &i = e->info;
+    i.k = rd64(ob);
+    i.l = rd64(ob + 8);
+    i.spaced_seed_mask = rd64(ob + 16);
+    i.toggle_mask = rd64(ob + 24);
+    i.dna_db = ob[32];
+    i.minimum_acceptable_hash_value = rd64(ob + 40);
+    memcpy(&i.revcom_version, ob + 48, 4);
+    if (!i.dna_db) return set_error(NH_EDB, "opts.k2d: protein databases are not supported");
+    if (i.l == 0 || i.l > 31 || i.l > i.k)
+        return set_error(NH_EDB, "opts.k2d: unsupported k=%llu l=%llu", (unsigned long long)i.k,
+                         (unsigned long long)i.l);
+    if (i.k - i.l > 64)
+        return set_error(NH_EDB, "opts.k2d: k-l=%llu exceeds the 64 supported by the tile layout",
+                         (unsigned long long)(i.k - i.l));
+    return NH_OK;
+}
+
+static int parse_taxonomy(Engine *e, const void *taxo, size_t taxo_len) {
+    const uint8_t *tb = (const uint8_t *)taxo;
+    if (taxo_len < 32 || memcmp(tb, "K2TAXDAT", 8) != 0)
+        return set_error(NH_EDB, "taxo.k2d: bad magic");
+    uint64_t nc = rd64(tb + 8), nl = rd64(tb + 16), rl = rd64(tb + 24);
+    if (nc == 0 || nc > 0xFFFFFFF0ull || taxo_len != 32 + 56 * nc + nl + rl)
+        return set_error(NH_EDB, "taxo.k2d: size does not match its header");
+    e->taxo_image.assign(tb, tb + taxo_len);
+    e->info.node_count = nc;
+    e->parent.resize(nc);
+    e->external.resize(nc);
+    for (uint64_t i = 0; i < nc; i++) {
+        const uint8_t *n = tb + 32 + 56 * i;
+        uint64_t p = rd64(n);
+        if (i >= 2 && p >= i) return set_error(NH_EDB, "taxo.k2d: parent id not below child id");
+        e->parent[i] = (uint32_t)p;
+        e->external[i] = rd64(n + 40);
+    }
+    return NH_OK;
+}
+
+static void finish_devdb(Engine *e) {
+    DevDB &d = e->dev;
+    const nh_db_info &i = e->info;
+    d.table = e->d_table;
+    d.capacity = i.capacity;
+    d.cap_magic = ~0ull / i.capacity;
+    d.parent = e->d_parent;
+    d.node_count = (uint32_t)i.node_count;
+    d.value_bits = (uint32_t)i.value_bits;
+    d.vmask = (uint32_t)((1ull << i.value_bits) - 1);
+    d.k = (uint32_t)i.k;
+    d.l = (uint32_t)i.l;
+    d.window = (uint32_t)(i.k - i.l);
+    d.lmer_mask = (1ull << (2 * i.l)) - 1;
+    d.spaced_mask = i.spaced_seed_mask ? i.spaced_seed_mask : ~0ull;
+    d.toggle = i.toggle_mask & d.lmer_mask;
+    d.min_hash = i.minimum_acceptable_hash_value;
+    d.revcom_version = i.revcom_version;
+    d.linear_probing = e->options.linear_probing;
+    d.reset_per_mate = e->options.reset_per_mate;
+    d.min_hit_groups = e->options.minimum_hit_groups;
+}
+
+static int alloc_table(Engine *e, uint64_t capacity) {
+    // padded so that 16-byte chunk loads at the end of the table stay in bounds
+    e->table_cells_alloc = ((capacity + 3) & ~3ull) + 4;
+    HIP_TRY(hipMalloc((void **)&e->d_table, e->table_cells_alloc * sizeof(uint32_t)));
+    return NH_OK;
+}
+
+static int common_open(Engine *e, int device) {
+    int rc = check_device(device);
+    if (rc) return rc;
+    e->device = device;
+    e->info.device = device;
+    HIP_TRY(hipSetDevice(device));
+    hipDeviceProp_t prop;
+    HIP_TRY(hipGetDeviceProperties(&prop, device));
+    e->n_cu = prop.multiProcessorCount;
+    e->grid_blocks = e->n_cu * classify_blocks_per_cu();  // every resident wave slot, persistent
+    e->options.minimum_hit_groups = 2;
+    e->options.linear_probing = 1;
+    e->options.reset_per_mate = 1;
+    HIP_TRY(hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking));
+    HIP_TRY(hipMalloc((void **)&e->d_counters, CNT_N * sizeof(uint64_t)));
+    HIP_TRY(hipMemset(e->d_counters, 0, CNT_N * sizeof(uint64_t)));
+    HIP_TRY(hipMalloc((void **)&e->d_error, sizeof(int)));
+    HIP_TRY(hipMemset(e->d_error, 0, sizeof(int)));
+    return NH_OK;
+}
+
+static int upload_taxonomy(Engine *e) {
+    HIP_TRY(hipMalloc((void **)&e->d_parent, e->parent.size() * sizeof(uint32_t)));
+    HIP_TRY(hipMemcpy(e->d_parent, e->parent.data(), e->parent.size() * sizeof(uint32_t),
+                      hipMemcpyHostToDevice));
+    return NH_OK;
+}
+
+void destroy(Engine *e) {
+    if (!e) return;
+    if (e->device >= 0) (void)hipSetDevice(e->device);
+    if (e->d_table) (void)hipFree(e->d_table);
+    if (e->d_parent) (void)hipFree(e->d_parent);
+    if (e->d_counters) (void)hipFree(e->d_counters);
+    if (e->d_error) (void)hipFree(e->d_error);
+    for (void *p : {e->st.d_bases, e->st.d_offsets, e->st.d_results, e->st.d_taxa, e->st.d_taxa_off})
+        if (p) (void)hipFree(p);
+    if (e->stream) (void)hipStreamDestroy(e->stream);
+    delete e;
+}
+
+int open_images(const void *opts, size_t opts_len, const void *taxo, size_t taxo_len,
+                const void *hash, size_t hash_len, int device, Engine **out) {
+    if (!opts || !taxo || !hash || !out) return set_error(NH_EINVAL, "null argument");
+    Engine *e = new Engine();
+    int rc = common_open(e, device);
+    if (!rc) rc = parse_opts(e, opts, opts_len);
+    if (!rc) rc = parse_taxonomy(e, taxo, taxo_len);
+    if (!rc) {
+        const uint8_t *hb = (const uint8_t *)hash;
+        if (hash_len < 32) rc = set_error(NH_EDB, "hash.k2d: truncated header");
+        else {
+            e->info.capacity = rd64(hb);
+            e->info.size = rd64(hb + 8);
+            e->info.key_bits = rd64(hb + 16);
+            e->info.value_bits = rd64(hb + 24);
+            if (e->info.key_bits + e->info.value_bits != 32 || e->info.value_bits == 0 ||
+                e->info.value_bits > 31)
+                rc = set_error(NH_EDB, "hash.k2d: key_bits + value_bits != 32");
+            else if (e->info.capacity == 0 || hash_len != 32 + 4 * e->info.capacity)
+                rc = set_error(NH_EDB, "hash.k2d: size %zu != 32 + 4*capacity (%llu)", hash_len,
+                               (unsigned long long)e->info.capacity);
+        }
+        if (!rc) rc = alloc_table(e, e->info.capacity);
+        if (!rc) {
+            hipError_t he = hipMemset(e->d_table, 0, e->table_cells_alloc * sizeof(uint32_t));
+            if (he == hipSuccess)
+                he = hipMemcpy(e->d_table, hb + 32, 4 * e->info.capacity, hipMemcpyHostToDevice);
+            if (he != hipSuccess) rc = set_error(NH_EDEVICE, "table upload: %s", hipGetErrorString(he));
+        }
+    }
+    if (!rc) rc = upload_taxonomy(e);
+    if (rc) {
+        destroy(e);
+        return rc;
+    }
+    finish_devdb(e);
+    *out = e;
+    return NH_OK;
+}
+
+static bool file_exists(const std::string &p) {
+    struct stat st;
+    return stat(p.c_str(), &st) == 0 && S_ISREG(st.st_mode);
+}
+
+static int slurp(const std::string &path, std::vector<uint8_t> &buf) {
+    FILE *f = fopen(path.c_str(), "rb");
+    if (!f) return set_error(NH_EIO, "cannot open %s", path.c_str());
+    struct stat st;
+    if (fstat(fileno(f), &st) != 0) {
+        fclose(f);
+        return set_error(NH_EIO, "cannot stat %s", path.c_str());
+    }
+    buf.resize((size_t)st.st_size);
+    size_t got = buf.empty() ? 0 : fread(buf.data(), 1, buf.size(), f);
+    fclose(f);
+    if (got != buf.size()) return set_error(NH_EIO, "short read on %s", path.c_str());
+    return NH_OK;
+}
+
+// validate_db_directory semantics (/root/reference/src/lib.rs:119-141)
+int resolve_db_dir(const char *db_dir, std::string &resolved) {
+    static const char *req[3] = {"hash.k2d", "opts.k2d", "taxo.k2d"};
+    for (const char *sub : {"", "/db"}) {
+        std::string d = std::string(db_dir) + sub;
+        bool ok = true;
+        for (const char *r : req) ok = ok && file_exists(d + "/" + r);
+        if (ok) {
+            resolved = d;
+            return NH_OK;
+        }
+    }
+    return set_error(NH_EDB,
+                     "Required files (hash.k2d, opts.k2d, taxo.k2d) not found in \"%s\" or its "
+                     "'db' subdirectory",
+                     db_dir);
+}
+
+int open_dir(const char *db_dir, int device, Engine **out) {
+    if (!db_dir || !out) return set_error(NH_EINVAL, "null argument");
+    std::string dir;
+    int rc = resolve_db_dir(db_dir, dir);
+    if (rc) return rc;
+    std::vector<uint8_t> ob, tb;
+    if ((rc = slurp(dir + "/opts.k2d", ob))) return rc;
+    if ((rc = slurp(dir + "/taxo.k2d", tb))) return rc;
+    // hash.k2d can be many GB: stream it to the device through a pinned bounce buffer
+    Engine *e = new Engine();
+    rc = common_open(e, device);
+    if (!rc) rc = parse_opts(e, ob.data(), ob.size());
+    if (!rc) rc = parse_taxonomy(e, tb.data(), tb.size());
+    FILE *f = nullptr;
+    if (!rc) {
+        std::string hp = dir + "/hash.k2d";
+        f = fopen(hp.c_str(), "rb");
+        uint8_t hdr[32];
+        struct stat st;
+        if (!f || fstat(fileno(f), &st) != 0 || fread(hdr, 1, 32, f) != 32)
+            rc = set_error(NH_EIO, "cannot read %s", hp.c_str());
+        else {
+            e->info.capacity = rd64(hdr);
+            e->info.size = rd64(hdr + 8);
+            e->info.key_bits = rd64(hdr + 16);
+            e->info.value_bits = rd64(hdr + 24);
+            if (e->info.key_bits + e->info.value_bits != 32 || e->info.value_bits == 0 ||
+                e->info.value_bits > 31)
+                rc = set_error(NH_EDB, "hash.k2d: key_bits + value_bits != 32");
+            else if (e->info.capacity == 0 ||
+                     (uint64_t)st.st_size != 32 + 4 * e->info.capacity)
+                rc = set_error(NH_EDB, "hash.k2d: file size does not match capacity");
+        }
+    }
+    if (!rc) rc = alloc_table(e, e->info.capacity);
+    if (!rc) {
+        const size_t CH = 64u << 20;
+        void *pin[2] = {nullptr, nullptr};
+        hipEvent_t ev[2];
+        hipError_t he = hipMemset(e->d_table, 0, e->table_cells_alloc * sizeof(uint32_t));
+        for (int i = 0; i < 2 && he == hipSuccess; i++) {
+            he = hipHostMalloc(&pin[i], CH, hipHostMallocDefault);
+            if (he == hipSuccess) he = hipEventCreate(&ev[i]);
+        }
+        uint64_t left = 4 * e->info.capacity, off = 0;
+        int slot = 0;
+        bool used[2] = {false, false};
+        while (he == hipSuccess && left > 0) {
+            size_t n = left < CH ? (size_t)left : CH;
+            if (used[slot]) he = hipEventSynchronize(ev[slot]);
+            if (he != hipSuccess) break;
+            if (fread(pin[slot], 1, n, f) != n) {
+                rc = set_error(NH_EIO, "short read on hash.k2d");
+                break;
+            }
+            he = hipMemcpyAsync((uint8_t *)e->d_table + off, pin[slot], n, hipMemcpyHostToDevice,
+                                e->stream);
+            if (he == hipSuccess) he = hipEventRecord(ev[slot], e->stream);
+            used[slot] = true;
+            slot ^= 1;
+            off += n;
+            left -= n;
+        }
+        if (he == hipSuccess) he = hipStreamSynchronize(e->stream);
+        for (int i = 0; i < 2; i++)
+            if (pin[i]) {
+                (void)hipHostFree(pin[i]);
+                (void)hipEventDestroy(ev[i]);
+            }
+        if (he != hipSuccess && !rc) rc = set_error(NH_EDEVICE, "table upload: %s", hipGetErrorString(he));
+    }
+    if (f) fclose(f);
+    if (!rc) rc = upload_taxonomy(e);
+    if (rc) {
+        destroy(e);
+        return rc;
+    }
+    finish_devdb(e);
+    *out = e;
+    return NH_OK;
+}
+
+// chain taxonomy 1 -> 2 -> ... -> depth, external ids: 1 (root), 2..depth-1, 9606 for the leaf
+static std::vector<uint8_t> chain_taxonomy(uint32_t depth) {
+    const uint64_t nc = (uint64_t)depth + 1;
+    std::string names, ranks = std::string("no rank") + '\0';
+    std::vector<uint64_t> nodes(7 * nc, 0);
+    for (uint64_t i = 0; i < nc; i++) {
+        uint64_t *n = &nodes[7 * i];
+        n[0] = i >= 2 ? i - 1 : 0;
+        n[1] = (i >= 1 && i + 1 < nc) ? i + 1 : 0;
+        n[2] = (i >= 1 && i + 1 < nc) ? 1 : 0;
+        n[3] = names.size();
+        n[4] = 0;
+        n[5] = i == 0 ? 0 : (i + 1 == nc ? 9606 : i);
+        char nm[32];
+        snprintf(nm, sizeof nm, "node%llu", (unsigned long long)i);
+        names += nm;
+        names += '\0';
+    }
+    std::vector<uint8_t> img;
+    img.insert(img.end(), (const uint8_t *)"K2TAXDAT", (const uint8_t *)"K2TAXDAT" + 8);
+    uint64_t hdr[3] = {nc, names.size(), ranks.size()};
+    img.insert(img.end(), (uint8_t *)hdr, (uint8_t *)hdr + 24);
+    img.insert(img.end(), (uint8_t *)nodes.data(), (uint8_t *)nodes.data() + 56 * nc);
+    img.insert(img.end(), names.begin(), names.end());
+    img.insert(img.end(), ranks.begin(), ranks.end());
+    return img;
+}
+
+int open_synthetic(uint64_t capacity, uint64_t n_keys, uint32_t depth, uint64_t seed, int device,
+                   Engine **out) {
+    if (!out || capacity == 0 || depth == 0 || n_keys >= capacity)
+        return set_error(NH_EINVAL, "open_synthetic: need 0 < n_keys < capacity and depth > 0");
+    Engine *e = new Engine();
+    int rc = common_open(e, device);
+    // kraken2 nucleotide defaults: k=35 l=31, 7 spaced positions, default toggle
+    uint8_t ob[64];
+    memset(ob, 0, sizeof ob);
+    uint64_t v[4] = {35, 31, 0x3FFFFFFFF3333333ull, 0xe37e28c4271b5a2dull};
+    memcpy(ob, v, 32);
+    ob[32] = 1;
+    int32_t rv = 1;
+    memcpy(ob + 48, &rv, 4);
+    if (!rc) rc = parse_opts(e, ob, sizeof ob);
+    std::vector<uint8_t> tx = chain_taxonomy(depth);
+    if (!rc) rc = parse_taxonomy(e, tx.data(), tx.size());
+    if (!rc) {
+        uint32_t vb = 1;
+        while ((1ull << vb) < e->info.node_count) vb++;
+        e->info.capacity = capacity;
+        e->info.value_bits = vb;
+        e->info.key_bits = 32 - vb;
+        rc = alloc_table(e, capacity);
+    }
+    if (!rc) rc = upload_taxonomy(e);
+    if (!rc) {
+        hipError_t he = hipMemsetAsync(e->d_table, 0, e->table_cells_alloc * sizeof(uint32_t), e->stream);
+        unsigned long long *d_size = (unsigned long long *)e->d_counters;
+        if (he == hipSuccess)
+            he = launch_synth_insert(e->d_table, capacity, ~0ull / capacity,
+                                     (uint32_t)e->info.value_bits, depth, n_keys, seed,
+                                     (1ull << 62) - 1, d_size, e->stream);
+        unsigned long long sz = 0;
+        if (he == hipSuccess) he = hipStreamSynchronize(e->stream);
+        if (he == hipSuccess) he = hipMemcpy(&sz, d_size, 8, hipMemcpyDeviceToHost);
+        if (he == hipSuccess) he = hipMemset(e->d_counters, 0, CNT_N * sizeof(uint64_t));
+        if (he != hipSuccess) rc = set_error(NH_EDEVICE, "synthetic table: %s", hipGetErrorString(he));
+        e->info.size = sz;
+    }
+    if (rc) {
+        destroy(e);
+        return rc;
+    }
+    finish_devdb(e);
+    *out = e;
+    return NH_OK;
+}
+
+static int ensure(void **p, size_t *cap, size_t need) {
+    if (*cap >= need) return NH_OK;
+    if (*p) (void)hipFree(*p);
+    *p = nullptr;
+    *cap = 0;
+    size_t want = need + need / 4 + 256;
+    HIP_TRY(hipMalloc(p, want));
+    *cap = want;
+    return NH_OK;
+}
+
+uint64_t kmer_taxa_entries(const Engine *e, const uint64_t *seq_offsets, uint64_t n_frag, int mates,
+                           uint64_t *offsets_out) {
+    const uint64_t k = e->info.k;
+    uint64_t total = 0;
+    for (uint64_t f = 0; f < n_frag; f++) {
+        if (offsets_out) offsets_out[f] = total;
+        for (int m = 0; m < mates; m++) {
+            uint64_t s = f * (uint64_t)mates + (uint64_t)m;
+            uint64_t len = seq_offsets[s + 1] - seq_offsets[s];
+            if (len >= k) total += len - k + 1;
+        }
+        if (mates == 2) total += 1;
+    }
+    if (offsets_out) offsets_out[n_frag] = total;
+    return total;
+}
+
+int classify_device(Engine *e, const void *d_bases, const void *d_seq_off, uint64_t n_frag,
+                    uint32_t flags, double confidence, void *d_results, void *d_kmer_taxa,
+                    const void *d_kmer_taxa_off, void *d_counters, hipStream_t stream) {
+    if (!(confidence >= 0.0 && confidence <= 1.0))
+        return set_error(NH_EINVAL, "Confidence score must be in the closed interval [0, 1]");
+    if ((d_kmer_taxa != nullptr) != (d_kmer_taxa_off != nullptr))
+        return set_error(NH_EINVAL, "kmer_taxa and kmer_taxa_offsets go together");
+    if (((uintptr_t)d_bases & 3) != 0) return set_error(NH_EINVAL, "d_bases must be 4-byte aligned");
+    finish_devdb(e);
+    hipError_t he = launch_classify(e->dev, d_bases, d_seq_off, n_frag,
+                                    (flags & NH_FLAG_PAIRED) ? 2 : 1, confidence, d_results,
+                                    d_kmer_taxa, d_kmer_taxa_off, d_counters, e->d_error,
+                                    e->grid_blocks, stream);
+    if (he != hipSuccess) return set_error(NH_EDEVICE, "classify launch: %s", hipGetErrorString(he));
+    return NH_OK;
+}
+
+int check_error_flag(Engine *e) {
+    int flag = 0;
+    HIP_TRY(hipMemcpy(&flag, e->d_error, sizeof(int), hipMemcpyDeviceToHost));
+    if (flag) {
+        HIP_TRY(hipMemset(e->d_error, 0, sizeof(int)));
+        return set_error(NH_ECAPACITY,
+                         "a fragment hit more than %d distinct taxa (per-wave LDS list capacity)",
+                         LIST_CAP);
+    }
+    return NH_OK;
+}
+
+int classify_host(Engine *e, const uint8_t *bases, const uint64_t *seq_offsets, uint64_t n_frag,
+                  uint32_t flags, double confidence, nh_result *results, uint32_t *kmer_taxa,
+                  uint64_t *kmer_taxa_offsets, uint64_t kmer_taxa_cap) {
+    if (!seq_offsets || !results || (!bases && n_frag))
+        return set_error(NH_EINVAL, "null argument");
+    if ((kmer_taxa != nullptr) != (kmer_taxa_offsets != nullptr))
+        return set_error(NH_EINVAL, "kmer_taxa and kmer_taxa_offsets go together");
+    std::lock_guard<std::mutex> lock(e->mu);
+    HIP_TRY(hipSetDevice(e->device));
+    const int mates = (flags & NH_FLAG_PAIRED) ? 2 : 1;
+    const uint64_t n_seq = n_frag * (uint64_t)mates;
+    if (n_frag == 0) return NH_OK;
+    const uint64_t base0 = seq_offsets[0];
+    const uint64_t total = seq_offsets[n_seq] - base0;
+    for (uint64_t s = 0; s < n_seq; s++)
+        if (seq_offsets[s + 1] < seq_offsets[s]) return set_error(NH_EINVAL, "seq_offsets not monotone");
+    auto t0 = std::chrono::steady_clock::now();
+    Staging &st = e->st;
+    int rc;
+    if ((rc = ensure(&st.d_bases, &st.cap_bases, total + 64))) return rc;
+    if ((rc = ensure(&st.d_offsets, &st.cap_offsets, (n_seq + 1) * 8))) return rc;
+    if ((rc = ensure(&st.d_results, &st.cap_results, n_frag * sizeof(nh_result)))) return rc;
+    // offsets are rebased so that the staged bases start at 0 (4-byte aligned by hipMalloc)
+    std::vector<uint64_t> rebased;
+    const uint64_t *offs = seq_offsets;
+    if (base0 != 0) {
+        rebased.resize(n_seq + 1);
+        for (uint64_t s = 0; s <= n_seq; s++) rebased[s] = seq_offsets[s] - base0;
+        offs = rebased.data();
+    }
+    uint64_t n_taxa = 0;
+    if (kmer_taxa) {
+        n_taxa = kmer_taxa_entries(e, offs, n_frag, mates, kmer_taxa_offsets);
+        if (n_taxa > kmer_taxa_cap) return set_error(NH_EINVAL, "kmer_taxa buffer too small");
+        if ((rc = ensure(&st.d_taxa, &st.cap_taxa, (n_taxa + 1) * 4))) return rc;
+        if ((rc = ensure(&st.d_taxa_off, &st.cap_taxa_off, (n_frag + 1) * 8))) return rc;
+        HIP_TRY(hipMemcpyAsync(st.d_taxa_off, kmer_taxa_offsets, (n_frag + 1) * 8,
+                               hipMemcpyHostToDevice, e->stream));
+    }
+    if (total) HIP_TRY(hipMemcpyAsync(st.d_bases, bases + base0, total, hipMemcpyHostToDevice, e->stream));
+    HIP_TRY(hipMemsetAsync((uint8_t *)st.d_bases + total, 'A', 64, e->stream));
+    HIP_TRY(hipMemcpyAsync(st.d_offsets, offs, (n_seq + 1) * 8, hipMemcpyHostToDevice, e->stream));
+    rc = classify_device(e, st.d_bases, st.d_offsets, n_frag, flags, confidence, st.d_results,
+                         kmer_taxa ? st.d_taxa : nullptr, kmer_taxa ? st.d_taxa_off : nullptr,
+                         e->d_counters, e->stream);
+    if (rc) return rc;
+    HIP_TRY(hipMemcpyAsync(results, st.d_results, n_frag * sizeof(nh_result), hipMemcpyDeviceToHost,
+                           e->stream));
+    if (kmer_taxa && n_taxa)
+        HIP_TRY(hipMemcpyAsync(kmer_taxa, st.d_taxa, n_taxa * 4, hipMemcpyDeviceToHost, e->stream));
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    if ((rc = check_error_flag(e))) return rc;
+    e->seconds += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    return NH_OK;
+}
+
+}  // namespace nh
+
+// ------------------------------------------------------------------------------------------------
+using nh::Engine;
+using nh::set_error;
+
+extern "C" {
+
+const char *nh_last_error(void) { return nh::g_last_error.c_str(); }
+int nh_abi_version(void) { return NH_ABI_VERSION; }
+
+int nh_device_count(int *count) {
+    if (!count) return set_error(NH_EINVAL, "null argument");
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess) {
+        *count = 0;
+        return set_error(NH_EDEVICE, "hipGetDeviceCount: %s", hipGetErrorString(e));
+    }
+    *count = n;
+    return NH_OK;
+}
+
+int nh_probe(char *msg, size_t msg_len) {
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    int rc = NH_OK;
+    char buf[256];
+    if (e != hipSuccess || n <= 0) {
+        snprintf(buf, sizeof buf, "no HIP device available (%s)",
+                 e == hipSuccess ? "count 0" : hipGetErrorString(e));
+        rc = NH_EDEVICE;
+    } else {
+        hipDeviceProp_t prop;
+        e = hipGetDeviceProperties(&prop, 0);
+        if (e != hipSuccess) {
+            snprintf(buf, sizeof buf, "hipGetDeviceProperties: %s", hipGetErrorString(e));
+            rc = NH_EDEVICE;
+        } else if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
+            snprintf(buf, sizeof buf, "device 0 is %s, need gfx950", prop.gcnArchName);
+            rc = NH_EDEVICE;
+        } else {
+            snprintf(buf, sizeof buf, "%d x %s (%s), %d CUs, %.0f GiB", n, prop.name,
+                     prop.gcnArchName, prop.multiProcessorCount,
+                     (double)prop.totalGlobalMem / (1024.0 * 1024.0 * 1024.0));
+        }
+    }
+    if (msg && msg_len) snprintf(msg, msg_len, "%s", buf);
+    if (rc) set_error(rc, "%s", buf);
+    return rc;
+}
+
+int nh_open(const char *db_dir, int device, nh_engine **out) {
+    return nh::open_dir(db_dir, device, (Engine **)out);
+}
+int nh_open_images(const void *opts, size_t opts_len, const void *taxo, size_t taxo_len,
+                   const void *hash, size_t hash_len, int device, nh_engine **out) {
+    return nh::open_images(opts, opts_len, taxo, taxo_len, hash, hash_len, device, (Engine **)out);
+}
+int nh_open_synthetic(uint64_t capacity, uint64_t n_keys, uint32_t depth, uint64_t seed, int device,
+                      nh_engine **out) {
+    return nh::open_synthetic(capacity, n_keys, depth, seed, device, (Engine **)out);
+}
+int nh_close(nh_engine *e) {
+    nh::destroy((Engine *)e);
+    return NH_OK;
+}
+
+int nh_db_info_get(const nh_engine *e, nh_db_info *info) {
+    if (!e || !info) return set_error(NH_EINVAL, "null argument");
+    *info = ((const Engine *)e)->info;
+    return NH_OK;
+}
+int nh_options_get(const nh_engine *e, nh_options *o) {
+    if (!e || !o) return set_error(NH_EINVAL, "null argument");
+    *o = ((const Engine *)e)->options;
+    return NH_OK;
+}
+int nh_options_set(nh_engine *e, const nh_options *o) {
+    if (!e || !o) return set_error(NH_EINVAL, "null argument");
+    ((Engine *)e)->options = *o;
+    return NH_OK;
+}
+int nh_taxon_external(const nh_engine *e_, uint32_t internal, uint64_t *external) {
+    const Engine *e = (const Engine *)e_;
+    if (!e || !external) return set_error(NH_EINVAL, "null argument");
+    if (internal >= e->external.size()) return set_error(NH_EINVAL, "taxon id out of range");
+    *external = e->external[internal];
+    return NH_OK;
+}
+int nh_table_download(const nh_engine *e_, uint32_t *cells, uint64_t n_cells) {
+    const Engine *e = (const Engine *)e_;
+    if (!e || !cells) return set_error(NH_EINVAL, "null argument");
+    if (n_cells != e->info.capacity) return set_error(NH_EINVAL, "n_cells != capacity");
+    HIP_TRY(hipSetDevice(e->device));
+    HIP_TRY(hipMemcpy(cells, e->d_table, n_cells * 4, hipMemcpyDeviceToHost));
+    return NH_OK;
+}
+static int copy_image(const std::vector<uint8_t> &img, void *buf, size_t cap, size_t *len) {
+    if (!len) return set_error(NH_EINVAL, "null argument");
+    *len = img.size();
+    if (buf) {
+        if (cap < img.size()) return set_error(NH_EINVAL, "buffer too small");
+        memcpy(buf, img.data(), img.size());
+    }
+    return NH_OK;
+}
+int nh_taxonomy_image(const nh_engine *e, void *buf, size_t cap, size_t *len) {
+    if (!e) return set_error(NH_EINVAL, "null argument");
+    return copy_image(((const Engine *)e)->taxo_image, buf, cap, len);
+}
+int nh_opts_image(const nh_engine *e, void *buf, size_t cap, size_t *len) {
+    if (!e) return set_error(NH_EINVAL, "null argument");
+    return copy_image(((const Engine *)e)->opts_image, buf, cap, len);
+}
+
+int nh_classify_batch(nh_engine *e, const uint8_t *bases, const uint64_t *seq_offsets,
+                      uint64_t n_frag, uint32_t flags, double confidence, nh_result *results,
+                      uint32_t *kmer_taxa, uint64_t *kmer_taxa_offsets, uint64_t kmer_taxa_cap) {
+    if (!e) return set_error(NH_EINVAL, "null engine");
+    return nh::classify_host((Engine *)e, bases, seq_offsets, n_frag, flags, confidence, results,
+                             kmer_taxa, kmer_taxa_offsets, kmer_taxa_cap);
+}
+
+uint64_t nh_kmer_taxa_entries(const nh_engine *e, const uint64_t *seq_offsets, uint64_t n_frag,
+                              uint32_t flags) {
+    if (!e || !seq_offsets) return 0;
+    return nh::kmer_taxa_entries((const Engine *)e, seq_offsets, n_frag,
+                                 (flags & NH_FLAG_PAIRED) ? 2 : 1, nullptr);
+}
+
+int nh_classify_batch_device(nh_engine *e_, const void *d_bases, const void *d_seq_offsets,
+                             uint64_t n_frag, uint32_t flags, double confidence, void *d_results,
+                             void *d_kmer_taxa, const void *d_kmer_taxa_offsets, void *d_counters,
+                             void *stream) {
+    Engine *e = (Engine *)e_;
+    if (!e || !d_bases || !d_seq_offsets || !d_results) return set_error(NH_EINVAL, "null argument");
+    return nh::classify_device(e, d_bases, d_seq_offsets, n_frag, flags, confidence, d_results,
+                               d_kmer_taxa, d_kmer_taxa_offsets, d_counters, (hipStream_t)stream);
+}
+
+int nh_stats_get(nh_engine *e_, nh_stats *s) {
+    Engine *e = (Engine *)e_;
+    if (!e || !s) return set_error(NH_EINVAL, "null argument");
+    std::lock_guard<std::mutex> lock(e->mu);
+    HIP_TRY(hipSetDevice(e->device));
+    uint64_t c[nh::CNT_N];
+    HIP_TRY(hipMemcpy(c, e->d_counters, sizeof c, hipMemcpyDeviceToHost));
+    s->total_sequences = c[nh::CNT_FRAGMENTS];
+    s->classified = c[nh::CNT_CLASSIFIED];
+    s->unclassified = c[nh::CNT_FRAGMENTS] - c[nh::CNT_CLASSIFIED];
+    s->total_bases = c[nh::CNT_BASES];
+    s->table_lookups = c[nh::CNT_LOOKUPS];
+    s->seconds = e->seconds;
+    return NH_OK;
+}
+int nh_stats_reset(nh_engine *e_) {
+    Engine *e = (Engine *)e_;
+    if (!e) return set_error(NH_EINVAL, "null argument");
+    std::lock_guard<std::mutex> lock(e->mu);
+    HIP_TRY(hipSetDevice(e->device));
+    HIP_TRY(hipMemset(e->d_counters, 0, nh::CNT_N * sizeof(uint64_t)));
+    e->seconds = 0;
+    return NH_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,71 @@
+// nh_internal.h -- host-side engine state shared by nh_engine.hip and nh_run.hip.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "nh_device.h"
+#include "nohuman_engine.h"
+
+namespace nh {
+
+struct Staging {  // grow-only device buffers behind nh_classify_batch (host-buffer entry)
+    void *d_bases = nullptr, *d_offsets = nullptr, *d_results = nullptr, *d_taxa = nullptr,
+         *d_taxa_off = nullptr;
+    size_t cap_bases = 0, cap_offsets = 0, cap_results = 0, cap_taxa = 0, cap_taxa_off = 0;
+};
+
+struct Engine {
+    int device = -1;
+    int n_cu = 0;
+    int grid_blocks = 0;
+    nh_db_info info{};
+    nh_options options{};
+    DevDB dev{};
+    uint32_t *d_table = nullptr;
+    uint64_t table_cells_alloc = 0;
+    uint32_t *d_parent = nullptr;
+    uint64_t *d_counters = nullptr;
+    int *d_error = nullptr;
+    hipStream_t stream = nullptr;
+    std::vector<uint32_t> parent;
+    std::vector<uint64_t> external;
+    std::vector<uint8_t> taxo_image, opts_image;
+    Staging st;
+    std::mutex mu;
+    double seconds = 0;
+};
+
+extern thread_local std::string g_last_error;
+int set_error(int code, const char *fmt, ...) __attribute__((format(printf, 2, 3)));
+
+hipError_t launch_classify(const DevDB &db, const void *d_bases, const void *d_seq_off,
+                           uint64_t n_frag, int mates, double confidence, void *d_out,
+                           void *d_kmer_taxa, const void *d_kmer_taxa_off, void *d_counters,
+                           int *d_error, int grid_blocks, hipStream_t stream);
+int classify_blocks_per_cu();
+hipError_t launch_synth_insert(uint32_t *table, uint64_t capacity, uint64_t cap_magic,
+                               uint32_t value_bits, uint32_t value, uint64_t n_keys, uint64_t seed,
+                               uint64_t key_mask, unsigned long long *d_size, hipStream_t stream);
+
+int open_dir(const char *db_dir, int device, Engine **out);
+int open_images(const void *opts, size_t opts_len, const void *taxo, size_t taxo_len,
+                const void *hash, size_t hash_len, int device, Engine **out);
+int open_synthetic(uint64_t capacity, uint64_t n_keys, uint32_t depth, uint64_t seed, int device,
+                   Engine **out);
+void destroy(Engine *e);
+int resolve_db_dir(const char *db_dir, std::string &resolved);
+int classify_device(Engine *e, const void *d_bases, const void *d_seq_off, uint64_t n_frag,
+                    uint32_t flags, double confidence, void *d_results, void *d_kmer_taxa,
+                    const void *d_kmer_taxa_off, void *d_counters, hipStream_t stream);
+int classify_host(Engine *e, const uint8_t *bases, const uint64_t *seq_offsets, uint64_t n_frag,
+                  uint32_t flags, double confidence, nh_result *results, uint32_t *kmer_taxa,
+                  uint64_t *kmer_taxa_offsets, uint64_t kmer_taxa_cap);
+int check_error_flag(Engine *e);
+uint64_t kmer_taxa_entries(const Engine *e, const uint64_t *seq_offsets, uint64_t n_frag, int mates,
+                           uint64_t *offsets_out);
+
+}  // namespace nh

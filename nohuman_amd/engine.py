@@ -1,0 +1,206 @@
+"""Engine: Python view of the C ABI (include/nohuman_engine.h).  numpy in, numpy out."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+from . import _lib
+
+RESULT_DTYPE = np.dtype([("call", "<u4"), ("total_kmers", "<u4"), ("clade_hits", "<u4"),
+                         ("hit_groups", "<u4")])
+TAXON_AMBIGUOUS = 0xFFFFFFFF
+TAXON_MATE_BORDER = 0xFFFFFFFE
+FLAG_PAIRED = 1
+
+
+class EngineError(RuntimeError):
+    def __init__(self, code: int, message: str):
+        super().__init__("nohuman engine error %d: %s" % (code, message))
+        self.code = code
+        self.message = message
+
+
+def _check(rc: int):
+    if rc != 0:
+        raise EngineError(rc, _lib.lib().nh_last_error().decode(errors="replace"))
+
+
+def probe() -> str:
+    """`nohuman --check` counterpart (/root/reference/src/lib.rs:50-57): raises if unusable."""
+    buf = C.create_string_buffer(256)
+    rc = _lib.lib().nh_probe(buf, 256)
+    if rc != 0:
+        raise EngineError(rc, buf.value.decode(errors="replace"))
+    return buf.value.decode()
+
+
+def device_count() -> int:
+    n = C.c_int(0)
+    _check(_lib.lib().nh_device_count(C.byref(n)))
+    return n.value
+
+
+class Engine:
+    """A kraken2 database resident in one GPU's HBM plus the classify entry points."""
+
+    def __init__(self, handle):
+        self._L = _lib.lib()
+        self._h = handle
+
+    # -- constructors -------------------------------------------------------------------------
+    @classmethod
+    def open(cls, db_dir, device: int = 0) -> "Engine":
+        L = _lib.lib()
+        h = C.c_void_p()
+        _check(L.nh_open(os.fsencode(db_dir), device, C.byref(h)))
+        return cls(h)
+
+    @classmethod
+    def from_images(cls, opts: bytes, taxo: bytes, hashb, device: int = 0) -> "Engine":
+        L = _lib.lib()
+        h = C.c_void_p()
+        hb = np.frombuffer(hashb, dtype=np.uint8) if isinstance(hashb, (bytes, bytearray)) \
+            else np.ascontiguousarray(hashb).view(np.uint8)
+        _check(L.nh_open_images(opts, len(opts), taxo, len(taxo), hb.ctypes.data, hb.nbytes, device,
+                                C.byref(h)))
+        return cls(h)
+
+    @classmethod
+    def synthetic(cls, capacity: int, n_keys: int, depth: int = 30, seed: int = 1,
+                  device: int = 0) -> "Engine":
+        L = _lib.lib()
+        h = C.c_void_p()
+        _check(L.nh_open_synthetic(capacity, n_keys, depth, seed, device, C.byref(h)))
+        return cls(h)
+
+    def close(self):
+        if self._h is not None:
+            self._L.nh_close(self._h)
+            self._h = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    @property
+    def handle(self):
+        return self._h
+
+    # -- database ------------------------------------------------------------------------------
+    @property
+    def info(self) -> _lib.nh_db_info:
+        i = _lib.nh_db_info()
+        _check(self._L.nh_db_info_get(self._h, C.byref(i)))
+        return i
+
+    def options(self) -> _lib.nh_options:
+        o = _lib.nh_options()
+        _check(self._L.nh_options_get(self._h, C.byref(o)))
+        return o
+
+    def set_options(self, *, minimum_hit_groups=None, linear_probing=None, reset_per_mate=None):
+        o = self.options()
+        if minimum_hit_groups is not None:
+            o.minimum_hit_groups = int(minimum_hit_groups)
+        if linear_probing is not None:
+            o.linear_probing = int(linear_probing)
+        if reset_per_mate is not None:
+            o.reset_per_mate = int(reset_per_mate)
+        _check(self._L.nh_options_set(self._h, C.byref(o)))
+
+    def external_id(self, internal: int) -> int:
+        v = C.c_uint64(0)
+        _check(self._L.nh_taxon_external(self._h, internal, C.byref(v)))
+        return v.value
+
+    def download_table(self) -> np.ndarray:
+        cells = np.empty(self.info.capacity, dtype=np.uint32)
+        _check(self._L.nh_table_download(self._h, cells.ctypes.data, cells.size))
+        return cells
+
+    def taxonomy_image(self) -> bytes:
+        n = C.c_size_t(0)
+        _check(self._L.nh_taxonomy_image(self._h, None, 0, C.byref(n)))
+        buf = C.create_string_buffer(n.value)
+        _check(self._L.nh_taxonomy_image(self._h, buf, n.value, C.byref(n)))
+        return buf.raw
+
+    def opts_image(self) -> bytes:
+        n = C.c_size_t(0)
+        _check(self._L.nh_opts_image(self._h, None, 0, C.byref(n)))
+        buf = C.create_string_buffer(n.value)
+        _check(self._L.nh_opts_image(self._h, buf, n.value, C.byref(n)))
+        return buf.raw
+
+    # -- classify ------------------------------------------------------------------------------
+    def classify(self, bases: np.ndarray, seq_offsets: np.ndarray, paired: bool = False,
+                 confidence: float = 0.0, want_taxa: bool = False):
+        """Host buffers in, result records (RESULT_DTYPE) out; optional per-k-mer taxa list."""
+        bases = np.ascontiguousarray(bases, dtype=np.uint8)
+        seq_offsets = np.ascontiguousarray(seq_offsets, dtype=np.uint64)
+        mates = 2 if paired else 1
+        n_seq = seq_offsets.size - 1
+        if n_seq % mates:
+            raise ValueError("paired input needs an even number of sequences")
+        n_frag = n_seq // mates
+        flags = FLAG_PAIRED if paired else 0
+        out = np.zeros(n_frag, dtype=RESULT_DTYPE)
+        bptr = bases.ctypes.data if bases.size else None
+        if not want_taxa:
+            _check(self._L.nh_classify_batch(self._h, bptr, seq_offsets.ctypes.data, n_frag, flags,
+                                             float(confidence), out.ctypes.data, None, None, 0))
+            return out
+        cap = int(self._L.nh_kmer_taxa_entries(self._h, seq_offsets.ctypes.data, n_frag, flags))
+        taxa = np.zeros(cap + 1, dtype=np.uint32)
+        toff = np.zeros(n_frag + 1, dtype=np.uint64)
+        _check(self._L.nh_classify_batch(self._h, bptr, seq_offsets.ctypes.data, n_frag, flags,
+                                         float(confidence), out.ctypes.data, taxa.ctypes.data,
+                                         toff.ctypes.data, cap + 1))
+        return out, taxa[:cap], toff
+
+    def classify_device(self, d_bases: int, d_seq_offsets: int, n_frag: int, paired: bool,
+                        confidence: float, d_results: int, d_counters: int = 0, stream: int = 0,
+                        d_kmer_taxa: int = 0, d_kmer_taxa_offsets: int = 0):
+        """Device pointers in (ints), asynchronous on `stream` (a hipStream_t as int)."""
+        _check(self._L.nh_classify_batch_device(
+            self._h, d_bases, d_seq_offsets, n_frag, FLAG_PAIRED if paired else 0,
+            float(confidence), d_results, d_kmer_taxa or None, d_kmer_taxa_offsets or None,
+            d_counters or None, stream or None))
+
+    def stats(self) -> _lib.nh_stats:
+        s = _lib.nh_stats()
+        _check(self._L.nh_stats_get(self._h, C.byref(s)))
+        return s
+
+    def reset_stats(self):
+        _check(self._L.nh_stats_reset(self._h))
+
+    # -- whole run -----------------------------------------------------------------------------
+    def run(self, in1, out1, in2=None, out2=None, kraken_output=None, report=None,
+            confidence: float = 0.0, threads: int = 1, keep_human: bool = False) -> _lib.nh_stats:
+        a = _lib.nh_run_args()
+        a.db_dir = None
+        a.in1 = os.fsencode(in1)
+        a.in2 = os.fsencode(in2) if in2 else None
+        a.out1 = os.fsencode(out1)
+        a.out2 = os.fsencode(out2) if out2 else None
+        a.kraken_output = os.fsencode(kraken_output) if kraken_output else None
+        a.report = os.fsencode(report) if report else None
+        a.confidence = float(confidence)
+        a.threads = int(threads)
+        a.keep_human = int(bool(keep_human))
+        a.n_devices = 1
+        a.device_ids = None
+        s = _lib.nh_stats()
+        _check(self._L.nh_run_engine(self._h, C.byref(a), C.byref(s)))
+        return s

@@ -1,0 +1,121 @@
+"""GPU parity tests proper: the HIP path (through the C ABI) against the CPU oracle, bit-exact."""
+import numpy as np
+import pytest
+
+from oracle import oracle as orc
+from tests import synth
+
+pytestmark = pytest.mark.gpu
+
+
+def _assert_same(got, exp, what=""):
+    for f in ("call", "total_kmers", "clade_hits", "hit_groups"):
+        bad = np.nonzero(got[f] != exp[f])[0]
+        assert bad.size == 0, "%s: field %s differs at %s (got %s, oracle %s)" % (
+            what, f, bad[:5], got[f][bad[:5]], exp[f][bad[:5]])
+
+
+def test_probe_reports_gfx950():
+    import nohuman_amd
+    msg = nohuman_amd.probe()
+    assert "gfx950" in msg
+
+
+@pytest.mark.parametrize("paired", [False, True])
+@pytest.mark.parametrize("confidence", [0.0, 0.1, 0.5, 1.0])
+def test_toy_db_parity(toy, toy_oracle, toy_engine, paired, confidence):
+    _, _, _, genomes, _ = toy
+    rng = np.random.default_rng(11 + int(paired))
+    reads = synth.sample_reads(rng, genomes, 2000, paired=paired, len_jitter=120)
+    bases, offs = orc.pack_reads(reads, paired)
+    exp, lookups, etaxa, etoff = toy_oracle.classify(bases, offs, paired, confidence, want_taxa=True)
+    toy_engine.reset_stats()
+    got, taxa, toff = toy_engine.classify(bases, offs, paired, confidence, want_taxa=True)
+    _assert_same(got, exp, "toy paired=%s conf=%s" % (paired, confidence))
+    assert np.array_equal(toff, etoff)
+    assert np.array_equal(taxa, etaxa)
+    st = toy_engine.stats()
+    assert st.total_sequences == len(reads)
+    assert st.classified == int((exp["call"] != 0).sum())
+    assert st.table_lookups == int(lookups.sum())
+    assert st.total_bases == bases.size
+    assert (exp["call"] != 0).sum() > 100  # the hit / LCA paths are really exercised
+
+
+def test_edge_cases(toy, toy_oracle, toy_engine):
+    """empty reads, reads shorter than l / k, all-N, N at every offset, lower case, long reads."""
+    _, _, _, genomes, _ = toy
+    g = genomes[111]
+    reads = [b"", b"A", g[:30], g[:31], g[:34], g[:35], g[:36], b"N" * 150, g[:150].lower(),
+             g[100:100 + 124 + 34], g[100:100 + 125 + 34], g[100:100 + 126 + 34],
+             g[:1200], g[37:1800] + g[5:900]]
+    for i in range(0, 150, 7):
+        r = bytearray(g[200:350])
+        r[i] = ord("N")
+        reads.append(bytes(r))
+    for i in (0, 1, 33, 34, 35, 36, 120, 148, 149):
+        r = bytearray(g[300:450])
+        r[i] = ord("n")
+        r[(i * 3) % 150] = ord("R")
+        reads.append(bytes(r))
+    bases, offs = orc.pack_reads(reads, False)
+    for conf in (0.0, 0.3):
+        exp, _, etaxa, etoff = toy_oracle.classify(bases, offs, False, conf, want_taxa=True)
+        got, taxa, toff = toy_engine.classify(bases, offs, False, conf, want_taxa=True)
+        _assert_same(got, exp, "edge")
+        assert np.array_equal(taxa, etaxa)
+    # the same reads as mates of pairs (mixed lengths inside a pair)
+    pairs = [(reads[i], reads[-1 - i]) for i in range(len(reads) // 2)]
+    bases, offs = orc.pack_reads(pairs, True)
+    exp, _, etaxa, etoff = toy_oracle.classify(bases, offs, True, 0.05, want_taxa=True)
+    got, taxa, toff = toy_engine.classify(bases, offs, True, 0.05, want_taxa=True)
+    _assert_same(got, exp, "edge pairs")
+    assert np.array_equal(taxa, etaxa)
+
+
+def test_empty_batch(toy_engine):
+    out = toy_engine.classify(np.zeros(0, np.uint8), np.zeros(1, np.uint64))
+    assert out.size == 0
+
+
+def test_long_reads_parity(toy, toy_oracle, toy_engine):
+    """variable-length long reads (config 4 shape, scaled down): many tiles per read."""
+    _, _, _, genomes, _ = toy
+    rng = np.random.default_rng(5)
+    allg = b"".join(genomes[k] for k in sorted(genomes))
+    reads = []
+    for _ in range(300):
+        ln = int(np.clip(rng.lognormal(7.5, 0.8), 200, 12000))
+        parts = []
+        while sum(map(len, parts)) < ln:
+            st = int(rng.integers(0, len(allg) - 300))
+            parts.append(allg[st:st + int(rng.integers(100, 700))])
+        reads.append(synth.mutate(rng, b"".join(parts)[:ln], 0.05, 0.001, 0.0))
+    bases, offs = orc.pack_reads(reads, False)
+    exp, _, etaxa, _ = toy_oracle.classify(bases, offs, False, 0.0, want_taxa=True)
+    got, taxa, _ = toy_engine.classify(bases, offs, False, 0.0, want_taxa=True)
+    _assert_same(got, exp, "long")
+    assert np.array_equal(taxa, etaxa)
+
+
+@pytest.mark.parametrize("variant", ["k31l31", "k40l25_nospace", "revcom0", "minhash", "double_hash"])
+def test_db_variants(variant):
+    """other k/l, no spaced seed, legacy revcom_version 0, min-hash subsampling, double hashing."""
+    from nohuman_amd import Engine
+    kw = {"k31l31": dict(k=31, l=31), "k40l25_nospace": dict(k=40, l=25, spaced_mask=0),
+          "revcom0": dict(revcom_version=0), "minhash": dict(min_hash=1 << 62),
+          "double_hash": dict(linear_probing=False)}[variant]
+    ob, tb, hb, genomes, _ = synth.toy_db(seed=3, **kw)
+    odb = orc.OracleDB(ob, tb, hb)
+    rng = np.random.default_rng(8)
+    reads = synth.sample_reads(rng, genomes, 600, paired=False, len_jitter=60)
+    bases, offs = orc.pack_reads(reads, False)
+    with Engine.from_images(ob, tb, hb) as eng:
+        if variant == "double_hash":
+            odb.set(linear_probing=False)
+            eng.set_options(linear_probing=False)
+        exp, _, etaxa, _ = odb.classify(bases, offs, False, 0.1, want_taxa=True)
+        got, taxa, _ = eng.classify(bases, offs, False, 0.1, want_taxa=True)
+    _assert_same(got, exp, variant)
+    assert np.array_equal(taxa, etaxa)
+    assert (exp["call"] != 0).sum() > 50

@@ -1,0 +1,178 @@
+"""CPU tests of the oracle: the C state-machine restatement (oracle/k2_oracle.c) against the
+committed golden vectors (made by the closed-form Python restatement) and against that
+restatement on fresh random inputs.  No GPU."""
+import json
+import os
+
+import numpy as np
+import pytest
+from hypothesis import given, settings, strategies as st
+
+from oracle import k2_literal as lit
+from oracle import minidb
+from oracle import oracle as orc
+from tests import synth
+from tests.fastq_util import read_fastq
+
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+
+
+@pytest.fixture(scope="module")
+def gold_db():
+    return orc.OracleDB(directory=os.path.join(GOLD, "toy_db"))
+
+
+def test_kat_primitives():
+    kat = json.load(open(os.path.join(GOLD, "kat.json")))
+    L = orc.lib()
+    for x, y in kat["fmix64"]:
+        assert L.k2o_fmix64(int(x)) == int(y)
+    for x, n, rv, y in kat["revcomp"]:
+        assert L.k2o_reverse_complement(int(x), n, rv) == int(y)
+    # independent anchors: fmix64 is a bijection fixing 0; the spaced mask of SURVEY.md A.1
+    assert L.k2o_fmix64(0) == 0
+    assert int(kat["default_spaced_mask"]) == 0x3FFFFFFFF3333333
+    # revcomp of a palindrome (ACGT) is itself; of AAAA is TTTT
+    acgt = 0b00011011
+    assert L.k2o_reverse_complement(acgt, 4, 1) == acgt
+    assert L.k2o_reverse_complement(0, 4, 1) == 0xFF
+
+
+def _check_against_golden(gold_db, fastqs, expected_json, paired):
+    exp = json.load(open(os.path.join(GOLD, expected_json)))
+    recs = [read_fastq(os.path.join(GOLD, f)) for f in fastqs]
+    n = len(recs[0])
+    assert n == len(exp["records"])
+    frags = [tuple(r[i][2] for r in recs) if paired else recs[0][i][2] for i in range(n)]
+    bases, offs = orc.pack_reads(frags, paired)
+    ext = gold_db.external_ids
+    assert list(ext) == exp["meta"]["external_ids"]
+    for conf in exp["meta"]["confidences"]:
+        out, lookups, taxa, toff = gold_db.classify(bases, offs, paired, conf, want_taxa=True)
+        for i, rec in enumerate(exp["records"]):
+            want = rec["by_conf"][str(conf)]
+            got = [int(out[i][f]) for f in ("call", "total_kmers", "clade_hits", "hit_groups")]
+            assert got == want, (i, conf, got, want)
+            assert int(lookups[i]) == rec["lookups"]
+            hl = _hitlist(ext, taxa[int(toff[i]):int(toff[i + 1])])
+            assert hl == rec["hitlist"], (i, hl, rec["hitlist"])
+    return exp
+
+
+def _hitlist(ext, taxa):
+    if len(taxa) == 0:
+        return "0:0"
+    parts, i = [], 0
+    while i < len(taxa):
+        j = i
+        while j < len(taxa) and taxa[j] == taxa[i]:
+            j += 1
+        t = int(taxa[i])
+        if t == orc.BORDER:
+            parts += ["|:|"] * (j - i)
+        elif t == orc.AMBIG:
+            parts.append("A:%d" % (j - i))
+        else:
+            parts.append("%d:%d" % (int(ext[t]), j - i))
+        i = j
+    return " ".join(parts)
+
+
+def test_golden_single_end(gold_db):
+    exp = _check_against_golden(gold_db, ["reads_se.fq"], "expected_se.json", False)
+    calls = {r["by_conf"]["0.0"][0] for r in exp["records"]}
+    assert len(calls) >= 6  # LCA calls at several depths are present in the fixture
+
+
+def test_golden_paired_end(gold_db):
+    _check_against_golden(gold_db, ["reads_pe_1.fq", "reads_pe_2.fq"], "expected_pe.json", True)
+
+
+def test_multithreaded_equals_serial(toy, toy_oracle):
+    _, _, _, genomes, _ = toy
+    rng = np.random.default_rng(3)
+    reads = synth.sample_reads(rng, genomes, 5000, paired=True, len_jitter=50)
+    bases, offs = orc.pack_reads(reads, True)
+    a, la = toy_oracle.classify(bases, offs, True, 0.2)
+    b, lb = toy_oracle.classify(bases, offs, True, 0.2, threads=4)
+    assert np.array_equal(a, b) and np.array_equal(la, lb)
+
+
+_alphabet = st.sampled_from(list(b"ACGTacgtNnRX-"))
+
+
+@settings(max_examples=150, deadline=None)
+@given(st.lists(_alphabet, min_size=0, max_size=260).map(bytes))
+def test_scanner_state_machine_equals_closed_form(toy, toy_oracle, seq):
+    """mmscanner state machine (C) == closed form of SURVEY.md A.3 (Python), incl. ambiguity."""
+    ob, tb, hb, _, _ = toy
+    ldb = _literal(ob, tb, hb)
+    mins, amb = toy_oracle.scan(seq)
+    want = lit.kmer_minimizers(ldb, seq)
+    assert len(want) == len(mins)
+    for (wa, wm), m, a in zip(want, mins, amb):
+        assert bool(a) == wa
+        if not wa:
+            assert int(m) == wm
+
+
+_LIT = {}
+
+
+def _literal(ob, tb, hb):
+    key = id(hb)
+    if key not in _LIT:
+        _LIT[key] = lit.DB.from_images(ob, tb, hb)
+    return _LIT[key]
+
+
+@pytest.mark.parametrize("kw", [dict(k=31, l=31), dict(k=40, l=25, spaced_mask=0),
+                                dict(revcom_version=0), dict(min_hash=1 << 62), dict(k=35, l=31)])
+def test_variants_c_equals_literal(kw):
+    ob, tb, hb, genomes, _ = synth.toy_db(seed=5, **kw)
+    odb = orc.OracleDB(ob, tb, hb)
+    ldb = lit.DB.from_images(ob, tb, hb)
+    rng = np.random.default_rng(2)
+    reads = synth.sample_reads(rng, genomes, 120, paired=False, len_jitter=80)
+    bases, offs = orc.pack_reads(reads, False)
+    out, lookups, taxa, toff = odb.classify(bases, offs, False, 0.15, want_taxa=True)
+    for i, r in enumerate(reads):
+        call, tk, ch, hg, tl, nl = lit.classify_fragment(ldb, (r,), 0.15)
+        assert (int(out[i]["call"]), int(out[i]["total_kmers"]), int(out[i]["clade_hits"]),
+                int(out[i]["hit_groups"])) == (call, tk, ch, hg)
+        assert list(taxa[int(toff[i]):int(toff[i + 1])]) == tl
+        assert nl == lookups[i]
+
+
+def test_double_hashing_switch():
+    ob, tb, hb, genomes, _ = synth.toy_db(seed=9, linear_probing=False)
+    odb = orc.OracleDB(ob, tb, hb)
+    odb.set(linear_probing=False)
+    ldb = lit.DB.from_images(ob, tb, hb)
+    ldb.linear_probing = False
+    rng = np.random.default_rng(4)
+    reads = synth.sample_reads(rng, genomes, 100, frac_random=0.1)
+    bases, offs = orc.pack_reads(reads, False)
+    out, _ = odb.classify(bases, offs, False, 0.0)
+    for i, r in enumerate(reads):
+        assert int(out[i]["call"]) == lit.classify_fragment(ldb, (r,), 0.0)[0]
+    assert (out["call"] != 0).sum() > 50
+
+
+def test_db_directory_shapes(tmp_path, toy):
+    """validate_db_directory semantics: <dir> or <dir>/db (/root/reference/src/lib.rs:119-141)."""
+    ob, tb, hb, _, _ = toy
+    minidb.write_db(tmp_path / "a", ob, tb, hb)
+    minidb.write_db(tmp_path / "b" / "db", ob, tb, hb)
+    assert orc.OracleDB(directory=str(tmp_path / "a")).k == 35
+    assert orc.OracleDB(directory=str(tmp_path / "b")).k == 35
+    with pytest.raises(RuntimeError):
+        orc.OracleDB(directory=str(tmp_path / "missing"))
+
+
+def test_malformed_images_rejected(toy):
+    ob, tb, hb, _, _ = toy
+    with pytest.raises(RuntimeError):
+        orc.OracleDB(ob, tb, hb[:-4])
+    with pytest.raises(RuntimeError):
+        orc.OracleDB(ob, b"XXXXXXXX" + tb[8:], hb)
