@@ -6,7 +6,7 @@ import importlib.util
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libnohuman_engine.so")
+LIB_PATH = os.environ.get("NOHUMAN_ENGINE_LIB", os.path.join(_HERE, "libnohuman_engine.so"))
 _LIB = None
 
 

@@ -130,11 +130,13 @@ static void finish_devdb(Engine *e) {
     d.linear_probing = e->options.linear_probing;
     d.reset_per_mate = e->options.reset_per_mate;
     d.min_hit_groups = e->options.minimum_hit_groups;
+    const uint64_t mc = i.capacity / 4 + 2;
+    d.max_chunks = mc > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)mc;
 }
 
 static int alloc_table(Engine *e, uint64_t capacity) {
     // padded so that 16-byte chunk loads at the end of the table stay in bounds
-    e->table_cells_alloc = ((capacity + 3) & ~3ull) + 4;
+    e->table_cells_alloc = ((capacity + 3) & ~3ull) + 32;
     HIP_TRY(hipMalloc((void **)&e->d_table, e->table_cells_alloc * sizeof(uint32_t)));
     return NH_OK;
 }
@@ -153,8 +155,9 @@ static int common_open(Engine *e, int device) {
     e->options.linear_probing = 1;
     e->options.reset_per_mate = 1;
     HIP_TRY(hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking));
-    HIP_TRY(hipMalloc((void **)&e->d_counters, CNT_N * sizeof(uint64_t)));
-    HIP_TRY(hipMemset(e->d_counters, 0, CNT_N * sizeof(uint64_t)));
+    HIP_TRY(hipMalloc((void **)&e->d_counters, (CNT_N + 8) * sizeof(uint64_t)));
+    HIP_TRY(hipMemset(e->d_counters, 0, (CNT_N + 8) * sizeof(uint64_t)));
+    HIP_TRY(hipMalloc((void **)&e->d_work, sizeof(unsigned long long)));
     HIP_TRY(hipMalloc((void **)&e->d_error, sizeof(int)));
     HIP_TRY(hipMemset(e->d_error, 0, sizeof(int)));
     return NH_OK;
@@ -174,6 +177,7 @@ void destroy(Engine *e) {
     if (e->d_parent) (void)hipFree(e->d_parent);
     if (e->d_counters) (void)hipFree(e->d_counters);
     if (e->d_error) (void)hipFree(e->d_error);
+    if (e->d_work) (void)hipFree(e->d_work);
     for (void *p : {e->st.d_bases, e->st.d_offsets, e->st.d_results, e->st.d_taxa, e->st.d_taxa_off})
         if (p) (void)hipFree(p);
     if (e->stream) (void)hipStreamDestroy(e->stream);
@@ -404,7 +408,7 @@ int open_synthetic(uint64_t capacity, uint64_t n_keys, uint32_t depth, uint64_t 
         unsigned long long sz = 0;
         if (he == hipSuccess) he = hipStreamSynchronize(e->stream);
         if (he == hipSuccess) he = hipMemcpy(&sz, d_size, 8, hipMemcpyDeviceToHost);
-        if (he == hipSuccess) he = hipMemset(e->d_counters, 0, CNT_N * sizeof(uint64_t));
+        if (he == hipSuccess) he = hipMemset(e->d_counters, 0, (CNT_N + 8) * sizeof(uint64_t));
         if (he != hipSuccess) rc = set_error(NH_EDEVICE, "synthetic table: %s", hipGetErrorString(he));
         e->info.size = sz;
     }
@@ -456,8 +460,8 @@ int classify_device(Engine *e, const void *d_bases, const void *d_seq_off, uint6
     finish_devdb(e);
     hipError_t he = launch_classify(e->dev, d_bases, d_seq_off, n_frag,
                                     (flags & NH_FLAG_PAIRED) ? 2 : 1, confidence, d_results,
-                                    d_kmer_taxa, d_kmer_taxa_off, d_counters, e->d_error,
-                                    e->grid_blocks, stream);
+                                    d_kmer_taxa, d_kmer_taxa_off, d_counters, e->d_error, e->d_work,
+                                    e->frag_chunk, e->grid_blocks, stream);
     if (he != hipSuccess) return set_error(NH_EDEVICE, "classify launch: %s", hipGetErrorString(he));
     return NH_OK;
 }
@@ -467,6 +471,8 @@ int check_error_flag(Engine *e) {
     HIP_TRY(hipMemcpy(&flag, e->d_error, sizeof(int), hipMemcpyDeviceToHost));
     if (flag) {
         HIP_TRY(hipMemset(e->d_error, 0, sizeof(int)));
+        if (flag == 2)
+            return set_error(NH_EINVAL, "a sequence of 2^31 bases or more is not supported");
         return set_error(NH_ECAPACITY,
                          "a fragment hit more than %d distinct taxa (per-wave LDS list capacity)",
                          LIST_CAP);
@@ -691,7 +697,7 @@ int nh_stats_reset(nh_engine *e_) {
     if (!e) return set_error(NH_EINVAL, "null argument");
     std::lock_guard<std::mutex> lock(e->mu);
     HIP_TRY(hipSetDevice(e->device));
-    HIP_TRY(hipMemset(e->d_counters, 0, nh::CNT_N * sizeof(uint64_t)));
+    HIP_TRY(hipMemset(e->d_counters, 0, (nh::CNT_N + 8) * sizeof(uint64_t)));
     e->seconds = 0;
     return NH_OK;
 }

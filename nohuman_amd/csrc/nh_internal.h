@@ -30,6 +30,8 @@ struct Engine {
     uint32_t *d_parent = nullptr;
     uint64_t *d_counters = nullptr;
     int *d_error = nullptr;
+    unsigned long long *d_work = nullptr;  // dynamic fragment-chunk counter of k_classify
+    uint32_t frag_chunk = 16;              // fragments a wave pulls at a time
     hipStream_t stream = nullptr;
     std::vector<uint32_t> parent;
     std::vector<uint64_t> external;
@@ -45,7 +47,8 @@ int set_error(int code, const char *fmt, ...) __attribute__((format(printf, 2, 3
 hipError_t launch_classify(const DevDB &db, const void *d_bases, const void *d_seq_off,
                            uint64_t n_frag, int mates, double confidence, void *d_out,
                            void *d_kmer_taxa, const void *d_kmer_taxa_off, void *d_counters,
-                           int *d_error, int grid_blocks, hipStream_t stream);
+                           int *d_error, unsigned long long *d_work, uint32_t frag_chunk,
+                           int grid_blocks, hipStream_t stream);
 int classify_blocks_per_cu();
 hipError_t launch_synth_insert(uint32_t *table, uint64_t capacity, uint64_t cap_magic,
                                uint32_t value_bits, uint32_t value, uint64_t n_keys, uint64_t seed,

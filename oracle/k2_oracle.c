@@ -416,7 +416,7 @@ typedef struct {
     uint64_t *next;
 } mt_job;
 
-#define MT_BLOCK 4096
+#define MT_BLOCK 256
 
 static void *mt_worker(void *arg) {
     mt_job *j = (mt_job *)arg;

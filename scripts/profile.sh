@@ -1,0 +1,23 @@
+#!/bin/bash
+# Profiles bench.py on the GPU box: kernel-trace stats, then PMC passes (separate runs, as the
+# MI355X guide prescribes: no --pmc together with trace domains other than --kernel-trace).
+#   gpurun -- 'bash scripts/profile.sh r01'
+set -u
+TAG=${1:-r01}
+REPO=$(pwd)
+OUT=$REPO/gpurun_out/prof_$TAG
+mkdir -p "$OUT"
+export TMPDIR=/tmp
+BENCH="python3 $REPO/bench.py --steps 5 --warmup 2 --no-cpu-baseline"
+cd /tmp
+rocprofv3 --output-format csv --kernel-trace --stats -d "$OUT/trace" -o trace -- $BENCH > "$OUT/bench_trace.json" 2> "$OUT/trace.err"
+rocprofv3 --output-format csv --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_WAIT_ANY -d "$OUT/pmc1" -o pmc1 -- $BENCH > /dev/null 2> "$OUT/pmc1.err"
+rocprofv3 --output-format csv --pmc SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM SQ_INST_CYCLES_VMEM SQ_ACTIVE_INST_SCA SQ_WAIT_INST_LDS -d "$OUT/pmc2" -o pmc2 -- $BENCH > /dev/null 2> "$OUT/pmc2.err"
+rocprofv3 --output-format csv --pmc FETCH_SIZE -d "$OUT/pmc3" -o pmc3 -- $BENCH > /dev/null 2> "$OUT/pmc3.err"
+rocprofv3 --output-format csv --pmc TCC_HIT_sum TCC_MISS_sum TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum -d "$OUT/pmc4" -o pmc4 -- $BENCH > /dev/null 2> "$OUT/pmc4.err"
+rocprofv3 --output-format csv --pmc WRITE_SIZE -d "$OUT/pmc5" -o pmc5 -- $BENCH > /dev/null 2> "$OUT/pmc5.err"
+cd "$REPO"
+python3 scripts/summarize_prof.py "$OUT" > "$OUT/summary.txt" 2>&1
+cat "$OUT/summary.txt"
+find "$OUT" -name "*.db" -delete 2>/dev/null
+du -sh "$OUT"

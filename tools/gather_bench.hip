@@ -1,0 +1,164 @@
+// gather_bench.hip -- microbenchmark: how many random 16-byte probes per second can one MI355X
+// sustain into a multi-GB table?  This is the practical ceiling of the CompactHashTable::Get step
+// (one 64-B line per lookup in the roofline formula of BASELINE.md section 4).
+//
+//   hipcc --offload-arch=gfx950 -O3 tools/gather_bench.hip -o tools/gather_bench
+//   ./gather_bench [table_GiB=6] [loads_per_thread=64]
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+
+#define CK(x)                                                                  \
+    do {                                                                       \
+        hipError_t e = (x);                                                    \
+        if (e != hipSuccess) {                                                 \
+            fprintf(stderr, "%s: %s\n", #x, hipGetErrorString(e));             \
+            exit(1);                                                           \
+        }                                                                      \
+    } while (0)
+
+__device__ __forceinline__ uint64_t mix(uint64_t x) {
+    x ^= x >> 33;
+    x *= 0xff51afd7ed558ccdull;
+    x ^= x >> 33;
+    x *= 0xc4ceb9fe1a85ec53ull;
+    x ^= x >> 33;
+    return x;
+}
+
+// ILP independent loads in flight per lane; WIDTH = bytes per load (4 or 16)
+template <int ILP, int WIDTH>
+__global__ __launch_bounds__(256) void k_gather(const uint32_t *__restrict__ table, uint64_t n_chunks,
+                                                int iters, uint32_t *__restrict__ sink) {
+    uint64_t s = mix(((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) * 0x9E3779B97F4A7C15ull + 1);
+    uint32_t acc = 0;
+    for (int it = 0; it < iters; it += ILP) {
+        uint64_t idx[ILP];
+#pragma unroll
+        for (int j = 0; j < ILP; j++) {
+            s = mix(s + j + 1);
+            idx[j] = __umul64hi(s, n_chunks);  // uniform in [0, n_chunks)
+        }
+        if (WIDTH == 16) {
+            uint4 v[ILP];
+#pragma unroll
+            for (int j = 0; j < ILP; j++) v[j] = reinterpret_cast<const uint4 *>(table)[idx[j]];
+#pragma unroll
+            for (int j = 0; j < ILP; j++) acc += v[j].x ^ v[j].y ^ v[j].z ^ v[j].w;
+        } else {
+            uint32_t v[ILP];
+#pragma unroll
+            for (int j = 0; j < ILP; j++) v[j] = table[idx[j] * 4];
+#pragma unroll
+            for (int j = 0; j < ILP; j++) acc += v[j];
+        }
+    }
+    if (acc == 0x12345678u) sink[0] = acc;
+}
+
+static uint64_t n_chunks0(uint64_t bytes) { return bytes / 16; }
+
+template <int ILP, int WIDTH>
+static void run(const uint32_t *d_table, uint64_t n_chunks, int iters, uint32_t *d_sink, int blocks) {
+    hipEvent_t e0, e1;
+    CK(hipEventCreate(&e0));
+    CK(hipEventCreate(&e1));
+    hipLaunchKernelGGL((k_gather<ILP, WIDTH>), dim3(blocks), dim3(256), 0, 0, d_table, n_chunks, iters, d_sink);
+    CK(hipDeviceSynchronize());
+    CK(hipEventRecord(e0));
+    hipLaunchKernelGGL((k_gather<ILP, WIDTH>), dim3(blocks), dim3(256), 0, 0, d_table, n_chunks, iters, d_sink);
+    CK(hipEventRecord(e1));
+    CK(hipEventSynchronize(e1));
+    float ms = 0;
+    CK(hipEventElapsedTime(&ms, e0, e1));
+    double n = (double)blocks * 256 * iters;
+    printf("ILP=%d width=%2d blocks=%5d: %8.3f ms  %7.2f G probes/s  = %7.1f GB/s at 64 B/probe\n", ILP,
+           WIDTH, blocks, ms, n / ms / 1e6, n * 64 / ms / 1e6);
+}
+
+// dependent chain: one lane, each load's address comes from the previous value (idle latency)
+__global__ void k_chase(const uint32_t *__restrict__ table, uint64_t n_chunks, int iters, uint32_t *sink,
+                        long long *cycles) {
+    uint64_t s = 12345;
+    uint32_t acc = 0;
+    long long t0 = wall_clock64();
+    for (int i = 0; i < iters; i++) {
+        s = mix(s + acc);
+        uint64_t idx = __umul64hi(s, n_chunks);
+        acc += table[idx * 4];
+    }
+    long long t1 = wall_clock64();
+    sink[1] = acc;
+    cycles[0] = t1 - t0;
+}
+
+template <int TPB>
+__global__ __launch_bounds__(TPB) void k_gather1(const uint32_t *__restrict__ table, uint64_t n_chunks,
+                                                 int iters, uint32_t *__restrict__ sink) {
+    uint64_t s = mix(((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) * 0x9E3779B97F4A7C15ull + 1);
+    uint32_t acc = 0;
+    for (int it = 0; it < iters; it++) {
+        s = mix(s + 1);
+        const uint64_t idx = __umul64hi(s, n_chunks);
+        const uint4 v = reinterpret_cast<const uint4 *>(table)[idx];
+        acc += v.x ^ v.y ^ v.z ^ v.w;
+        s += acc & 1;  // serialise: the next address depends on this load
+    }
+    if (acc == 0x12345678u) sink[0] = acc;
+}
+
+static void curve(const uint32_t *d_table, uint64_t n_chunks, uint32_t *d_sink) {
+    printf("latency/throughput curve: every lane keeps exactly ONE dependent 16-B probe in flight\n");
+    const int iters = 256;
+    for (int waves : {256, 512, 1024, 2048, 4096, 8192, 16384, 32768}) {
+        hipEvent_t e0, e1;
+        CK(hipEventCreate(&e0));
+        CK(hipEventCreate(&e1));
+        hipLaunchKernelGGL((k_gather1<64>), dim3(waves), dim3(64), 0, 0, d_table, n_chunks, iters, d_sink);
+        CK(hipDeviceSynchronize());
+        CK(hipEventRecord(e0));
+        hipLaunchKernelGGL((k_gather1<64>), dim3(waves), dim3(64), 0, 0, d_table, n_chunks, iters, d_sink);
+        CK(hipEventRecord(e1));
+        CK(hipEventSynchronize(e1));
+        float ms = 0;
+        CK(hipEventElapsedTime(&ms, e0, e1));
+        double lanes = (double)waves * 64;
+        double rate = lanes * iters / ms / 1e6;  // G probes/s
+        // resident lanes are capped by the chip (256 CUs x 32 waves x 64)
+        double resident = lanes < 256.0 * 32 * 64 ? lanes : 256.0 * 32 * 64;
+        printf("  waves=%6d lanes=%8.0f: %7.2f G probes/s, latency per probe ~ %6.2f us\n", waves, lanes, rate,
+               resident / (rate * 1e3));
+    }
+}
+
+int main(int argc, char **argv) {
+    double gib = argc > 1 ? atof(argv[1]) : 6.0;
+    int iters = argc > 2 ? atoi(argv[2]) : 64;
+    uint64_t bytes = (uint64_t)(gib * (1ull << 30)) & ~15ull;
+    uint32_t *d_table, *d_sink;
+    CK(hipMalloc((void **)&d_table, bytes));
+    CK(hipMalloc((void **)&d_sink, 64));
+    CK(hipMemset(d_table, 1, bytes));
+    uint64_t n_chunks = bytes / 16;
+    printf("table %.2f GiB, %d loads per thread\n", gib, iters);
+    {
+        long long *d_cyc, cyc = 0;
+        CK(hipMalloc((void **)&d_cyc, 8));
+        hipLaunchKernelGGL(k_chase, dim3(1), dim3(1), 0, 0, d_table, n_chunks0(bytes), 2000, d_sink, d_cyc);
+        CK(hipDeviceSynchronize());
+        hipLaunchKernelGGL(k_chase, dim3(1), dim3(1), 0, 0, d_table, n_chunks0(bytes), 2000, d_sink, d_cyc);
+        CK(hipMemcpy(&cyc, d_cyc, 8, hipMemcpyDeviceToHost));
+        printf("idle dependent-chain latency: %.1f ticks of the 100 MHz wall clock per probe = %.2f us\n",
+               cyc / 2000.0, cyc / 2000.0 / 100.0);
+        curve(d_table, n_chunks0(bytes), d_sink);
+    }
+    for (int blocks : {256 * 4, 256 * 8, 256 * 16}) {
+        run<1, 16>(d_table, n_chunks, iters, d_sink, blocks);
+        run<2, 16>(d_table, n_chunks, iters, d_sink, blocks);
+        run<4, 16>(d_table, n_chunks, iters, d_sink, blocks);
+        run<8, 16>(d_table, n_chunks, iters, d_sink, blocks);
+        run<4, 4>(d_table, n_chunks, iters, d_sink, blocks);
+    }
+    return 0;
+}
