@@ -34,6 +34,25 @@ struct Result {
     uint32_t call, total_kmers, clade_hits, hit_groups;
 };
 
+// The one kernel argument of k_classify.  Device code never names the parameter: it reads the
+// fields it needs, phase by phase, through the kernarg-segment pointer, so that the ~50 dwords of
+// arguments are not all kept live in SGPRs for the whole kernel (see nh_kernels.hip).
+struct KArgs {
+    DevDB db;
+    const uint8_t *bases;
+    const uint64_t *seq_off;
+    uint64_t n_frag;
+    int32_t mates;
+    uint32_t frag_chunk;
+    double confidence;
+    Result *out;
+    uint32_t *kmer_taxa;
+    const uint64_t *kmer_taxa_off;
+    unsigned long long *counters;
+    int *error_flag;
+    unsigned long long *work;
+};
+
 constexpr uint32_t TAXON_AMBIGUOUS = 0xFFFFFFFFu;
 constexpr uint32_t TAXON_MATE_BORDER = 0xFFFFFFFEu;
 

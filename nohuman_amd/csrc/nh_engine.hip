@@ -109,6 +109,16 @@ static int parse_taxonomy(Engine *e, const void *taxo, size_t taxo_len) {
     return NH_OK;
 }
 
+// the probe queue packs (home cell << key_bits | compacted key) into 63 bits
+static int check_queue_packing(Engine *e) {
+    uint32_t cap_bits = 0;
+    while (cap_bits < 64 && (e->info.capacity >> cap_bits) != 0) cap_bits++;
+    if (cap_bits + e->info.key_bits > 63)
+        return set_error(NH_EDB, "hash.k2d: capacity (%u bits) + key_bits (%llu) exceeds the 63 bits "
+                         "of a probe-queue entry", cap_bits, (unsigned long long)e->info.key_bits);
+    return NH_OK;
+}
+
 static void finish_devdb(Engine *e) {
     DevDB &d = e->dev;
     const nh_db_info &i = e->info;
@@ -206,6 +216,7 @@ int open_images(const void *opts, size_t opts_len, const void *taxo, size_t taxo
                 rc = set_error(NH_EDB, "hash.k2d: size %zu != 32 + 4*capacity (%llu)", hash_len,
                                (unsigned long long)e->info.capacity);
         }
+        if (!rc) rc = check_queue_packing(e);
         if (!rc) rc = alloc_table(e, e->info.capacity);
         if (!rc) {
             hipError_t he = hipMemset(e->d_table, 0, e->table_cells_alloc * sizeof(uint32_t));
@@ -296,6 +307,7 @@ int open_dir(const char *db_dir, int device, Engine **out) {
                 rc = set_error(NH_EDB, "hash.k2d: file size does not match capacity");
         }
     }
+    if (!rc) rc = check_queue_packing(e);
     if (!rc) rc = alloc_table(e, e->info.capacity);
     if (!rc) {
         const size_t CH = 64u << 20;
@@ -395,7 +407,8 @@ int open_synthetic(uint64_t capacity, uint64_t n_keys, uint32_t depth, uint64_t 
         e->info.capacity = capacity;
         e->info.value_bits = vb;
         e->info.key_bits = 32 - vb;
-        rc = alloc_table(e, capacity);
+        rc = check_queue_packing(e);
+        if (!rc) rc = alloc_table(e, capacity);
     }
     if (!rc) rc = upload_taxonomy(e);
     if (!rc) {

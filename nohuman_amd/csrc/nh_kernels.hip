@@ -1,23 +1,29 @@
 // nh_kernels.hip -- gfx950 (CDNA4) kernels of the read-classification hot path.
 //
-// One 64-lane wavefront classifies one fragment (read or read pair) end to end; it replaces the
+// One 64-lane wavefront classifies fragments (reads or read pairs) end to end; it replaces the
 // body of kraken2's ClassifySequence loop (minimizer scan -> compact-hash probe -> ResolveTree;
 // SURVEY.md section 8a rows a5-a9, Appendix A.2-A.5) that nohuman reaches through
 // /root/reference/src/lib.rs:22-48.  Integer / byte work bound by random HBM line fetches:
 // no MFMA by design.
 //
-// Data flow of one tile (128 l-mers = 2 per lane, i.e. 128-(k-l) k-mers):
-//   global bases (one coalesced dword per lane, prefetched one tile ahead)
-//   -> 2-bit packed stream in LDS (1 byte per lane)
-//   -> per lane two l-mers by one 64-bit funnel read; ONE 32-base reverse complement serves both
-//   -> canonical/spaced/toggled candidates in LDS
-//   -> per lane two k-mer minimizers = min over a (k-l+1)-wide candidate window
-//   -> run starts (minimizer != previous non-ambiguous minimizer) compacted into an LDS queue
-//   -> one lane per queued minimizer: fmix64, exact hc % capacity, 16-byte-chunk linear probe
-//   -> taxa back through LDS -> per-taxon hit counts, hit groups -> ResolveTree on the wave.
-// The kernel is instruction-issue sensitive (see profiles/): tile-local arithmetic is 32-bit,
-// control flow is wave-uniform wherever possible, and kraken2's default k=35/l=31 geometry is a
-// compile-time specialisation (STD) next to the fully general variant.
+// Work unit = a GROUP of up to NSLOT tiles (a tile = 128 l-mers = 2 per lane = 128-(k-l) k-mers;
+// a 150-bp read is one tile, a read pair or two single reads one group):
+//   SCAN each tile of the group
+//     global bases (one coalesced dword per lane, prefetched one tile ahead)
+//     -> 2-bit packed stream in LDS (1 byte per lane)
+//     -> per lane two l-mers by one 64-bit funnel read; ONE 32-base reverse complement serves both
+//     -> canonical/spaced/toggled candidates in LDS -> per lane two k-mer minimizers (window min)
+//     -> run starts (minimizer != previous non-ambiguous minimizer) appended to the LDS queue
+//   HASH the queue densely (fmix64, exact hc % capacity), then PROBE it with lane refill: a lane
+//     owns one lookup at a time, walks its 128-byte line in 16-byte chunks, and pulls the next
+//     queued lookup the moment it resolves -- the wave does not idle on the longest probe sequence
+//     (linear probing at load 0.7 is heavy-tailed: the max over 39 lookups is ~10 chunks)
+//   POST each tile: taxa back from LDS -> per-taxon hit counts, hit groups; at the end of a
+//     fragment ResolveTree runs on the wave.
+// The kernel is instruction-issue and latency sensitive (profiles/): tile-local arithmetic is
+// 32-bit, control flow is wave-uniform wherever possible, kraken2's default k=35/l=31 geometry is a
+// compile-time specialisation (STD) next to the fully general variant, and fragments are handed
+// out dynamically in chunks so that non-resident workgroups of the grid cost nothing.
 #include <hip/hip_runtime.h>
 #include <stdlib.h>
 
@@ -32,14 +38,33 @@ namespace nh {
 
 constexpr int CAND_PAD = 66;  // window reads of idle lanes stay inside the array (k-l <= 64)
 
+constexpr int NSLOT = 2;  // tiles scanned before one shared probe phase
+constexpr int QCAP = NSLOT * TL;
+constexpr uint32_t QTAX_SKIP = 0xFFFFFFFFu;  // queue entry dropped by the min-hash filter
+
+struct SlotLds {  // a scanned tile waiting for its probe results (written by lane 0)
+    uint32_t f_lo, f_hi;    // fragment
+    uint32_t kt_lo, kt_hi;  // index in kmer_taxa of the tile's first k-mer
+    uint32_t nqt, qbase, nruns;
+    uint32_t fi;            // which FragLds / taxon list (parity of the wave's fragment count)
+    uint32_t last_lane;     // 2*lane+slot of the last unambiguous k-mer, 0xFFFFFFFF if none
+    uint32_t flags;         // 1 = last tile of its fragment, 2 = last tile of mate 0, mate 1 follows
+    uint32_t nk0, total_kmers;
+};
+struct FragLds {  // accumulation state of a fragment between its tiles
+    uint32_t nlist, hit_groups, carry_tax, overflow;
+};
+
 struct WaveLds {
+    SlotLds slot[NSLOT];
+    FragLds fs[2];
     uint32_t pk[24];  // 2-bit packed bases: base i' of the tile frame at bit 2*(255-i'); 64 B + zero pad
     uint32_t pa[24];  // same layout, value 1 where the base is ambiguous
     uint64_t cand[TL + CAND_PAD];
-    uint64_t runmin[TL];
-    uint32_t runtax[TL];
-    uint32_t list_tax[LIST_CAP];
-    uint32_t list_cnt[LIST_CAP];
+    uint64_t q[QCAP];     // queue: run-start minimizers, hashed in place (see probe_queue)
+    uint32_t qtax[QCAP];  // taxon found for each queued run
+    uint32_t list_tax[2][LIST_CAP];  // (taxon, count) lists of the (at most two) fragments in flight
+    uint32_t list_cnt[2][LIST_CAP];
 };
 
 __device__ __forceinline__ void wave_sync() {
@@ -76,83 +101,19 @@ __device__ __forceinline__ uint64_t revcomp_word(uint64_t x) {
 
 __device__ __forceinline__ uint64_t umin64(uint64_t a, uint64_t b) { return a < b ? a : b; }
 
+// Kernel arguments are read on demand from the kernarg segment (constant address space, scalar
+// loads).  Each phase launders the pointer first, which stops the compiler from hoisting every
+// argument load to the kernel entry and pinning ~50 SGPRs for the whole kernel.
+typedef const __attribute__((address_space(4))) KArgs *KArgsP;
+__device__ __forceinline__ KArgsP launder(KArgsP p) {
+    asm volatile("" : "+s"(p));
+    return p;
+}
+
 __device__ __forceinline__ uint64_t readlane64(uint64_t v, int src) {
     uint32_t lo = __builtin_amdgcn_readlane((uint32_t)v, src);
     uint32_t hi = __builtin_amdgcn_readlane((uint32_t)(v >> 32), src);
     return ((uint64_t)hi << 32) | lo;
-}
-
-// CompactHashTable::Get (A.4).  Linear probing walks aligned 16-byte chunks (4 cells per load)
-// and decides each chunk with selects only; the loop branch is the single divergent one.
-template <bool LINEAR>
-__device__ __forceinline__ uint32_t table_get(const DevDB &db, uint64_t hc, bool active) {
-    const uint32_t vbits = db.value_bits;
-    const uint32_t vmask = db.vmask;
-    const uint32_t compacted = (uint32_t)(hc >> (32 + vbits));
-    const uint64_t cap = db.capacity;
-    uint64_t pos = mod_capacity(hc, cap, db.cap_magic);
-    uint32_t result = 0;
-    if (LINEAR) {
-        // Each round fetches up to PROBE_CHUNKS 16-byte chunks, never past the end of the 128-byte
-        // line that holds `pos`: the line is the unit HBM delivers (profiles/: 1.16 fabric requests
-        // per lookup), L1/L2 are too small to keep it until a later round, and the mean number of
-        // dependent rounds a wave waits for drops from ~10 to ~3.3 (39 lookups, load factor 0.7).
-        constexpr int PROBE_CHUNKS = NH_PROBE_CHUNKS;
-        const uint32_t ckey = compacted << vbits;
-        uint32_t chunks_left = db.max_chunks;
-        bool done = !active;
-        while (!done) {
-            const uint64_t base = pos & ~3ull;
-            const uint32_t first = (uint32_t)pos & 3u;
-            const uint64_t room = cap - base;                              // existing cells from base
-            const uint32_t in_line = (32u - ((uint32_t)base & 31u)) >> 2;  // chunks to the line end
-            uint32_t nch = in_line < (uint32_t)PROBE_CHUNKS ? in_line : (uint32_t)PROBE_CHUNKS;
-            const uint32_t room_chunks = room >= 4 * PROBE_CHUNKS ? PROBE_CHUNKS : (uint32_t)((room + 3) >> 2);
-            nch = nch < room_chunks ? nch : room_chunks;
-            const uint32_t nvalid = room < 4 * nch ? (uint32_t)room : 4 * nch;
-            uint4 c[PROBE_CHUNKS];
-            const uint4 *src = reinterpret_cast<const uint4 *>(db.table + base);
-#pragma unroll
-            for (int q = 0; q < PROBE_CHUNKS; q++)  // idle slots re-read the last useful chunk
-                c[q] = src[(uint32_t)q < nch ? (uint32_t)q : nch - 1];
-            bool found = false;
-            uint32_t res = 0;
-#pragma unroll
-            for (int j = 4 * PROBE_CHUNKS - 1; j >= 0; j--) {  // lowest eligible stopping cell wins
-                const uint4 &cq = c[j >> 2];
-                const uint32_t cell = (j & 3) == 0 ? cq.x : (j & 3) == 1 ? cq.y : (j & 3) == 2 ? cq.z : cq.w;
-                const uint32_t x = cell ^ ckey;  // key bits vanish on a match
-                const bool elig = ((uint32_t)j >= first) & ((uint32_t)j < nvalid);
-                const bool stop = elig & ((x <= vmask) | ((cell & vmask) == 0));
-                found = stop ? true : found;
-                res = stop ? (x <= vmask ? x : 0u) : res;
-            }
-            result = res;
-            const uint64_t nxt = base + 4 * nch;
-            pos = nxt >= cap ? 0 : nxt;
-            chunks_left = chunks_left > nch ? chunks_left - nch : 0;
-            done = found | (chunks_left == 0);
-            if (!found) result = 0;
-        }
-    } else {
-        const uint64_t first_idx = pos;
-        const uint64_t step = mod_capacity((hc >> 8) | 1, cap, db.cap_magic);
-        bool done = !active;
-        while (!done) {
-            const uint32_t cell = db.table[pos];
-            if ((cell & vmask) == 0) {
-                done = true;
-            } else if ((cell >> vbits) == compacted) {
-                result = cell & vmask;
-                done = true;
-            } else {
-                pos += step;
-                if (pos >= cap) pos -= cap;
-                if (pos == first_idx) done = true;
-            }
-        }
-    }
-    return result;
 }
 
 __device__ __forceinline__ bool is_a_ancestor_of_b(const uint32_t *parent, uint32_t a, uint32_t b) {
@@ -240,19 +201,24 @@ struct FragState {
         }                                                  \
     } while (0)
 
-template <bool LINEAR, bool STD, bool PROF>
-__device__ __forceinline__ void process_tile(const DevDB &db, WaveLds &S, const int lane,
-                                             const uint64_t lane_lt, const uint32_t w,
-                                             const uint32_t sh, const uint32_t nlt,
-                                             const uint32_t nqt, FragState &st,
-                                             uint32_t *__restrict__ kmer_taxa, const uint64_t kt,
-                                             uint32_t &acc_lookups, uint64_t (&prof)[8],
-                                             uint64_t &tprev) {
-    const uint32_t L = STD ? 31u : db.l;
-    const uint32_t W = STD ? 4u : db.window;
-    const uint64_t LMASK = STD ? ((1ull << 62) - 1) : db.lmer_mask;
-    const int RV = STD ? 1 : db.revcom_version;
-    const uint64_t MIN_HASH = STD ? 0ull : db.min_hash;
+// SCAN one tile: l-mers [q0, q0+nlt) / k-mers [q0, q0+nqt) of a sequence whose tile frame starts
+// `sh` bytes into the dword stream `w` (4 bases per lane).  Appends the run-start minimizers to
+// S.q[qbase ...], returns their number, and leaves in `ps` the lane's packed per-k-mer state
+// (bit0/1 = k-mer 2t / 2t+1 is valid and unambiguous, bits 8-15 / 16-23 = 1 + index of the run
+// that covers it, 0 = continuation of the run that entered the tile).
+template <bool STD, bool PROF>
+__device__ __forceinline__ uint32_t scan_tile(KArgsP ap, WaveLds &S, const int lane,
+                                              const uint64_t lane_lt, const uint32_t w,
+                                              const uint32_t sh, const uint32_t nlt,
+                                              const uint32_t nqt, const uint32_t qbase,
+                                              uint64_t &carry_min, uint32_t &ps, int &last_lane,
+                                              uint64_t (&prof)[8], uint64_t &tprev) {
+    ap = launder(ap);
+    const uint32_t L = STD ? 31u : ap->db.l;
+    const uint32_t W = STD ? 4u : ap->db.window;
+    const uint64_t LMASK = STD ? ((1ull << 62) - 1) : ap->db.lmer_mask;
+    const int RV = STD ? 1 : ap->db.revcom_version;
+    const uint64_t SPACED = ap->db.spaced_mask, TOGGLE = ap->db.toggle;
 
     // ---- 1. bases -> packed 2-bit stream -------------------------------------------------------
     bool suspect;
@@ -283,8 +249,8 @@ __device__ __forceinline__ void process_tile(const DevDB &db, WaveLds &S, const 
             rc1 = revcomp_word(lm1) & LMASK;
             rc0 = revcomp_word(lm0) & LMASK;
         }
-        const uint64_t c0 = (umin64(lm0, rc0) & db.spaced_mask) ^ db.toggle;
-        const uint64_t c1 = (umin64(lm1, rc1) & db.spaced_mask) ^ db.toggle;
+        const uint64_t c0 = (umin64(lm0, rc0) & SPACED) ^ TOGGLE;
+        const uint64_t c1 = (umin64(lm1, rc1) & SPACED) ^ TOGGLE;
         bool dead0 = 2u * lane >= nlt, dead1 = 2u * lane + 1 >= nlt;
         if (has_amb) {
             const uint64_t wa = funnel_read(S.pa, s);
@@ -328,8 +294,8 @@ __device__ __forceinline__ void process_tile(const DevDB &db, WaveLds &S, const 
         const uint64_t m1 = (!STD && W == 0) ? last1 : umin64(mid, last1);
         v0 = (qi0 < nqt) & (last0 != NH_FULL);
         v1 = (qi1 < nqt) & (last1 != NH_FULL);
-        mz0 = m0 ^ db.toggle;
-        mz1 = m1 ^ db.toggle;
+        mz0 = m0 ^ TOGGLE;
+        mz1 = m1 ^ TOGGLE;
     }
 
     NH_STAMP(2);
@@ -337,7 +303,7 @@ __device__ __forceinline__ void process_tile(const DevDB &db, WaveLds &S, const 
     uint64_t prev_in;
     if (!has_amb) {
         prev_in = __shfl_up(mz1, 1, 64);
-        if (lane == 0) prev_in = st.carry_min;
+        if (lane == 0) prev_in = carry_min;
     } else {
         // inclusive scan of "rightmost lane that holds a non-ambiguous k-mer"
         bool has = v0 | v1;
@@ -353,65 +319,204 @@ __device__ __forceinline__ void process_tile(const DevDB &db, WaveLds &S, const 
         }
         const bool hx = __shfl_up((int)has, 1, 64) != 0;
         const uint64_t vx = __shfl_up(val, 1, 64);
-        prev_in = (lane > 0 && hx) ? vx : st.carry_min;
+        prev_in = (lane > 0 && hx) ? vx : carry_min;
     }
     const uint64_t prev1 = v0 ? mz0 : prev_in;
     const bool new0 = v0 & (mz0 != prev_in);
     const bool new1 = v1 & (mz1 != prev1);
 
-    // ---- 5. compact run starts into the LDS queue ----------------------------------------------
+    // ---- 5. append run starts to the LDS queue; remember the last minimizer --------------------
     const uint64_t b0 = __ballot(new0), b1 = __ballot(new1);
     const uint32_t ex = __popcll(b0 & lane_lt) + __popcll(b1 & lane_lt);
     const uint32_t nruns = __popcll(b0) + __popcll(b1);
-    if (new0) S.runmin[ex] = mz0;
-    if (new1) S.runmin[ex + (new0 ? 1u : 0u)] = mz1;
-    const int ri0 = (int)(ex + (new0 ? 1u : 0u)) - 1;
-    const int ri1 = ri0 + (new1 ? 1 : 0);
-    wave_sync();
+    if (new0) S.q[qbase + ex] = mz0;
+    if (new1) S.q[qbase + ex + (new0 ? 1u : 0u)] = mz1;
+    const uint32_t r0p = ex + (new0 ? 1u : 0u);  // 1 + run index of k-mer 2t (0 = carried run)
+    const uint32_t r1p = r0p + (new1 ? 1u : 0u);
+    ps = (v0 ? 1u : 0u) | (v1 ? 2u : 0u) | (r0p << 8) | (r1p << 16);
+    {
+        const uint64_t m1 = __ballot(v1), m0 = __ballot(v0);
+        last_lane = -1;
+        if (m0 | m1) {
+            const int l1 = m1 ? 63 - __builtin_clzll(m1) : -1;
+            const int l0 = m0 ? 63 - __builtin_clzll(m0) : -1;
+            if (l1 >= l0) {
+                carry_min = readlane64(mz1, l1);
+                last_lane = 2 * l1 + 1;
+            } else {
+                carry_min = readlane64(mz0, l0);
+                last_lane = 2 * l0;
+            }
+        }
+    }
     NH_STAMP(3);
+    return nruns;
+}
 
-    // ---- 6. one lane per queued minimizer: hash + probe ----------------------------------------
-    uint64_t hit_mask_any = 0;
-    for (uint32_t r0 = 0; r0 < nruns; r0 += 64) {
+// HASH + PROBE the queue S.q[0, qn): CompactHashTable::Get (A.4) for every entry, result in S.qtax.
+// Linear probing: the entry is rewritten as (home cell << key_bits | compacted key), which fits in
+// 63 bits (checked when the database is opened).  Double hashing keeps the hash code itself.
+template <bool LINEAR, bool STD, bool PROF>
+__device__ __forceinline__ void probe_queue(KArgsP ap, WaveLds &S, const int lane,
+                                            const uint64_t lane_lt, const uint32_t qn,
+                                            uint32_t &acc_lookups, uint64_t (&prof)[8],
+                                            uint64_t &tprev) {
+    ap = launder(ap);
+    const uint64_t MIN_HASH = STD ? 0ull : ap->db.min_hash;
+    const uint32_t vbits = ap->db.value_bits;
+    const uint32_t vmask = ap->db.vmask;
+    const uint32_t kbits = 32 - vbits;
+    const uint64_t cap = ap->db.capacity;
+    const uint64_t magic = ap->db.cap_magic;
+    const uint32_t max_chunks = ap->db.max_chunks;
+    const uint32_t *const table = ap->db.table;
+
+    // ---- 6a. dense hash pass ----------------------------------------------------------------------
+    for (uint32_t r0 = 0; r0 < qn; r0 += 64) {
         const uint32_t r = r0 + lane;
-        const bool act = r < nruns;
-        const uint64_t hc = fmix64(S.runmin[r & (TL - 1)]);
+        const bool act = r < qn;
+        const uint64_t hc = fmix64(S.q[r & (QCAP - 1)]);
         const bool look = act & !(MIN_HASH != 0 && hc < MIN_HASH);
-        const uint32_t taxon = table_get<LINEAR>(db, hc, look);
-        if (act) S.runtax[r] = taxon;
-        const uint64_t hm = __ballot(taxon != 0);
-        hit_mask_any |= hm;
-        st.hit_groups += __popcll(hm);
+        uint64_t e = hc;
+        if (LINEAR) e = (mod_capacity(hc, cap, magic) << kbits) | (hc >> (32 + vbits));
+        if (act) {
+            S.q[r] = e;
+            S.qtax[r] = look ? 0u : QTAX_SKIP;
+        }
         acc_lookups += __popcll(__ballot(look));
     }
     wave_sync();
     NH_STAMP(4);
 
-    // ---- 7. per-k-mer taxa, hit counts, carry --------------------------------------------------
+    // ---- 6b. probe with lane refill ---------------------------------------------------------------
+    uint32_t qhead = 0;      // next queue entry to hand out (uniform)
+    bool busy = false;       // this lane owns an unresolved lookup
+    uint32_t r = 0;          // its queue index
+    uint64_t pos = 0;        // next cell to examine
+    uint64_t first_pos = 0;  // double hashing: home cell
+    uint64_t step = 0;       // double hashing: stride
+    uint32_t ckey = 0;       // compacted key << value_bits
+    uint32_t budget = 0;     // linear probing: chunks left before the whole table was seen
+    for (;;) {
+        const uint64_t idle_mask = __ballot(!busy);
+        if (qhead < qn && idle_mask) {
+            const uint32_t my = qhead + __popcll(idle_mask & lane_lt);
+            if (!busy && my < qn) {
+                const uint64_t e = S.q[my];
+                bool skip = false;
+                if (!STD) {
+                    skip = S.qtax[my] == QTAX_SKIP;
+                    if (skip) S.qtax[my] = 0;
+                }
+                if (!skip) {
+                    r = my;
+                    if (LINEAR) {
+                        pos = e >> kbits;
+                        ckey = (uint32_t)(e & ((1ull << kbits) - 1)) << vbits;
+                        budget = max_chunks;
+                    } else {
+                        pos = mod_capacity(e, cap, magic);
+                        first_pos = pos;
+                        step = mod_capacity((e >> 8) | 1, cap, magic);
+                        ckey = (uint32_t)(e >> (32 + vbits)) << vbits;
+                    }
+                    busy = true;
+                }
+            }
+            const uint32_t taken = __popcll(idle_mask);
+            qhead = qhead + taken < qn ? qhead + taken : qn;
+        }
+        if (__ballot(busy) == 0) {
+            if (qhead >= qn) break;
+            continue;
+        }
+        if (busy) {
+            if (LINEAR) {
+                // up to NH_PROBE_CHUNKS aligned 16-byte chunks, never past the end of the
+                // 128-byte line (the unit HBM delivers) nor past the end of the table
+                constexpr int PC = NH_PROBE_CHUNKS;
+                const uint64_t base = pos & ~3ull;
+                const uint32_t first = (uint32_t)pos & 3u;
+                const uint64_t room = cap - base;
+                const uint32_t in_line = (32u - ((uint32_t)base & 31u)) >> 2;
+                uint32_t nch = in_line < (uint32_t)PC ? in_line : (uint32_t)PC;
+                const uint32_t room_chunks =
+                    room >= 4 * PC ? (uint32_t)PC : (uint32_t)((room + 3) >> 2);
+                nch = nch < room_chunks ? nch : room_chunks;
+                const uint32_t nvalid = room < 4 * nch ? (uint32_t)room : 4 * nch;
+                uint4 c[PC];
+                const uint4 *src = reinterpret_cast<const uint4 *>(table + base);
+#pragma unroll
+                for (int qq = 0; qq < PC; qq++)  // idle slots re-read the last useful chunk
+                    c[qq] = src[(uint32_t)qq < nch ? (uint32_t)qq : nch - 1];
+                bool found = false;
+                uint32_t res = 0;
+#pragma unroll
+                for (int j = 4 * PC - 1; j >= 0; j--) {  // lowest eligible stopping cell wins
+                    const uint4 &cq = c[j >> 2];
+                    const uint32_t cell =
+                        (j & 3) == 0 ? cq.x : (j & 3) == 1 ? cq.y : (j & 3) == 2 ? cq.z : cq.w;
+                    const uint32_t x = cell ^ ckey;  // key bits vanish on a match
+                    const bool elig = ((uint32_t)j >= first) & ((uint32_t)j < nvalid);
+                    const bool stop = elig & ((x <= vmask) | ((cell & vmask) == 0));
+                    found = stop ? true : found;
+                    res = stop ? (x <= vmask ? x : 0u) : res;
+                }
+                const uint64_t nxt = base + 4 * nch;
+                pos = nxt >= cap ? 0 : nxt;
+                budget = budget > nch ? budget - nch : 0;
+                if (found) S.qtax[r] = res;
+                busy = !(found | (budget == 0));
+            } else {
+                const uint32_t cell = table[pos];
+                const uint32_t x = cell ^ ckey;
+                if ((cell & vmask) == 0) {
+                    busy = false;
+                } else if (x <= vmask) {
+                    S.qtax[r] = x;
+                    busy = false;
+                } else {
+                    pos += step;
+                    if (pos >= cap) pos -= cap;
+                    if (pos == first_pos) busy = false;
+                }
+            }
+        }
+    }
+    wave_sync();
+    NH_STAMP(5);
+}
+
+// POST one tile: per-k-mer taxa from the probe results, hit groups, (taxon, count) list.
+template <bool PROF>
+__device__ __forceinline__ void post_tile(WaveLds &S, const int lane, const uint32_t ps,
+                                          const uint32_t nqt, const uint32_t qbase,
+                                          const uint32_t nruns, const int last_lane, FragState &st,
+                                          const uint32_t li, uint32_t *__restrict__ kmer_taxa,
+                                          const uint64_t kt, uint64_t (&prof)[8], uint64_t &tprev) {
+    const uint32_t qi0 = 2u * lane, qi1 = 2u * lane + 1;
+    const bool v0 = ps & 1u, v1 = (ps >> 1) & 1u;
+    const uint32_t r0p = (ps >> 8) & 0xFFu, r1p = (ps >> 16) & 0xFFu;
+    // hit groups = runs of this tile that found a taxon
+    uint64_t hit_any = 0;
+    for (uint32_t r0 = 0; r0 < nruns; r0 += 64) {
+        const uint32_t r = r0 + lane;
+        const uint64_t hm = __ballot(r < nruns && S.qtax[qbase + (r & (TL - 1))] != 0);
+        hit_any |= hm;
+        st.hit_groups += __popcll(hm);
+    }
     uint32_t t0 = 0, t1 = 0;
-    const bool any_hit = (hit_mask_any != 0) | (st.carry_tax != 0);
+    const bool any_hit = (hit_any != 0) | (st.carry_tax != 0);
     if (any_hit || kmer_taxa) {
-        if (v0) t0 = ri0 >= 0 ? S.runtax[ri0] : st.carry_tax;
-        if (v1) t1 = ri1 >= 0 ? S.runtax[ri1] : st.carry_tax;
+        if (v0) t0 = r0p ? S.qtax[qbase + r0p - 1] : st.carry_tax;
+        if (v1) t1 = r1p ? S.qtax[qbase + r1p - 1] : st.carry_tax;
     }
     if (kmer_taxa) {
         if (qi0 < nqt) kmer_taxa[kt + qi0] = v0 ? t0 : TAXON_AMBIGUOUS;
         if (qi1 < nqt) kmer_taxa[kt + qi1] = v1 ? t1 : TAXON_AMBIGUOUS;
     }
-    {
-        const uint64_t m1 = __ballot(v1), m0 = __ballot(v0);
-        if (m0 | m1) {
-            const int l1 = m1 ? 63 - __builtin_clzll(m1) : -1;
-            const int l0 = m0 ? 63 - __builtin_clzll(m0) : -1;
-            if (l1 >= l0) {
-                st.carry_min = readlane64(mz1, l1);
-                st.carry_tax = __builtin_amdgcn_readlane(t1, l1);
-            } else {
-                st.carry_min = readlane64(mz0, l0);
-                st.carry_tax = __builtin_amdgcn_readlane(t0, l0);
-            }
-        }
-    }
+    if (last_lane >= 0)
+        st.carry_tax = __builtin_amdgcn_readlane((last_lane & 1) ? t1 : t0, last_lane >> 1);
     // distinct non-zero taxa of this tile -> (taxon, count) list
     if (any_hit) {
         for (;;) {
@@ -425,14 +530,14 @@ __device__ __forceinline__ void process_tile(const DevDB &db, WaveLds &S, const 
             const uint32_t cnt = __popcll(__ballot(t0 == T)) + __popcll(__ballot(t1 == T));
             if (t0 == T) t0 = 0;
             if (t1 == T) t1 = 0;
-            const bool match = (uint32_t)lane < st.nlist && S.list_tax[lane] == T;
+            const bool match = (uint32_t)lane < st.nlist && S.list_tax[li][lane] == T;
             const uint64_t mb = __ballot(match);
             if (mb) {
-                if (match) S.list_cnt[lane] += cnt;
+                if (match) S.list_cnt[li][lane] += cnt;
             } else if (st.nlist < (uint32_t)LIST_CAP) {
                 if (lane == 0) {
-                    S.list_tax[st.nlist] = T;
-                    S.list_cnt[st.nlist] = cnt;
+                    S.list_tax[li][st.nlist] = T;
+                    S.list_cnt[li][st.nlist] = cnt;
                 }
                 st.nlist++;
             } else {
@@ -441,25 +546,28 @@ __device__ __forceinline__ void process_tile(const DevDB &db, WaveLds &S, const 
             wave_sync();
         }
     }
-    NH_STAMP(5);
+    NH_STAMP(6);
 }
 
 // ResolveTree (A.5) on the wave: lane i owns list entry i.  Returns the call; sets clade_hits.
-__device__ __forceinline__ uint32_t resolve_tree(const DevDB &db, WaveLds &S, const int lane,
-                                                 const FragState &st, const uint32_t total_kmers,
-                                                 const double confidence, uint32_t &clade_hits) {
+__device__ __forceinline__ uint32_t resolve_tree(KArgsP ap, WaveLds &S, const int lane,
+                                                 const FragState &st, const uint32_t li,
+                                                 const uint32_t total_kmers, uint32_t &clade_hits) {
+    ap = launder(ap);
     const uint32_t nlist = st.nlist;
-    const uint32_t *parent = db.parent;
+    const uint32_t *parent = ap->db.parent;
+    const double confidence = ap->confidence;
+    const uint32_t min_hit_groups = ap->db.min_hit_groups;
     const bool own = (uint32_t)lane < nlist;
-    const uint32_t my_t = own ? S.list_tax[lane] : 0;
-    const uint32_t my_c = own ? S.list_cnt[lane] : 0;
+    const uint32_t my_t = own ? S.list_tax[li][lane] : 0;
+    const uint32_t my_c = own ? S.list_cnt[li][lane] : 0;
     uint32_t call = 0;
     if (nlist == 1) {
-        call = S.list_tax[0];
+        call = S.list_tax[li][0];
     } else {
         uint32_t score = 0;
         for (uint32_t j = 0; j < nlist; j++) {
-            const uint32_t tj = S.list_tax[j], cj = S.list_cnt[j];
+            const uint32_t tj = S.list_tax[li][j], cj = S.list_cnt[li][j];
             if (own && is_a_ancestor_of_b(parent, tj, my_t)) score += cj;
         }
         const uint32_t top = wave_max(score);
@@ -467,7 +575,7 @@ __device__ __forceinline__ uint32_t resolve_tree(const DevDB &db, WaveLds &S, co
         while (best_mask) {
             const int j = __builtin_ctzll(best_mask);
             best_mask &= best_mask - 1;
-            call = lowest_common_ancestor(parent, call, S.list_tax[j]);
+            call = lowest_common_ancestor(parent, call, S.list_tax[li][j]);
         }
     }
     const uint32_t required = (uint32_t)ceil(confidence * (double)total_kmers);
@@ -477,7 +585,7 @@ __device__ __forceinline__ uint32_t resolve_tree(const DevDB &db, WaveLds &S, co
         if (s >= required) break;
         call = parent[call];
     }
-    if (call && st.hit_groups < db.min_hit_groups) call = 0;
+    if (call && st.hit_groups < min_hit_groups) call = 0;
     clade_hits = 0;
     if (call) clade_hits = wave_sum((own && is_a_ancestor_of_b(parent, call, my_t)) ? my_c : 0u);
     return call;
@@ -485,13 +593,11 @@ __device__ __forceinline__ uint32_t resolve_tree(const DevDB &db, WaveLds &S, co
 
 constexpr uint32_t PREF_LANES = 42;  // dwords a tile can need: (3 + 128 + 30 + 3) / 4 <= 41
 
+__device__ __forceinline__ uint32_t uni(uint32_t v) { return __builtin_amdgcn_readfirstlane(v); }
+
 template <bool LINEAR, bool STD, bool PROF>
-__global__ __launch_bounds__(WAVE * WAVES_PER_BLOCK) void k_classify(
-    const DevDB db, const uint8_t *__restrict__ bases, const uint64_t *__restrict__ seq_off,
-    const uint64_t n_frag, const int mates, const double confidence, Result *__restrict__ out,
-    uint32_t *__restrict__ kmer_taxa, const uint64_t *__restrict__ kmer_taxa_off,
-    unsigned long long *__restrict__ counters, int *__restrict__ error_flag,
-    unsigned long long *__restrict__ work, const uint32_t frag_chunk) {
+__global__ __launch_bounds__(WAVE * WAVES_PER_BLOCK) void k_classify(const KArgs args_by_kernarg_pointer) {
+    KArgsP ap = (KArgsP)__builtin_amdgcn_kernarg_segment_ptr();
     __shared__ WaveLds lds_all[WAVES_PER_BLOCK];
     const int lane = threadIdx.x & 63;
     const int wib = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -505,9 +611,14 @@ __global__ __launch_bounds__(WAVE * WAVES_PER_BLOCK) void k_classify(
     for (int i = lane; i < CAND_PAD; i += 64) S.cand[TL + i] = NH_FULL;
     wave_sync();
 
-    const uint32_t K = STD ? 35u : db.k;
-    const uint32_t L = STD ? 31u : db.l;
-    const uint32_t TQ = TL - (STD ? 4u : db.window);  // k-mers per tile
+    const uint32_t K = STD ? 35u : ap->db.k;
+    const uint32_t L = STD ? 31u : ap->db.l;
+    const uint32_t TQ = TL - (STD ? 4u : ap->db.window);  // k-mers per tile
+    const int mates = ap->mates;
+    const uint64_t n_frag = ap->n_frag;
+    const uint64_t *const seq_off = ap->seq_off;
+    const uint8_t *const bases = ap->bases;
+    const bool reset_per_mate = ap->db.reset_per_mate != 0;
     const uint64_t lane_lt = (lane == 0) ? 0ull : (NH_FULL >> (64 - lane));
     // dword index of the last dword the caller guarantees readable (8 bytes of slack, see ABI)
     const uint64_t last_dw = (seq_off[n_frag * (uint64_t)mates] + 4) >> 2;
@@ -523,96 +634,206 @@ __global__ __launch_bounds__(WAVE * WAVES_PER_BLOCK) void k_classify(
     uint32_t acc_frag = 0, acc_class = 0, acc_lookups = 0;
     uint64_t acc_bases = 0;
     bool bad_input = false;
+    uint64_t prof[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    uint64_t tprev = PROF ? __builtin_readcyclecounter() : 0;
 
     // speculative one-tile-ahead prefetch: pref_g0 is the byte offset w_pref was loaded for
     uint64_t pref_g0 = ~0ull;
     uint32_t w_pref = 0;
 
-    uint64_t prof[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    uint64_t tprev = PROF ? __builtin_readcyclecounter() : 0;
+    uint32_t nslot = 0;      // scanned tiles waiting for the probe phase (descriptors in S.slot)
+    uint32_t qn = 0;         // queue entries they hold
+    uint32_t fcount = 0;     // fragments with k-mers started by this wave
+    uint32_t ps0 = 0, ps1 = 0;  // per-lane packed k-mer state of the waiting tiles
 
-    // Dynamic distribution: every wave pulls chunks of consecutive fragments from one counter, so
-    // late-starting (non-resident) workgroups of the grid find no work instead of a static share.
+    // probe the queue, then finish every waiting tile (and its fragment if that was its last tile)
+    auto flush = [&]() {
+        if (nslot == 0) return;
+        probe_queue<LINEAR, STD, PROF>(ap, S, lane, lane_lt, qn, acc_lookups, prof, tprev);
+        KArgsP a2 = launder(ap);
+        uint32_t *const kmer_taxa = a2->kmer_taxa;
+        for (uint32_t s = 0; s < nslot; s++) {
+            const SlotLds d = S.slot[s];
+            const uint32_t fi = uni(d.fi);
+            const uint32_t flags = uni(d.flags);
+            const FragLds fl = S.fs[fi];
+            FragState st;
+            st.nlist = uni(fl.nlist);
+            st.hit_groups = uni(fl.hit_groups);
+            st.carry_tax = uni(fl.carry_tax);
+            st.overflow = uni(fl.overflow) != 0;
+            st.carry_min = 0;  // not used after the scan
+            const uint64_t f = ((uint64_t)uni(d.f_hi) << 32) | uni(d.f_lo);
+            const uint64_t kt = ((uint64_t)uni(d.kt_hi) << 32) | uni(d.kt_lo);
+            post_tile<PROF>(S, lane, s ? ps1 : ps0, uni(d.nqt), uni(d.qbase), uni(d.nruns),
+                            (int)uni(d.last_lane), st, fi, kmer_taxa, kt, prof, tprev);
+            if ((flags & 2u) && reset_per_mate) st.carry_tax = 0;  // mate 0 ended, mate 1 follows
+            if (flags & 1u) {                                      // fragment ended
+                const uint32_t total_kmers = uni(d.total_kmers);
+                uint32_t call = 0, clade_hits = 0;
+                if (st.nlist > 0) call = resolve_tree(ap, S, lane, st, fi, total_kmers, clade_hits);
+                if (lane == 0) {
+                    uint4 rec;
+                    rec.x = call;
+                    rec.y = total_kmers;
+                    rec.z = clade_hits;
+                    rec.w = st.hit_groups;
+                    *reinterpret_cast<uint4 *>(&a2->out[f]) = rec;
+                    if (kmer_taxa && mates == 2)
+                        kmer_taxa[a2->kmer_taxa_off[f] + uni(d.nk0)] = TAXON_MATE_BORDER;
+                    if (st.overflow) atomicMax(a2->error_flag, 1);
+                }
+                acc_class += call ? 1 : 0;
+            } else if (lane == 0) {
+                S.fs[fi].nlist = st.nlist;
+                S.fs[fi].hit_groups = st.hit_groups;
+                S.fs[fi].carry_tax = st.carry_tax;
+                S.fs[fi].overflow = st.overflow ? 1u : 0u;
+            }
+            wave_sync();
+        }
+        nslot = 0;
+        qn = 0;
+        NH_STAMP(7);
+    };
+
+    // Fragments are handed out dynamically: every wave pulls chunks of consecutive fragments from
+    // one counter, so late-starting (non-resident) workgroups of the grid find no work instead of
+    // a static share.  The tile iterator below is a flat state machine (one scan site, one flush
+    // site) over chunk -> fragment -> mate -> tile.
+    uint64_t f = 0, cend = 0;                 // current fragment, end of the current chunk
+    uint64_t o0 = 0, o1 = 0, o2 = 0;          // sequence bounds of the current fragment
+    uint32_t n0 = 0, n1 = 0, nk0 = 0, nk1 = 0;
+    uint64_t kt_base = 0;
+    uint32_t m = 0, q0 = 0, fi = 0;
+    uint64_t carry_min = NH_FULL;             // kraken2 last_minimizer of the current fragment
+    bool frag_valid = false;
     for (;;) {
-    unsigned long long cbeg = 0;
-    if (lane == 0) cbeg = atomicAdd(work, (unsigned long long)frag_chunk);
-    cbeg = readlane64(cbeg, 0);
-    if (cbeg >= n_frag) break;
-    const uint64_t cend = cbeg + frag_chunk < n_frag ? cbeg + frag_chunk : n_frag;
-    for (uint64_t f = cbeg; f < cend; f++) {
-        const uint64_t s0 = f * (uint64_t)mates;
-        const uint64_t o0 = seq_off[s0], o1 = seq_off[s0 + 1];
-        const uint64_t o2 = mates == 2 ? seq_off[s0 + 2] : o1;
-        if (((o1 - o0) | (o2 - o1)) >> 31) bad_input = true;  // sequences of 2 Gbases and more
-        const uint32_t n0 = (uint32_t)(o1 - o0), n1 = (uint32_t)(o2 - o1);
-        const uint32_t nk0 = n0 >= K ? n0 - K + 1 : 0;
-        const uint32_t nk1 = n1 >= K ? n1 - K + 1 : 0;
-        // the next fragment of this chunk starts where this one ends (prefetch across fragments)
-        const uint64_t next_frag_g0 = f + 1 < cend ? o2 : ~0ull;
-        const uint64_t kt_base = kmer_taxa ? kmer_taxa_off[f] : 0;
-
-        FragState st;
-        st.nlist = 0;
-        st.hit_groups = 0;
-        st.carry_min = NH_FULL;
-        st.carry_tax = 0;
-        st.overflow = false;
-
-        for (int m = 0; m < mates; m++) {
+        bool have = false;
+        for (;;) {
+            if (frag_valid) {
+                if (q0 < (m ? nk1 : nk0)) {
+                    have = true;
+                    break;
+                }
+                if ((int)m + 1 < mates) {
+                    m++;
+                    q0 = 0;
+                    if (reset_per_mate) carry_min = NH_FULL;
+                    continue;
+                }
+                frag_valid = false;
+            }
+            f++;
+            if (f >= cend) {
+                unsigned long long cbeg = 0;
+                const uint32_t frag_chunk = ap->frag_chunk;
+                if (lane == 0) cbeg = atomicAdd(ap->work, (unsigned long long)frag_chunk);
+                cbeg = readlane64(cbeg, 0);
+                if (cbeg >= n_frag) break;
+                f = cbeg;
+                cend = cbeg + frag_chunk < n_frag ? cbeg + frag_chunk : n_frag;
+            }
+            const uint64_t s0 = f * (uint64_t)mates;
+            o0 = seq_off[s0];
+            o1 = seq_off[s0 + 1];
+            o2 = mates == 2 ? seq_off[s0 + 2] : o1;
+            if (((o1 - o0) | (o2 - o1)) >> 31) bad_input = true;  // sequences of 2 Gbases and more
+            n0 = (uint32_t)(o1 - o0);
+            n1 = (uint32_t)(o2 - o1);
+            nk0 = n0 >= K ? n0 - K + 1 : 0;
+            nk1 = n1 >= K ? n1 - K + 1 : 0;
+            uint32_t *const kmer_taxa = ap->kmer_taxa;
+            kt_base = kmer_taxa ? ap->kmer_taxa_off[f] : 0;
+            acc_frag += 1;
+            acc_bases += (uint64_t)n0 + n1;
+            if (nk0 + nk1 == 0) {  // no k-mer at all: all-zero record, only the mate border
+                if (lane == 0) {
+                    uint4 rec = {0, 0, 0, 0};
+                    *reinterpret_cast<uint4 *>(&ap->out[f]) = rec;
+                    if (kmer_taxa && mates == 2) kmer_taxa[kt_base] = TAXON_MATE_BORDER;
+                }
+                continue;
+            }
+            // A fragment takes the state slot that the fragment before the previous one used:
+            // with NSLOT = 2 that fragment has no tile in flight any more.
+            fi = fcount & 1u;
+            fcount++;
+            carry_min = NH_FULL;
+            if (lane == 0) {
+                FragLds z;
+                z.nlist = 0;
+                z.hit_groups = 0;
+                z.carry_tax = 0;
+                z.overflow = 0;
+                S.fs[fi] = z;
+            }
+            frag_valid = true;
+            m = 0;
+            q0 = 0;
+        }
+        if (have) {
             const uint32_t n = m ? n1 : n0;
             const uint32_t nk = m ? nk1 : nk0;
-            const uint64_t sb = m ? o1 : o0;
-            if (m == 1 && db.reset_per_mate) {
-                st.carry_min = NH_FULL;
-                st.carry_tax = 0;
-            }
-            for (uint32_t q0 = 0; q0 < nk; q0 += TQ) {
-                const uint64_t g0 = sb + q0;
-                NH_STAMP(0);
-                const uint32_t w = (pref_g0 == g0) ? w_pref : load_tile(g0);
-                // guess the tile after this one and start its load now
-                uint64_t ng0;
-                if (q0 + TQ < nk)
-                    ng0 = g0 + TQ;
-                else if (m == 0 && mates == 2)
-                    ng0 = o1;
-                else
-                    ng0 = next_frag_g0;
-                if (ng0 != ~0ull) w_pref = load_tile(ng0);
-                pref_g0 = ng0;
+            const uint64_t g0 = (m ? o1 : o0) + q0;
+            NH_STAMP(0);
+            const uint32_t w = (pref_g0 == g0) ? w_pref : load_tile(g0);
+            // guess the tile after this one and start its load now: next tile of the sequence,
+            // else the mate, else the next fragment of the chunk (it starts where this one ends)
+            uint64_t ng0;
+            if (q0 + TQ < nk)
+                ng0 = g0 + TQ;
+            else if (m == 0 && mates == 2)
+                ng0 = o1;
+            else
+                ng0 = f + 1 < cend ? o2 : ~0ull;
+            if (ng0 != ~0ull) w_pref = load_tile(ng0);
+            pref_g0 = ng0;
 
-                const uint32_t nl_left = (n - L + 1) - q0;
-                const uint32_t nlt = nl_left < (uint32_t)TL ? nl_left : (uint32_t)TL;
-                const uint32_t nq_left = nk - q0;
-                const uint32_t nqt = nq_left < TQ ? nq_left : TQ;
+            const uint32_t nl_left = (n - L + 1) - q0;
+            const uint32_t nlt = nl_left < (uint32_t)TL ? nl_left : (uint32_t)TL;
+            const uint32_t nq_left = nk - q0;
+            const uint32_t nqt = nq_left < TQ ? nq_left : TQ;
+            const bool seq_end = q0 + TQ >= nk;
+            const bool frag_end = seq_end && ((int)m == mates - 1 || nk1 == 0);
+            const bool mate_end = seq_end && m == 0 && mates == 2 && nk1 != 0;
+
+            uint32_t ps;
+            int last_lane;
+            const uint32_t nruns = scan_tile<STD, PROF>(ap, S, lane, lane_lt, w, (uint32_t)g0 & 3u, nlt,
+                                                        nqt, qn, carry_min, ps, last_lane, prof, tprev);
+            if (lane == 0) {
+                SlotLds d;
                 const uint64_t kt = kt_base + (m ? (uint64_t)nk0 + 1 : 0) + q0;
-                process_tile<LINEAR, STD, PROF>(db, S, lane, lane_lt, w, (uint32_t)g0 & 3u, nlt, nqt,
-                                                st, kmer_taxa, kt, acc_lookups, prof, tprev);
+                d.f_lo = (uint32_t)f;
+                d.f_hi = (uint32_t)(f >> 32);
+                d.kt_lo = (uint32_t)kt;
+                d.kt_hi = (uint32_t)(kt >> 32);
+                d.nqt = nqt;
+                d.qbase = qn;
+                d.nruns = nruns;
+                d.fi = fi;
+                d.last_lane = (uint32_t)last_lane;
+                d.flags = (frag_end ? 1u : 0u) | (mate_end ? 2u : 0u);
+                d.nk0 = nk0;
+                d.total_kmers = nk0 + nk1;
+                S.slot[nslot] = d;
             }
+            if (nslot == 0)
+                ps0 = ps;
+            else
+                ps1 = ps;
+            qn += nruns;
+            nslot++;
+            q0 += TQ;
         }
-
-        // ---- end of fragment --------------------------------------------------------------------
-        const uint32_t total_kmers = nk0 + nk1;
-        uint32_t call = 0, clade_hits = 0;
-        if (st.nlist > 0) call = resolve_tree(db, S, lane, st, total_kmers, confidence, clade_hits);
-        if (lane == 0) {
-            uint4 rec;
-            rec.x = call;
-            rec.y = total_kmers;
-            rec.z = clade_hits;
-            rec.w = st.hit_groups;
-            *reinterpret_cast<uint4 *>(&out[f]) = rec;
-            if (kmer_taxa && mates == 2) kmer_taxa[kt_base + nk0] = TAXON_MATE_BORDER;
-            if (st.overflow) atomicMax(error_flag, 1);
-        }
-        acc_frag += 1;
-        acc_class += call ? 1 : 0;
-        acc_bases += (uint64_t)n0 + n1;
-        NH_STAMP(6);
-    }
+        if (nslot == NSLOT || !have) flush();
+        if (!have) break;
     }
 
     if (lane == 0) {
+        unsigned long long *const counters = ap->counters;
+        int *const error_flag = ap->error_flag;
         if (PROF && counters)
             for (int i = 0; i < 8; i++) atomicAdd(&counters[CNT_N + i], (unsigned long long)prof[i]);
         if (counters) {
@@ -668,15 +889,8 @@ static bool is_std(const DevDB &db) {
 }
 
 template <bool LINEAR, bool STD, bool PROF = false>
-static void launch_variant(const DevDB &db, dim3 g, dim3 b, hipStream_t stream, const void *d_bases,
-                           const void *d_seq_off, uint64_t n_frag, int mates, double confidence,
-                           void *d_out, void *d_kmer_taxa, const void *d_kmer_taxa_off,
-                           void *d_counters, int *d_error, unsigned long long *d_work,
-                           uint32_t frag_chunk) {
-    hipLaunchKernelGGL((k_classify<LINEAR, STD, PROF>), g, b, 0, stream, db, (const uint8_t *)d_bases,
-                       (const uint64_t *)d_seq_off, n_frag, mates, confidence, (Result *)d_out,
-                       (uint32_t *)d_kmer_taxa, (const uint64_t *)d_kmer_taxa_off,
-                       (unsigned long long *)d_counters, d_error, d_work, frag_chunk);
+static void launch_variant(const KArgs &ka, dim3 g, dim3 b, hipStream_t stream) {
+    hipLaunchKernelGGL((k_classify<LINEAR, STD, PROF>), g, b, 0, stream, ka);
 }
 
 hipError_t launch_classify(const DevDB &db, const void *d_bases, const void *d_seq_off,
@@ -692,22 +906,28 @@ hipError_t launch_classify(const DevDB &db, const void *d_bases, const void *d_s
     int grid = (int)(need < (uint64_t)grid_blocks ? need : (uint64_t)grid_blocks);
     dim3 g(grid), b(WAVE * WAVES_PER_BLOCK);
     const bool std_geom = is_std(db);
-    if (db.linear_probing && std_geom && getenv("NH_PHASE_PROF")) {
-        // phase profile build of the default variant: d_counters must hold CNT_N + 8 words
-        launch_variant<true, true, true>(db, g, b, stream, d_bases, d_seq_off, n_frag, mates, confidence,
-                                         d_out, d_kmer_taxa, d_kmer_taxa_off, d_counters, d_error, d_work, frag_chunk);
-    } else if (db.linear_probing) {
-        if (std_geom)
-            launch_variant<true, true>(db, g, b, stream, d_bases, d_seq_off, n_frag, mates, confidence,
-                                       d_out, d_kmer_taxa, d_kmer_taxa_off, d_counters, d_error, d_work, frag_chunk);
-        else
-            launch_variant<true, false>(db, g, b, stream, d_bases, d_seq_off, n_frag, mates,
-                                        confidence, d_out, d_kmer_taxa, d_kmer_taxa_off, d_counters,
-                                        d_error, d_work, frag_chunk);
-    } else {
-        launch_variant<false, false>(db, g, b, stream, d_bases, d_seq_off, n_frag, mates, confidence,
-                                     d_out, d_kmer_taxa, d_kmer_taxa_off, d_counters, d_error, d_work, frag_chunk);
-    }
+    KArgs ka;
+    ka.db = db;
+    ka.bases = (const uint8_t *)d_bases;
+    ka.seq_off = (const uint64_t *)d_seq_off;
+    ka.n_frag = n_frag;
+    ka.mates = mates;
+    ka.frag_chunk = frag_chunk;
+    ka.confidence = confidence;
+    ka.out = (Result *)d_out;
+    ka.kmer_taxa = (uint32_t *)d_kmer_taxa;
+    ka.kmer_taxa_off = (const uint64_t *)d_kmer_taxa_off;
+    ka.counters = (unsigned long long *)d_counters;
+    ka.error_flag = d_error;
+    ka.work = d_work;
+    if (db.linear_probing && std_geom && getenv("NH_PHASE_PROF"))
+        launch_variant<true, true, true>(ka, g, b, stream);  // d_counters holds CNT_N + 8 words
+    else if (db.linear_probing && std_geom)
+        launch_variant<true, true>(ka, g, b, stream);
+    else if (db.linear_probing)
+        launch_variant<true, false>(ka, g, b, stream);
+    else
+        launch_variant<false, false>(ka, g, b, stream);
     return hipGetLastError();
 }
 
