@@ -24,7 +24,7 @@ struct DevDB {
     int32_t linear_probing;
     int32_t reset_per_mate;
     uint32_t min_hit_groups;
-    uint32_t max_chunks;    // bound of the linear-probe loop: capacity/4 + 2 chunks
+    uint32_t max_chunks;    // bound of the linear-probe loop in rounds (>= 1 cell per round)
 };
 
 // per-launch device counters (uint64 each)

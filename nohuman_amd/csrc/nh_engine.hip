@@ -140,8 +140,8 @@ static void finish_devdb(Engine *e) {
     d.linear_probing = e->options.linear_probing;
     d.reset_per_mate = e->options.reset_per_mate;
     d.min_hit_groups = e->options.minimum_hit_groups;
-    const uint64_t mc = i.capacity / 4 + 2;
-    d.max_chunks = mc > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)mc;
+    // bound of the probe loop: every round advances by at least one cell
+    d.max_chunks = i.capacity + 1 > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)(i.capacity + 1);
 }
 
 static int alloc_table(Engine *e, uint64_t capacity) {
@@ -474,7 +474,7 @@ int classify_device(Engine *e, const void *d_bases, const void *d_seq_off, uint6
     hipError_t he = launch_classify(e->dev, d_bases, d_seq_off, n_frag,
                                     (flags & NH_FLAG_PAIRED) ? 2 : 1, confidence, d_results,
                                     d_kmer_taxa, d_kmer_taxa_off, d_counters, e->d_error, e->d_work,
-                                    e->frag_chunk, e->grid_blocks, stream);
+                                    e->frag_chunk > 31 ? 31 : e->frag_chunk, e->grid_blocks, stream);
     if (he != hipSuccess) return set_error(NH_EDEVICE, "classify launch: %s", hipGetErrorString(he));
     return NH_OK;
 }

@@ -36,7 +36,9 @@ namespace nh {
 #define NH_PROBE_CHUNKS 2
 #endif
 
-constexpr int CAND_PAD = 66;  // window reads of idle lanes stay inside the array (k-l <= 64)
+// window reads of idle lanes stay inside the candidate array: k-l+2 pad entries (k-l = 4 for
+// kraken2's default geometry, <= 64 in general)
+template <bool STD> struct CandPad { static constexpr int value = STD ? 6 : 66; };
 
 constexpr int NSLOT = 2;  // tiles scanned before one shared probe phase
 constexpr int QCAP = NSLOT * TL;
@@ -55,14 +57,19 @@ struct FragLds {  // accumulation state of a fragment between its tiles
     uint32_t nlist, hit_groups, carry_tax, overflow;
 };
 
-struct WaveLds {
+// the generic kernel keeps the probe results apart from the queue entries; STD aliases them
+template <bool STD> struct QTax { uint32_t v[QCAP]; };
+template <> struct QTax<true> {};
+
+template <bool STD>
+struct WaveLdsT {
     SlotLds slot[NSLOT];
     FragLds fs[2];
     uint32_t pk[24];  // 2-bit packed bases: base i' of the tile frame at bit 2*(255-i'); 64 B + zero pad
     uint32_t pa[24];  // same layout, value 1 where the base is ambiguous
-    uint64_t cand[TL + CAND_PAD];
+    uint64_t cand[TL + CandPad<STD>::value];
     uint64_t q[QCAP];     // queue: run-start minimizers, hashed in place (see probe_queue)
-    uint32_t qtax[QCAP];  // taxon found for each queued run
+    QTax<STD> qtax;       // taxon found for each queued run (generic kernel only, see tax_at)
     uint32_t list_tax[2][LIST_CAP];  // (taxon, count) lists of the (at most two) fragments in flight
     uint32_t list_cnt[2][LIST_CAP];
 };
@@ -207,7 +214,7 @@ struct FragState {
 // (bit0/1 = k-mer 2t / 2t+1 is valid and unambiguous, bits 8-15 / 16-23 = 1 + index of the run
 // that covers it, 0 = continuation of the run that entered the tile).
 template <bool STD, bool PROF>
-__device__ __forceinline__ uint32_t scan_tile(KArgsP ap, WaveLds &S, const int lane,
+__device__ __forceinline__ uint32_t scan_tile(KArgsP ap, WaveLdsT<STD> &S, const int lane,
                                               const uint64_t lane_lt, const uint32_t w,
                                               const uint32_t sh, const uint32_t nlt,
                                               const uint32_t nqt, const uint32_t qbase,
@@ -353,11 +360,24 @@ __device__ __forceinline__ uint32_t scan_tile(KArgsP ap, WaveLds &S, const int l
     return nruns;
 }
 
-// HASH + PROBE the queue S.q[0, qn): CompactHashTable::Get (A.4) for every entry, result in S.qtax.
-// Linear probing: the entry is rewritten as (home cell << key_bits | compacted key), which fits in
-// 63 bits (checked when the database is opened).  Double hashing keeps the hash code itself.
-template <bool LINEAR, bool STD, bool PROF>
-__device__ __forceinline__ void probe_queue(KArgsP ap, WaveLds &S, const int lane,
+// Where the taxon of queued run r is stored: the generic kernel has its own array (it also marks
+// entries dropped by the min-hash filter there); the STD kernel reuses the low dword of the queue
+// entry itself, which the owning lane has copied to registers before it writes the result.
+template <bool STD>
+__device__ __forceinline__ uint32_t &tax_at(WaveLdsT<STD> &S, uint32_t r) {
+    if constexpr (STD)
+        return reinterpret_cast<uint32_t *>(&S.q[r])[0];
+    else
+        return S.qtax.v[r];
+}
+
+// HASH + PROBE the queue S.q[0, qn): CompactHashTable::Get (A.4) for every entry, result in
+// tax_at(r).  Queue entry after the hash pass (linear probing):
+//   CAP32 (capacity < 2^32 - 256):  low dword = home cell, high dword = compacted key << value_bits
+//   otherwise:                      home cell << key_bits | compacted key   (<= 63 bits, checked at open)
+// Double hashing keeps the hash code itself.
+template <bool LINEAR, bool STD, bool CAP32, bool PROF>
+__device__ __forceinline__ void probe_queue(KArgsP ap, WaveLdsT<STD> &S, const int lane,
                                             const uint64_t lane_lt, const uint32_t qn,
                                             uint32_t &acc_lookups, uint64_t (&prof)[8],
                                             uint64_t &tprev) {
@@ -368,7 +388,7 @@ __device__ __forceinline__ void probe_queue(KArgsP ap, WaveLds &S, const int lan
     const uint32_t kbits = 32 - vbits;
     const uint64_t cap = ap->db.capacity;
     const uint64_t magic = ap->db.cap_magic;
-    const uint32_t max_chunks = ap->db.max_chunks;
+    const uint32_t max_rounds = ap->db.max_chunks;
     const uint32_t *const table = ap->db.table;
 
     // ---- 6a. dense hash pass ----------------------------------------------------------------------
@@ -378,10 +398,15 @@ __device__ __forceinline__ void probe_queue(KArgsP ap, WaveLds &S, const int lan
         const uint64_t hc = fmix64(S.q[r & (QCAP - 1)]);
         const bool look = act & !(MIN_HASH != 0 && hc < MIN_HASH);
         uint64_t e = hc;
-        if (LINEAR) e = (mod_capacity(hc, cap, magic) << kbits) | (hc >> (32 + vbits));
+        if (LINEAR) {
+            const uint64_t home = mod_capacity(hc, cap, magic);
+            const uint32_t compacted = (uint32_t)(hc >> (32 + vbits));
+            e = CAP32 ? (((uint64_t)(compacted << vbits) << 32) | (uint32_t)home)
+                      : ((home << kbits) | compacted);
+        }
         if (act) {
             S.q[r] = e;
-            S.qtax[r] = look ? 0u : QTAX_SKIP;
+            if constexpr (!STD) S.qtax.v[r] = look ? 0u : QTAX_SKIP;
         }
         acc_lookups += __popcll(__ballot(look));
     }
@@ -390,95 +415,126 @@ __device__ __forceinline__ void probe_queue(KArgsP ap, WaveLds &S, const int lan
 
     // ---- 6b. probe with lane refill ---------------------------------------------------------------
     uint32_t qhead = 0;      // next queue entry to hand out (uniform)
-    bool busy = false;       // this lane owns an unresolved lookup
+    uint32_t busy = 0;       // this lane owns an unresolved lookup
     uint32_t r = 0;          // its queue index
-    uint64_t pos = 0;        // next cell to examine
+    uint64_t pos = 0;        // next cell to examine (32 bits used when CAP32)
     uint64_t first_pos = 0;  // double hashing: home cell
     uint64_t step = 0;       // double hashing: stride
     uint32_t ckey = 0;       // compacted key << value_bits
-    uint32_t budget = 0;     // linear probing: chunks left before the whole table was seen
+    uint32_t budget = 0;     // rounds left before the whole table was seen
     for (;;) {
-        const uint64_t idle_mask = __ballot(!busy);
-        if (qhead < qn && idle_mask) {
-            const uint32_t my = qhead + __popcll(idle_mask & lane_lt);
-            if (!busy && my < qn) {
-                const uint64_t e = S.q[my];
-                bool skip = false;
-                if (!STD) {
-                    skip = S.qtax[my] == QTAX_SKIP;
-                    if (skip) S.qtax[my] = 0;
-                }
-                if (!skip) {
-                    r = my;
-                    if (LINEAR) {
-                        pos = e >> kbits;
-                        ckey = (uint32_t)(e & ((1ull << kbits) - 1)) << vbits;
-                        budget = max_chunks;
-                    } else {
-                        pos = mod_capacity(e, cap, magic);
-                        first_pos = pos;
-                        step = mod_capacity((e >> 8) | 1, cap, magic);
-                        ckey = (uint32_t)(e >> (32 + vbits)) << vbits;
+        if (qhead < qn) {
+            const uint64_t idle_mask = __ballot(busy == 0);
+            if (idle_mask) {
+                const uint32_t my = qhead + __popcll(idle_mask & lane_lt);
+                if (busy == 0 && my < qn) {
+                    const uint64_t e = S.q[my];
+                    bool skip = false;
+                    if constexpr (!STD) {
+                        skip = S.qtax.v[my] == QTAX_SKIP;
+                        if (skip) S.qtax.v[my] = 0;
                     }
-                    busy = true;
+                    if (!skip) {
+                        r = my;
+                        budget = max_rounds;
+                        if (LINEAR) {
+                            if (CAP32) {
+                                pos = (uint32_t)e;
+                                ckey = (uint32_t)(e >> 32);
+                            } else {
+                                pos = e >> kbits;
+                                ckey = (uint32_t)(e & ((1ull << kbits) - 1)) << vbits;
+                            }
+                        } else {
+                            pos = mod_capacity(e, cap, magic);
+                            first_pos = pos;
+                            step = mod_capacity((e >> 8) | 1, cap, magic);
+                            ckey = (uint32_t)(e >> (32 + vbits)) << vbits;
+                        }
+                        busy = 1;
+                    }
                 }
+                const uint32_t taken = __popcll(idle_mask);
+                qhead = qhead + taken < qn ? qhead + taken : qn;
             }
-            const uint32_t taken = __popcll(idle_mask);
-            qhead = qhead + taken < qn ? qhead + taken : qn;
         }
-        if (__ballot(busy) == 0) {
+        if (__ballot(busy != 0) == 0) {
             if (qhead >= qn) break;
             continue;
         }
         if (busy) {
             if (LINEAR) {
-                // up to NH_PROBE_CHUNKS aligned 16-byte chunks, never past the end of the
-                // 128-byte line (the unit HBM delivers) nor past the end of the table
+                // One round: the 4*PC cells from `pos` on (unaligned 16-byte loads), of which only
+                // those before the end of the 128-byte line (the unit HBM delivers) and before the
+                // end of the table count.  All loaded cells are scanned; the first stopping cell
+                // decides, and it only counts if it is one of the nvalid eligible ones.
                 constexpr int PC = NH_PROBE_CHUNKS;
-                const uint64_t base = pos & ~3ull;
-                const uint32_t first = (uint32_t)pos & 3u;
-                const uint64_t room = cap - base;
-                const uint32_t in_line = (32u - ((uint32_t)base & 31u)) >> 2;
-                uint32_t nch = in_line < (uint32_t)PC ? in_line : (uint32_t)PC;
-                const uint32_t room_chunks =
-                    room >= 4 * PC ? (uint32_t)PC : (uint32_t)((room + 3) >> 2);
-                nch = nch < room_chunks ? nch : room_chunks;
-                const uint32_t nvalid = room < 4 * nch ? (uint32_t)room : 4 * nch;
+                uint32_t nvalid, in_line;
+                const uint32_t *src;
+                if (CAP32) {
+                    const uint32_t p32 = (uint32_t)pos;
+                    in_line = 32u - (p32 & 31u);
+                    const uint32_t room = (uint32_t)cap - p32;
+                    nvalid = in_line < room ? in_line : room;
+                    src = table + p32;
+                } else {
+                    in_line = 32u - ((uint32_t)pos & 31u);
+                    const uint64_t room = cap - pos;
+                    nvalid = room < in_line ? (uint32_t)room : in_line;
+                    src = table + pos;
+                }
+                nvalid = nvalid < 4u * PC ? nvalid : 4u * PC;
+                const uint32_t last_chunk = (nvalid - 1) >> 2;
                 uint4 c[PC];
-                const uint4 *src = reinterpret_cast<const uint4 *>(table + base);
 #pragma unroll
-                for (int qq = 0; qq < PC; qq++)  // idle slots re-read the last useful chunk
-                    c[qq] = src[(uint32_t)qq < nch ? (uint32_t)qq : nch - 1];
-                bool found = false;
-                uint32_t res = 0;
+                for (int qq = 0; qq < PC; qq++) {  // idle slots re-read the last useful chunk
+                    const uint32_t ch = (uint32_t)qq < last_chunk ? (uint32_t)qq : last_chunk;
+                    c[qq] = *reinterpret_cast<const uint4 *>(src + 4 * ch);
+                }
+                uint32_t res = 0, resj = 4 * PC;
 #pragma unroll
-                for (int j = 4 * PC - 1; j >= 0; j--) {  // lowest eligible stopping cell wins
+                for (int j = 4 * PC - 1; j >= 0; j--) {  // lowest stopping cell wins
                     const uint4 &cq = c[j >> 2];
                     const uint32_t cell =
                         (j & 3) == 0 ? cq.x : (j & 3) == 1 ? cq.y : (j & 3) == 2 ? cq.z : cq.w;
                     const uint32_t x = cell ^ ckey;  // key bits vanish on a match
-                    const bool elig = ((uint32_t)j >= first) & ((uint32_t)j < nvalid);
-                    const bool stop = elig & ((x <= vmask) | ((cell & vmask) == 0));
-                    found = stop ? true : found;
-                    res = stop ? (x <= vmask ? x : 0u) : res;
+                    const bool stop = (x <= vmask) | ((cell & vmask) == 0);
+                    res = stop ? x : res;
+                    resj = stop ? (uint32_t)j : resj;
                 }
-                const uint64_t nxt = base + 4 * nch;
-                pos = nxt >= cap ? 0 : nxt;
-                budget = budget > nch ? budget - nch : 0;
-                if (found) S.qtax[r] = res;
-                busy = !(found | (budget == 0));
+                // a re-read chunk repeats cells of an earlier one: its stops can only come after
+                // an identical earlier stop, so resj < nvalid is exact
+                const bool found = resj < nvalid;
+                if (CAP32) {
+                    uint32_t np = (uint32_t)pos + nvalid;
+                    pos = np >= (uint32_t)cap ? 0u : np;
+                } else {
+                    const uint64_t np = pos + nvalid;
+                    pos = np >= cap ? 0 : np;
+                }
+                budget--;
+                if (found | (budget == 0)) {
+                    tax_at<STD>(S, r) = (found && res <= vmask) ? res : 0u;
+                    busy = 0;
+                }
             } else {
                 const uint32_t cell = table[pos];
                 const uint32_t x = cell ^ ckey;
+                bool end = false;
+                uint32_t val = 0;
                 if ((cell & vmask) == 0) {
-                    busy = false;
+                    end = true;
                 } else if (x <= vmask) {
-                    S.qtax[r] = x;
-                    busy = false;
+                    val = x;
+                    end = true;
                 } else {
                     pos += step;
                     if (pos >= cap) pos -= cap;
-                    if (pos == first_pos) busy = false;
+                    if (pos == first_pos) end = true;
+                }
+                if (end) {
+                    tax_at<STD>(S, r) = val;
+                    busy = 0;
                 }
             }
         }
@@ -488,8 +544,8 @@ __device__ __forceinline__ void probe_queue(KArgsP ap, WaveLds &S, const int lan
 }
 
 // POST one tile: per-k-mer taxa from the probe results, hit groups, (taxon, count) list.
-template <bool PROF>
-__device__ __forceinline__ void post_tile(WaveLds &S, const int lane, const uint32_t ps,
+template <bool STD, bool PROF>
+__device__ __forceinline__ void post_tile(WaveLdsT<STD> &S, const int lane, const uint32_t ps,
                                           const uint32_t nqt, const uint32_t qbase,
                                           const uint32_t nruns, const int last_lane, FragState &st,
                                           const uint32_t li, uint32_t *__restrict__ kmer_taxa,
@@ -501,15 +557,15 @@ __device__ __forceinline__ void post_tile(WaveLds &S, const int lane, const uint
     uint64_t hit_any = 0;
     for (uint32_t r0 = 0; r0 < nruns; r0 += 64) {
         const uint32_t r = r0 + lane;
-        const uint64_t hm = __ballot(r < nruns && S.qtax[qbase + (r & (TL - 1))] != 0);
+        const uint64_t hm = __ballot(r < nruns && tax_at<STD>(S, qbase + (r & (TL - 1))) != 0);
         hit_any |= hm;
         st.hit_groups += __popcll(hm);
     }
     uint32_t t0 = 0, t1 = 0;
     const bool any_hit = (hit_any != 0) | (st.carry_tax != 0);
     if (any_hit || kmer_taxa) {
-        if (v0) t0 = r0p ? S.qtax[qbase + r0p - 1] : st.carry_tax;
-        if (v1) t1 = r1p ? S.qtax[qbase + r1p - 1] : st.carry_tax;
+        if (v0) t0 = r0p ? tax_at<STD>(S, qbase + r0p - 1) : st.carry_tax;
+        if (v1) t1 = r1p ? tax_at<STD>(S, qbase + r1p - 1) : st.carry_tax;
     }
     if (kmer_taxa) {
         if (qi0 < nqt) kmer_taxa[kt + qi0] = v0 ? t0 : TAXON_AMBIGUOUS;
@@ -550,7 +606,8 @@ __device__ __forceinline__ void post_tile(WaveLds &S, const int lane, const uint
 }
 
 // ResolveTree (A.5) on the wave: lane i owns list entry i.  Returns the call; sets clade_hits.
-__device__ __forceinline__ uint32_t resolve_tree(KArgsP ap, WaveLds &S, const int lane,
+template <bool STD>
+__device__ __forceinline__ uint32_t resolve_tree(KArgsP ap, WaveLdsT<STD> &S, const int lane,
                                                  const FragState &st, const uint32_t li,
                                                  const uint32_t total_kmers, uint32_t &clade_hits) {
     ap = launder(ap);
@@ -595,20 +652,20 @@ constexpr uint32_t PREF_LANES = 42;  // dwords a tile can need: (3 + 128 + 30 + 
 
 __device__ __forceinline__ uint32_t uni(uint32_t v) { return __builtin_amdgcn_readfirstlane(v); }
 
-template <bool LINEAR, bool STD, bool PROF>
-__global__ __launch_bounds__(WAVE * WAVES_PER_BLOCK) void k_classify(const KArgs args_by_kernarg_pointer) {
+template <bool LINEAR, bool STD, bool CAP32, bool PROF>
+__global__ __launch_bounds__(WAVE * WAVES_PER_BLOCK, STD ? 7 : 5) void k_classify(const KArgs args_by_kernarg_pointer) {
     KArgsP ap = (KArgsP)__builtin_amdgcn_kernarg_segment_ptr();
-    __shared__ WaveLds lds_all[WAVES_PER_BLOCK];
+    __shared__ WaveLdsT<STD> lds_all[WAVES_PER_BLOCK];
     const int lane = threadIdx.x & 63;
     const int wib = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    WaveLds &S = lds_all[wib];
+    WaveLdsT<STD> &S = lds_all[wib];
 
     // one-time LDS init: zero pads of the packed streams, sentinel tail of the candidate array
     if (lane < 24) {
         S.pk[lane] = 0;
         S.pa[lane] = 0;
     }
-    for (int i = lane; i < CAND_PAD; i += 64) S.cand[TL + i] = NH_FULL;
+    for (int i = lane; i < CandPad<STD>::value; i += 64) S.cand[TL + i] = NH_FULL;
     wave_sync();
 
     const uint32_t K = STD ? 35u : ap->db.k;
@@ -649,7 +706,7 @@ __global__ __launch_bounds__(WAVE * WAVES_PER_BLOCK) void k_classify(const KArgs
     // probe the queue, then finish every waiting tile (and its fragment if that was its last tile)
     auto flush = [&]() {
         if (nslot == 0) return;
-        probe_queue<LINEAR, STD, PROF>(ap, S, lane, lane_lt, qn, acc_lookups, prof, tprev);
+        probe_queue<LINEAR, STD, CAP32, PROF>(ap, S, lane, lane_lt, qn, acc_lookups, prof, tprev);
         KArgsP a2 = launder(ap);
         uint32_t *const kmer_taxa = a2->kmer_taxa;
         for (uint32_t s = 0; s < nslot; s++) {
@@ -665,7 +722,7 @@ __global__ __launch_bounds__(WAVE * WAVES_PER_BLOCK) void k_classify(const KArgs
             st.carry_min = 0;  // not used after the scan
             const uint64_t f = ((uint64_t)uni(d.f_hi) << 32) | uni(d.f_lo);
             const uint64_t kt = ((uint64_t)uni(d.kt_hi) << 32) | uni(d.kt_lo);
-            post_tile<PROF>(S, lane, s ? ps1 : ps0, uni(d.nqt), uni(d.qbase), uni(d.nruns),
+            post_tile<STD, PROF>(S, lane, s ? ps1 : ps0, uni(d.nqt), uni(d.qbase), uni(d.nruns),
                             (int)uni(d.last_lane), st, fi, kmer_taxa, kt, prof, tprev);
             if ((flags & 2u) && reset_per_mate) st.carry_tax = 0;  // mate 0 ended, mate 1 follows
             if (flags & 1u) {                                      // fragment ended
@@ -701,6 +758,11 @@ __global__ __launch_bounds__(WAVE * WAVES_PER_BLOCK) void k_classify(const KArgs
     // one counter, so late-starting (non-resident) workgroups of the grid find no work instead of
     // a static share.  The tile iterator below is a flat state machine (one scan site, one flush
     // site) over chunk -> fragment -> mate -> tile.
+    const uint32_t frag_chunk = ap->frag_chunk;  // <= 31: its offsets fit the 64 lanes of off_v
+    unsigned long long next_chunk = 0;        // lane 0: first fragment of the chunk claimed ahead
+    if (lane == 0) next_chunk = atomicAdd(ap->work, (unsigned long long)frag_chunk);
+    uint64_t off_v = 0;                       // lane i: sequence offset i of the current chunk
+    uint64_t chunk_first = 0;
     uint64_t f = 0, cend = 0;                 // current fragment, end of the current chunk
     uint64_t o0 = 0, o1 = 0, o2 = 0;          // sequence bounds of the current fragment
     uint32_t n0 = 0, n1 = 0, nk0 = 0, nk1 = 0;
@@ -726,18 +788,21 @@ __global__ __launch_bounds__(WAVE * WAVES_PER_BLOCK) void k_classify(const KArgs
             }
             f++;
             if (f >= cend) {
-                unsigned long long cbeg = 0;
-                const uint32_t frag_chunk = ap->frag_chunk;
-                if (lane == 0) cbeg = atomicAdd(ap->work, (unsigned long long)frag_chunk);
-                cbeg = readlane64(cbeg, 0);
+                // chunk ids are claimed one chunk ahead, so the atomic's latency is off the path
+                const unsigned long long cbeg = readlane64(next_chunk, 0);
                 if (cbeg >= n_frag) break;
+                if (lane == 0) next_chunk = atomicAdd(ap->work, (unsigned long long)frag_chunk);
                 f = cbeg;
                 cend = cbeg + frag_chunk < n_frag ? cbeg + frag_chunk : n_frag;
+                // all sequence offsets of the chunk with ONE coalesced load (lane i = offset i)
+                const uint64_t nof = (cend - cbeg) * (uint64_t)mates + 1;
+                off_v = seq_off[cbeg * (uint64_t)mates + ((uint64_t)lane < nof ? (uint64_t)lane : nof - 1)];
+                chunk_first = cbeg;
             }
-            const uint64_t s0 = f * (uint64_t)mates;
-            o0 = seq_off[s0];
-            o1 = seq_off[s0 + 1];
-            o2 = mates == 2 ? seq_off[s0 + 2] : o1;
+            const int oi = (int)(f - chunk_first) * mates;
+            o0 = readlane64(off_v, oi);
+            o1 = readlane64(off_v, oi + 1);
+            o2 = mates == 2 ? readlane64(off_v, oi + 2) : o1;
             if (((o1 - o0) | (o2 - o1)) >> 31) bad_input = true;  // sequences of 2 Gbases and more
             n0 = (uint32_t)(o1 - o0);
             n1 = (uint32_t)(o2 - o1);
@@ -888,9 +953,9 @@ static bool is_std(const DevDB &db) {
     return db.k == 35 && db.l == 31 && db.revcom_version != 0 && db.min_hash == 0;
 }
 
-template <bool LINEAR, bool STD, bool PROF = false>
+template <bool LINEAR, bool STD, bool CAP32, bool PROF = false>
 static void launch_variant(const KArgs &ka, dim3 g, dim3 b, hipStream_t stream) {
-    hipLaunchKernelGGL((k_classify<LINEAR, STD, PROF>), g, b, 0, stream, ka);
+    hipLaunchKernelGGL((k_classify<LINEAR, STD, CAP32, PROF>), g, b, 0, stream, ka);
 }
 
 hipError_t launch_classify(const DevDB &db, const void *d_bases, const void *d_seq_off,
@@ -920,20 +985,23 @@ hipError_t launch_classify(const DevDB &db, const void *d_bases, const void *d_s
     ka.counters = (unsigned long long *)d_counters;
     ka.error_flag = d_error;
     ka.work = d_work;
-    if (db.linear_probing && std_geom && getenv("NH_PHASE_PROF"))
-        launch_variant<true, true, true>(ka, g, b, stream);  // d_counters holds CNT_N + 8 words
+    const bool cap32 = db.capacity < 0xFFFFFF00ull;
+    if (db.linear_probing && std_geom && cap32 && getenv("NH_PHASE_PROF"))
+        launch_variant<true, true, true, true>(ka, g, b, stream);  // d_counters: CNT_N + 8 words
+    else if (db.linear_probing && std_geom && cap32)
+        launch_variant<true, true, true>(ka, g, b, stream);
     else if (db.linear_probing && std_geom)
-        launch_variant<true, true>(ka, g, b, stream);
+        launch_variant<true, true, false>(ka, g, b, stream);
     else if (db.linear_probing)
-        launch_variant<true, false>(ka, g, b, stream);
+        launch_variant<true, false, false>(ka, g, b, stream);
     else
-        launch_variant<false, false>(ka, g, b, stream);
+        launch_variant<false, false, false>(ka, g, b, stream);
     return hipGetLastError();
 }
 
 int classify_blocks_per_cu() {
     int nb = 0;
-    hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_classify<true, true, false>,
+    hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_classify<true, true, true, false>,
                                                                 WAVE * WAVES_PER_BLOCK, 0);
     if (e != hipSuccess || nb < 1) nb = 4;
     return nb > 8 ? 8 : nb;
