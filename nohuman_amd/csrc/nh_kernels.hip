@@ -41,10 +41,10 @@ namespace nh {
 template <bool STD> struct CandPad { static constexpr int value = STD ? 6 : 66; };
 
 constexpr int NSLOT = 2;  // tiles scanned before one shared probe phase
-constexpr int QCAP = NSLOT * TL;
+constexpr int QCAP = 192;  // queue entries per group: a second tile joins only if it is sure to fit
 constexpr uint32_t QTAX_SKIP = 0xFFFFFFFFu;  // queue entry dropped by the min-hash filter
 
-struct SlotLds {  // a scanned tile waiting for its probe results (written by lane 0)
+struct alignas(16) SlotLds {  // a scanned tile waiting for its probe results (written by lane 0)
     uint32_t f_lo, f_hi;    // fragment
     uint32_t kt_lo, kt_hi;  // index in kmer_taxa of the tile's first k-mer
     uint32_t nqt, qbase, nruns;
@@ -53,25 +53,27 @@ struct SlotLds {  // a scanned tile waiting for its probe results (written by la
     uint32_t flags;         // 1 = last tile of its fragment, 2 = last tile of mate 0, mate 1 follows
     uint32_t nk0, total_kmers;
 };
-struct FragLds {  // accumulation state of a fragment between its tiles
+struct alignas(16) FragLds {  // accumulation state of a fragment between its tiles
     uint32_t nlist, hit_groups, carry_tax, overflow;
 };
 
 // the generic kernel keeps the probe results apart from the queue entries; STD aliases them
-template <bool STD> struct QTax { uint32_t v[QCAP]; };
+template <bool STD> struct QTax { uint32_t v[2][QCAP]; };
 template <> struct QTax<true> {};
 
 template <bool STD>
 struct WaveLdsT {
-    SlotLds slot[NSLOT];
-    FragLds fs[2];
+    SlotLds slot[2][NSLOT];  // [parity of the group][tile]
+    uint16_t ps[2][NSLOT][WAVE];  // per-lane packed k-mer state of the tiles in flight
     uint32_t pk[24];  // 2-bit packed bases: base i' of the tile frame at bit 2*(255-i'); 64 B + zero pad
     uint32_t pa[24];  // same layout, value 1 where the base is ambiguous
     uint64_t cand[TL + CandPad<STD>::value];
-    uint64_t q[QCAP];     // queue: run-start minimizers, hashed in place (see probe_queue)
+    uint64_t q[2][QCAP];  // [parity] queue: run-start minimizers, hashed in place (see probe_queue)
     QTax<STD> qtax;       // taxon found for each queued run (generic kernel only, see tax_at)
-    uint32_t list_tax[2][LIST_CAP];  // (taxon, count) lists of the (at most two) fragments in flight
-    uint32_t list_cnt[2][LIST_CAP];
+    // (taxon, count) list of the fragment being post-processed: tiles are post-processed strictly
+    // in input order, so one list (and one FragState, kept in registers) serves all fragments
+    uint32_t list_tax[LIST_CAP];
+    uint32_t list_cnt[LIST_CAP];
 };
 
 __device__ __forceinline__ void wave_sync() {
@@ -108,13 +110,21 @@ __device__ __forceinline__ uint64_t revcomp_word(uint64_t x) {
 
 __device__ __forceinline__ uint64_t umin64(uint64_t a, uint64_t b) { return a < b ? a : b; }
 
+// number of set bits of a wave mask below this lane
+__device__ __forceinline__ uint32_t below(uint64_t mask) {
+    return __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
+}
+
 // Kernel arguments are read on demand from the kernarg segment (constant address space, scalar
 // loads).  Each phase launders the pointer first, which stops the compiler from hoisting every
 // argument load to the kernel entry and pinning ~50 SGPRs for the whole kernel.
 typedef const __attribute__((address_space(4))) KArgs *KArgsP;
 __device__ __forceinline__ KArgsP launder(KArgsP p) {
-    asm volatile("" : "+s"(p));
-    return p;
+    const uint64_t v = (uint64_t)p;
+    uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)v);
+    uint32_t hi = __builtin_amdgcn_readfirstlane((uint32_t)(v >> 32));
+    asm volatile("" : "+s"(lo), "+s"(hi));
+    return (KArgsP)(((uint64_t)hi << 32) | lo);
 }
 
 __device__ __forceinline__ uint64_t readlane64(uint64_t v, int src) {
@@ -210,15 +220,18 @@ struct FragState {
 
 // SCAN one tile: l-mers [q0, q0+nlt) / k-mers [q0, q0+nqt) of a sequence whose tile frame starts
 // `sh` bytes into the dword stream `w` (4 bases per lane).  Appends the run-start minimizers to
-// S.q[qbase ...], returns their number, and leaves in `ps` the lane's packed per-k-mer state
-// (bit0/1 = k-mer 2t / 2t+1 is valid and unambiguous, bits 8-15 / 16-23 = 1 + index of the run
-// that covers it, 0 = continuation of the run that entered the tile).
+// S.q[par][qbase ...], returns their number, and leaves in `ps` the lane's packed per-k-mer state
+// (bit0/1 = k-mer 2t / 2t+1 is valid and unambiguous, bit 2 = k-mer 2t+1 starts a run, bits 3-10 = 1 + index of the run
+// that covers k-mer 2t, 0 = continuation of the run that entered the tile).
 template <bool STD, bool PROF>
 __device__ __forceinline__ uint32_t scan_tile(KArgsP ap, WaveLdsT<STD> &S, const int lane,
-                                              const uint64_t lane_lt, const uint32_t w,
+                                              const uint32_t w,
                                               const uint32_t sh, const uint32_t nlt,
-                                              const uint32_t nqt, const uint32_t qbase,
-                                              uint64_t &carry_min, uint32_t &ps, int &last_lane,
+                                              const uint32_t nqt, const uint32_t par,
+                                              const uint32_t qbase, uint64_t &carry_min,
+                                              uint32_t &ps, int &last_lane,
+                                              const uint32_t *pf_ptr, const bool pf_on,
+                                              uint32_t &w_pref,
                                               uint64_t (&prof)[8], uint64_t &tprev) {
     ap = launder(ap);
     const uint32_t L = STD ? 31u : ap->db.l;
@@ -238,6 +251,9 @@ __device__ __forceinline__ uint32_t scan_tile(KArgsP ap, WaveLdsT<STD> &S, const
         reinterpret_cast<uint8_t *>(S.pa)[63 - lane] = (uint8_t)bad;
     }
     wave_sync();
+    // `w` has been consumed: start the load of the next tile's bases now, so that no wait for
+    // `w` can be widened into a wait for the prefetch (vmcnt retires loads in issue order)
+    if (pf_on) w_pref = *pf_ptr;
     NH_STAMP(1);
 
     // ---- 2. two l-mers per lane -> candidates --------------------------------------------------
@@ -334,13 +350,13 @@ __device__ __forceinline__ uint32_t scan_tile(KArgsP ap, WaveLdsT<STD> &S, const
 
     // ---- 5. append run starts to the LDS queue; remember the last minimizer --------------------
     const uint64_t b0 = __ballot(new0), b1 = __ballot(new1);
-    const uint32_t ex = __popcll(b0 & lane_lt) + __popcll(b1 & lane_lt);
+    const uint32_t ex = below(b0) + below(b1);
     const uint32_t nruns = __popcll(b0) + __popcll(b1);
-    if (new0) S.q[qbase + ex] = mz0;
-    if (new1) S.q[qbase + ex + (new0 ? 1u : 0u)] = mz1;
+    if (new0) S.q[par][qbase + ex] = mz0;
+    if (new1) S.q[par][qbase + ex + (new0 ? 1u : 0u)] = mz1;
     const uint32_t r0p = ex + (new0 ? 1u : 0u);  // 1 + run index of k-mer 2t (0 = carried run)
     const uint32_t r1p = r0p + (new1 ? 1u : 0u);
-    ps = (v0 ? 1u : 0u) | (v1 ? 2u : 0u) | (r0p << 8) | (r1p << 16);
+    ps = (v0 ? 1u : 0u) | (v1 ? 2u : 0u) | (new1 ? 4u : 0u) | (r0p << 3);
     {
         const uint64_t m1 = __ballot(v1), m0 = __ballot(v0);
         last_lane = -1;
@@ -364,21 +380,37 @@ __device__ __forceinline__ uint32_t scan_tile(KArgsP ap, WaveLdsT<STD> &S, const
 // entries dropped by the min-hash filter there); the STD kernel reuses the low dword of the queue
 // entry itself, which the owning lane has copied to registers before it writes the result.
 template <bool STD>
-__device__ __forceinline__ uint32_t &tax_at(WaveLdsT<STD> &S, uint32_t r) {
+__device__ __forceinline__ uint32_t &tax_at(WaveLdsT<STD> &S, uint32_t par, uint32_t r) {
     if constexpr (STD)
-        return reinterpret_cast<uint32_t *>(&S.q[r])[0];
+        return reinterpret_cast<uint32_t *>(&S.q[par][r])[0];
     else
-        return S.qtax.v[r];
+        return S.qtax.v[par][r];
 }
 
-// HASH + PROBE the queue S.q[0, qn): CompactHashTable::Get (A.4) for every entry, result in
-// tax_at(r).  Queue entry after the hash pass (linear probing):
+// The lookup a lane currently owns.  It persists across probe_queue calls: a lane may carry an
+// unresolved lookup of group g into the probe phase of group g+1 (software pipelining: tiles of
+// group g are only post-processed after that phase), so no wave ever drains a probe tail alone.
+struct LaneLookup {
+    uint32_t busy;       // owns an unresolved lookup
+    uint32_t r;          // queue index | parity << 8
+    uint64_t pos;        // next cell to examine (32 bits used when CAP32)
+    uint64_t first_pos;  // double hashing: home cell
+    uint64_t step;       // double hashing: stride
+    uint32_t ckey;       // compacted key << value_bits
+    uint32_t budget;     // rounds left before the whole table was seen
+};
+
+// HASH the queue S.q[par][0, qn) and PROBE it: CompactHashTable::Get (A.4) for every entry, result
+// in tax_at(par, r).  Returns when every entry has been handed to a lane AND every lookup of the
+// other parity (the previous group) is resolved; lookups of this group may still be in flight.
+// Queue entry after the hash pass (linear probing):
 //   CAP32 (capacity < 2^32 - 256):  low dword = home cell, high dword = compacted key << value_bits
 //   otherwise:                      home cell << key_bits | compacted key   (<= 63 bits, checked at open)
 // Double hashing keeps the hash code itself.
 template <bool LINEAR, bool STD, bool CAP32, bool PROF>
 __device__ __forceinline__ void probe_queue(KArgsP ap, WaveLdsT<STD> &S, const int lane,
-                                            const uint64_t lane_lt, const uint32_t qn,
+                                            const uint32_t par,
+                                            const uint32_t qn, LaneLookup &lk,
                                             uint32_t &acc_lookups, uint64_t (&prof)[8],
                                             uint64_t &tprev) {
     ap = launder(ap);
@@ -395,7 +427,7 @@ __device__ __forceinline__ void probe_queue(KArgsP ap, WaveLdsT<STD> &S, const i
     for (uint32_t r0 = 0; r0 < qn; r0 += 64) {
         const uint32_t r = r0 + lane;
         const bool act = r < qn;
-        const uint64_t hc = fmix64(S.q[r & (QCAP - 1)]);
+        const uint64_t hc = fmix64(S.q[par][act ? r : 0u]);
         const bool look = act & !(MIN_HASH != 0 && hc < MIN_HASH);
         uint64_t e = hc;
         if (LINEAR) {
@@ -405,8 +437,8 @@ __device__ __forceinline__ void probe_queue(KArgsP ap, WaveLdsT<STD> &S, const i
                       : ((home << kbits) | compacted);
         }
         if (act) {
-            S.q[r] = e;
-            if constexpr (!STD) S.qtax.v[r] = look ? 0u : QTAX_SKIP;
+            S.q[par][r] = e;
+            if constexpr (!STD) S.qtax.v[par][r] = look ? 0u : QTAX_SKIP;
         }
         acc_lookups += __popcll(__ballot(look));
     }
@@ -414,28 +446,23 @@ __device__ __forceinline__ void probe_queue(KArgsP ap, WaveLdsT<STD> &S, const i
     NH_STAMP(4);
 
     // ---- 6b. probe with lane refill ---------------------------------------------------------------
-    uint32_t qhead = 0;      // next queue entry to hand out (uniform)
-    uint32_t busy = 0;       // this lane owns an unresolved lookup
-    uint32_t r = 0;          // its queue index
-    uint64_t pos = 0;        // next cell to examine (32 bits used when CAP32)
-    uint64_t first_pos = 0;  // double hashing: home cell
-    uint64_t step = 0;       // double hashing: stride
-    uint32_t ckey = 0;       // compacted key << value_bits
-    uint32_t budget = 0;     // rounds left before the whole table was seen
+    uint32_t qhead = 0;  // next queue entry to hand out (uniform)
+    uint32_t busy = lk.busy, r = lk.r, ckey = lk.ckey, budget = lk.budget;
+    uint64_t pos = lk.pos, first_pos = lk.first_pos, step = lk.step;
     for (;;) {
         if (qhead < qn) {
             const uint64_t idle_mask = __ballot(busy == 0);
             if (idle_mask) {
-                const uint32_t my = qhead + __popcll(idle_mask & lane_lt);
+                const uint32_t my = qhead + below(idle_mask);
                 if (busy == 0 && my < qn) {
-                    const uint64_t e = S.q[my];
+                    const uint64_t e = S.q[par][my];
                     bool skip = false;
                     if constexpr (!STD) {
-                        skip = S.qtax.v[my] == QTAX_SKIP;
-                        if (skip) S.qtax.v[my] = 0;
+                        skip = S.qtax.v[par][my] == QTAX_SKIP;
+                        if (skip) S.qtax.v[par][my] = 0;
                     }
                     if (!skip) {
-                        r = my;
+                        r = my | (par << 8);
                         budget = max_rounds;
                         if (LINEAR) {
                             if (CAP32) {
@@ -458,10 +485,8 @@ __device__ __forceinline__ void probe_queue(KArgsP ap, WaveLdsT<STD> &S, const i
                 qhead = qhead + taken < qn ? qhead + taken : qn;
             }
         }
-        if (__ballot(busy != 0) == 0) {
-            if (qhead >= qn) break;
-            continue;
-        }
+        // done when the queue is handed out and no lane still works for the previous group
+        if (qhead >= qn && __ballot(busy != 0 && (r >> 8) != par) == 0) break;
         if (busy) {
             if (LINEAR) {
                 // One round: the 4*PC cells from `pos` on (unaligned 16-byte loads), of which only
@@ -514,7 +539,7 @@ __device__ __forceinline__ void probe_queue(KArgsP ap, WaveLdsT<STD> &S, const i
                 }
                 budget--;
                 if (found | (budget == 0)) {
-                    tax_at<STD>(S, r) = (found && res <= vmask) ? res : 0u;
+                    tax_at<STD>(S, r >> 8, r & 0xFFu) = (found && res <= vmask) ? res : 0u;
                     busy = 0;
                 }
             } else {
@@ -533,12 +558,19 @@ __device__ __forceinline__ void probe_queue(KArgsP ap, WaveLdsT<STD> &S, const i
                     if (pos == first_pos) end = true;
                 }
                 if (end) {
-                    tax_at<STD>(S, r) = val;
+                    tax_at<STD>(S, r >> 8, r & 0xFFu) = val;
                     busy = 0;
                 }
             }
         }
     }
+    lk.busy = busy;
+    lk.r = r;
+    lk.ckey = ckey;
+    lk.budget = budget;
+    lk.pos = pos;
+    lk.first_pos = first_pos;
+    lk.step = step;
     wave_sync();
     NH_STAMP(5);
 }
@@ -546,26 +578,27 @@ __device__ __forceinline__ void probe_queue(KArgsP ap, WaveLdsT<STD> &S, const i
 // POST one tile: per-k-mer taxa from the probe results, hit groups, (taxon, count) list.
 template <bool STD, bool PROF>
 __device__ __forceinline__ void post_tile(WaveLdsT<STD> &S, const int lane, const uint32_t ps,
-                                          const uint32_t nqt, const uint32_t qbase,
-                                          const uint32_t nruns, const int last_lane, FragState &st,
+                                          const uint32_t nqt, const uint32_t par,
+                                          const uint32_t qbase, const uint32_t nruns,
+                                          const int last_lane, FragState &st,
                                           const uint32_t li, uint32_t *__restrict__ kmer_taxa,
                                           const uint64_t kt, uint64_t (&prof)[8], uint64_t &tprev) {
     const uint32_t qi0 = 2u * lane, qi1 = 2u * lane + 1;
     const bool v0 = ps & 1u, v1 = (ps >> 1) & 1u;
-    const uint32_t r0p = (ps >> 8) & 0xFFu, r1p = (ps >> 16) & 0xFFu;
+    const uint32_t r0p = (ps >> 3) & 0xFFu, r1p = r0p + ((ps >> 2) & 1u);
     // hit groups = runs of this tile that found a taxon
     uint64_t hit_any = 0;
     for (uint32_t r0 = 0; r0 < nruns; r0 += 64) {
         const uint32_t r = r0 + lane;
-        const uint64_t hm = __ballot(r < nruns && tax_at<STD>(S, qbase + (r & (TL - 1))) != 0);
+        const uint64_t hm = __ballot(r < nruns && tax_at<STD>(S, par, qbase + (r & (TL - 1))) != 0);
         hit_any |= hm;
         st.hit_groups += __popcll(hm);
     }
     uint32_t t0 = 0, t1 = 0;
     const bool any_hit = (hit_any != 0) | (st.carry_tax != 0);
     if (any_hit || kmer_taxa) {
-        if (v0) t0 = r0p ? tax_at<STD>(S, qbase + r0p - 1) : st.carry_tax;
-        if (v1) t1 = r1p ? tax_at<STD>(S, qbase + r1p - 1) : st.carry_tax;
+        if (v0) t0 = r0p ? tax_at<STD>(S, par, qbase + r0p - 1) : st.carry_tax;
+        if (v1) t1 = r1p ? tax_at<STD>(S, par, qbase + r1p - 1) : st.carry_tax;
     }
     if (kmer_taxa) {
         if (qi0 < nqt) kmer_taxa[kt + qi0] = v0 ? t0 : TAXON_AMBIGUOUS;
@@ -586,14 +619,14 @@ __device__ __forceinline__ void post_tile(WaveLdsT<STD> &S, const int lane, cons
             const uint32_t cnt = __popcll(__ballot(t0 == T)) + __popcll(__ballot(t1 == T));
             if (t0 == T) t0 = 0;
             if (t1 == T) t1 = 0;
-            const bool match = (uint32_t)lane < st.nlist && S.list_tax[li][lane] == T;
+            const bool match = (uint32_t)lane < st.nlist && S.list_tax[lane] == T;
             const uint64_t mb = __ballot(match);
             if (mb) {
-                if (match) S.list_cnt[li][lane] += cnt;
+                if (match) S.list_cnt[lane] += cnt;
             } else if (st.nlist < (uint32_t)LIST_CAP) {
                 if (lane == 0) {
-                    S.list_tax[li][st.nlist] = T;
-                    S.list_cnt[li][st.nlist] = cnt;
+                    S.list_tax[st.nlist] = T;
+                    S.list_cnt[st.nlist] = cnt;
                 }
                 st.nlist++;
             } else {
@@ -616,15 +649,15 @@ __device__ __forceinline__ uint32_t resolve_tree(KArgsP ap, WaveLdsT<STD> &S, co
     const double confidence = ap->confidence;
     const uint32_t min_hit_groups = ap->db.min_hit_groups;
     const bool own = (uint32_t)lane < nlist;
-    const uint32_t my_t = own ? S.list_tax[li][lane] : 0;
-    const uint32_t my_c = own ? S.list_cnt[li][lane] : 0;
+    const uint32_t my_t = own ? S.list_tax[lane] : 0;
+    const uint32_t my_c = own ? S.list_cnt[lane] : 0;
     uint32_t call = 0;
     if (nlist == 1) {
-        call = S.list_tax[li][0];
+        call = S.list_tax[0];
     } else {
         uint32_t score = 0;
         for (uint32_t j = 0; j < nlist; j++) {
-            const uint32_t tj = S.list_tax[li][j], cj = S.list_cnt[li][j];
+            const uint32_t tj = S.list_tax[j], cj = S.list_cnt[j];
             if (own && is_a_ancestor_of_b(parent, tj, my_t)) score += cj;
         }
         const uint32_t top = wave_max(score);
@@ -632,7 +665,7 @@ __device__ __forceinline__ uint32_t resolve_tree(KArgsP ap, WaveLdsT<STD> &S, co
         while (best_mask) {
             const int j = __builtin_ctzll(best_mask);
             best_mask &= best_mask - 1;
-            call = lowest_common_ancestor(parent, call, S.list_tax[li][j]);
+            call = lowest_common_ancestor(parent, call, S.list_tax[j]);
         }
     }
     const uint32_t required = (uint32_t)ceil(confidence * (double)total_kmers);
@@ -653,7 +686,7 @@ constexpr uint32_t PREF_LANES = 42;  // dwords a tile can need: (3 + 128 + 30 + 
 __device__ __forceinline__ uint32_t uni(uint32_t v) { return __builtin_amdgcn_readfirstlane(v); }
 
 template <bool LINEAR, bool STD, bool CAP32, bool PROF>
-__global__ __launch_bounds__(WAVE * WAVES_PER_BLOCK, STD ? 7 : 5) void k_classify(const KArgs args_by_kernarg_pointer) {
+__global__ __launch_bounds__(WAVE * WAVES_PER_BLOCK, STD ? 6 : 4) void k_classify(const KArgs args_by_kernarg_pointer) {
     KArgsP ap = (KArgsP)__builtin_amdgcn_kernarg_segment_ptr();
     __shared__ WaveLdsT<STD> lds_all[WAVES_PER_BLOCK];
     const int lane = threadIdx.x & 63;
@@ -676,16 +709,15 @@ __global__ __launch_bounds__(WAVE * WAVES_PER_BLOCK, STD ? 7 : 5) void k_classif
     const uint64_t *const seq_off = ap->seq_off;
     const uint8_t *const bases = ap->bases;
     const bool reset_per_mate = ap->db.reset_per_mate != 0;
-    const uint64_t lane_lt = (lane == 0) ? 0ull : (NH_FULL >> (64 - lane));
     // dword index of the last dword the caller guarantees readable (8 bytes of slack, see ABI)
     const uint64_t last_dw = (seq_off[n_frag * (uint64_t)mates] + 4) >> 2;
     const uint32_t pl = (uint32_t)lane < PREF_LANES ? (uint32_t)lane : PREF_LANES - 1;
 
     // the dword stream of the tile that starts at byte g0: 4 bases per lane, coalesced
-    auto load_tile = [&](uint64_t g0) -> uint32_t {
+    auto tile_ptr = [&](uint64_t g0) -> const uint32_t * {
         uint64_t dw = (g0 >> 2) + pl;
         dw = dw < last_dw ? dw : last_dw;
-        return reinterpret_cast<const uint32_t *>(bases)[dw];
+        return reinterpret_cast<const uint32_t *>(bases) + dw;
     };
 
     uint32_t acc_frag = 0, acc_class = 0, acc_lookups = 0;
@@ -698,35 +730,51 @@ __global__ __launch_bounds__(WAVE * WAVES_PER_BLOCK, STD ? 7 : 5) void k_classif
     uint64_t pref_g0 = ~0ull;
     uint32_t w_pref = 0;
 
-    uint32_t nslot = 0;      // scanned tiles waiting for the probe phase (descriptors in S.slot)
-    uint32_t qn = 0;         // queue entries they hold
-    uint32_t fcount = 0;     // fragments with k-mers started by this wave
-    uint32_t ps0 = 0, ps1 = 0;  // per-lane packed k-mer state of the waiting tiles
+    // Two groups of tiles are in flight: the one being scanned / probed (parity `par`) and the
+    // previous one, which is post-processed only after the probe phase of its successor.
+    uint32_t par = 0;
+    uint32_t nslot_new = 0;     // tiles scanned into the current group (descriptors in S.slot[par])
+    uint32_t nslot_old = 0;     // tiles of the previous group still to be post-processed
+    uint32_t qn = 0;            // queue entries of the current group
+    LaneLookup lk;
+    lk.busy = 0;
+    lk.r = 0;
+    lk.pos = lk.first_pos = lk.step = 0;
+    lk.ckey = 0;
+    lk.budget = 0;
 
-    // probe the queue, then finish every waiting tile (and its fragment if that was its last tile)
-    auto flush = [&]() {
-        if (nslot == 0) return;
-        probe_queue<LINEAR, STD, CAP32, PROF>(ap, S, lane, lane_lt, qn, acc_lookups, prof, tprev);
+    FragState st;  // accumulation state of the fragment being post-processed
+    st.nlist = 0;
+    st.hit_groups = 0;
+    st.carry_min = 0;  // (the scan keeps its own last-minimizer)
+    st.carry_tax = 0;
+    st.overflow = false;
+    // finish the tiles of group `pp` (and each fragment whose last tile is among them)
+    auto post_group = [&](const uint32_t pp, const uint32_t nslot) {
         KArgsP a2 = launder(ap);
         uint32_t *const kmer_taxa = a2->kmer_taxa;
         for (uint32_t s = 0; s < nslot; s++) {
-            const SlotLds d = S.slot[s];
-            const uint32_t fi = uni(d.fi);
-            const uint32_t flags = uni(d.flags);
-            const FragLds fl = S.fs[fi];
-            FragState st;
-            st.nlist = uni(fl.nlist);
-            st.hit_groups = uni(fl.hit_groups);
-            st.carry_tax = uni(fl.carry_tax);
-            st.overflow = uni(fl.overflow) != 0;
-            st.carry_min = 0;  // not used after the scan
-            const uint64_t f = ((uint64_t)uni(d.f_hi) << 32) | uni(d.f_lo);
-            const uint64_t kt = ((uint64_t)uni(d.kt_hi) << 32) | uni(d.kt_lo);
-            post_tile<STD, PROF>(S, lane, s ? ps1 : ps0, uni(d.nqt), uni(d.qbase), uni(d.nruns),
-                            (int)uni(d.last_lane), st, fi, kmer_taxa, kt, prof, tprev);
+            // descriptor: three 16-byte LDS reads (same address in every lane), then scalars
+            const uint4 *dp = reinterpret_cast<const uint4 *>(&S.slot[pp][s]);
+            const uint4 d0 = dp[0], d1 = dp[1], d2 = dp[2];
+            const uint64_t f = ((uint64_t)uni(d0.y) << 32) | uni(d0.x);   // f_lo, f_hi
+            const uint64_t kt = ((uint64_t)uni(d0.w) << 32) | uni(d0.z);  // kt_lo, kt_hi
+            const uint32_t d_nqt = uni(d1.x), d_qbase = uni(d1.y), d_nruns = uni(d1.z);
+            const uint32_t fi = 0;
+            const uint32_t d_last = uni(d2.x), flags = uni(d2.y);
+            const uint32_t d_nk0 = uni(d2.z), d_total = uni(d2.w);
+            if (flags & 4u) {  // first tile of its fragment: fresh accumulation state
+                st.nlist = 0;
+                st.hit_groups = 0;
+                st.carry_tax = 0;
+                st.overflow = false;
+            }
+            const uint32_t ps = S.ps[pp][s][lane];
+            post_tile<STD, PROF>(S, lane, ps, d_nqt, pp, d_qbase, d_nruns, (int)d_last, st, fi,
+                                 kmer_taxa, kt, prof, tprev);
             if ((flags & 2u) && reset_per_mate) st.carry_tax = 0;  // mate 0 ended, mate 1 follows
             if (flags & 1u) {                                      // fragment ended
-                const uint32_t total_kmers = uni(d.total_kmers);
+                const uint32_t total_kmers = d_total;
                 uint32_t call = 0, clade_hits = 0;
                 if (st.nlist > 0) call = resolve_tree(ap, S, lane, st, fi, total_kmers, clade_hits);
                 if (lane == 0) {
@@ -737,20 +785,13 @@ __global__ __launch_bounds__(WAVE * WAVES_PER_BLOCK, STD ? 7 : 5) void k_classif
                     rec.w = st.hit_groups;
                     *reinterpret_cast<uint4 *>(&a2->out[f]) = rec;
                     if (kmer_taxa && mates == 2)
-                        kmer_taxa[a2->kmer_taxa_off[f] + uni(d.nk0)] = TAXON_MATE_BORDER;
+                        kmer_taxa[a2->kmer_taxa_off[f] + d_nk0] = TAXON_MATE_BORDER;
                     if (st.overflow) atomicMax(a2->error_flag, 1);
                 }
                 acc_class += call ? 1 : 0;
-            } else if (lane == 0) {
-                S.fs[fi].nlist = st.nlist;
-                S.fs[fi].hit_groups = st.hit_groups;
-                S.fs[fi].carry_tax = st.carry_tax;
-                S.fs[fi].overflow = st.overflow ? 1u : 0u;
             }
             wave_sync();
         }
-        nslot = 0;
-        qn = 0;
         NH_STAMP(7);
     };
 
@@ -767,7 +808,8 @@ __global__ __launch_bounds__(WAVE * WAVES_PER_BLOCK, STD ? 7 : 5) void k_classif
     uint64_t o0 = 0, o1 = 0, o2 = 0;          // sequence bounds of the current fragment
     uint32_t n0 = 0, n1 = 0, nk0 = 0, nk1 = 0;
     uint64_t kt_base = 0;
-    uint32_t m = 0, q0 = 0, fi = 0;
+    uint32_t m = 0, q0 = 0;
+    bool frag_first = false;                  // the next tile is the first of its fragment
     uint64_t carry_min = NH_FULL;             // kraken2 last_minimizer of the current fragment
     bool frag_valid = false;
     for (;;) {
@@ -820,19 +862,8 @@ __global__ __launch_bounds__(WAVE * WAVES_PER_BLOCK, STD ? 7 : 5) void k_classif
                 }
                 continue;
             }
-            // A fragment takes the state slot that the fragment before the previous one used:
-            // with NSLOT = 2 that fragment has no tile in flight any more.
-            fi = fcount & 1u;
-            fcount++;
             carry_min = NH_FULL;
-            if (lane == 0) {
-                FragLds z;
-                z.nlist = 0;
-                z.hit_groups = 0;
-                z.carry_tax = 0;
-                z.overflow = 0;
-                S.fs[fi] = z;
-            }
+            frag_first = true;
             frag_valid = true;
             m = 0;
             q0 = 0;
@@ -842,7 +873,8 @@ __global__ __launch_bounds__(WAVE * WAVES_PER_BLOCK, STD ? 7 : 5) void k_classif
             const uint32_t nk = m ? nk1 : nk0;
             const uint64_t g0 = (m ? o1 : o0) + q0;
             NH_STAMP(0);
-            const uint32_t w = (pref_g0 == g0) ? w_pref : load_tile(g0);
+            uint32_t w = w_pref;
+            if (pref_g0 != g0) w = *tile_ptr(g0);
             // guess the tile after this one and start its load now: next tile of the sequence,
             // else the mate, else the next fragment of the chunk (it starts where this one ends)
             uint64_t ng0;
@@ -852,7 +884,8 @@ __global__ __launch_bounds__(WAVE * WAVES_PER_BLOCK, STD ? 7 : 5) void k_classif
                 ng0 = o1;
             else
                 ng0 = f + 1 < cend ? o2 : ~0ull;
-            if (ng0 != ~0ull) w_pref = load_tile(ng0);
+            const bool pf_on = ng0 != ~0ull;
+            const uint32_t *pf_ptr = tile_ptr(pf_on ? ng0 : g0);
             pref_g0 = ng0;
 
             const uint32_t nl_left = (n - L + 1) - q0;
@@ -865,35 +898,46 @@ __global__ __launch_bounds__(WAVE * WAVES_PER_BLOCK, STD ? 7 : 5) void k_classif
 
             uint32_t ps;
             int last_lane;
-            const uint32_t nruns = scan_tile<STD, PROF>(ap, S, lane, lane_lt, w, (uint32_t)g0 & 3u, nlt,
-                                                        nqt, qn, carry_min, ps, last_lane, prof, tprev);
+            const uint32_t nruns =
+                scan_tile<STD, PROF>(ap, S, lane, w, (uint32_t)g0 & 3u, nlt, nqt, par, qn,
+                                     carry_min, ps, last_lane, pf_ptr, pf_on, w_pref, prof, tprev);
             if (lane == 0) {
-                SlotLds d;
                 const uint64_t kt = kt_base + (m ? (uint64_t)nk0 + 1 : 0) + q0;
-                d.f_lo = (uint32_t)f;
-                d.f_hi = (uint32_t)(f >> 32);
-                d.kt_lo = (uint32_t)kt;
-                d.kt_hi = (uint32_t)(kt >> 32);
-                d.nqt = nqt;
-                d.qbase = qn;
-                d.nruns = nruns;
-                d.fi = fi;
-                d.last_lane = (uint32_t)last_lane;
-                d.flags = (frag_end ? 1u : 0u) | (mate_end ? 2u : 0u);
-                d.nk0 = nk0;
-                d.total_kmers = nk0 + nk1;
-                S.slot[nslot] = d;
+                uint4 d0, d1, d2;  // layout of SlotLds
+                d0.x = (uint32_t)f;
+                d0.y = (uint32_t)(f >> 32);
+                d0.z = (uint32_t)kt;
+                d0.w = (uint32_t)(kt >> 32);
+                d1.x = nqt;
+                d1.y = qn;
+                d1.z = nruns;
+                d1.w = 0;
+                d2.x = (uint32_t)last_lane;
+                d2.y = (frag_end ? 1u : 0u) | (mate_end ? 2u : 0u) | (frag_first ? 4u : 0u);
+                d2.z = nk0;
+                d2.w = nk0 + nk1;
+                uint4 *dp = reinterpret_cast<uint4 *>(&S.slot[par][nslot_new]);
+                dp[0] = d0;
+                dp[1] = d1;
+                dp[2] = d2;
             }
-            if (nslot == 0)
-                ps0 = ps;
-            else
-                ps1 = ps;
+            S.ps[par][nslot_new][lane] = (uint16_t)ps;
+            frag_first = false;
             qn += nruns;
-            nslot++;
+            nslot_new++;
             q0 += TQ;
+            // collect another tile into this group if its run starts are sure to fit the queue
+            if (nslot_new < NSLOT && qn + TL <= (uint32_t)QCAP) continue;
         }
-        if (nslot == NSLOT || !have) flush();
-        if (!have) break;
+        // group complete (or input exhausted): hash + probe it -- which also resolves what is left
+        // of the previous group -- then post-process the previous group
+        probe_queue<LINEAR, STD, CAP32, PROF>(ap, S, lane, par, qn, lk, acc_lookups, prof, tprev);
+        if (nslot_old) post_group(par ^ 1u, nslot_old);
+        nslot_old = nslot_new;
+        if (!have && nslot_old == 0) break;  // nothing in flight any more
+        par ^= 1u;
+        nslot_new = 0;
+        qn = 0;
     }
 
     if (lane == 0) {

@@ -108,6 +108,47 @@ __global__ __launch_bounds__(TPB) void k_gather1(const uint32_t *__restrict__ ta
     if (acc == 0x12345678u) sink[0] = acc;
 }
 
+// cache-policy variants of the same dependent 16-B gather: does any of them make the L2 fetch less
+// than a 128-B line from HBM?  MODE 0 plain, 1 nt, 2 sc1, 3 sc0 sc1, 4 sc0 sc1 nt, 5 sc0
+template <int MODE>
+__global__ __launch_bounds__(64) void k_gather_mode(const uint32_t *__restrict__ table, uint64_t n_chunks,
+                                                    int iters, uint32_t *__restrict__ sink) {
+    uint64_t s = mix(((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) * 0x9E3779B97F4A7C15ull + 1);
+    uint32_t acc = 0;
+    for (int it = 0; it < iters; it++) {
+        s = mix(s + 1);
+        const uint64_t idx = __umul64hi(s, n_chunks);
+        const uint4 *p = reinterpret_cast<const uint4 *>(table) + idx;
+        uint4 v;
+        if (MODE == 0) asm volatile("global_load_dwordx4 %0, %1, off\n s_waitcnt vmcnt(0)" : "=v"(v) : "v"(p) : "memory");
+        if (MODE == 1) asm volatile("global_load_dwordx4 %0, %1, off nt\n s_waitcnt vmcnt(0)" : "=v"(v) : "v"(p) : "memory");
+        if (MODE == 2) asm volatile("global_load_dwordx4 %0, %1, off sc1\n s_waitcnt vmcnt(0)" : "=v"(v) : "v"(p) : "memory");
+        if (MODE == 3) asm volatile("global_load_dwordx4 %0, %1, off sc0 sc1\n s_waitcnt vmcnt(0)" : "=v"(v) : "v"(p) : "memory");
+        if (MODE == 4) asm volatile("global_load_dwordx4 %0, %1, off sc0 sc1 nt\n s_waitcnt vmcnt(0)" : "=v"(v) : "v"(p) : "memory");
+        if (MODE == 5) asm volatile("global_load_dwordx4 %0, %1, off sc0\n s_waitcnt vmcnt(0)" : "=v"(v) : "v"(p) : "memory");
+        acc += v.x ^ v.y ^ v.z ^ v.w;
+        s += acc & 1;
+    }
+    if (acc == 0x12345678u) sink[0] = acc;
+}
+
+template <int MODE>
+static void run_mode(const char *name, const uint32_t *d_table, uint64_t n_chunks, uint32_t *d_sink) {
+    const int iters = 256, waves = 8192;
+    hipEvent_t e0, e1;
+    CK(hipEventCreate(&e0));
+    CK(hipEventCreate(&e1));
+    hipLaunchKernelGGL((k_gather_mode<MODE>), dim3(waves), dim3(64), 0, 0, d_table, n_chunks, iters, d_sink);
+    CK(hipDeviceSynchronize());
+    CK(hipEventRecord(e0));
+    hipLaunchKernelGGL((k_gather_mode<MODE>), dim3(waves), dim3(64), 0, 0, d_table, n_chunks, iters, d_sink);
+    CK(hipEventRecord(e1));
+    CK(hipEventSynchronize(e1));
+    float ms = 0;
+    CK(hipEventElapsedTime(&ms, e0, e1));
+    printf("  policy %-12s: %7.2f G probes/s\n", name, (double)waves * 64 * iters / ms / 1e6);
+}
+
 static void curve(const uint32_t *d_table, uint64_t n_chunks, uint32_t *d_sink) {
     printf("latency/throughput curve: every lane keeps exactly ONE dependent 16-B probe in flight\n");
     const int iters = 256;
@@ -152,6 +193,13 @@ int main(int argc, char **argv) {
         printf("idle dependent-chain latency: %.1f ticks of the 100 MHz wall clock per probe = %.2f us\n",
                cyc / 2000.0, cyc / 2000.0 / 100.0);
         curve(d_table, n_chunks0(bytes), d_sink);
+        printf("cache-policy variants (8192 waves, one dependent probe per lane):\n");
+        run_mode<0>("plain", d_table, n_chunks0(bytes), d_sink);
+        run_mode<1>("nt", d_table, n_chunks0(bytes), d_sink);
+        run_mode<2>("sc1", d_table, n_chunks0(bytes), d_sink);
+        run_mode<3>("sc0 sc1", d_table, n_chunks0(bytes), d_sink);
+        run_mode<4>("sc0 sc1 nt", d_table, n_chunks0(bytes), d_sink);
+        run_mode<5>("sc0", d_table, n_chunks0(bytes), d_sink);
     }
     for (int blocks : {256 * 4, 256 * 8, 256 * 16}) {
         run<1, 16>(d_table, n_chunks, iters, d_sink, blocks);
