@@ -120,13 +120,8 @@ def main():
     kernel_ms = ev0.elapsed_time(ev1) / max(args.steps, 1)
 
     # ---- totals: the one collective of the path (classified-count all-reduce) ------------------
-    tot = counters.clone()
-    tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-    if world > 1:
-        dist.all_reduce(tot, op=dist.ReduceOp.SUM)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-    elapsed_max = float(tmax.item())
-    frags, classified, nbases, lookups = [int(x) for x in tot.tolist()]
+    from nohuman_amd.dist import reduce_counters
+    (frags, classified, nbases, lookups), elapsed_max = reduce_counters(counters, elapsed)
     reads_total = frags * mates
     value = reads_total / elapsed_max / 1e6
 
@@ -168,7 +163,7 @@ def main():
             "peak": HBM_PEAK_GBS,
             "unit": "GB/s",
             "frac": round(achieved / HBM_PEAK_GBS, 4),
-            "traffic": None,
+            "traffic": measured_traffic(n_frag, paired, L, info.capacity),
             "kernel": "k_classify",
             "kernel_ms": round(kernel_ms, 4),
             "algorithmic_bytes_per_launch": int(alg_bytes_launch),
@@ -185,17 +180,33 @@ def main():
         dist.destroy_process_group()
 
 
+def measured_traffic(n_frag, paired, read_len, capacity):
+    """HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/traffic.json), if
+    they were taken on exactly this workload; null otherwise.  bench.py cannot host the counter
+    passes itself: the guide requires them in separate profiler runs."""
+    path = os.path.join(ROOT, "profiles", "traffic.json")
+    try:
+        t = json.load(open(path))
+    except (OSError, ValueError):
+        return None
+    key = {"fragments_per_step": n_frag, "paired": paired, "read_len": read_len, "capacity": capacity}
+    if t.get("workload") != key:
+        return None
+    return t.get("traffic_bytes_per_launch")
+
+
 def cpu_baseline(eng, bases_dev, L, mates, paired, args, np, results, step):
     """Times oracle/k2_oracle.c (pthreads, all host cores) on the first fragments of batch 0 with
     the very same table (downloaded from HBM), and checks the GPU results on that sample."""
     from oracle import oracle as orc
-    cores = os.cpu_count() or 1
+    from nohuman_amd.dist import usable_cpu_count
+    cores = usable_cpu_count()
     cells = eng.download_table()
     info = eng.info
     odb = orc.OracleDB(eng.opts_image(), eng.taxonomy_image(), cells=cells,
                        header=(info.capacity, info.size, info.key_bits, info.value_bits))
     del cells
-    chunk = 65536
+    chunk = 262144
     done = 0
     spent = 0.0
     n_frag = args.pairs

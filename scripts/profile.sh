@@ -16,6 +16,11 @@ rocprofv3 --output-format csv --pmc SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY SQ_WA
 rocprofv3 --output-format csv --pmc FETCH_SIZE -d "$OUT/pmc3" -o pmc3 -- $BENCH > /dev/null 2> "$OUT/pmc3.err"
 rocprofv3 --output-format csv --pmc TCC_HIT_sum TCC_MISS_sum TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum -d "$OUT/pmc4" -o pmc4 -- $BENCH > /dev/null 2> "$OUT/pmc4.err"
 rocprofv3 --output-format csv --pmc WRITE_SIZE -d "$OUT/pmc5" -o pmc5 -- $BENCH > /dev/null 2> "$OUT/pmc5.err"
+# calibration of FETCH_SIZE on a known pattern: tools/gather_bench issues a known number of random
+# 16-byte probes, each of which misses to one 128-byte line
+if [ -x "$REPO/tools/gather_bench" ]; then
+  rocprofv3 --output-format csv --pmc FETCH_SIZE TCC_EA0_RDREQ_sum -d "$OUT/calib" -o calib -- "$REPO/tools/gather_bench" 6 64 > "$OUT/calib_stdout.txt" 2> "$OUT/calib.err"
+fi
 cd "$REPO"
 python3 scripts/summarize_prof.py "$OUT" > "$OUT/summary.txt" 2>&1
 cat "$OUT/summary.txt"

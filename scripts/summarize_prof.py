@@ -18,8 +18,8 @@ for f in find("*kernel_stats.csv"):
     print("== kernel stats:", os.path.relpath(f, out))
     with open(f) as fh:
         for i, row in enumerate(csv.reader(fh)):
-            if i < 12:
-                print("  " + ", ".join(row))
+            if i < 8:
+                print("  " + ", ".join(c[:90] for c in row))
 for f in find("*counter_collection.csv"):
     print("== counters:", os.path.relpath(f, out))
     acc = defaultdict(lambda: defaultdict(list))

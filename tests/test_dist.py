@@ -1,0 +1,69 @@
+"""N>1 path on CPU: world_size-2 gloo run of the shard plan + the counter all-reduce (the only
+collective of the path; RCCL on the GPU box)."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from nohuman_amd.dist import reduce_counters, shard_range, usable_cpu_count
+
+
+def test_shard_range_partitions_in_order():
+    for n in (0, 1, 7, 1000, 1001):
+        for world in (1, 2, 3, 8):
+            spans = [shard_range(n, r, world) for r in range(world)]
+            assert spans[0][0] == 0 and spans[-1][1] == n
+            for (a, b), (c, d) in zip(spans, spans[1:]):
+                assert b == c and a <= b
+            sizes = [b - a for a, b in spans]
+            assert max(sizes) - min(sizes) <= 1
+    with pytest.raises(ValueError):
+        shard_range(10, 2, 2)
+
+
+def test_usable_cpu_count_positive():
+    assert usable_cpu_count() >= 1
+
+
+def _worker(rank, world, port, n_frag, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    lo, hi = shard_range(n_frag, rank, world)
+    # per-rank counters as the engine would report them for its shard:
+    # {fragments, classified (every 3rd fragment), bases (150 per fragment), lookups (39 each)}
+    frs = torch.arange(lo, hi)
+    counters = torch.tensor([hi - lo, int((frs % 3 == 0).sum()), 150 * (hi - lo), 39 * (hi - lo)],
+                            dtype=torch.int64)
+    tot, tmax = reduce_counters(counters, 1.0 + rank)
+    q.put((rank, tot, tmax))
+    dist.destroy_process_group()
+
+
+def test_counter_all_reduce_world2():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    n_frag = 1001
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, n_frag, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    out = [q.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    want = [n_frag, len([i for i in range(n_frag) if i % 3 == 0]), 150 * n_frag, 39 * n_frag]
+    for rank, tot, tmax in out:
+        assert tot == want
+        assert tmax == 2.0  # the slowest rank defines the job time
+
+
+def test_reduce_without_process_group_is_identity():
+    tot, tmax = reduce_counters(torch.tensor([1, 2, 3, 4], dtype=torch.int64), 0.5)
+    assert tot == [1, 2, 3, 4] and tmax == 0.5

@@ -1,0 +1,124 @@
+"""GPU end-to-end tests of the whole-run entry (nh_run through the C ABI and through the
+CommandRunner mirror): FASTQ fixtures in, kraken2-compatible files out, checked against the golden
+expectations (made by the closed-form Python restatement) and the record semantics of SURVEY.md A.6."""
+import gzip
+import json
+import os
+
+import pytest
+
+from tests.fastq_util import read_fastq
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+DB = os.path.join(GOLD, "toy_db")
+
+
+def _expected(name, conf):
+    exp = json.load(open(os.path.join(GOLD, name)))
+    ext = exp["meta"]["external_ids"]
+    recs = exp["records"]
+    calls = [r["by_conf"][str(conf)][0] for r in recs]
+    return exp, ext, recs, calls
+
+
+def _fastq_bytes(recs, suffixes=None):
+    out = []
+    for i, (h, _rid, seq, quals) in enumerate(recs):
+        sfx = suffixes[i] if suffixes else b""
+        out.append(h + sfx + b"\n" + seq + b"\n+\n" + quals + b"\n")
+    return b"".join(out)
+
+
+@pytest.mark.parametrize("keep_human", [False, True])
+@pytest.mark.parametrize("conf", [0.0, 0.5])
+def test_single_end_run(tmp_path, keep_human, conf):
+    from nohuman_amd import Engine
+    _, ext, recs, calls = _expected("expected_se.json", conf)
+    inp = os.path.join(GOLD, "reads_se.fq")
+    reads = read_fastq(inp)
+    out = tmp_path / "kraken_out.fq"
+    kout = tmp_path / "k.txt"
+    with Engine.open(DB) as eng:
+        st = eng.run(inp, str(out), kraken_output=str(kout), confidence=conf, keep_human=keep_human)
+    n_class = sum(1 for c in calls if c)
+    assert (st.total_sequences, st.classified, st.unclassified) == (len(reads), n_class, len(reads) - n_class)
+    assert st.total_bases == sum(len(r[2]) for r in reads)
+    keep = [i for i, c in enumerate(calls) if bool(c) == keep_human]
+    sfx = [b" kraken:taxid|%d" % ext[calls[i]] if calls[i] else b"" for i in keep]
+    assert out.read_bytes() == _fastq_bytes([reads[i] for i in keep], sfx)
+    # kraken output: C/U, id, external taxid, length, hit list
+    lines = kout.read_text().split("\n")[:-1]
+    assert len(lines) == len(reads)
+    for i, line in enumerate(lines):
+        cu, rid, taxid, ln, hl = line.split("\t")
+        assert cu == ("C" if calls[i] else "U")
+        assert rid.encode() == reads[i][1]
+        assert int(taxid) == (ext[calls[i]] if calls[i] else 0)
+        assert int(ln) == len(reads[i][2])
+        assert hl == recs[i]["hitlist"]
+
+
+def test_paired_end_run_gzip_inputs(tmp_path):
+    """paired inputs, one of them gzip-compressed (kraken2 reads .gz transparently), '#' naming."""
+    from nohuman_amd import CommandRunner
+    conf = 0.1
+    _, ext, recs, calls = _expected("expected_pe.json", conf)
+    in1 = os.path.join(GOLD, "reads_pe_1.fq")
+    in2gz = tmp_path / "reads_pe_2.fq.gz"
+    with open(os.path.join(GOLD, "reads_pe_2.fq"), "rb") as f, gzip.open(in2gz, "wb") as g:
+        g.write(f.read())
+    r1 = read_fastq(in1)
+    r2 = read_fastq(os.path.join(GOLD, "reads_pe_2.fq"))
+    kout = tmp_path / "k.txt"
+    runner = CommandRunner("kraken2")
+    assert runner.is_executable()
+    # exactly the argv nohuman builds (/root/reference/src/main.rs:215-267)
+    runner.run(["--threads", "2", "--db", DB, "--output", str(kout), "--confidence", str(conf),
+                "--paired", "--unclassified-out", str(tmp_path / "kraken_out#.fq"), in1, str(in2gz)])
+    st = runner.last_stats
+    n_class = sum(1 for c in calls if c)
+    assert (st.total_sequences, st.classified) == (len(r1), n_class)
+    keep = [i for i, c in enumerate(calls) if not c]
+    assert (tmp_path / "kraken_out_1.fq").read_bytes() == _fastq_bytes([r1[i] for i in keep])
+    assert (tmp_path / "kraken_out_2.fq").read_bytes() == _fastq_bytes([r2[i] for i in keep])
+    lines = kout.read_text().split("\n")[:-1]
+    assert len(lines) == len(r1)
+    for i, line in enumerate(lines):
+        cu, rid, taxid, ln, hl = line.split("\t")
+        assert cu == ("C" if calls[i] else "U")
+        want_id = r1[i][1]
+        if len(want_id) > 2 and want_id[-2:] in (b"/1", b"/2"):
+            want_id = want_id[:-2]
+        assert rid.encode() == want_id
+        assert int(taxid) == (ext[calls[i]] if calls[i] else 0)
+        assert ln == "%d|%d" % (len(r1[i][2]), len(r2[i][2]))
+        assert hl == recs[i]["hitlist"]
+
+
+def test_run_errors_are_reported(tmp_path):
+    from nohuman_amd import CommandRunner, Engine, EngineError
+    with pytest.raises(EngineError) as ei:
+        Engine.open(str(tmp_path))
+    assert "Required files (hash.k2d, opts.k2d, taxo.k2d) not found" in str(ei.value)
+    with Engine.open(DB) as eng:
+        with pytest.raises(EngineError):
+            eng.run(str(tmp_path / "missing.fq"), str(tmp_path / "o.fq"))
+        bad = tmp_path / "bad.fq"
+        bad.write_bytes(b"this is not fastq\n")
+        with pytest.raises(EngineError) as ei:
+            eng.run(str(bad), str(tmp_path / "o.fq"))
+        assert "unrecognized file format" in str(ei.value)
+    with pytest.raises(OSError) as ei:
+        CommandRunner("kraken2").run(["--db", DB, "--unclassified-out", str(tmp_path / "o.fq"),
+                                      str(tmp_path / "missing.fq")])
+    assert str(ei.value).startswith("kraken2 failed with stderr ")
+
+
+def test_db_directory_with_db_subdir(tmp_path):
+    """<dir>/db/*.k2d is accepted like <dir>/*.k2d (/root/reference/src/lib.rs:119-141)."""
+    import shutil
+    from nohuman_amd import Engine
+    shutil.copytree(DB, tmp_path / "outer" / "db")
+    with Engine.open(str(tmp_path / "outer")) as eng:
+        assert eng.info.k == 35 and eng.info.l == 31
