@@ -165,8 +165,8 @@ static int common_open(Engine *e, int device) {
     e->options.linear_probing = 1;
     e->options.reset_per_mate = 1;
     HIP_TRY(hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking));
-    HIP_TRY(hipMalloc((void **)&e->d_counters, (CNT_N + 8) * sizeof(uint64_t)));
-    HIP_TRY(hipMemset(e->d_counters, 0, (CNT_N + 8) * sizeof(uint64_t)));
+    HIP_TRY(hipMalloc((void **)&e->d_counters, (CNT_N + 12) * sizeof(uint64_t)));
+    HIP_TRY(hipMemset(e->d_counters, 0, (CNT_N + 12) * sizeof(uint64_t)));
     HIP_TRY(hipMalloc((void **)&e->d_work, sizeof(unsigned long long)));
     HIP_TRY(hipMalloc((void **)&e->d_error, sizeof(int)));
     HIP_TRY(hipMemset(e->d_error, 0, sizeof(int)));
@@ -421,7 +421,7 @@ int open_synthetic(uint64_t capacity, uint64_t n_keys, uint32_t depth, uint64_t 
         unsigned long long sz = 0;
         if (he == hipSuccess) he = hipStreamSynchronize(e->stream);
         if (he == hipSuccess) he = hipMemcpy(&sz, d_size, 8, hipMemcpyDeviceToHost);
-        if (he == hipSuccess) he = hipMemset(e->d_counters, 0, (CNT_N + 8) * sizeof(uint64_t));
+        if (he == hipSuccess) he = hipMemset(e->d_counters, 0, (CNT_N + 12) * sizeof(uint64_t));
         if (he != hipSuccess) rc = set_error(NH_EDEVICE, "synthetic table: %s", hipGetErrorString(he));
         e->info.size = sz;
     }
@@ -710,7 +710,7 @@ int nh_stats_reset(nh_engine *e_) {
     if (!e) return set_error(NH_EINVAL, "null argument");
     std::lock_guard<std::mutex> lock(e->mu);
     HIP_TRY(hipSetDevice(e->device));
-    HIP_TRY(hipMemset(e->d_counters, 0, (nh::CNT_N + 8) * sizeof(uint64_t)));
+    HIP_TRY(hipMemset(e->d_counters, 0, (nh::CNT_N + 12) * sizeof(uint64_t)));
     e->seconds = 0;
     return NH_OK;
 }

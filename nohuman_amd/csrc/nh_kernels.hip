@@ -46,7 +46,7 @@ constexpr uint32_t QTAX_SKIP = 0xFFFFFFFFu;  // queue entry dropped by the min-h
 
 struct alignas(16) SlotLds {  // a scanned tile waiting for its probe results (written by lane 0)
     uint32_t f_lo, f_hi;    // fragment
-    uint32_t kt_lo, kt_hi;  // index in kmer_taxa of the tile's first k-mer
+    uint32_t koff, pad0;    // k-mer index of the tile within its fragment
     uint32_t nqt, qbase, nruns;
     uint32_t fi;            // which FragLds / taxon list (parity of the wave's fragment count)
     uint32_t last_lane;     // 2*lane+slot of the last unambiguous k-mer, 0xFFFFFFFF if none
@@ -63,6 +63,8 @@ template <> struct QTax<true> {};
 
 template <bool STD>
 struct WaveLdsT {
+    unsigned long long acc[4];  // fragments, classified, bases, lookups of this wave (lane 0 adds)
+    uint64_t last_dw;           // last readable dword of the bases buffer
     SlotLds slot[2][NSLOT];  // [parity of the group][tile]
     uint16_t ps[2][NSLOT][WAVE];  // per-lane packed k-mer state of the tiles in flight
     uint32_t pk[24];  // 2-bit packed bases: base i' of the tile frame at bit 2*(255-i'); 64 B + zero pad
@@ -232,7 +234,7 @@ __device__ __forceinline__ uint32_t scan_tile(KArgsP ap, WaveLdsT<STD> &S, const
                                               uint32_t &ps, int &last_lane,
                                               const uint32_t *pf_ptr, const bool pf_on,
                                               uint32_t &w_pref,
-                                              uint64_t (&prof)[8], uint64_t &tprev) {
+                                              uint64_t (&prof)[12], uint64_t &tprev) {
     ap = launder(ap);
     const uint32_t L = STD ? 31u : ap->db.l;
     const uint32_t W = STD ? 4u : ap->db.window;
@@ -411,7 +413,7 @@ template <bool LINEAR, bool STD, bool CAP32, bool PROF>
 __device__ __forceinline__ void probe_queue(KArgsP ap, WaveLdsT<STD> &S, const int lane,
                                             const uint32_t par,
                                             const uint32_t qn, LaneLookup &lk,
-                                            uint32_t &acc_lookups, uint64_t (&prof)[8],
+                                            uint64_t (&prof)[12],
                                             uint64_t &tprev) {
     ap = launder(ap);
     const uint64_t MIN_HASH = STD ? 0ull : ap->db.min_hash;
@@ -440,7 +442,8 @@ __device__ __forceinline__ void probe_queue(KArgsP ap, WaveLdsT<STD> &S, const i
             S.q[par][r] = e;
             if constexpr (!STD) S.qtax.v[par][r] = look ? 0u : QTAX_SKIP;
         }
-        acc_lookups += __popcll(__ballot(look));
+        const uint32_t nlook = __popcll(__ballot(look));
+        if (lane == 0) S.acc[CNT_LOOKUPS] += nlook;
     }
     wave_sync();
     NH_STAMP(4);
@@ -582,7 +585,7 @@ __device__ __forceinline__ void post_tile(WaveLdsT<STD> &S, const int lane, cons
                                           const uint32_t qbase, const uint32_t nruns,
                                           const int last_lane, FragState &st,
                                           const uint32_t li, uint32_t *__restrict__ kmer_taxa,
-                                          const uint64_t kt, uint64_t (&prof)[8], uint64_t &tprev) {
+                                          const uint64_t kt, uint64_t (&prof)[12], uint64_t &tprev) {
     const uint32_t qi0 = 2u * lane, qi1 = 2u * lane + 1;
     const bool v0 = ps & 1u, v1 = (ps >> 1) & 1u;
     const uint32_t r0p = (ps >> 3) & 0xFFu, r1p = r0p + ((ps >> 2) & 1u);
@@ -706,29 +709,29 @@ __global__ __launch_bounds__(WAVE * WAVES_PER_BLOCK, STD ? 6 : 4) void k_classif
     const uint32_t TQ = TL - (STD ? 4u : ap->db.window);  // k-mers per tile
     const int mates = ap->mates;
     const uint64_t n_frag = ap->n_frag;
-    const uint64_t *const seq_off = ap->seq_off;
-    const uint8_t *const bases = ap->bases;
     const bool reset_per_mate = ap->db.reset_per_mate != 0;
-    // dword index of the last dword the caller guarantees readable (8 bytes of slack, see ABI)
-    const uint64_t last_dw = (seq_off[n_frag * (uint64_t)mates] + 4) >> 2;
+    // dword index of the last dword the caller guarantees readable (8 bytes of slack, see ABI),
+    // parked in LDS: it is needed once per tile, not worth two SGPRs for the whole kernel
+    if (lane == 0) S.last_dw = (ap->seq_off[n_frag * (uint64_t)mates] + 4) >> 2;
     const uint32_t pl = (uint32_t)lane < PREF_LANES ? (uint32_t)lane : PREF_LANES - 1;
 
     // the dword stream of the tile that starts at byte g0: 4 bases per lane, coalesced
     auto tile_ptr = [&](uint64_t g0) -> const uint32_t * {
+        KArgsP a3 = launder(ap);
+        const uint64_t last_dw = S.last_dw;
         uint64_t dw = (g0 >> 2) + pl;
         dw = dw < last_dw ? dw : last_dw;
-        return reinterpret_cast<const uint32_t *>(bases) + dw;
+        return reinterpret_cast<const uint32_t *>(a3->bases) + dw;
     };
 
-    uint32_t acc_frag = 0, acc_class = 0, acc_lookups = 0;
-    uint64_t acc_bases = 0;
+    if (lane < 4) S.acc[lane] = 0;
     bool bad_input = false;
-    uint64_t prof[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    uint64_t prof[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     uint64_t tprev = PROF ? __builtin_readcyclecounter() : 0;
 
-    // speculative one-tile-ahead prefetch: pref_g0 is the byte offset w_pref was loaded for
-    uint64_t pref_g0 = ~0ull;
-    uint32_t w_pref = 0;
+    // speculative prefetch of the bases of the next two tiles (byte offset tags, loaded dwords)
+    uint64_t tag1 = ~0ull, tag2 = ~0ull;
+    uint32_t w1 = 0, w2 = 0;
 
     // Two groups of tiles are in flight: the one being scanned / probed (parity `par`) and the
     // previous one, which is post-processed only after the probe phase of its successor.
@@ -758,7 +761,7 @@ __global__ __launch_bounds__(WAVE * WAVES_PER_BLOCK, STD ? 6 : 4) void k_classif
             const uint4 *dp = reinterpret_cast<const uint4 *>(&S.slot[pp][s]);
             const uint4 d0 = dp[0], d1 = dp[1], d2 = dp[2];
             const uint64_t f = ((uint64_t)uni(d0.y) << 32) | uni(d0.x);   // f_lo, f_hi
-            const uint64_t kt = ((uint64_t)uni(d0.w) << 32) | uni(d0.z);  // kt_lo, kt_hi
+            const uint64_t kt = kmer_taxa ? a2->kmer_taxa_off[f] + uni(d0.z) : 0;  // tile's first k-mer
             const uint32_t d_nqt = uni(d1.x), d_qbase = uni(d1.y), d_nruns = uni(d1.z);
             const uint32_t fi = 0;
             const uint32_t d_last = uni(d2.x), flags = uni(d2.y);
@@ -788,168 +791,166 @@ __global__ __launch_bounds__(WAVE * WAVES_PER_BLOCK, STD ? 6 : 4) void k_classif
                         kmer_taxa[a2->kmer_taxa_off[f] + d_nk0] = TAXON_MATE_BORDER;
                     if (st.overflow) atomicMax(a2->error_flag, 1);
                 }
-                acc_class += call ? 1 : 0;
+                if (lane == 0 && call) S.acc[CNT_CLASSIFIED] += 1;
             }
             wave_sync();
         }
         NH_STAMP(7);
     };
 
-    // Fragments are handed out dynamically: every wave pulls chunks of consecutive fragments from
-    // one counter, so late-starting (non-resident) workgroups of the grid find no work instead of
-    // a static share.  The tile iterator below is a flat state machine (one scan site, one flush
-    // site) over chunk -> fragment -> mate -> tile.
-    const uint32_t frag_chunk = ap->frag_chunk;  // <= 31: its offsets fit the 64 lanes of off_v
-    unsigned long long next_chunk = 0;        // lane 0: first fragment of the chunk claimed ahead
-    if (lane == 0) next_chunk = atomicAdd(ap->work, (unsigned long long)frag_chunk);
-    uint64_t off_v = 0;                       // lane i: sequence offset i of the current chunk
-    uint64_t chunk_first = 0;
-    uint64_t f = 0, cend = 0;                 // current fragment, end of the current chunk
-    uint64_t o0 = 0, o1 = 0, o2 = 0;          // sequence bounds of the current fragment
-    uint32_t n0 = 0, n1 = 0, nk0 = 0, nk1 = 0;
-    uint64_t kt_base = 0;
-    uint32_t m = 0, q0 = 0;
-    bool frag_first = false;                  // the next tile is the first of its fragment
-    uint64_t carry_min = NH_FULL;             // kraken2 last_minimizer of the current fragment
-    bool frag_valid = false;
-    for (;;) {
-        bool have = false;
-        for (;;) {
-            if (frag_valid) {
-                if (q0 < (m ? nk1 : nk0)) {
-                    have = true;
-                    break;
-                }
-                if ((int)m + 1 < mates) {
-                    m++;
-                    q0 = 0;
-                    if (reset_per_mate) carry_min = NH_FULL;
-                    continue;
-                }
-                frag_valid = false;
-            }
-            f++;
-            if (f >= cend) {
-                // chunk ids are claimed one chunk ahead, so the atomic's latency is off the path
-                const unsigned long long cbeg = readlane64(next_chunk, 0);
-                if (cbeg >= n_frag) break;
-                if (lane == 0) next_chunk = atomicAdd(ap->work, (unsigned long long)frag_chunk);
-                f = cbeg;
-                cend = cbeg + frag_chunk < n_frag ? cbeg + frag_chunk : n_frag;
-                // all sequence offsets of the chunk with ONE coalesced load (lane i = offset i)
-                const uint64_t nof = (cend - cbeg) * (uint64_t)mates + 1;
-                off_v = seq_off[cbeg * (uint64_t)mates + ((uint64_t)lane < nof ? (uint64_t)lane : nof - 1)];
-                chunk_first = cbeg;
-            }
-            const int oi = (int)(f - chunk_first) * mates;
-            o0 = readlane64(off_v, oi);
-            o1 = readlane64(off_v, oi + 1);
-            o2 = mates == 2 ? readlane64(off_v, oi + 2) : o1;
-            if (((o1 - o0) | (o2 - o1)) >> 31) bad_input = true;  // sequences of 2 Gbases and more
-            n0 = (uint32_t)(o1 - o0);
-            n1 = (uint32_t)(o2 - o1);
-            nk0 = n0 >= K ? n0 - K + 1 : 0;
-            nk1 = n1 >= K ? n1 - K + 1 : 0;
-            uint32_t *const kmer_taxa = ap->kmer_taxa;
-            kt_base = kmer_taxa ? ap->kmer_taxa_off[f] : 0;
-            acc_frag += 1;
-            acc_bases += (uint64_t)n0 + n1;
-            if (nk0 + nk1 == 0) {  // no k-mer at all: all-zero record, only the mate border
-                if (lane == 0) {
-                    uint4 rec = {0, 0, 0, 0};
-                    *reinterpret_cast<uint4 *>(&ap->out[f]) = rec;
-                    if (kmer_taxa && mates == 2) kmer_taxa[kt_base] = TAXON_MATE_BORDER;
-                }
-                continue;
-            }
-            carry_min = NH_FULL;
-            frag_first = true;
-            frag_valid = true;
-            m = 0;
-            q0 = 0;
-        }
-        if (have) {
-            const uint32_t n = m ? n1 : n0;
-            const uint32_t nk = m ? nk1 : nk0;
-            const uint64_t g0 = (m ? o1 : o0) + q0;
-            NH_STAMP(0);
-            uint32_t w = w_pref;
-            if (pref_g0 != g0) w = *tile_ptr(g0);
-            // guess the tile after this one and start its load now: next tile of the sequence,
-            // else the mate, else the next fragment of the chunk (it starts where this one ends)
-            uint64_t ng0;
-            if (q0 + TQ < nk)
-                ng0 = g0 + TQ;
-            else if (m == 0 && mates == 2)
-                ng0 = o1;
-            else
-                ng0 = f + 1 < cend ? o2 : ~0ull;
-            const bool pf_on = ng0 != ~0ull;
-            const uint32_t *pf_ptr = tile_ptr(pf_on ? ng0 : g0);
-            pref_g0 = ng0;
-
-            const uint32_t nl_left = (n - L + 1) - q0;
-            const uint32_t nlt = nl_left < (uint32_t)TL ? nl_left : (uint32_t)TL;
-            const uint32_t nq_left = nk - q0;
-            const uint32_t nqt = nq_left < TQ ? nq_left : TQ;
-            const bool seq_end = q0 + TQ >= nk;
-            const bool frag_end = seq_end && ((int)m == mates - 1 || nk1 == 0);
-            const bool mate_end = seq_end && m == 0 && mates == 2 && nk1 != 0;
-
-            uint32_t ps;
-            int last_lane;
-            const uint32_t nruns =
-                scan_tile<STD, PROF>(ap, S, lane, w, (uint32_t)g0 & 3u, nlt, nqt, par, qn,
-                                     carry_min, ps, last_lane, pf_ptr, pf_on, w_pref, prof, tprev);
-            if (lane == 0) {
-                const uint64_t kt = kt_base + (m ? (uint64_t)nk0 + 1 : 0) + q0;
-                uint4 d0, d1, d2;  // layout of SlotLds
-                d0.x = (uint32_t)f;
-                d0.y = (uint32_t)(f >> 32);
-                d0.z = (uint32_t)kt;
-                d0.w = (uint32_t)(kt >> 32);
-                d1.x = nqt;
-                d1.y = qn;
-                d1.z = nruns;
-                d1.w = 0;
-                d2.x = (uint32_t)last_lane;
-                d2.y = (frag_end ? 1u : 0u) | (mate_end ? 2u : 0u) | (frag_first ? 4u : 0u);
-                d2.z = nk0;
-                d2.w = nk0 + nk1;
-                uint4 *dp = reinterpret_cast<uint4 *>(&S.slot[par][nslot_new]);
-                dp[0] = d0;
-                dp[1] = d1;
-                dp[2] = d2;
-            }
-            S.ps[par][nslot_new][lane] = (uint16_t)ps;
-            frag_first = false;
-            qn += nruns;
-            nslot_new++;
-            q0 += TQ;
-            // collect another tile into this group if its run starts are sure to fit the queue
-            if (nslot_new < NSLOT && qn + TL <= (uint32_t)QCAP) continue;
-        }
-        // group complete (or input exhausted): hash + probe it -- which also resolves what is left
-        // of the previous group -- then post-process the previous group
-        probe_queue<LINEAR, STD, CAP32, PROF>(ap, S, lane, par, qn, lk, acc_lookups, prof, tprev);
+    // group complete (or input exhausted): hash + probe it -- which also resolves what is left of
+    // the previous group -- then post-process the previous group and switch buffers
+    auto turn = [&]() {
+        probe_queue<LINEAR, STD, CAP32, PROF>(ap, S, lane, par, qn, lk, prof, tprev);
         if (nslot_old) post_group(par ^ 1u, nslot_old);
         nslot_old = nslot_new;
-        if (!have && nslot_old == 0) break;  // nothing in flight any more
         par ^= 1u;
         nslot_new = 0;
         qn = 0;
-    }
+    };
 
+    // Fragments are handed out dynamically: every wave pulls chunks of consecutive fragments from
+    // one counter (claimed one chunk ahead), so late-starting (non-resident) workgroups of the grid
+    // find no work instead of a static share.
+    const uint32_t frag_chunk = ap->frag_chunk;  // <= 31: its offsets fit the 64 lanes of off_v
+    unsigned long long next_chunk = 0;           // lane 0: first fragment of the chunk claimed ahead
+    if (lane == 0) next_chunk = atomicAdd(ap->work, (unsigned long long)frag_chunk);
+    for (;;) {
+        const uint64_t cbeg = readlane64(next_chunk, 0);
+        if (cbeg >= n_frag) break;
+        if (lane == 0) next_chunk = atomicAdd(ap->work, (unsigned long long)frag_chunk);
+        const uint32_t ncf = cbeg + frag_chunk <= n_frag ? frag_chunk : (uint32_t)(n_frag - cbeg);
+        // all sequence offsets of the chunk with ONE coalesced load (lane i = offset i), kept
+        // relative to the chunk's first byte so that everything per fragment is 32-bit
+        const uint32_t nof = ncf * (uint32_t)mates + 1;
+        const uint64_t off64 = launder(ap)->seq_off[cbeg * (uint64_t)mates + ((uint32_t)lane < nof ? (uint32_t)lane : nof - 1)];
+        const uint64_t cbase = readlane64(off64, 0);
+        const uint64_t crel = off64 - cbase;
+        if (__ballot((crel >> 32) != 0)) bad_input = true;  // a chunk of 4 Gbases and more
+        if ((uint32_t)lane == nof - 1) {  // this lane holds the chunk's last offset = its bases
+            S.acc[CNT_FRAGMENTS] += ncf;
+            S.acc[CNT_BASES] += crel;
+        }
+        const uint32_t off_v = (uint32_t)crel;
+        for (uint32_t fc = 0; fc < ncf; fc++) {
+            NH_STAMP(8);
+            const uint64_t f = cbeg + fc;
+            const int oi = (int)fc * mates;
+            const uint32_t o0 = __builtin_amdgcn_readlane(off_v, oi);
+            const uint32_t o1 = __builtin_amdgcn_readlane(off_v, oi + 1);
+            const uint32_t o2 = mates == 2 ? __builtin_amdgcn_readlane(off_v, oi + 2) : o1;
+            const uint32_t n0 = o1 - o0, n1 = o2 - o1;
+            const uint32_t nk0 = n0 >= K ? n0 - K + 1 : 0;
+            const uint32_t nk1 = n1 >= K ? n1 - K + 1 : 0;
+            if (nk0 + nk1 == 0) {  // no k-mer at all: all-zero record, only the mate border
+                if (lane == 0) {
+                    KArgsP a2 = launder(ap);
+                    uint4 rec = {0, 0, 0, 0};
+                    *reinterpret_cast<uint4 *>(&a2->out[f]) = rec;
+                    uint32_t *const kmer_taxa = a2->kmer_taxa;
+                    if (kmer_taxa && mates == 2) kmer_taxa[a2->kmer_taxa_off[f]] = TAXON_MATE_BORDER;
+                }
+                continue;
+            }
+            uint64_t carry_min = NH_FULL;  // kraken2 last_minimizer of this fragment
+            bool frag_first = true;
+            NH_STAMP(9);
+            for (int m = 0; m < mates; m++) {
+                const uint32_t n = m ? n1 : n0;
+                const uint32_t nk = m ? nk1 : nk0;
+                if (m == 1 && reset_per_mate) carry_min = NH_FULL;
+                for (uint32_t q0 = 0; q0 < nk; q0 += TQ) {
+                    const uint64_t g0 = cbase + (m ? o1 : o0) + q0;
+                    NH_STAMP(0);
+                    // two-deep prefetch FIFO: (tag1, w1) was loaded for the next tile, (tag2, w2)
+                    // for the one after it
+                    uint32_t w = w1;
+                    if (tag1 != g0) {
+                        w = w2;
+                        if (tag2 != g0) w = *tile_ptr(g0);
+                    }
+                    tag1 = tag2;
+                    w1 = w2;
+                    // the tile to be scanned two scans from now (a full group away, so its load has
+                    // a whole probe phase to arrive): two tiles on in this sequence, else the first
+                    // tile of the sequence after the next one; only guessed inside the chunk
+                    const bool seq_end = q0 + TQ >= nk;
+                    uint64_t ng0 = g0 + 2 * TQ;
+                    bool pf_on = true;
+                    if (q0 + 2 * TQ >= nk) {
+                        uint32_t o_next;
+                        if (!seq_end) {  // one more tile here, then the next sequence
+                            o_next = (m == 0 && mates == 2) ? o1 : o2;
+                            pf_on = (m == 0 && mates == 2) || fc + 1 < ncf;
+                        } else if (mates == 2) {  // same mate of the next fragment
+                            o_next = m == 0 ? o2 : __builtin_amdgcn_readlane(off_v, oi + 3);
+                            pf_on = fc + 1 < ncf;
+                        } else {  // single-end: the fragment after the next
+                            o_next = __builtin_amdgcn_readlane(off_v, oi + 2);
+                            pf_on = fc + 2 < ncf;
+                        }
+                        ng0 = cbase + o_next;
+                    }
+                    const uint32_t *pf_ptr = tile_ptr(pf_on ? ng0 : g0);
+                    tag2 = pf_on ? ng0 : ~0ull;
+
+                    const uint32_t nl_left = (n - L + 1) - q0;
+                    const uint32_t nlt = nl_left < (uint32_t)TL ? nl_left : (uint32_t)TL;
+                    const uint32_t nq_left = nk - q0;
+                    const uint32_t nqt = nq_left < TQ ? nq_left : TQ;
+                    const bool frag_end = seq_end && (m == mates - 1 || nk1 == 0);
+                    const bool mate_end = seq_end && m == 0 && mates == 2 && nk1 != 0;
+
+                    uint32_t ps;
+                    int last_lane;
+                    const uint32_t nruns =
+                        scan_tile<STD, PROF>(ap, S, lane, w, (uint32_t)g0 & 3u, nlt, nqt, par, qn,
+                                             carry_min, ps, last_lane, pf_ptr, pf_on, w2, prof, tprev);
+                    if (lane == 0) {
+                        uint4 d0, d1, d2;  // layout of SlotLds
+                        d0.x = (uint32_t)f;
+                        d0.y = (uint32_t)(f >> 32);
+                        d0.z = (m ? nk0 + 1 : 0) + q0;  // k-mer index of the tile within its fragment
+                        d0.w = 0;
+                        d1.x = nqt;
+                        d1.y = qn;
+                        d1.z = nruns;
+                        d1.w = 0;
+                        d2.x = (uint32_t)last_lane;
+                        d2.y = (frag_end ? 1u : 0u) | (mate_end ? 2u : 0u) | (frag_first ? 4u : 0u);
+                        d2.z = nk0;
+                        d2.w = nk0 + nk1;
+                        uint4 *dp = reinterpret_cast<uint4 *>(&S.slot[par][nslot_new]);
+                        dp[0] = d0;
+                        dp[1] = d1;
+                        dp[2] = d2;
+                    }
+                    S.ps[par][nslot_new][lane] = (uint16_t)ps;
+                    NH_STAMP(10);
+                    frag_first = false;
+                    qn += nruns;
+                    nslot_new++;
+                    // another tile joins this group only if its run starts are sure to fit the queue
+                    if (nslot_new == NSLOT || qn + TL > (uint32_t)QCAP) turn();
+                }
+            }
+        }
+    }
+    // drain: probe what is left, post-process the last two groups
+    turn();
+    turn();
+
+    wave_sync();
     if (lane == 0) {
         unsigned long long *const counters = ap->counters;
         int *const error_flag = ap->error_flag;
         if (PROF && counters)
-            for (int i = 0; i < 8; i++) atomicAdd(&counters[CNT_N + i], (unsigned long long)prof[i]);
+            for (int i = 0; i < 12; i++) atomicAdd(&counters[CNT_N + i], (unsigned long long)prof[i]);
         if (counters) {
-            atomicAdd(&counters[CNT_FRAGMENTS], (unsigned long long)acc_frag);
-            atomicAdd(&counters[CNT_CLASSIFIED], (unsigned long long)acc_class);
-            atomicAdd(&counters[CNT_BASES], (unsigned long long)acc_bases);
-            atomicAdd(&counters[CNT_LOOKUPS], (unsigned long long)acc_lookups);
+            atomicAdd(&counters[CNT_FRAGMENTS], S.acc[CNT_FRAGMENTS]);
+            atomicAdd(&counters[CNT_CLASSIFIED], S.acc[CNT_CLASSIFIED]);
+            atomicAdd(&counters[CNT_BASES], S.acc[CNT_BASES]);
+            atomicAdd(&counters[CNT_LOOKUPS], S.acc[CNT_LOOKUPS]);
         }
         if (bad_input) atomicMax(error_flag, 2);
     }

@@ -14,7 +14,7 @@ acgt = torch.tensor([65, 67, 71, 84], dtype=torch.uint8, device=dev)
 bases = acgt[torch.randint(0, 4, (n * mates * L + 64,), device=dev)].contiguous()
 offs = (torch.arange(n * mates + 1, dtype=torch.int64, device=dev) * L).contiguous()
 res = torch.empty((n, 4), dtype=torch.int32, device=dev)
-cnt = torch.zeros(12, dtype=torch.int64, device=dev)
+cnt = torch.zeros(16, dtype=torch.int64, device=dev)
 st = torch.cuda.current_stream().cuda_stream
 for i in range(3):
     cnt.zero_()
@@ -24,8 +24,9 @@ for i in range(3):
     e1.record(); torch.cuda.synchronize()
 c = cnt.tolist()
 ms = e0.elapsed_time(e1)
-names = ["0 frag setup+loop", "1 base wait+encode", "2 lmer+window(LDS)", "3 runs+compact", "4 hash+probe",
-         "5 taxa/hits", "6 finalize", "7 -"]
+names = ["0 ->tile start", "1 base wait+encode", "2 lmer+window(LDS)", "3 runs+compact", "4 hash pass",
+         "5 probe loop", "6 post tiles", "7 end of turn", "8 ->fragment top", "9 fragment header",
+         "10 descriptor write", "11 -"]
 tot = sum(c[4:])
 print("kernel %.3f ms (instrumented), %d fragments, lookups %d" % (ms, c[0], c[3]))
 for i, nm in enumerate(names):
