@@ -10,6 +10,7 @@
 #include <stdio.h>
 #include <string.h>
 
+#include <algorithm>
 #include <chrono>
 #include <memory>
 #include <string>
@@ -94,6 +95,73 @@ static void append_hitlist(std::string &dst, const Engine *e, const uint32_t *ta
     }
 }
 
+// kraken2 reports.cc ReportKrakenStyle / KrakenReportDFS (reached through
+// nohuman's -r/--kraken-report, /root/reference/src/main.rs:97-99,226-228).  Lowest-confidence part
+// of the restatement: the line format is "%6.2f\tclade\ttaxon\trank\ttaxid\t<2*depth spaces>name".
+struct TaxoView {
+    uint64_t n = 0;
+    const uint8_t *nodes = nullptr;
+    const char *names = nullptr, *ranks = nullptr;
+    uint64_t field(uint64_t i, int k) const {
+        uint64_t v;
+        memcpy(&v, nodes + 56 * i + 8 * k, 8);
+        return v;
+    }
+};
+
+static void report_dfs(FILE *f, const TaxoView &t, const std::vector<uint64_t> &clade,
+                       const std::vector<uint64_t> &own, uint64_t total, uint64_t id, char rank_code,
+                       int rank_depth, int depth) {
+    if (clade[id] == 0) return;  // clades absent from the sample are not printed
+    const std::string rank = t.ranks + t.field(id, 4);
+    if (rank == "superkingdom" || rank == "domain") { rank_code = 'D'; rank_depth = 0; }
+    else if (rank == "kingdom") { rank_code = 'K'; rank_depth = 0; }
+    else if (rank == "phylum") { rank_code = 'P'; rank_depth = 0; }
+    else if (rank == "class") { rank_code = 'C'; rank_depth = 0; }
+    else if (rank == "order") { rank_code = 'O'; rank_depth = 0; }
+    else if (rank == "family") { rank_code = 'F'; rank_depth = 0; }
+    else if (rank == "genus") { rank_code = 'G'; rank_depth = 0; }
+    else if (rank == "species") { rank_code = 'S'; rank_depth = 0; }
+    else rank_depth++;
+    std::string rank_str(1, rank_code);
+    if (rank_depth != 0) rank_str += std::to_string(rank_depth);
+    fprintf(f, "%6.2f\t%llu\t%llu\t%s\t%llu\t", 100.0 * (double)clade[id] / (double)total,
+            (unsigned long long)clade[id], (unsigned long long)own[id], rank_str.c_str(),
+            (unsigned long long)t.field(id, 5));
+    for (int i = 0; i < depth; i++) fputs("  ", f);
+    fprintf(f, "%s\n", t.names + t.field(id, 3));
+    const uint64_t first = t.field(id, 1), cnt = t.field(id, 2);
+    std::vector<uint64_t> kids(cnt);
+    for (uint64_t i = 0; i < cnt; i++) kids[i] = first + i;
+    std::stable_sort(kids.begin(), kids.end(),
+                     [&](uint64_t x, uint64_t y) { return clade[x] > clade[y]; });
+    for (uint64_t c : kids) report_dfs(f, t, clade, own, total, c, rank_code, rank_depth, depth + 1);
+}
+
+static int write_report(const Engine *e, const char *path, const std::vector<uint64_t> &own,
+                        uint64_t total, uint64_t unclassified) {
+    TaxoView t;
+    const uint8_t *img = e->taxo_image.data();
+    memcpy(&t.n, img + 8, 8);
+    uint64_t name_len;
+    memcpy(&name_len, img + 16, 8);
+    t.nodes = img + 32;
+    t.names = (const char *)(img + 32 + 56 * t.n);
+    t.ranks = t.names + name_len;
+    std::vector<uint64_t> clade(own);
+    for (uint64_t i = t.n; i-- > 1;)  // children have larger ids than their parents
+        if (clade[i]) clade[t.field(i, 0)] += clade[i];
+    FILE *f = fopen(path, "w");
+    if (!f) return set_error(NH_EIO, "cannot create %s", path);
+    if (unclassified != 0)
+        fprintf(f, "%6.2f\t%llu\t%llu\tU\t0\tunclassified\n",
+                100.0 * (double)unclassified / (double)total, (unsigned long long)unclassified,
+                (unsigned long long)unclassified);
+    if (t.n > 1 && total) report_dfs(f, t, clade, own, total, 1, 'R', -1, 0);
+    if (fclose(f) != 0) return set_error(NH_EIO, "write error on %s", path);
+    return NH_OK;
+}
+
 int run_engine(Engine *e, const nh_run_args *a, nh_stats *stats) {
     if (!a || !a->in1 || !a->out1) return set_error(NH_EINVAL, "nh_run: in1 and out1 are required");
     const bool paired = a->in2 != nullptr;
@@ -123,6 +191,7 @@ int run_engine(Engine *e, const nh_run_args *a, nh_stats *stats) {
     std::vector<uint64_t> taxa_off;
     std::string buf1, buf2, bufk;
     uint64_t total = 0, classified = 0, total_bases = 0;
+    std::vector<uint64_t> call_counts(e->external.size(), 0);  // fragments called at each taxon
     const uint32_t flags = paired ? NH_FLAG_PAIRED : 0;
     auto t0 = std::chrono::steady_clock::now();
     bool done = false;
@@ -175,6 +244,7 @@ int run_engine(Engine *e, const nh_run_args *a, nh_stats *stats) {
             const bool is_class = call != 0;
             total++;
             classified += is_class;
+            call_counts[call] += is_class;
             total_bases += recs1[i].seq.size() + (paired ? recs2[i].seq.size() : 0);
             const uint64_t ext = is_class ? e->external[call] : 0;
             if (is_class == (a->keep_human != 0)) {
@@ -209,6 +279,9 @@ int run_engine(Engine *e, const nh_run_args *a, nh_stats *stats) {
         if (want_k && !bufk.empty() && fwrite(bufk.data(), 1, bufk.size(), ok.f) != bufk.size())
             return set_error(NH_EIO, "write error on %s", a->kraken_output);
     }
+    if (a->report && a->report[0] &&
+        (rc = write_report(e, a->report, call_counts, total, total - classified)))
+        return rc;
     if ((rc = o1.close())) return rc;
     if (paired && (rc = o2.close())) return rc;
     if (want_k && (rc = ok.close())) return rc;

@@ -122,3 +122,48 @@ def test_db_directory_with_db_subdir(tmp_path):
     shutil.copytree(DB, tmp_path / "outer" / "db")
     with Engine.open(str(tmp_path / "outer")) as eng:
         assert eng.info.k == 35 and eng.info.l == 31
+
+
+def test_kraken_report(tmp_path):
+    """-r/--kraken-report (/root/reference/src/main.rs:97-99,226-228): kraken-style report lines
+    `%6.2f \\t clade \\t taxon \\t rank \\t taxid \\t indented name`, children by descending clade
+    count, unclassified line first."""
+    from nohuman_amd import Engine
+    from oracle import minidb
+    from tests import synth
+    conf = 0.0
+    _, ext, recs, calls = _expected("expected_se.json", conf)
+    inp = os.path.join(GOLD, "reads_se.fq")
+    rep = tmp_path / "report.txt"
+    with Engine.open(DB) as eng:
+        eng.run(inp, str(tmp_path / "o.fq"), report=str(rep), confidence=conf)
+    tax = minidb.Taxonomy(synth.TOY_EDGES)
+    n = tax.node_count
+    own = [0] * n
+    for c in calls:
+        if c:
+            own[c] += 1
+    clade = own[:]
+    for i in range(n - 1, 1, -1):
+        clade[tax.parent[i]] += clade[i]
+    total = len(calls)
+    uncl = sum(1 for c in calls if not c)
+    kids = {i: [j for j in range(1, n) if tax.parent[j] == i] for i in range(n)}
+    lines = []
+    if uncl:
+        lines.append("%6.2f\t%d\t%d\tU\t0\tunclassified" % (100.0 * uncl / total, uncl, uncl))
+
+    def dfs(i, depth, rank_depth):
+        if clade[i] == 0:
+            return
+        rank_depth += 1  # every toy rank is "no rank": the code stays R, the depth counts up
+        rank = "R" + (str(rank_depth) if rank_depth else "")
+        lines.append("%6.2f\t%d\t%d\t%s\t%d\t%s%s" % (100.0 * clade[i] / total, clade[i], own[i], rank,
+                                                     tax.external[i], "  " * depth,
+                                                     "taxon%d" % tax.external[i]))
+        for j in sorted(kids[i], key=lambda j: -clade[j]):
+            dfs(j, depth + 1, rank_depth)
+
+    dfs(1, 0, -1)
+    assert rep.read_text().split("\n")[:-1] == lines
+    assert len(lines) >= 8
