@@ -167,7 +167,7 @@ static int common_open(Engine *e, int device) {
     HIP_TRY(hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking));
     HIP_TRY(hipMalloc((void **)&e->d_counters, (CNT_N + 12) * sizeof(uint64_t)));
     HIP_TRY(hipMemset(e->d_counters, 0, (CNT_N + 12) * sizeof(uint64_t)));
-    HIP_TRY(hipMalloc((void **)&e->d_work, sizeof(unsigned long long)));
+    HIP_TRY(hipMalloc((void **)&e->d_work, 2 * sizeof(unsigned long long)));
     HIP_TRY(hipMalloc((void **)&e->d_error, sizeof(int)));
     HIP_TRY(hipMemset(e->d_error, 0, sizeof(int)));
     return NH_OK;
@@ -465,6 +465,16 @@ uint64_t kmer_taxa_entries(const Engine *e, const uint64_t *seq_offsets, uint64_
 int classify_device(Engine *e, const void *d_bases, const void *d_seq_off, uint64_t n_frag,
                     uint32_t flags, double confidence, void *d_results, void *d_kmer_taxa,
                     const void *d_kmer_taxa_off, void *d_counters, hipStream_t stream) {
+    return classify_device_slot(e, d_bases, d_seq_off, n_frag, flags, confidence, d_results, d_kmer_taxa,
+                                d_kmer_taxa_off, d_counters, stream, 0);
+}
+
+// work_slot selects one of two dynamic-scheduling counters, so that launches queued on two streams
+// of the same engine do not share one
+int classify_device_slot(Engine *e, const void *d_bases, const void *d_seq_off, uint64_t n_frag,
+                         uint32_t flags, double confidence, void *d_results, void *d_kmer_taxa,
+                         const void *d_kmer_taxa_off, void *d_counters, hipStream_t stream,
+                         int work_slot) {
     if (!(confidence >= 0.0 && confidence <= 1.0))
         return set_error(NH_EINVAL, "Confidence score must be in the closed interval [0, 1]");
     if ((d_kmer_taxa != nullptr) != (d_kmer_taxa_off != nullptr))
@@ -473,7 +483,7 @@ int classify_device(Engine *e, const void *d_bases, const void *d_seq_off, uint6
     finish_devdb(e);
     hipError_t he = launch_classify(e->dev, d_bases, d_seq_off, n_frag,
                                     (flags & NH_FLAG_PAIRED) ? 2 : 1, confidence, d_results,
-                                    d_kmer_taxa, d_kmer_taxa_off, d_counters, e->d_error, e->d_work,
+                                    d_kmer_taxa, d_kmer_taxa_off, d_counters, e->d_error, e->d_work + (work_slot & 1),
                                     e->frag_chunk > 31 ? 31 : e->frag_chunk, e->grid_blocks, stream);
     if (he != hipSuccess) return set_error(NH_EDEVICE, "classify launch: %s", hipGetErrorString(he));
     return NH_OK;

@@ -163,4 +163,142 @@ int FastxReader::next(SeqRecord &rec, std::string &err) {
     return 1;
 }
 
+// ------------------------------------------------------------------------------------------------
+int BlockReader::open(const char *path, std::string &err) {
+    buf_.resize(8u << 20);
+    pos_ = len_ = 0;
+    eof_ = false;
+    format_ = FMT_AUTO;
+    have_carry_ = false;
+    return src_.open(path, err);
+}
+
+bool BlockReader::fill() {
+    if (eof_) return false;
+    if (pos_ > 0) {  // keep the unread tail at the front
+        memmove(buf_.data(), buf_.data() + pos_, len_ - pos_);
+        len_ -= pos_;
+        pos_ = 0;
+    }
+    if (len_ == buf_.size()) buf_.resize(buf_.size() * 2);  // a line longer than the buffer
+    long n = src_.read((uint8_t *)buf_.data() + len_, buf_.size() - len_);
+    if (n <= 0) {
+        eof_ = true;
+        return false;
+    }
+    len_ += (size_t)n;
+    return true;
+}
+
+// std::getline semantics: false only if not a single character could be extracted
+bool BlockReader::line(const char *&b, const char *&e) {
+    for (;;) {
+        const char *p = buf_.data() + pos_;
+        const char *nl = (const char *)memchr(p, '\n', len_ - pos_);
+        if (nl) {
+            b = p;
+            e = nl;
+            pos_ = (size_t)(nl - buf_.data()) + 1;
+            return true;
+        }
+        if (!fill()) {  // end of input: the rest (if any) is the last line
+            if (pos_ == len_) return false;
+            b = buf_.data() + pos_;
+            e = buf_.data() + len_;
+            pos_ = len_;
+            return true;
+        }
+    }
+}
+
+static inline const char *rstrip(const char *b, const char *e) {
+    while (e > b && isspace((unsigned char)e[-1])) e--;
+    return e;
+}
+
+void BlockReader::next_batch(HalfBatch &hb, size_t max_recs, size_t max_text) {
+    hb.format = format_;
+    while (hb.recs.size() < max_recs && hb.text.size() < max_text) {
+        const char *b, *e;
+        std::string hdr;
+        if (have_carry_) {
+            hdr.swap(carry_);
+            have_carry_ = false;
+        } else {
+            if (!line(b, e)) {
+                hb.eof = true;
+                return;
+            }
+            hdr.assign(b, rstrip(b, e));
+        }
+        if (format_ == FMT_AUTO) {
+            if (!hdr.empty() && hdr[0] == '@')
+                format_ = FMT_FASTQ;
+            else if (!hdr.empty() && hdr[0] == '>')
+                format_ = FMT_FASTA;
+            else {
+                hb.error = "sequence reader - unrecognized file format";
+                return;
+            }
+            hb.format = format_;
+        }
+        if (format_ == FMT_FASTQ) {
+            if (hdr.empty()) {  // an empty line may end the file
+                hb.eof = true;
+                return;
+            }
+            if (hdr[0] != '@') {
+                hb.error = "malformed FASTQ file (exp. '@', saw \"" + hdr + "\"), aborting";
+                return;
+            }
+        } else if (hdr.empty() || hdr[0] != '>') {
+            hb.error = "malformed FASTA file (exp. '>', saw \"" + hdr + "\"), aborting";
+            return;
+        }
+        if (hdr.size() <= 1) {
+            hb.eof = true;
+            return;
+        }
+        RecRef r;
+        r.h = (uint32_t)hb.text.size();
+        r.hlen = (uint32_t)hdr.size();
+        size_t ws = hdr.find_first_of(" \t\r", 1);
+        r.idlen = (uint32_t)((ws == std::string::npos ? hdr.size() : ws) - 1);
+        hb.text.insert(hb.text.end(), hdr.begin(), hdr.end());
+        if (format_ == FMT_FASTQ) {
+            if (!line(b, e)) {
+                hb.text.resize(r.h);
+                hb.eof = true;
+                return;
+            }
+            const char *se = rstrip(b, e);
+            r.s = (uint32_t)hb.text.size();
+            r.slen = (uint32_t)(se - b);
+            hb.text.insert(hb.text.end(), b, se);
+            const char *pb, *pe;
+            if (!line(pb, pe) || !line(b, e)) {  // '+' line (discarded), qualities
+                hb.text.resize(r.h);
+                hb.eof = true;
+                return;
+            }
+            const char *qe = rstrip(b, e);
+            r.q = (uint32_t)hb.text.size();
+            r.qlen = (uint32_t)(qe - b);
+            hb.text.insert(hb.text.end(), b, qe);
+        } else {
+            r.s = (uint32_t)hb.text.size();
+            for (;;) {  // join sequence lines up to the next header
+                if (pos_ == len_ && !fill()) break;
+                if (buf_[pos_] == '>') break;
+                if (!line(b, e)) break;
+                hb.text.insert(hb.text.end(), b, rstrip(b, e));
+            }
+            r.slen = (uint32_t)(hb.text.size() - r.s);
+            r.q = r.s + r.slen;
+            r.qlen = 0;
+        }
+        hb.recs.push_back(r);
+    }
+}
+
 }  // namespace nh

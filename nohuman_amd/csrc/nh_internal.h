@@ -30,7 +30,7 @@ struct Engine {
     uint32_t *d_parent = nullptr;
     uint64_t *d_counters = nullptr;
     int *d_error = nullptr;
-    unsigned long long *d_work = nullptr;  // dynamic fragment-chunk counter of k_classify
+    unsigned long long *d_work = nullptr;  // dynamic fragment-chunk counters of k_classify (2 slots)
     uint32_t frag_chunk = 16;              // fragments a wave pulls at a time
     hipStream_t stream = nullptr;
     std::vector<uint32_t> parent;
@@ -64,6 +64,10 @@ int resolve_db_dir(const char *db_dir, std::string &resolved);
 int classify_device(Engine *e, const void *d_bases, const void *d_seq_off, uint64_t n_frag,
                     uint32_t flags, double confidence, void *d_results, void *d_kmer_taxa,
                     const void *d_kmer_taxa_off, void *d_counters, hipStream_t stream);
+int classify_device_slot(Engine *e, const void *d_bases, const void *d_seq_off, uint64_t n_frag,
+                         uint32_t flags, double confidence, void *d_results, void *d_kmer_taxa,
+                         const void *d_kmer_taxa_off, void *d_counters, hipStream_t stream,
+                         int work_slot);
 int classify_host(Engine *e, const uint8_t *bases, const uint64_t *seq_offsets, uint64_t n_frag,
                   uint32_t flags, double confidence, nh_result *results, uint32_t *kmer_taxa,
                   uint64_t *kmer_taxa_offsets, uint64_t kmer_taxa_cap);

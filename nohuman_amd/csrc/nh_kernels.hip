@@ -357,7 +357,6 @@ __device__ __forceinline__ uint32_t scan_tile(KArgsP ap, WaveLdsT<STD> &S, const
     if (new0) S.q[par][qbase + ex] = mz0;
     if (new1) S.q[par][qbase + ex + (new0 ? 1u : 0u)] = mz1;
     const uint32_t r0p = ex + (new0 ? 1u : 0u);  // 1 + run index of k-mer 2t (0 = carried run)
-    const uint32_t r1p = r0p + (new1 ? 1u : 0u);
     ps = (v0 ? 1u : 0u) | (v1 ? 2u : 0u) | (new1 ? 4u : 0u) | (r0p << 3);
     {
         const uint64_t m1 = __ballot(v1), m0 = __ballot(v0);

@@ -12,7 +12,11 @@
 
 #include <algorithm>
 #include <chrono>
+#include <condition_variable>
+#include <deque>
 #include <memory>
+#include <mutex>
+#include <thread>
 #include <string>
 #include <vector>
 
@@ -42,18 +46,6 @@ struct OutFile {
         if (f) fclose(f);
     }
 };
-
-static void append_record(std::string &dst, const SeqRecord &r, const char *suffix) {
-    dst += r.header;
-    if (suffix) dst += suffix;
-    dst += '\n';
-    dst += r.seq;
-    if (r.format == FMT_FASTQ) {
-        dst += "\n+\n";
-        dst += r.quals;
-    }
-    dst += '\n';
-}
 
 // kraken2 TrimPairInfo: drop a trailing /1 or /2 from ids longer than two characters
 static void trim_pair_info(std::string &id) {
@@ -162,140 +154,453 @@ static int write_report(const Engine *e, const char *path, const std::vector<uin
     return NH_OK;
 }
 
-int run_engine(Engine *e, const nh_run_args *a, nh_stats *stats) {
+// ---- the pipeline -----------------------------------------------------------------------------------
+// reader thread(s): inflate + parse one input file each into HalfBatches (bounded queue)
+// main thread:      pair the halves, gather the sequence bytes into pinned memory, H2D + classify +
+//                   D2H asynchronously on one of two stream slots per device (batch b -> device
+//                   b mod G, database replicated per device: SURVEY.md section 8e)
+// writer thread:    format and write the outputs of finished batches in input order
+static size_t estimate_batch_frags(const char *path) {
+    BlockReader r;
+    std::string err;
+    if (r.open(path, err) != 0) return 1u << 18;
+    HalfBatch hb;
+    r.next_batch(hb, 256, 64u << 20);
+    if (hb.recs.empty()) return 1u << 18;
+    uint64_t sum = 0;
+    for (const RecRef &x : hb.recs) sum += x.slen;
+    const uint64_t mean = sum / hb.recs.size() + 1;
+    uint64_t frags = (96ull << 20) / mean;
+    if (frags < 256) frags = 256;
+    if (frags > (1u << 18)) frags = 1u << 18;
+    return (size_t)frags;
+}
+
+template <class T>
+class BoundedQueue {
+public:
+    explicit BoundedQueue(size_t cap) : cap_(cap) {}
+    void push(T &&v) {
+        std::unique_lock<std::mutex> lk(mu_);
+        not_full_.wait(lk, [&] { return q_.size() < cap_ || closed_; });
+        if (closed_) return;
+        q_.push_back(std::move(v));
+        not_empty_.notify_one();
+    }
+    bool pop(T &out) {  // false when closed and drained
+        std::unique_lock<std::mutex> lk(mu_);
+        not_empty_.wait(lk, [&] { return !q_.empty() || closed_; });
+        if (q_.empty()) return false;
+        out = std::move(q_.front());
+        q_.pop_front();
+        not_full_.notify_one();
+        return true;
+    }
+    void close() {
+        std::lock_guard<std::mutex> lk(mu_);
+        closed_ = true;
+        not_empty_.notify_all();
+        not_full_.notify_all();
+    }
+
+private:
+    std::mutex mu_;
+    std::condition_variable not_full_, not_empty_;
+    std::deque<T> q_;
+    size_t cap_;
+    bool closed_ = false;
+};
+
+struct Batch {
+    std::unique_ptr<HalfBatch> h1, h2;
+    size_t n = 0;
+    int slot = -1;  // device * 2 + stream slot that carries its results
+};
+
+struct Slot {  // pinned host + device buffers of one in-flight batch
+    Engine *e = nullptr;
+    hipStream_t stream = nullptr;
+    int work_slot = 0;
+    uint8_t *h_bases = nullptr;
+    uint64_t *h_off = nullptr;
+    nh_result *h_res = nullptr;
+    uint32_t *h_taxa = nullptr;
+    uint64_t *h_taxa_off = nullptr;
+    void *d_bases = nullptr, *d_off = nullptr, *d_res = nullptr, *d_taxa = nullptr, *d_taxa_off = nullptr;
+    size_t cap_bases = 0, cap_frag = 0, cap_taxa = 0;
+    uint64_t n_taxa = 0;
+    bool busy = false;
+};
+
+static int slot_reserve(Slot &s, size_t nbases, size_t nseq, size_t nfrag, size_t ntaxa) {
+    if (hipSetDevice(s.e->device) != hipSuccess) return set_error(NH_EDEVICE, "hipSetDevice failed");
+    auto grow = [](size_t need) { return need + need / 4 + 4096; };
+    if (nbases + 64 > s.cap_bases) {
+        if (s.h_bases) (void)hipHostFree(s.h_bases);
+        if (s.d_bases) (void)hipFree(s.d_bases);
+        s.cap_bases = grow(nbases + 64);
+        if (hipHostMalloc((void **)&s.h_bases, s.cap_bases, hipHostMallocDefault) != hipSuccess ||
+            hipMalloc(&s.d_bases, s.cap_bases) != hipSuccess)
+            return set_error(NH_EOOM, "cannot allocate batch buffers (%zu bytes)", s.cap_bases);
+    }
+    if (nfrag > s.cap_frag || nseq + 1 > 2 * s.cap_frag + 1) {
+        if (s.h_off) (void)hipHostFree(s.h_off);
+        if (s.h_res) (void)hipHostFree(s.h_res);
+        if (s.h_taxa_off) (void)hipHostFree(s.h_taxa_off);
+        if (s.d_off) (void)hipFree(s.d_off);
+        if (s.d_res) (void)hipFree(s.d_res);
+        if (s.d_taxa_off) (void)hipFree(s.d_taxa_off);
+        s.cap_frag = grow(nfrag);
+        const size_t no = 2 * s.cap_frag + 2;
+        if (hipHostMalloc((void **)&s.h_off, no * 8, hipHostMallocDefault) != hipSuccess ||
+            hipHostMalloc((void **)&s.h_res, s.cap_frag * sizeof(nh_result), hipHostMallocDefault) != hipSuccess ||
+            hipHostMalloc((void **)&s.h_taxa_off, (s.cap_frag + 1) * 8, hipHostMallocDefault) != hipSuccess ||
+            hipMalloc(&s.d_off, no * 8) != hipSuccess ||
+            hipMalloc(&s.d_res, s.cap_frag * sizeof(nh_result)) != hipSuccess ||
+            hipMalloc(&s.d_taxa_off, (s.cap_frag + 1) * 8) != hipSuccess)
+            return set_error(NH_EOOM, "cannot allocate batch buffers (%zu fragments)", s.cap_frag);
+    }
+    if (ntaxa > s.cap_taxa) {
+        if (s.h_taxa) (void)hipHostFree(s.h_taxa);
+        if (s.d_taxa) (void)hipFree(s.d_taxa);
+        s.cap_taxa = grow(ntaxa);
+        if (hipHostMalloc((void **)&s.h_taxa, s.cap_taxa * 4, hipHostMallocDefault) != hipSuccess ||
+            hipMalloc(&s.d_taxa, s.cap_taxa * 4) != hipSuccess)
+            return set_error(NH_EOOM, "cannot allocate k-mer taxa buffers");
+    }
+    return NH_OK;
+}
+
+static void slot_free(Slot &s) {
+    if (!s.e) return;
+    (void)hipSetDevice(s.e->device);
+    for (void *p : {(void *)s.h_bases, (void *)s.h_off, (void *)s.h_res, (void *)s.h_taxa, (void *)s.h_taxa_off})
+        if (p) (void)hipHostFree(p);
+    for (void *p : {s.d_bases, s.d_off, s.d_res, s.d_taxa, s.d_taxa_off})
+        if (p) (void)hipFree(p);
+    if (s.stream) (void)hipStreamDestroy(s.stream);
+}
+
+struct RunState {
+    const nh_run_args *a;
+    std::vector<Engine *> engines;
+    bool paired, want_k;
+    // results of the run
+    uint64_t total = 0, classified = 0, total_bases = 0;
+    std::vector<uint64_t> call_counts;
+    // first error of any thread
+    std::mutex err_mu;
+    int err_code = NH_OK;
+    std::string err_msg;
+    void fail(int code, const std::string &msg) {
+        std::lock_guard<std::mutex> lk(err_mu);
+        if (err_code == NH_OK) {
+            err_code = code;
+            err_msg = msg;
+        }
+    }
+    bool failed() {
+        std::lock_guard<std::mutex> lk(err_mu);
+        return err_code != NH_OK;
+    }
+};
+
+static void reader_main(const char *path, BoundedQueue<std::unique_ptr<HalfBatch>> *out, RunState *rs,
+                        size_t batch_frags, size_t batch_text) {
+    BlockReader r;
+    std::string err;
+    if (r.open(path, err) != 0) {
+        rs->fail(NH_EIO, err);
+        out->close();
+        return;
+    }
+    for (;;) {
+        std::unique_ptr<HalfBatch> hb(new HalfBatch());
+        hb->text.reserve(batch_frags * 340);
+        hb->recs.reserve(batch_frags);
+        r.next_batch(*hb, batch_frags, batch_text);
+        if (!hb->error.empty()) {
+            rs->fail(NH_EIO, hb->error);
+            break;
+        }
+        const bool eof = hb->eof;
+        out->push(std::move(hb));
+        if (eof || rs->failed()) break;
+    }
+    out->close();
+}
+
+static inline void put_record(std::string &dst, const HalfBatch &hb, const RecRef &r, const char *suffix) {
+    dst.append(hb.text.data() + r.h, r.hlen);
+    if (suffix) dst += suffix;
+    dst += '\n';
+    dst.append(hb.text.data() + r.s, r.slen);
+    if (hb.format == FMT_FASTQ) {
+        dst += "\n+\n";
+        dst.append(hb.text.data() + r.q, r.qlen);
+    }
+    dst += '\n';
+}
+
+// format + write one finished batch (runs on the writer thread, batches arrive in input order)
+static int write_batch(RunState *rs, const Batch &b, const Slot &s, OutFile &o1, OutFile &o2, OutFile &ok,
+                       std::string &buf1, std::string &buf2, std::string &bufk) {
+    const nh_run_args *a = rs->a;
+    const Engine *e = s.e;
+    buf1.clear();
+    buf2.clear();
+    bufk.clear();
+    char tmp[128];
+    for (size_t i = 0; i < b.n; i++) {
+        const RecRef &r1 = b.h1->recs[i];
+        const uint32_t call = s.h_res[i].call;
+        const bool is_class = call != 0;
+        rs->total++;
+        rs->classified += is_class;
+        rs->call_counts[call] += is_class;
+        rs->total_bases += r1.slen + (rs->paired ? b.h2->recs[i].slen : 0);
+        const uint64_t ext = is_class ? e->external[call] : 0;
+        if (is_class == (a->keep_human != 0)) {
+            const char *suffix = nullptr;
+            if (is_class) {
+                snprintf(tmp, sizeof tmp, " kraken:taxid|%llu", (unsigned long long)ext);
+                suffix = tmp;
+            }
+            put_record(buf1, *b.h1, r1, suffix);
+            if (rs->paired) put_record(buf2, *b.h2, b.h2->recs[i], suffix);
+        }
+        if (rs->want_k) {
+            std::string id(b.h1->text.data() + r1.h + 1, r1.idlen);
+            if (rs->paired) trim_pair_info(id);
+            bufk += is_class ? "C\t" : "U\t";
+            bufk += id;
+            snprintf(tmp, sizeof tmp, "\t%llu\t", (unsigned long long)ext);
+            bufk += tmp;
+            if (rs->paired)
+                snprintf(tmp, sizeof tmp, "%u|%u\t", r1.slen, b.h2->recs[i].slen);
+            else
+                snprintf(tmp, sizeof tmp, "%u\t", r1.slen);
+            bufk += tmp;
+            append_hitlist(bufk, e, s.h_taxa + s.h_taxa_off[i], s.h_taxa_off[i + 1] - s.h_taxa_off[i]);
+            bufk += '\n';
+        }
+    }
+    if (!buf1.empty() && fwrite(buf1.data(), 1, buf1.size(), o1.f) != buf1.size())
+        return set_error(NH_EIO, "write error on %s", a->out1);
+    if (rs->paired && !buf2.empty() && fwrite(buf2.data(), 1, buf2.size(), o2.f) != buf2.size())
+        return set_error(NH_EIO, "write error on %s", a->out2);
+    if (rs->want_k && !bufk.empty() && fwrite(bufk.data(), 1, bufk.size(), ok.f) != bufk.size())
+        return set_error(NH_EIO, "write error on %s", a->kraken_output);
+    return NH_OK;
+}
+
+int run_engines(const std::vector<Engine *> &engines, const nh_run_args *a, nh_stats *stats) {
     if (!a || !a->in1 || !a->out1) return set_error(NH_EINVAL, "nh_run: in1 and out1 are required");
-    const bool paired = a->in2 != nullptr;
-    if (paired && !a->out2) return set_error(NH_EINVAL, "nh_run: paired input needs out2");
+    if (engines.empty()) return set_error(NH_EINVAL, "nh_run: no engine");
+    RunState rs;
+    rs.a = a;
+    rs.engines = engines;
+    rs.paired = a->in2 != nullptr;
+    if (rs.paired && !a->out2) return set_error(NH_EINVAL, "nh_run: paired input needs out2");
     if (!(a->confidence >= 0.0 && a->confidence <= 1.0))
         return set_error(NH_EINVAL, "Confidence score must be in the closed interval [0, 1]");
-    const bool want_k =
-        a->kraken_output && a->kraken_output[0] && strcmp(a->kraken_output, "/dev/null") != 0;
-
-    std::string err;
-    FastxReader r1, r2;
-    if (r1.open(a->in1, err) != 0) return set_error(NH_EIO, "%s", err.c_str());
-    if (paired && r2.open(a->in2, err) != 0) return set_error(NH_EIO, "%s", err.c_str());
+    rs.want_k = a->kraken_output && a->kraken_output[0] && strcmp(a->kraken_output, "/dev/null") != 0;
+    rs.call_counts.assign(engines[0]->external.size(), 0);
+    for (const char *p : {a->in1, a->in2}) {  // fail on unreadable inputs before creating outputs
+        if (!p) continue;
+        FILE *f = fopen(p, "rb");
+        if (!f) return set_error(NH_EIO, "cannot open %s", p);
+        fclose(f);
+    }
     OutFile o1, o2, ok;
     int rc;
     if ((rc = o1.open(a->out1))) return rc;
-    if (paired && (rc = o2.open(a->out2))) return rc;
-    if (want_k && (rc = ok.open(a->kraken_output))) return rc;
+    if (rs.paired && (rc = o2.open(a->out2))) return rc;
+    if (rs.want_k && (rc = ok.open(a->kraken_output))) return rc;
 
-    const size_t BATCH_FRAGS = 1u << 18;
-    const size_t BATCH_BYTES = 256u << 20;
-    std::vector<SeqRecord> recs1(BATCH_FRAGS), recs2(paired ? BATCH_FRAGS : 0);
-    std::vector<uint8_t> bases;
-    std::vector<uint64_t> offsets;
-    std::vector<nh_result> results;
-    std::vector<uint32_t> taxa;
-    std::vector<uint64_t> taxa_off;
-    std::string buf1, buf2, bufk;
-    uint64_t total = 0, classified = 0, total_bases = 0;
-    std::vector<uint64_t> call_counts(e->external.size(), 0);  // fragments called at each taxon
-    const uint32_t flags = paired ? NH_FLAG_PAIRED : 0;
+    // fragments per batch: ~96 MB of sequence, at most 262144; both readers cut at the same record
+    // count so that paired batches stay aligned (a byte budget only cuts single-end batches)
+    const size_t BATCH_FRAGS = estimate_batch_frags(a->in1);
+    const size_t BATCH_TEXT = rs.paired ? (size_t)-1 : (size_t)(512u << 20);
+    const int G = (int)engines.size();
+    const int mates = rs.paired ? 2 : 1;
+    const uint32_t flags = rs.paired ? NH_FLAG_PAIRED : 0;
     auto t0 = std::chrono::steady_clock::now();
-    bool done = false;
-    while (!done) {
-        size_t n = 0;
-        bases.clear();
-        offsets.clear();
-        offsets.push_back(0);
-        while (n < BATCH_FRAGS && bases.size() < BATCH_BYTES) {
-            int g1 = r1.next(recs1[n], err);
-            if (g1 < 0) return set_error(NH_EIO, "%s", err.c_str());
-            if (g1 == 0) {
-                done = true;
+
+    std::vector<Slot> slots(2 * G);
+    for (int i = 0; i < 2 * G; i++) {
+        slots[i].e = engines[i / 2];
+        slots[i].work_slot = i & 1;
+        if (hipSetDevice(slots[i].e->device) != hipSuccess ||
+            hipStreamCreateWithFlags(&slots[i].stream, hipStreamNonBlocking) != hipSuccess) {
+            for (auto &s : slots) slot_free(s);
+            return set_error(NH_EDEVICE, "cannot create streams");
+        }
+    }
+
+    BoundedQueue<std::unique_ptr<HalfBatch>> q1(3), q2(3);
+    std::thread t1(reader_main, a->in1, &q1, &rs, BATCH_FRAGS, BATCH_TEXT);
+    std::thread t2;
+    if (rs.paired) t2 = std::thread(reader_main, a->in2, &q2, &rs, BATCH_FRAGS, BATCH_TEXT);
+
+    // writer: consumes batches in order; each arrives after its stream was synchronised
+    BoundedQueue<Batch> wq((size_t)(2 * G));
+    std::mutex slot_mu;
+    std::condition_variable slot_cv;
+    std::thread tw([&] {
+        std::string buf1, buf2, bufk;
+        Batch b;
+        while (wq.pop(b)) {
+            Slot &s = slots[b.slot];
+            if (!rs.failed()) {
+                (void)hipSetDevice(s.e->device);
+                hipError_t he = hipStreamSynchronize(s.stream);
+                int wrc = NH_OK;
+                if (he != hipSuccess) wrc = set_error(NH_EDEVICE, "classify: %s", hipGetErrorString(he));
+                if (!wrc) wrc = check_error_flag(s.e);
+                if (!wrc) wrc = write_batch(&rs, b, s, o1, o2, ok, buf1, buf2, bufk);
+                if (wrc) rs.fail(wrc, g_last_error);
+            }
+            {
+                std::lock_guard<std::mutex> lk(slot_mu);
+                s.busy = false;
+            }
+            slot_cv.notify_all();
+        }
+    });
+
+    // main: pair halves, stage, launch
+    std::unique_ptr<HalfBatch> carry1, carry2;
+    uint64_t batch_no = 0;
+    bool end1 = false, end2 = false;
+    for (;;) {
+        if (rs.failed()) break;
+        Batch b;
+        if (!q1.pop(b.h1)) break;
+        end1 = b.h1->eof;
+        if (rs.paired) {
+            if (!q2.pop(b.h2)) break;
+            end2 = b.h2->eof;
+        }
+        // kraken2 reads the files in lockstep and stops at the shorter one; both readers cut
+        // batches at the same record count, so only the last batch can differ in length
+        b.n = b.h1->recs.size();
+        if (rs.paired && b.h2->recs.size() < b.n) b.n = b.h2->recs.size();
+        const bool last = end1 || (rs.paired && end2) ||
+                          (rs.paired && b.h1->recs.size() != b.h2->recs.size());
+        if (b.n > 0) {
+            const int si = (int)(batch_no % (uint64_t)(2 * G));
+            Slot &s = slots[si];
+            {
+                std::unique_lock<std::mutex> lk(slot_mu);
+                slot_cv.wait(lk, [&] { return !s.busy; });
+                s.busy = true;
+            }
+            b.slot = si;
+            size_t nbases = 0;
+            for (size_t i = 0; i < b.n; i++)
+                nbases += b.h1->recs[i].slen + (rs.paired ? b.h2->recs[i].slen : 0);
+            uint64_t ntaxa = 0;
+            if (rs.want_k) {
+                const uint64_t k = s.e->info.k;
+                for (size_t i = 0; i < b.n; i++) {
+                    const uint64_t l1 = b.h1->recs[i].slen;
+                    ntaxa += l1 >= k ? l1 - k + 1 : 0;
+                    if (rs.paired) {
+                        const uint64_t l2 = b.h2->recs[i].slen;
+                        ntaxa += (l2 >= k ? l2 - k + 1 : 0) + 1;
+                    }
+                }
+            }
+            rc = slot_reserve(s, nbases, b.n * mates, b.n, ntaxa + 1);
+            if (rc) {
+                rs.fail(rc, g_last_error);
+                wq.push(std::move(b));
                 break;
             }
-            if (paired) {
-                int g2 = r2.next(recs2[n], err);
-                if (g2 < 0) return set_error(NH_EIO, "%s", err.c_str());
-                if (g2 == 0) {
-                    done = true;
-                    break;
+            // gather the sequence bytes of the batch into pinned memory
+            uint64_t off = 0, toff = 0;
+            const uint64_t k = s.e->info.k;
+            for (size_t i = 0; i < b.n; i++) {
+                const RecRef &r1 = b.h1->recs[i];
+                s.h_off[i * mates] = off;
+                memcpy(s.h_bases + off, b.h1->text.data() + r1.s, r1.slen);
+                off += r1.slen;
+                if (rs.want_k) {
+                    s.h_taxa_off[i] = toff;
+                    toff += r1.slen >= k ? r1.slen - k + 1 : 0;
+                }
+                if (rs.paired) {
+                    const RecRef &r2 = b.h2->recs[i];
+                    s.h_off[i * mates + 1] = off;
+                    memcpy(s.h_bases + off, b.h2->text.data() + r2.s, r2.slen);
+                    off += r2.slen;
+                    if (rs.want_k) toff += (r2.slen >= k ? r2.slen - k + 1 : 0) + 1;
                 }
             }
-            bases.insert(bases.end(), recs1[n].seq.begin(), recs1[n].seq.end());
-            offsets.push_back(bases.size());
-            if (paired) {
-                bases.insert(bases.end(), recs2[n].seq.begin(), recs2[n].seq.end());
-                offsets.push_back(bases.size());
+            s.h_off[b.n * mates] = off;
+            memset(s.h_bases + off, 'A', 64);
+            if (rs.want_k) s.h_taxa_off[b.n] = toff;
+            s.n_taxa = toff;
+            // H2D, classify, D2H: all asynchronous on the slot's stream
+            hipError_t he = hipSetDevice(s.e->device);
+            if (he == hipSuccess)
+                he = hipMemcpyAsync(s.d_bases, s.h_bases, off + 64, hipMemcpyHostToDevice, s.stream);
+            if (he == hipSuccess)
+                he = hipMemcpyAsync(s.d_off, s.h_off, (b.n * mates + 1) * 8, hipMemcpyHostToDevice, s.stream);
+            if (he == hipSuccess && rs.want_k)
+                he = hipMemcpyAsync(s.d_taxa_off, s.h_taxa_off, (b.n + 1) * 8, hipMemcpyHostToDevice, s.stream);
+            if (he != hipSuccess) {
+                rs.fail(NH_EDEVICE, std::string("H2D: ") + hipGetErrorString(he));
+            } else {
+                rc = classify_device_slot(s.e, s.d_bases, s.d_off, b.n, flags, a->confidence, s.d_res,
+                                          rs.want_k ? s.d_taxa : nullptr, rs.want_k ? s.d_taxa_off : nullptr,
+                                          s.e->d_counters, s.stream, s.work_slot);
+                if (rc) rs.fail(rc, g_last_error);
             }
-            n++;
-        }
-        if (n == 0) break;
-        results.resize(n);
-        uint64_t ntaxa = 0;
-        if (want_k) {
-            ntaxa = kmer_taxa_entries(e, offsets.data(), n, paired ? 2 : 1, nullptr);
-            taxa.resize(ntaxa + 1);
-            taxa_off.resize(n + 1);
-        }
-        rc = classify_host(e, bases.data(), offsets.data(), n, flags, a->confidence, results.data(),
-                           want_k ? taxa.data() : nullptr, want_k ? taxa_off.data() : nullptr,
-                           ntaxa + 1);
-        if (rc) return rc;
-        buf1.clear();
-        buf2.clear();
-        bufk.clear();
-        char tmp[128];
-        for (size_t i = 0; i < n; i++) {
-            const uint32_t call = results[i].call;
-            const bool is_class = call != 0;
-            total++;
-            classified += is_class;
-            call_counts[call] += is_class;
-            total_bases += recs1[i].seq.size() + (paired ? recs2[i].seq.size() : 0);
-            const uint64_t ext = is_class ? e->external[call] : 0;
-            if (is_class == (a->keep_human != 0)) {
-                const char *suffix = nullptr;
-                if (is_class) {
-                    snprintf(tmp, sizeof tmp, " kraken:taxid|%llu", (unsigned long long)ext);
-                    suffix = tmp;
-                }
-                append_record(buf1, recs1[i], suffix);
-                if (paired) append_record(buf2, recs2[i], suffix);
+            if (!rs.failed()) {
+                he = hipMemcpyAsync(s.h_res, s.d_res, b.n * sizeof(nh_result), hipMemcpyDeviceToHost, s.stream);
+                if (he == hipSuccess && rs.want_k && toff)
+                    he = hipMemcpyAsync(s.h_taxa, s.d_taxa, toff * 4, hipMemcpyDeviceToHost, s.stream);
+                if (he != hipSuccess) rs.fail(NH_EDEVICE, std::string("D2H: ") + hipGetErrorString(he));
             }
-            if (want_k) {
-                std::string id = recs1[i].id;
-                if (paired) trim_pair_info(id);
-                bufk += is_class ? "C\t" : "U\t";
-                bufk += id;
-                snprintf(tmp, sizeof tmp, "\t%llu\t", (unsigned long long)ext);
-                bufk += tmp;
-                if (paired)
-                    snprintf(tmp, sizeof tmp, "%zu|%zu\t", recs1[i].seq.size(), recs2[i].seq.size());
-                else
-                    snprintf(tmp, sizeof tmp, "%zu\t", recs1[i].seq.size());
-                bufk += tmp;
-                append_hitlist(bufk, e, taxa.data() + taxa_off[i], taxa_off[i + 1] - taxa_off[i]);
-                bufk += '\n';
-            }
+            batch_no++;
+            wq.push(std::move(b));
         }
-        if (!buf1.empty() && fwrite(buf1.data(), 1, buf1.size(), o1.f) != buf1.size())
-            return set_error(NH_EIO, "write error on %s", a->out1);
-        if (paired && !buf2.empty() && fwrite(buf2.data(), 1, buf2.size(), o2.f) != buf2.size())
-            return set_error(NH_EIO, "write error on %s", a->out2);
-        if (want_k && !bufk.empty() && fwrite(bufk.data(), 1, bufk.size(), ok.f) != bufk.size())
-            return set_error(NH_EIO, "write error on %s", a->kraken_output);
+        if (last) break;
     }
+    // shut the pipeline down (also on errors): unblock readers, drain the writer
+    q1.close();
+    q2.close();
+    wq.close();
+    t1.join();
+    if (t2.joinable()) t2.join();
+    tw.join();
+    for (auto &s : slots) slot_free(s);
+    if (rs.err_code != NH_OK) return set_error(rs.err_code, "%s", rs.err_msg.c_str());
+
     if (a->report && a->report[0] &&
-        (rc = write_report(e, a->report, call_counts, total, total - classified)))
+        (rc = write_report(engines[0], a->report, rs.call_counts, rs.total, rs.total - rs.classified)))
         return rc;
     if ((rc = o1.close())) return rc;
-    if (paired && (rc = o2.close())) return rc;
-    if (want_k && (rc = ok.close())) return rc;
+    if (rs.paired && (rc = o2.close())) return rc;
+    if (rs.want_k && (rc = ok.close())) return rc;
     if (stats) {
         nh_stats st;
         memset(&st, 0, sizeof st);
-        st.total_sequences = total;
-        st.classified = classified;
-        st.unclassified = total - classified;
-        st.total_bases = total_bases;
+        st.total_sequences = rs.total;
+        st.classified = rs.classified;
+        st.unclassified = rs.total - rs.classified;
+        st.total_bases = rs.total_bases;
         st.seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
         *stats = st;
     }
     return NH_OK;
+}
+
+int run_engine(Engine *e, const nh_run_args *a, nh_stats *stats) {
+    std::vector<Engine *> v{e};
+    return run_engines(v, a, stats);
 }
 
 }  // namespace nh
@@ -307,14 +612,30 @@ int nh_run_engine(nh_engine *e, const nh_run_args *args, nh_stats *stats) {
     return nh::run_engine((nh::Engine *)e, args, stats);
 }
 
+// Whole run on one or several devices: the database is loaded into every device's HBM, batches go
+// round-robin, outputs stay in input order, the counts are summed on the host.
 int nh_run(const nh_run_args *args, nh_stats *stats) {
     if (!args || !args->db_dir) return nh::set_error(NH_EINVAL, "nh_run: db_dir is required");
-    int device = (args->device_ids && args->n_devices > 0) ? args->device_ids[0] : 0;
-    nh::Engine *e = nullptr;
-    int rc = nh::open_dir(args->db_dir, device, &e);
-    if (rc) return rc;
-    rc = nh::run_engine(e, args, stats);
-    nh::destroy(e);
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+        return nh::set_error(NH_EDEVICE, "no HIP device available");
+    std::vector<int> devs;
+    if (args->device_ids && args->n_devices > 0)
+        devs.assign(args->device_ids, args->device_ids + args->n_devices);
+    else
+        for (int i = 0; i < (args->n_devices > 0 ? args->n_devices : ndev); i++) devs.push_back(i);
+    std::vector<nh::Engine *> engines;
+    int rc = NH_OK;
+    for (int d : devs) {
+        nh::Engine *e = nullptr;
+        rc = nh::open_dir(args->db_dir, d, &e);
+        if (rc) break;
+        engines.push_back(e);
+    }
+    if (!rc) rc = nh::run_engines(engines, args, stats);
+    std::string keep = nh::g_last_error;
+    for (nh::Engine *e : engines) nh::destroy(e);
+    if (rc) nh::g_last_error = keep;
     return rc;
 }
 
