@@ -41,6 +41,12 @@ def main():
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the CPU baseline leg")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--confidence", type=float, default=0.0)
+    ap.add_argument("--hit-frac", type=float, default=0.0,
+                    help="fraction of the fragments of every batch made 'human': their minimizers are "
+                         "inserted into the table before the timed region, then 1%% of their bases mutated")
+    ap.add_argument("--ont", action="store_true",
+                    help="config[3] shape: single-end long reads, length ~ lognormal(8.8, 0.85) in "
+                         "[200, 200000] (N50 ~ 10 kb); --pairs = number of reads")
     args = ap.parse_args()
 
     import numpy as np
@@ -61,33 +67,54 @@ def main():
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         dist.init_process_group("nccl", device_id=dev)
 
-    paired = not args.single_end
+    paired = not (args.single_end or args.ont)
     mates = 2 if paired else 1
     n_frag = args.pairs
     L = args.read_len
 
     # ---- database: synthetic HPRC.r2-like table built directly in this GPU's HBM -------------
     n_keys = int(args.capacity * args.load)
+    if args.hit_frac > 0:  # leave room for the minimizers of the "human" reads: final load = --load
+        n_keys = max(1, n_keys - int(args.hit_frac * args.pairs * (1 if (args.single_end or args.ont) else 2)
+                                     * 39.0 * args.read_len / 150.0 * args.pool))
     t0 = time.time()
     eng = Engine.synthetic(args.capacity, n_keys, depth=30, seed=20250101, device=local_rank)
-    info = eng.info
     t_db = time.time() - t0
 
     # ---- synthetic batches resident in HBM (iid uniform ACGT) -----------
     acgt = torch.tensor([65, 67, 71, 84], dtype=torch.uint8, device=dev)
     n_seq = n_frag * mates
-    offsets = (torch.arange(n_seq + 1, dtype=torch.int64, device=dev) * L).contiguous()
+    if args.ont:
+        g0 = torch.Generator(device=dev)
+        g0.manual_seed(4)
+        lens = torch.exp(torch.randn(n_seq, generator=g0, device=dev, dtype=torch.float64) * 0.85 + 8.8)
+        lens = lens.clamp(200, 200000).to(torch.int64)
+        offsets = torch.zeros(n_seq + 1, dtype=torch.int64, device=dev)
+        offsets[1:] = torch.cumsum(lens, 0)
+        offsets = offsets.contiguous()
+    else:
+        offsets = (torch.arange(n_seq + 1, dtype=torch.int64, device=dev) * L).contiguous()
+    total_bases = int(offsets[-1].item())
     pool = []
     for b in range(args.pool):
         g = torch.Generator(device=dev)
         g.manual_seed(1000 * (rank + 1) + b)
-        idx = torch.randint(0, 4, (n_seq * L + 64,), generator=g, device=dev, dtype=torch.int64)
+        idx = torch.randint(0, 4, (total_bases + 64,), generator=g, device=dev, dtype=torch.int64)
         bases = acgt[idx].contiguous()
         del idx
         if args.n_rate > 0:
             m = torch.rand(bases.shape, generator=g, device=dev) < args.n_rate
             bases[m] = 78
+        if args.hit_frac > 0:
+            n_hit_seq = int(args.hit_frac * n_frag) * mates
+            if n_hit_seq:
+                eng.add_sequences(bases.data_ptr(), offsets.data_ptr(), n_hit_seq, 30)
+                hit_end = int(offsets[n_hit_seq].item())
+                m = torch.rand(hit_end, generator=g, device=dev) < 0.01
+                sub = acgt[torch.randint(0, 4, (hit_end,), generator=g, device=dev)]
+                bases[:hit_end] = torch.where(m, sub, bases[:hit_end])
         pool.append(bases)
+    info = eng.info  # after the inserts: size / capacity is the realised load factor
     results = torch.empty((n_frag, 4), dtype=torch.int32, device=dev)
     counters = torch.zeros(4, dtype=torch.int64, device=dev)
     stream = torch.cuda.current_stream()
@@ -131,7 +158,7 @@ def main():
     achieved = alg_bytes_launch / (kernel_ms * 1e-3) / 1e9 if kernel_ms > 0 else 0.0
 
     out = {
-        "metric": "Mreads/sec classified (HPRC.r2 DB, 150bp PE)",
+        "metric": "Mreads/sec classified (HPRC.r2 DB, 150bp PE)" if not args.ont else "Mreads/sec classified (ONT)",
         "value": round(value, 3),
         "unit": "Mreads/s",
         "n_gpus": world,
@@ -144,7 +171,9 @@ def main():
         "dtype": "u64",
         "data": "synthetic",
         "config": {
-            "workload": ("%d x %d bp %s reads per step per GPU, iid uniform ACGT, resident in HBM; "
+            "workload": (("ONT-like long reads (lognormal, %d bases per step), " % total_bases if args.ont else "")
+                         + ("hit fraction %.2f, " % args.hit_frac if args.hit_frac else "") +
+                         "%d x %d bp %s reads per step per GPU, iid uniform ACGT, resident in HBM; "
                          "synthetic HPRC.r2-like hash table (capacity %d cells = %.2f GB, load %.2f, "
                          "k=%d l=%d) replicated per GPU; confidence %g"
                          % (n_frag * mates, L, "paired-end" if paired else "single-end",
@@ -163,7 +192,7 @@ def main():
             "peak": HBM_PEAK_GBS,
             "unit": "GB/s",
             "frac": round(achieved / HBM_PEAK_GBS, 4),
-            "traffic": measured_traffic(n_frag, paired, L, info.capacity),
+            "traffic": measured_traffic(n_frag, paired, L, info.capacity, bool(args.ont or args.hit_frac or args.n_rate)),
             "kernel": "k_classify",
             "kernel_ms": round(kernel_ms, 4),
             "algorithmic_bytes_per_launch": int(alg_bytes_launch),
@@ -172,7 +201,7 @@ def main():
 
     # ---- CPU baseline: the oracle on the host cores, bounded sample (rank 0, N=1 only) --------
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        out["cpu_baseline"] = cpu_baseline(eng, pool[0], L, mates, paired, args, np, results, step)
+        out["cpu_baseline"] = cpu_baseline(eng, pool[0], offsets, mates, paired, args, np, results, step)
     if rank == 0:
         print(json.dumps(out), flush=True)
     eng.close()
@@ -180,7 +209,7 @@ def main():
         dist.destroy_process_group()
 
 
-def measured_traffic(n_frag, paired, read_len, capacity):
+def measured_traffic(n_frag, paired, read_len, capacity, variant=False):
     """HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/traffic.json), if
     they were taken on exactly this workload; null otherwise.  bench.py cannot host the counter
     passes itself: the guide requires them in separate profiler runs."""
@@ -190,12 +219,14 @@ def measured_traffic(n_frag, paired, read_len, capacity):
     except (OSError, ValueError):
         return None
     key = {"fragments_per_step": n_frag, "paired": paired, "read_len": read_len, "capacity": capacity}
+    if variant:
+        return None
     if t.get("workload") != key:
         return None
     return t.get("traffic_bytes_per_launch")
 
 
-def cpu_baseline(eng, bases_dev, L, mates, paired, args, np, results, step):
+def cpu_baseline(eng, bases_dev, offsets_dev, mates, paired, args, np, results, step):
     """Times oracle/k2_oracle.c (pthreads, all host cores) on the first fragments of batch 0 with
     the very same table (downloaded from HBM), and checks the GPU results on that sample."""
     from oracle import oracle as orc
@@ -214,8 +245,9 @@ def cpu_baseline(eng, bases_dev, L, mates, paired, args, np, results, step):
     outs = []
     while done < n_frag and spent < args.cpu_seconds:
         n = min(chunk, n_frag - done)
-        host = bases_dev[done * mates * L:(done + n) * mates * L].cpu().numpy()
-        offs = (np.arange(n * mates + 1, dtype=np.uint64) * L)
+        o = offsets_dev[done * mates:(done + n) * mates + 1].cpu().numpy().astype(np.uint64)
+        host = bases_dev[int(o[0]):int(o[-1])].cpu().numpy()
+        offs = o - o[0]
         t0 = time.perf_counter()
         exp, _ = odb.classify(host, offs, paired, args.confidence, threads=cores)
         spent += time.perf_counter() - t0

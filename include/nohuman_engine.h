@@ -108,6 +108,11 @@ int nh_open_images(const void *opts, size_t opts_len, const void *taxo, size_t t
  * downloaded on the build or GPU boxes. */
 int nh_open_synthetic(uint64_t capacity, uint64_t n_keys, uint32_t depth, uint64_t seed, int device,
                       nh_engine **out);
+/* Bench/test support: inserts every minimizer of the given device-resident sequences into the
+ * table with internal taxon id `value` (kraken2 build semantics: CompareAndSet, linear probing), so
+ * that reads drawn from them hit.  Default k=35/l=31 geometry only. */
+int nh_synthetic_add_sequences(nh_engine *e, const void *d_bases, const void *d_seq_offsets,
+                               uint64_t n_seq, uint32_t value, void *stream);
 int nh_close(nh_engine *e);
 
 int nh_db_info_get(const nh_engine *e, nh_db_info *info);

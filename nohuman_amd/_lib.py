@@ -54,6 +54,7 @@ SYMBOLS = {
                                  C.POINTER(_P)]),
     "nh_open_synthetic": (C.c_int, [C.c_uint64, C.c_uint64, C.c_uint32, C.c_uint64, C.c_int,
                                     C.POINTER(_P)]),
+    "nh_synthetic_add_sequences": (C.c_int, [_P, _P, _P, C.c_uint64, C.c_uint32, _P]),
     "nh_close": (C.c_int, [_P]),
     "nh_db_info_get": (C.c_int, [_P, C.POINTER(nh_db_info)]),
     "nh_options_get": (C.c_int, [_P, C.POINTER(nh_options)]),

@@ -144,6 +144,8 @@ static void finish_devdb(Engine *e) {
     d.max_chunks = i.capacity + 1 > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)(i.capacity + 1);
 }
 
+void finish_devdb_public(Engine *e) { finish_devdb(e); }
+
 static int alloc_table(Engine *e, uint64_t capacity) {
     // padded so that 16-byte chunk loads at the end of the table stay in bounds
     e->table_cells_alloc = ((capacity + 3) & ~3ull) + 32;
@@ -564,6 +566,7 @@ int classify_host(Engine *e, const uint8_t *bases, const uint64_t *seq_offsets, 
 // ------------------------------------------------------------------------------------------------
 using nh::Engine;
 using nh::set_error;
+using nh::finish_devdb_public;
 
 extern "C" {
 
@@ -698,6 +701,29 @@ int nh_classify_batch_device(nh_engine *e_, const void *d_bases, const void *d_s
     if (!e || !d_bases || !d_seq_offsets || !d_results) return set_error(NH_EINVAL, "null argument");
     return nh::classify_device(e, d_bases, d_seq_offsets, n_frag, flags, confidence, d_results,
                                d_kmer_taxa, d_kmer_taxa_offsets, d_counters, (hipStream_t)stream);
+}
+
+int nh_synthetic_add_sequences(nh_engine *e_, const void *d_bases, const void *d_seq_offsets,
+                               uint64_t n_seq, uint32_t value, void *stream) {
+    Engine *e = (Engine *)e_;
+    if (!e || !d_bases || !d_seq_offsets) return set_error(NH_EINVAL, "null argument");
+    if (value == 0 || value >= e->info.node_count) return set_error(NH_EINVAL, "value is not a taxon id");
+    std::lock_guard<std::mutex> lock(e->mu);
+    HIP_TRY(hipSetDevice(e->device));
+    finish_devdb_public(e);
+    unsigned long long *d_ins = nullptr, ins = 0;
+    HIP_TRY(hipMalloc((void **)&d_ins, 8));
+    HIP_TRY(hipMemsetAsync(d_ins, 0, 8, (hipStream_t)stream));
+    hipError_t he = nh::launch_insert_sequences(e->dev, d_bases, d_seq_offsets, n_seq, value, d_ins,
+                                                e->grid_blocks, (hipStream_t)stream);
+    if (he == hipSuccess) he = hipStreamSynchronize((hipStream_t)stream);
+    if (he == hipSuccess) he = hipMemcpy(&ins, d_ins, 8, hipMemcpyDeviceToHost);
+    (void)hipFree(d_ins);
+    if (he != hipSuccess)
+        return set_error(NH_EDEVICE, "insert sequences (default k=35/l=31 linear-probing DBs only): %s",
+                         hipGetErrorString(he));
+    e->info.size += ins;
+    return NH_OK;
 }
 
 int nh_stats_get(nh_engine *e_, nh_stats *s) {

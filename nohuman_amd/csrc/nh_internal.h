@@ -50,6 +50,9 @@ hipError_t launch_classify(const DevDB &db, const void *d_bases, const void *d_s
                            int *d_error, unsigned long long *d_work, uint32_t frag_chunk,
                            int grid_blocks, hipStream_t stream);
 int classify_blocks_per_cu();
+hipError_t launch_insert_sequences(const DevDB &db, const void *d_bases, const void *d_seq_off,
+                                   uint64_t n_seq, uint32_t value, unsigned long long *d_inserted,
+                                   int grid_blocks, hipStream_t stream);
 hipError_t launch_synth_insert(uint32_t *table, uint64_t capacity, uint64_t cap_magic,
                                uint32_t value_bits, uint32_t value, uint64_t n_keys, uint64_t seed,
                                uint64_t key_mask, unsigned long long *d_size, hipStream_t stream);
@@ -60,6 +63,7 @@ int open_images(const void *opts, size_t opts_len, const void *taxo, size_t taxo
 int open_synthetic(uint64_t capacity, uint64_t n_keys, uint32_t depth, uint64_t seed, int device,
                    Engine **out);
 void destroy(Engine *e);
+void finish_devdb_public(Engine *e);
 int resolve_db_dir(const char *db_dir, std::string &resolved);
 int classify_device(Engine *e, const void *d_bases, const void *d_seq_off, uint64_t n_frag,
                     uint32_t flags, double confidence, void *d_results, void *d_kmer_taxa,

@@ -26,6 +26,7 @@
 // out dynamically in chunks so that non-resident workgroups of the grid cost nothing.
 #include <hip/hip_runtime.h>
 #include <stdlib.h>
+#include <string.h>
 
 #include "nh_device.h"
 
@@ -992,6 +993,77 @@ __global__ void k_synth_insert(uint32_t *table, uint64_t capacity, uint64_t cap_
     if ((threadIdx.x & 63) == 0 && inserted) atomicAdd(size_counter, (unsigned long long)inserted);
 }
 
+// Inserts every minimizer of the given sequences into the table with a constant value (kraken2
+// build_db.cc ProcessSequence + CompareAndSet, linear probing): lets the bench put "human" reads
+// into the synthetic table so that the hit path is measured too.  Default geometry (STD) only.
+__global__ __launch_bounds__(WAVE * WAVES_PER_BLOCK) void k_insert_sequences(const KArgs args_by_kernarg_pointer,
+                                                                            const uint32_t value) {
+    KArgsP ap = (KArgsP)__builtin_amdgcn_kernarg_segment_ptr();
+    __shared__ WaveLdsT<true> lds_all[WAVES_PER_BLOCK];
+    const int lane = threadIdx.x & 63;
+    const int wib = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    WaveLdsT<true> &S = lds_all[wib];
+    if (lane < 24) {
+        S.pk[lane] = 0;
+        S.pa[lane] = 0;
+    }
+    for (int i = lane; i < CandPad<true>::value; i += 64) S.cand[TL + i] = NH_FULL;
+    wave_sync();
+    const uint32_t TQ = TL - 4u;
+    const uint64_t n_seq = ap->n_frag;
+    const uint64_t *const seq_off = ap->seq_off;
+    const uint64_t last_dw = (seq_off[n_seq] + 4) >> 2;
+    uint32_t *const table = const_cast<uint32_t *>(ap->db.table);
+    const uint64_t cap = ap->db.capacity, magic = ap->db.cap_magic;
+    const uint32_t vbits = ap->db.value_bits;
+    uint64_t prof[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    uint64_t tprev = 0;
+    unsigned long long inserted = 0;
+    const uint64_t n_waves = (uint64_t)gridDim.x * WAVES_PER_BLOCK;
+    for (uint64_t s = (uint64_t)blockIdx.x * WAVES_PER_BLOCK + wib; s < n_seq; s += n_waves) {
+        const uint64_t o0 = seq_off[s];
+        const uint32_t n = (uint32_t)(seq_off[s + 1] - o0);
+        const uint32_t nk = n >= 35u ? n - 34u : 0;
+        uint64_t carry_min = NH_FULL;
+        for (uint32_t q0 = 0; q0 < nk; q0 += TQ) {
+            const uint64_t g0 = o0 + q0;
+            uint64_t dw = (g0 >> 2) + ((uint32_t)lane < PREF_LANES ? (uint32_t)lane : PREF_LANES - 1);
+            dw = dw < last_dw ? dw : last_dw;
+            const uint32_t *wp = reinterpret_cast<const uint32_t *>(ap->bases) + dw;
+            const uint32_t w = *wp;
+            const uint32_t nl_left = (n - 31u + 1) - q0;
+            const uint32_t nlt = nl_left < (uint32_t)TL ? nl_left : (uint32_t)TL;
+            const uint32_t nq_left = nk - q0;
+            const uint32_t nqt = nq_left < TQ ? nq_left : TQ;
+            uint32_t ps, wdummy = 0;
+            int last_lane;
+            const uint32_t nruns = scan_tile<true, false>(ap, S, lane, w, (uint32_t)g0 & 3u, nlt, nqt, 0u, 0u,
+                                                          carry_min, ps, last_lane, wp, false, wdummy, prof,
+                                                          tprev);
+            wave_sync();
+            for (uint32_t r = lane; r < nruns; r += 64) {
+                const uint64_t hc = fmix64(S.q[0][r]);
+                const uint32_t compacted = (uint32_t)(hc >> (32 + vbits));
+                const uint32_t cell = (compacted << vbits) | value;
+                uint64_t idx = mod_capacity(hc, cap, magic);
+                for (uint64_t tries = 0; tries < cap; tries++) {
+                    const uint32_t old = atomicCAS(&table[idx], 0u, cell);
+                    if (old == 0) {
+                        inserted++;
+                        break;
+                    }
+                    if ((old >> vbits) == compacted) break;
+                    idx++;
+                    if (idx >= cap) idx = 0;
+                }
+            }
+            wave_sync();
+        }
+    }
+    for (int d = 32; d >= 1; d >>= 1) inserted += __shfl_xor(inserted, d, 64);
+    if (lane == 0 && inserted) atomicAdd(&ap->counters[0], inserted);
+}
+
 // ---- host-side launchers ---------------------------------------------------------------------
 static bool is_std(const DevDB &db) {
     return db.k == 35 && db.l == 31 && db.revcom_version != 0 && db.min_hash == 0;
@@ -1040,6 +1112,23 @@ hipError_t launch_classify(const DevDB &db, const void *d_bases, const void *d_s
         launch_variant<true, false, false>(ka, g, b, stream);
     else
         launch_variant<false, false, false>(ka, g, b, stream);
+    return hipGetLastError();
+}
+
+hipError_t launch_insert_sequences(const DevDB &db, const void *d_bases, const void *d_seq_off,
+                                   uint64_t n_seq, uint32_t value, unsigned long long *d_inserted,
+                                   int grid_blocks, hipStream_t stream) {
+    if (n_seq == 0) return hipSuccess;
+    if (!is_std(db) || !db.linear_probing) return hipErrorInvalidValue;
+    KArgs ka;
+    memset(&ka, 0, sizeof ka);
+    ka.db = db;
+    ka.bases = (const uint8_t *)d_bases;
+    ka.seq_off = (const uint64_t *)d_seq_off;
+    ka.n_frag = n_seq;
+    ka.counters = d_inserted;
+    hipLaunchKernelGGL(k_insert_sequences, dim3(grid_blocks), dim3(WAVE * WAVES_PER_BLOCK), 0, stream, ka,
+                       value);
     return hipGetLastError();
 }
 

@@ -177,6 +177,11 @@ class Engine:
             float(confidence), d_results, d_kmer_taxa or None, d_kmer_taxa_offsets or None,
             d_counters or None, stream or None))
 
+    def add_sequences(self, d_bases: int, d_seq_offsets: int, n_seq: int, value: int, stream: int = 0):
+        """Bench/test support: insert the minimizers of device-resident sequences into the table."""
+        _check(self._L.nh_synthetic_add_sequences(self._h, d_bases, d_seq_offsets, n_seq, value,
+                                                  stream or None))
+
     def stats(self) -> _lib.nh_stats:
         s = _lib.nh_stats()
         _check(self._L.nh_stats_get(self._h, C.byref(s)))
