@@ -34,15 +34,24 @@ namespace nh {
 
 #define NH_FULL 0xFFFFFFFFFFFFFFFFull
 #ifndef NH_PROBE_CHUNKS
-#define NH_PROBE_CHUNKS 2
+#define NH_PROBE_CHUNKS 1
 #endif
 
 // window reads of idle lanes stay inside the candidate array: k-l+2 pad entries (k-l = 4 for
 // kraken2's default geometry, <= 64 in general)
 template <bool STD> struct CandPad { static constexpr int value = STD ? 6 : 66; };
 
-constexpr int NSLOT = 2;  // tiles scanned before one shared probe phase
-constexpr int QCAP = 192;  // queue entries per group: a second tile joins only if it is sure to fit
+#ifndef NH_MIN_WAVES
+#define NH_MIN_WAVES 4
+#endif
+#ifndef NH_NSLOT
+#define NH_NSLOT 4
+#endif
+#ifndef NH_QCAP
+#define NH_QCAP 320
+#endif
+constexpr int NSLOT = NH_NSLOT;  // tiles scanned before one shared probe phase
+constexpr int QCAP = NH_QCAP;  // queue entries per group: a tile joins only if it is sure to fit (< 512)
 constexpr uint32_t QTAX_SKIP = 0xFFFFFFFFu;  // queue entry dropped by the min-hash filter
 
 struct alignas(16) SlotLds {  // a scanned tile waiting for its probe results (written by lane 0)
@@ -64,6 +73,9 @@ template <> struct QTax<true> {};
 
 template <bool STD>
 struct WaveLdsT {
+#if defined(NH_LDS_PAD) && NH_LDS_PAD > 0
+    uint32_t occupancy_pad[NH_LDS_PAD / 4];  // tuning aid: lowers the number of resident workgroups
+#endif
     unsigned long long acc[4];  // fragments, classified, bases, lookups of this wave (lane 0 adds)
     uint64_t last_dw;           // last readable dword of the bases buffer
     SlotLds slot[2][NSLOT];  // [parity of the group][tile]
@@ -465,7 +477,7 @@ __device__ __forceinline__ void probe_queue(KArgsP ap, WaveLdsT<STD> &S, const i
                         if (skip) S.qtax.v[par][my] = 0;
                     }
                     if (!skip) {
-                        r = my | (par << 8);
+                        r = my | (par << 9);
                         budget = max_rounds;
                         if (LINEAR) {
                             if (CAP32) {
@@ -489,7 +501,8 @@ __device__ __forceinline__ void probe_queue(KArgsP ap, WaveLdsT<STD> &S, const i
             }
         }
         // done when the queue is handed out and no lane still works for the previous group
-        if (qhead >= qn && __ballot(busy != 0 && (r >> 8) != par) == 0) break;
+        if (qhead >= qn && __ballot(busy != 0 && (r >> 9) != par) == 0) break;
+        if (PROF) prof[11] += 1;  // probe rounds executed (not cycles)
         if (busy) {
             if (LINEAR) {
                 // One round: the 4*PC cells from `pos` on (unaligned 16-byte loads), of which only
@@ -512,27 +525,44 @@ __device__ __forceinline__ void probe_queue(KArgsP ap, WaveLdsT<STD> &S, const i
                     src = table + pos;
                 }
                 nvalid = nvalid < 4u * PC ? nvalid : 4u * PC;
-                const uint32_t last_chunk = (nvalid - 1) >> 2;
-                uint4 c[PC];
+                uint32_t res = 0, resj = 4 * PC, lo = 0;
+                if constexpr (PC == 1) {
+                    // one 16-byte load that must not leave the line: if fewer than 4 cells remain
+                    // it starts up to 3 cells early and those are skipped (a load across the line
+                    // end would cost a second fabric request for cells that do not count)
+                    lo = in_line < 4u ? 4u - in_line : 0u;
+                    const uint4 cq = *reinterpret_cast<const uint4 *>(src - lo);
+                    const uint32_t cells[4] = {cq.x, cq.y, cq.z, cq.w};
 #pragma unroll
-                for (int qq = 0; qq < PC; qq++) {  // idle slots re-read the last useful chunk
-                    const uint32_t ch = (uint32_t)qq < last_chunk ? (uint32_t)qq : last_chunk;
-                    c[qq] = *reinterpret_cast<const uint4 *>(src + 4 * ch);
-                }
-                uint32_t res = 0, resj = 4 * PC;
+                    for (int j = 3; j >= 0; j--) {  // lowest eligible stopping cell wins
+                        const uint32_t cell = cells[j];
+                        const uint32_t x = cell ^ ckey;  // key bits vanish on a match
+                        const bool stop = ((uint32_t)j >= lo) & ((x <= vmask) | ((cell & vmask) == 0));
+                        res = stop ? x : res;
+                        resj = stop ? (uint32_t)j : resj;
+                    }
+                } else {
+                    const uint32_t last_chunk = (nvalid - 1) >> 2;
+                    uint4 c[PC];
 #pragma unroll
-                for (int j = 4 * PC - 1; j >= 0; j--) {  // lowest stopping cell wins
-                    const uint4 &cq = c[j >> 2];
-                    const uint32_t cell =
-                        (j & 3) == 0 ? cq.x : (j & 3) == 1 ? cq.y : (j & 3) == 2 ? cq.z : cq.w;
-                    const uint32_t x = cell ^ ckey;  // key bits vanish on a match
-                    const bool stop = (x <= vmask) | ((cell & vmask) == 0);
-                    res = stop ? x : res;
-                    resj = stop ? (uint32_t)j : resj;
+                    for (int qq = 0; qq < PC; qq++) {  // idle slots re-read the last useful chunk
+                        const uint32_t ch = (uint32_t)qq < last_chunk ? (uint32_t)qq : last_chunk;
+                        c[qq] = *reinterpret_cast<const uint4 *>(src + 4 * ch);
+                    }
+#pragma unroll
+                    for (int j = 4 * PC - 1; j >= 0; j--) {  // lowest stopping cell wins
+                        const uint4 &cq = c[j >> 2];
+                        const uint32_t cell =
+                            (j & 3) == 0 ? cq.x : (j & 3) == 1 ? cq.y : (j & 3) == 2 ? cq.z : cq.w;
+                        const uint32_t x = cell ^ ckey;  // key bits vanish on a match
+                        const bool stop = (x <= vmask) | ((cell & vmask) == 0);
+                        res = stop ? x : res;
+                        resj = stop ? (uint32_t)j : resj;
+                    }
                 }
                 // a re-read chunk repeats cells of an earlier one: its stops can only come after
                 // an identical earlier stop, so resj < nvalid is exact
-                const bool found = resj < nvalid;
+                const bool found = resj < lo + nvalid;
                 if (CAP32) {
                     uint32_t np = (uint32_t)pos + nvalid;
                     pos = np >= (uint32_t)cap ? 0u : np;
@@ -542,7 +572,7 @@ __device__ __forceinline__ void probe_queue(KArgsP ap, WaveLdsT<STD> &S, const i
                 }
                 budget--;
                 if (found | (budget == 0)) {
-                    tax_at<STD>(S, r >> 8, r & 0xFFu) = (found && res <= vmask) ? res : 0u;
+                    tax_at<STD>(S, r >> 9, r & 0x1FFu) = (found && res <= vmask) ? res : 0u;
                     busy = 0;
                 }
             } else {
@@ -561,7 +591,7 @@ __device__ __forceinline__ void probe_queue(KArgsP ap, WaveLdsT<STD> &S, const i
                     if (pos == first_pos) end = true;
                 }
                 if (end) {
-                    tax_at<STD>(S, r >> 8, r & 0xFFu) = val;
+                    tax_at<STD>(S, r >> 9, r & 0x1FFu) = val;
                     busy = 0;
                 }
             }
@@ -689,7 +719,7 @@ constexpr uint32_t PREF_LANES = 42;  // dwords a tile can need: (3 + 128 + 30 + 
 __device__ __forceinline__ uint32_t uni(uint32_t v) { return __builtin_amdgcn_readfirstlane(v); }
 
 template <bool LINEAR, bool STD, bool CAP32, bool PROF>
-__global__ __launch_bounds__(WAVE * WAVES_PER_BLOCK, STD ? 6 : 4) void k_classify(const KArgs args_by_kernarg_pointer) {
+__global__ __launch_bounds__(WAVE * WAVES_PER_BLOCK, NH_MIN_WAVES) void k_classify(const KArgs args_by_kernarg_pointer) {
     KArgsP ap = (KArgsP)__builtin_amdgcn_kernarg_segment_ptr();
     __shared__ WaveLdsT<STD> lds_all[WAVES_PER_BLOCK];
     const int lane = threadIdx.x & 63;

@@ -26,7 +26,7 @@ c = cnt.tolist()
 ms = e0.elapsed_time(e1)
 names = ["0 ->tile start", "1 base wait+encode", "2 lmer+window(LDS)", "3 runs+compact", "4 hash pass",
          "5 probe loop", "6 post tiles", "7 end of turn", "8 ->fragment top", "9 fragment header",
-         "10 descriptor write", "11 -"]
+         "10 descriptor write", "11 probe rounds (count, not cycles)"]
 tot = sum(c[4:])
 print("kernel %.3f ms (instrumented), %d fragments, lookups %d" % (ms, c[0], c[3]))
 for i, nm in enumerate(names):
