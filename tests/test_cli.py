@@ -1,0 +1,139 @@
+"""The C++ `nohuman` host (nohuman_amd/bin/nohuman) against the reference CLI contract
+(/root/reference/src/main.rs:21-386): flags, error texts / exit codes, default output names, codec
+decision, temp-dir clean-up, log lines.  GPU-free checks first, full runs marked gpu."""
+import gzip
+import json
+import os
+import shutil
+import subprocess
+
+import pytest
+
+from tests.fastq_util import read_fastq
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+BIN = os.path.join(ROOT, "nohuman_amd", "bin", "nohuman")
+GOLD = os.path.join(ROOT, "tests", "golden")
+DB = os.path.join(GOLD, "toy_db")
+
+pytestmark = pytest.mark.skipif(not os.path.exists(BIN), reason="CLI host not built")
+
+
+def run(args, cwd=None, env=None):
+    e = dict(os.environ)
+    e.pop("NOHUMAN_DB", None)
+    if env:
+        e.update(env)
+    return subprocess.run([BIN] + args, cwd=cwd, env=e, capture_output=True, text=True)
+
+
+def test_help_lists_the_reference_flags():
+    r = run(["--help"])
+    assert r.returncode == 0
+    for flag in ("--out1", "--out2", "--check", "--download", "--db", "--db-version", "--list-db-versions",
+                 "--output-type", "--threads", "--human", "--conf", "--kraken-output", "--kraken-report",
+                 "--verbose"):
+        assert flag in r.stdout
+
+
+def test_argument_errors_exit_2(tmp_path):
+    f = tmp_path / "in.fq"
+    f.write_text("@r\nACGT\n+\nIIII\n")
+    assert run([]).returncode == 2  # INPUT required unless --check/--download/--list-db-versions
+    r = run(["-t", "0", str(f)])
+    assert r.returncode == 2 and "--threads" in r.stderr
+    r = run(["-C", "1.1", str(f)])
+    assert r.returncode == 2 and "Confidence score must be in the closed interval [0, 1]" in r.stderr
+    r = run(["-C", "abc", str(f)])
+    assert r.returncode == 2 and "Confidence score must be a number" in r.stderr
+    r = run(["-F", "q", str(f)])
+    assert r.returncode == 2 and "is not a valid output format" in r.stderr
+    r = run([str(tmp_path / "missing.fq")])
+    assert r.returncode == 2 and "does not exist" in r.stderr
+
+
+def _has_gpu():
+    return run(["-c"]).returncode == 0
+
+
+@pytest.mark.skipif(_has_gpu(), reason="checks the no-GPU failure mode")
+def test_check_fails_loudly_without_a_device():
+    r = run(["--check"])
+    assert r.returncode == 1
+    assert "The following dependencies are missing:" in r.stderr
+    assert "Error: Missing dependencies" in r.stderr
+
+
+@pytest.mark.gpu
+def test_check_ok():
+    r = run(["-c"])
+    assert r.returncode == 0
+    assert r.stderr.rstrip().endswith("INFO ] All dependencies are available")
+
+
+@pytest.mark.gpu
+def test_single_end_default_name_and_codec_from_input(tmp_path):
+    """no -o: `<stem>.nohuman.fq` beside the input, compressed like the input (main.rs:238-245,274-290)."""
+    exp = json.load(open(os.path.join(GOLD, "expected_se.json")))
+    calls = [r["by_conf"]["0.0"][0] for r in exp["records"]]
+    reads = read_fastq(os.path.join(GOLD, "reads_se.fq"))
+    inp = tmp_path / "sample.fq.gz"
+    with open(os.path.join(GOLD, "reads_se.fq"), "rb") as f, gzip.open(inp, "wb") as g:
+        g.write(f.read())
+    r = run(["-D", DB, "-t", "2", str(inp)], cwd=tmp_path)
+    assert r.returncode == 0, r.stderr
+    out = tmp_path / "sample.nohuman.fq.gz"
+    assert out.exists()
+    want = b"".join(h + b"\n" + s + b"\n+\n" + q + b"\n" for (h, _i, s, q), c in zip(reads, calls) if not c)
+    assert gzip.open(out, "rb").read() == want
+    n_class = sum(1 for c in calls if c)
+    assert "%d / %d (%.2f%%) sequences classified as human; %d (%.2f%%) as non-human" % (
+        n_class, len(calls), 100.0 * n_class / len(calls), len(calls) - n_class,
+        100.0 * (len(calls) - n_class) / len(calls)) in r.stderr
+    assert "Removing human reads..." in r.stderr and "Done." in r.stderr
+    assert not [d for d in os.listdir(tmp_path) if d.startswith("nohuman")]  # temp dir removed
+
+
+@pytest.mark.gpu
+def test_paired_keep_human_with_outputs_report_and_kraken_file(tmp_path):
+    exp = json.load(open(os.path.join(GOLD, "expected_pe.json")))
+    ext = exp["meta"]["external_ids"]
+    calls = [r["by_conf"]["0.1"][0] for r in exp["records"]]
+    r1 = read_fastq(os.path.join(GOLD, "reads_pe_1.fq"))
+    r2 = read_fastq(os.path.join(GOLD, "reads_pe_2.fq"))
+    for n in ("reads_pe_1.fq", "reads_pe_2.fq"):
+        shutil.copy(os.path.join(GOLD, n), tmp_path / n)
+    o1, o2 = tmp_path / "h_1.fq", tmp_path / "h_2.fq.gz"
+    r = run(["--db", DB, "-H", "-C", "0.1", "-t", "4", "-o", str(o1), "-O", str(o2), "-k", str(tmp_path / "k.txt"),
+             "-r", str(tmp_path / "rep.txt"), "reads_pe_1.fq", "reads_pe_2.fq"], cwd=tmp_path)
+    assert r.returncode == 0, r.stderr
+    assert "Keeping human reads..." in r.stderr
+
+    def want(reads):
+        return b"".join(h + b" kraken:taxid|%d" % ext[c] + b"\n" + s + b"\n+\n" + q + b"\n"
+                        for (h, _i, s, q), c in zip(reads, calls) if c)
+    # codec follows --out1's extension (none) for BOTH outputs, as in the reference (main.rs:240-241)
+    assert o1.read_bytes() == want(r1)
+    assert o2.read_bytes() == want(r2)
+    assert len((tmp_path / "k.txt").read_text().splitlines()) == len(calls)
+    assert (tmp_path / "rep.txt").read_text().count("\n") >= 5
+    assert "Kraken output file written to:" in r.stderr and "Kraken report file written to:" in r.stderr
+
+
+@pytest.mark.gpu
+def test_database_resolution_errors_and_env(tmp_path):
+    f = tmp_path / "in.fq"
+    f.write_text("@r\nACGT\n+\nIIII\n")
+    r = run(["-D", str(tmp_path / "nodb"), str(f)], cwd=tmp_path)
+    assert r.returncode == 1
+    assert "Database does not exist at" in r.stderr and "Run `nohuman --download` to fetch one." in r.stderr
+    r = run(["--db-version", "HPRC.r9", "-D", str(tmp_path), str(f)], cwd=tmp_path)
+    assert r.returncode == 1 and "Database version 'HPRC.r9' is not installed under" in r.stderr
+    # versioned install discovered through nohuman-db.toml; NOHUMAN_DB supplies the root
+    root = tmp_path / "dbroot"
+    shutil.copytree(DB, root / "HPRC.rX" / "db")
+    (root / "HPRC.rX" / "nohuman-db.toml").write_text('version = "HPRC.rX"\nadded = "2025-11-19"\n')
+    r = run([str(f)], cwd=tmp_path, env={"NOHUMAN_DB": str(root)})
+    assert r.returncode == 0, r.stderr
+    assert "Using database version HPRC.rX at" in r.stderr
+    assert (tmp_path / "in.nohuman.fq").exists()
