@@ -122,7 +122,7 @@ def main():
     def step(i):
         eng.classify_device(pool[i % len(pool)].data_ptr(), offsets.data_ptr(), n_frag, paired,
                             args.confidence, results.data_ptr(), counters.data_ptr(),
-                            stream.cuda_stream)
+                            stream.cuda_stream, long_reads=args.ont)
 
     def barrier():
         if world > 1:

@@ -87,6 +87,7 @@ typedef struct {
 
 /* flags of nh_classify_* */
 #define NH_FLAG_PAIRED 1u /* sequences 2f and 2f+1 are the mates of fragment f (--paired) */
+#define NH_FLAG_LONG 2u   /* scheduling hint: fragments are long (kilobases); hand them out one by one */
 
 const char *nh_last_error(void);
 int nh_abi_version(void);

@@ -486,7 +486,8 @@ int classify_device_slot(Engine *e, const void *d_bases, const void *d_seq_off, 
     hipError_t he = launch_classify(e->dev, d_bases, d_seq_off, n_frag,
                                     (flags & NH_FLAG_PAIRED) ? 2 : 1, confidence, d_results,
                                     d_kmer_taxa, d_kmer_taxa_off, d_counters, e->d_error, e->d_work + (work_slot & 1),
-                                    e->frag_chunk > 31 ? 31 : e->frag_chunk, e->grid_blocks, stream);
+                                    (flags & NH_FLAG_LONG) ? 1u : (e->frag_chunk > 31 ? 31 : e->frag_chunk), e->grid_blocks,
+                                    stream);
     if (he != hipSuccess) return set_error(NH_EDEVICE, "classify launch: %s", hipGetErrorString(he));
     return NH_OK;
 }
@@ -547,6 +548,7 @@ int classify_host(Engine *e, const uint8_t *bases, const uint64_t *seq_offsets, 
     if (total) HIP_TRY(hipMemcpyAsync(st.d_bases, bases + base0, total, hipMemcpyHostToDevice, e->stream));
     HIP_TRY(hipMemsetAsync((uint8_t *)st.d_bases + total, 'A', 64, e->stream));
     HIP_TRY(hipMemcpyAsync(st.d_offsets, offs, (n_seq + 1) * 8, hipMemcpyHostToDevice, e->stream));
+    if (total / n_frag > 2000) flags |= NH_FLAG_LONG;  // long reads: finer dynamic scheduling
     rc = classify_device(e, st.d_bases, st.d_offsets, n_frag, flags, confidence, st.d_results,
                          kmer_taxa ? st.d_taxa : nullptr, kmer_taxa ? st.d_taxa_off : nullptr,
                          e->d_counters, e->stream);

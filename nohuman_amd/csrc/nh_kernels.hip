@@ -719,7 +719,7 @@ constexpr uint32_t PREF_LANES = 42;  // dwords a tile can need: (3 + 128 + 30 + 
 __device__ __forceinline__ uint32_t uni(uint32_t v) { return __builtin_amdgcn_readfirstlane(v); }
 
 template <bool LINEAR, bool STD, bool CAP32, bool PROF>
-__global__ __launch_bounds__(WAVE * WAVES_PER_BLOCK, NH_MIN_WAVES) void k_classify(const KArgs args_by_kernarg_pointer) {
+__global__ __launch_bounds__(WAVE * WAVES_PER_BLOCK, STD ? NH_MIN_WAVES : 3) void k_classify(const KArgs args_by_kernarg_pointer) {
     KArgsP ap = (KArgsP)__builtin_amdgcn_kernarg_segment_ptr();
     __shared__ WaveLdsT<STD> lds_all[WAVES_PER_BLOCK];
     const int lane = threadIdx.x & 63;

@@ -13,6 +13,7 @@ RESULT_DTYPE = np.dtype([("call", "<u4"), ("total_kmers", "<u4"), ("clade_hits",
 TAXON_AMBIGUOUS = 0xFFFFFFFF
 TAXON_MATE_BORDER = 0xFFFFFFFE
 FLAG_PAIRED = 1
+FLAG_LONG = 2
 
 
 class EngineError(RuntimeError):
@@ -170,10 +171,11 @@ class Engine:
 
     def classify_device(self, d_bases: int, d_seq_offsets: int, n_frag: int, paired: bool,
                         confidence: float, d_results: int, d_counters: int = 0, stream: int = 0,
-                        d_kmer_taxa: int = 0, d_kmer_taxa_offsets: int = 0):
+                        d_kmer_taxa: int = 0, d_kmer_taxa_offsets: int = 0, long_reads: bool = False):
         """Device pointers in (ints), asynchronous on `stream` (a hipStream_t as int)."""
         _check(self._L.nh_classify_batch_device(
-            self._h, d_bases, d_seq_offsets, n_frag, FLAG_PAIRED if paired else 0,
+            self._h, d_bases, d_seq_offsets, n_frag,
+            (FLAG_PAIRED if paired else 0) | (FLAG_LONG if long_reads else 0),
             float(confidence), d_results, d_kmer_taxa or None, d_kmer_taxa_offsets or None,
             d_counters or None, stream or None))
 
