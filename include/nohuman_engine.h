@@ -182,6 +182,11 @@ typedef struct {
 } nh_run_args;
 
 int nh_run(const nh_run_args *args, nh_stats *stats);
+/* Host-side check of the sequence reader nh_run uses (kraken2 record semantics, SURVEY.md A.6;
+ * plain / gzip / bzip2, FASTA / FASTQ): number of records, total bases, and an FNV-1a-64 digest
+ * over every record's header line, sequence and qualities (each followed by one 0 byte).
+ * Needs no GPU. */
+int nh_fastx_scan(const char *path, uint64_t *n_records, uint64_t *n_bases, uint64_t *digest);
 /* nh_run on an already opened engine (single device) */
 int nh_run_engine(nh_engine *e, const nh_run_args *args, nh_stats *stats);
 

@@ -613,6 +613,35 @@ int nh_run_engine(nh_engine *e, const nh_run_args *args, nh_stats *stats) {
     return nh::run_engine((nh::Engine *)e, args, stats);
 }
 
+int nh_fastx_scan(const char *path, uint64_t *n_records, uint64_t *n_bases, uint64_t *digest) {
+    if (!path || !n_records || !n_bases || !digest) return nh::set_error(NH_EINVAL, "null argument");
+    nh::BlockReader r;
+    std::string err;
+    if (r.open(path, err) != 0) return nh::set_error(NH_EIO, "%s", err.c_str());
+    uint64_t n = 0, nb = 0, h = 0xcbf29ce484222325ull;
+    auto mix = [&](const char *p, size_t len) {
+        for (size_t i = 0; i < len; i++) h = (h ^ (unsigned char)p[i]) * 0x100000001b3ull;
+        h = (h ^ 0) * 0x100000001b3ull;
+    };
+    for (;;) {
+        nh::HalfBatch hb;
+        r.next_batch(hb, 4096, 64u << 20);
+        if (!hb.error.empty()) return nh::set_error(NH_EIO, "%s", hb.error.c_str());
+        for (const nh::RecRef &x : hb.recs) {
+            n++;
+            nb += x.slen;
+            mix(hb.text.data() + x.h, x.hlen);
+            mix(hb.text.data() + x.s, x.slen);
+            mix(hb.text.data() + x.q, x.qlen);
+        }
+        if (hb.eof) break;
+    }
+    *n_records = n;
+    *n_bases = nb;
+    *digest = h;
+    return NH_OK;
+}
+
 // Whole run on one or several devices: the database is loaded into every device's HBM, batches go
 // round-robin, outputs stay in input order, the counts are summed on the host.
 int nh_run(const nh_run_args *args, nh_stats *stats) {

@@ -1,0 +1,119 @@
+"""Host logic without a GPU: the FASTA/FASTQ reader of nh_run (nh_fastx_scan entry of the C ABI)
+against a plain-Python statement of kraken2's record semantics."""
+import bz2
+import ctypes as C
+import gzip
+import os
+
+import pytest
+
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def fnv(parts):
+    h = 0xcbf29ce484222325
+    for p in parts:
+        for b in p:
+            h = ((h ^ b) * 0x100000001b3) & 0xFFFFFFFFFFFFFFFF
+        h = ((h ^ 0) * 0x100000001b3) & 0xFFFFFFFFFFFFFFFF
+    return h
+
+
+def py_records(data: bytes):
+    """kraken2 BatchSequenceReader semantics, line by line (getline + StripString)."""
+    lines = data.split(b"\n")
+    if lines and lines[-1] == b"":
+        lines.pop()  # a final newline does not start another line
+    i, recs, fmt = 0, [], None
+    while i < len(lines):
+        h = lines[i].rstrip()
+        i += 1
+        if fmt is None:
+            fmt = "fq" if h[:1] == b"@" else "fa" if h[:1] == b">" else None
+            if fmt is None:
+                raise ValueError("unrecognized file format")
+        if fmt == "fq":
+            if not h:
+                break
+            if h[:1] != b"@":
+                raise ValueError("malformed FASTQ")
+            if len(h) <= 1 or i + 2 >= len(lines):  # sequence, '+' and quality lines must exist
+                break
+            seq, qual = lines[i].rstrip(), lines[i + 2].rstrip()
+            i += 3
+            recs.append((h, seq, qual))
+        else:
+            if h[:1] != b">":
+                raise ValueError("malformed FASTA")
+            if len(h) <= 1:
+                break
+            seq = b""
+            while i < len(lines) and lines[i][:1] != b">":
+                seq += lines[i].rstrip()
+                i += 1
+            recs.append((h, seq, b""))
+    return recs
+
+
+def scan(path):
+    from nohuman_amd import _lib
+    L = _lib.lib()
+    n, nb, d = C.c_uint64(), C.c_uint64(), C.c_uint64()
+    rc = L.nh_fastx_scan(os.fsencode(path), C.byref(n), C.byref(nb), C.byref(d))
+    if rc != 0:
+        raise RuntimeError(L.nh_last_error().decode())
+    return n.value, nb.value, d.value
+
+
+def expect(data):
+    recs = py_records(data)
+    return len(recs), sum(len(r[1]) for r in recs), fnv([x for r in recs for x in r])
+
+
+CASES = {
+    "plain": b"@r1 desc\nACGT\n+\nIIII\n@r2\nGGCC\n+r2\nJJJJ\n",
+    "no_final_newline": b"@r1\nACGT\n+\nIIII\n@r2\nGG\n+\nJJ",
+    "crlf_and_trailing_ws": b"@r1 x \r\nACGT \r\n+\r\nIIII\t\r\n",
+    "blank_line_ends_file": b"@r1\nACGT\n+\nIIII\n\n@r2\nGG\n+\nJJ\n",
+    "truncated_last_record": b"@r1\nACGT\n+\nIIII\n@r2\nGG\n+\n",
+    "empty_sequence": b"@r1\n\n+\n\n@r2\nAC\n+\nII\n",
+    "fasta_multiline": b">s1 first\nACGT\nTTGG\n\n>s2\nA\n>s3\n",
+    "fasta_no_final_newline": b">s1\nACGT\nTT",
+}
+
+
+@pytest.mark.parametrize("name", sorted(CASES))
+def test_reader_edge_cases(tmp_path, name):
+    p = tmp_path / (name + ".txt")
+    p.write_bytes(CASES[name])
+    assert scan(p) == expect(CASES[name])
+
+
+def test_reader_golden_fixtures_plain_gzip_bzip2(tmp_path):
+    data = open(os.path.join(GOLD, "reads_se.fq"), "rb").read() * 30  # 3.8 MB: several refills of the inflate buffer
+    want = expect(data)
+    plain = tmp_path / "r.fq"
+    plain.write_bytes(data)
+    gz = tmp_path / "r.fq.gz"
+    with gzip.open(gz, "wb") as f:
+        f.write(data)
+    bz = tmp_path / "r.fq.bz2"
+    bz.write_bytes(bz2.compress(data))
+    assert scan(plain) == want
+    assert scan(gz) == want
+    assert scan(bz) == want
+    assert want[0] == 406 * 30
+
+
+def test_reader_errors(tmp_path):
+    p = tmp_path / "bad.txt"
+    p.write_bytes(b"hello\nworld\n")
+    with pytest.raises(RuntimeError) as ei:
+        scan(p)
+    assert "unrecognized file format" in str(ei.value)
+    p.write_bytes(b"@r1\nACGT\n+\nIIII\nACGT\n")
+    with pytest.raises(RuntimeError) as ei:
+        scan(p)
+    assert "malformed FASTQ" in str(ei.value)
+    with pytest.raises(RuntimeError):
+        scan(tmp_path / "missing.fq")
