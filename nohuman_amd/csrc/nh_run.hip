@@ -8,6 +8,7 @@
 // kraken2 units restated: classify.cc ProcessFiles / output formatting.
 #include <hip/hip_runtime.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <algorithm>
@@ -420,7 +421,11 @@ int run_engines(const std::vector<Engine *> &engines, const nh_run_args *a, nh_s
 
     // fragments per batch: ~96 MB of sequence, at most 262144; both readers cut at the same record
     // count so that paired batches stay aligned (a byte budget only cuts single-end batches)
-    const size_t BATCH_FRAGS = estimate_batch_frags(a->in1);
+    size_t BATCH_FRAGS = estimate_batch_frags(a->in1);
+    if (const char *env = getenv("NOHUMAN_BATCH_FRAGS")) {  // tuning / test knob
+        const long v = atol(env);
+        if (v > 0) BATCH_FRAGS = (size_t)v;
+    }
     const size_t BATCH_TEXT = rs.paired ? (size_t)-1 : (size_t)(512u << 20);
     const int G = (int)engines.size();
     const int mates = rs.paired ? 2 : 1;

@@ -37,6 +37,33 @@ def probe() -> str:
     return buf.value.decode()
 
 
+def run(db_dir, in1, out1, in2=None, out2=None, kraken_output=None, report=None, confidence: float = 0.0,
+        threads: int = 1, keep_human: bool = False, device_ids=None) -> "_lib.nh_stats":
+    """nh_run: whole run, database loaded into every listed device (default: all visible)."""
+    a = _lib.nh_run_args()
+    a.db_dir = os.fsencode(db_dir)
+    a.in1 = os.fsencode(in1)
+    a.in2 = os.fsencode(in2) if in2 else None
+    a.out1 = os.fsencode(out1)
+    a.out2 = os.fsencode(out2) if out2 else None
+    a.kraken_output = os.fsencode(kraken_output) if kraken_output else None
+    a.report = os.fsencode(report) if report else None
+    a.confidence = float(confidence)
+    a.threads = int(threads)
+    a.keep_human = int(bool(keep_human))
+    ids = None
+    if device_ids:
+        ids = (C.c_int32 * len(device_ids))(*device_ids)
+        a.n_devices = len(device_ids)
+        a.device_ids = ids
+    else:
+        a.n_devices = 0
+        a.device_ids = None
+    s = _lib.nh_stats()
+    _check(_lib.lib().nh_run(C.byref(a), C.byref(s)))
+    return s
+
+
 def device_count() -> int:
     n = C.c_int(0)
     _check(_lib.lib().nh_device_count(C.byref(n)))

@@ -167,3 +167,22 @@ def test_kraken_report(tmp_path):
     dfs(1, 0, -1)
     assert rep.read_text().split("\n")[:-1] == lines
     assert len(lines) >= 8
+
+
+def test_many_small_batches_two_engines_keep_input_order(tmp_path, monkeypatch):
+    """nh_run with tiny batches (64 fragments) spread round-robin over two engines (both on GPU 0,
+    which exercises exactly the multi-device path: one database replica per engine, two stream slots
+    each, ordered writer): outputs must equal the single-batch run byte for byte."""
+    from nohuman_amd import engine
+    _, ext, recs, calls = _expected("expected_pe.json", 0.0)
+    in1, in2 = os.path.join(GOLD, "reads_pe_1.fq"), os.path.join(GOLD, "reads_pe_2.fq")
+    ref = engine.run(DB, in1, str(tmp_path / "a_1.fq"), in2=in2, out2=str(tmp_path / "a_2.fq"),
+                     kraken_output=str(tmp_path / "a.k"), device_ids=[0])
+    monkeypatch.setenv("NOHUMAN_BATCH_FRAGS", "64")
+    st = engine.run(DB, in1, str(tmp_path / "b_1.fq"), in2=in2, out2=str(tmp_path / "b_2.fq"),
+                    kraken_output=str(tmp_path / "b.k"), device_ids=[0, 0])
+    assert (st.total_sequences, st.classified, st.total_bases) == (ref.total_sequences, ref.classified,
+                                                                     ref.total_bases)
+    assert st.total_sequences == len(calls) and st.classified == sum(1 for c in calls if c)
+    for n in ("_1.fq", "_2.fq", ".k"):
+        assert (tmp_path / ("a" + n)).read_bytes() == (tmp_path / ("b" + n)).read_bytes()
