@@ -170,8 +170,8 @@ static int common_open(Engine *e, int device) {
     HIP_TRY(hipMalloc((void **)&e->d_counters, (CNT_N + 12) * sizeof(uint64_t)));
     HIP_TRY(hipMemset(e->d_counters, 0, (CNT_N + 12) * sizeof(uint64_t)));
     HIP_TRY(hipMalloc((void **)&e->d_work, 2 * sizeof(unsigned long long)));
-    HIP_TRY(hipMalloc((void **)&e->d_error, sizeof(int)));
-    HIP_TRY(hipMemset(e->d_error, 0, sizeof(int)));
+    HIP_TRY(hipMalloc((void **)&e->d_error, 2 * sizeof(int)));  // [0] overflow pending, [1] errors
+    HIP_TRY(hipMemset(e->d_error, 0, 2 * sizeof(int)));
     return NH_OK;
 }
 
@@ -494,14 +494,12 @@ int classify_device_slot(Engine *e, const void *d_bases, const void *d_seq_off, 
 
 int check_error_flag(Engine *e) {
     int flag = 0;
-    HIP_TRY(hipMemcpy(&flag, e->d_error, sizeof(int), hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(&flag, e->d_error + 1, sizeof(int), hipMemcpyDeviceToHost));
     if (flag) {
-        HIP_TRY(hipMemset(e->d_error, 0, sizeof(int)));
-        if (flag == 2)
+        HIP_TRY(hipMemset(e->d_error, 0, 2 * sizeof(int)));
+        if (flag & 2)
             return set_error(NH_EINVAL, "a sequence of 2^31 bases or more is not supported");
-        return set_error(NH_ECAPACITY,
-                         "a fragment hit more than %d distinct taxa (per-wave LDS list capacity)",
-                         LIST_CAP);
+        return set_error(NH_ECAPACITY, "a fragment hit more than 2048 distinct taxa");
     }
     return NH_OK;
 }

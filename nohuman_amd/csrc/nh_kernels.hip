@@ -424,7 +424,7 @@ struct LaneLookup {
 template <bool LINEAR, bool STD, bool CAP32, bool PROF>
 __device__ __forceinline__ void probe_queue(KArgsP ap, WaveLdsT<STD> &S, const int lane,
                                             const uint32_t par,
-                                            const uint32_t qn, LaneLookup &lk,
+                                            const uint32_t qn, LaneLookup &lk, const bool count_lookups,
                                             uint64_t (&prof)[12],
                                             uint64_t &tprev) {
     ap = launder(ap);
@@ -455,7 +455,7 @@ __device__ __forceinline__ void probe_queue(KArgsP ap, WaveLdsT<STD> &S, const i
             if constexpr (!STD) S.qtax.v[par][r] = look ? 0u : QTAX_SKIP;
         }
         const uint32_t nlook = __popcll(__ballot(look));
-        if (lane == 0) S.acc[CNT_LOOKUPS] += nlook;
+        if (lane == 0 && count_lookups) S.acc[CNT_LOOKUPS] += nlook;
     }
     wave_sync();
     NH_STAMP(4);
@@ -608,9 +608,19 @@ __device__ __forceinline__ void probe_queue(KArgsP ap, WaveLdsT<STD> &S, const i
     NH_STAMP(5);
 }
 
+// The (taxon, count) list of the fragment being post-processed.  The hot kernel keeps 64 entries in
+// the wave's LDS slice (enough whenever the taxonomy has <= 64 nodes, e.g. every human-only
+// database); the BIG kernel variant re-runs the few fragments that overflowed it with 2048 entries.
+constexpr uint32_t BIG_LIST_CAP = 2048;
+constexpr uint32_t CALL_OVERFLOW = 0xFFFFFFFFu;  // result.call of a fragment left to the BIG variant
+struct TaxList {
+    uint32_t *tax, *cnt, *score;  // score: BIG only
+    uint32_t cap;
+};
+
 // POST one tile: per-k-mer taxa from the probe results, hit groups, (taxon, count) list.
-template <bool STD, bool PROF>
-__device__ __forceinline__ void post_tile(WaveLdsT<STD> &S, const int lane, const uint32_t ps,
+template <bool STD, bool BIG, bool PROF>
+__device__ __forceinline__ void post_tile(WaveLdsT<STD> &S, const TaxList &TLI, const int lane, const uint32_t ps,
                                           const uint32_t nqt, const uint32_t par,
                                           const uint32_t qbase, const uint32_t nruns,
                                           const int last_lane, FragState &st,
@@ -652,23 +662,91 @@ __device__ __forceinline__ void post_tile(WaveLdsT<STD> &S, const int lane, cons
             const uint32_t cnt = __popcll(__ballot(t0 == T)) + __popcll(__ballot(t1 == T));
             if (t0 == T) t0 = 0;
             if (t1 == T) t1 = 0;
-            const bool match = (uint32_t)lane < st.nlist && S.list_tax[lane] == T;
-            const uint64_t mb = __ballot(match);
-            if (mb) {
-                if (match) S.list_cnt[lane] += cnt;
-            } else if (st.nlist < (uint32_t)LIST_CAP) {
-                if (lane == 0) {
-                    S.list_tax[st.nlist] = T;
-                    S.list_cnt[st.nlist] = cnt;
+            if constexpr (!BIG) {  // hot variant: at most 64 entries, lane i looks at entry i
+                const bool match = (uint32_t)lane < st.nlist && S.list_tax[lane] == T;
+                const uint64_t mb = __ballot(match);
+                if (mb) {
+                    if (match) S.list_cnt[lane] += cnt;
+                } else if (st.nlist < (uint32_t)LIST_CAP) {
+                    if (lane == 0) {
+                        S.list_tax[st.nlist] = T;
+                        S.list_cnt[st.nlist] = cnt;
+                    }
+                    st.nlist++;
+                } else {
+                    st.overflow = true;
                 }
-                st.nlist++;
             } else {
-                st.overflow = true;
+                bool found = false;
+                for (uint32_t base = 0; base < st.nlist; base += 64) {
+                    const uint32_t idx = base + lane;
+                    const bool match = idx < st.nlist && TLI.tax[idx] == T;
+                    if (__ballot(match)) {
+                        if (match) TLI.cnt[idx] += cnt;
+                        found = true;
+                        break;
+                    }
+                }
+                if (!found) {
+                    if (st.nlist < TLI.cap) {
+                        if (lane == 0) {
+                            TLI.tax[st.nlist] = T;
+                            TLI.cnt[st.nlist] = cnt;
+                        }
+                        st.nlist++;
+                    } else {
+                        st.overflow = true;
+                    }
+                }
             }
             wave_sync();
         }
     }
     NH_STAMP(6);
+}
+
+// ResolveTree (A.5) for lists of any length (BIG variant): lane i owns entries i, i+64, ...
+__device__ __forceinline__ uint32_t resolve_tree_big(KArgsP ap, const TaxList &TLI, const int lane,
+                                                     const FragState &st, const uint32_t total_kmers,
+                                                     uint32_t &clade_hits) {
+    ap = launder(ap);
+    const uint32_t n = st.nlist;
+    const uint32_t *parent = ap->db.parent;
+    const double confidence = ap->confidence;
+    const uint32_t min_hit_groups = ap->db.min_hit_groups;
+    uint32_t top = 0;
+    for (uint32_t i = lane; i < n; i += 64) {  // LTR score of every entry
+        const uint32_t t = TLI.tax[i];
+        uint32_t score = 0;
+        for (uint32_t j = 0; j < n; j++)
+            if (is_a_ancestor_of_b(parent, TLI.tax[j], t)) score += TLI.cnt[j];
+        TLI.score[i] = score;
+        top = score > top ? score : top;
+    }
+    top = wave_max(top);
+    uint32_t call = 0;  // LCA of all entries that reach the top score (order independent)
+    for (uint32_t i = lane; i < n; i += 64)
+        if (TLI.score[i] == top) call = lowest_common_ancestor(parent, call, TLI.tax[i]);
+    for (int d = 32; d >= 1; d >>= 1)
+        call = lowest_common_ancestor(parent, call, (uint32_t)__shfl_xor((int)call, d, 64));
+    auto sum_if = [&](bool clade) {
+        uint32_t s = 0;
+        for (uint32_t i = lane; i < n; i += 64) {
+            const uint32_t t = TLI.tax[i];
+            if (clade ? is_a_ancestor_of_b(parent, call, t) : (t == call)) s += TLI.cnt[i];
+        }
+        return wave_sum(s);
+    };
+    const uint32_t required = (uint32_t)ceil(confidence * (double)total_kmers);
+    uint32_t s = sum_if(false);  // hits exactly at the call
+    while (call && s < required) {
+        s = sum_if(true);
+        if (s >= required) break;
+        call = parent[call];
+    }
+    if (call && st.hit_groups < min_hit_groups) call = 0;
+    clade_hits = call ? sum_if(true) : 0;
+    return call;
 }
 
 // ResolveTree (A.5) on the wave: lane i owns list entry i.  Returns the call; sets clade_hits.
@@ -718,13 +796,23 @@ constexpr uint32_t PREF_LANES = 42;  // dwords a tile can need: (3 + 128 + 30 + 
 
 __device__ __forceinline__ uint32_t uni(uint32_t v) { return __builtin_amdgcn_readfirstlane(v); }
 
-template <bool LINEAR, bool STD, bool CAP32, bool PROF>
-__global__ __launch_bounds__(WAVE * WAVES_PER_BLOCK, STD ? NH_MIN_WAVES : 3) void k_classify(const KArgs args_by_kernarg_pointer) {
+template <bool LINEAR, bool STD, bool CAP32, bool PROF, bool BIG>
+__global__ __launch_bounds__(WAVE * WAVES_PER_BLOCK, BIG ? 1 : (STD ? NH_MIN_WAVES : 3)) void k_classify(const KArgs args_by_kernarg_pointer) {
     KArgsP ap = (KArgsP)__builtin_amdgcn_kernarg_segment_ptr();
+    // BIG variant: only runs when some fragment overflowed the 64-entry list of the hot variant
+    if (BIG && ap->error_flag[0] == 0) return;
     __shared__ WaveLdsT<STD> lds_all[WAVES_PER_BLOCK];
+    __shared__ uint32_t big_lists[BIG ? WAVES_PER_BLOCK * 3 * BIG_LIST_CAP : 1];
     const int lane = threadIdx.x & 63;
     const int wib = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     WaveLdsT<STD> &S = lds_all[wib];
+    TaxList TLI = {nullptr, nullptr, nullptr, 0};  // used by the BIG variant only
+    if constexpr (BIG) {
+        TLI.tax = &big_lists[(wib * 3 + 0) * BIG_LIST_CAP];
+        TLI.cnt = &big_lists[(wib * 3 + 1) * BIG_LIST_CAP];
+        TLI.score = &big_lists[(wib * 3 + 2) * BIG_LIST_CAP];
+        TLI.cap = BIG_LIST_CAP;
+    }
 
     // one-time LDS init: zero pads of the packed streams, sentinel tail of the candidate array
     if (lane < 24) {
@@ -803,23 +891,32 @@ __global__ __launch_bounds__(WAVE * WAVES_PER_BLOCK, STD ? NH_MIN_WAVES : 3) voi
                 st.overflow = false;
             }
             const uint32_t ps = S.ps[pp][s][lane];
-            post_tile<STD, PROF>(S, lane, ps, d_nqt, pp, d_qbase, d_nruns, (int)d_last, st, fi,
-                                 kmer_taxa, kt, prof, tprev);
+            post_tile<STD, BIG, PROF>(S, TLI, lane, ps, d_nqt, pp, d_qbase, d_nruns, (int)d_last, st, fi,
+                                      kmer_taxa, kt, prof, tprev);
             if ((flags & 2u) && reset_per_mate) st.carry_tax = 0;  // mate 0 ended, mate 1 follows
             if (flags & 1u) {                                      // fragment ended
                 const uint32_t total_kmers = d_total;
                 uint32_t call = 0, clade_hits = 0;
-                if (st.nlist > 0) call = resolve_tree(ap, S, lane, st, fi, total_kmers, clade_hits);
+                if (st.nlist > 0) {
+                    if (BIG)
+                        call = resolve_tree_big(ap, TLI, lane, st, total_kmers, clade_hits);
+                    else
+                        call = resolve_tree(ap, S, lane, st, fi, total_kmers, clade_hits);
+                }
+                // hot variant: a fragment with more than 64 distinct taxa is left to the BIG variant
+                const bool defer = !BIG && st.overflow;
+                if (defer) call = 0;
                 if (lane == 0) {
                     uint4 rec;
-                    rec.x = call;
+                    rec.x = defer ? CALL_OVERFLOW : call;
                     rec.y = total_kmers;
                     rec.z = clade_hits;
                     rec.w = st.hit_groups;
                     *reinterpret_cast<uint4 *>(&a2->out[f]) = rec;
                     if (kmer_taxa && mates == 2)
                         kmer_taxa[a2->kmer_taxa_off[f] + d_nk0] = TAXON_MATE_BORDER;
-                    if (st.overflow) atomicMax(a2->error_flag, 1);
+                    if (defer) atomicMax(&a2->error_flag[0], 1);            // work for the BIG variant
+                    if (BIG && st.overflow) atomicOr(&a2->error_flag[1], 1);  // beyond 2048 too: error
                 }
                 if (lane == 0 && call) S.acc[CNT_CLASSIFIED] += 1;
             }
@@ -831,7 +928,7 @@ __global__ __launch_bounds__(WAVE * WAVES_PER_BLOCK, STD ? NH_MIN_WAVES : 3) voi
     // group complete (or input exhausted): hash + probe it -- which also resolves what is left of
     // the previous group -- then post-process the previous group and switch buffers
     auto turn = [&]() {
-        probe_queue<LINEAR, STD, CAP32, PROF>(ap, S, lane, par, qn, lk, prof, tprev);
+        probe_queue<LINEAR, STD, CAP32, PROF>(ap, S, lane, par, qn, lk, !BIG, prof, tprev);
         if (nslot_old) post_group(par ^ 1u, nslot_old);
         nslot_old = nslot_new;
         par ^= 1u;
@@ -857,7 +954,7 @@ __global__ __launch_bounds__(WAVE * WAVES_PER_BLOCK, STD ? NH_MIN_WAVES : 3) voi
         const uint64_t cbase = readlane64(off64, 0);
         const uint64_t crel = off64 - cbase;
         if (__ballot((crel >> 32) != 0)) bad_input = true;  // a chunk of 4 Gbases and more
-        if ((uint32_t)lane == nof - 1) {  // this lane holds the chunk's last offset = its bases
+        if (!BIG && (uint32_t)lane == nof - 1) {  // this lane holds the chunk's last offset = its bases
             S.acc[CNT_FRAGMENTS] += ncf;
             S.acc[CNT_BASES] += crel;
         }
@@ -872,6 +969,10 @@ __global__ __launch_bounds__(WAVE * WAVES_PER_BLOCK, STD ? NH_MIN_WAVES : 3) voi
             const uint32_t n0 = o1 - o0, n1 = o2 - o1;
             const uint32_t nk0 = n0 >= K ? n0 - K + 1 : 0;
             const uint32_t nk1 = n1 >= K ? n1 - K + 1 : 0;
+            if (BIG) {  // only the fragments the hot variant gave up on
+                const uint32_t prev_call = launder(ap)->out[f].call;
+                if (uni(prev_call) != CALL_OVERFLOW) continue;
+            }
             if (nk0 + nk1 == 0) {  // no k-mer at all: all-zero record, only the mate border
                 if (lane == 0) {
                     KArgsP a2 = launder(ap);
@@ -982,7 +1083,7 @@ __global__ __launch_bounds__(WAVE * WAVES_PER_BLOCK, STD ? NH_MIN_WAVES : 3) voi
             atomicAdd(&counters[CNT_BASES], S.acc[CNT_BASES]);
             atomicAdd(&counters[CNT_LOOKUPS], S.acc[CNT_LOOKUPS]);
         }
-        if (bad_input) atomicMax(error_flag, 2);
+        if (bad_input) atomicOr(&error_flag[1], 2);
     }
 }
 
@@ -1100,8 +1201,15 @@ static bool is_std(const DevDB &db) {
 }
 
 template <bool LINEAR, bool STD, bool CAP32, bool PROF = false>
-static void launch_variant(const KArgs &ka, dim3 g, dim3 b, hipStream_t stream) {
-    hipLaunchKernelGGL((k_classify<LINEAR, STD, CAP32, PROF>), g, b, 0, stream, ka);
+static void launch_variant(const KArgs &ka, dim3 g, dim3 b, hipStream_t stream, bool may_overflow,
+                           unsigned long long *d_work) {
+    hipLaunchKernelGGL((k_classify<LINEAR, STD, CAP32, PROF, false>), g, b, 0, stream, ka);
+    if (may_overflow) {
+        // second pass for fragments with more than 64 distinct taxa: exits at once if there are none
+        (void)hipMemsetAsync(d_work, 0, sizeof(unsigned long long), stream);
+        hipLaunchKernelGGL((k_classify<LINEAR, STD, CAP32, false, true>), g, b, 0, stream, ka);
+        (void)hipMemsetAsync(ka.error_flag, 0, sizeof(int), stream);  // "overflow pending" word
+    }
 }
 
 hipError_t launch_classify(const DevDB &db, const void *d_bases, const void *d_seq_off,
@@ -1132,16 +1240,17 @@ hipError_t launch_classify(const DevDB &db, const void *d_bases, const void *d_s
     ka.error_flag = d_error;
     ka.work = d_work;
     const bool cap32 = db.capacity < 0xFFFFFF00ull;
+    const bool may_overflow = db.node_count > LIST_CAP;  // <= 64 taxa can never overflow the list
     if (db.linear_probing && std_geom && cap32 && getenv("NH_PHASE_PROF"))
-        launch_variant<true, true, true, true>(ka, g, b, stream);  // d_counters: CNT_N + 8 words
+        launch_variant<true, true, true, true>(ka, g, b, stream, may_overflow, d_work);  // d_counters: CNT_N + 12 words
     else if (db.linear_probing && std_geom && cap32)
-        launch_variant<true, true, true>(ka, g, b, stream);
+        launch_variant<true, true, true>(ka, g, b, stream, may_overflow, d_work);
     else if (db.linear_probing && std_geom)
-        launch_variant<true, true, false>(ka, g, b, stream);
+        launch_variant<true, true, false>(ka, g, b, stream, may_overflow, d_work);
     else if (db.linear_probing)
-        launch_variant<true, false, false>(ka, g, b, stream);
+        launch_variant<true, false, false>(ka, g, b, stream, may_overflow, d_work);
     else
-        launch_variant<false, false, false>(ka, g, b, stream);
+        launch_variant<false, false, false>(ka, g, b, stream, may_overflow, d_work);
     return hipGetLastError();
 }
 
@@ -1164,7 +1273,7 @@ hipError_t launch_insert_sequences(const DevDB &db, const void *d_bases, const v
 
 int classify_blocks_per_cu() {
     int nb = 0;
-    hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_classify<true, true, true, false>,
+    hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_classify<true, true, true, false, false>,
                                                                 WAVE * WAVES_PER_BLOCK, 0);
     if (e != hipSuccess || nb < 1) nb = 4;
     return nb > 8 ? 8 : nb;

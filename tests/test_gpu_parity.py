@@ -119,3 +119,47 @@ def test_db_variants(variant):
     _assert_same(got, exp, variant)
     assert np.array_equal(taxa, etaxa)
     assert (exp["call"] != 0).sum() > 50
+
+
+def test_more_than_64_distinct_taxa_take_the_second_pass():
+    """A fragment that hits more than 64 distinct taxa overflows the hot kernel's LDS list and is
+    finished by the BIG kernel variant (2048 entries); results stay bit-exact."""
+    from nohuman_amd import Engine
+    from oracle import minidb
+    rng = np.random.default_rng(21)
+    n_leaf = 150
+    edges = {1: 0}
+    for g in range(10):          # 10 genera under the root, 15 leaves each
+        edges[100 + g] = 1
+    leaves = []
+    for i in range(n_leaf):
+        ext = 1000 + i
+        edges[ext] = 100 + i % 10
+        leaves.append(ext)
+    tax = minidb.Taxonomy(edges)
+    segs = {ext: synth.random_seq(rng, 120) for ext in leaves}
+    hashb, size = minidb.build_hash(tax, sorted(segs.items()), 40009)
+    ob, tb = minidb.opts_bytes(), tax.to_bytes()
+    assert tax.node_count > 64
+    reads = []
+    for _ in range(40):          # long reads visiting 70-140 different leaves
+        k = int(rng.integers(70, 141))
+        pick = rng.choice(leaves, size=k, replace=False)
+        reads.append(b"".join(segs[int(e)][10:110] for e in pick))
+    reads += synth.sample_reads(rng, {e: segs[e] for e in leaves[:20]}, 200, length=100, frac_random=0.2)
+    bases, offs = orc.pack_reads(reads, False)
+    odb = orc.OracleDB(ob, tb, hashb)
+    for conf in (0.0, 0.02, 0.3):
+        exp, lookups, etaxa, _ = odb.classify(bases, offs, False, conf, want_taxa=True)
+        with Engine.from_images(ob, tb, hashb) as eng:
+            got, taxa, _ = eng.classify(bases, offs, False, conf, want_taxa=True)
+            st = eng.stats()
+        _assert_same(got, exp, "many taxa conf=%s" % conf)
+        assert np.array_equal(taxa, etaxa)
+        assert st.classified == int((exp["call"] != 0).sum())
+        assert st.table_lookups == int(lookups.sum())
+    # the long reads really exceed the 64-entry list
+    from oracle import k2_literal as lit
+    ldb = lit.DB.from_images(ob, tb, hashb)
+    distinct = {t for t in lit.classify_fragment(ldb, (reads[0],), 0.0)[4] if t not in (0, lit.AMBIG)}
+    assert len(distinct) > 64
