@@ -187,6 +187,20 @@ int nh_run(const nh_run_args *args, nh_stats *stats);
  * over every record's header line, sequence and qualities (each followed by one 0 byte).
  * Needs no GPU. */
 int nh_fastx_scan(const char *path, uint64_t *n_records, uint64_t *n_bases, uint64_t *digest);
+/* Output compression stage: replaces CompressionFormat::compress
+ * (/root/reference/src/compression.rs:182-200, called from src/main.rs:342-368).  Compresses file
+ * `in` to file `out`; gzip runs block-parallel on `threads` workers like the reference's gzp
+ * encoder (compression.rs:214-233) and produces one ordinary gzip member at level 6; bzip2 and xz
+ * go through the system tools; NH_CODEC_NONE copies.  Parity target is the decompressed content and
+ * the container magic (compression.rs:282-288).  Needs no GPU. */
+typedef enum nh_codec {
+    NH_CODEC_NONE = 0,
+    NH_CODEC_BZIP2 = 1,
+    NH_CODEC_GZIP = 2,
+    NH_CODEC_XZ = 3,
+    NH_CODEC_ZSTD = 4 /* not available in this build: NH_EINVAL */
+} nh_codec;
+int nh_compress_file(const char *in, const char *out, int codec, uint32_t threads);
 /* nh_run on an already opened engine (single device) */
 int nh_run_engine(nh_engine *e, const nh_run_args *args, nh_stats *stats);
 

@@ -2,6 +2,9 @@
 #include "nh_fastx.h"
 
 #include <ctype.h>
+#include <errno.h>
+#include <fcntl.h>
+#include <unistd.h>
 #include <string.h>
 #include <zlib.h>
 
@@ -36,7 +39,16 @@ int ByteSource::open(const char *path, std::string &err) {
         }
         return 0;
     }
-    gzFile g = gzopen(path, "rb");  // transparent for plain files
+    if (!(got >= 2 && magic[0] == 0x1f && magic[1] == 0x8b)) {  // plain text: no inflate layer
+        fd_ = ::open(path, O_RDONLY | O_CLOEXEC);
+        if (fd_ < 0) {
+            err = std::string("cannot open ") + path;
+            return -1;
+        }
+        (void)posix_fadvise(fd_, 0, 0, POSIX_FADV_SEQUENTIAL);
+        return 0;
+    }
+    gzFile g = gzopen(path, "rb");
     if (!g) {
         err = std::string("cannot open ") + path;
         return -1;
@@ -47,6 +59,19 @@ int ByteSource::open(const char *path, std::string &err) {
 }
 
 long ByteSource::read(uint8_t *buf, size_t cap) {
+    if (fd_ >= 0) {
+        size_t got = 0;
+        while (got < cap) {  // fill the request like gzread / fread do
+            ssize_t n = ::read(fd_, buf + got, cap - got);
+            if (n < 0) {
+                if (errno == EINTR) continue;
+                return -1;
+            }
+            if (n == 0) break;
+            got += (size_t)n;
+        }
+        return (long)got;
+    }
     if (gz_) {
         int n = gzread((gzFile)gz_, buf, (unsigned)cap);
         return n;
@@ -62,6 +87,8 @@ long ByteSource::read(uint8_t *buf, size_t cap) {
 void ByteSource::close() {
     if (gz_) gzclose((gzFile)gz_);
     if (pipe_) pclose(pipe_);
+    if (fd_ >= 0) ::close(fd_);
+    fd_ = -1;
     gz_ = nullptr;
     pipe_ = nullptr;
 }
@@ -165,50 +192,16 @@ int FastxReader::next(SeqRecord &rec, std::string &err) {
 
 // ------------------------------------------------------------------------------------------------
 int BlockReader::open(const char *path, std::string &err) {
-    buf_.resize(8u << 20);
-    pos_ = len_ = 0;
+    tail_.clear();
     eof_ = false;
     format_ = FMT_AUTO;
-    have_carry_ = false;
+    fa_resume_rec_ = (size_t)-1;
+    chunk_ = 4u << 20;
+    if (const char *env = getenv("NOHUMAN_READ_CHUNK")) {  // test knob: records across read boundaries
+        const long v = atol(env);
+        if (v > 0) chunk_ = (size_t)v;
+    }
     return src_.open(path, err);
-}
-
-bool BlockReader::fill() {
-    if (eof_) return false;
-    if (pos_ > 0) {  // keep the unread tail at the front
-        memmove(buf_.data(), buf_.data() + pos_, len_ - pos_);
-        len_ -= pos_;
-        pos_ = 0;
-    }
-    if (len_ == buf_.size()) buf_.resize(buf_.size() * 2);  // a line longer than the buffer
-    long n = src_.read((uint8_t *)buf_.data() + len_, buf_.size() - len_);
-    if (n <= 0) {
-        eof_ = true;
-        return false;
-    }
-    len_ += (size_t)n;
-    return true;
-}
-
-// std::getline semantics: false only if not a single character could be extracted
-bool BlockReader::line(const char *&b, const char *&e) {
-    for (;;) {
-        const char *p = buf_.data() + pos_;
-        const char *nl = (const char *)memchr(p, '\n', len_ - pos_);
-        if (nl) {
-            b = p;
-            e = nl;
-            pos_ = (size_t)(nl - buf_.data()) + 1;
-            return true;
-        }
-        if (!fill()) {  // end of input: the rest (if any) is the last line
-            if (pos_ == len_) return false;
-            b = buf_.data() + pos_;
-            e = buf_.data() + len_;
-            pos_ = len_;
-            return true;
-        }
-    }
 }
 
 static inline const char *rstrip(const char *b, const char *e) {
@@ -216,89 +209,191 @@ static inline const char *rstrip(const char *b, const char *e) {
     return e;
 }
 
-void BlockReader::next_batch(HalfBatch &hb, size_t max_recs, size_t max_text) {
-    hb.format = format_;
-    while (hb.recs.size() < max_recs && hb.text.size() < max_text) {
-        const char *b, *e;
-        std::string hdr;
-        if (have_carry_) {
-            hdr.swap(carry_);
-            have_carry_ = false;
-        } else {
-            if (!line(b, e)) {
-                hb.eof = true;
-                return;
-            }
-            hdr.assign(b, rstrip(b, e));
-        }
-        if (format_ == FMT_AUTO) {
-            if (!hdr.empty() && hdr[0] == '@')
-                format_ = FMT_FASTQ;
-            else if (!hdr.empty() && hdr[0] == '>')
-                format_ = FMT_FASTA;
-            else {
-                hb.error = "sequence reader - unrecognized file format";
-                return;
-            }
-            hb.format = format_;
-        }
-        if (format_ == FMT_FASTQ) {
-            if (hdr.empty()) {  // an empty line may end the file
-                hb.eof = true;
-                return;
-            }
-            if (hdr[0] != '@') {
-                hb.error = "malformed FASTQ file (exp. '@', saw \"" + hdr + "\"), aborting";
-                return;
-            }
-        } else if (hdr.empty() || hdr[0] != '>') {
-            hb.error = "malformed FASTA file (exp. '>', saw \"" + hdr + "\"), aborting";
-            return;
-        }
-        if (hdr.size() <= 1) {
-            hb.eof = true;
-            return;
-        }
-        RecRef r;
-        r.h = (uint32_t)hb.text.size();
-        r.hlen = (uint32_t)hdr.size();
-        size_t ws = hdr.find_first_of(" \t\r", 1);
-        r.idlen = (uint32_t)((ws == std::string::npos ? hdr.size() : ws) - 1);
-        hb.text.insert(hb.text.end(), hdr.begin(), hdr.end());
-        if (format_ == FMT_FASTQ) {
-            if (!line(b, e)) {
-                hb.text.resize(r.h);
-                hb.eof = true;
-                return;
-            }
-            const char *se = rstrip(b, e);
-            r.s = (uint32_t)hb.text.size();
-            r.slen = (uint32_t)(se - b);
-            hb.text.insert(hb.text.end(), b, se);
-            const char *pb, *pe;
-            if (!line(pb, pe) || !line(b, e)) {  // '+' line (discarded), qualities
-                hb.text.resize(r.h);
-                hb.eof = true;
-                return;
-            }
-            const char *qe = rstrip(b, e);
-            r.q = (uint32_t)hb.text.size();
-            r.qlen = (uint32_t)(qe - b);
-            hb.text.insert(hb.text.end(), b, qe);
-        } else {
-            r.s = (uint32_t)hb.text.size();
-            for (;;) {  // join sequence lines up to the next header
-                if (pos_ == len_ && !fill()) break;
-                if (buf_[pos_] == '>') break;
-                if (!line(b, e)) break;
-                hb.text.insert(hb.text.end(), b, rstrip(b, e));
-            }
-            r.slen = (uint32_t)(hb.text.size() - r.s);
-            r.q = r.s + r.slen;
-            r.qlen = 0;
-        }
-        hb.recs.push_back(r);
+namespace {
+struct Line {
+    const char *b, *e;  // [b, e) without the newline
+    size_t next;        // offset of the byte after the line
+    bool term;          // ended by a newline (false: ended by the end of the input)
+};
+}  // namespace
+
+// std::getline semantics on text[p..len): 1 = a line, 0 = the line is not complete yet (more input
+// to come), -1 = end of input and not a single character left
+static inline int get_line(const char *t, size_t p, size_t len, bool eof, Line &L) {
+    const char *nl = (const char *)memchr(t + p, '\n', len - p);
+    if (nl) {
+        L.b = t + p;
+        L.e = nl;
+        L.next = (size_t)(nl - t) + 1;
+        L.term = true;
+        return 1;
     }
+    if (!eof) return 0;
+    if (p == len) return -1;
+    L.b = t + p;
+    L.e = t + len;
+    L.next = len;
+    L.term = false;
+    return 1;
+}
+
+int BlockReader::parse_one(HalfBatch &hb, size_t &pos, size_t len) {
+    char *t = hb.text.data();
+    Line h;
+    int g = get_line(t, pos, len, eof_, h);
+    if (g == 0) return 0;
+    if (g < 0) {
+        hb.eof = true;
+        return -1;
+    }
+    const char *he = rstrip(h.b, h.e);
+    if (format_ == FMT_AUTO) {
+        if (he > h.b && *h.b == '@')
+            format_ = FMT_FASTQ;
+        else if (he > h.b && *h.b == '>')
+            format_ = FMT_FASTA;
+        else {
+            hb.error = "sequence reader - unrecognized file format";
+            return -2;
+        }
+        hb.format = format_;
+    }
+    if (format_ == FMT_FASTQ) {
+        if (he == h.b) {  // an empty line may end the file
+            hb.eof = true;
+            return -1;
+        }
+        if (*h.b != '@') {
+            hb.error = "malformed FASTQ file (exp. '@', saw \"" + std::string(h.b, he) + "\"), aborting";
+            return -2;
+        }
+    } else if (he == h.b || *h.b != '>') {
+        hb.error = "malformed FASTA file (exp. '>', saw \"" + std::string(h.b, he) + "\"), aborting";
+        return -2;
+    }
+    if (he - h.b <= 1) {
+        hb.eof = true;
+        return -1;
+    }
+    RecRef r;
+    r.h = (uint32_t)(h.b - t);
+    r.hlen = (uint32_t)(he - h.b);
+    const char *ws = h.b + 1;
+    while (ws < he && *ws != ' ' && *ws != '\t' && *ws != '\r') ws++;
+    r.idlen = (uint32_t)(ws - h.b - 1);
+    bool canon = h.term && he == h.e;
+    if (format_ == FMT_FASTQ) {
+        Line s, pl, q;
+        for (Line *L : {&s, &pl, &q}) {  // sequence, '+' line (discarded), qualities
+            g = get_line(t, L == &s ? h.next : L == &pl ? s.next : pl.next, len, eof_, *L);
+            if (g == 0) return 0;
+            if (g < 0) {  // the file ends inside the record: kraken2 drops it
+                hb.eof = true;
+                return -1;
+            }
+        }
+        const char *se = rstrip(s.b, s.e), *qe = rstrip(q.b, q.e);
+        r.s = (uint32_t)(s.b - t);
+        r.slen = (uint32_t)(se - s.b);
+        r.q = (uint32_t)(q.b - t);
+        r.qlen = (uint32_t)(qe - q.b);
+        canon = canon && se == s.e && qe == q.e && q.term && pl.e - pl.b == 1 && *pl.b == '+';
+        r.raw_end = canon ? (uint32_t)q.next : 0;
+        pos = q.next;
+    } else {
+        // pass 1: find the end of the record (next line starting with '>' or the end of input)
+        size_t p = fa_resume_rec_ == pos ? fa_resume_ : h.next;
+        for (;;) {
+            if (p == len) {
+                if (eof_) break;
+                fa_resume_rec_ = pos;
+                fa_resume_ = p;
+                return 0;
+            }
+            if (t[p] == '>') break;
+            Line L;
+            if (get_line(t, p, len, eof_, L) == 0) {
+                fa_resume_rec_ = pos;
+                fa_resume_ = p;
+                return 0;
+            }
+            p = L.next;
+        }
+        fa_resume_rec_ = (size_t)-1;
+        // pass 2: join the sequence lines in place
+        char *dst = t + h.next;
+        size_t nlines = 0;
+        bool plain = true;
+        for (size_t x = h.next; x < p;) {
+            Line L;
+            get_line(t, x, p, true, L);
+            const char *le = rstrip(L.b, L.e);
+            const size_t n = (size_t)(le - L.b);
+            if (dst != L.b) memmove(dst, L.b, n);
+            dst += n;
+            plain = plain && le == L.e && L.term;
+            nlines++;
+            x = L.next;
+        }
+        r.s = (uint32_t)h.next;
+        r.slen = (uint32_t)(dst - (t + h.next));
+        r.q = r.s + r.slen;
+        r.qlen = 0;
+        r.raw_end = canon && plain && nlines == 1 ? (uint32_t)p : 0;
+        pos = p;
+    }
+    hb.recs.push_back(r);
+    return 1;
+}
+
+void BlockReader::next_batch(HalfBatch &hb, size_t max_recs, size_t max_text) {
+    const size_t CHUNK = chunk_;
+    const size_t LIMIT = 0xFFF00000ull;  // offsets are 32-bit
+    hb.reset();
+    hb.format = format_;
+    if (max_text > (3ull << 30)) max_text = 3ull << 30;
+    if (!hb.text.reserve(tail_.size() + CHUNK)) {
+        hb.error = "out of memory";
+        return;
+    }
+    memcpy(hb.text.data(), tail_.data(), tail_.size());
+    hb.text.set_size(tail_.size());
+    tail_.clear();
+    if (fa_resume_rec_ != (size_t)-1) fa_resume_rec_ = (size_t)-1;  // offsets changed: rescan
+    size_t pos = 0;
+    bool done = false;
+    while (!done) {
+        int r = 1;
+        while (hb.recs.size() < max_recs && pos < max_text) {
+            r = parse_one(hb, pos, hb.text.size());
+            if (r != 1) break;
+        }
+        if (r < 0) {  // end of input or malformed
+            hb.text.set_size(pos);
+            return;
+        }
+        if (r == 1) break;  // batch full
+        // more input needed
+        if (hb.text.size() + CHUNK > LIMIT) {
+            hb.error = "sequence record larger than 4 GB";
+            return;
+        }
+        if (!hb.text.reserve(hb.text.size() + CHUNK)) {
+            hb.error = "out of memory";
+            return;
+        }
+        long n = src_.read((uint8_t *)hb.text.data() + hb.text.size(), CHUNK);
+        if (n <= 0)
+            eof_ = true;
+        else
+            hb.text.set_size(hb.text.size() + (size_t)n);
+    }
+    // keep what follows the last complete record for the next batch
+    if (!tail_.append(hb.text.data() + pos, hb.text.size() - pos)) {
+        hb.error = "out of memory";
+        return;
+    }
+    hb.text.set_size(pos);
 }
 
 }  // namespace nh

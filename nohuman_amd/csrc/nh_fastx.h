@@ -4,6 +4,8 @@
 #pragma once
 #include <stdint.h>
 #include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
 
 #include <string>
 #include <vector>
@@ -32,6 +34,7 @@ public:
 private:
     void *gz_ = nullptr;   // gzFile
     FILE *pipe_ = nullptr; // bzip2 -dc
+    int fd_ = -1;          // plain text
 };
 
 class FastxReader {
@@ -52,41 +55,89 @@ private:
     std::string line_;
 };
 
-// ---- block reader: whole batches of records as slices of one text buffer ------------------------
+// ---- block reader: whole batches of records as slices of the raw input text -----------------------
 struct RecRef {  // offsets into HalfBatch::text
     uint32_t h, hlen;  // header line (with '@' / '>'), trailing whitespace stripped
     uint32_t idlen;    // id = text[h+1 .. h+1+idlen)
     uint32_t s, slen;  // sequence
     uint32_t q, qlen;  // qualities (FASTQ)
+    // != 0: text[h .. raw_end) is byte for byte what the record looks like when written back
+    // ("header\nseq\n+\nquals\n" / "header\nseq\n"), so kept records can be written without a copy
+    uint32_t raw_end;
+};
+
+// Growable byte buffer that never zero-fills (batches are ~100 MB and recycled between reads).
+class RawBuf {
+public:
+    RawBuf() = default;
+    RawBuf(const RawBuf &) = delete;
+    RawBuf &operator=(const RawBuf &) = delete;
+    ~RawBuf() { free(p_); }
+    char *data() { return p_; }
+    const char *data() const { return p_; }
+    size_t size() const { return len_; }
+    size_t capacity() const { return cap_; }
+    void set_size(size_t n) { len_ = n; }
+    void clear() { len_ = 0; }
+    bool reserve(size_t n) {  // false = out of memory
+        if (n <= cap_) return true;
+        size_t c = cap_ ? cap_ : 4096;
+        while (c < n) c += c / 2 + 4096;
+        char *q = (char *)realloc(p_, c);
+        if (!q) return false;
+        p_ = q;
+        cap_ = c;
+        return true;
+    }
+    bool append(const char *b, size_t n) {
+        if (!reserve(len_ + n)) return false;
+        memcpy(p_ + len_, b, n);
+        len_ += n;
+        return true;
+    }
+
+private:
+    char *p_ = nullptr;
+    size_t len_ = 0, cap_ = 0;
 };
 
 struct HalfBatch {  // the records one input file contributes to a batch
-    std::vector<char> text;
+    RawBuf text;
     std::vector<RecRef> recs;
     SeqFormat format = FMT_AUTO;
     bool eof = false;
     std::string error;  // non-empty: malformed input
+    void reset() {
+        text.clear();
+        recs.clear();
+        format = FMT_AUTO;
+        eof = false;
+        error.clear();
+    }
 };
 
-// Same record semantics as FastxReader (kraken2 seqreader.cc), but parses straight
-// out of the inflate buffer into one contiguous text block per batch -- no per-record allocation.
+// Same record semantics as FastxReader (kraken2 seqreader.cc).  The input is read
+// (inflated) straight into the batch's text buffer and parsed in place: a RecRef is a set of offsets
+// into the raw bytes, nothing is copied per record (multi-line FASTA sequences are joined in place).
 class BlockReader {
 public:
     int open(const char *path, std::string &err);
-    // appends up to max_recs records (or max_text bytes) to hb; sets hb.eof at end of input
+    // parses up to max_recs records (or about max_text bytes) into hb (which is reset first);
+    // sets hb.eof at end of input.  Text offsets are 32-bit: max_text is clamped below 2^32.
     void next_batch(HalfBatch &hb, size_t max_recs, size_t max_text);
     void close() { src_.close(); }
 
 private:
-    bool fill();                                   // read more bytes; false at end of input
-    bool line(const char *&b, const char *&e);     // next line [b,e) without '\n'; false at EOF
+    // one record at text[pos..len): 1 parsed, 0 more input needed, -1 end of input reached
+    // (hb.eof set), -2 malformed (hb.error set)
+    int parse_one(HalfBatch &hb, size_t &pos, size_t len);
     ByteSource src_;
-    std::vector<char> buf_;
-    size_t pos_ = 0, len_ = 0;
-    bool eof_ = false;
+    RawBuf tail_;       // bytes after the last complete record of the previous batch
+    bool eof_ = false;  // the source is drained
     SeqFormat format_ = FMT_AUTO;
-    std::string carry_;  // FASTA: header line already consumed while joining the previous record
-    bool have_carry_ = false;
+    size_t chunk_ = 4u << 20;  // bytes per read of the source
+    size_t fa_resume_ = 0;  // FASTA: the scan of the record at `pos` may resume here (long records)
+    size_t fa_resume_rec_ = (size_t)-1;
 };
 
 }  // namespace nh

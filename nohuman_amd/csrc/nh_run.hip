@@ -7,11 +7,16 @@
 // (--output) and return the counts nohuman scrapes from stderr (src/lib.rs:61-97).
 // kraken2 units restated: classify.cc ProcessFiles / output formatting.
 #include <hip/hip_runtime.h>
+#include <errno.h>
+#include <fcntl.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <sys/uio.h>
+#include <unistd.h>
 
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <condition_variable>
 #include <deque>
@@ -27,24 +32,74 @@
 
 namespace nh {
 
+// Output file written with writev(): a batch's output is a list of spans, either slices of the raw
+// input text (kept records that need no reformatting -- the common case, no copy) or pieces of a
+// scratch buffer (reformatted records, kraken output lines).
 struct OutFile {
-    FILE *f = nullptr;
-    std::vector<char> iobuf;
-    int open(const char *path) {
-        f = fopen(path, "wb");
-        if (!f) return set_error(NH_EIO, "cannot create %s", path);
-        iobuf.resize(4u << 20);
-        setvbuf(f, iobuf.data(), _IOFBF, iobuf.size());
+    int fd = -1;
+    std::string path;
+    std::vector<struct iovec> iov;
+    std::vector<char> is_scratch;  // per span: iov_base is an offset into scratch
+    std::string scratch;
+    int open(const char *p) {
+        path = p;
+        fd = ::open(p, O_WRONLY | O_CREAT | O_TRUNC | O_CLOEXEC, 0666);
+        if (fd < 0) return set_error(NH_EIO, "cannot create %s", p);
         return NH_OK;
+    }
+    void add_raw(const char *p, size_t n) {
+        if (!n) return;
+        if (!iov.empty() && !is_scratch.back() && (const char *)iov.back().iov_base + iov.back().iov_len == p) {
+            iov.back().iov_len += n;
+            return;
+        }
+        iov.push_back({(void *)p, n});
+        is_scratch.push_back(0);
+    }
+    // the caller appended [from, scratch.size()) to scratch
+    void add_scratch(size_t from) {
+        const size_t n = scratch.size() - from;
+        if (!n) return;
+        if (!iov.empty() && is_scratch.back() && (size_t)iov.back().iov_base + iov.back().iov_len == from) {
+            iov.back().iov_len += n;
+            return;
+        }
+        iov.push_back({(void *)from, n});
+        is_scratch.push_back(1);
+    }
+    int flush() {  // write all spans, then forget them
+        for (size_t i = 0; i < iov.size(); i++)
+            if (is_scratch[i]) iov[i].iov_base = (void *)(scratch.data() + (size_t)iov[i].iov_base);
+        size_t i = 0;
+        int rc = NH_OK;
+        while (i < iov.size()) {
+            const int cnt = (int)std::min<size_t>(iov.size() - i, 512);
+            ssize_t w = ::writev(fd, &iov[i], cnt);
+            if (w < 0) {
+                if (errno == EINTR) continue;
+                rc = set_error(NH_EIO, "write error on %s", path.c_str());
+                break;
+            }
+            size_t left = (size_t)w;  // consume whole spans, shorten a partly written one
+            while (i < iov.size() && left >= iov[i].iov_len) left -= iov[i++].iov_len;
+            if (left) {
+                iov[i].iov_base = (char *)iov[i].iov_base + left;
+                iov[i].iov_len -= left;
+            }
+        }
+        iov.clear();
+        is_scratch.clear();
+        scratch.clear();
+        return rc;
     }
     int close() {
         int rc = NH_OK;
-        if (f && fclose(f) != 0) rc = set_error(NH_EIO, "write error on output file");
-        f = nullptr;
+        if (fd >= 0 && ::close(fd) != 0) rc = set_error(NH_EIO, "write error on %s", path.c_str());
+        fd = -1;
         return rc;
     }
     ~OutFile() {
-        if (f) fclose(f);
+        if (fd >= 0) ::close(fd);
     }
 };
 
@@ -306,8 +361,47 @@ struct RunState {
     }
 };
 
+// Recycles batch buffers (~100 MB each) between the writer and the readers, so that steady state
+// neither allocates nor page-faults.
+class BatchPool {
+public:
+    std::unique_ptr<HalfBatch> get() {
+        {
+            std::lock_guard<std::mutex> lk(mu_);
+            if (!free_.empty()) {
+                std::unique_ptr<HalfBatch> hb = std::move(free_.back());
+                free_.pop_back();
+                return hb;
+            }
+        }
+        return std::unique_ptr<HalfBatch>(new HalfBatch());
+    }
+    void put(std::unique_ptr<HalfBatch> hb) {
+        if (!hb) return;
+        std::lock_guard<std::mutex> lk(mu_);
+        free_.push_back(std::move(hb));
+    }
+
+private:
+    std::mutex mu_;
+    std::vector<std::unique_ptr<HalfBatch>> free_;
+};
+
+struct StageClock {  // NOHUMAN_TRACE=1: where the wall time of a run goes, per thread
+    std::atomic<uint64_t> ns[12];
+    StageClock() {
+        for (auto &x : ns) x = 0;
+    }
+    static uint64_t now() {
+        return (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(
+                   std::chrono::steady_clock::now().time_since_epoch())
+            .count();
+    }
+};
+enum { ST_READ1 = 0, ST_READ2, ST_RPUSH1, ST_RPUSH2, ST_MPOP, ST_MSLOT, ST_MGATHER, ST_MLAUNCH, ST_WPOP, ST_WSYNC, ST_WFORMAT, ST_WWRITE };
+
 static void reader_main(const char *path, BoundedQueue<std::unique_ptr<HalfBatch>> *out, RunState *rs,
-                        size_t batch_frags, size_t batch_text) {
+                        BatchPool *pool, StageClock *clk, int which, size_t batch_frags, size_t batch_text) {
     BlockReader r;
     std::string err;
     if (r.open(path, err) != 0) {
@@ -316,16 +410,19 @@ static void reader_main(const char *path, BoundedQueue<std::unique_ptr<HalfBatch
         return;
     }
     for (;;) {
-        std::unique_ptr<HalfBatch> hb(new HalfBatch());
-        hb->text.reserve(batch_frags * 340);
+        std::unique_ptr<HalfBatch> hb = pool->get();
         hb->recs.reserve(batch_frags);
+        uint64_t t0 = StageClock::now();
         r.next_batch(*hb, batch_frags, batch_text);
+        uint64_t t1 = StageClock::now();
+        clk->ns[ST_READ1 + which] += t1 - t0;
         if (!hb->error.empty()) {
             rs->fail(NH_EIO, hb->error);
             break;
         }
         const bool eof = hb->eof;
         out->push(std::move(hb));
+        clk->ns[ST_RPUSH1 + which] += StageClock::now() - t1;
         if (eof || rs->failed()) break;
     }
     out->close();
@@ -343,35 +440,51 @@ static inline void put_record(std::string &dst, const HalfBatch &hb, const RecRe
     dst += '\n';
 }
 
-// format + write one finished batch (runs on the writer thread, batches arrive in input order)
-static int write_batch(RunState *rs, const Batch &b, const Slot &s, OutFile &o1, OutFile &o2, OutFile &ok,
-                       std::string &buf1, std::string &buf2, std::string &bufk) {
+// decide + format one finished batch into the span lists of the output files (runs on the writer
+// thread, batches arrive in input order)
+static void format_batch(RunState *rs, const Batch &b, const Slot &s, OutFile &o1, OutFile &o2, OutFile &ok) {
     const nh_run_args *a = rs->a;
     const Engine *e = s.e;
-    buf1.clear();
-    buf2.clear();
-    bufk.clear();
+    const bool keep_class = a->keep_human != 0;
+    const char *t1 = b.h1->text.data();
+    const char *t2 = rs->paired ? b.h2->text.data() : nullptr;
     char tmp[128];
+    uint64_t bases = 0, classified = 0;
     for (size_t i = 0; i < b.n; i++) {
         const RecRef &r1 = b.h1->recs[i];
         const uint32_t call = s.h_res[i].call;
         const bool is_class = call != 0;
-        rs->total++;
-        rs->classified += is_class;
+        classified += is_class;
         rs->call_counts[call] += is_class;
-        rs->total_bases += r1.slen + (rs->paired ? b.h2->recs[i].slen : 0);
-        const uint64_t ext = is_class ? e->external[call] : 0;
-        if (is_class == (a->keep_human != 0)) {
-            const char *suffix = nullptr;
-            if (is_class) {
-                snprintf(tmp, sizeof tmp, " kraken:taxid|%llu", (unsigned long long)ext);
-                suffix = tmp;
+        bases += r1.slen + (rs->paired ? b.h2->recs[i].slen : 0);
+        if (is_class == keep_class) {
+            if (!is_class && r1.raw_end) {
+                o1.add_raw(t1 + r1.h, r1.raw_end - r1.h);
+            } else {
+                const char *suffix = nullptr;
+                if (is_class) {
+                    snprintf(tmp, sizeof tmp, " kraken:taxid|%llu", (unsigned long long)e->external[call]);
+                    suffix = tmp;
+                }
+                const size_t from = o1.scratch.size();
+                put_record(o1.scratch, *b.h1, r1, suffix);
+                o1.add_scratch(from);
             }
-            put_record(buf1, *b.h1, r1, suffix);
-            if (rs->paired) put_record(buf2, *b.h2, b.h2->recs[i], suffix);
+            if (rs->paired) {
+                const RecRef &r2 = b.h2->recs[i];
+                if (!is_class && r2.raw_end) {
+                    o2.add_raw(t2 + r2.h, r2.raw_end - r2.h);
+                } else {
+                    const size_t from = o2.scratch.size();
+                    put_record(o2.scratch, *b.h2, r2, is_class ? tmp : nullptr);
+                    o2.add_scratch(from);
+                }
+            }
         }
         if (rs->want_k) {
-            std::string id(b.h1->text.data() + r1.h + 1, r1.idlen);
+            const uint64_t ext = is_class ? e->external[call] : 0;
+            std::string &bufk = ok.scratch;
+            std::string id(t1 + r1.h + 1, r1.idlen);
             if (rs->paired) trim_pair_info(id);
             bufk += is_class ? "C\t" : "U\t";
             bufk += id;
@@ -386,13 +499,10 @@ static int write_batch(RunState *rs, const Batch &b, const Slot &s, OutFile &o1,
             bufk += '\n';
         }
     }
-    if (!buf1.empty() && fwrite(buf1.data(), 1, buf1.size(), o1.f) != buf1.size())
-        return set_error(NH_EIO, "write error on %s", a->out1);
-    if (rs->paired && !buf2.empty() && fwrite(buf2.data(), 1, buf2.size(), o2.f) != buf2.size())
-        return set_error(NH_EIO, "write error on %s", a->out2);
-    if (rs->want_k && !bufk.empty() && fwrite(bufk.data(), 1, bufk.size(), ok.f) != bufk.size())
-        return set_error(NH_EIO, "write error on %s", a->kraken_output);
-    return NH_OK;
+    if (rs->want_k) ok.add_scratch(0);
+    rs->total += b.n;
+    rs->classified += classified;
+    rs->total_bases += bases;
 }
 
 int run_engines(const std::vector<Engine *> &engines, const nh_run_args *a, nh_stats *stats) {
@@ -444,28 +554,77 @@ int run_engines(const std::vector<Engine *> &engines, const nh_run_args *a, nh_s
     }
 
     BoundedQueue<std::unique_ptr<HalfBatch>> q1(3), q2(3);
-    std::thread t1(reader_main, a->in1, &q1, &rs, BATCH_FRAGS, BATCH_TEXT);
+    BatchPool pool1, pool2;
+    StageClock clk;
+    std::thread t1(reader_main, a->in1, &q1, &rs, &pool1, &clk, 0, BATCH_FRAGS, BATCH_TEXT);
     std::thread t2;
-    if (rs.paired) t2 = std::thread(reader_main, a->in2, &q2, &rs, BATCH_FRAGS, BATCH_TEXT);
+    if (rs.paired) t2 = std::thread(reader_main, a->in2, &q2, &rs, &pool2, &clk, 1, BATCH_FRAGS, BATCH_TEXT);
 
-    // writer: consumes batches in order; each arrives after its stream was synchronised
+    // writer: consumes batches in order; each arrives after its stream was synchronised.  The second
+    // mate file is written by a helper so that both files are written at the same time.
     BoundedQueue<Batch> wq((size_t)(2 * G));
     std::mutex slot_mu;
     std::condition_variable slot_cv;
+    std::mutex w2_mu;
+    std::condition_variable w2_cv;
+    int w2_state = 0;  // 0 idle, 1 flush requested, 2 done, -1 quit
+    int w2_rc = NH_OK;
+    std::string w2_err;
+    std::thread tw2;
+    if (rs.paired)
+        tw2 = std::thread([&] {
+            for (;;) {
+                std::unique_lock<std::mutex> lk(w2_mu);
+                w2_cv.wait(lk, [&] { return w2_state == 1 || w2_state == -1; });
+                if (w2_state == -1) return;
+                lk.unlock();
+                int frc = o2.flush();
+                lk.lock();
+                w2_rc = frc;
+                if (frc) w2_err = g_last_error;
+                w2_state = 2;
+                w2_cv.notify_all();
+            }
+        });
     std::thread tw([&] {
-        std::string buf1, buf2, bufk;
         Batch b;
-        while (wq.pop(b)) {
+        for (;;) {
+            uint64_t c0 = StageClock::now();
+            if (!wq.pop(b)) break;
+            uint64_t c1 = StageClock::now();
+            clk.ns[ST_WPOP] += c1 - c0;
             Slot &s = slots[b.slot];
             if (!rs.failed()) {
                 (void)hipSetDevice(s.e->device);
                 hipError_t he = hipStreamSynchronize(s.stream);
+                uint64_t c2 = StageClock::now();
+                clk.ns[ST_WSYNC] += c2 - c1;
                 int wrc = NH_OK;
                 if (he != hipSuccess) wrc = set_error(NH_EDEVICE, "classify: %s", hipGetErrorString(he));
                 if (!wrc) wrc = check_error_flag(s.e);
-                if (!wrc) wrc = write_batch(&rs, b, s, o1, o2, ok, buf1, buf2, bufk);
+                if (!wrc) {
+                    format_batch(&rs, b, s, o1, o2, ok);
+                    uint64_t c3 = StageClock::now();
+                    clk.ns[ST_WFORMAT] += c3 - c2;
+                    if (rs.paired) {
+                        std::lock_guard<std::mutex> lk(w2_mu);
+                        w2_state = 1;
+                        w2_cv.notify_all();
+                    }
+                    wrc = o1.flush();
+                    if (!wrc && rs.want_k) wrc = ok.flush();
+                    if (rs.paired) {
+                        std::unique_lock<std::mutex> lk(w2_mu);
+                        w2_cv.wait(lk, [&] { return w2_state == 2; });
+                        w2_state = 0;
+                        if (!wrc && w2_rc) wrc = set_error(w2_rc, "%s", w2_err.c_str());
+                    }
+                    clk.ns[ST_WWRITE] += StageClock::now() - c3;
+                }
                 if (wrc) rs.fail(wrc, g_last_error);
             }
+            pool1.put(std::move(b.h1));
+            pool2.put(std::move(b.h2));
             {
                 std::lock_guard<std::mutex> lk(slot_mu);
                 s.busy = false;
@@ -481,6 +640,7 @@ int run_engines(const std::vector<Engine *> &engines, const nh_run_args *a, nh_s
     for (;;) {
         if (rs.failed()) break;
         Batch b;
+        uint64_t m0 = StageClock::now();
         if (!q1.pop(b.h1)) break;
         end1 = b.h1->eof;
         if (rs.paired) {
@@ -496,11 +656,15 @@ int run_engines(const std::vector<Engine *> &engines, const nh_run_args *a, nh_s
         if (b.n > 0) {
             const int si = (int)(batch_no % (uint64_t)(2 * G));
             Slot &s = slots[si];
+            uint64_t m1 = StageClock::now();
+            clk.ns[ST_MPOP] += m1 - m0;
             {
                 std::unique_lock<std::mutex> lk(slot_mu);
                 slot_cv.wait(lk, [&] { return !s.busy; });
                 s.busy = true;
             }
+            uint64_t m2 = StageClock::now();
+            clk.ns[ST_MSLOT] += m2 - m1;
             b.slot = si;
             size_t nbases = 0;
             for (size_t i = 0; i < b.n; i++)
@@ -526,10 +690,12 @@ int run_engines(const std::vector<Engine *> &engines, const nh_run_args *a, nh_s
             // gather the sequence bytes of the batch into pinned memory
             uint64_t off = 0, toff = 0;
             const uint64_t k = s.e->info.k;
+            const char *txt1 = b.h1->text.data();
+            const char *txt2 = rs.paired ? b.h2->text.data() : nullptr;
             for (size_t i = 0; i < b.n; i++) {
                 const RecRef &r1 = b.h1->recs[i];
                 s.h_off[i * mates] = off;
-                memcpy(s.h_bases + off, b.h1->text.data() + r1.s, r1.slen);
+                memcpy(s.h_bases + off, txt1 + r1.s, r1.slen);
                 off += r1.slen;
                 if (rs.want_k) {
                     s.h_taxa_off[i] = toff;
@@ -538,7 +704,7 @@ int run_engines(const std::vector<Engine *> &engines, const nh_run_args *a, nh_s
                 if (rs.paired) {
                     const RecRef &r2 = b.h2->recs[i];
                     s.h_off[i * mates + 1] = off;
-                    memcpy(s.h_bases + off, b.h2->text.data() + r2.s, r2.slen);
+                    memcpy(s.h_bases + off, txt2 + r2.s, r2.slen);
                     off += r2.slen;
                     if (rs.want_k) toff += (r2.slen >= k ? r2.slen - k + 1 : 0) + 1;
                 }
@@ -548,6 +714,8 @@ int run_engines(const std::vector<Engine *> &engines, const nh_run_args *a, nh_s
             if (rs.want_k) s.h_taxa_off[b.n] = toff;
             s.n_taxa = toff;
             // H2D, classify, D2H: all asynchronous on the slot's stream
+            uint64_t m3 = StageClock::now();
+            clk.ns[ST_MGATHER] += m3 - m2;
             hipError_t he = hipSetDevice(s.e->device);
             if (he == hipSuccess)
                 he = hipMemcpyAsync(s.d_bases, s.h_bases, off + 64, hipMemcpyHostToDevice, s.stream);
@@ -572,6 +740,7 @@ int run_engines(const std::vector<Engine *> &engines, const nh_run_args *a, nh_s
             }
             batch_no++;
             wq.push(std::move(b));
+            clk.ns[ST_MLAUNCH] += StageClock::now() - m3;
         }
         if (last) break;
     }
@@ -582,7 +751,25 @@ int run_engines(const std::vector<Engine *> &engines, const nh_run_args *a, nh_s
     t1.join();
     if (t2.joinable()) t2.join();
     tw.join();
+    if (tw2.joinable()) {
+        {
+            std::lock_guard<std::mutex> lk(w2_mu);
+            w2_state = -1;
+        }
+        w2_cv.notify_all();
+        tw2.join();
+    }
     for (auto &s : slots) slot_free(s);
+    if (const char *tr = getenv("NOHUMAN_TRACE")) {
+        if (tr[0] == '1') {
+            static const char *names[] = {"read1", "read2", "rpush1", "rpush2", "main.pop", "main.slot", "main.gather",
+                                          "main.launch", "wr.pop", "wr.sync", "wr.format", "wr.write"};
+            fprintf(stderr, "[nohuman trace] wall %.3fs |",
+                    std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count());
+            for (int i = 0; i < 12; i++) fprintf(stderr, " %s %.3f", names[i], (double)clk.ns[i].load() * 1e-9);
+            fprintf(stderr, "\n");
+        }
+    }
     if (rs.err_code != NH_OK) return set_error(rs.err_code, "%s", rs.err_msg.c_str());
 
     if (a->report && a->report[0] &&
@@ -628,9 +815,14 @@ int nh_fastx_scan(const char *path, uint64_t *n_records, uint64_t *n_bases, uint
         for (size_t i = 0; i < len; i++) h = (h ^ (unsigned char)p[i]) * 0x100000001b3ull;
         h = (h ^ 0) * 0x100000001b3ull;
     };
+    size_t scan_batch = 4096;
+    if (const char *env = getenv("NOHUMAN_SCAN_BATCH")) {  // test knob
+        const long v = atol(env);
+        if (v > 0) scan_batch = (size_t)v;
+    }
+    nh::HalfBatch hb;
     for (;;) {
-        nh::HalfBatch hb;
-        r.next_batch(hb, 4096, 64u << 20);
+        r.next_batch(hb, scan_batch, 64u << 20);
         if (!hb.error.empty()) return nh::set_error(NH_EIO, "%s", hb.error.c_str());
         for (const nh::RecRef &x : hb.recs) {
             n++;

@@ -151,37 +151,10 @@ static std::string add_extension(Codec c, const std::string &p) {
 
 // compress stage (src/compression.rs:182-268): content parity, not byte-identical streams
 static void compress_to(Codec c, const std::string &in, const std::string &out, unsigned threads) {
-    FILE *fi = fopen(in.c_str(), "rb");
-    if (!fi) die("Failed to open %s", quoted(in).c_str());
-    std::vector<char> buf(4u << 20);
-    size_t n;
-    if (c == C_NONE) {
-        FILE *fo = fopen(out.c_str(), "wb");
-        if (!fo) die("Failed to create %s", quoted(out).c_str());
-        while ((n = fread(buf.data(), 1, buf.size(), fi)) > 0)
-            if (fwrite(buf.data(), 1, n, fo) != n) die("Failed to write %s", quoted(out).c_str());
-        if (fclose(fo) != 0) die("Failed to write %s", quoted(out).c_str());
-    } else if (c == C_GZ) {
-        gzFile g = gzopen(out.c_str(), "wb6");
-        if (!g) die("Failed to create %s", quoted(out).c_str());
-        gzbuffer(g, 1u << 20);
-        while ((n = fread(buf.data(), 1, buf.size(), fi)) > 0)
-            if (gzwrite(g, buf.data(), (unsigned)n) != (int)n) die("Failed to write %s", quoted(out).c_str());
-        if (gzclose(g) != Z_OK) die("Failed to write %s", quoted(out).c_str());
-    } else if (c == C_BZ2 || c == C_XZ) {
-        // the codec libraries' headers are not in this image; their command-line tools are
-        std::string cmd = c == C_BZ2 ? "bzip2 -c > '" : "xz -6 -c -T" + std::to_string(threads ? threads : 1) + " > '";
-        for (char ch : out) cmd += ch == '\'' ? std::string("'\\''") : std::string(1, ch);
-        cmd += "'";
-        FILE *p = popen(cmd.c_str(), "w");
-        if (!p) die("Failed to run the %s compressor", codec_ext(c));
-        while ((n = fread(buf.data(), 1, buf.size(), fi)) > 0)
-            if (fwrite(buf.data(), 1, n, p) != n) die("Failed to write %s", quoted(out).c_str());
-        if (pclose(p) != 0) die("The %s compressor failed on %s", codec_ext(c), quoted(out).c_str());
-    } else {
-        die("Zstd output is not available in this build (no libzstd headers / zstd tool in the image)");
-    }
-    fclose(fi);
+    const int codec = c == C_GZ ? NH_CODEC_GZIP : c == C_BZ2 ? NH_CODEC_BZIP2 : c == C_XZ ? NH_CODEC_XZ
+                    : c == C_ZST ? NH_CODEC_ZSTD : NH_CODEC_NONE;
+    if (nh_compress_file(in.c_str(), out.c_str(), codec, threads) != 0)
+        die("Failed to compress file: %s", nh_last_error());
 }
 
 // ---- database discovery (src/download.rs:178-232, src/lib.rs:119-141) --------------------------------

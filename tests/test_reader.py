@@ -89,6 +89,32 @@ def test_reader_edge_cases(tmp_path, name):
     assert scan(p) == expect(CASES[name])
 
 
+@pytest.mark.parametrize("chunk,batch", [(1, 1), (7, 2), (64, 3), (5, 4096)])
+@pytest.mark.parametrize("name", sorted(CASES))
+def test_reader_records_across_read_and_batch_boundaries(tmp_path, monkeypatch, name, chunk, batch):
+    """The reader parses in place in the buffer it reads into: tiny reads and tiny batches put every
+    kind of boundary (inside a line, between lines of a record, between records) at a buffer edge."""
+    monkeypatch.setenv("NOHUMAN_READ_CHUNK", str(chunk))
+    monkeypatch.setenv("NOHUMAN_SCAN_BATCH", str(batch))
+    p = tmp_path / (name + ".txt")
+    p.write_bytes(CASES[name])
+    assert scan(p) == expect(CASES[name])
+    gz = tmp_path / (name + ".gz")
+    with gzip.open(gz, "wb") as f:
+        f.write(CASES[name])
+    assert scan(gz) == expect(CASES[name])
+
+
+def test_reader_long_fasta_record_over_many_reads(tmp_path, monkeypatch):
+    monkeypatch.setenv("NOHUMAN_READ_CHUNK", "1000")
+    body = b"".join(b"ACGTTGCA" * 10 + b"\n" for _ in range(2000))  # one 160 kb record, 80-column lines
+    data = b">chr1 test\n" + body + b">chr2\nAC\n"
+    p = tmp_path / "long.fa"
+    p.write_bytes(data)
+    assert scan(p) == expect(data)
+    assert expect(data)[:2] == (2, 160002)
+
+
 def test_reader_golden_fixtures_plain_gzip_bzip2(tmp_path):
     data = open(os.path.join(GOLD, "reads_se.fq"), "rb").read() * 30  # 3.8 MB: several refills of the inflate buffer
     want = expect(data)
