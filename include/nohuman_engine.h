@@ -201,6 +201,12 @@ typedef enum nh_codec {
     NH_CODEC_ZSTD = 4 /* not available in this build: NH_EINVAL */
 } nh_codec;
 int nh_compress_file(const char *in, const char *out, int codec, uint32_t threads);
+/* Test / tool support for the multi-threaded gzip input decoder nh_run reads .gz inputs with
+ * (kraken2's wrapper pipes them through `gzip -dc`): decompress `in` to
+ * `out` on `threads` workers, cutting the compressed file every chunk_bytes (0 = default).
+ * stats3 (optional) receives {chunks accepted, chunks rejected, bytes decoded in order by the
+ * consumer}.  Needs no GPU. */
+int nh_gunzip_file(const char *in, const char *out, uint32_t threads, uint64_t chunk_bytes, uint64_t *stats3);
 /* nh_run on an already opened engine (single device) */
 int nh_run_engine(nh_engine *e, const nh_run_args *args, nh_stats *stats);
 

@@ -25,6 +25,7 @@
 #include <thread>
 #include <vector>
 
+#include "nh_inflate.h"
 #include "nh_internal.h"
 #include "nohuman_engine.h"
 
@@ -254,6 +255,33 @@ int compress_file(const char *in, const char *out, int codec, unsigned threads) 
 }
 
 }  // namespace nh
+
+extern "C" int nh_gunzip_file(const char *in, const char *out, uint32_t threads, uint64_t chunk_bytes,
+                              uint64_t *stats3) {
+    if (!in || !out) return nh::set_error(NH_EINVAL, "nh_gunzip_file: null path");
+    nh::ParallelGunzip gz;
+    std::string err;
+    if (gz.open(in, threads, (size_t)chunk_bytes, err) != 0) return nh::set_error(NH_EIO, "%s", err.c_str());
+    int fout = ::open(out, O_WRONLY | O_CREAT | O_TRUNC | O_CLOEXEC, 0666);
+    if (fout < 0) return nh::set_error(NH_EIO, "cannot create %s", out);
+    std::vector<uint8_t> buf(8u << 20);
+    int rc = NH_OK;
+    for (;;) {
+        const long n = gz.read(buf.data(), buf.size());
+        if (n < 0) {
+            rc = nh::set_error(NH_EIO, "%s", gz.error().c_str());
+            break;
+        }
+        if (n == 0) break;
+        if (!nh::write_all(fout, buf.data(), (size_t)n)) {
+            rc = nh::set_error(NH_EIO, "write error on %s", out);
+            break;
+        }
+    }
+    if (::close(fout) != 0 && rc == NH_OK) rc = nh::set_error(NH_EIO, "write error on %s", out);
+    if (stats3) gz.stats(&stats3[0], &stats3[1], &stats3[2]);
+    return rc;
+}
 
 extern "C" int nh_compress_file(const char *in, const char *out, int codec, uint32_t threads) {
     return nh::compress_file(in, out, codec, threads);

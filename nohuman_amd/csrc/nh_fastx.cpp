@@ -1,5 +1,6 @@
 // nh_fastx.cpp -- see nh_fastx.h.  Record semantics follow SURVEY.md A.6 (kraken2 seqreader.cc).
 #include "nh_fastx.h"
+#include "nh_inflate.h"
 
 #include <ctype.h>
 #include <errno.h>
@@ -12,7 +13,7 @@ namespace nh {
 
 ByteSource::~ByteSource() { close(); }
 
-int ByteSource::open(const char *path, std::string &err) {
+int ByteSource::open(const char *path, std::string &err, unsigned gz_threads) {
     close();
     FILE *f = fopen(path, "rb");
     if (!f) {
@@ -48,6 +49,16 @@ int ByteSource::open(const char *path, std::string &err) {
         (void)posix_fadvise(fd_, 0, 0, POSIX_FADV_SEQUENTIAL);
         return 0;
     }
+    if (const char *env = getenv("NOHUMAN_GZ_THREADS")) gz_threads = (unsigned)atoi(env);  // 0 = zlib
+    if (gz_threads > 0) {
+        size_t chunk = 0;
+        if (const char *env = getenv("NOHUMAN_GZ_CHUNK")) chunk = (size_t)atol(env);  // test knob
+        pgz_ = new ParallelGunzip();
+        std::string perr;
+        if (pgz_->open(path, gz_threads, chunk, perr) == 0) return 0;
+        delete pgz_;  // e.g. not a regular file: zlib takes it
+        pgz_ = nullptr;
+    }
     gzFile g = gzopen(path, "rb");
     if (!g) {
         err = std::string("cannot open ") + path;
@@ -59,6 +70,11 @@ int ByteSource::open(const char *path, std::string &err) {
 }
 
 long ByteSource::read(uint8_t *buf, size_t cap) {
+    if (pgz_) {
+        long n = pgz_->read(buf, cap);
+        if (n < 0) pgz_error_ = pgz_->error();
+        return n;
+    }
     if (fd_ >= 0) {
         size_t got = 0;
         while (got < cap) {  // fill the request like gzread / fread do
@@ -74,6 +90,11 @@ long ByteSource::read(uint8_t *buf, size_t cap) {
     }
     if (gz_) {
         int n = gzread((gzFile)gz_, buf, (unsigned)cap);
+        if (n < 0) {
+            int code = 0;
+            const char *msg = gzerror((gzFile)gz_, &code);
+            pgz_error_ = std::string("gzip: ") + (msg ? msg : "read error");
+        }
         return n;
     }
     if (pipe_) {
@@ -88,6 +109,8 @@ void ByteSource::close() {
     if (gz_) gzclose((gzFile)gz_);
     if (pipe_) pclose(pipe_);
     if (fd_ >= 0) ::close(fd_);
+    delete pgz_;
+    pgz_ = nullptr;
     fd_ = -1;
     gz_ = nullptr;
     pipe_ = nullptr;
@@ -191,7 +214,7 @@ int FastxReader::next(SeqRecord &rec, std::string &err) {
 }
 
 // ------------------------------------------------------------------------------------------------
-int BlockReader::open(const char *path, std::string &err) {
+int BlockReader::open(const char *path, std::string &err, unsigned gz_threads) {
     tail_.clear();
     eof_ = false;
     format_ = FMT_AUTO;
@@ -201,7 +224,7 @@ int BlockReader::open(const char *path, std::string &err) {
         const long v = atol(env);
         if (v > 0) chunk_ = (size_t)v;
     }
-    return src_.open(path, err);
+    return src_.open(path, err, gz_threads);
 }
 
 static inline const char *rstrip(const char *b, const char *e) {
@@ -383,7 +406,11 @@ void BlockReader::next_batch(HalfBatch &hb, size_t max_recs, size_t max_text) {
             return;
         }
         long n = src_.read((uint8_t *)hb.text.data() + hb.text.size(), CHUNK);
-        if (n <= 0)
+        if (n < 0) {
+            hb.error = src_.error().empty() ? std::string("read error on input file") : src_.error();
+            return;
+        }
+        if (n == 0)
             eof_ = true;
         else
             hb.text.set_size(hb.text.size() + (size_t)n);

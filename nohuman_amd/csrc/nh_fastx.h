@@ -23,18 +23,25 @@ struct SeqRecord {
 };
 
 // Byte source: plain, gzip (zlib) or bzip2 (through `bzip2 -dc`, as kraken2's wrapper does).
+class ParallelGunzip;
+
 class ByteSource {
 public:
     ~ByteSource();
-    int open(const char *path, std::string &err);
+    // gz_threads > 0: gzip files are decoded by the in-process multi-threaded decoder
+    // (nh_inflate.h) on that many workers; 0: zlib on the calling thread
+    int open(const char *path, std::string &err, unsigned gz_threads = 0);
     // fills up to cap bytes; returns bytes read, 0 at EOF, -1 on error
     long read(uint8_t *buf, size_t cap);
     void close();
+    const std::string &error() const { return pgz_error_; }
 
 private:
     void *gz_ = nullptr;   // gzFile
     FILE *pipe_ = nullptr; // bzip2 -dc
     int fd_ = -1;          // plain text
+    ParallelGunzip *pgz_ = nullptr;
+    std::string pgz_error_;
 };
 
 class FastxReader {
@@ -121,7 +128,7 @@ struct HalfBatch {  // the records one input file contributes to a batch
 // into the raw bytes, nothing is copied per record (multi-line FASTA sequences are joined in place).
 class BlockReader {
 public:
-    int open(const char *path, std::string &err);
+    int open(const char *path, std::string &err, unsigned gz_threads = 0);
     // parses up to max_recs records (or about max_text bytes) into hb (which is reset first);
     // sets hb.eof at end of input.  Text offsets are 32-bit: max_text is clamped below 2^32.
     void next_batch(HalfBatch &hb, size_t max_recs, size_t max_text);

@@ -401,10 +401,11 @@ struct StageClock {  // NOHUMAN_TRACE=1: where the wall time of a run goes, per 
 enum { ST_READ1 = 0, ST_READ2, ST_RPUSH1, ST_RPUSH2, ST_MPOP, ST_MSLOT, ST_MGATHER, ST_MLAUNCH, ST_WPOP, ST_WSYNC, ST_WFORMAT, ST_WWRITE };
 
 static void reader_main(const char *path, BoundedQueue<std::unique_ptr<HalfBatch>> *out, RunState *rs,
-                        BatchPool *pool, StageClock *clk, int which, size_t batch_frags, size_t batch_text) {
+                        BatchPool *pool, StageClock *clk, int which, size_t batch_frags, size_t batch_text,
+                        unsigned gz_threads) {
     BlockReader r;
     std::string err;
-    if (r.open(path, err) != 0) {
+    if (r.open(path, err, gz_threads) != 0) {
         rs->fail(NH_EIO, err);
         out->close();
         return;
@@ -556,9 +557,13 @@ int run_engines(const std::vector<Engine *> &engines, const nh_run_args *a, nh_s
     BoundedQueue<std::unique_ptr<HalfBatch>> q1(3), q2(3);
     BatchPool pool1, pool2;
     StageClock clk;
-    std::thread t1(reader_main, a->in1, &q1, &rs, &pool1, &clk, 0, BATCH_FRAGS, BATCH_TEXT);
+    // gzip inputs are inflated by `threads` workers in all, shared between the files
+    unsigned gz_threads = (a->threads ? a->threads : 1) / (unsigned)mates;
+    if (gz_threads < 1) gz_threads = 1;
+    std::thread t1(reader_main, a->in1, &q1, &rs, &pool1, &clk, 0, BATCH_FRAGS, BATCH_TEXT, gz_threads);
     std::thread t2;
-    if (rs.paired) t2 = std::thread(reader_main, a->in2, &q2, &rs, &pool2, &clk, 1, BATCH_FRAGS, BATCH_TEXT);
+    if (rs.paired)
+        t2 = std::thread(reader_main, a->in2, &q2, &rs, &pool2, &clk, 1, BATCH_FRAGS, BATCH_TEXT, gz_threads);
 
     // writer: consumes batches in order; each arrives after its stream was synchronised.  The second
     // mate file is written by a helper so that both files are written at the same time.

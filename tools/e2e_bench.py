@@ -39,23 +39,37 @@ try:
     f1, f2 = os.path.join(tmp, "r_1.fq"), os.path.join(tmp, "r_2.fq")
     write_fastq(f1, 1); write_fastq(f2, 2)
     print("setup %.1fs: db %.2f GB, 2 x %.0f MB FASTQ" % (time.time() - t0, cap * 4 / 1e9, os.path.getsize(f1) / 1e6))
+    reps = int(os.environ.get("E2E_REPS", "4"))  # the inputs are the generated files repeated `reps` times
+    threads = int(os.environ.get("E2E_THREADS", str(min(16, os.cpu_count() or 1))))
+    t = time.time()
+    os.system("gzip -6 -k %s %s" % (f1, f2))
+    print("gzip -6 took %.1fs" % (time.time() - t))
+    def rep_file(path):
+        if reps == 1:
+            return path
+        out = path + ".x%d" % reps
+        with open(out, "wb") as fo:
+            data = open(path, "rb").read()
+            for _ in range(reps):
+                fo.write(data)
+        return out
+    F1, F2, G1, G2 = rep_file(f1), rep_file(f2), rep_file(f1 + ".gz"), rep_file(f2 + ".gz")
+    o1, o2 = os.path.join(tmp, "o_1.fq"), os.path.join(tmp, "o_2.fq")
     with Engine.open(db) as e:
-        for label, a, b in (("plain PE", f1, f2),):
-            for rep in range(2):
-                t = time.time()
-                st = e.run(a, os.path.join(tmp, "o_1.fq"), in2=b, out2=os.path.join(tmp, "o_2.fq"))
-                dt = time.time() - t
-                print("%s run %d: %.2fs wall, %.2f Mreads/s e2e (%d fragments, %d classified)" % (label, rep, dt, 2 * st.total_sequences / dt / 1e6, st.total_sequences, st.classified))
-        t = time.time()
-        st = e.run(f1, os.path.join(tmp, "o.fq"))
-        dt = time.time() - t
-        print("plain SE: %.2fs wall, %.2f Mreads/s e2e" % (dt, st.total_sequences / dt / 1e6))
-        t = time.time()
-        os.system("gzip -1 -k %s %s" % (f1, f2))
-        print("gzip -1 took %.1fs" % (time.time() - t))
-        t = time.time()
-        st = e.run(f1 + ".gz", os.path.join(tmp, "o_1.fq"), in2=f2 + ".gz", out2=os.path.join(tmp, "o_2.fq"))
-        dt = time.time() - t
-        print("gzip PE: %.2fs wall, %.2f Mreads/s e2e" % (dt, 2 * st.total_sequences / dt / 1e6))
+        def go(label, a, b, th):
+            for p in (o1, o2):
+                if os.path.exists(p):
+                    os.remove(p)
+            t = time.time()
+            st = e.run(a, o1, in2=b, out2=o2 if b else None, threads=th)
+            dt = time.time() - t
+            n = st.total_sequences * (2 if b else 1)
+            print("%-28s %6.2fs wall  %7.2f Mreads/s e2e  (%d reads, %d classified)" % (label, dt, n / dt / 1e6, n, st.classified))
+        go("plain PE (warm-up)", F1, F2, threads)
+        go("plain PE", F1, F2, threads)
+        go("plain SE", F1, None, threads)
+        go("gzip PE, 1 thread (zlib-like)", G1, G2, 1)
+        go("gzip PE, %d threads" % threads, G1, G2, threads)
+        go("gzip SE, %d threads" % threads, G1, None, threads)
 finally:
     shutil.rmtree(tmp, ignore_errors=True)
