@@ -1239,7 +1239,10 @@ hipError_t launch_classify(const DevDB &db, const void *d_bases, const void *d_s
     ka.counters = (unsigned long long *)d_counters;
     ka.error_flag = d_error;
     ka.work = d_work;
-    const bool cap32 = db.capacity < 0xFFFFFF00ull;
+    // tables of 2^32 - 256 cells or more take the variant with 64-bit cell positions;
+    // NOHUMAN_FORCE_WIDE=1 selects it for any table (tests: small tables through the wide path)
+    static const bool force_wide = getenv("NOHUMAN_FORCE_WIDE") != nullptr;
+    const bool cap32 = db.capacity < 0xFFFFFF00ull && !force_wide;
     const bool may_overflow = db.node_count > LIST_CAP;  // <= 64 taxa can never overflow the list
     if (db.linear_probing && std_geom && cap32 && getenv("NH_PHASE_PROF"))
         launch_variant<true, true, true, true>(ka, g, b, stream, may_overflow, d_work);  // d_counters: CNT_N + 12 words

@@ -163,3 +163,60 @@ def test_more_than_64_distinct_taxa_take_the_second_pass():
     ldb = lit.DB.from_images(ob, tb, hashb)
     distinct = {t for t in lit.classify_fragment(ldb, (reads[0],), 0.0)[4] if t not in (0, lit.AMBIG)}
     assert len(distinct) > 64
+
+
+def test_wide_position_variant_on_small_tables():
+    """Tables of 2^32 - 256 cells or more are probed with 64-bit cell positions by a separate kernel
+    variant.  NOHUMAN_FORCE_WIDE routes the small test tables through that variant: the parity tests
+    of this file must hold there as well (the variant is picked once per process, hence a child)."""
+    import os
+    import subprocess
+    import sys
+    env = dict(os.environ, NOHUMAN_FORCE_WIDE="1")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-m", "pytest", "tests/test_gpu_parity.py", "-m", "gpu", "-q", "-x",
+                        "-k", "toy_db_parity or edge_cases or long_reads or distinct_taxa or k31l31"],
+                       cwd=root, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+    assert " passed" in r.stdout
+
+
+def test_table_larger_than_2_pow_32_cells():
+    """A 4.4 G-cell table (17.6 GB in HBM): cell positions beyond 2^32 are really addressed.  Reads
+    cut from sequences whose minimizers were inserted must all classify to the inserted taxon, random
+    reads must not, and the lookup count must equal the one a small table gives for the same reads."""
+    import torch
+    from nohuman_amd import Engine
+    dev = torch.device("cuda:0")
+    g = torch.Generator(device=dev)
+    g.manual_seed(77)
+    acgt = torch.tensor([65, 67, 71, 84], dtype=torch.uint8, device=dev)
+    n_src, L = 4000, 1000
+    src = acgt[torch.randint(0, 4, (n_src * L + 64,), generator=g, device=dev)].contiguous()
+    src_off = (torch.arange(n_src + 1, dtype=torch.int64, device=dev) * L).contiguous()
+    n_reads, R = 20000, 150
+    starts = torch.randint(0, n_src * L - R, (n_reads // 2,), generator=g, device=dev)
+    starts = starts - torch.clamp((starts % L) + R - L, min=0)  # stay inside one source sequence
+    idx = starts[:, None] + torch.arange(R, device=dev)[None, :]
+    hit_reads = src[idx.reshape(-1)]
+    rnd_reads = acgt[torch.randint(0, 4, (n_reads // 2 * R,), generator=g, device=dev)]
+    bases = torch.cat([hit_reads, rnd_reads, torch.full((64,), 65, dtype=torch.uint8, device=dev)]).contiguous()
+    offs = (torch.arange(n_reads + 1, dtype=torch.int64, device=dev) * R).contiguous()
+    res = {}
+    for name, cap in (("small", 50_000_017), ("wide", 4_400_000_011)):
+        with Engine.synthetic(cap, int(cap * 0.5), depth=30, seed=5) as eng:
+            assert (eng.info.capacity >= 2 ** 32) == (name == "wide")
+            eng.add_sequences(src.data_ptr(), src_off.data_ptr(), n_src, 30)
+            out = torch.zeros(n_reads * 4, dtype=torch.int32, device=dev)
+            eng.reset_stats()
+            eng.classify_device(bases.data_ptr(), offs.data_ptr(), n_reads, False, 0.0, out.data_ptr())
+            torch.cuda.synchronize()
+            st = eng.stats()
+            rec = out.cpu().numpy().view(np.uint32).reshape(n_reads, 4)
+            res[name] = (rec.copy(), st.table_lookups)
+            assert (rec[: n_reads // 2, 0] == 30).all(), name  # every read of inserted sequence is found
+            assert (rec[: n_reads // 2, 2] == R - 35 + 1).all(), name  # all of its k-mers hit the taxon
+            # random reads: only chance matches of the compacted keys, far below 1 %
+            assert (rec[n_reads // 2:, 0] != 0).mean() < 0.01, name
+    assert res["small"][1] == res["wide"][1]  # same minimizer runs -> same number of lookups
+    assert np.array_equal(res["small"][0][: n_reads // 2], res["wide"][0][: n_reads // 2])
