@@ -150,6 +150,7 @@ uint64_t nh_kmer_taxa_entries(const nh_engine *e, const uint64_t *seq_offsets, u
  * 8 bytes past the last base.  d_kmer_taxa / d_kmer_taxa_offsets may be NULL.  d_counters (may be
  * NULL) points at 4 uint64 accumulators {fragments, classified, bases, table_lookups} that the
  * kernel adds to.  This is the entry the roofline number of bench.py is measured on.
+ * Up to 16 launches of one engine may be in flight at once (on any streams).
  */
 int nh_classify_batch_device(nh_engine *e, const void *d_bases, const void *d_seq_offsets,
                              uint64_t n_frag, uint32_t flags, double confidence, void *d_results,

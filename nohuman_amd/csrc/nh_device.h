@@ -49,7 +49,8 @@ struct KArgs {
     uint32_t *kmer_taxa;
     const uint64_t *kmer_taxa_off;
     unsigned long long *counters;
-    int *error_flag;
+    int *error_flag;  // sticky error bits of the engine (1: > 2048 distinct taxa, 2: sequence too long)
+    int *pending;     // per launch slot: fragments were left to the BIG variant
     unsigned long long *work;
 };
 

@@ -169,9 +169,10 @@ static int common_open(Engine *e, int device) {
     HIP_TRY(hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking));
     HIP_TRY(hipMalloc((void **)&e->d_counters, (CNT_N + 12) * sizeof(uint64_t)));
     HIP_TRY(hipMemset(e->d_counters, 0, (CNT_N + 12) * sizeof(uint64_t)));
-    HIP_TRY(hipMalloc((void **)&e->d_work, 2 * sizeof(unsigned long long)));
-    HIP_TRY(hipMalloc((void **)&e->d_error, 2 * sizeof(int)));  // [0] overflow pending, [1] errors
-    HIP_TRY(hipMemset(e->d_error, 0, 2 * sizeof(int)));
+    HIP_TRY(hipMalloc((void **)&e->d_work, LAUNCH_SLOTS * sizeof(unsigned long long)));
+    // [0, LAUNCH_SLOTS) "fragments left to the BIG variant" per launch slot, then the sticky error bits
+    HIP_TRY(hipMalloc((void **)&e->d_error, (LAUNCH_SLOTS + 1) * sizeof(int)));
+    HIP_TRY(hipMemset(e->d_error, 0, (LAUNCH_SLOTS + 1) * sizeof(int)));
     return NH_OK;
 }
 
@@ -464,19 +465,14 @@ uint64_t kmer_taxa_entries(const Engine *e, const uint64_t *seq_offsets, uint64_
     return total;
 }
 
-int classify_device(Engine *e, const void *d_bases, const void *d_seq_off, uint64_t n_frag,
-                    uint32_t flags, double confidence, void *d_results, void *d_kmer_taxa,
-                    const void *d_kmer_taxa_off, void *d_counters, hipStream_t stream) {
-    return classify_device_slot(e, d_bases, d_seq_off, n_frag, flags, confidence, d_results, d_kmer_taxa,
-                                d_kmer_taxa_off, d_counters, stream, 0);
-}
 
-// work_slot selects one of two dynamic-scheduling counters, so that launches queued on two streams
-// of the same engine do not share one
-int classify_device_slot(Engine *e, const void *d_bases, const void *d_seq_off, uint64_t n_frag,
+// Every launch takes the next of LAUNCH_SLOTS (scheduling counter, "BIG pass pending" word), so
+// launches in flight on different streams of one engine never share them (more than LAUNCH_SLOTS
+// launches in flight at once on one engine are not supported).
+int classify_device(Engine *e, const void *d_bases, const void *d_seq_off, uint64_t n_frag,
                          uint32_t flags, double confidence, void *d_results, void *d_kmer_taxa,
-                         const void *d_kmer_taxa_off, void *d_counters, hipStream_t stream,
-                         int work_slot) {
+                         const void *d_kmer_taxa_off, void *d_counters, hipStream_t stream) {
+    const unsigned slot = e->launch_seq.fetch_add(1) % LAUNCH_SLOTS;
     if (!(confidence >= 0.0 && confidence <= 1.0))
         return set_error(NH_EINVAL, "Confidence score must be in the closed interval [0, 1]");
     if ((d_kmer_taxa != nullptr) != (d_kmer_taxa_off != nullptr))
@@ -485,7 +481,8 @@ int classify_device_slot(Engine *e, const void *d_bases, const void *d_seq_off, 
     finish_devdb(e);
     hipError_t he = launch_classify(e->dev, d_bases, d_seq_off, n_frag,
                                     (flags & NH_FLAG_PAIRED) ? 2 : 1, confidence, d_results,
-                                    d_kmer_taxa, d_kmer_taxa_off, d_counters, e->d_error, e->d_work + (work_slot & 1),
+                                    d_kmer_taxa, d_kmer_taxa_off, d_counters, e->d_error + LAUNCH_SLOTS, e->d_error + slot,
+                                    e->d_work + slot,
                                     (flags & NH_FLAG_LONG) ? 1u : (e->frag_chunk > 31 ? 31 : e->frag_chunk), e->grid_blocks,
                                     stream);
     if (he != hipSuccess) return set_error(NH_EDEVICE, "classify launch: %s", hipGetErrorString(he));
@@ -494,9 +491,9 @@ int classify_device_slot(Engine *e, const void *d_bases, const void *d_seq_off, 
 
 int check_error_flag(Engine *e) {
     int flag = 0;
-    HIP_TRY(hipMemcpy(&flag, e->d_error + 1, sizeof(int), hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(&flag, e->d_error + LAUNCH_SLOTS, sizeof(int), hipMemcpyDeviceToHost));
     if (flag) {
-        HIP_TRY(hipMemset(e->d_error, 0, 2 * sizeof(int)));
+        HIP_TRY(hipMemset(e->d_error + LAUNCH_SLOTS, 0, sizeof(int)));
         if (flag & 2)
             return set_error(NH_EINVAL, "a sequence of 2^31 bases or more is not supported");
         return set_error(NH_ECAPACITY, "a fragment hit more than 2048 distinct taxa");
@@ -543,6 +540,9 @@ int classify_host(Engine *e, const uint8_t *bases, const uint64_t *seq_offsets, 
         HIP_TRY(hipMemcpyAsync(st.d_taxa_off, kmer_taxa_offsets, (n_frag + 1) * 8,
                                hipMemcpyHostToDevice, e->stream));
     }
+    // One H2D copy, one launch, one D2H copy on one stream.  (Measured on the MI355X box: cutting the
+    // batch into pieces on two streams to overlap the copy with the kernel is slower, 11.5 vs 9.4 ms
+    // per 1 M pairs -- tools/host_batch_bench.py.)
     if (total) HIP_TRY(hipMemcpyAsync(st.d_bases, bases + base0, total, hipMemcpyHostToDevice, e->stream));
     HIP_TRY(hipMemsetAsync((uint8_t *)st.d_bases + total, 'A', 64, e->stream));
     HIP_TRY(hipMemcpyAsync(st.d_offsets, offs, (n_seq + 1) * 8, hipMemcpyHostToDevice, e->stream));

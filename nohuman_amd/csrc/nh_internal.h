@@ -3,12 +3,17 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <atomic>
 #include <mutex>
 #include <string>
 #include <vector>
 
 #include "nh_device.h"
 #include "nohuman_engine.h"
+
+namespace nh {
+constexpr unsigned LAUNCH_SLOTS = 16;  // launches of one engine that may be in flight at once
+}
 
 namespace nh {
 
@@ -30,7 +35,8 @@ struct Engine {
     uint32_t *d_parent = nullptr;
     uint64_t *d_counters = nullptr;
     int *d_error = nullptr;
-    unsigned long long *d_work = nullptr;  // dynamic fragment-chunk counters of k_classify (2 slots)
+    unsigned long long *d_work = nullptr;  // dynamic fragment-chunk counters of k_classify, one per launch slot
+    std::atomic<unsigned> launch_seq{0};
     uint32_t frag_chunk = 16;              // fragments a wave pulls at a time
     hipStream_t stream = nullptr;
     std::vector<uint32_t> parent;
@@ -47,7 +53,7 @@ int set_error(int code, const char *fmt, ...) __attribute__((format(printf, 2, 3
 hipError_t launch_classify(const DevDB &db, const void *d_bases, const void *d_seq_off,
                            uint64_t n_frag, int mates, double confidence, void *d_out,
                            void *d_kmer_taxa, const void *d_kmer_taxa_off, void *d_counters,
-                           int *d_error, unsigned long long *d_work, uint32_t frag_chunk,
+                           int *d_error, int *d_pending, unsigned long long *d_work, uint32_t frag_chunk,
                            int grid_blocks, hipStream_t stream);
 int classify_blocks_per_cu();
 hipError_t launch_insert_sequences(const DevDB &db, const void *d_bases, const void *d_seq_off,
@@ -68,10 +74,6 @@ int resolve_db_dir(const char *db_dir, std::string &resolved);
 int classify_device(Engine *e, const void *d_bases, const void *d_seq_off, uint64_t n_frag,
                     uint32_t flags, double confidence, void *d_results, void *d_kmer_taxa,
                     const void *d_kmer_taxa_off, void *d_counters, hipStream_t stream);
-int classify_device_slot(Engine *e, const void *d_bases, const void *d_seq_off, uint64_t n_frag,
-                         uint32_t flags, double confidence, void *d_results, void *d_kmer_taxa,
-                         const void *d_kmer_taxa_off, void *d_counters, hipStream_t stream,
-                         int work_slot);
 int classify_host(Engine *e, const uint8_t *bases, const uint64_t *seq_offsets, uint64_t n_frag,
                   uint32_t flags, double confidence, nh_result *results, uint32_t *kmer_taxa,
                   uint64_t *kmer_taxa_offsets, uint64_t kmer_taxa_cap);

@@ -800,7 +800,7 @@ template <bool LINEAR, bool STD, bool CAP32, bool PROF, bool BIG>
 __global__ __launch_bounds__(WAVE * WAVES_PER_BLOCK, BIG ? 1 : (STD ? NH_MIN_WAVES : 3)) void k_classify(const KArgs args_by_kernarg_pointer) {
     KArgsP ap = (KArgsP)__builtin_amdgcn_kernarg_segment_ptr();
     // BIG variant: only runs when some fragment overflowed the 64-entry list of the hot variant
-    if (BIG && ap->error_flag[0] == 0) return;
+    if (BIG && ap->pending[0] == 0) return;
     __shared__ WaveLdsT<STD> lds_all[WAVES_PER_BLOCK];
     __shared__ uint32_t big_lists[BIG ? WAVES_PER_BLOCK * 3 * BIG_LIST_CAP : 1];
     const int lane = threadIdx.x & 63;
@@ -915,8 +915,8 @@ __global__ __launch_bounds__(WAVE * WAVES_PER_BLOCK, BIG ? 1 : (STD ? NH_MIN_WAV
                     *reinterpret_cast<uint4 *>(&a2->out[f]) = rec;
                     if (kmer_taxa && mates == 2)
                         kmer_taxa[a2->kmer_taxa_off[f] + d_nk0] = TAXON_MATE_BORDER;
-                    if (defer) atomicMax(&a2->error_flag[0], 1);            // work for the BIG variant
-                    if (BIG && st.overflow) atomicOr(&a2->error_flag[1], 1);  // beyond 2048 too: error
+                    if (defer) atomicMax(&a2->pending[0], 1);               // work for the BIG variant
+                    if (BIG && st.overflow) atomicOr(&a2->error_flag[0], 1);  // beyond 2048 too: error
                 }
                 if (lane == 0 && call) S.acc[CNT_CLASSIFIED] += 1;
             }
@@ -1083,7 +1083,7 @@ __global__ __launch_bounds__(WAVE * WAVES_PER_BLOCK, BIG ? 1 : (STD ? NH_MIN_WAV
             atomicAdd(&counters[CNT_BASES], S.acc[CNT_BASES]);
             atomicAdd(&counters[CNT_LOOKUPS], S.acc[CNT_LOOKUPS]);
         }
-        if (bad_input) atomicOr(&error_flag[1], 2);
+        if (bad_input) atomicOr(&error_flag[0], 2);
     }
 }
 
@@ -1208,14 +1208,14 @@ static void launch_variant(const KArgs &ka, dim3 g, dim3 b, hipStream_t stream, 
         // second pass for fragments with more than 64 distinct taxa: exits at once if there are none
         (void)hipMemsetAsync(d_work, 0, sizeof(unsigned long long), stream);
         hipLaunchKernelGGL((k_classify<LINEAR, STD, CAP32, false, true>), g, b, 0, stream, ka);
-        (void)hipMemsetAsync(ka.error_flag, 0, sizeof(int), stream);  // "overflow pending" word
+        (void)hipMemsetAsync(ka.pending, 0, sizeof(int), stream);
     }
 }
 
 hipError_t launch_classify(const DevDB &db, const void *d_bases, const void *d_seq_off,
                            uint64_t n_frag, int mates, double confidence, void *d_out,
                            void *d_kmer_taxa, const void *d_kmer_taxa_off, void *d_counters,
-                           int *d_error, unsigned long long *d_work, uint32_t frag_chunk,
+                           int *d_error, int *d_pending, unsigned long long *d_work, uint32_t frag_chunk,
                            int grid_blocks, hipStream_t stream) {
     if (n_frag == 0) return hipSuccess;
     if (frag_chunk == 0) frag_chunk = 1;
@@ -1238,6 +1238,7 @@ hipError_t launch_classify(const DevDB &db, const void *d_bases, const void *d_s
     ka.kmer_taxa_off = (const uint64_t *)d_kmer_taxa_off;
     ka.counters = (unsigned long long *)d_counters;
     ka.error_flag = d_error;
+    ka.pending = d_pending;
     ka.work = d_work;
     // tables of 2^32 - 256 cells or more take the variant with 64-bit cell positions;
     // NOHUMAN_FORCE_WIDE=1 selects it for any table (tests: small tables through the wide path)

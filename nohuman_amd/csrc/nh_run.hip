@@ -731,10 +731,10 @@ int run_engines(const std::vector<Engine *> &engines, const nh_run_args *a, nh_s
             if (he != hipSuccess) {
                 rs.fail(NH_EDEVICE, std::string("H2D: ") + hipGetErrorString(he));
             } else {
-                rc = classify_device_slot(s.e, s.d_bases, s.d_off, b.n,
+                rc = classify_device(s.e, s.d_bases, s.d_off, b.n,
                                           flags | (nbases / b.n > 2000 ? NH_FLAG_LONG : 0u), a->confidence, s.d_res,
                                           rs.want_k ? s.d_taxa : nullptr, rs.want_k ? s.d_taxa_off : nullptr,
-                                          s.e->d_counters, s.stream, s.work_slot);
+                                          s.e->d_counters, s.stream);
                 if (rc) rs.fail(rc, g_last_error);
             }
             if (!rs.failed()) {
