@@ -186,3 +186,50 @@ def test_many_small_batches_two_engines_keep_input_order(tmp_path, monkeypatch):
     assert st.total_sequences == len(calls) and st.classified == sum(1 for c in calls if c)
     for n in ("_1.fq", "_2.fq", ".k"):
         assert (tmp_path / ("a" + n)).read_bytes() == (tmp_path / ("b" + n)).read_bytes()
+
+
+def test_fragments_with_many_taxa_in_concurrent_batches(tmp_path, monkeypatch):
+    """Batches in flight on the two stream slots of an engine each carry fragments that hit more than
+    64 distinct taxa (second kernel pass): every launch has its own 'left for the second pass' word,
+    so no batch may lose such a fragment.  Compared per read with the oracle."""
+    import numpy as np
+    from nohuman_amd import engine
+    from oracle import minidb
+    from oracle import oracle as orc
+    from tests import synth
+    rng = np.random.default_rng(33)
+    edges = {1: 0}
+    for g in range(10):
+        edges[100 + g] = 1
+    leaves = []
+    for i in range(150):
+        edges[1000 + i] = 100 + i % 10
+        leaves.append(1000 + i)
+    tax = minidb.Taxonomy(edges)
+    segs = {e: synth.random_seq(rng, 120) for e in leaves}
+    hashb, _ = minidb.build_hash(tax, sorted(segs.items()), 40009)
+    db = tmp_path / "db"
+    db.mkdir()
+    (db / "opts.k2d").write_bytes(minidb.opts_bytes())
+    (db / "taxo.k2d").write_bytes(tax.to_bytes())
+    (db / "hash.k2d").write_bytes(hashb)
+    reads = []
+    for i in range(600):
+        if i % 3 == 0:  # every third read visits 70-140 leaves
+            pick = rng.choice(leaves, size=int(rng.integers(70, 141)), replace=False)
+            reads.append(b"".join(segs[int(e)][10:110] for e in pick))
+        else:
+            reads.append(synth.random_seq(rng, 150) if i % 3 == 1 else segs[leaves[i % 150]][5:115])
+    fq = tmp_path / "r.fq"
+    fq.write_bytes(b"".join(b"@r%d\n%s\n+\n%s\n" % (i, r, b"I" * len(r)) for i, r in enumerate(reads)))
+    bases, offs = orc.pack_reads(reads, False)
+    odb = orc.OracleDB(minidb.opts_bytes(), tax.to_bytes(), hashb)
+    exp, _ = odb.classify(bases, offs, False, 0.0)
+    monkeypatch.setenv("NOHUMAN_BATCH_FRAGS", "16")  # 38 batches over 2 slots
+    st = engine.run(str(db), str(fq), str(tmp_path / "o.fq"), kraken_output=str(tmp_path / "o.k"), device_ids=[0])
+    lines = (tmp_path / "o.k").read_text().splitlines()
+    assert len(lines) == len(reads)
+    got_ext = np.array([int(l.split("\t")[2]) for l in lines])
+    want_ext = np.asarray(odb.external_ids)[exp["call"]].astype(np.int64)
+    assert np.array_equal(got_ext, want_ext)
+    assert st.classified == int((exp["call"] != 0).sum())
