@@ -35,6 +35,9 @@ namespace nh {
 #define NH_FULL 0xFFFFFFFFFFFFFFFFull
 #ifndef NH_PROBE_CHUNKS
 #define NH_PROBE_CHUNKS 1
+#ifndef NH_WIDE_AFTER
+#define NH_WIDE_AFTER 2  // rounds after which a lookup examines 16 cells per round instead of 4
+#endif
 #endif
 
 // window reads of idle lanes stay inside the candidate array: k-l+2 pad entries (k-l = 4 for
@@ -524,15 +527,39 @@ __device__ __forceinline__ void probe_queue(KArgsP ap, WaveLdsT<STD> &S, const i
                     nvalid = room < in_line ? (uint32_t)room : in_line;
                     src = table + pos;
                 }
-                nvalid = nvalid < 4u * PC ? nvalid : 4u * PC;
-                uint32_t res = 0, resj = 4 * PC, lo = 0;
+                uint32_t res = 0, resj = 16, lo = 0;
                 if constexpr (PC == 1) {
-                    // one 16-byte load that must not leave the line: if fewer than 4 cells remain
-                    // it starts up to 3 cells early and those are skipped (a load across the line
-                    // end would cost a second fabric request for cells that do not count)
-                    lo = in_line < 4u ? 4u - in_line : 0u;
-                    const uint4 cq = *reinterpret_cast<const uint4 *>(src - lo);
-                    const uint32_t cells[4] = {cq.x, cq.y, cq.z, cq.w};
+                    // A lookup's first NH_WIDE_AFTER rounds examine 4 cells with ONE 16-byte load that
+                    // must not leave the line: if fewer than 4 cells remain it starts up to 3 cells
+                    // early and those are skipped (a load across the line end would cost a second
+                    // fabric request for cells that do not count).  Most lookups end there.  An older
+                    // lookup is in a long probe run -- linear probing at load 0.7 is heavy-tailed, and
+                    // the slowest lookup of a group decides when the group can be post-processed -- so
+                    // it examines up to 16 cells (a whole 64-byte sector) per round from then on.
+                    const bool wide = max_rounds - budget >= (uint32_t)NH_WIDE_AFTER;
+                    const uint32_t lim = wide ? 16u : 4u;
+                    nvalid = nvalid < lim ? nvalid : lim;
+                    lo = (!wide && in_line < 4u) ? 4u - in_line : 0u;
+                    const uint4 c0 = *reinterpret_cast<const uint4 *>(src - lo);
+                    uint4 c1 = {0, 0, 0, 0}, c2 = {0, 0, 0, 0}, c3 = {0, 0, 0, 0};
+                    if (wide) {  // chunks past the last useful one re-read it (no new line is touched)
+                        const uint32_t last_chunk = (nvalid - 1) >> 2;
+                        c1 = *reinterpret_cast<const uint4 *>(src + 4 * (last_chunk < 1u ? last_chunk : 1u));
+                        c2 = *reinterpret_cast<const uint4 *>(src + 4 * (last_chunk < 2u ? last_chunk : 2u));
+                        c3 = *reinterpret_cast<const uint4 *>(src + 4 * (last_chunk < 3u ? last_chunk : 3u));
+                    }
+                    if (wide) {
+                        const uint32_t cw[12] = {c1.x, c1.y, c1.z, c1.w, c2.x, c2.y, c2.z, c2.w, c3.x, c3.y, c3.z, c3.w};
+#pragma unroll
+                        for (int j = 11; j >= 0; j--) {
+                            const uint32_t cell = cw[j];
+                            const uint32_t x = cell ^ ckey;
+                            const bool stop = (x <= vmask) | ((cell & vmask) == 0);
+                            res = stop ? x : res;
+                            resj = stop ? (uint32_t)(j + 4) : resj;
+                        }
+                    }
+                    const uint32_t cells[4] = {c0.x, c0.y, c0.z, c0.w};
 #pragma unroll
                     for (int j = 3; j >= 0; j--) {  // lowest eligible stopping cell wins
                         const uint32_t cell = cells[j];
@@ -542,6 +569,7 @@ __device__ __forceinline__ void probe_queue(KArgsP ap, WaveLdsT<STD> &S, const i
                         resj = stop ? (uint32_t)j : resj;
                     }
                 } else {
+                    nvalid = nvalid < 4u * PC ? nvalid : 4u * PC;
                     const uint32_t last_chunk = (nvalid - 1) >> 2;
                     uint4 c[PC];
 #pragma unroll

@@ -32,3 +32,4 @@ print("kernel %.3f ms (instrumented), %d fragments, lookups %d" % (ms, c[0], c[3
 for i, nm in enumerate(names):
     print("  %-22s %6.2f%%  %8.0f cycles/fragment" % (nm, 100.0 * c[4 + i] / tot, c[4 + i] / c[0]))
 print("  total %.0f cycles/fragment/wave" % (tot / c[0]))
+
