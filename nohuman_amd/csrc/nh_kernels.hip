@@ -35,9 +35,9 @@ namespace nh {
 #define NH_FULL 0xFFFFFFFFFFFFFFFFull
 #ifndef NH_PROBE_CHUNKS
 #define NH_PROBE_CHUNKS 1
+#endif
 #ifndef NH_WIDE_AFTER
 #define NH_WIDE_AFTER 2  // rounds after which a lookup examines 16 cells per round instead of 4
-#endif
 #endif
 
 // window reads of idle lanes stay inside the candidate array: k-l+2 pad entries (k-l = 4 for
