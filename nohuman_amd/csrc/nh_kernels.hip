@@ -36,6 +36,9 @@ namespace nh {
 #ifndef NH_PROBE_CHUNKS
 #define NH_PROBE_CHUNKS 1
 #endif
+#ifndef NH_LINE_CELLS
+#define NH_LINE_CELLS 32  // a probe round never crosses a boundary of this many cells (32 = 128-byte line)
+#endif
 #ifndef NH_WIDE_AFTER
 #define NH_WIDE_AFTER 2  // rounds after which a lookup examines 16 cells per round instead of 4
 #endif
@@ -517,12 +520,12 @@ __device__ __forceinline__ void probe_queue(KArgsP ap, WaveLdsT<STD> &S, const i
                 const uint32_t *src;
                 if (CAP32) {
                     const uint32_t p32 = (uint32_t)pos;
-                    in_line = 32u - (p32 & 31u);
+                    in_line = (uint32_t)NH_LINE_CELLS - (p32 & (uint32_t)(NH_LINE_CELLS - 1));
                     const uint32_t room = (uint32_t)cap - p32;
                     nvalid = in_line < room ? in_line : room;
                     src = table + p32;
                 } else {
-                    in_line = 32u - ((uint32_t)pos & 31u);
+                    in_line = (uint32_t)NH_LINE_CELLS - ((uint32_t)pos & (uint32_t)(NH_LINE_CELLS - 1));
                     const uint64_t room = cap - pos;
                     nvalid = room < in_line ? (uint32_t)room : in_line;
                     src = table + pos;
