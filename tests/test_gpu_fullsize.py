@@ -1,0 +1,130 @@
+"""BASELINE.json's full sizes on the GPU (configs[1]: 1 M x 150 bp single-end, the bench workload:
+1 M x 150 bp pairs, an HPRC.r2-sized table of 1.43 G cells resident in HBM), checked
+  * bit-exact against the CPU oracle over the WHOLE batch (the oracle probes the very table that sits
+    in HBM, downloaded once), and
+  * through properties that do not depend on the size: splitting the batch, permuting the fragments,
+    reverse-complementing every read, and repeating the launch leave the records unchanged."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+CAP = 1_431_655_765  # bench.py's HPRC.r2-like table: 5.73 GB
+N = 1_000_000
+L = 150
+
+
+class Counters:
+    def __init__(self, fragments, classified, bases, lookups):
+        self.total_sequences, self.classified, self.total_bases, self.table_lookups = fragments, classified, bases, lookups
+
+
+@pytest.fixture(scope="module")
+def big():
+    import torch
+    from nohuman_amd import Engine
+    dev = torch.device("cuda:0")
+    eng = Engine.synthetic(CAP, int(CAP * 0.7), depth=30, seed=20250101)
+    g = torch.Generator(device=dev)
+    g.manual_seed(99)
+    acgt = torch.tensor([65, 67, 71, 84], dtype=torch.uint8, device=dev)
+    codes = torch.randint(0, 4, (2 * N * L,), generator=g, device=dev)
+    # a tenth of the reads are cut from sequences put into the table, so hits, LCAs and the
+    # confidence climb take part; 0.1 % of all bases are N
+    n_hit = N // 10
+    bases = acgt[codes]
+    offs2 = (torch.arange(2 * N + 1, dtype=torch.int64, device=dev) * L).contiguous()
+    pad = torch.full((64,), 65, dtype=torch.uint8, device=dev)
+    eng.add_sequences(torch.cat([bases, pad]).contiguous().data_ptr(), offs2.data_ptr(), 2 * n_hit, 30)
+    eng.add_sequences(torch.cat([bases[2 * n_hit * L:], pad]).contiguous().data_ptr(), offs2.data_ptr(), n_hit, 17)
+    nmask = torch.rand(bases.shape, generator=g, device=dev) < 0.001
+    bases = torch.where(nmask, torch.tensor(78, dtype=torch.uint8, device=dev), bases)
+    bases = torch.cat([bases, pad]).contiguous()
+    torch.cuda.synchronize()
+    yield dict(torch=torch, dev=dev, eng=eng, bases=bases, offs2=offs2, acgt=acgt)
+    eng.close()
+
+
+def _classify(b, bases, offs, n, paired, conf=0.0, counters=False):
+    torch = b["torch"]
+    out = torch.zeros((n, 4), dtype=torch.int32, device=b["dev"])
+    cnt = torch.zeros(4, dtype=torch.int64, device=b["dev"])  # fragments, classified, bases, lookups
+    b["eng"].classify_device(bases.data_ptr(), offs.data_ptr(), n, paired, conf, out.data_ptr(), cnt.data_ptr())
+    torch.cuda.synchronize()
+    return (out, Counters(*cnt.tolist())) if counters else out
+
+
+@pytest.fixture(scope="module")
+def oracle_db(big):
+    from oracle import oracle as orc
+    eng = big["eng"]
+    info = eng.info
+    cells = eng.download_table()
+    return orc.OracleDB(eng.opts_image(), eng.taxonomy_image(), cells=cells,
+                        header=(info.capacity, info.size, info.key_bits, info.value_bits))
+
+
+@pytest.mark.parametrize("paired,conf", [(False, 0.0), (True, 0.0), (True, 0.1)])
+def test_whole_batch_equals_the_oracle(big, oracle_db, paired, conf):
+    from nohuman_amd.dist import usable_cpu_count
+    torch = big["torch"]
+    mates = 2 if paired else 1
+    offs = big["offs2"][: N * mates + 1].contiguous()
+    got, st = _classify(big, big["bases"], offs, N, paired, conf, counters=True)
+    host = big["bases"][: N * mates * L].cpu().numpy()
+    exp, lookups = oracle_db.classify(host, offs.cpu().numpy().astype(np.uint64), paired, conf,
+                                      threads=usable_cpu_count())
+    rec = got.cpu().numpy().view(np.uint32)
+    for i, f in enumerate(("call", "total_kmers", "clade_hits", "hit_groups")):
+        bad = np.nonzero(rec[:, i] != exp[f])[0]
+        assert bad.size == 0, "%s differs at %s" % (f, bad[:5])
+    assert st.total_sequences == N and st.total_bases == N * mates * L
+    assert st.classified == int((exp["call"] != 0).sum())
+    assert st.table_lookups == int(lookups.sum())
+    assert 0.05 * N < st.classified < 0.4 * N  # the hit paths took part
+
+
+def test_split_permute_repeat_leave_the_records_unchanged(big):
+    torch = big["torch"]
+    offs = big["offs2"]
+    ref, st = _classify(big, big["bases"], offs, N, True, counters=True)
+    # repeat: dynamic scheduling must not show in the results
+    assert torch.equal(ref, _classify(big, big["bases"], offs, N, True))
+    # split into 7 uneven pieces: records concatenate, counters add up
+    cuts = [0, 1, 1000, 123_457, 500_000, 500_001, 999_999, N]
+    parts, seqs, cls, looks = [], 0, 0, 0
+    for a, c in zip(cuts[:-1], cuts[1:]):
+        o = offs[2 * a: 2 * c + 1].contiguous()
+        out, s = _classify(big, big["bases"], o, c - a, True, counters=True)
+        parts.append(out)
+        seqs += s.total_sequences
+        cls += s.classified
+        looks += s.table_lookups
+    assert torch.equal(torch.cat(parts), ref)
+    assert (seqs, cls, looks) == (st.total_sequences, st.classified, st.table_lookups)
+    # permute the fragments (offsets stay sorted: the reads are gathered into a new buffer)
+    g = torch.Generator(device=big["dev"])
+    g.manual_seed(5)
+    perm = torch.randperm(N, generator=g, device=big["dev"])
+    idx = (perm[:, None] * (2 * L) + torch.arange(2 * L, device=big["dev"])[None, :]).reshape(-1)
+    pb = torch.cat([big["bases"][idx], big["bases"][-64:]]).contiguous()
+    assert torch.equal(_classify(big, pb, offs, N, True), ref[perm])
+
+
+def test_reverse_complement_of_every_read_gives_the_same_record(big):
+    """Minimizers are canonical, runs of equal minimizers and the taxon tallies are symmetric under
+    reversal: call, k-mer count, clade hits and hit groups of a read equal those of its reverse
+    complement (single-end, so that no mate order is involved).  Reads with an N are left out:
+    kraken2 calls a k-mer ambiguous when the N lies in its LAST l bases, which is not symmetric."""
+    torch = big["torch"]
+    offs = big["offs2"][: N + 1].contiguous()
+    ref = _classify(big, big["bases"], offs, N, False)
+    b = big["bases"][: N * L].reshape(N, L).flip(1)
+    comp = torch.full((256,), 78, dtype=torch.uint8, device=big["dev"])
+    for x, y in ((65, 84), (67, 71), (71, 67), (84, 65)):
+        comp[x] = y
+    rc = torch.cat([comp[b.reshape(-1).long()], big["bases"][-64:]]).contiguous()
+    got = _classify(big, rc, offs, N, False)
+    clean = (b != 78).all(dim=1)
+    assert 0.8 * N < int(clean.sum()) < N
+    assert torch.equal(got[clean], ref[clean])
