@@ -64,13 +64,10 @@ struct alignas(16) SlotLds {  // a scanned tile waiting for its probe results (w
     uint32_t f_lo, f_hi;    // fragment
     uint32_t koff, pad0;    // k-mer index of the tile within its fragment
     uint32_t nqt, qbase, nruns;
-    uint32_t fi;            // which FragLds / taxon list (parity of the wave's fragment count)
+    uint32_t pad1;
     uint32_t last_lane;     // 2*lane+slot of the last unambiguous k-mer, 0xFFFFFFFF if none
     uint32_t flags;         // 1 = last tile of its fragment, 2 = last tile of mate 0, mate 1 follows
     uint32_t nk0, total_kmers;
-};
-struct alignas(16) FragLds {  // accumulation state of a fragment between its tiles
-    uint32_t nlist, hit_groups, carry_tax, overflow;
 };
 
 // the generic kernel keeps the probe results apart from the queue entries; STD aliases them
@@ -655,7 +652,7 @@ __device__ __forceinline__ void post_tile(WaveLdsT<STD> &S, const TaxList &TLI, 
                                           const uint32_t nqt, const uint32_t par,
                                           const uint32_t qbase, const uint32_t nruns,
                                           const int last_lane, FragState &st,
-                                          const uint32_t li, uint32_t *__restrict__ kmer_taxa,
+                                          uint32_t *__restrict__ kmer_taxa,
                                           const uint64_t kt, uint64_t (&prof)[12], uint64_t &tprev) {
     const uint32_t qi0 = 2u * lane, qi1 = 2u * lane + 1;
     const bool v0 = ps & 1u, v1 = (ps >> 1) & 1u;
@@ -783,8 +780,8 @@ __device__ __forceinline__ uint32_t resolve_tree_big(KArgsP ap, const TaxList &T
 // ResolveTree (A.5) on the wave: lane i owns list entry i.  Returns the call; sets clade_hits.
 template <bool STD>
 __device__ __forceinline__ uint32_t resolve_tree(KArgsP ap, WaveLdsT<STD> &S, const int lane,
-                                                 const FragState &st, const uint32_t li,
-                                                 const uint32_t total_kmers, uint32_t &clade_hits) {
+                                                 const FragState &st, const uint32_t total_kmers,
+                                                 uint32_t &clade_hits) {
     ap = launder(ap);
     const uint32_t nlist = st.nlist;
     const uint32_t *parent = ap->db.parent;
@@ -912,7 +909,6 @@ __global__ __launch_bounds__(WAVE * WAVES_PER_BLOCK, BIG ? 1 : (STD ? NH_MIN_WAV
             const uint64_t f = ((uint64_t)uni(d0.y) << 32) | uni(d0.x);   // f_lo, f_hi
             const uint64_t kt = kmer_taxa ? a2->kmer_taxa_off[f] + uni(d0.z) : 0;  // tile's first k-mer
             const uint32_t d_nqt = uni(d1.x), d_qbase = uni(d1.y), d_nruns = uni(d1.z);
-            const uint32_t fi = 0;
             const uint32_t d_last = uni(d2.x), flags = uni(d2.y);
             const uint32_t d_nk0 = uni(d2.z), d_total = uni(d2.w);
             if (flags & 4u) {  // first tile of its fragment: fresh accumulation state
@@ -922,7 +918,7 @@ __global__ __launch_bounds__(WAVE * WAVES_PER_BLOCK, BIG ? 1 : (STD ? NH_MIN_WAV
                 st.overflow = false;
             }
             const uint32_t ps = S.ps[pp][s][lane];
-            post_tile<STD, BIG, PROF>(S, TLI, lane, ps, d_nqt, pp, d_qbase, d_nruns, (int)d_last, st, fi,
+            post_tile<STD, BIG, PROF>(S, TLI, lane, ps, d_nqt, pp, d_qbase, d_nruns, (int)d_last, st,
                                       kmer_taxa, kt, prof, tprev);
             if ((flags & 2u) && reset_per_mate) st.carry_tax = 0;  // mate 0 ended, mate 1 follows
             if (flags & 1u) {                                      // fragment ended
@@ -932,7 +928,7 @@ __global__ __launch_bounds__(WAVE * WAVES_PER_BLOCK, BIG ? 1 : (STD ? NH_MIN_WAV
                     if (BIG)
                         call = resolve_tree_big(ap, TLI, lane, st, total_kmers, clade_hits);
                     else
-                        call = resolve_tree(ap, S, lane, st, fi, total_kmers, clade_hits);
+                        call = resolve_tree(ap, S, lane, st, total_kmers, clade_hits);
                 }
                 // hot variant: a fragment with more than 64 distinct taxa is left to the BIG variant
                 const bool defer = !BIG && st.overflow;
