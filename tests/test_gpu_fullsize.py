@@ -128,3 +128,35 @@ def test_reverse_complement_of_every_read_gives_the_same_record(big):
     clean = (b != 78).all(dim=1)
     assert 0.8 * N < int(clean.sum()) < N
     assert torch.equal(got[clean], ref[clean])
+
+
+def test_long_reads_at_byte_offsets_beyond_4_gib(big):
+    """configs[3] shape: 620 k reads of 10 kb = 6.2 GB of bases in ONE batch, so sequence offsets pass
+    2^32.  The reads at the far end must classify exactly as they do from a compact copy at offset 0."""
+    torch = big["torch"]
+    dev = big["dev"]
+    n, ln = 620_000, 10_000
+    g = torch.Generator(device=dev)
+    g.manual_seed(4)
+    bases = torch.empty(n * ln + 64, dtype=torch.uint8, device=dev)
+    step = 20_000
+    for i in range(0, n, step):  # filled piecewise: randint needs 8 bytes per element
+        m = min(step, n - i)
+        bases[i * ln:(i + m) * ln] = big["acgt"][torch.randint(0, 4, (m * ln,), generator=g, device=dev)]
+    bases[n * ln:] = 65
+    # some of the far reads carry sequence that is in the table (first reads of the shared fixture)
+    src = big["bases"][: 150 * 1000]
+    bases[(n - 500) * ln:(n - 500) * ln + src.numel()] = src
+    offs = (torch.arange(n + 1, dtype=torch.int64, device=dev) * ln).contiguous()
+    assert int(offs[-1]) > 2 ** 32
+    out = torch.zeros((n, 4), dtype=torch.int32, device=dev)
+    big["eng"].classify_device(bases.data_ptr(), offs.data_ptr(), n, False, 0.0, out.data_ptr(), long_reads=True)
+    tail_n = 2_000
+    tail = bases[(n - tail_n) * ln:].clone().contiguous()
+    toffs = (torch.arange(tail_n + 1, dtype=torch.int64, device=dev) * ln).contiguous()
+    tout = torch.zeros((tail_n, 4), dtype=torch.int32, device=dev)
+    big["eng"].classify_device(tail.data_ptr(), toffs.data_ptr(), tail_n, False, 0.0, tout.data_ptr(), long_reads=True)
+    torch.cuda.synchronize()
+    assert torch.equal(out[n - tail_n:], tout)
+    assert (out[:, 1] == ln - 35 + 1).all()
+    assert int((tout[:, 0] != 0).sum()) >= 10  # the planted sequence was found
