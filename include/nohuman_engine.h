@@ -192,14 +192,14 @@ int nh_fastx_scan(const char *path, uint64_t *n_records, uint64_t *n_bases, uint
  * (/root/reference/src/compression.rs:182-200, called from src/main.rs:342-368).  Compresses file
  * `in` to file `out`; gzip runs block-parallel on `threads` workers like the reference's gzp
  * encoder (compression.rs:214-233) and produces one ordinary gzip member at level 6; bzip2 and xz
- * go through the system tools; NH_CODEC_NONE copies.  Parity target is the decompressed content and
+ * go through the system tools, zstd through libzstd.so.1; NH_CODEC_NONE copies.  Parity target is the decompressed content and
  * the container magic (compression.rs:282-288).  Needs no GPU. */
 typedef enum nh_codec {
     NH_CODEC_NONE = 0,
     NH_CODEC_BZIP2 = 1,
     NH_CODEC_GZIP = 2,
     NH_CODEC_XZ = 3,
-    NH_CODEC_ZSTD = 4 /* not available in this build: NH_EINVAL */
+    NH_CODEC_ZSTD = 4 /* through the system's libzstd.so.1 (level 3, frame checksum, `threads` workers) */
 } nh_codec;
 int nh_compress_file(const char *in, const char *out, int codec, uint32_t threads);
 /* Test / tool support for the multi-threaded gzip input decoder nh_run reads .gz inputs with

@@ -10,6 +10,7 @@
 // primed with the previous block's last 32 KiB as dictionary and closed with a sync flush (byte
 // aligned, not final); the blocks are written in order inside ONE gzip member whose CRC-32 is
 // combined from the per-block CRCs.  Any gzip reader sees an ordinary single-member file.
+#include <dlfcn.h>
 #include <errno.h>
 #include <fcntl.h>
 #include <stdio.h>
@@ -204,6 +205,69 @@ int gzip_parallel(int fin, int fout, unsigned threads, const char *in_name, cons
     return NH_OK;
 }
 
+// ---- zstd through the system's libzstd.so.1 (the image has the library but not its header; the few
+// entry points of the stable streaming API are declared here) -- zstd_compress of the reference:
+// default level 3, `threads` workers, frame checksum (compression.rs:254-268)
+struct ZstdApi {
+    struct InBuf { const void *src; size_t size, pos; };
+    struct OutBuf { void *dst; size_t size, pos; };
+    void *(*createCCtx)(void) = nullptr;
+    size_t (*freeCCtx)(void *) = nullptr;
+    size_t (*setParameter)(void *, int, int) = nullptr;
+    size_t (*compressStream2)(void *, OutBuf *, InBuf *, int) = nullptr;
+    unsigned (*isError)(size_t) = nullptr;
+    const char *(*getErrorName)(size_t) = nullptr;
+    bool ok = false;
+    ZstdApi() {
+        void *h = dlopen("libzstd.so.1", RTLD_NOW | RTLD_LOCAL);
+        if (!h) return;
+        createCCtx = (void *(*)(void))dlsym(h, "ZSTD_createCCtx");
+        freeCCtx = (size_t(*)(void *))dlsym(h, "ZSTD_freeCCtx");
+        setParameter = (size_t(*)(void *, int, int))dlsym(h, "ZSTD_CCtx_setParameter");
+        compressStream2 = (size_t(*)(void *, OutBuf *, InBuf *, int))dlsym(h, "ZSTD_compressStream2");
+        isError = (unsigned (*)(size_t))dlsym(h, "ZSTD_isError");
+        getErrorName = (const char *(*)(size_t))dlsym(h, "ZSTD_getErrorName");
+        ok = createCCtx && freeCCtx && setParameter && compressStream2 && isError && getErrorName;
+    }
+};
+
+int zstd_file(int fin, int fout, unsigned threads, const char *in_name, const char *out_name) {
+    static const ZstdApi Z;
+    if (!Z.ok) return set_error(NH_EINVAL, "Zstd output is not available: libzstd.so.1 could not be loaded");
+    enum { C_LEVEL = 100, C_CHECKSUM = 201, C_WORKERS = 400, E_CONTINUE = 0, E_END = 2 };
+    void *cctx = Z.createCCtx();
+    if (!cctx) return set_error(NH_EOOM, "ZSTD_createCCtx failed");
+    (void)Z.setParameter(cctx, C_LEVEL, 3);
+    (void)Z.setParameter(cctx, C_CHECKSUM, 1);
+    if (threads > 1) (void)Z.setParameter(cctx, C_WORKERS, (int)threads);  // ignored by single-threaded builds
+    std::vector<char> ibuf(1u << 20), obuf(1u << 20);
+    int rc = NH_OK;
+    for (bool last = false; !last && rc == NH_OK;) {
+        const long n = read_full(fin, ibuf.data(), ibuf.size());
+        if (n < 0) {
+            rc = set_error(NH_EIO, "read error on %s", in_name);
+            break;
+        }
+        last = (size_t)n < ibuf.size();
+        ZstdApi::InBuf in = {ibuf.data(), (size_t)n, 0};
+        for (;;) {
+            ZstdApi::OutBuf out = {obuf.data(), obuf.size(), 0};
+            const size_t left = Z.compressStream2(cctx, &out, &in, last ? E_END : E_CONTINUE);
+            if (Z.isError(left)) {
+                rc = set_error(NH_EIO, "zstd: %s", Z.getErrorName(left));
+                break;
+            }
+            if (out.pos && !write_all(fout, obuf.data(), out.pos)) {
+                rc = set_error(NH_EIO, "write error on %s", out_name);
+                break;
+            }
+            if (last ? left == 0 : in.pos == in.size) break;
+        }
+    }
+    Z.freeCCtx(cctx);
+    return rc;
+}
+
 std::string shell_quote(const char *s) {
     std::string q = "'";
     for (; *s; s++) q += *s == '\'' ? std::string("'\\''") : std::string(1, *s);
@@ -214,14 +278,13 @@ std::string shell_quote(const char *s) {
 
 int compress_file(const char *in, const char *out, int codec, unsigned threads) {
     if (!in || !out) return set_error(NH_EINVAL, "nh_compress_file: null path");
-    if (codec == NH_CODEC_ZSTD)
-        return set_error(NH_EINVAL, "Zstd output is not available in this build (no libzstd in the image)");
-    if (codec != NH_CODEC_NONE && codec != NH_CODEC_GZIP && codec != NH_CODEC_BZIP2 && codec != NH_CODEC_XZ)
+    if (codec != NH_CODEC_NONE && codec != NH_CODEC_GZIP && codec != NH_CODEC_BZIP2 && codec != NH_CODEC_XZ &&
+        codec != NH_CODEC_ZSTD)
         return set_error(NH_EINVAL, "nh_compress_file: unknown codec %d", codec);
     int fin = ::open(in, O_RDONLY | O_CLOEXEC);
     if (fin < 0) return set_error(NH_EIO, "cannot open %s", in);
     int rc = NH_OK;
-    if (codec == NH_CODEC_NONE || codec == NH_CODEC_GZIP) {
+    if (codec == NH_CODEC_NONE || codec == NH_CODEC_GZIP || codec == NH_CODEC_ZSTD) {
         int fout = ::open(out, O_WRONLY | O_CREAT | O_TRUNC | O_CLOEXEC, 0666);
         if (fout < 0) {
             ::close(fin);
@@ -229,6 +292,8 @@ int compress_file(const char *in, const char *out, int codec, unsigned threads) 
         }
         if (codec == NH_CODEC_GZIP) {
             rc = gzip_parallel(fin, fout, threads, in, out);
+        } else if (codec == NH_CODEC_ZSTD) {
+            rc = zstd_file(fin, fout, threads, in, out);
         } else {
             std::vector<char> buf(4u << 20);
             for (;;) {

@@ -79,6 +79,19 @@ def test_gzip_binary_and_incompressible(tmp_path):
     assert gzip.decompress(dst.read_bytes()) == data
 
 
+def _zstd_decompress(raw, size):
+    """The image has libzstd.so.1 but no Python binding: decompress through ctypes."""
+    import ctypes
+    z = ctypes.CDLL("libzstd.so.1")
+    z.ZSTD_decompress.restype = ctypes.c_size_t
+    z.ZSTD_decompress.argtypes = [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p, ctypes.c_size_t]
+    z.ZSTD_isError.argtypes = [ctypes.c_size_t]
+    dst = ctypes.create_string_buffer(size + 16)
+    n = z.ZSTD_decompress(dst, size + 16, raw, len(raw))
+    assert not z.ZSTD_isError(n)
+    return dst.raw[:n]
+
+
 def test_other_codecs(tmp_path):
     data = fastq_like(200_000, seed=9)
     src = tmp_path / "in.fq"
@@ -91,9 +104,12 @@ def test_other_codecs(tmp_path):
     compress(src, tmp_path / "o.xz", XZ, 2)
     raw = (tmp_path / "o.xz").read_bytes()
     assert raw[:5] == b"\xfd\x37\x7a\x58\x5a" and lzma.decompress(raw) == data
-    with pytest.raises(RuntimeError) as ei:
-        compress(src, tmp_path / "o.zst", ZSTD, 1)
-    assert "Zstd" in str(ei.value)
+    for threads in (1, 4):
+        compress(src, tmp_path / "o.zst", ZSTD, threads)
+        raw = (tmp_path / "o.zst").read_bytes()
+        assert raw[:4] == b"\x28\xb5\x2f\xfd"  # compression.rs:285
+        assert _zstd_decompress(raw, len(data)) == data
+        assert raw[4] & 0x04  # frame header descriptor: content checksum present (include_checksum(true))
 
 
 def test_errors(tmp_path):
