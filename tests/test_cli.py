@@ -121,6 +121,32 @@ def test_paired_keep_human_with_outputs_report_and_kraken_file(tmp_path):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("flag,ext,magic", [("z", "zst", b"\x28\xb5\x2f\xfd"), ("b", "bz2", b"BZh"),
+                                            ("x", "xz", b"\xfd7zXZ"), ("g", "gz", b"\x1f\x8b"), ("u", "", b"@")])
+def test_output_type_flag_selects_the_codec(tmp_path, flag, ext, magic):
+    """-F overrides the codec guessed from the input / output name (main.rs:238-245); the file gets
+    the codec's extension appended (compression.rs:107-118) and the container magic of
+    compression.rs:282-288; the content is the kept reads."""
+    import bz2
+    import lzma
+    from tests.test_codec import _zstd_decompress
+    exp = json.load(open(os.path.join(GOLD, "expected_se.json")))
+    calls = [r["by_conf"]["0.0"][0] for r in exp["records"]]
+    reads = read_fastq(os.path.join(GOLD, "reads_se.fq"))
+    shutil.copy(os.path.join(GOLD, "reads_se.fq"), tmp_path / "s.fq")
+    r = run(["-D", DB, "-t", "3", "-F", flag, "s.fq"], cwd=tmp_path)
+    assert r.returncode == 0, r.stderr
+    out = tmp_path / ("s.nohuman.fq" + ("." + ext if ext else ""))
+    assert out.exists(), os.listdir(tmp_path)
+    raw = out.read_bytes()
+    assert raw.startswith(magic)
+    want = b"".join(h + b"\n" + s + b"\n+\n" + q + b"\n" for (h, _i, s, q), c in zip(reads, calls) if not c)
+    got = {"z": lambda: _zstd_decompress(raw, len(want)), "b": lambda: bz2.decompress(raw),
+           "x": lambda: lzma.decompress(raw), "g": lambda: gzip.decompress(raw), "u": lambda: raw}[flag]()
+    assert got == want
+
+
+@pytest.mark.gpu
 def test_database_resolution_errors_and_env(tmp_path):
     f = tmp_path / "in.fq"
     f.write_text("@r\nACGT\n+\nIIII\n")
