@@ -1059,14 +1059,22 @@ private:
         static const bool debug = getenv("NOHUMAN_GZ_DEBUG") != nullptr;
         timespec t0, t1, t2;
         if (debug) clock_gettime(CLOCK_MONOTONIC, &t0);
-        const uint64_t s = find_block(base_, end, chunk_bit(c.index), to, c.dec.scratch);
+        // A position that passes the header test by chance decodes into an error sooner or later:
+        // go on searching behind it (a few times; the consumer fills in whatever stays undecoded).
+        uint64_t s = (uint64_t)-1, from = chunk_bit(c.index);
+        for (int attempt = 0; attempt < 8 && !c.found; attempt++) {
+            s = find_block(base_, end, from, to, c.dec.scratch);
+            if (s == (uint64_t)-1) break;
+            if (attempt) c.dec.reset(base_, end);
+            c.dec.run(s, chunk_bit(c.index + 1), chunk_bit(c.index + 2), false);
+            c.found = c.dec.stop != STOP_ERROR;
+            from = s + 1;
+        }
         if (debug) clock_gettime(CLOCK_MONOTONIC, &t1);
         if (s == (uint64_t)-1) return;
-        c.dec.run(s, chunk_bit(c.index + 1), chunk_bit(c.index + 2), false);
-        c.found = c.dec.stop != STOP_ERROR;
         if (debug) {
             clock_gettime(CLOCK_MONOTONIC, &t2);
-            fprintf(stderr, "[gz] chunk %zu: search %.1f ms (%llu bits), decode %.1f ms, n16 %zu n8 %zu stop %d\n", c.index,
+            fprintf(stderr, "[gz] chunk %zu: search+decode %.1f ms (start +%llu bits), %.1f ms, n16 %zu n8 %zu stop %d\n", c.index,
                     (t1.tv_sec - t0.tv_sec) * 1e3 + (t1.tv_nsec - t0.tv_nsec) * 1e-6,
                     (unsigned long long)(s - chunk_bit(c.index)),
                     (t2.tv_sec - t1.tv_sec) * 1e3 + (t2.tv_nsec - t1.tv_nsec) * 1e-6, c.dec.n16, c.dec.n8, (int)c.dec.stop);
