@@ -379,7 +379,7 @@ void BlockReader::next_batch(HalfBatch &hb, size_t max_recs, size_t max_text) {
         hb.error = "out of memory";
         return;
     }
-    memcpy(hb.text.data(), tail_.data(), tail_.size());
+    if (tail_.size()) memcpy(hb.text.data(), tail_.data(), tail_.size());
     hb.text.set_size(tail_.size());
     tail_.clear();
     if (fa_resume_rec_ != (size_t)-1) fa_resume_rec_ = (size_t)-1;  // offsets changed: rescan

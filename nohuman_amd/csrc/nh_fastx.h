@@ -98,7 +98,7 @@ public:
     }
     bool append(const char *b, size_t n) {
         if (!reserve(len_ + n)) return false;
-        memcpy(p_ + len_, b, n);
+        if (n) memcpy(p_ + len_, b, n);
         len_ += n;
         return true;
     }
