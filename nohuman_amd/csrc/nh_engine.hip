@@ -469,6 +469,21 @@ uint64_t kmer_taxa_entries(const Engine *e, const uint64_t *seq_offsets, uint64_
 // Every launch takes the next of LAUNCH_SLOTS (scheduling counter, "BIG pass pending" word), so
 // launches in flight on different streams of one engine never share them (more than LAUNCH_SLOTS
 // launches in flight at once on one engine are not supported).
+// Fragments a wave claims at a time.  Their offsets (mates * n + 1) must fit the 64 lanes; larger
+// chunks amortise the claim and the offsets load (measured best: 24 paired, 32 single-end), but a
+// small batch is cut finer so that every resident wave still gets about two chunks.
+static uint32_t frag_chunk_for(const Engine *e, uint32_t flags, uint64_t n_frag) {
+    if (flags & NH_FLAG_LONG) return 1;
+    static const char *env = getenv("NOHUMAN_FRAG_CHUNK");  // tuning knob
+    const bool paired = (flags & NH_FLAG_PAIRED) != 0;
+    uint32_t c = env ? (uint32_t)atoi(env) : (paired ? 24u : 32u);
+    const uint64_t waves = (uint64_t)e->grid_blocks * 4;
+    const uint64_t fair = n_frag / (2 * waves);
+    if (!env && fair < c) c = (uint32_t)fair;
+    const uint32_t cap = paired ? 31u : 63u;
+    return c < 1 ? 1 : c > cap ? cap : c;
+}
+
 int classify_device(Engine *e, const void *d_bases, const void *d_seq_off, uint64_t n_frag,
                          uint32_t flags, double confidence, void *d_results, void *d_kmer_taxa,
                          const void *d_kmer_taxa_off, void *d_counters, hipStream_t stream) {
@@ -483,7 +498,7 @@ int classify_device(Engine *e, const void *d_bases, const void *d_seq_off, uint6
                                     (flags & NH_FLAG_PAIRED) ? 2 : 1, confidence, d_results,
                                     d_kmer_taxa, d_kmer_taxa_off, d_counters, e->d_error + LAUNCH_SLOTS, e->d_error + slot,
                                     e->d_work + slot,
-                                    (flags & NH_FLAG_LONG) ? 1u : (e->frag_chunk > 31 ? 31 : e->frag_chunk), e->grid_blocks,
+                                    frag_chunk_for(e, flags, n_frag), e->grid_blocks,
                                     stream);
     if (he != hipSuccess) return set_error(NH_EDEVICE, "classify launch: %s", hipGetErrorString(he));
     return NH_OK;

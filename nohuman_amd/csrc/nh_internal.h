@@ -37,7 +37,6 @@ struct Engine {
     int *d_error = nullptr;
     unsigned long long *d_work = nullptr;  // dynamic fragment-chunk counters of k_classify, one per launch slot
     std::atomic<unsigned> launch_seq{0};
-    uint32_t frag_chunk = 16;              // fragments a wave pulls at a time
     hipStream_t stream = nullptr;
     std::vector<uint32_t> parent;
     std::vector<uint64_t> external;

@@ -966,7 +966,7 @@ __global__ __launch_bounds__(WAVE * WAVES_PER_BLOCK, BIG ? 1 : (STD ? NH_MIN_WAV
     // Fragments are handed out dynamically: every wave pulls chunks of consecutive fragments from
     // one counter (claimed one chunk ahead), so late-starting (non-resident) workgroups of the grid
     // find no work instead of a static share.
-    const uint32_t frag_chunk = ap->frag_chunk;  // <= 31: its offsets fit the 64 lanes of off_v
+    const uint32_t frag_chunk = ap->frag_chunk;  // mates * frag_chunk + 1 <= 64: the offsets fit the lanes of off_v
     unsigned long long next_chunk = 0;           // lane 0: first fragment of the chunk claimed ahead
     if (lane == 0) next_chunk = atomicAdd(ap->work, (unsigned long long)frag_chunk);
     for (;;) {
