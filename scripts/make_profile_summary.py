@@ -18,7 +18,14 @@ def mean_counter(pattern, kernel_sub, counter):
 
 out = []
 out.append("# profiles/%s_summary.txt -- rocprofv3 summaries of bench.py on 1 x MI355X" % rnd)
-out.append("# command: bash scripts/profile.sh <tag>   (bench.py --steps 5 --warmup 2 --no-cpu-baseline)")
+out.append("# command: bash scripts/profile.sh <tag>   (trace pass: bench.py --no-cpu-baseline, 20 + 3 launches;")
+out.append("#          PMC passes: bench.py --steps 5 --warmup 2 --no-cpu-baseline)")
+try:
+    bj = json.loads(open(os.path.join(src, 'bench_trace.json')).read().strip().splitlines()[-1])
+    out.append("# bench.py's own line in the trace pass: value %.1f %s, ms_per_step %.4f, roofline.kernel_ms %.4f" % (
+        bj['value'], bj['unit'], bj['ms_per_step'], bj['roofline']['kernel_ms']))
+except Exception as e:
+    out.append("# (bench line of the trace pass not available: %s)" % e)
 out.append("# workload: 1,000,000 fragments = 2,000,000 x 150 bp PE reads per launch, synthetic HPRC.r2-like table")
 out.append("#           1,431,655,765 cells (5.73 GB), load 0.70, k=35 l=31")
 out.append("")
