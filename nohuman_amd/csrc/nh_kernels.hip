@@ -39,6 +39,9 @@ namespace nh {
 #ifndef NH_LINE_CELLS
 #define NH_LINE_CELLS 32  // a probe round never crosses a boundary of this many cells (32 = 128-byte line)
 #endif
+#ifndef NH_WIDE_CELLS
+#define NH_WIDE_CELLS 16  // cells per round of an old lookup (8, 12 or 16)
+#endif
 #ifndef NH_WIDE_AFTER
 #define NH_WIDE_AFTER 2  // rounds after which a lookup examines 16 cells per round instead of 4
 #endif
@@ -527,7 +530,7 @@ __device__ __forceinline__ void probe_queue(KArgsP ap, WaveLdsT<STD> &S, const i
                     nvalid = room < in_line ? (uint32_t)room : in_line;
                     src = table + pos;
                 }
-                uint32_t res = 0, resj = 16, lo = 0;
+                uint32_t res = 0, resj = 64, lo = 0;
                 if constexpr (PC == 1) {
                     // A lookup's first NH_WIDE_AFTER rounds examine 4 cells with ONE 16-byte load that
                     // must not leave the line: if fewer than 4 cells remain it starts up to 3 cells
@@ -537,26 +540,27 @@ __device__ __forceinline__ void probe_queue(KArgsP ap, WaveLdsT<STD> &S, const i
                     // the slowest lookup of a group decides when the group can be post-processed -- so
                     // it examines up to 16 cells (a whole 64-byte sector) per round from then on.
                     const bool wide = max_rounds - budget >= (uint32_t)NH_WIDE_AFTER;
-                    const uint32_t lim = wide ? 16u : 4u;
+                    const uint32_t lim = wide ? (uint32_t)NH_WIDE_CELLS : 4u;
                     nvalid = nvalid < lim ? nvalid : lim;
                     lo = (!wide && in_line < 4u) ? 4u - in_line : 0u;
                     const uint4 c0 = *reinterpret_cast<const uint4 *>(src - lo);
-                    uint4 c1 = {0, 0, 0, 0}, c2 = {0, 0, 0, 0}, c3 = {0, 0, 0, 0};
+                    constexpr int WCH = NH_WIDE_CELLS / 4;  // 16-byte chunks of a wide round
+                    uint4 cw[WCH];
                     if (wide) {  // chunks past the last useful one re-read it (no new line is touched)
                         const uint32_t last_chunk = (nvalid - 1) >> 2;
-                        c1 = *reinterpret_cast<const uint4 *>(src + 4 * (last_chunk < 1u ? last_chunk : 1u));
-                        c2 = *reinterpret_cast<const uint4 *>(src + 4 * (last_chunk < 2u ? last_chunk : 2u));
-                        c3 = *reinterpret_cast<const uint4 *>(src + 4 * (last_chunk < 3u ? last_chunk : 3u));
+#pragma unroll
+                        for (int q = 1; q < WCH; q++)
+                            cw[q] = *reinterpret_cast<const uint4 *>(src + 4 * (last_chunk < (uint32_t)q ? last_chunk : (uint32_t)q));
                     }
                     if (wide) {
-                        const uint32_t cw[12] = {c1.x, c1.y, c1.z, c1.w, c2.x, c2.y, c2.z, c2.w, c3.x, c3.y, c3.z, c3.w};
 #pragma unroll
-                        for (int j = 11; j >= 0; j--) {
-                            const uint32_t cell = cw[j];
+                        for (int j = 4 * WCH - 1; j >= 4; j--) {
+                            const uint4 &cq = cw[j >> 2];
+                            const uint32_t cell = (j & 3) == 0 ? cq.x : (j & 3) == 1 ? cq.y : (j & 3) == 2 ? cq.z : cq.w;
                             const uint32_t x = cell ^ ckey;
                             const bool stop = (x <= vmask) | ((cell & vmask) == 0);
                             res = stop ? x : res;
-                            resj = stop ? (uint32_t)(j + 4) : resj;
+                            resj = stop ? (uint32_t)j : resj;
                         }
                     }
                     const uint32_t cells[4] = {c0.x, c0.y, c0.z, c0.w};
