@@ -84,6 +84,7 @@ struct WaveLdsT {
 #endif
     unsigned long long acc[4];  // fragments, classified, bases, lookups of this wave (lane 0 adds)
     uint64_t last_dw;           // last readable dword of the bases buffer
+    uint4 frag_state;        // FragState between post_group calls: nlist, hit_groups, carry_tax, overflow
     SlotLds slot[2][NSLOT];  // [parity of the group][tile]
     uint16_t ps[2][NSLOT][WAVE];  // per-lane packed k-mer state of the tiles in flight
     uint32_t pk[24];  // 2-bit packed bases: base i' of the tile frame at bit 2*(255-i'); 64 B + zero pad
@@ -880,7 +881,7 @@ __global__ __launch_bounds__(WAVE * WAVES_PER_BLOCK, BIG ? 1 : (STD ? NH_MIN_WAV
     uint64_t tprev = PROF ? __builtin_readcyclecounter() : 0;
 
     // speculative prefetch of the bases of the next two tiles (byte offset tags, loaded dwords)
-    uint64_t tag1 = ~0ull, tag2 = ~0ull;
+    uint32_t tag1 = 0, tag2 = 0;  // 1 + byte offset relative to the chunk's first base; 0 = nothing loaded
     uint32_t w1 = 0, w2 = 0;
 
     // Two groups of tiles are in flight: the one being scanned / probed (parity `par`) and the
@@ -896,15 +897,21 @@ __global__ __launch_bounds__(WAVE * WAVES_PER_BLOCK, BIG ? 1 : (STD ? NH_MIN_WAV
     lk.ckey = 0;
     lk.budget = 0;
 
-    FragState st;  // accumulation state of the fragment being post-processed
-    st.nlist = 0;
-    st.hit_groups = 0;
-    st.carry_min = 0;  // (the scan keeps its own last-minimizer)
-    st.carry_tax = 0;
-    st.overflow = false;
+    // accumulation state of the fragment being post-processed: parked in LDS between post_group calls
+    // (it is wave-uniform and idle during scan and probe: four scalar registers less to keep there)
+    if (lane == 0) S.frag_state = make_uint4(0, 0, 0, 0);
     // finish the tiles of group `pp` (and each fragment whose last tile is among them)
     auto post_group = [&](const uint32_t pp, const uint32_t nslot) {
         KArgsP a2 = launder(ap);
+        FragState st;
+        {
+            const uint4 fs = S.frag_state;
+            st.nlist = uni(fs.x);
+            st.hit_groups = uni(fs.y);
+            st.carry_tax = uni(fs.z);
+            st.overflow = uni(fs.w) != 0;
+            st.carry_min = 0;  // (the scan keeps its own last-minimizer)
+        }
         uint32_t *const kmer_taxa = a2->kmer_taxa;
         for (uint32_t s = 0; s < nslot; s++) {
             // descriptor: three 16-byte LDS reads (same address in every lane), then scalars
@@ -953,6 +960,7 @@ __global__ __launch_bounds__(WAVE * WAVES_PER_BLOCK, BIG ? 1 : (STD ? NH_MIN_WAV
             }
             wave_sync();
         }
+        if (lane == 0) S.frag_state = make_uint4(st.nlist, st.hit_groups, st.carry_tax, st.overflow ? 1u : 0u);
         NH_STAMP(7);
     };
 
@@ -990,6 +998,7 @@ __global__ __launch_bounds__(WAVE * WAVES_PER_BLOCK, BIG ? 1 : (STD ? NH_MIN_WAV
             S.acc[CNT_BASES] += crel;
         }
         const uint32_t off_v = (uint32_t)crel;
+        tag1 = tag2 = 0;  // tags are relative to the chunk
         for (uint32_t fc = 0; fc < ncf; fc++) {
             NH_STAMP(8);
             const uint64_t f = cbeg + fc;
@@ -1026,10 +1035,11 @@ __global__ __launch_bounds__(WAVE * WAVES_PER_BLOCK, BIG ? 1 : (STD ? NH_MIN_WAV
                     NH_STAMP(0);
                     // two-deep prefetch FIFO: (tag1, w1) was loaded for the next tile, (tag2, w2)
                     // for the one after it
+                    const uint32_t gtag = (uint32_t)(g0 - cbase) + 1u;
                     uint32_t w = w1;
-                    if (tag1 != g0) {
+                    if (tag1 != gtag) {
                         w = w2;
-                        if (tag2 != g0) w = *tile_ptr(g0);
+                        if (tag2 != gtag) w = *tile_ptr(g0);
                     }
                     tag1 = tag2;
                     w1 = w2;
@@ -1054,7 +1064,7 @@ __global__ __launch_bounds__(WAVE * WAVES_PER_BLOCK, BIG ? 1 : (STD ? NH_MIN_WAV
                         ng0 = cbase + o_next;
                     }
                     const uint32_t *pf_ptr = tile_ptr(pf_on ? ng0 : g0);
-                    tag2 = pf_on ? ng0 : ~0ull;
+                    tag2 = pf_on ? (uint32_t)(ng0 - cbase) + 1u : 0u;
 
                     const uint32_t nl_left = (n - L + 1) - q0;
                     const uint32_t nlt = nl_left < (uint32_t)TL ? nl_left : (uint32_t)TL;
