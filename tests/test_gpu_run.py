@@ -233,3 +233,48 @@ def test_fragments_with_many_taxa_in_concurrent_batches(tmp_path, monkeypatch):
     want_ext = np.asarray(odb.external_ids)[exp["call"]].astype(np.int64)
     assert np.array_equal(got_ext, want_ext)
     assert st.classified == int((exp["call"] != 0).sum())
+
+
+def test_ultra_long_reads_gzip_fasta_and_fastq(tmp_path, toy, toy_oracle, monkeypatch):
+    """Reads of 0.3-1.5 Mb (records far longer than the 4 MiB read granularity is not, but longer than
+    one gzip chunk): gzip FASTQ through the multi-threaded decoder and 60-column FASTA (joined in place),
+    compared per read with the oracle; the kept records must come back byte for byte."""
+    import numpy as np
+    from nohuman_amd import engine
+    from oracle import oracle as orc
+    from tests import synth
+    _, _, _, genomes, _ = toy
+    rng = np.random.default_rng(42)
+    allg = b"".join(genomes[k] for k in sorted(genomes))
+    reads = []
+    for ln in (1_500_000, 300_000, 777_777, 35, 20, 1_000_001, 150):
+        parts = []
+        while sum(map(len, parts)) < ln:
+            if rng.random() < 0.5:
+                st = int(rng.integers(0, len(allg) - 2000))
+                parts.append(allg[st:st + int(rng.integers(200, 2000))])
+            else:
+                parts.append(synth.random_seq(rng, int(rng.integers(500, 5000))))
+        reads.append(synth.mutate(rng, b"".join(parts)[:ln], 0.03, 0.0005, 0.0))
+    bases, offs = orc.pack_reads(reads, False)
+    exp, _ = toy_oracle.classify(bases, offs, False, 0.0)
+    want_ext = np.asarray(toy_oracle.external_ids)[exp["call"]].astype(np.int64)
+    monkeypatch.setenv("NOHUMAN_GZ_CHUNK", "65536")
+    fq = b"".join(b"@long%d len=%d\n%s\n+\n%s\n" % (i, len(r), r, b"5" * len(r)) for i, r in enumerate(reads))
+    fa = b"".join(b">long%d\n" % i + b"".join(r[j:j + 60] + b"\n" for j in range(0, len(r), 60)) for i, r in enumerate(reads))
+    for name, data in (("r.fq.gz", fq), ("r.fa.gz", fa)):
+        p = tmp_path / name
+        p.write_bytes(gzip.compress(data, 6))
+        out, k = tmp_path / (name + ".out"), tmp_path / (name + ".k")
+        st = engine.run(DB, str(p), str(out), kraken_output=str(k), threads=4, device_ids=[0])
+        lines = k.read_text().splitlines()
+        assert [int(l.split("\t")[2]) for l in lines] == list(want_ext), name
+        assert [int(l.split("\t")[3]) for l in lines] == [len(r) for r in reads]
+        assert st.total_bases == sum(len(r) for r in reads)
+        kept = [i for i, c in enumerate(exp["call"]) if c == 0]
+        if name.endswith("fq.gz"):
+            want = b"".join(b"@long%d len=%d\n%s\n+\n%s\n" % (i, len(reads[i]), reads[i], b"5" * len(reads[i])) for i in kept)
+        else:
+            want = b"".join(b">long%d\n%s\n" % (i, reads[i]) for i in kept)
+        assert out.read_bytes() == want, name
+    assert (exp["call"] != 0).sum() >= 3
