@@ -220,3 +220,38 @@ def test_table_larger_than_2_pow_32_cells():
             assert (rec[n_reads // 2:, 0] != 0).mean() < 0.01, name
     assert res["small"][1] == res["wide"][1]  # same minimizer runs -> same number of lookups
     assert np.array_equal(res["small"][0][: n_reads // 2], res["wide"][0][: n_reads // 2])
+
+
+@pytest.mark.parametrize("value_bits", [8, 16, 24, 28])
+def test_wide_values_and_short_keys_collide_identically(value_bits):
+    """The cell layout is key_bits + value_bits = 32.  With wide values only a few key bits are left
+    (4 at value_bits 28), so unrelated minimizers match by chance all the time: the GPU must report
+    exactly the oracle's (false) hits, LCAs over a 200-level deep taxonomy included."""
+    from nohuman_amd import Engine
+    from oracle import minidb
+    rng = np.random.default_rng(100 + value_bits)
+    edges = {1: 0}
+    for d in range(2, 202):      # a chain 200 levels deep ...
+        edges[d] = d - 1
+    leaves = []
+    for i in range(40):          # ... with leaves hanging off it at many depths
+        ext = 1000 + i
+        edges[ext] = 5 * i + 2
+        leaves.append(ext)
+    tax = minidb.Taxonomy(edges)
+    segs = {ext: synth.random_seq(rng, 400) for ext in leaves}
+    hashb, size = minidb.build_hash(tax, sorted(segs.items()), 30011, value_bits=value_bits)
+    ob, tb = minidb.opts_bytes(), tax.to_bytes()
+    reads = synth.sample_reads(rng, segs, 1500, length=150, frac_random=0.5)
+    reads += [b"".join(segs[int(e)][50:250] for e in rng.choice(leaves, size=6, replace=False)) for _ in range(60)]
+    bases, offs = orc.pack_reads(reads, False)
+    odb = orc.OracleDB(ob, tb, hashb)
+    for conf in (0.0, 0.2):
+        exp, lookups, etaxa, _ = odb.classify(bases, offs, False, conf, want_taxa=True)
+        with Engine.from_images(ob, tb, hashb) as eng:
+            assert eng.info.value_bits == value_bits
+            got, taxa, _ = eng.classify(bases, offs, False, conf, want_taxa=True)
+        _assert_same(got, exp, "value_bits=%d conf=%s" % (value_bits, conf))
+        assert np.array_equal(taxa, etaxa)
+    if value_bits >= 24:  # chance matches really happen: random reads get classified
+        assert (exp["call"][750:1500] != 0).mean() > 0.02
