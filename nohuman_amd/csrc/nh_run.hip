@@ -560,6 +560,7 @@ int run_engines(const std::vector<Engine *> &engines, const nh_run_args *a, nh_s
     // gzip inputs are inflated by `threads` workers in all, shared between the files
     unsigned gz_threads = (a->threads ? a->threads : 1) / (unsigned)mates;
     if (gz_threads < 1) gz_threads = 1;
+    if (gz_threads > 16) gz_threads = 16;  // beyond that the record parser of the file is the limit
     std::thread t1(reader_main, a->in1, &q1, &rs, &pool1, &clk, 0, BATCH_FRAGS, BATCH_TEXT, gz_threads);
     std::thread t2;
     if (rs.paired)
