@@ -30,7 +30,9 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--pairs", type=int, default=1_000_000, help="read pairs per step per GPU")
+    ap.add_argument("--pairs", type=int, default=2_500_000,
+                    help="read pairs per step (= per launch) per GPU; the default 20 steps then cover the "
+                         "50 M pairs of BASELINE.json configs[2]")
     ap.add_argument("--read-len", type=int, default=150)
     ap.add_argument("--single-end", action="store_true", help="config[1]: 150 bp single-end")
     ap.add_argument("--capacity", type=int, default=1_431_655_765,

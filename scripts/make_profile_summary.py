@@ -4,7 +4,7 @@ profiles/<round>_summary.txt, profiles/<round>_kernel_stats.csv and profiles/tra
     python scripts/make_profile_summary.py gpurun_out/prof_r01c r01"""
 import csv, glob, json, os, sys
 src, rnd = sys.argv[1], sys.argv[2]
-LOOKUPS = 77.43e6
+LOOKUPS = 77.43e6 * 2.5  # 2.5 M pairs per launch
 
 
 def mean_counter(pattern, kernel_sub, counter):
@@ -26,7 +26,7 @@ try:
         bj['value'], bj['unit'], bj['ms_per_step'], bj['roofline']['kernel_ms']))
 except Exception as e:
     out.append("# (bench line of the trace pass not available: %s)" % e)
-out.append("# workload: 1,000,000 fragments = 2,000,000 x 150 bp PE reads per launch, synthetic HPRC.r2-like table")
+out.append("# workload: 2,500,000 fragments = 5,000,000 x 150 bp PE reads per launch, synthetic HPRC.r2-like table")
 out.append("#           1,431,655,765 cells (5.73 GB), load 0.70, k=35 l=31")
 out.append("")
 out.append("== rocprofv3 --kernel-trace --stats (trace_kernel_stats.csv), our kernels")
@@ -60,15 +60,15 @@ if cf is not None:
 out.append("")
 out.append("== derived, per launch")
 out.append("  lookups D                   %.4g   (38.7 per read)" % LOOKUPS)
-out.append("  fabric read requests        %.4g   (%.2f per lookup, incl. ~4.9e6 for the streamed bases)" % (rq, rq / LOOKUPS))
+out.append("  fabric read requests        %.4g   (%.2f per lookup, incl. ~1.2e7 for the streamed bases)" % (rq, rq / LOOKUPS))
 out.append("  FETCH_SIZE as counted       %.4g bytes ; WRITE_SIZE %.4g bytes" % (fs * 1024, ws * 1024))
-out.append("  algorithmic bytes           5.27e9  (sum len + 64*D + 16 per fragment, BASELINE.md section 4)")
+out.append("  algorithmic bytes           1.318e10  (sum len + 64*D + 16 per fragment, BASELINE.md section 4)")
 os.makedirs('profiles', exist_ok=True)
 open('profiles/%s_summary.txt' % rnd, 'w').write("\n".join(out) + "\n")
 with open('profiles/%s_kernel_stats.csv' % rnd, 'w') as g:
     for row in csv.reader(open(os.path.join(src, 'trace/trace_kernel_stats.csv'))):
         g.write(",".join('"%s"' % c[:120] for c in row) + "\n")
-json.dump({"workload": {"fragments_per_step": 1000000, "paired": True, "read_len": 150, "capacity": 1431655765},
+json.dump({"workload": {"fragments_per_step": 2500000, "paired": True, "read_len": 150, "capacity": 1431655765},
            "source": "profiles/%s_summary.txt (rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE, separate passes, k_classify mean per launch)" % rnd,
            "fetch_size_kb": fs, "write_size_kb": ws,
            "note": "FETCH_SIZE calibrated at 64 B per fabric read request on a random 16-byte gather (one request per probe); "
