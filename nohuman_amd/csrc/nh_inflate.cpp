@@ -14,6 +14,7 @@
 #include <zlib.h>  // crc32_combine only
 
 #include <condition_variable>
+#include <functional>
 #include <deque>
 #include <map>
 #include <memory>
@@ -621,6 +622,7 @@ struct ChunkDecoder {
         end = e;
         n16 = n8 = marker_end = 0;
         floor_off = 0;
+        at_block = nullptr;
         bytes_mode = false;
         members.clear();
         stop = STOP_NONE;
@@ -638,6 +640,30 @@ struct ChunkDecoder {
         stop = STOP_ERROR;
         return false;
     }
+    // Called at block boundaries while the output is still 16-bit (speculative chunks): the owner may
+    // hand over the window that precedes the chunk as soon as it is known, see adopt_window().
+    // Returning false aborts the chunk (its start turned out not to be a block boundary).
+    std::function<bool(ChunkDecoder &)> at_block;
+
+    // The WSIZE bytes before the chunk are known now: the last WSIZE symbols (markers replaced) become
+    // the byte decoder's history and the rest of the chunk is decoded as bytes.
+    bool adopt_window(const uint8_t *window) {
+        if (!out8.reserve(1u << 20)) return false;
+        uint8_t *h = out8.data() - WSIZE;
+        const uint16_t *s = out16.data();
+        if (n16 >= WSIZE) {
+            s += n16 - WSIZE;
+            for (size_t i = 0; i < WSIZE; i++) h[i] = s[i] & 0x8000u ? window[s[i] & 0x7fffu] : (uint8_t)s[i];
+        } else {
+            memcpy(h, window + n16, WSIZE - n16);
+            uint8_t *d = h + (WSIZE - n16);
+            for (size_t i = 0; i < n16; i++) d[i] = s[i] & 0x8000u ? window[s[i] & 0x7fffu] : (uint8_t)s[i];
+        }
+        floor_off = -(ptrdiff_t)WSIZE;
+        bytes_mode = true;
+        return true;
+    }
+
     void to_bytes_mode() {  // the last WSIZE symbols are clean: they become the byte decoder's history
         out8.reserve(1u << 20);
         uint8_t *h = out8.data() - WSIZE;
@@ -713,6 +739,10 @@ struct ChunkDecoder {
         in.init(base, end, from_bit);
         start_bit = from_bit;
         for (;;) {
+            if (!bytes_mode && at_block && !at_block(*this)) {
+                fail("superseded");
+                return;
+            }
             bool final = false;
             if (!block(in, final)) return;
             if (final) {
@@ -1003,18 +1033,23 @@ private:
         return c >= n_chunks_ ? (uint64_t)-1 : (uint64_t)c * chunk_ * 8;
     }
 
-    // last WSIZE bytes of the stream after a chained chunk (all of its output is bytes)
+    // last WSIZE bytes of the stream after a chunk whose start is certain (c.window_before holds the
+    // window it started with: markers of its 16-bit part can be replaced)
     std::shared_ptr<TailInfo> make_tail(Chunk &c) {
         std::shared_ptr<TailInfo> t(new TailInfo());
         t->end_bit = c.dec.end_bit;
         t->stream_end = c.dec.stop == STOP_STREAM_END;
-        const size_t n = c.dec.n8;
-        if (n >= WSIZE) {
-            memcpy(t->window, c.dec.out8.data() + n - WSIZE, WSIZE);
-        } else {  // short chunk: the rest comes from the window it started with
-            memcpy(t->window, c.window_before + n, WSIZE - n);
-            memcpy(t->window + WSIZE - n, c.dec.out8.data(), n);
+        const size_t n16 = c.dec.n16, n8 = c.dec.n8, total = n16 + n8;
+        const uint16_t *s = c.dec.out16.data();
+        const uint8_t *w = c.window_before;
+        size_t k = 0;
+        if (total < WSIZE) {
+            memcpy(t->window, w + total, WSIZE - total);
+            k = WSIZE - total;
         }
+        for (size_t pos = total > WSIZE ? total - WSIZE : 0; pos < n16; pos++, k++)
+            t->window[k] = s[pos] & 0x8000u ? w[s[pos] & 0x7fffu] : (uint8_t)s[pos];
+        if (k < WSIZE) memcpy(t->window + k, c.dec.out8.data() + n8 - (WSIZE - k), WSIZE - k);
         return t;
     }
 
@@ -1062,13 +1097,38 @@ private:
         // A position that passes the header test by chance decodes into an error sooner or later:
         // go on searching behind it (a few times; the consumer fills in whatever stays undecoded).
         uint64_t s = (uint64_t)-1, from = chunk_bit(c.index);
-        for (int attempt = 0; attempt < 8 && !c.found; attempt++) {
+        bool pred_known = false;  // the predecessor finished meanwhile and this chunk did not start at its end
+        for (int attempt = 0; attempt < 8 && !c.found && !pred_known; attempt++) {
             s = find_block(base_, end, from, to, c.dec.scratch);
             if (s == (uint64_t)-1) break;
             if (attempt) c.dec.reset(base_, end);
+            // As soon as the predecessor is finished and certain, this chunk either starts exactly at
+            // its end -- then it is certain too, takes over the predecessor's last 32 KiB and goes on
+            // with the (three times faster) byte decoder -- or it started at a false positive.
+            c.dec.at_block = [this, &c, &pred_known](ChunkDecoder &d) {
+                std::shared_ptr<TailInfo> t;
+                {
+                    std::lock_guard<std::mutex> lk(mu_);
+                    auto it = tails_.find(c.index - 1);
+                    if (it == tails_.end()) return true;
+                    t = it->second;
+                }
+                pred_known = true;
+                if (t->failed || t->stream_end || t->end_bit != d.start_bit) return false;
+                memcpy(c.window_before, t->window, WSIZE);
+                if (!d.adopt_window(t->window)) return false;
+                c.chained = true;
+                return true;
+            };
             c.dec.run(s, chunk_bit(c.index + 1), chunk_bit(c.index + 2), false);
             c.found = c.dec.stop != STOP_ERROR;
+            if (!c.found) c.chained = false;
             from = s + 1;
+        }
+        c.dec.at_block = nullptr;
+        if (!c.found && pred_known) {  // start over from the predecessor's end, which is known now
+            speculate(c);
+            return;
         }
         if (debug) clock_gettime(CLOCK_MONOTONIC, &t1);
         if (s == (uint64_t)-1) return;
@@ -1145,11 +1205,20 @@ private:
         P_ = c->dec.end_bit;
         if (c->dec.stop == STOP_STREAM_END) ended_ = true;
         Chunk *raw = c.get();
+        std::shared_ptr<TailInfo> t;
+        if (!raw->chained) {  // accepted: its end and the window after it are certain now
+            t.reset(new TailInfo());
+            t->end_bit = P_;
+            t->stream_end = ended_;
+            memcpy(t->window, window_, WSIZE);
+        }
         pieces_.push_back(std::move(c));
         {
             std::lock_guard<std::mutex> lk(mu_);
+            if (t && !tails_.count(raw->index)) tails_[raw->index] = t;
             resolve_jobs_.push_back({raw, 1});
         }
+        if (t) cv_done_.notify_all();
         cv_work_.notify_one();
     }
 
@@ -1204,16 +1273,38 @@ private:
         }
         if (!c.found || c.dec.start_bit < P_) {  // no block start, garbage, or a start we already passed
             rejected_++;
+            const size_t idx = c.index;
             spare_.push_back(std::move(inflight_.front()));
             inflight_.pop_front();
+            publish_position(idx);
             return true;
         }
-        if (c.dec.start_bit > P_) return block ? gap_decode(c.dec.start_bit) : false;
+        if (c.dec.start_bit > P_) {
+            if (!block) return false;
+            const size_t idx = c.index;
+            const bool ok = gap_decode(c.dec.start_bit);
+            if (ok && idx > 0) publish_position(idx - 1);
+            return ok;
+        }
         std::unique_ptr<Chunk> own = std::move(inflight_.front());
         inflight_.pop_front();
         accepted_++;
         accept(std::move(own));
         return true;
+    }
+
+    // The consumer's own position stands in for the tail of chunk idx (rejected, or followed by a gap the
+    // consumer decoded): chunk idx + 1, if still being decoded, can adopt the window or give up.
+    void publish_position(size_t idx) {
+        if (ended_ || P_ < chunk_bit(idx + 1)) return;
+        std::shared_ptr<TailInfo> t(new TailInfo());
+        t->end_bit = P_;
+        memcpy(t->window, window_, WSIZE);
+        {
+            std::lock_guard<std::mutex> lk(mu_);
+            if (!tails_.count(idx)) tails_[idx] = t;
+        }
+        cv_done_.notify_all();
     }
 
     bool verify(Chunk &c) {
