@@ -36,6 +36,40 @@ try:
                     rows.append(seq[b0 + i].tobytes())
                     rows.append(b"\n+\n" + b"I" * L + b"\n")
                 f.write(b"".join(rows))
+    if os.environ.get("E2E_ONT"):  # configs[3] shape, scaled: long single-end reads, N50 ~ 10 kb
+        from nohuman_amd import _lib
+        n = int(os.environ["E2E_ONT"])
+        threads = int(os.environ.get("E2E_THREADS", "16"))
+        lens = np.clip(np.exp(rng.normal(8.8, 0.85, n)), 200, 200000).astype(np.int64)
+        total = int(lens.sum())
+        seq = np.frombuffer(b"ACGT", dtype=np.uint8)[rng.integers(0, 4, size=total, dtype=np.uint8)]
+        fo = os.path.join(tmp, "ont.fq")
+        with open(fo, "wb") as f:
+            off = 0
+            for i in range(n):
+                ln = int(lens[i])
+                f.write(b"@ont.%d\n" % i)
+                f.write(seq[off:off + ln].tobytes())
+                f.write(b"\n+\n" + b"5" * ln + b"\n")
+                off += ln
+        del seq
+        srt = np.sort(lens)[::-1]
+        n50 = int(srt[np.searchsorted(np.cumsum(srt), total / 2)])
+        print("setup %.1fs: %d reads, %.2f Gbases, N50 %d, FASTQ %.1f GB" % (time.time() - t0, n, total / 1e9, n50, os.path.getsize(fo) / 1e9))
+        t = time.time()
+        assert _lib.lib().nh_compress_file(os.fsencode(fo), os.fsencode(fo + ".gz"), 2, threads) == 0
+        print("gzip took %.1fs, ratio %.2f" % (time.time() - t, os.path.getsize(fo) / os.path.getsize(fo + ".gz")))
+        with Engine.open(db) as e:
+            for label, path in (("ONT plain", fo), ("ONT plain", fo), ("ONT gzip", fo + ".gz"), ("ONT gzip", fo + ".gz")):
+                out = os.path.join(tmp, "o.fq")
+                if os.path.exists(out):
+                    os.remove(out)
+                t = time.time()
+                st = e.run(path, out, threads=threads)
+                dt = time.time() - t
+                print("%-10s %6.2fs wall  %6.3f Mreads/s  %6.2f Gbases/s e2e  (%d reads, %d classified)" % (
+                    label, dt, st.total_sequences / dt / 1e6, st.total_bases / dt / 1e9, st.total_sequences, st.classified))
+        raise SystemExit(0)
     f1, f2 = os.path.join(tmp, "r_1.fq"), os.path.join(tmp, "r_2.fq")
     write_fastq(f1, 1); write_fastq(f2, 2)
     print("setup %.1fs: db %.2f GB, 2 x %.0f MB FASTQ" % (time.time() - t0, cap * 4 / 1e9, os.path.getsize(f1) / 1e6))
