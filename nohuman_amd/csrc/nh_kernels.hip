@@ -936,10 +936,20 @@ __global__ __launch_bounds__(WAVE * WAVES_PER_BLOCK, BIG ? 1 : (STD ? NH_MIN_WAV
                 const uint32_t total_kmers = d_total;
                 uint32_t call = 0, clade_hits = 0;
                 if (st.nlist > 0) {
-                    if (BIG)
+                    if (BIG) {
                         call = resolve_tree_big(ap, TLI, lane, st, total_kmers, clade_hits);
-                    else
+                    } else if (st.nlist == 1) {
+                        // one taxon only (nearly every fragment on a human-only database): its score is
+                        // its count and climbing to its ancestors cannot add hits, so ResolveTree is a
+                        // comparison -- no walk up the parent chain (a dependent global load per level)
+                        const uint32_t cnt = S.list_cnt[0];
+                        const uint32_t required = (uint32_t)ceil(a2->confidence * (double)total_kmers);
+                        call = cnt >= required ? S.list_tax[0] : 0u;
+                        if (call && st.hit_groups < a2->db.min_hit_groups) call = 0;
+                        clade_hits = call ? cnt : 0u;
+                    } else {
                         call = resolve_tree(ap, S, lane, st, total_kmers, clade_hits);
+                    }
                 }
                 // hot variant: a fragment with more than 64 distinct taxa is left to the BIG variant
                 const bool defer = !BIG && st.overflow;
