@@ -195,6 +195,10 @@ def main():
             "unit": "GB/s",
             "frac": round(achieved / HBM_PEAK_GBS, 4),
             "traffic": measured_traffic(n_frag, paired, L, info.capacity, bool(args.ont or args.hit_frac or args.n_rate)),
+            # informative: the limit this gather-bound kernel actually runs into is the fabric's random
+            # request rate (profiles/traffic.json), not bytes: requests per launch / kernel time vs ceiling
+            "fabric_request_frac": request_rate_frac(n_frag, paired, L, info.capacity, kernel_ms,
+                                                     bool(args.ont or args.hit_frac or args.n_rate)),
             "kernel": "k_classify",
             "kernel_ms": round(kernel_ms, 4),
             "algorithmic_bytes_per_launch": int(alg_bytes_launch),
@@ -226,6 +230,19 @@ def measured_traffic(n_frag, paired, read_len, capacity, variant=False):
     if t.get("workload") != key:
         return None
     return t.get("traffic_bytes_per_launch")
+
+
+def request_rate_frac(n_frag, paired, read_len, capacity, kernel_ms, variant=False):
+    """Fabric read requests per second of k_classify (PMC count per launch from profiles/traffic.json over
+    the kernel time measured here) as a fraction of the rate a pure random gather sustains on the chip."""
+    try:
+        t = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
+    except (OSError, ValueError):
+        return None
+    key = {"fragments_per_step": n_frag, "paired": paired, "read_len": read_len, "capacity": capacity}
+    if variant or t.get("workload") != key or not t.get("fabric_read_requests_per_launch") or kernel_ms <= 0:
+        return None
+    return round(t["fabric_read_requests_per_launch"] / (kernel_ms * 1e-3) / t["fabric_request_ceiling_per_s"], 4)
 
 
 def cpu_baseline(eng, bases_dev, offsets_dev, mates, paired, args, np, results, step):

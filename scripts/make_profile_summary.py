@@ -73,5 +73,10 @@ json.dump({"workload": {"fragments_per_step": 2500000, "paired": True, "read_len
            "fetch_size_kb": fs, "write_size_kb": ws,
            "note": "FETCH_SIZE calibrated at 64 B per fabric read request on a random 16-byte gather (one request per probe); "
                    "if every request moved a full 128-byte line, HBM bytes are twice this",
-           "traffic_bytes_per_launch": int(fs * 1024 + ws * 1024)}, open('profiles/traffic.json', 'w'), indent=1)
+           "traffic_bytes_per_launch": int(fs * 1024 + ws * 1024),
+           "fabric_read_requests_per_launch": int(rq),
+           "fabric_request_ceiling_per_s": 50e9,
+           "ceiling_source": "tools/gather_bench (profiles/%s_gather_bench.txt, %s_phase_prof.txt): a pure random gather "
+                             "sustains ~50e9 fabric read requests/s on this chip whatever the table size" % (rnd, rnd)},
+          open('profiles/traffic.json', 'w'), indent=1)
 print("\n".join(out))
