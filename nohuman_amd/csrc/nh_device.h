@@ -8,6 +8,10 @@ namespace nh {
 // argument (lives in SGPRs / the kernarg segment; no global loads for it).
 struct DevDB {
     const uint32_t *table;  // hash.k2d cells, capacity entries (+ padding to a multiple of 4, +4)
+    // second copy of the same cells placed 32 bytes off the 64-byte grid (== table if there is none):
+    // a lookup whose home cell lies in the second half of a 64-byte sector probes this copy, where the
+    // same cell lies in the first half, so fewer probe runs cross a sector boundary
+    const uint32_t *table_b;
     uint64_t capacity;
     uint64_t cap_magic;     // floor((2^64 - 1) / capacity): exact `hc % capacity` without a divide
     const uint32_t *parent; // taxonomy: internal parent ids [node_count]

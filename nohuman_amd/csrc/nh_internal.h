@@ -31,6 +31,9 @@ struct Engine {
     nh_options options{};
     DevDB dev{};
     uint32_t *d_table = nullptr;
+    void *d_table_b_raw = nullptr;  // second, 32-byte shifted copy of the table (see DevDB::table_b)
+    uint32_t *d_table_b = nullptr;
+    bool table_b_dirty = true;
     uint64_t table_cells_alloc = 0;
     uint32_t *d_parent = nullptr;
     uint64_t *d_counters = nullptr;

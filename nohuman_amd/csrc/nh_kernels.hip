@@ -443,6 +443,8 @@ __device__ __forceinline__ void probe_queue(KArgsP ap, WaveLdsT<STD> &S, const i
     const uint64_t magic = ap->db.cap_magic;
     const uint32_t max_rounds = ap->db.max_chunks;
     const uint32_t *const table = ap->db.table;
+    const uint32_t *const table_b = ap->db.table_b;
+    const bool two_copies = table_b != table;
 
     // ---- 6a. dense hash pass ----------------------------------------------------------------------
     for (uint32_t r0 = 0; r0 < qn; r0 += 64) {
@@ -490,6 +492,8 @@ __device__ __forceinline__ void probe_queue(KArgsP ap, WaveLdsT<STD> &S, const i
                             if (CAP32) {
                                 pos = (uint32_t)e;
                                 ckey = (uint32_t)(e >> 32);
+                                // home in the second half of its sector: use the shifted copy
+                                if (two_copies && ((uint32_t)e & 8u)) r |= 1u << 10;
                             } else {
                                 pos = e >> kbits;
                                 ckey = (uint32_t)(e & ((1ull << kbits) - 1)) << vbits;
@@ -508,7 +512,7 @@ __device__ __forceinline__ void probe_queue(KArgsP ap, WaveLdsT<STD> &S, const i
             }
         }
         // done when the queue is handed out and no lane still works for the previous group
-        if (qhead >= qn && __ballot(busy != 0 && (r >> 9) != par) == 0) break;
+        if (qhead >= qn && __ballot(busy != 0 && ((r >> 9) & 1u) != par) == 0) break;
         if (PROF) prof[11] += 1;  // probe rounds executed (not cycles)
         if (busy) {
             if (LINEAR) {
@@ -521,10 +525,11 @@ __device__ __forceinline__ void probe_queue(KArgsP ap, WaveLdsT<STD> &S, const i
                 const uint32_t *src;
                 if (CAP32) {
                     const uint32_t p32 = (uint32_t)pos;
-                    in_line = (uint32_t)NH_LINE_CELLS - (p32 & (uint32_t)(NH_LINE_CELLS - 1));
+                    const bool ub = (r >> 10) & 1u;  // probing the copy that sits 8 cells off the grid
+                    in_line = (uint32_t)NH_LINE_CELLS - ((p32 + (ub ? 8u : 0u)) & (uint32_t)(NH_LINE_CELLS - 1));
                     const uint32_t room = (uint32_t)cap - p32;
                     nvalid = in_line < room ? in_line : room;
-                    src = table + p32;
+                    src = (ub ? table_b : table) + p32;
                 } else {
                     in_line = (uint32_t)NH_LINE_CELLS - ((uint32_t)pos & (uint32_t)(NH_LINE_CELLS - 1));
                     const uint64_t room = cap - pos;
@@ -605,7 +610,7 @@ __device__ __forceinline__ void probe_queue(KArgsP ap, WaveLdsT<STD> &S, const i
                 }
                 budget--;
                 if (found | (budget == 0)) {
-                    tax_at<STD>(S, r >> 9, r & 0x1FFu) = (found && res <= vmask) ? res : 0u;
+                    tax_at<STD>(S, (r >> 9) & 1u, r & 0x1FFu) = (found && res <= vmask) ? res : 0u;
                     busy = 0;
                 }
             } else {
@@ -624,7 +629,7 @@ __device__ __forceinline__ void probe_queue(KArgsP ap, WaveLdsT<STD> &S, const i
                     if (pos == first_pos) end = true;
                 }
                 if (end) {
-                    tax_at<STD>(S, r >> 9, r & 0x1FFu) = val;
+                    tax_at<STD>(S, (r >> 9) & 1u, r & 0x1FFu) = val;
                     busy = 0;
                 }
             }
