@@ -509,9 +509,12 @@ int classify_device(Engine *e, const void *d_bases, const void *d_seq_off, uint6
         return set_error(NH_EINVAL, "kmer_taxa and kmer_taxa_offsets go together");
     if (((uintptr_t)d_bases & 3) != 0) return set_error(NH_EINVAL, "d_bases must be 4-byte aligned");
     finish_devdb(e);
-    if (e->d_table_b && e->table_b_dirty) {  // the table changed since the copy was made
+    if (e->d_table_b && e->table_b_dirty) {
+        // The table changed since the copy was made (load, inserts).  The copy is waited for here:
+        // the next launch may come on another stream and must not read a half-written copy.
         hipError_t ce = hipMemcpyAsync(e->d_table_b, e->d_table, e->table_cells_alloc * sizeof(uint32_t),
                                        hipMemcpyDeviceToDevice, stream);
+        if (ce == hipSuccess) ce = hipStreamSynchronize(stream);
         if (ce != hipSuccess) return set_error(NH_EDEVICE, "table copy: %s", hipGetErrorString(ce));
         e->table_b_dirty = false;
     }
