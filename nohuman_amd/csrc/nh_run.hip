@@ -857,13 +857,25 @@ int nh_run(const nh_run_args *args, nh_stats *stats) {
         devs.assign(args->device_ids, args->device_ids + args->n_devices);
     else
         for (int i = 0; i < (args->n_devices > 0 ? args->n_devices : ndev); i++) devs.push_back(i);
+    // one replica of the database per device, loaded at the same time (each device has its own PCIe
+    // link; the file comes from the page cache after the first reader)
+    std::vector<nh::Engine *> opened(devs.size(), nullptr);
+    std::vector<int> rcs(devs.size(), NH_OK);
+    std::vector<std::string> errs(devs.size());
+    {
+        std::vector<std::thread> loaders;
+        for (size_t i = 0; i < devs.size(); i++)
+            loaders.emplace_back([&, i] {
+                rcs[i] = nh::open_dir(args->db_dir, devs[i], &opened[i]);
+                if (rcs[i]) errs[i] = nh::g_last_error;  // thread-local: carry it over
+            });
+        for (auto &t : loaders) t.join();
+    }
     std::vector<nh::Engine *> engines;
     int rc = NH_OK;
-    for (int d : devs) {
-        nh::Engine *e = nullptr;
-        rc = nh::open_dir(args->db_dir, d, &e);
-        if (rc) break;
-        engines.push_back(e);
+    for (size_t i = 0; i < devs.size(); i++) {
+        if (opened[i]) engines.push_back(opened[i]);
+        if (rcs[i] && !rc) rc = nh::set_error(rcs[i], "%s", errs[i].c_str());
     }
     if (!rc) rc = nh::run_engines(engines, args, stats);
     std::string keep = nh::g_last_error;
