@@ -255,3 +255,52 @@ def test_wide_values_and_short_keys_collide_identically(value_bits):
         assert np.array_equal(taxa, etaxa)
     if value_bits >= 24:  # chance matches really happen: random reads get classified
         assert (exp["call"][750:1500] != 0).mean() > 0.02
+
+
+@pytest.mark.parametrize("seed", range(40))
+def test_random_database_geometries(seed):
+    """A seeded sweep over what opts.k2d / hash.k2d can say -- k, l, spaced seed, toggle, legacy
+    reverse complement, min-hash subsampling, load factor, probing rule, paired or not, confidence,
+    mate reset, hit-group threshold -- with reads around every length boundary: GPU == oracle."""
+    from nohuman_amd import Engine
+    rng = np.random.default_rng(7000 + seed)
+    l = int(rng.integers(8, 32))
+    k = int(l + rng.integers(0, 12))
+    kw = dict(k=k, l=l)
+    if rng.random() < 0.5:  # spaced seed: clear the low bit of some of the last base pairs
+        s = int(rng.integers(1, max(2, l // 4)))
+        mask = (1 << (2 * l)) - 1
+        for i in range(s):
+            mask &= ~(0b10 << (4 * i))
+        kw["spaced_mask"] = mask
+    else:
+        kw["spaced_mask"] = 0
+    kw["toggle"] = int(rng.integers(0, 1 << 62))
+    kw["revcom_version"] = int(rng.integers(0, 2))
+    if rng.random() < 0.3:
+        kw["min_hash"] = int(rng.integers(1 << 60, 1 << 63))
+    linear = bool(rng.random() < 0.7)
+    kw["linear_probing"] = linear
+    capacity = int(rng.choice([1999, 2503, 4001, 9973]))  # load factor ~0.9 ... 0.2
+    ob, tb, hb, genomes, _ = synth.toy_db(seed=seed, seg=int(rng.integers(150, 400)), capacity=capacity, **kw)
+    odb = orc.OracleDB(ob, tb, hb)
+    paired = bool(rng.random() < 0.5)
+    reads = synth.sample_reads(rng, genomes, 400, length=int(rng.integers(k, 3 * k + 40)), paired=paired,
+                               len_jitter=int(rng.integers(0, k)), n_rate=float(rng.choice([0.0, 0.002, 0.02])))
+    g = genomes[sorted(genomes)[0]]
+    edge = [g[:n] for n in (0, 1, l - 1, l, k - 1, k, k + 1, k + 123, k + 124, k + 125, 2 * 124 + k)]
+    reads += [(a, b) for a, b in zip(edge, edge[::-1])] if paired else edge
+    bases, offs = orc.pack_reads(reads, paired)
+    conf = float(rng.choice([0.0, 0.05, 0.3, 1.0]))
+    opts = dict(linear_probing=linear, reset_per_mate=bool(rng.random() < 0.8),
+                minimum_hit_groups=int(rng.integers(0, 4)))
+    with Engine.from_images(ob, tb, hb) as eng:
+        odb.set(**opts)
+        eng.set_options(**opts)
+        exp, lookups, etaxa, _ = odb.classify(bases, offs, paired, conf, want_taxa=True)
+        eng.reset_stats()
+        got, taxa, _ = eng.classify(bases, offs, paired, conf, want_taxa=True)
+        st = eng.stats()
+    _assert_same(got, exp, "seed %d k=%d l=%d %s" % (seed, k, l, kw))
+    assert np.array_equal(taxa, etaxa)
+    assert st.table_lookups == int(lookups.sum())
