@@ -7,15 +7,25 @@ nh_classify_batch_device) over one batch of synthetic read pairs already residen
 Reads shard across ranks with the database replicated; the only collective
 is the final all-reduce of the classified counts (RCCL via torch.distributed "nccl").
 
+`python bench.py --gpus N` works both ways: under torch.distributed.run (RANK / LOCAL_RANK /
+WORLD_SIZE in the environment) this process IS one rank; started directly with N > 1 it only spawns
+the N rank processes (before anything here touches the GPU), relays rank 0's line and exits with
+their status.
+
 Prints ONE JSON line on rank 0 (contract in the round brief), including
   "roofline":     algorithmic bytes (sum len + 64*D + 16 per fragment) per
                   launch / average kernel duration measured with HIP events on the launch stream,
   "cpu_baseline": the CPU oracle (oracle/k2_oracle.c, kind "port": kraken2 itself is not on the
-                  box) timed on the host cores on a bounded sample of the same workload.
+                  box) timed on the host cores on a bounded sample of the same workload,
+  "variants":     N=1 only, reduced step counts: the hit path (half of the fragments "human") and the
+                  single-end shape of BASELINE.json configs[1], each checked against the oracle,
+  "e2e":          N=1 only: nh_run() files-in -> files-out on gzip pairs (configs[2] shape at a stated
+                  scale), wall clock and per-stage times; never mixed into `value`.
 """
 import argparse
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -25,7 +35,7 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md:35)
 
 
-def main():
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
@@ -42,6 +52,10 @@ def main():
     ap.add_argument("--pool", type=int, default=4, help="distinct batches cycled through")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the CPU baseline leg")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-variants", action="store_true", help="skip the hit-path / single-end legs")
+    ap.add_argument("--no-e2e", action="store_true", help="skip the nh_run files-in -> files-out leg")
+    ap.add_argument("--e2e-pairs", type=int, default=4_000_000, help="pairs per gzip member of the e2e inputs")
+    ap.add_argument("--e2e-reps", type=int, default=4, help="members per e2e input file")
     ap.add_argument("--confidence", type=float, default=0.0)
     ap.add_argument("--hit-frac", type=float, default=0.0,
                     help="fraction of the fragments of every batch made 'human': their minimizers are "
@@ -49,44 +63,66 @@ def main():
     ap.add_argument("--ont", action="store_true",
                     help="config[3] shape: single-end long reads, length ~ lognormal(8.8, 0.85) in "
                          "[200, 200000] (N50 ~ 10 kb); --pairs = number of reads")
-    args = ap.parse_args()
+    return ap.parse_args(argv)
 
-    import numpy as np
-    import torch  # first: this process must use ONE HIP runtime (torch's bundled copy)
-    import torch.distributed as dist
 
-    import nohuman_amd
+# ---- direct start with --gpus N > 1: spawn the ranks, touch nothing else ---------------------------
+def launch_ranks(args):
+    """One child process per GPU with the torch.distributed environment set.  This parent never
+    imports torch or calls HIP (a process that has initialised the GPU must not start ranks that
+    replace it), prints what rank 0 printed and returns the worst exit status."""
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    procs = []
+    for r in range(args.gpus):
+        env = dict(os.environ)
+        env.update(RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), LOCAL_WORLD_SIZE=str(args.gpus),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
+    out0, _ = procs[0].communicate()
+    rc = procs[0].returncode
+    for p in procs[1:]:
+        p.wait()
+        rc = rc or p.returncode
+    sys.stdout.write(out0.decode(errors="replace"))
+    sys.stdout.flush()
+    if rc:
+        sys.stderr.write("bench.py: a rank exited with status %d (%d GPUs requested)\n" % (rc, args.gpus))
+    return 1 if rc else 0
+
+
+class Ctx:
+    """Per-process state shared by the legs: torch, numpy, device, rank layout."""
+
+
+def measure(cx, args, *, steps, warmup, single_end=False, ont=False, hit_frac=0.0, n_rate=0.0, pairs=None,
+            keep=False):
+    """Builds the synthetic table and batches in this GPU's HBM and times `steps` launches.  Returns a
+    dict with the numbers of one bench line; with keep=True also the live objects (engine, batches)."""
+    torch, dist, np = cx.torch, cx.dist, cx.np
     from nohuman_amd import Engine
-
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if args.gpus > 1 and world != args.gpus:
-        raise SystemExit("launch with torch.distributed.run --nproc-per-node %d" % args.gpus)
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
-    if world > 1:
-        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=dev)
-
-    paired = not (args.single_end or args.ont)
+    dev = cx.dev
+    paired = not (single_end or ont)
     mates = 2 if paired else 1
-    n_frag = args.pairs
+    n_frag = pairs if pairs is not None else args.pairs
     L = args.read_len
 
     # ---- database: synthetic HPRC.r2-like table built directly in this GPU's HBM -------------
     n_keys = int(args.capacity * args.load)
-    if args.hit_frac > 0:  # leave room for the minimizers of the "human" reads: final load = --load
-        n_keys = max(1, n_keys - int(args.hit_frac * args.pairs * (1 if (args.single_end or args.ont) else 2)
-                                     * 39.0 * args.read_len / 150.0 * args.pool))
+    if hit_frac > 0:  # leave room for the minimizers of the "human" reads: final load = --load
+        n_keys = max(1, n_keys - int(hit_frac * n_frag * mates * 39.0 * L / 150.0 * args.pool))
     t0 = time.time()
-    eng = Engine.synthetic(args.capacity, n_keys, depth=30, seed=20250101, device=local_rank)
+    eng = Engine.synthetic(args.capacity, n_keys, depth=30, seed=20250101, device=cx.local_rank)
     t_db = time.time() - t0
 
     # ---- synthetic batches resident in HBM (iid uniform ACGT; SURVEY.md section 8d) -----------
     acgt = torch.tensor([65, 67, 71, 84], dtype=torch.uint8, device=dev)
     n_seq = n_frag * mates
-    if args.ont:
+    if ont:
         g0 = torch.Generator(device=dev)
         g0.manual_seed(4)
         lens = torch.exp(torch.randn(n_seq, generator=g0, device=dev, dtype=torch.float64) * 0.85 + 8.8)
@@ -100,15 +136,15 @@ def main():
     pool = []
     for b in range(args.pool):
         g = torch.Generator(device=dev)
-        g.manual_seed(1000 * (rank + 1) + b)
+        g.manual_seed(1000 * (cx.rank + 1) + b)
         idx = torch.randint(0, 4, (total_bases + 64,), generator=g, device=dev, dtype=torch.int64)
         bases = acgt[idx].contiguous()
         del idx
-        if args.n_rate > 0:
-            m = torch.rand(bases.shape, generator=g, device=dev) < args.n_rate
+        if n_rate > 0:
+            m = torch.rand(bases.shape, generator=g, device=dev) < n_rate
             bases[m] = 78
-        if args.hit_frac > 0:
-            n_hit_seq = int(args.hit_frac * n_frag) * mates
+        if hit_frac > 0:
+            n_hit_seq = int(hit_frac * n_frag) * mates
             if n_hit_seq:
                 eng.add_sequences(bases.data_ptr(), offsets.data_ptr(), n_hit_seq, 30)
                 hit_end = int(offsets[n_hit_seq].item())
@@ -124,13 +160,13 @@ def main():
     def step(i):
         eng.classify_device(pool[i % len(pool)].data_ptr(), offsets.data_ptr(), n_frag, paired,
                             args.confidence, results.data_ptr(), counters.data_ptr(),
-                            stream.cuda_stream, long_reads=args.ont)
+                            stream.cuda_stream, long_reads=ont)
 
     def barrier():
-        if world > 1:
+        if cx.world > 1:
             dist.barrier()
 
-    for i in range(args.warmup):
+    for i in range(warmup):
         step(i)
     torch.cuda.synchronize()
     counters.zero_()
@@ -140,132 +176,225 @@ def main():
     ev1 = torch.cuda.Event(enable_timing=True)
     t_start = time.perf_counter()
     ev0.record(stream)
-    for i in range(args.steps):
-        step(args.warmup + i)
+    for i in range(steps):
+        step(warmup + i)
     ev1.record(stream)
     torch.cuda.synchronize()
     barrier()
     elapsed = time.perf_counter() - t_start
-    kernel_ms = ev0.elapsed_time(ev1) / max(args.steps, 1)
+    kernel_ms = ev0.elapsed_time(ev1) / max(steps, 1)
 
     # ---- totals: the one collective of the path (classified-count all-reduce) ------------------
-    from nohuman_amd.dist import reduce_counters
+    from nohuman_amd.dist import gather_floats, reduce_counters
     (frags, classified, nbases, lookups), elapsed_max = reduce_counters(counters, elapsed)
+    rank_kernel_ms = gather_floats(kernel_ms, dev)
     reads_total = frags * mates
     value = reads_total / elapsed_max / 1e6
 
     # per-launch algorithmic bytes on this rank
     c = [int(x) for x in counters.tolist()]
-    alg_bytes_launch = (c[2] + 64 * c[3] + 16 * c[0]) / max(args.steps, 1)
+    alg_bytes_launch = (c[2] + 64 * c[3] + 16 * c[0]) / max(steps, 1)
     achieved = alg_bytes_launch / (kernel_ms * 1e-3) / 1e9 if kernel_ms > 0 else 0.0
-
-    out = {
-        "metric": "Mreads/sec classified (HPRC.r2 DB, 150bp PE)" if not args.ont else "Mreads/sec classified (ONT)",
+    variant = bool(ont or hit_frac or n_rate)
+    m = {
         "value": round(value, 3),
-        "unit": "Mreads/s",
-        "n_gpus": world,
-        "steps": args.steps,
-        "warmup": args.warmup,
-        "ms_per_step": round(elapsed_max / max(args.steps, 1) * 1e3, 4),
-        "higher_is_better": True,
-        "scaling": "weak",
-        "vs_baseline": None,
-        "dtype": "u64",
-        "data": "synthetic",
-        "config": {
-            "workload": (("ONT-like long reads (lognormal, %d bases per step), " % total_bases if args.ont else "")
-                         + ("hit fraction %.2f, " % args.hit_frac if args.hit_frac else "") +
-                         "%d x %d bp %s reads per step per GPU, iid uniform ACGT, resident in HBM; "
-                         "synthetic HPRC.r2-like hash table (capacity %d cells = %.2f GB, load %.2f, "
-                         "k=%d l=%d) replicated per GPU; confidence %g"
-                         % (n_frag * mates, L, "paired-end" if paired else "single-end",
-                            info.capacity, info.capacity * 4 / 1e9, info.size / info.capacity,
-                            info.k, info.l, args.confidence)),
-            "fragments_per_step": n_frag,
-            "paired": paired,
-            "parallelism": "reads sharded over %d GPU(s), DB replicated" % world,
-            "classified_fraction": classified / max(frags, 1),
-            "lookups_per_read": lookups / max(reads_total, 1),
-            "db_build_seconds": round(t_db, 2),
-        },
+        "ms_per_step": round(elapsed_max / max(steps, 1) * 1e3, 4),
+        "workload": (("ONT-like long reads (lognormal, %d bases per step), " % total_bases if ont else "")
+                     + ("hit fraction %.2f, " % hit_frac if hit_frac else "") +
+                     "%d x %d bp %s reads per step per GPU, iid uniform ACGT, resident in HBM; "
+                     "synthetic HPRC.r2-like hash table (capacity %d cells = %.2f GB, load %.2f, "
+                     "k=%d l=%d) replicated per GPU; confidence %g"
+                     % (n_frag * mates, L, "paired-end" if paired else "single-end",
+                        info.capacity, info.capacity * 4 / 1e9, info.size / info.capacity,
+                        info.k, info.l, args.confidence)),
+        "fragments_per_step": n_frag,
+        "paired": paired,
+        "classified_fraction": classified / max(frags, 1),
+        "lookups_per_read": lookups / max(reads_total, 1),
+        "db_build_seconds": round(t_db, 2),
         "roofline": {
             "bound": "hbm",
             "achieved": round(achieved, 2),
             "peak": HBM_PEAK_GBS,
             "unit": "GB/s",
             "frac": round(achieved / HBM_PEAK_GBS, 4),
-            "traffic": measured_traffic(n_frag, paired, L, info.capacity, bool(args.ont or args.hit_frac or args.n_rate)),
-            # informative: the limit this gather-bound kernel actually runs into is the fabric's random
-            # request rate (profiles/traffic.json), not bytes: requests per launch / kernel time vs ceiling
-            "fabric_request_frac": request_rate_frac(n_frag, paired, L, info.capacity, kernel_ms,
-                                                     bool(args.ont or args.hit_frac or args.n_rate)),
+            # PMC counters cannot be collected inside this run (the guide wants them in separate
+            # rocprofv3 passes): these two come from the committed passes on exactly this workload
+            "traffic": static_traffic(n_frag, paired, L, info.capacity, variant, "traffic_bytes_per_launch"),
+            "traffic_source": "profiles/traffic.json (static: rocprofv3 --pmc passes of this workload, "
+                              "not measured in this run)",
+            "fabric_request_frac": request_rate_frac(n_frag, paired, L, info.capacity, kernel_ms, variant),
             "kernel": "k_classify",
             "kernel_ms": round(kernel_ms, 4),
+            "kernel_ms_per_rank": [round(x, 4) for x in rank_kernel_ms],
             "algorithmic_bytes_per_launch": int(alg_bytes_launch),
         },
     }
-
-    # ---- CPU baseline: the oracle on the host cores, bounded sample (rank 0, N=1 only) --------
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        out["cpu_baseline"] = cpu_baseline(eng, pool[0], offsets, mates, paired, args, np, results, step)
-    if rank == 0:
-        print(json.dumps(out), flush=True)
+    live = dict(eng=eng, pool=pool, offsets=offsets, results=results, step=step, mates=mates, paired=paired,
+                n_frag=n_frag)
+    if keep:
+        return m, live
     eng.close()
-    if world > 1:
+    return m, None
+
+
+def main():
+    args = parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(launch_ranks(args))
+
+    import numpy as np
+    import torch  # first: this process must use ONE HIP runtime (torch's bundled copy)
+    import torch.distributed as dist
+
+    import nohuman_amd  # noqa: F401
+
+    cx = Ctx()
+    cx.torch, cx.dist, cx.np = torch, dist, np
+    cx.world = int(os.environ.get("WORLD_SIZE", "1"))
+    cx.rank = int(os.environ.get("RANK", "0"))
+    cx.local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus > 1 and cx.world != args.gpus:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, cx.world))
+    if os.environ.get("NOHUMAN_BENCH_DRYRUN"):
+        # CPU check of the launch plumbing (tests/test_dist.py): rendezvous over gloo, one all-reduce
+        if cx.world > 1:
+            dist.init_process_group("gloo")
+        one = torch.ones(1, dtype=torch.int64)
+        if cx.world > 1:
+            dist.all_reduce(one)
+        if cx.rank == 0:
+            print(json.dumps({"dryrun": True, "n_gpus": cx.world, "ranks_counted": int(one.item()),
+                              "world_size_seen": dist.get_world_size() if cx.world > 1 else 1}), flush=True)
+        if cx.world > 1:
+            dist.destroy_process_group()
+        return
+    if cx.local_rank >= torch.cuda.device_count():
+        raise SystemExit("rank %d: no GPU %d on this node (%d visible)" % (cx.rank, cx.local_rank,
+                                                                           torch.cuda.device_count()))
+    torch.cuda.set_device(cx.local_rank)
+    cx.dev = torch.device("cuda", cx.local_rank)
+    backend = None
+    if cx.world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", device_id=cx.dev)
+        backend = dist.get_backend()
+
+    m, live = measure(cx, args, steps=args.steps, warmup=args.warmup, single_end=args.single_end, ont=args.ont,
+                      hit_frac=args.hit_frac, n_rate=args.n_rate, keep=True)
+    out = {
+        "metric": "Mreads/sec classified (HPRC.r2 DB, 150bp PE)" if not args.ont else "Mreads/sec classified (ONT)",
+        "value": m["value"],
+        "unit": "Mreads/s",
+        "n_gpus": cx.world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": m["ms_per_step"],
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "u64",
+        "data": "synthetic",
+        "config": {
+            "workload": m["workload"],
+            "fragments_per_step": m["fragments_per_step"],
+            "paired": m["paired"],
+            "parallelism": "reads sharded over %d GPU(s), DB replicated" % cx.world,
+            "world_size_seen": dist.get_world_size() if cx.world > 1 else 1,
+            "collective_backend": ("%s (RCCL)" % backend) if backend else "none (single process)",
+            "classified_fraction": m["classified_fraction"],
+            "lookups_per_read": m["lookups_per_read"],
+            "db_build_seconds": m["db_build_seconds"],
+        },
+        "roofline": m["roofline"],
+    }
+    solo = cx.rank == 0 and cx.world == 1
+    # ---- CPU baseline: the oracle on the host cores, bounded sample (rank 0, N=1 only) --------
+    if solo and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(cx, args, live, args.cpu_seconds)
+    # ---- e2e: files in -> files out through nh_run on the same engine (N=1 only) --------------------
+    if solo and not args.no_e2e and not (args.ont or args.single_end):
+        try:
+            out["e2e"] = e2e_leg(cx, args, live["eng"])
+        except Exception as ex:  # the e2e leg must never cost the headline line
+            out["e2e"] = {"error": repr(ex)}
+    live["eng"].close()
+    del live
+    torch.cuda.empty_cache()
+    # ---- variants at reduced step counts: hit path, single-end (N=1 only) --------------------------
+    if solo and not args.no_variants and not (args.ont or args.single_end or args.hit_frac):
+        out["variants"] = {}
+        for name, kw in (("hit_frac_0.5_PE", dict(hit_frac=0.5, pairs=1_000_000)),
+                         ("single_end_config1", dict(single_end=True, pairs=1_000_000))):
+            vm, vlive = measure(cx, args, steps=6, warmup=2, keep=True, **kw)
+            chk = cpu_baseline(cx, args, vlive, 1.5)
+            vlive["eng"].close()
+            del vlive
+            torch.cuda.empty_cache()
+            out["variants"][name] = {
+                "value": vm["value"], "unit": "Mreads/s", "steps": 6, "warmup": 2,
+                "fragments_per_step": vm["fragments_per_step"], "paired": vm["paired"],
+                "classified_fraction": vm["classified_fraction"], "lookups_per_read": vm["lookups_per_read"],
+                "roofline_frac": vm["roofline"]["frac"], "kernel_ms": vm["roofline"]["kernel_ms"],
+                "gpu_equals_oracle_on_sample": chk["gpu_equals_oracle"], "oracle_sample_fragments": chk["fragments"],
+                "workload": vm["workload"],
+            }
+    if cx.rank == 0:
+        print(json.dumps(out), flush=True)
+    if cx.world > 1:
         dist.destroy_process_group()
 
 
-def measured_traffic(n_frag, paired, read_len, capacity, variant=False):
-    """HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/traffic.json), if
-    they were taken on exactly this workload; null otherwise.  bench.py cannot host the counter
-    passes itself: the guide requires them in separate profiler runs."""
-    path = os.path.join(ROOT, "profiles", "traffic.json")
-    try:
-        t = json.load(open(path))
-    except (OSError, ValueError):
-        return None
-    key = {"fragments_per_step": n_frag, "paired": paired, "read_len": read_len, "capacity": capacity}
-    if variant:
-        return None
-    if t.get("workload") != key:
-        return None
-    return t.get("traffic_bytes_per_launch")
-
-
-def request_rate_frac(n_frag, paired, read_len, capacity, kernel_ms, variant=False):
-    """Fabric read requests per second of k_classify (PMC count per launch from profiles/traffic.json over
-    the kernel time measured here) as a fraction of the rate a pure random gather sustains on the chip."""
+def _traffic_record(n_frag, paired, read_len, capacity, variant):
     try:
         t = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
     except (OSError, ValueError):
         return None
     key = {"fragments_per_step": n_frag, "paired": paired, "read_len": read_len, "capacity": capacity}
-    if variant or t.get("workload") != key or not t.get("fabric_read_requests_per_launch") or kernel_ms <= 0:
+    if variant or t.get("workload") != key:
+        return None
+    return t
+
+
+def static_traffic(n_frag, paired, read_len, capacity, variant, field):
+    """HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/traffic.json), if
+    they were taken on exactly this workload; null otherwise.  bench.py cannot host the counter
+    passes itself: the guide requires them in separate profiler runs."""
+    t = _traffic_record(n_frag, paired, read_len, capacity, variant)
+    return t.get(field) if t else None
+
+
+def request_rate_frac(n_frag, paired, read_len, capacity, kernel_ms, variant=False):
+    """Fabric read requests per second of k_classify (PMC count per launch from profiles/traffic.json over
+    the kernel time measured here) as a fraction of the rate a pure random gather sustains on the chip."""
+    t = _traffic_record(n_frag, paired, read_len, capacity, variant)
+    if not t or not t.get("fabric_read_requests_per_launch") or kernel_ms <= 0:
         return None
     return round(t["fabric_read_requests_per_launch"] / (kernel_ms * 1e-3) / t["fabric_request_ceiling_per_s"], 4)
 
 
-def cpu_baseline(eng, bases_dev, offsets_dev, mates, paired, args, np, results, step):
+def cpu_baseline(cx, args, live, budget_s):
     """Times oracle/k2_oracle.c (pthreads, all host cores) on the first fragments of batch 0 with
     the very same table (downloaded from HBM), and checks the GPU results on that sample."""
+    np, torch = cx.np, cx.torch
     from oracle import oracle as orc
     from nohuman_amd.dist import usable_cpu_count
+    eng, mates, paired = live["eng"], live["mates"], live["paired"]
     cores = usable_cpu_count()
     cells = eng.download_table()
     info = eng.info
     odb = orc.OracleDB(eng.opts_image(), eng.taxonomy_image(), cells=cells,
                        header=(info.capacity, info.size, info.key_bits, info.value_bits))
     del cells
-    chunk = 262144
+    chunk = 65536 if budget_s < 5 else 262144
     done = 0
     spent = 0.0
-    n_frag = args.pairs
-    host = None
+    n_frag = live["n_frag"]
     outs = []
-    while done < n_frag and spent < args.cpu_seconds:
+    while done < n_frag and spent < budget_s:
         n = min(chunk, n_frag - done)
-        o = offsets_dev[done * mates:(done + n) * mates + 1].cpu().numpy().astype(np.uint64)
-        host = bases_dev[int(o[0]):int(o[-1])].cpu().numpy()
+        o = live["offsets"][done * mates:(done + n) * mates + 1].cpu().numpy().astype(np.uint64)
+        host = live["pool"][0][int(o[0]):int(o[-1])].cpu().numpy()
         offs = o - o[0]
         t0 = time.perf_counter()
         exp, _ = odb.classify(host, offs, paired, args.confidence, threads=cores)
@@ -274,10 +403,9 @@ def cpu_baseline(eng, bases_dev, offsets_dev, mates, paired, args, np, results, 
         done += n
         chunk = min(chunk * 2, 1 << 20)
     # parity of the GPU results on the sample (the oracle as checker)
-    step(0)
-    import torch
+    live["step"](0)
     torch.cuda.synchronize()
-    got = results[:done].cpu().numpy().view(np.uint32)
+    got = live["results"][:done].cpu().numpy().view(np.uint32)
     exp = np.concatenate(outs)
     ok = (np.array_equal(got[:, 0], exp["call"]) and np.array_equal(got[:, 1], exp["total_kmers"])
           and np.array_equal(got[:, 2], exp["clade_hits"]) and np.array_equal(got[:, 3], exp["hit_groups"]))
@@ -286,10 +414,105 @@ def cpu_baseline(eng, bases_dev, offsets_dev, mates, paired, args, np, results, 
         "unit": "Mreads/s",
         "cores": cores,
         "kind": "port",
+        "gpu_equals_oracle": bool(ok),
+        "fragments": done,
         "sample": "first %d fragments (%d reads) of batch 0, same table; oracle/k2_oracle.c on %d "
                   "pthreads (kraken2 binary not on the box); GPU==oracle on sample: %s"
                   % (done, done * mates, cores, ok),
     }
+
+
+def e2e_leg(cx, args, eng):
+    """nh_run_engine on gzip FASTQ pairs: first byte read -> last byte written, database load excluded
+    (as kraken2's own timer).  Inputs: `e2e_reps` gzip members of `e2e_pairs` synthetic pairs each per
+    mate file (level 6, written by the library's own block-parallel encoder), in tmpfs."""
+    import shutil
+    import tempfile
+    np, torch = cx.np, cx.torch
+    from nohuman_amd import _lib
+    from nohuman_amd.dist import usable_cpu_count
+    threads = min(16, usable_cpu_count())
+    n, L, reps = args.e2e_pairs, args.read_len, args.e2e_reps
+    base = "/dev/shm" if os.path.isdir("/dev/shm") and os.access("/dev/shm", os.W_OK) else None
+    tmp = tempfile.mkdtemp(prefix="nh_bench_e2e_", dir=base)
+    try:
+        dev = cx.dev
+        acgt = torch.tensor([65, 67, 71, 84], dtype=torch.uint8, device=dev)
+        t0 = time.time()
+        files = []
+        for tag in (1, 2):
+            g = torch.Generator(device=dev)
+            g.manual_seed(300 + tag)
+            hdr = ("@syn.000000000/%d\n" % tag).encode()
+            reclen = len(hdr) + L + 3 + L + 1
+            rec = torch.empty((n, reclen), dtype=torch.uint8, device=dev)
+            rec[:, :len(hdr)] = torch.tensor(list(hdr), dtype=torch.uint8, device=dev)
+            idx = torch.arange(n, device=dev, dtype=torch.int64)
+            for d in range(9):  # decimal digits of the record number, fixed width
+                rec[:, 5 + 8 - d] = (48 + (idx // (10 ** d)) % 10).to(torch.uint8)
+            p = len(hdr)
+            rec[:, p:p + L] = acgt[torch.randint(0, 4, (n, L), generator=g, device=dev)]
+            rec[:, p + L:p + L + 3] = torch.tensor(list(b"\n+\n"), dtype=torch.uint8, device=dev)
+            rec[:, p + L + 3:p + 2 * L + 3] = 73  # 'I'
+            rec[:, p + 2 * L + 3] = 10
+            path = os.path.join(tmp, "r_%d.fq" % tag)
+            rec.cpu().numpy().tofile(path)
+            del rec, idx
+            rc = _lib.lib().nh_compress_file(os.fsencode(path), os.fsencode(path + ".1.gz"), 2, threads)
+            if rc != 0:
+                raise RuntimeError("nh_compress_file failed")
+            os.remove(path)
+            member = open(path + ".1.gz", "rb").read()
+            with open(path + ".gz", "wb") as f:
+                for _ in range(reps):
+                    f.write(member)
+            os.remove(path + ".1.gz")
+            files.append(path + ".gz")
+        t_setup = time.time() - t0
+        o1, o2 = os.path.join(tmp, "o_1.fq"), os.path.join(tmp, "o_2.fq")
+        best = None
+        trace = ""
+        for _ in range(2):  # first run warms the buffers (pinned allocations, page cache of the outputs)
+            for p in (o1, o2):
+                if os.path.exists(p):
+                    os.remove(p)
+            tr_path = os.path.join(tmp, "trace.txt")
+            saved = os.dup(2)
+            fd = os.open(tr_path, os.O_WRONLY | os.O_CREAT | os.O_TRUNC, 0o600)
+            os.environ["NOHUMAN_TRACE"] = "1"
+            try:
+                os.dup2(fd, 2)
+                t = time.perf_counter()
+                st = eng.run(files[0], o1, in2=files[1], out2=o2, threads=threads)
+                dt = time.perf_counter() - t
+            finally:
+                os.dup2(saved, 2)
+                os.close(saved)
+                os.close(fd)
+                os.environ.pop("NOHUMAN_TRACE", None)
+            if best is None or dt < best[0]:
+                best = (dt, st.total_sequences, st.classified)
+                trace = open(tr_path).read().strip()
+        dt, nfr, ncl = best
+        expect = 2 * (nfr - ncl) * (len(b"@syn.000000000/1\n") + 2 * L + 4)
+        written = os.path.getsize(o1) + os.path.getsize(o2)
+        return {
+            "workload": "%d pairs of %d bp = 2 gzip FASTQ files of %d members x %d pairs (level 6, %.2f GB "
+                        "compressed, %.2f GB of text), every read kept and written back uncompressed; "
+                        "configs[2] shape at %.0f %% scale" % (nfr, L, reps, n, sum(os.path.getsize(f) for f in files) / 1e9,
+                                                               expect / 1e9, 100.0 * nfr / 50e6),
+            "value": round(2 * nfr / dt / 1e6, 3),
+            "unit": "Mreads/s",
+            "wall_s": round(dt, 4),
+            "host_threads": threads,
+            "fragments": int(nfr),
+            "classified": int(ncl),
+            "output_bytes_ok": bool(written == expect and nfr == n * reps),
+            "stages": trace,
+            "setup_seconds": round(t_setup, 1),
+        }
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
 
 
 if __name__ == "__main__":

@@ -335,8 +335,25 @@ __device__ __forceinline__ uint32_t scan_tile(KArgsP ap, WaveLdsT<STD> &S, const
             last0 = S.cand[qi0 + W];
             last1 = S.cand[qi1 + W];
         }
-        const uint64_t m0 = umin64(first, mid);
-        const uint64_t m1 = (!STD && W == 0) ? last1 : umin64(mid, last1);
+        uint64_t m0 = umin64(first, mid);
+        uint64_t m1 = (!STD && W == 0) ? last1 : umin64(mid, last1);
+        if (!STD && has_amb && W > L) {
+            // kraken2's scanner empties its queue at an ambiguous base, so a k-mer's window holds only
+            // the l-mers that lie wholly after the last ambiguous base.  While k-l <= l
+            // every l-mer of the window before that base contains it (is +inf) and the plain min is
+            // the same thing; beyond that, walk back from the last l-mer and stop at the first dead one.
+            uint64_t a0 = NH_FULL, a1 = NH_FULL;
+            bool open0 = true, open1 = true;
+            for (uint32_t i = W + 1; i-- > 0;) {
+                const uint64_t c0 = S.cand[qi0 + i], c1 = S.cand[qi1 + i];
+                open0 &= c0 != NH_FULL;
+                open1 &= c1 != NH_FULL;
+                if (open0) a0 = umin64(a0, c0);
+                if (open1) a1 = umin64(a1, c1);
+            }
+            m0 = a0;
+            m1 = a1;
+        }
         v0 = (qi0 < nqt) & (last0 != NH_FULL);
         v1 = (qi1 < nqt) & (last1 != NH_FULL);
         mz0 = m0 ^ TOGGLE;

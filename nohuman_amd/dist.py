@@ -34,6 +34,18 @@ def reduce_counters(counters, elapsed_seconds: float, group=None):
     return [int(x) for x in tot.tolist()], float(tmax.item())
 
 
+def gather_floats(value: float, device=None, group=None):
+    """One float per rank, in rank order (e.g. each rank's kernel time for the bench line)."""
+    import torch
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        return [float(value)]
+    mine = torch.tensor([float(value)], dtype=torch.float64, device=device)
+    out = [torch.zeros_like(mine) for _ in range(dist.get_world_size(group))]
+    dist.all_gather(out, mine, group=group)
+    return [float(t.item()) for t in out]
+
+
 def usable_cpu_count() -> int:
     """Threads the host side may really use: the scheduler affinity capped by the cgroup CPU quota
     (the GPU boxes expose 256 logical CPUs but run under a 16-CPU quota)."""

@@ -64,6 +64,77 @@ def test_counter_all_reduce_world2():
         assert tmax == 2.0  # the slowest rank defines the job time
 
 
+def _shard_worker(rank, world, port, paired, q):
+    """One rank of the N>1 path on CPU: classify this rank's contiguous shard (the oracle stands in
+    for the per-rank GPU engine), then the path's only collective on the real counters."""
+    import numpy as np
+    from oracle import oracle as orc
+    from tests import synth
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    ob, tb, hb, genomes, _ = synth.toy_db()  # DB replicated: every rank builds the same images
+    reads = synth.sample_reads(np.random.default_rng(11), genomes, 1001, paired=paired, len_jitter=30)
+    lo, hi = shard_range(len(reads), rank, world)
+    bases, offs = orc.pack_reads(reads[lo:hi], paired)
+    out, lookups = orc.OracleDB(ob, tb, hb).classify(bases, offs, paired, 0.05)
+    counters = torch.tensor([hi - lo, int((out["call"] != 0).sum()), int(offs[-1]), int(lookups.sum())],
+                            dtype=torch.int64)
+    tot, tmax = reduce_counters(counters, 0.25 * (rank + 1))
+    q.put((rank, lo, hi, out.tobytes(), tot, tmax))
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("paired", [False, True])
+def test_real_shards_reduce_to_unsharded_totals(paired):
+    import numpy as np
+    from oracle import oracle as orc
+    from tests import synth
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_shard_worker, args=(r, 2, port, paired, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = sorted(q.get(timeout=180) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    # the unsharded run
+    ob, tb, hb, genomes, _ = synth.toy_db()
+    reads = synth.sample_reads(np.random.default_rng(11), genomes, 1001, paired=paired, len_jitter=30)
+    bases, offs = orc.pack_reads(reads, paired)
+    out, lookups = orc.OracleDB(ob, tb, hb).classify(bases, offs, paired, 0.05)
+    want = [len(reads), int((out["call"] != 0).sum()), int(offs[-1]), int(lookups.sum())]
+    assert want[1] > 100  # the shards really classify something
+    assert got[0][1] == 0 and got[0][2] == got[1][1] and got[1][2] == len(reads)  # contiguous, in order
+    assert b"".join(g[3] for g in got) == out.tobytes()  # rank-order concatenation == input order
+    for _, _, _, _, tot, tmax in got:
+        assert tot == want and tmax == 0.5
+
+
+def test_bench_self_launch_dry_run():
+    """`python bench.py --gpus N` started directly spawns its own ranks; the
+    dry-run switch swaps the GPU work for one gloo all-reduce so that the plumbing runs on CPU."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, NOHUMAN_BENCH_DRYRUN="1")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2"], env=env,
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    rec = json.loads(lines[0])
+    assert rec["n_gpus"] == 2 and rec["ranks_counted"] == 2 and rec["world_size_seen"] == 2
+
+
 def test_reduce_without_process_group_is_identity():
     tot, tmax = reduce_counters(torch.tensor([1, 2, 3, 4], dtype=torch.int64), 0.5)
     assert tot == [1, 2, 3, 4] and tmax == 0.5

@@ -304,3 +304,25 @@ def test_random_database_geometries(seed):
     _assert_same(got, exp, "seed %d k=%d l=%d %s" % (seed, k, l, kw))
     assert np.array_equal(taxa, etaxa)
     assert st.table_lookups == int(lookups.sum())
+
+
+@pytest.mark.parametrize("k,l", [(19, 8), (35, 15), (31, 10), (72, 8), (40, 19)])
+def test_window_wider_than_lmer_with_ambiguous_bases(k, l):
+    """k - l > l: the (k-l+1)-window of a k-mer reaches l-mers that lie wholly BEFORE an ambiguous base
+    whose own l-mers are long past.  kraken2's scanner cleared its queue at that base, so they must not
+    take part in the minimum (the kernel used a plain min over the window)."""
+    from nohuman_amd import Engine
+    rng = np.random.default_rng(k * 100 + l)
+    ob, tb, hb, genomes, _ = synth.toy_db(seed=k + l, k=k, l=l, spaced_mask=0, capacity=9973)
+    odb = orc.OracleDB(ob, tb, hb)
+    for paired in (False, True):
+        reads = synth.sample_reads(rng, genomes, 500, length=160, paired=paired, len_jitter=60, n_rate=0.02,
+                                   frac_random=0.2)
+        bases, offs = orc.pack_reads(reads, paired)
+        exp, lookups, etaxa, _ = odb.classify(bases, offs, paired, 0.05, want_taxa=True)
+        with Engine.from_images(ob, tb, hb) as eng:
+            got, taxa, _ = eng.classify(bases, offs, paired, 0.05, want_taxa=True)
+            st = eng.stats()
+        _assert_same(got, exp, "k=%d l=%d paired=%s" % (k, l, paired))
+        assert np.array_equal(taxa, etaxa)
+        assert st.table_lookups == int(lookups.sum())

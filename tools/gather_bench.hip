@@ -149,6 +149,54 @@ static void run_mode(const char *name, const uint32_t *d_table, uint64_t n_chunk
     printf("  policy %-12s: %7.2f G probes/s\n", name, (double)waves * 64 * iters / ms / 1e6);
 }
 
+
+// Two probes per lane and round: one 16-B load at a random 64-B sector and a second one `stride`
+// bytes further on (XOR 64 = the other half of the same
+// 128-byte line).  Question: is the ~50 G/s ceiling a rate of 64-B requests, or of
+// 128-byte lines / DRAM rows -- i.e. is a second sector next to the first one (almost) free?
+// MODE 0: second = first ^ 64 (same 128-B line); 1: first + stride; 2: independent random sector.
+template <int MODE>
+__global__ __launch_bounds__(64) void k_pair(const uint32_t *__restrict__ table, uint64_t n_sectors,
+                                             uint64_t stride, int iters, uint32_t *__restrict__ sink) {
+    uint64_t s = mix(((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) * 0x9E3779B97F4A7C15ull + 1);
+    uint32_t acc = 0;
+    const char *base = reinterpret_cast<const char *>(table);
+    for (int it = 0; it < iters; it++) {
+        s = mix(s + 1);
+        const uint64_t a = __umul64hi(s, n_sectors) * 64;
+        uint64_t b;
+        if (MODE == 0) b = a ^ 64;
+        else if (MODE == 1) { b = a + stride; if (b >= n_sectors * 64) b -= n_sectors * 64; }
+        else b = __umul64hi(mix(s ^ 0x5555), n_sectors) * 64;
+        const uint4 v = *reinterpret_cast<const uint4 *>(base + a);
+        const uint4 w = *reinterpret_cast<const uint4 *>(base + b);
+        acc += v.x ^ v.y ^ v.z ^ v.w ^ w.x ^ w.y ^ w.z ^ w.w;
+        s += acc & 1;
+    }
+    if (acc == 0x12345678u) sink[0] = acc;
+}
+
+template <int MODE>
+static void run_pair(const char *name, const uint32_t *d_table, uint64_t bytes, uint64_t stride, uint32_t *d_sink) {
+    const int iters = 256;
+    for (int waves : {4096, 8192, 16384}) {
+        hipEvent_t e0, e1;
+        CK(hipEventCreate(&e0));
+        CK(hipEventCreate(&e1));
+        hipLaunchKernelGGL((k_pair<MODE>), dim3(waves), dim3(64), 0, 0, d_table, bytes / 64, stride, iters, d_sink);
+        CK(hipDeviceSynchronize());
+        CK(hipEventRecord(e0));
+        hipLaunchKernelGGL((k_pair<MODE>), dim3(waves), dim3(64), 0, 0, d_table, bytes / 64, stride, iters, d_sink);
+        CK(hipEventRecord(e1));
+        CK(hipEventSynchronize(e1));
+        float ms = 0;
+        CK(hipEventElapsedTime(&ms, e0, e1));
+        const double pairs = (double)waves * 64 * iters;
+        printf("  pair %-22s waves=%5d: %7.2f G pairs/s = %7.2f G sector requests/s\n", name, waves,
+               pairs / ms / 1e6, 2 * pairs / ms / 1e6);
+    }
+}
+
 static void curve(const uint32_t *d_table, uint64_t n_chunks, uint32_t *d_sink) {
     printf("latency/throughput curve: every lane keeps exactly ONE dependent 16-B probe in flight\n");
     const int iters = 256;
@@ -183,6 +231,18 @@ int main(int argc, char **argv) {
     CK(hipMemset(d_table, 1, bytes));
     uint64_t n_chunks = bytes / 16;
     printf("table %.2f GiB, %d loads per thread\n", gib, iters);
+
+    if (argc > 3 && atoi(argv[3]) == 1) {  // pair study only
+        printf("pair study: two 16-B probes per lane per round (one dependent round in flight per lane)\n");
+        run_pair<2>("random + random", d_table, bytes, 0, d_sink);
+        run_pair<0>("same 128-B line (^64)", d_table, bytes, 0, d_sink);
+        char nm[64];
+        for (uint64_t st : {64ull, 128ull, 256ull, 512ull, 1024ull, 2048ull, 4096ull, 65536ull, 2097152ull}) {
+            snprintf(nm, sizeof nm, "+%llu B", (unsigned long long)st);
+            run_pair<1>(nm, d_table, bytes, st, d_sink);
+        }
+        return 0;
+    }
     {
         long long *d_cyc, cyc = 0;
         CK(hipMalloc((void **)&d_cyc, 8));
