@@ -7,11 +7,16 @@ namespace nh {
 // Everything a classify wave needs to know about the database, passed by value as a kernel
 // argument (lives in SGPRs / the kernarg segment; no global loads for it).
 struct DevDB {
-    const uint32_t *table;  // hash.k2d cells, capacity entries (+ padding to a multiple of 4, +4)
-    // second copy of the same cells placed 32 bytes off the 64-byte grid (== table if there is none):
-    // a lookup whose home cell lies in the second half of a 64-byte sector probes this copy, where the
-    // same cell lies in the first half, so fewer probe runs cross a sector boundary
-    const uint32_t *table_b;
+    const uint32_t *table;  // hash.k2d cells, capacity entries (+ padding to a multiple of 4, +32); 128-byte aligned
+    // The table is resident n_copies times (1, 2 or 4).  Copy j starts copy_stride cells after copy
+    // j-1 and lies 32/n_copies cells (mod 32) further to the LEFT on the 128-byte line grid, so cell i
+    // of copy j sits (i - j * 32/n_copies) mod 32 cells into its line.  A probe round at cell p uses
+    // copy (p mod 32) / (32/n_copies): there p lies in the first 32/n_copies cells of a line and the
+    // run has at least 32 - 32/n_copies + 1 cells before it leaves the line -- the unit the fabric
+    // fetches (profiles/r02_pair_study.txt: the gather ceiling is a rate of 128-byte lines).
+    uint64_t copy_stride;   // cells from one copy to the next
+    uint32_t n_copies;
+    uint32_t copy_shift;    // log2(32 / n_copies): 5, 4 or 3
     uint64_t capacity;
     uint64_t cap_magic;     // floor((2^64 - 1) / capacity): exact `hc % capacity` without a divide
     const uint32_t *parent; // taxonomy: internal parent ids [node_count]

@@ -123,7 +123,9 @@ static void finish_devdb(Engine *e) {
     DevDB &d = e->dev;
     const nh_db_info &i = e->info;
     d.table = e->d_table;
-    d.table_b = e->d_table_b ? e->d_table_b : e->d_table;
+    d.copy_stride = e->copy_stride;
+    d.n_copies = e->n_copies;
+    d.copy_shift = e->n_copies == 4 ? 3u : e->n_copies == 2 ? 4u : 5u;
     d.capacity = i.capacity;
     d.cap_magic = ~0ull / i.capacity;
     d.parent = e->d_parent;
@@ -150,20 +152,41 @@ void finish_devdb_public(Engine *e) { finish_devdb(e); }
 static int alloc_table(Engine *e, uint64_t capacity) {
     // padded so that 16-byte chunk loads at the end of the table stay in bounds
     e->table_cells_alloc = ((capacity + 3) & ~3ull) + 32;
-    HIP_TRY(hipMalloc((void **)&e->d_table, e->table_cells_alloc * sizeof(uint32_t)));
-    // Second copy, 32 bytes off the 64-byte grid (DevDB::table_b): the kernel runs at ~90 % of the
-    // fabric's request rate, and a probe run that starts in the first half of its 64-byte sector
-    // crosses into the next sector less often (-11 % requests per lookup in the model, +2.4 %
-    // measured).  HBM is not the scarce resource here (a 5.7 GB table on a 288 GB device).  Only for
-    // tables with 32-bit cell positions (<= 17 GB; the kernel variant that uses it);
-    // NOHUMAN_SINGLE_TABLE=1 turns it off.
-    if (capacity < 0xFFFFFF00ull && !getenv("NOHUMAN_SINGLE_TABLE")) {
-        if (hipMalloc(&e->d_table_b_raw, e->table_cells_alloc * sizeof(uint32_t) + 512) == hipSuccess)
-            e->d_table_b = (uint32_t *)((uint8_t *)e->d_table_b_raw + 256 + 32);
-        else
-            (void)hipGetLastError();  // not enough memory: one copy works as well
+    // Staggered copies (DevDB::copy_stride): the gather ceiling of the chip is a rate of 128-byte lines,
+    // and a probe run that starts in the first half of its line leaves it 3.5x less often than one
+    // that starts anywhere (tools/probe_cost_model.py: 1.158 -> 1.045 lines per lookup at load 0.7).  HBM is not the scarce resource here (4 x 5.7 GB on a 288 GB device).  Only for tables with
+    // 32-bit cell positions (the kernel variant that uses them); NOHUMAN_TABLE_COPIES=1|2|4.
+    uint32_t want = 2;  // 4 measured the same as 2 (profiles/r02_tuning.txt): not worth another 11 GB
+    if (const char *env = getenv("NOHUMAN_TABLE_COPIES")) {
+        const int v = atoi(env);
+        want = v >= 4 ? 4u : v >= 2 ? 2u : 1u;
     }
-    e->table_b_dirty = true;
+    if (capacity >= 0xFFFFFF00ull) want = 1;
+    for (;; want >>= 1) {
+        const uint64_t sh = 32 / want;
+        const uint64_t stride = ((e->table_cells_alloc + 32 + 31) & ~31ull) - (want > 1 ? sh : 0);
+        const size_t bytes = (size_t)(stride * want + 64) * sizeof(uint32_t) + 256;
+        if (hipMalloc(&e->d_table_raw, bytes) == hipSuccess) {
+            e->d_table = (uint32_t *)(((uintptr_t)e->d_table_raw + 127) & ~(uintptr_t)127);
+            e->n_copies = want;
+            e->copy_stride = stride;
+            return NH_OK;
+        }
+        (void)hipGetLastError();
+        if (want == 1) return set_error(NH_EOOM, "cannot allocate the hash table (%zu bytes)", bytes);
+    }
+}
+
+// Copies 1.. are refreshed from copy 0 whenever its cells changed (load, synthetic inserts).  Done at
+// that time, after a device-wide sync, never lazily in the launch path: launches come in on several
+// streams and host threads at once.
+int refresh_table_copies(Engine *e) {
+    HIP_TRY(hipSetDevice(e->device));
+    HIP_TRY(hipDeviceSynchronize());
+    for (uint32_t j = 1; j < e->n_copies; j++)
+        HIP_TRY(hipMemcpyAsync(e->d_table + j * e->copy_stride, e->d_table, e->table_cells_alloc * sizeof(uint32_t),
+                               hipMemcpyDeviceToDevice, e->stream));
+    HIP_TRY(hipStreamSynchronize(e->stream));
     return NH_OK;
 }
 
@@ -200,8 +223,7 @@ static int upload_taxonomy(Engine *e) {
 void destroy(Engine *e) {
     if (!e) return;
     if (e->device >= 0) (void)hipSetDevice(e->device);
-    if (e->d_table) (void)hipFree(e->d_table);
-    if (e->d_table_b_raw) (void)hipFree(e->d_table_b_raw);
+    if (e->d_table_raw) (void)hipFree(e->d_table_raw);
     if (e->d_parent) (void)hipFree(e->d_parent);
     if (e->d_counters) (void)hipFree(e->d_counters);
     if (e->d_error) (void)hipFree(e->d_error);
@@ -244,6 +266,7 @@ int open_images(const void *opts, size_t opts_len, const void *taxo, size_t taxo
         }
     }
     if (!rc) rc = upload_taxonomy(e);
+    if (!rc) rc = refresh_table_copies(e);
     if (rc) {
         destroy(e);
         return rc;
@@ -365,6 +388,7 @@ int open_dir(const char *db_dir, int device, Engine **out) {
     }
     if (f) fclose(f);
     if (!rc) rc = upload_taxonomy(e);
+    if (!rc) rc = refresh_table_copies(e);
     if (rc) {
         destroy(e);
         return rc;
@@ -443,6 +467,7 @@ int open_synthetic(uint64_t capacity, uint64_t n_keys, uint32_t depth, uint64_t 
         if (he != hipSuccess) rc = set_error(NH_EDEVICE, "synthetic table: %s", hipGetErrorString(he));
         e->info.size = sz;
     }
+    if (!rc) rc = refresh_table_copies(e);
     if (rc) {
         destroy(e);
         return rc;
@@ -508,17 +533,13 @@ int classify_device(Engine *e, const void *d_bases, const void *d_seq_off, uint6
     if ((d_kmer_taxa != nullptr) != (d_kmer_taxa_off != nullptr))
         return set_error(NH_EINVAL, "kmer_taxa and kmer_taxa_offsets go together");
     if (((uintptr_t)d_bases & 3) != 0) return set_error(NH_EINVAL, "d_bases must be 4-byte aligned");
-    finish_devdb(e);
-    if (e->d_table_b && e->table_b_dirty) {
-        // The table changed since the copy was made (load, inserts).  The copy is waited for here:
-        // the next launch may come on another stream and must not read a half-written copy.
-        hipError_t ce = hipMemcpyAsync(e->d_table_b, e->d_table, e->table_cells_alloc * sizeof(uint32_t),
-                                       hipMemcpyDeviceToDevice, stream);
-        if (ce == hipSuccess) ce = hipStreamSynchronize(stream);
-        if (ce != hipSuccess) return set_error(NH_EDEVICE, "table copy: %s", hipGetErrorString(ce));
-        e->table_b_dirty = false;
+    DevDB db;
+    {   // options may be set from another thread: build this launch's parameter block under the lock
+        std::lock_guard<std::mutex> lock(e->db_mu);
+        finish_devdb(e);
+        db = e->dev;
     }
-    hipError_t he = launch_classify(e->dev, d_bases, d_seq_off, n_frag,
+    hipError_t he = launch_classify(db, d_bases, d_seq_off, n_frag,
                                     (flags & NH_FLAG_PAIRED) ? 2 : 1, confidence, d_results,
                                     d_kmer_taxa, d_kmer_taxa_off, d_counters, e->d_error + LAUNCH_SLOTS, e->d_error + slot,
                                     e->d_work + slot,
@@ -681,6 +702,7 @@ int nh_options_get(const nh_engine *e, nh_options *o) {
 }
 int nh_options_set(nh_engine *e, const nh_options *o) {
     if (!e || !o) return set_error(NH_EINVAL, "null argument");
+    std::lock_guard<std::mutex> lock(((Engine *)e)->db_mu);
     ((Engine *)e)->options = *o;
     return NH_OK;
 }
@@ -762,8 +784,7 @@ int nh_synthetic_add_sequences(nh_engine *e_, const void *d_bases, const void *d
         return set_error(NH_EDEVICE, "insert sequences (default k=35/l=31 linear-probing DBs only): %s",
                          hipGetErrorString(he));
     e->info.size += ins;
-    e->table_b_dirty = true;
-    return NH_OK;
+    return refresh_table_copies(e);
 }
 
 int nh_stats_get(nh_engine *e_, nh_stats *s) {

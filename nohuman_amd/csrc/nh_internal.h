@@ -30,11 +30,11 @@ struct Engine {
     nh_db_info info{};
     nh_options options{};
     DevDB dev{};
-    uint32_t *d_table = nullptr;
-    void *d_table_b_raw = nullptr;  // second, 32-byte shifted copy of the table (see DevDB::table_b)
-    uint32_t *d_table_b = nullptr;
-    bool table_b_dirty = true;
-    uint64_t table_cells_alloc = 0;
+    void *d_table_raw = nullptr;    // one allocation: n_copies staggered copies of the table (DevDB::copy_stride)
+    uint32_t *d_table = nullptr;    // copy 0, 128-byte aligned
+    uint32_t n_copies = 1;
+    uint64_t copy_stride = 0;       // cells
+    uint64_t table_cells_alloc = 0; // cells of one copy incl. padding
     uint32_t *d_parent = nullptr;
     uint64_t *d_counters = nullptr;
     int *d_error = nullptr;
@@ -46,6 +46,7 @@ struct Engine {
     std::vector<uint8_t> taxo_image, opts_image;
     Staging st;
     std::mutex mu;
+    std::mutex db_mu;  // options / DevDB parameter block (set from one thread, read by launches on others)
     double seconds = 0;
 };
 
@@ -72,6 +73,7 @@ int open_synthetic(uint64_t capacity, uint64_t n_keys, uint32_t depth, uint64_t 
                    Engine **out);
 void destroy(Engine *e);
 void finish_devdb_public(Engine *e);
+int refresh_table_copies(Engine *e);  // after the cells of copy 0 changed (load, inserts): device-wide sync + re-copy
 int resolve_db_dir(const char *db_dir, std::string &resolved);
 int classify_device(Engine *e, const void *d_bases, const void *d_seq_off, uint64_t n_frag,
                     uint32_t flags, double confidence, void *d_results, void *d_kmer_taxa,

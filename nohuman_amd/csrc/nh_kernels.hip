@@ -33,12 +33,6 @@
 namespace nh {
 
 #define NH_FULL 0xFFFFFFFFFFFFFFFFull
-#ifndef NH_PROBE_CHUNKS
-#define NH_PROBE_CHUNKS 1
-#endif
-#ifndef NH_LINE_CELLS
-#define NH_LINE_CELLS 32  // a probe round never crosses a boundary of this many cells (32 = 128-byte line)
-#endif
 #ifndef NH_WIDE_CELLS
 #define NH_WIDE_CELLS 16  // cells per round of an old lookup (8, 12 or 16)
 #endif
@@ -51,13 +45,13 @@ namespace nh {
 template <bool STD> struct CandPad { static constexpr int value = STD ? 6 : 66; };
 
 #ifndef NH_MIN_WAVES
-#define NH_MIN_WAVES 4
+#define NH_MIN_WAVES 5  // waves per SIMD the hot variant is built for (LDS: 5 workgroups of 31.5 KB per CU)
 #endif
 #ifndef NH_NSLOT
 #define NH_NSLOT 4
 #endif
 #ifndef NH_QCAP
-#define NH_QCAP 320
+#define NH_QCAP 288  // 5 waves per SIMD with groups of 4 tiles: +6 % over 4 waves / 320 entries (profiles/r02_tuning.txt)
 #endif
 constexpr int NSLOT = NH_NSLOT;  // tiles scanned before one shared probe phase
 constexpr int QCAP = NH_QCAP;  // queue entries per group: a tile joins only if it is sure to fit (< 512)
@@ -430,13 +424,40 @@ __device__ __forceinline__ uint32_t &tax_at(WaveLdsT<STD> &S, uint32_t par, uint
 // group g are only post-processed after that phase), so no wave ever drains a probe tail alone.
 struct LaneLookup {
     uint32_t busy;       // owns an unresolved lookup
-    uint32_t r;          // queue index | parity << 8
+    uint32_t r;          // queue index | parity << 9 | table copy << 10
     uint64_t pos;        // next cell to examine (32 bits used when CAP32)
     uint64_t first_pos;  // double hashing: home cell
     uint64_t step;       // double hashing: stride
     uint32_t ckey;       // compacted key << value_bits
     uint32_t budget;     // rounds left before the whole table was seen
 };
+
+// Which copy of the table a lookup probes (DevDB::copy_stride): the one where its HOME cell lies in the
+// first 2^copy_shift cells of a 128-byte line.  It stays there: later lines are entered at their start.
+__device__ __forceinline__ uint32_t pick_copy(uint32_t home, uint32_t copy_shift) {
+    return (home & 31u) >> copy_shift;  // 0 when there is one copy (copy_shift 5)
+}
+// Where a probe round at cell p32 reads in copy j; in_line = cells from p32 to the end of its line.
+__device__ __forceinline__ const uint32_t *probe_src(const uint32_t *table, uint64_t copy_stride,
+                                                     uint32_t copy_shift, uint32_t j, uint32_t p32,
+                                                     uint32_t &in_line) {
+    in_line = 32u - ((p32 - (j << copy_shift)) & 31u);
+    return table + (uint64_t)j * copy_stride + p32;
+}
+
+// stopping cell among 4 loaded cells: the lowest j >= lo that is empty or holds the key
+__device__ __forceinline__ void scan4(const uint4 &c, uint32_t ckey, uint32_t vmask, uint32_t lo, uint32_t &res,
+                                      uint32_t &resj) {
+    const uint32_t cells[4] = {c.x, c.y, c.z, c.w};
+#pragma unroll
+    for (int j = 3; j >= 0; j--) {
+        const uint32_t cell = cells[j];
+        const uint32_t x = cell ^ ckey;  // key bits vanish on a match
+        const bool stop = ((uint32_t)j >= lo) & ((x <= vmask) | ((cell & vmask) == 0));
+        res = stop ? x : res;
+        resj = stop ? (uint32_t)j : resj;
+    }
+}
 
 // HASH the queue S.q[par][0, qn) and PROBE it: CompactHashTable::Get (A.4) for every entry, result
 // in tax_at(par, r).  Returns when every entry has been handed to a lane AND every lookup of the
@@ -445,6 +466,10 @@ struct LaneLookup {
 //   CAP32 (capacity < 2^32 - 256):  low dword = home cell, high dword = compacted key << value_bits
 //   otherwise:                      home cell << key_bits | compacted key   (<= 63 bits, checked at open)
 // Double hashing keeps the hash code itself.
+// (Tried in round 2 and dropped: issuing the first round of EVERY queue entry from the hash pass, 2.4 loads
+// in flight per lane.  Half the round trips per group, 10 % fewer instructions -- and 16 % slower:
+// on this chip a random gather runs fastest with ONE load in flight per lane and many waves
+// (profiles/r02_pair_study.txt, tools/gather_bench: deep per-wave queues lower the line rate).)
 template <bool LINEAR, bool STD, bool CAP32, bool PROF>
 __device__ __forceinline__ void probe_queue(KArgsP ap, WaveLdsT<STD> &S, const int lane,
                                             const uint32_t par,
@@ -460,161 +485,133 @@ __device__ __forceinline__ void probe_queue(KArgsP ap, WaveLdsT<STD> &S, const i
     const uint64_t magic = ap->db.cap_magic;
     const uint32_t max_rounds = ap->db.max_chunks;
     const uint32_t *const table = ap->db.table;
-    const uint32_t *const table_b = ap->db.table_b;
-    const bool two_copies = table_b != table;
+    const uint64_t copy_stride = ap->db.copy_stride;
+    const uint32_t copy_shift = ap->db.copy_shift;
 
-    // ---- 6a. dense hash pass ----------------------------------------------------------------------
-    for (uint32_t r0 = 0; r0 < qn; r0 += 64) {
-        const uint32_t r = r0 + lane;
-        const bool act = r < qn;
-        const uint64_t hc = fmix64(S.q[par][act ? r : 0u]);
-        const bool look = act & !(MIN_HASH != 0 && hc < MIN_HASH);
-        uint64_t e = hc;
-        if (LINEAR) {
-            const uint64_t home = mod_capacity(hc, cap, magic);
-            const uint32_t compacted = (uint32_t)(hc >> (32 + vbits));
-            e = CAP32 ? (((uint64_t)(compacted << vbits) << 32) | (uint32_t)home)
-                      : ((home << kbits) | compacted);
+    uint32_t qhead = 0;  // next queue entry to hand out (uniform)
+    const uint32_t qend = qn;
+    {
+        // ---- 6a. dense hash pass ------------------------------------------------------------------
+        for (uint32_t r0 = 0; r0 < qn; r0 += 64) {
+            const uint32_t r = r0 + lane;
+            const bool act = r < qn;
+            const uint64_t hc = fmix64(S.q[par][act ? r : 0u]);
+            const bool look = act & !(MIN_HASH != 0 && hc < MIN_HASH);
+            uint64_t e = hc;
+            if (LINEAR) {
+                const uint64_t home = mod_capacity(hc, cap, magic);
+                const uint32_t compacted = (uint32_t)(hc >> (32 + vbits));
+                e = CAP32 ? (((uint64_t)(compacted << vbits) << 32) | (uint32_t)home)
+                          : ((home << kbits) | compacted);
+            }
+            if (act) {
+                S.q[par][r] = e;
+                if constexpr (!STD) S.qtax.v[par][r] = look ? 0u : QTAX_SKIP;
+            }
+            const uint32_t nlook = __popcll(__ballot(look));
+            if (lane == 0 && count_lookups) S.acc[CNT_LOOKUPS] += nlook;
         }
-        if (act) {
-            S.q[par][r] = e;
-            if constexpr (!STD) S.qtax.v[par][r] = look ? 0u : QTAX_SKIP;
-        }
-        const uint32_t nlook = __popcll(__ballot(look));
-        if (lane == 0 && count_lookups) S.acc[CNT_LOOKUPS] += nlook;
+        wave_sync();
+        NH_STAMP(4);
     }
-    wave_sync();
-    NH_STAMP(4);
 
     // ---- 6b. probe with lane refill ---------------------------------------------------------------
-    uint32_t qhead = 0;  // next queue entry to hand out (uniform)
     uint32_t busy = lk.busy, r = lk.r, ckey = lk.ckey, budget = lk.budget;
     uint64_t pos = lk.pos, first_pos = lk.first_pos, step = lk.step;
     for (;;) {
-        if (qhead < qn) {
+        if (qhead < qend) {
             const uint64_t idle_mask = __ballot(busy == 0);
             if (idle_mask) {
                 const uint32_t my = qhead + below(idle_mask);
-                if (busy == 0 && my < qn) {
-                    const uint64_t e = S.q[par][my];
-                    bool skip = false;
-                    if constexpr (!STD) {
-                        skip = S.qtax.v[par][my] == QTAX_SKIP;
-                        if (skip) S.qtax.v[par][my] = 0;
-                    }
-                    if (!skip) {
-                        r = my | (par << 9);
-                        budget = max_rounds;
-                        if (LINEAR) {
-                            if (CAP32) {
-                                pos = (uint32_t)e;
-                                ckey = (uint32_t)(e >> 32);
-                                // home in the second half of its sector: use the shifted copy
-                                if (two_copies && ((uint32_t)e & 8u)) r |= 1u << 10;
-                            } else {
-                                pos = e >> kbits;
-                                ckey = (uint32_t)(e & ((1ull << kbits) - 1)) << vbits;
-                            }
-                        } else {
-                            pos = mod_capacity(e, cap, magic);
-                            first_pos = pos;
-                            step = mod_capacity((e >> 8) | 1, cap, magic);
-                            ckey = (uint32_t)(e >> (32 + vbits)) << vbits;
+                if (busy == 0 && my < qend) {
+                    {
+                        const uint64_t e = S.q[par][my];
+                        bool skip = false;
+                        if constexpr (!STD) {
+                            skip = S.qtax.v[par][my] == QTAX_SKIP;
+                            if (skip) S.qtax.v[par][my] = 0;
                         }
-                        busy = 1;
+                        if (!skip) {
+                            r = my | (par << 9);
+                            budget = max_rounds;
+                            if (LINEAR) {
+                                if (CAP32) {
+                                    pos = (uint32_t)e;
+                                    ckey = (uint32_t)(e >> 32);
+                                    r |= pick_copy((uint32_t)e, copy_shift) << 10;
+                                } else {
+                                    pos = e >> kbits;
+                                    ckey = (uint32_t)(e & ((1ull << kbits) - 1)) << vbits;
+                                }
+                            } else {
+                                pos = mod_capacity(e, cap, magic);
+                                first_pos = pos;
+                                step = mod_capacity((e >> 8) | 1, cap, magic);
+                                ckey = (uint32_t)(e >> (32 + vbits)) << vbits;
+                            }
+                            busy = 1;
+                        }
                     }
                 }
                 const uint32_t taken = __popcll(idle_mask);
-                qhead = qhead + taken < qn ? qhead + taken : qn;
+                qhead = qhead + taken < qend ? qhead + taken : qend;
             }
         }
-        // done when the queue is handed out and no lane still works for the previous group
-        if (qhead >= qn && __ballot(busy != 0 && ((r >> 9) & 1u) != par) == 0) break;
+        // done when everything is handed out and no lane still works for the previous group
+        if (qhead >= qend && __ballot(busy != 0 && ((r >> 9) & 1u) != par) == 0) break;
         if (PROF) prof[11] += 1;  // probe rounds executed (not cycles)
         if (busy) {
             if (LINEAR) {
-                // One round: the 4*PC cells from `pos` on (unaligned 16-byte loads), of which only
-                // those before the end of the 128-byte line (the unit HBM delivers) and before the
-                // end of the table count.  All loaded cells are scanned; the first stopping cell
-                // decides, and it only counts if it is one of the nvalid eligible ones.
-                constexpr int PC = NH_PROBE_CHUNKS;
+                // One round: cells from `pos` on (unaligned 16-byte loads), of which only those
+                // before the end of the 128-byte line (the unit HBM delivers) and before the end of
+                // the table count.  All loaded cells are scanned; the first stopping cell decides,
+                // and it only counts if it is one of the nvalid eligible ones.
                 uint32_t nvalid, in_line;
                 const uint32_t *src;
                 if (CAP32) {
                     const uint32_t p32 = (uint32_t)pos;
-                    const bool ub = (r >> 10) & 1u;  // probing the copy that sits 8 cells off the grid
-                    in_line = (uint32_t)NH_LINE_CELLS - ((p32 + (ub ? 8u : 0u)) & (uint32_t)(NH_LINE_CELLS - 1));
+                    src = probe_src(table, copy_stride, copy_shift, (r >> 10) & 3u, p32, in_line);
                     const uint32_t room = (uint32_t)cap - p32;
                     nvalid = in_line < room ? in_line : room;
-                    src = (ub ? table_b : table) + p32;
                 } else {
-                    in_line = (uint32_t)NH_LINE_CELLS - ((uint32_t)pos & (uint32_t)(NH_LINE_CELLS - 1));
+                    in_line = 32u - ((uint32_t)pos & 31u);
                     const uint64_t room = cap - pos;
                     nvalid = room < in_line ? (uint32_t)room : in_line;
                     src = table + pos;
                 }
                 uint32_t res = 0, resj = 64, lo = 0;
-                if constexpr (PC == 1) {
-                    // A lookup's first NH_WIDE_AFTER rounds examine 4 cells with ONE 16-byte load that
-                    // must not leave the line: if fewer than 4 cells remain it starts up to 3 cells
-                    // early and those are skipped (a load across the line end would cost a second
-                    // fabric request for cells that do not count).  Most lookups end there.  An older
-                    // lookup is in a long probe run -- linear probing at load 0.7 is heavy-tailed, and
-                    // the slowest lookup of a group decides when the group can be post-processed -- so
-                    // it examines up to 16 cells (a whole 64-byte sector) per round from then on.
-                    const bool wide = max_rounds - budget >= (uint32_t)NH_WIDE_AFTER;
-                    const uint32_t lim = wide ? (uint32_t)NH_WIDE_CELLS : 4u;
-                    nvalid = nvalid < lim ? nvalid : lim;
-                    lo = (!wide && in_line < 4u) ? 4u - in_line : 0u;
-                    const uint4 c0 = *reinterpret_cast<const uint4 *>(src - lo);
-                    constexpr int WCH = NH_WIDE_CELLS / 4;  // 16-byte chunks of a wide round
-                    uint4 cw[WCH];
-                    if (wide) {  // chunks past the last useful one re-read it (no new line is touched)
-                        const uint32_t last_chunk = (nvalid - 1) >> 2;
-#pragma unroll
-                        for (int q = 1; q < WCH; q++)
-                            cw[q] = *reinterpret_cast<const uint4 *>(src + 4 * (last_chunk < (uint32_t)q ? last_chunk : (uint32_t)q));
-                    }
-                    if (wide) {
-#pragma unroll
-                        for (int j = 4 * WCH - 1; j >= 4; j--) {
-                            const uint4 &cq = cw[j >> 2];
-                            const uint32_t cell = (j & 3) == 0 ? cq.x : (j & 3) == 1 ? cq.y : (j & 3) == 2 ? cq.z : cq.w;
-                            const uint32_t x = cell ^ ckey;
-                            const bool stop = (x <= vmask) | ((cell & vmask) == 0);
-                            res = stop ? x : res;
-                            resj = stop ? (uint32_t)j : resj;
-                        }
-                    }
-                    const uint32_t cells[4] = {c0.x, c0.y, c0.z, c0.w};
-#pragma unroll
-                    for (int j = 3; j >= 0; j--) {  // lowest eligible stopping cell wins
-                        const uint32_t cell = cells[j];
-                        const uint32_t x = cell ^ ckey;  // key bits vanish on a match
-                        const bool stop = ((uint32_t)j >= lo) & ((x <= vmask) | ((cell & vmask) == 0));
-                        res = stop ? x : res;
-                        resj = stop ? (uint32_t)j : resj;
-                    }
-                } else {
-                    nvalid = nvalid < 4u * PC ? nvalid : 4u * PC;
+                // A lookup's first NH_WIDE_AFTER rounds examine 4 cells with ONE 16-byte load that
+                // must not leave the line: if fewer than 4 cells remain it starts up to 3 cells
+                // early and those are skipped (a load across the line end would cost a second
+                // fabric request for cells that do not count).  Most lookups end there.  An older
+                // lookup is in a long probe run -- linear probing at load 0.7 is heavy-tailed, and
+                // the slowest lookup of a group decides when the group can be post-processed -- so
+                // it examines up to 16 cells per round from then on.
+                const bool wide = max_rounds - budget >= (uint32_t)NH_WIDE_AFTER;
+                const uint32_t lim = wide ? (uint32_t)NH_WIDE_CELLS : 4u;
+                nvalid = nvalid < lim ? nvalid : lim;
+                lo = (!wide && in_line < 4u) ? 4u - in_line : 0u;
+                const uint4 c0 = *reinterpret_cast<const uint4 *>(src - lo);
+                constexpr int WCH = NH_WIDE_CELLS / 4;  // 16-byte chunks of a wide round
+                uint4 cw[WCH];
+                if (wide) {  // chunks past the last useful one re-read it (no new line is touched)
                     const uint32_t last_chunk = (nvalid - 1) >> 2;
-                    uint4 c[PC];
 #pragma unroll
-                    for (int qq = 0; qq < PC; qq++) {  // idle slots re-read the last useful chunk
-                        const uint32_t ch = (uint32_t)qq < last_chunk ? (uint32_t)qq : last_chunk;
-                        c[qq] = *reinterpret_cast<const uint4 *>(src + 4 * ch);
-                    }
+                    for (int q = 1; q < WCH; q++)
+                        cw[q] = *reinterpret_cast<const uint4 *>(src + 4 * (last_chunk < (uint32_t)q ? last_chunk : (uint32_t)q));
+                }
+                if (wide) {
 #pragma unroll
-                    for (int j = 4 * PC - 1; j >= 0; j--) {  // lowest stopping cell wins
-                        const uint4 &cq = c[j >> 2];
-                        const uint32_t cell =
-                            (j & 3) == 0 ? cq.x : (j & 3) == 1 ? cq.y : (j & 3) == 2 ? cq.z : cq.w;
-                        const uint32_t x = cell ^ ckey;  // key bits vanish on a match
+                    for (int j = 4 * WCH - 1; j >= 4; j--) {
+                        const uint4 &cq = cw[j >> 2];
+                        const uint32_t cell = (j & 3) == 0 ? cq.x : (j & 3) == 1 ? cq.y : (j & 3) == 2 ? cq.z : cq.w;
+                        const uint32_t x = cell ^ ckey;
                         const bool stop = (x <= vmask) | ((cell & vmask) == 0);
                         res = stop ? x : res;
                         resj = stop ? (uint32_t)j : resj;
                     }
                 }
+                scan4(c0, ckey, vmask, lo, res, resj);
                 // a re-read chunk repeats cells of an earlier one: its stops can only come after
                 // an identical earlier stop, so resj < nvalid is exact
                 const bool found = resj < lo + nvalid;

@@ -125,9 +125,33 @@ class CommandRunner:
                 opts["inputs"].append(a)
         return opts
 
+    def run_stock(self, args) -> None:
+        """The reference's own path, verbatim (src/lib.rs:22-48): spawn `self.command` with the argv,
+        fail on a non-zero exit with its stderr, scrape the three summary integers.  Only taken when
+        NOHUMAN_STOCK_KRAKEN2=1 (BASELINE.json configs[0]; the parity pin against a real kraken2)."""
+        import subprocess
+        from types import SimpleNamespace
+        try:
+            out = subprocess.run([self.command] + [str(a) for a in args], capture_output=True)
+        except OSError as e:  # Command::output()? -> io::Error (e.g. binary not found)
+            raise OSError(str(e)) from e
+        stderr_log = out.stderr.decode("utf-8", errors="replace")
+        if out.returncode != 0:
+            raise OSError("%s failed with stderr %s" % (self.command, stderr_log))
+        log.debug("kraken2 stderr:\n %s", stderr_log)
+        try:
+            total, classified, unclassified = parse_kraken_stderr(stderr_log)
+        except ValueError:  # .unwrap_or((0, 0, 0))
+            total = classified = unclassified = 0
+        self.last_stats = SimpleNamespace(total_sequences=total, classified=classified, unclassified=unclassified)
+        log.info("%d / %d (%s%%) sequences classified as human; %d (%s%%) as non-human",
+                 classified, total, _pct(classified, total), unclassified, _pct(unclassified, total))
+
     def run(self, args) -> None:
         """src/lib.rs:22-48.  Raises OSError("<command> failed with stderr ...") on failure and
         logs the reference's summary line on success."""
+        if os.environ.get("NOHUMAN_STOCK_KRAKEN2") == "1":
+            return self.run_stock(args)
         o = self.parse_argv(args)
         try:
             if o["db"] is None:

@@ -17,3 +17,10 @@ def read_fastq(path):
         recs.append((h, rid, seq, quals))
         i += 4
     return recs
+
+
+def write_fastq(path, records, qual=b"I"):
+    """records: iterable of (id str, sequence bytes); constant qualities."""
+    with open(path, "wb") as f:
+        for rid, seq in records:
+            f.write(b"@" + rid.encode() + b"\n" + seq + b"\n+\n" + qual * len(seq) + b"\n")

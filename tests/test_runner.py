@@ -85,3 +85,38 @@ def test_run_failure_maps_to_reference_error_text(tmp_path):
         r.run(["--db", str(tmp_path), "--unclassified-out", str(tmp_path / "o.fq"),
                str(tmp_path / "missing.fq")])
     assert str(ei.value).startswith("kraken2 failed with stderr ")
+
+
+def _fake_kraken2(tmp_path, body):
+    exe = tmp_path / "kraken2"
+    exe.write_text("#!/bin/sh\n" + body)
+    exe.chmod(0o755)
+    return str(exe)
+
+
+def test_stock_subprocess_path_config0(tmp_path, monkeypatch, caplog):
+    """NOHUMAN_STOCK_KRAKEN2=1: CommandRunner.run is the reference's own spawn-and-scrape path
+    (src/lib.rs:22-48; BASELINE.json configs[0]).  A stand-in script plays kraken2: it must receive the
+    argv verbatim and its stderr summary must come back as the three integers."""
+    import logging
+    args_seen = tmp_path / "argv.txt"
+    exe = _fake_kraken2(tmp_path, 'printf "%%s\\n" "$@" > %s\ncat >&2 <<X\n%sX\n' % (args_seen, STDERR))
+    monkeypatch.setenv("NOHUMAN_STOCK_KRAKEN2", "1")
+    argv = ["--threads", "1", "--db", "/some/db", "--output", "/dev/null", "--confidence", "0",
+            "--unclassified-out", "tmp/kraken_out.fq", "reads.fq"]
+    r = CommandRunner(exe)
+    with caplog.at_level(logging.INFO, logger="nohuman"):
+        r.run(argv)
+    assert args_seen.read_text().split("\n")[:-1] == argv
+    assert (r.last_stats.total_sequences, r.last_stats.classified, r.last_stats.unclassified) == (1000, 250, 750)
+    assert "250 / 1000 (25.00%) sequences classified as human; 750 (75.00%) as non-human" in caplog.text
+
+
+def test_stock_subprocess_failure_text(tmp_path, monkeypatch):
+    exe = _fake_kraken2(tmp_path, 'echo "kraken2: database (\\"/x\\") does not contain necessary file taxo.k2d" >&2\nexit 2\n')
+    monkeypatch.setenv("NOHUMAN_STOCK_KRAKEN2", "1")
+    with pytest.raises(OSError) as ei:
+        CommandRunner(exe).run(["--db", "/x", "r.fq"])
+    assert str(ei.value).startswith(exe + " failed with stderr kraken2: database")
+    with pytest.raises(OSError):  # binary missing: Command::output()? fails
+        CommandRunner(str(tmp_path / "no_such_kraken2")).run([])
