@@ -208,6 +208,16 @@ int nh_compress_file(const char *in, const char *out, int codec, uint32_t thread
  * stats3 (optional) receives {chunks accepted, chunks rejected, bytes decoded in order by the
  * consumer}.  Needs no GPU. */
 int nh_gunzip_file(const char *in, const char *out, uint32_t threads, uint64_t chunk_bytes, uint64_t *stats3);
+/* The one collective of the path: `counters` holds n_devices rows of 4 uint64
+ * {fragments, classified, bases, table_lookups}, row g being the totals of device_ids[g] (NULL =
+ * 0..n_devices-1); on return every row is the sum over the devices -- one ncclAllReduce(4 x uint64, sum)
+ * over RCCL / xGMI, single process, ncclCommInitAll.  nh_run calls it at the end of a multi-device run
+ * (and checks it against the host-side sum, which stays the fallback when RCCL cannot be loaded).
+ * `backend` (optional) receives a one-line description of what ran.  Replaces nothing in the
+ * reference (kraken2 sums its thread-local counters with atomics); it is the multi-GPU form of the
+ * three integers of src/lib.rs:61-97. */
+int nh_allreduce_counters(const int32_t *device_ids, int32_t n_devices, uint64_t *counters, char *backend,
+                          size_t backend_len);
 /* nh_run on an already opened engine (single device) */
 int nh_run_engine(nh_engine *e, const nh_run_args *args, nh_stats *stats);
 

@@ -76,6 +76,8 @@ SYMBOLS = {
                                 C.POINTER(C.c_uint64)]),
     "nh_run": (C.c_int, [C.POINTER(nh_run_args), C.POINTER(nh_stats)]),
     "nh_run_engine": (C.c_int, [_P, C.POINTER(nh_run_args), C.POINTER(nh_stats)]),
+    "nh_allreduce_counters": (C.c_int, [C.POINTER(C.c_int32), C.c_int32, C.POINTER(C.c_uint64), C.c_char_p,
+                                        C.c_size_t]),
 }
 
 

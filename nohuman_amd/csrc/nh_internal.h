@@ -82,6 +82,8 @@ int classify_host(Engine *e, const uint8_t *bases, const uint64_t *seq_offsets, 
                   uint32_t flags, double confidence, nh_result *results, uint32_t *kmer_taxa,
                   uint64_t *kmer_taxa_offsets, uint64_t kmer_taxa_cap);
 int check_error_flag(Engine *e);
+// the path's only collective: rows[g] = counters of device ids[g] -> every row = the sum (RCCL, nh_collective.hip)
+int allreduce_counters(const int *ids, int n_dev, uint64_t *rows, std::string &backend);
 uint64_t kmer_taxa_entries(const Engine *e, const uint64_t *seq_offsets, uint64_t n_frag, int mates,
                            uint64_t *offsets_out);
 

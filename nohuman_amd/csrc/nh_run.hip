@@ -343,6 +343,7 @@ struct RunState {
     bool paired, want_k;
     // results of the run
     uint64_t total = 0, classified = 0, total_bases = 0;
+    std::vector<uint64_t> dev_counts;  // per device {fragments, classified, bases, 0}: input of the all-reduce
     std::vector<uint64_t> call_counts;
     // first error of any thread
     std::mutex err_mu;
@@ -504,6 +505,10 @@ static void format_batch(RunState *rs, const Batch &b, const Slot &s, OutFile &o
     rs->total += b.n;
     rs->classified += classified;
     rs->total_bases += bases;
+    uint64_t *dc = &rs->dev_counts[4 * (size_t)(b.slot / 2)];
+    dc[0] += b.n;
+    dc[1] += classified;
+    dc[2] += bases;
 }
 
 int run_engines(const std::vector<Engine *> &engines, const nh_run_args *a, nh_stats *stats) {
@@ -518,6 +523,7 @@ int run_engines(const std::vector<Engine *> &engines, const nh_run_args *a, nh_s
         return set_error(NH_EINVAL, "Confidence score must be in the closed interval [0, 1]");
     rs.want_k = a->kraken_output && a->kraken_output[0] && strcmp(a->kraken_output, "/dev/null") != 0;
     rs.call_counts.assign(engines[0]->external.size(), 0);
+    rs.dev_counts.assign(4 * engines.size(), 0);
     for (const char *p : {a->in1, a->in2}) {  // fail on unreadable inputs before creating outputs
         if (!p) continue;
         FILE *f = fopen(p, "rb");
@@ -657,8 +663,14 @@ int run_engines(const std::vector<Engine *> &engines, const nh_run_args *a, nh_s
         // batches at the same record count, so only the last batch can differ in length
         b.n = b.h1->recs.size();
         if (rs.paired && b.h2->recs.size() < b.n) b.n = b.h2->recs.size();
-        const bool last = end1 || (rs.paired && end2) ||
-                          (rs.paired && b.h1->recs.size() != b.h2->recs.size());
+        const bool last = end1 || (rs.paired && end2);
+        if (rs.paired && !last && b.h1->recs.size() != b.h2->recs.size()) {
+            // both readers cut at the same record count, so only a byte-limited cut (the 32-bit text
+            // offsets of a batch) can desynchronise them before the end: never drop reads silently
+            rs.fail(NH_EIO, "paired inputs lost step before the end of either file (a batch of one mate "
+                            "file exceeded the 4 GB text limit); lower NOHUMAN_BATCH_FRAGS");
+            break;
+        }
         if (b.n > 0) {
             const int si = (int)(batch_no % (uint64_t)(2 * G));
             Slot &s = slots[si];
@@ -777,6 +789,30 @@ int run_engines(const std::vector<Engine *> &engines, const nh_run_args *a, nh_s
         }
     }
     if (rs.err_code != NH_OK) return set_error(rs.err_code, "%s", rs.err_msg.c_str());
+
+    // The run's only exchange step: one all-reduce of the per-device counters over
+    // RCCL.  The host-side sum the writer kept is the checker, and the fallback when RCCL cannot be
+    // loaded; NOHUMAN_RCCL=0 skips the collective, =1 also runs it for a single device.
+    {
+        const char *env = getenv("NOHUMAN_RCCL");
+        const bool want = env ? env[0] != '0' : G > 1;
+        if (want && (G > 1 || (env && env[0] == '1'))) {
+            std::vector<int> ids;
+            for (Engine *e : engines) ids.push_back(e->device);
+            std::vector<uint64_t> rows(rs.dev_counts);
+            std::string backend;
+            const int crc = allreduce_counters(ids.data(), G, rows.data(), backend);
+            const bool trace = getenv("NOHUMAN_TRACE") != nullptr;
+            if (crc == NH_OK) {
+                for (int g = 0; g < G; g++)
+                    if (rows[4 * g] != rs.total || rows[4 * g + 1] != rs.classified || rows[4 * g + 2] != rs.total_bases)
+                        return set_error(NH_EDEVICE, "count all-reduce disagrees with the host-side sum on device %d", ids[g]);
+                if (trace) fprintf(stderr, "[nohuman trace] counters reduced by %s\n", backend.c_str());
+            } else if (trace) {
+                fprintf(stderr, "[nohuman trace] %s; counters summed on the host\n", g_last_error.c_str());
+            }
+        }
+    }
 
     if (a->report && a->report[0] &&
         (rc = write_report(engines[0], a->report, rs.call_counts, rs.total, rs.total - rs.classified)))

@@ -278,3 +278,28 @@ def test_ultra_long_reads_gzip_fasta_and_fastq(tmp_path, toy, toy_oracle, monkey
             want = b"".join(b">long%d\n%s\n" % (i, reads[i]) for i in kept)
         assert out.read_bytes() == want, name
     assert (exp["call"] != 0).sum() >= 3
+
+
+def test_count_allreduce_over_rccl_single_device(tmp_path, monkeypatch, capfd):
+    """the run's only collective is ONE ncclAllReduce(4 x uint64, sum) over the per-device
+    counters (RCCL, single process, ncclCommInitAll).  On a 1-GPU box the communicator has one rank: the
+    row must come back unchanged, and nh_run with NOHUMAN_RCCL=1 must agree with its host-side sum."""
+    import ctypes as C
+    from nohuman_amd import Engine, _lib
+    L = _lib.lib()
+    rows = (C.c_uint64 * 4)(1001, 250, 150150, 39039)
+    backend = C.create_string_buffer(512)
+    rc = L.nh_allreduce_counters(None, 1, rows, backend, 512)
+    assert rc == 0, backend.value
+    assert list(rows) == [1001, 250, 150150, 39039]
+    assert b"RCCL" in backend.value and b"ncclAllReduce" in backend.value
+    print("collective:", backend.value.decode())
+    # the product path: NOHUMAN_RCCL=1 runs the collective even for one device and checks it
+    monkeypatch.setenv("NOHUMAN_RCCL", "1")
+    monkeypatch.setenv("NOHUMAN_TRACE", "1")
+    _, _, _, calls = _expected("expected_se.json", 0.0)
+    with Engine.open(DB) as eng:
+        st = eng.run(os.path.join(GOLD, "reads_se.fq"), str(tmp_path / "o.fq"))
+    assert st.classified == sum(1 for c in calls if c)
+    err = capfd.readouterr().err
+    assert "counters reduced by RCCL" in err
