@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define NH_ABI_VERSION 1
+#define NH_ABI_VERSION 2
 
 typedef enum {
     NH_OK = 0,
@@ -161,11 +161,20 @@ int nh_classify_batch_device(nh_engine *e, const void *d_bases, const void *d_se
 int nh_stats_get(nh_engine *e, nh_stats *s);
 int nh_stats_reset(nh_engine *e);
 
+/* container of the kept reads (CompressionFormat, /root/reference/src/compression.rs:12-20) */
+typedef enum nh_codec {
+    NH_CODEC_NONE = 0,
+    NH_CODEC_BZIP2 = 1,
+    NH_CODEC_GZIP = 2,
+    NH_CODEC_XZ = 3,
+    NH_CODEC_ZSTD = 4 /* through the system's libzstd.so.1 (level 3, frame checksum, `threads` workers) */
+} nh_codec;
+
 /*
  * Whole-run entry: the information of the argv at src/main.rs:210-267, outputs written
- * UNCOMPRESSED to the given paths exactly where kraken2 would write kraken_out.fq /
+ * UNCOMPRESSED (out_codec 0) to the given paths exactly where kraken2 would write kraken_out.fq /
  * kraken_out_1.fq + kraken_out_2.fq (src/main.rs:252-256,308-309,333), so nohuman's compress stage
- * (src/main.rs:342-368) is untouched.
+ * (src/main.rs:342-368) is untouched -- or, with out_codec set, already in their final container.
  */
 typedef struct {
     const char *db_dir;        /* --db */
@@ -180,6 +189,12 @@ typedef struct {
     int32_t keep_human;        /* 0: --unclassified-out (default), 1: --classified-out (-H) */
     int32_t n_devices;         /* 0 = all visible devices */
     const int32_t *device_ids; /* NULL = 0..n_devices-1 */
+    /* ABI 2 -- SURVEY.md 8f-4: the kept reads can leave the engine already compressed, written straight to
+     * their final paths by a streaming encoder, which removes the temporary uncompressed files and the
+     * second pass of the reference's compress stage (src/compression.rs:182-268, src/main.rs:342-368).
+     * 0 (NH_CODEC_NONE) keeps the kraken2 behaviour: plain text at out1 / out2. */
+    int32_t out_codec;         /* nh_codec of out1 / out2 */
+    uint32_t codec_threads;    /* encoder workers per output file (0 = 1) */
 } nh_run_args;
 
 int nh_run(const nh_run_args *args, nh_stats *stats);
@@ -192,15 +207,9 @@ int nh_fastx_scan(const char *path, uint64_t *n_records, uint64_t *n_bases, uint
  * (/root/reference/src/compression.rs:182-200, called from src/main.rs:342-368).  Compresses file
  * `in` to file `out`; gzip runs block-parallel on `threads` workers like the reference's gzp
  * encoder (compression.rs:214-233) and produces one ordinary gzip member at level 6; bzip2 and xz
- * go through the system tools, zstd through libzstd.so.1; NH_CODEC_NONE copies.  Parity target is the decompressed content and
+ * go through libbz2.so.1 / liblzma.so.5 (one thread / `threads` workers, preset 6, CRC64), zstd through
+ * libzstd.so.1; NH_CODEC_NONE copies.  Parity target is the decompressed content and
  * the container magic (compression.rs:282-288).  Needs no GPU. */
-typedef enum nh_codec {
-    NH_CODEC_NONE = 0,
-    NH_CODEC_BZIP2 = 1,
-    NH_CODEC_GZIP = 2,
-    NH_CODEC_XZ = 3,
-    NH_CODEC_ZSTD = 4 /* through the system's libzstd.so.1 (level 3, frame checksum, `threads` workers) */
-} nh_codec;
 int nh_compress_file(const char *in, const char *out, int codec, uint32_t threads);
 /* Test / tool support for the multi-threaded gzip input decoder nh_run reads .gz inputs with
  * (kraken2's wrapper pipes them through `gzip -dc`): decompress `in` to

@@ -39,7 +39,7 @@ class nh_run_args(C.Structure):
                 ("out1", C.c_char_p), ("out2", C.c_char_p), ("kraken_output", C.c_char_p),
                 ("report", C.c_char_p), ("confidence", C.c_double), ("threads", C.c_uint32),
                 ("keep_human", C.c_int32), ("n_devices", C.c_int32),
-                ("device_ids", C.POINTER(C.c_int32))]
+                ("device_ids", C.POINTER(C.c_int32)), ("out_codec", C.c_int32), ("codec_threads", C.c_uint32)]
 
 
 # every symbol include/nohuman_engine.h declares: name -> (restype, argtypes)

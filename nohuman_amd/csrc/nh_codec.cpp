@@ -2,8 +2,9 @@
 //
 // Mirrors CompressionFormat::compress (/root/reference/src/compression.rs:182-200): gzip with
 // `threads` workers (gzip_compress, compression.rs:214-233, gzp's block-parallel encoder at the
-// default level), bzip2 single-threaded (compression.rs:202-212), xz multi-threaded
-// (compression.rs:235-252).  Parity target is the decompressed content and the container magic
+// default level), bzip2 single-threaded through libbz2 (compression.rs:202-212), xz multi-threaded
+// through liblzma (compression.rs:235-252), zstd through libzstd -- every one a StreamEncoder
+// (nh_codec.h), so that nh_run can feed kept records to it directly.  Parity target is the decompressed content and the container magic
 // (compression.rs:282-288), not byte-identical streams.
 //
 // gzip: the input is cut into 512 KiB blocks; each worker deflates one block as a raw deflate stream
@@ -26,6 +27,7 @@
 #include <thread>
 #include <vector>
 
+#include "nh_codec.h"
 #include "nh_inflate.h"
 #include "nh_internal.h"
 #include "nohuman_engine.h"
@@ -125,85 +127,122 @@ long read_full(int fd, void *p, size_t n) {
     return (long)got;
 }
 
-int gzip_parallel(int fin, int fout, unsigned threads, const char *in_name, const char *out_name) {
-    if (threads < 1) threads = 1;
-    GzShared sh;
-    std::vector<std::thread> pool;
-    for (unsigned i = 0; i < threads; i++) pool.emplace_back(gz_worker, &sh);
-    auto stop = [&] {
+// ---- gzip: block-parallel, streaming ------------------------------------------------------------------
+class GzipEncoder : public StreamEncoder {
+public:
+    GzipEncoder(int fd, unsigned threads, const char *name) : fd_(fd), name_(name) {
+        if (threads < 1) threads = 1;
+        for (unsigned i = 0; i < threads; i++) pool_.emplace_back(gz_worker, &sh_);
+        max_inflight_ = 2 * (size_t)threads + 2;
+        static const unsigned char header[10] = {0x1f, 0x8b, 8, 0, 0, 0, 0, 0, 0, 3};  // no name, no mtime, unix
+        if (!write_all(fd_, header, sizeof header)) rc_ = set_error(NH_EIO, "write error on %s", name_.c_str());
+        crc_ = (uint32_t)crc32(0L, Z_NULL, 0);
+    }
+    ~GzipEncoder() override {
+        while (!inflight_.empty()) retire_head();  // workers still hold pointers
         {
-            std::lock_guard<std::mutex> lk(sh.mu);
-            sh.quit = true;
+            std::lock_guard<std::mutex> lk(sh_.mu);
+            sh_.quit = true;
         }
-        sh.work_cv.notify_all();
-        for (auto &t : pool) t.join();
-    };
-    static const unsigned char header[10] = {0x1f, 0x8b, 8, 0, 0, 0, 0, 0, 0, 3};  // no name, no mtime, unix
-    int rc = NH_OK;
-    if (!write_all(fout, header, sizeof header)) rc = set_error(NH_EIO, "write error on %s", out_name);
-    std::deque<std::unique_ptr<GzJob>> inflight;
-    std::vector<std::unique_ptr<GzJob>> spare;
-    std::vector<unsigned char> dict;
-    uint32_t crc = (uint32_t)crc32(0L, Z_NULL, 0);
-    uint64_t total = 0;
-    const size_t max_inflight = 2 * (size_t)threads + 2;
-    bool eof = false;
-    auto retire_head = [&]() {  // wait for the oldest block and write it
-        GzJob *j = inflight.front().get();
-        {
-            std::unique_lock<std::mutex> lk(sh.mu);
-            sh.done_cv.wait(lk, [&] { return j->done; });
+        sh_.work_cv.notify_all();
+        for (auto &t : pool_) t.join();
+    }
+    int write(const void *p, size_t n) override {
+        const unsigned char *c = (const unsigned char *)p;
+        while (n && rc_ == NH_OK) {
+            if (!cur_) begin_block();
+            const size_t room = GZ_BLOCK - cur_->len;
+            const size_t take = n < room ? n : room;
+            memcpy(cur_->in.data() + cur_->dict_len + cur_->len, c, take);
+            cur_->len += take;
+            c += take;
+            n -= take;
+            if (cur_->len == GZ_BLOCK) submit();
         }
-        if (j->failed)
-            rc = set_error(NH_EIO, "deflate failed on %s", in_name);
-        else if (!write_all(fout, j->out.data(), j->out_len))
-            rc = set_error(NH_EIO, "write error on %s", out_name);
-        crc = (uint32_t)crc32_combine(crc, j->crc, (z_off_t)j->len);
-        total += j->len;
-        spare.push_back(std::move(inflight.front()));
-        inflight.pop_front();
-    };
-    while (!eof && rc == NH_OK) {
-        std::unique_ptr<GzJob> j;
-        if (!spare.empty()) {
-            j = std::move(spare.back());
-            spare.pop_back();
+        return rc_;
+    }
+    int finish() override {
+        if (cur_ && cur_->len) submit();
+        while (!inflight_.empty()) retire_head();
+        if (rc_ != NH_OK) return rc_;
+        unsigned char tail[10] = {0x03, 0x00};  // final block: fixed Huffman, end-of-block only
+        for (int i = 0; i < 4; i++) {
+            tail[2 + i] = (unsigned char)(crc_ >> (8 * i));
+            tail[6 + i] = (unsigned char)((uint32_t)total_ >> (8 * i));
+        }
+        if (!write_all(fd_, tail, sizeof tail)) rc_ = set_error(NH_EIO, "write error on %s", name_.c_str());
+        return rc_;
+    }
+
+private:
+    void begin_block() {
+        if (!spare_.empty()) {
+            cur_ = std::move(spare_.back());
+            spare_.pop_back();
         } else {
-            j.reset(new GzJob());
+            cur_.reset(new GzJob());
         }
-        j->done = j->failed = false;
-        j->dict_len = dict.size();
-        j->in.resize(j->dict_len + GZ_BLOCK);
-        if (j->dict_len) memcpy(j->in.data(), dict.data(), j->dict_len);
-        const long n = read_full(fin, j->in.data() + j->dict_len, GZ_BLOCK);
-        if (n < 0) {
-            rc = set_error(NH_EIO, "read error on %s", in_name);
-            break;
-        }
-        if (n == 0) break;
-        eof = (size_t)n < GZ_BLOCK;
-        j->len = (size_t)n;
+        cur_->done = cur_->failed = false;
+        cur_->dict_len = dict_.size();
+        cur_->len = 0;
+        cur_->in.resize(cur_->dict_len + GZ_BLOCK);
+        if (cur_->dict_len) memcpy(cur_->in.data(), dict_.data(), cur_->dict_len);
+    }
+    void submit() {
+        GzJob *j = cur_.get();
         const size_t have = j->dict_len + j->len, keep = have < GZ_DICT ? have : GZ_DICT;
-        dict.assign(j->in.data() + have - keep, j->in.data() + have);
+        dict_.assign(j->in.data() + have - keep, j->in.data() + have);
         {
-            std::lock_guard<std::mutex> lk(sh.mu);
-            sh.pending.push_back(j.get());
+            std::lock_guard<std::mutex> lk(sh_.mu);
+            sh_.pending.push_back(j);
         }
-        sh.work_cv.notify_one();
-        inflight.push_back(std::move(j));
-        while (inflight.size() >= max_inflight && rc == NH_OK) retire_head();
+        sh_.work_cv.notify_one();
+        inflight_.push_back(std::move(cur_));
+        while (inflight_.size() >= max_inflight_) retire_head();
     }
-    while (!inflight.empty()) retire_head();  // also on errors: workers still hold pointers
-    stop();
-    if (rc != NH_OK) return rc;
-    unsigned char tail[10] = {0x03, 0x00};  // final block: fixed Huffman, end-of-block only
-    for (int i = 0; i < 4; i++) {
-        tail[2 + i] = (unsigned char)(crc >> (8 * i));
-        tail[6 + i] = (unsigned char)((uint32_t)total >> (8 * i));
+    void retire_head() {  // wait for the oldest block and write it
+        GzJob *j = inflight_.front().get();
+        {
+            std::unique_lock<std::mutex> lk(sh_.mu);
+            sh_.done_cv.wait(lk, [&] { return j->done; });
+        }
+        if (rc_ == NH_OK) {
+            if (j->failed)
+                rc_ = set_error(NH_EIO, "deflate failed on %s", name_.c_str());
+            else if (!write_all(fd_, j->out.data(), j->out_len))
+                rc_ = set_error(NH_EIO, "write error on %s", name_.c_str());
+        }
+        crc_ = (uint32_t)crc32_combine(crc_, j->crc, (z_off_t)j->len);
+        total_ += j->len;
+        spare_.push_back(std::move(inflight_.front()));
+        inflight_.pop_front();
     }
-    if (!write_all(fout, tail, sizeof tail)) return set_error(NH_EIO, "write error on %s", out_name);
-    return NH_OK;
-}
+    int fd_;
+    std::string name_;
+    GzShared sh_;
+    std::vector<std::thread> pool_;
+    std::deque<std::unique_ptr<GzJob>> inflight_;
+    std::vector<std::unique_ptr<GzJob>> spare_;
+    std::unique_ptr<GzJob> cur_;
+    std::vector<unsigned char> dict_;
+    size_t max_inflight_ = 4;
+    uint32_t crc_ = 0;
+    uint64_t total_ = 0;
+    int rc_ = NH_OK;
+};
+
+class PlainEncoder : public StreamEncoder {
+public:
+    PlainEncoder(int fd, const char *name) : fd_(fd), name_(name) {}
+    int write(const void *p, size_t n) override {
+        return write_all(fd_, p, n) ? NH_OK : set_error(NH_EIO, "write error on %s", name_.c_str());
+    }
+    int finish() override { return NH_OK; }
+
+private:
+    int fd_;
+    std::string name_;
+};
 
 // ---- zstd through the system's libzstd.so.1 (the image has the library but not its header; the few
 // entry points of the stable streaming API are declared here) -- zstd_compress of the reference:
@@ -230,51 +269,266 @@ struct ZstdApi {
         ok = createCCtx && freeCCtx && setParameter && compressStream2 && isError && getErrorName;
     }
 };
-
-int zstd_file(int fin, int fout, unsigned threads, const char *in_name, const char *out_name) {
+const ZstdApi &zstd_api() {
     static const ZstdApi Z;
-    if (!Z.ok) return set_error(NH_EINVAL, "Zstd output is not available: libzstd.so.1 could not be loaded");
-    enum { C_LEVEL = 100, C_CHECKSUM = 201, C_WORKERS = 400, E_CONTINUE = 0, E_END = 2 };
-    void *cctx = Z.createCCtx();
-    if (!cctx) return set_error(NH_EOOM, "ZSTD_createCCtx failed");
-    (void)Z.setParameter(cctx, C_LEVEL, 3);
-    (void)Z.setParameter(cctx, C_CHECKSUM, 1);
-    if (threads > 1) (void)Z.setParameter(cctx, C_WORKERS, (int)threads);  // ignored by single-threaded builds
-    std::vector<char> ibuf(1u << 20), obuf(1u << 20);
-    int rc = NH_OK;
-    for (bool last = false; !last && rc == NH_OK;) {
-        const long n = read_full(fin, ibuf.data(), ibuf.size());
-        if (n < 0) {
-            rc = set_error(NH_EIO, "read error on %s", in_name);
-            break;
+    return Z;
+}
+
+class ZstdEncoder : public StreamEncoder {
+public:
+    ZstdEncoder(int fd, unsigned threads, const char *name) : fd_(fd), name_(name), obuf_(1u << 20) {
+        const ZstdApi &Z = zstd_api();
+        enum { C_LEVEL = 100, C_CHECKSUM = 201, C_WORKERS = 400 };
+        cctx_ = Z.createCCtx();
+        if (!cctx_) {
+            rc_ = set_error(NH_EOOM, "ZSTD_createCCtx failed");
+            return;
         }
-        last = (size_t)n < ibuf.size();
-        ZstdApi::InBuf in = {ibuf.data(), (size_t)n, 0};
-        for (;;) {
-            ZstdApi::OutBuf out = {obuf.data(), obuf.size(), 0};
-            const size_t left = Z.compressStream2(cctx, &out, &in, last ? E_END : E_CONTINUE);
+        (void)Z.setParameter(cctx_, C_LEVEL, 3);
+        (void)Z.setParameter(cctx_, C_CHECKSUM, 1);
+        if (threads > 1) (void)Z.setParameter(cctx_, C_WORKERS, (int)threads);  // ignored by single-threaded builds
+    }
+    ~ZstdEncoder() override {
+        if (cctx_) zstd_api().freeCCtx(cctx_);
+    }
+    int write(const void *p, size_t n) override { return pump(p, n, false); }
+    int finish() override { return pump(nullptr, 0, true); }
+
+private:
+    int pump(const void *p, size_t n, bool last) {
+        const ZstdApi &Z = zstd_api();
+        enum { E_CONTINUE = 0, E_END = 2 };
+        ZstdApi::InBuf in = {p, n, 0};
+        while (rc_ == NH_OK) {
+            ZstdApi::OutBuf out = {obuf_.data(), obuf_.size(), 0};
+            const size_t left = Z.compressStream2(cctx_, &out, &in, last ? E_END : E_CONTINUE);
             if (Z.isError(left)) {
-                rc = set_error(NH_EIO, "zstd: %s", Z.getErrorName(left));
+                rc_ = set_error(NH_EIO, "zstd: %s", Z.getErrorName(left));
                 break;
             }
-            if (out.pos && !write_all(fout, obuf.data(), out.pos)) {
-                rc = set_error(NH_EIO, "write error on %s", out_name);
+            if (out.pos && !write_all(fd_, obuf_.data(), out.pos)) {
+                rc_ = set_error(NH_EIO, "write error on %s", name_.c_str());
                 break;
             }
             if (last ? left == 0 : in.pos == in.size) break;
         }
+        return rc_;
     }
-    Z.freeCCtx(cctx);
-    return rc;
+    int fd_;
+    std::string name_;
+    std::vector<char> obuf_;
+    void *cctx_ = nullptr;
+    int rc_ = NH_OK;
+};
+
+// ---- bzip2 through libbz2.so.1 (bzip2_compress of the reference, compression.rs:202-212: one thread,
+// bzip2::Compression::default() = block size 6).  The image has the library but not bzlib.h.
+struct Bz2Api {
+    struct Stream {
+        char *next_in;
+        unsigned avail_in, total_in_lo32, total_in_hi32;
+        char *next_out;
+        unsigned avail_out, total_out_lo32, total_out_hi32;
+        void *state;
+        void *(*bzalloc)(void *, int, int);
+        void (*bzfree)(void *, void *);
+        void *opaque;
+    };
+    int (*init)(Stream *, int, int, int) = nullptr;
+    int (*compress)(Stream *, int) = nullptr;
+    int (*end)(Stream *) = nullptr;
+    bool ok = false;
+    Bz2Api() {
+        void *h = dlopen("libbz2.so.1.0", RTLD_NOW | RTLD_LOCAL);
+        if (!h) h = dlopen("libbz2.so.1", RTLD_NOW | RTLD_LOCAL);
+        if (!h) return;
+        init = (int (*)(Stream *, int, int, int))dlsym(h, "BZ2_bzCompressInit");
+        compress = (int (*)(Stream *, int))dlsym(h, "BZ2_bzCompress");
+        end = (int (*)(Stream *))dlsym(h, "BZ2_bzCompressEnd");
+        ok = init && compress && end;
+    }
+};
+const Bz2Api &bz2_api() {
+    static const Bz2Api B;
+    return B;
 }
 
-std::string shell_quote(const char *s) {
-    std::string q = "'";
-    for (; *s; s++) q += *s == '\'' ? std::string("'\\''") : std::string(1, *s);
-    return q + "'";
+class Bzip2Encoder : public StreamEncoder {
+public:
+    Bzip2Encoder(int fd, const char *name) : fd_(fd), name_(name), obuf_(1u << 20) {
+        memset(&bs_, 0, sizeof bs_);
+        if (bz2_api().init(&bs_, 6, 0, 0) != 0) rc_ = set_error(NH_EOOM, "BZ2_bzCompressInit failed");
+        else live_ = true;
+    }
+    ~Bzip2Encoder() override {
+        if (live_) bz2_api().end(&bs_);
+    }
+    int write(const void *p, size_t n) override {
+        const char *c = (const char *)p;
+        while (n && rc_ == NH_OK) {  // avail_in is 32-bit
+            const size_t take = n < (1u << 30) ? n : (1u << 30);
+            pump(c, take, 0 /* BZ_RUN */);
+            c += take;
+            n -= take;
+        }
+        return rc_;
+    }
+    int finish() override { return pump(nullptr, 0, 2 /* BZ_FINISH */); }
+
+private:
+    int pump(const char *p, size_t n, int action) {
+        bs_.next_in = (char *)p;
+        bs_.avail_in = (unsigned)n;
+        while (rc_ == NH_OK) {
+            bs_.next_out = obuf_.data();
+            bs_.avail_out = (unsigned)obuf_.size();
+            const int r = bz2_api().compress(&bs_, action);
+            if (r < 0) {
+                rc_ = set_error(NH_EIO, "bzip2 compressor failed on %s (%d)", name_.c_str(), r);
+                break;
+            }
+            const size_t got = obuf_.size() - bs_.avail_out;
+            if (got && !write_all(fd_, obuf_.data(), got)) {
+                rc_ = set_error(NH_EIO, "write error on %s", name_.c_str());
+                break;
+            }
+            if (action == 0 ? bs_.avail_in == 0 : r == 4 /* BZ_STREAM_END */) break;
+        }
+        return rc_;
+    }
+    int fd_;
+    std::string name_;
+    std::vector<char> obuf_;
+    Bz2Api::Stream bs_;
+    bool live_ = false;
+    int rc_ = NH_OK;
+};
+
+// ---- xz through liblzma.so.5 (xz_compress of the reference, compression.rs:235-252: multi-threaded
+// stream encoder, preset 6, CRC64).  The image has the library but not lzma.h.
+struct LzmaApi {
+    struct Stream {
+        const unsigned char *next_in;
+        size_t avail_in;
+        uint64_t total_in;
+        unsigned char *next_out;
+        size_t avail_out;
+        uint64_t total_out;
+        const void *allocator;
+        void *internal;
+        void *reserved_ptr1, *reserved_ptr2, *reserved_ptr3, *reserved_ptr4;
+        uint64_t reserved_int1, reserved_int2;
+        size_t reserved_int3, reserved_int4;
+        int reserved_enum1, reserved_enum2;
+    };
+    struct Mt {
+        uint32_t flags, threads;
+        uint64_t block_size;
+        uint32_t timeout, preset;
+        const void *filters;
+        int check;
+        int reserved_enum1, reserved_enum2, reserved_enum3;
+        uint32_t reserved_int1, reserved_int2, reserved_int3, reserved_int4;
+        uint64_t reserved_int5, reserved_int6, reserved_int7, reserved_int8;
+        void *reserved_ptr1, *reserved_ptr2, *reserved_ptr3, *reserved_ptr4;
+    };
+    int (*encoder_mt)(Stream *, const Mt *) = nullptr;
+    int (*code)(Stream *, int) = nullptr;
+    void (*end)(Stream *) = nullptr;
+    bool ok = false;
+    LzmaApi() {
+        void *h = dlopen("liblzma.so.5", RTLD_NOW | RTLD_LOCAL);
+        if (!h) return;
+        encoder_mt = (int (*)(Stream *, const Mt *))dlsym(h, "lzma_stream_encoder_mt");
+        code = (int (*)(Stream *, int))dlsym(h, "lzma_code");
+        end = (void (*)(Stream *))dlsym(h, "lzma_end");
+        ok = encoder_mt && code && end;
+    }
+};
+const LzmaApi &lzma_api() {
+    static const LzmaApi X;
+    return X;
 }
+
+class XzEncoder : public StreamEncoder {
+public:
+    XzEncoder(int fd, unsigned threads, const char *name) : fd_(fd), name_(name), obuf_(1u << 20) {
+        memset(&ls_, 0, sizeof ls_);
+        LzmaApi::Mt mt;
+        memset(&mt, 0, sizeof mt);
+        mt.threads = threads ? threads : 1;
+        mt.preset = 6;
+        mt.check = 4;  // LZMA_CHECK_CRC64
+        const int r = lzma_api().encoder_mt(&ls_, &mt);
+        if (r != 0) rc_ = set_error(NH_EOOM, "lzma_stream_encoder_mt failed (%d)", r);
+        else live_ = true;
+    }
+    ~XzEncoder() override {
+        if (live_) lzma_api().end(&ls_);
+    }
+    int write(const void *p, size_t n) override { return pump(p, n, 0 /* LZMA_RUN */); }
+    int finish() override { return pump(nullptr, 0, 3 /* LZMA_FINISH */); }
+
+private:
+    int pump(const void *p, size_t n, int action) {
+        ls_.next_in = (const unsigned char *)p;
+        ls_.avail_in = n;
+        while (rc_ == NH_OK) {
+            ls_.next_out = (unsigned char *)obuf_.data();
+            ls_.avail_out = obuf_.size();
+            const int r = lzma_api().code(&ls_, action);
+            if (r != 0 && r != 1) {  // LZMA_OK, LZMA_STREAM_END
+                rc_ = set_error(NH_EIO, "xz compressor failed on %s (%d)", name_.c_str(), r);
+                break;
+            }
+            const size_t got = obuf_.size() - ls_.avail_out;
+            if (got && !write_all(fd_, obuf_.data(), got)) {
+                rc_ = set_error(NH_EIO, "write error on %s", name_.c_str());
+                break;
+            }
+            if (action == 0 ? (ls_.avail_in == 0 && ls_.avail_out != 0) : r == 1) break;
+        }
+        return rc_;
+    }
+    int fd_;
+    std::string name_;
+    std::vector<char> obuf_;
+    LzmaApi::Stream ls_;
+    bool live_ = false;
+    int rc_ = NH_OK;
+};
 
 }  // namespace
+
+StreamEncoder *make_encoder(int codec, int fd, unsigned threads, const char *name) {
+    switch (codec) {
+        case NH_CODEC_NONE:
+            return new PlainEncoder(fd, name);
+        case NH_CODEC_GZIP:
+            return new GzipEncoder(fd, threads, name);
+        case NH_CODEC_ZSTD:
+            if (!zstd_api().ok) {
+                set_error(NH_EINVAL, "Zstd output is not available: libzstd.so.1 could not be loaded");
+                return nullptr;
+            }
+            return new ZstdEncoder(fd, threads, name);
+        case NH_CODEC_BZIP2:
+            if (!bz2_api().ok) {
+                set_error(NH_EINVAL, "Bzip2 output is not available: libbz2.so.1 could not be loaded");
+                return nullptr;
+            }
+            return new Bzip2Encoder(fd, name);
+        case NH_CODEC_XZ:
+            if (!lzma_api().ok) {
+                set_error(NH_EINVAL, "Xz output is not available: liblzma.so.5 could not be loaded");
+                return nullptr;
+            }
+            return new XzEncoder(fd, threads, name);
+        default:
+            set_error(NH_EINVAL, "unknown codec %d", codec);
+            return nullptr;
+    }
+}
 
 int compress_file(const char *in, const char *out, int codec, unsigned threads) {
     if (!in || !out) return set_error(NH_EINVAL, "nh_compress_file: null path");
@@ -283,38 +537,28 @@ int compress_file(const char *in, const char *out, int codec, unsigned threads) 
         return set_error(NH_EINVAL, "nh_compress_file: unknown codec %d", codec);
     int fin = ::open(in, O_RDONLY | O_CLOEXEC);
     if (fin < 0) return set_error(NH_EIO, "cannot open %s", in);
+    int fout = ::open(out, O_WRONLY | O_CREAT | O_TRUNC | O_CLOEXEC, 0666);
+    if (fout < 0) {
+        ::close(fin);
+        return set_error(NH_EIO, "cannot create %s", out);
+    }
     int rc = NH_OK;
-    if (codec == NH_CODEC_NONE || codec == NH_CODEC_GZIP || codec == NH_CODEC_ZSTD) {
-        int fout = ::open(out, O_WRONLY | O_CREAT | O_TRUNC | O_CLOEXEC, 0666);
-        if (fout < 0) {
-            ::close(fin);
-            return set_error(NH_EIO, "cannot create %s", out);
-        }
-        if (codec == NH_CODEC_GZIP) {
-            rc = gzip_parallel(fin, fout, threads, in, out);
-        } else if (codec == NH_CODEC_ZSTD) {
-            rc = zstd_file(fin, fout, threads, in, out);
+    {
+        std::unique_ptr<StreamEncoder> enc(make_encoder(codec, fout, threads, out));
+        if (!enc) {
+            rc = NH_EINVAL;  // message set by make_encoder
         } else {
             std::vector<char> buf(4u << 20);
             for (;;) {
                 const long n = read_full(fin, buf.data(), buf.size());
                 if (n < 0) rc = set_error(NH_EIO, "read error on %s", in);
                 if (n <= 0) break;
-                if (!write_all(fout, buf.data(), (size_t)n)) {
-                    rc = set_error(NH_EIO, "write error on %s", out);
-                    break;
-                }
+                if ((rc = enc->write(buf.data(), (size_t)n))) break;
             }
+            if (rc == NH_OK) rc = enc->finish();
         }
-        if (::close(fout) != 0 && rc == NH_OK) rc = set_error(NH_EIO, "write error on %s", out);
-    } else {
-        // libbz2 / liblzma headers are not in this image; their command-line tools are
-        std::string cmd = codec == NH_CODEC_BZIP2 ? std::string("bzip2 -c")
-                                                  : "xz -6 -c -T" + std::to_string(threads ? threads : 1);
-        cmd += " < " + shell_quote(in) + " > " + shell_quote(out);
-        const int st = system(cmd.c_str());
-        if (st != 0) rc = set_error(NH_EIO, "the %s compressor failed on %s", codec == NH_CODEC_BZIP2 ? "bzip2" : "xz", out);
     }
+    if (::close(fout) != 0 && rc == NH_OK) rc = set_error(NH_EIO, "write error on %s", out);
     ::close(fin);
     return rc;
 }

@@ -1,0 +1,23 @@
+// nh_codec.h -- streaming output encoders: the writer of nh_run feeds the kept
+// records straight into one of these, so that the compress stage of the reference
+// (/root/reference/src/compression.rs:182-268, called at src/main.rs:342-368) needs no temporary
+// uncompressed file.
+#pragma once
+#include <stddef.h>
+
+namespace nh {
+
+class StreamEncoder {
+public:
+    virtual ~StreamEncoder() {}
+    // appends n bytes to the stream; NH_OK or an error (set_error)
+    virtual int write(const void *p, size_t n) = 0;
+    // flushes everything and writes the container's trailer; the file descriptor stays open
+    virtual int finish() = 0;
+};
+
+// codec: nh_codec of the C ABI.  The encoder writes to fd (not closed by it); `name` only labels errors.
+// Returns nullptr with the error set when the codec's library cannot be loaded.
+StreamEncoder *make_encoder(int codec, int fd, unsigned threads, const char *name);
+
+}  // namespace nh

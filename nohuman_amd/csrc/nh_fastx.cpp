@@ -3,6 +3,7 @@
 #include "nh_inflate.h"
 
 #include <ctype.h>
+#include <dlfcn.h>
 #include <errno.h>
 #include <fcntl.h>
 #include <unistd.h>
@@ -10,6 +11,107 @@
 #include <zlib.h>
 
 namespace nh {
+
+// bzip2 inputs (kraken2's wrapper pipes them through `bzip2 -dc`): decoded in process with the
+// system's libbz2.so.1 -- the image has the library but not bzlib.h.  Concatenated streams are decoded
+// one after the other as bzip2 -dc does; a truncated or damaged file is an ERROR, never a short read.
+class Bz2Source {
+public:
+    struct Stream {
+        char *next_in;
+        unsigned avail_in, total_in_lo32, total_in_hi32;
+        char *next_out;
+        unsigned avail_out, total_out_lo32, total_out_hi32;
+        void *state;
+        void *(*bzalloc)(void *, int, int);
+        void (*bzfree)(void *, void *);
+        void *opaque;
+    };
+    ~Bz2Source() {
+        if (live_) end_(&bs_);
+        if (fd_ >= 0) ::close(fd_);
+    }
+    int open(const char *path, std::string &err) {
+        void *h = dlopen("libbz2.so.1.0", RTLD_NOW | RTLD_LOCAL);
+        if (!h) h = dlopen("libbz2.so.1", RTLD_NOW | RTLD_LOCAL);
+        if (h) {
+            init_ = (int (*)(Stream *, int, int))dlsym(h, "BZ2_bzDecompressInit");
+            run_ = (int (*)(Stream *))dlsym(h, "BZ2_bzDecompress");
+            end_ = (int (*)(Stream *))dlsym(h, "BZ2_bzDecompressEnd");
+        }
+        if (!init_ || !run_ || !end_) {
+            err = std::string("bzip2 input needs libbz2.so.1, which could not be loaded (") + path + ")";
+            return -1;
+        }
+        fd_ = ::open(path, O_RDONLY | O_CLOEXEC);
+        if (fd_ < 0) {
+            err = std::string("cannot open ") + path;
+            return -1;
+        }
+        path_ = path;
+        in_.resize(1u << 20);
+        return 0;
+    }
+    long read(uint8_t *buf, size_t cap, std::string &err) {
+        size_t got = 0;
+        while (got < cap && !done_) {
+            if (bs_.avail_in == 0 && !in_eof_) {
+                ssize_t n;
+                do n = ::read(fd_, in_.data(), in_.size());
+                while (n < 0 && errno == EINTR);
+                if (n < 0) {
+                    err = "read error on " + path_;
+                    return -1;
+                }
+                if (n == 0) in_eof_ = true;
+                bs_.next_in = in_.data();
+                bs_.avail_in = (unsigned)n;
+            }
+            if (!live_) {
+                if (bs_.avail_in == 0 && in_eof_) {  // clean end between streams
+                    done_ = true;
+                    break;
+                }
+                char *ni = bs_.next_in;
+                const unsigned ai = bs_.avail_in;
+                memset(&bs_, 0, sizeof bs_);
+                bs_.next_in = ni;
+                bs_.avail_in = ai;
+                if (init_(&bs_, 0, 0) != 0) {
+                    err = "bzip2: cannot start the decoder";
+                    return -1;
+                }
+                live_ = true;
+            }
+            bs_.next_out = (char *)buf + got;
+            const size_t room = cap - got < (1u << 30) ? cap - got : (1u << 30);
+            bs_.avail_out = (unsigned)room;
+            const int r = run_(&bs_);
+            got += room - bs_.avail_out;
+            if (r == 4) {  // BZ_STREAM_END: another stream may follow
+                end_(&bs_);
+                live_ = false;
+            } else if (r != 0) {
+                err = "bzip2: damaged input " + path_;
+                return -1;
+            } else if (bs_.avail_in == 0 && in_eof_ && bs_.avail_out != 0) {
+                err = "bzip2: unexpected end of " + path_;
+                return -1;
+            }
+        }
+        return (long)got;
+    }
+
+private:
+    int (*init_)(Stream *, int, int) = nullptr;
+    int (*run_)(Stream *) = nullptr;
+    int (*end_)(Stream *) = nullptr;
+    Stream bs_ = {};
+    std::vector<char> in_;
+    std::string path_;
+    int fd_ = -1;
+    bool live_ = false, in_eof_ = false, done_ = false;
+};
 
 ByteSource::~ByteSource() { close(); }
 
@@ -24,18 +126,10 @@ int ByteSource::open(const char *path, std::string &err, unsigned gz_threads) {
     size_t got = fread(magic, 1, 3, f);
     fclose(f);
     if (got == 3 && magic[0] == 'B' && magic[1] == 'Z' && magic[2] == 'h') {
-        // kraken2's wrapper pipes bzip2 inputs through `bzip2 -dc`
-        std::string cmd = "bzip2 -dc '";
-        for (const char *p = path; *p; p++) {
-            if (*p == '\'')
-                cmd += "'\\''";
-            else
-                cmd += *p;
-        }
-        cmd += "'";
-        pipe_ = popen(cmd.c_str(), "r");
-        if (!pipe_) {
-            err = std::string("cannot run bzip2 -dc on ") + path;
+        bz_ = new Bz2Source();
+        if (bz_->open(path, err) != 0) {
+            delete bz_;
+            bz_ = nullptr;
             return -1;
         }
         return 0;
@@ -97,23 +191,19 @@ long ByteSource::read(uint8_t *buf, size_t cap) {
         }
         return n;
     }
-    if (pipe_) {
-        size_t n = fread(buf, 1, cap, pipe_);
-        if (n == 0 && ferror(pipe_)) return -1;
-        return (long)n;
-    }
+    if (bz_) return bz_->read(buf, cap, pgz_error_);
     return -1;
 }
 
 void ByteSource::close() {
     if (gz_) gzclose((gzFile)gz_);
-    if (pipe_) pclose(pipe_);
+    delete bz_;
+    bz_ = nullptr;
     if (fd_ >= 0) ::close(fd_);
     delete pgz_;
     pgz_ = nullptr;
     fd_ = -1;
     gz_ = nullptr;
-    pipe_ = nullptr;
 }
 
 int FastxReader::open(const char *path, std::string &err) {

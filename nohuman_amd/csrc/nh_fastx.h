@@ -22,8 +22,10 @@ struct SeqRecord {
     std::string quals;
 };
 
-// Byte source: plain, gzip (zlib) or bzip2 (through `bzip2 -dc`, as kraken2's wrapper does).
+// Byte source: plain, gzip (own multi-threaded decoder or zlib) or bzip2 (libbz2; kraken2's wrapper pipes
+// such inputs through `bzip2 -dc`).
 class ParallelGunzip;
+class Bz2Source;
 
 class ByteSource {
 public:
@@ -38,7 +40,7 @@ public:
 
 private:
     void *gz_ = nullptr;   // gzFile
-    FILE *pipe_ = nullptr; // bzip2 -dc
+    Bz2Source *bz_ = nullptr;  // bzip2 (libbz2 by dlopen)
     int fd_ = -1;          // plain text
     ParallelGunzip *pgz_ = nullptr;
     std::string pgz_error_;

@@ -26,6 +26,7 @@
 #include <string>
 #include <vector>
 
+#include "nh_codec.h"
 #include "nh_fastx.h"
 #include "nh_internal.h"
 #include "nohuman_engine.h"
@@ -41,10 +42,15 @@ struct OutFile {
     std::vector<struct iovec> iov;
     std::vector<char> is_scratch;  // per span: iov_base is an offset into scratch
     std::string scratch;
-    int open(const char *p) {
+    std::unique_ptr<StreamEncoder> enc;  // set: the spans go through a streaming encoder
+    int open(const char *p, int codec = NH_CODEC_NONE, unsigned codec_threads = 1) {
         path = p;
         fd = ::open(p, O_WRONLY | O_CREAT | O_TRUNC | O_CLOEXEC, 0666);
         if (fd < 0) return set_error(NH_EIO, "cannot create %s", p);
+        if (codec != NH_CODEC_NONE) {
+            enc.reset(make_encoder(codec, fd, codec_threads ? codec_threads : 1, p));
+            if (!enc) return NH_EINVAL;  // message set by make_encoder
+        }
         return NH_OK;
     }
     void add_raw(const char *p, size_t n) {
@@ -72,6 +78,10 @@ struct OutFile {
             if (is_scratch[i]) iov[i].iov_base = (void *)(scratch.data() + (size_t)iov[i].iov_base);
         size_t i = 0;
         int rc = NH_OK;
+        if (enc) {
+            for (; i < iov.size() && rc == NH_OK; i++) rc = enc->write(iov[i].iov_base, iov[i].iov_len);
+            i = iov.size();
+        }
         while (i < iov.size()) {
             const int cnt = (int)std::min<size_t>(iov.size() - i, 512);
             ssize_t w = ::writev(fd, &iov[i], cnt);
@@ -94,11 +104,16 @@ struct OutFile {
     }
     int close() {
         int rc = NH_OK;
-        if (fd >= 0 && ::close(fd) != 0) rc = set_error(NH_EIO, "write error on %s", path.c_str());
+        if (enc) {
+            rc = enc->finish();
+            enc.reset();
+        }
+        if (fd >= 0 && ::close(fd) != 0 && rc == NH_OK) rc = set_error(NH_EIO, "write error on %s", path.c_str());
         fd = -1;
         return rc;
     }
     ~OutFile() {
+        enc.reset();
         if (fd >= 0) ::close(fd);
     }
 };
@@ -532,8 +547,10 @@ int run_engines(const std::vector<Engine *> &engines, const nh_run_args *a, nh_s
     }
     OutFile o1, o2, ok;
     int rc;
-    if ((rc = o1.open(a->out1))) return rc;
-    if (rs.paired && (rc = o2.open(a->out2))) return rc;
+    if (a->out_codec < NH_CODEC_NONE || a->out_codec > NH_CODEC_ZSTD)
+        return set_error(NH_EINVAL, "nh_run: unknown out_codec %d", a->out_codec);
+    if ((rc = o1.open(a->out1, a->out_codec, a->codec_threads))) return rc;
+    if (rs.paired && (rc = o2.open(a->out2, a->out_codec, a->codec_threads))) return rc;
     if (rs.want_k && (rc = ok.open(a->kraken_output))) return rc;
 
     // fragments per batch: ~96 MB of sequence, at most 262144; both readers cut at the same record

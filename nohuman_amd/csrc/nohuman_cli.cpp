@@ -150,13 +150,6 @@ static std::string add_extension(Codec c, const std::string &p) {
 }
 
 // compress stage (src/compression.rs:182-268): content parity, not byte-identical streams
-static void compress_to(Codec c, const std::string &in, const std::string &out, unsigned threads) {
-    const int codec = c == C_GZ ? NH_CODEC_GZIP : c == C_BZ2 ? NH_CODEC_BZIP2 : c == C_XZ ? NH_CODEC_XZ
-                    : c == C_ZST ? NH_CODEC_ZSTD : NH_CODEC_NONE;
-    if (nh_compress_file(in.c_str(), out.c_str(), codec, threads) != 0)
-        die("Failed to compress file: %s", nh_last_error());
-}
-
 // ---- database discovery (src/download.rs:178-232, src/lib.rs:119-141) --------------------------------
 static bool validate_db_directory(const std::string &p, std::string &actual) {
     const char *req[3] = {"hash.k2d", "opts.k2d", "taxo.k2d"};
@@ -408,16 +401,14 @@ int main(int argc, char **argv) {
     const bool paired = args.input.size() == 2;
     Codec out_codec = args.has_type ? args.type : args.has_out1 ? codec_from_path(args.out1) : codec_from_magic(args.input[0]);
 
-    // temporary directory "nohuman*" in the current directory (src/main.rs:248-257)
-    char cwd[4096];
-    if (!getcwd(cwd, sizeof cwd)) die("Failed to create temporary directory");
-    std::string tmpl = join(cwd, "nohumanXXXXXX");
-    std::vector<char> tb(tmpl.begin(), tmpl.end());
-    tb.push_back(0);
-    if (!mkdtemp(tb.data())) die("Failed to create temporary directory");
-    const std::string tmpdir = tb.data();
-    const std::string tmp1 = join(tmpdir, paired ? "kraken_out_1.fq" : "kraken_out.fq");
-    const std::string tmp2 = join(tmpdir, "kraken_out_2.fq");
+    // The reference lets kraken2 write kraken_out*.fq into a temporary directory "nohuman*" in the current
+    // directory (src/main.rs:248-257) and compresses them to the output paths afterwards
+    // (src/main.rs:342-368).  Here the engine's writer feeds the kept records straight into the output
+    // encoder: no temporary file, one pass.
+    std::string out1 = args.has_out1 ? args.out1 : default_out_name(args.input[0], out_codec);
+    std::string out2 = paired ? (args.has_out2 ? args.out2 : default_out_name(args.input[1], out_codec)) : "";
+    const int codec = out_codec == C_GZ ? NH_CODEC_GZIP : out_codec == C_BZ2 ? NH_CODEC_BZIP2 : out_codec == C_XZ ? NH_CODEC_XZ
+                    : out_codec == C_ZST ? NH_CODEC_ZSTD : NH_CODEC_NONE;
     INFO(args.human ? "Keeping human reads..." : "Removing human reads...");
 
     std::string conf_text;
@@ -432,8 +423,10 @@ int main(int argc, char **argv) {
     ra.db_dir = db_path.c_str();
     ra.in1 = args.input[0].c_str();
     ra.in2 = paired ? args.input[1].c_str() : nullptr;
-    ra.out1 = tmp1.c_str();
-    ra.out2 = paired ? tmp2.c_str() : nullptr;
+    ra.out1 = out1.c_str();
+    ra.out2 = paired ? out2.c_str() : nullptr;
+    ra.out_codec = codec;
+    ra.codec_threads = paired ? (args.threads / 2 ? args.threads / 2 : 1) : args.threads;  // src/main.rs:342-346
     ra.kraken_output = args.kraken_output.empty() ? "/dev/null" : args.kraken_output.c_str();
     ra.report = args.kraken_report.empty() ? nullptr : args.kraken_report.c_str();
     ra.confidence = conf64;
@@ -452,7 +445,8 @@ int main(int argc, char **argv) {
     nh_stats st;
     if (nh_run(&ra, &st) != 0) {
         std::string msg = nh_last_error();
-        rmdir(tmpdir.c_str());
+        unlink(out1.c_str());  // nothing half-written stays behind (the reference's outputs do not exist yet)
+        if (paired) unlink(out2.c_str());
         die("Failed to run kraken2\n\nCaused by:\n    kraken2 failed with stderr %s", msg.c_str());
     }
     // src/lib.rs:38-45 (0/0 prints NaN there as well)
@@ -467,28 +461,16 @@ int main(int argc, char **argv) {
          (unsigned long long)st.unclassified, pct(st.unclassified).c_str());
     INFO("Kraken2 finished. Organising output...");
 
-    std::string out1 = args.has_out1 ? args.out1 : default_out_name(args.input[0], out_codec);
-    std::string out2 = paired ? (args.has_out2 ? args.out2 : default_out_name(args.input[1], out_codec)) : "";
-    const unsigned threads = paired ? args.threads / 2 : args.threads;
-    if (paired && threads > 1) {
-        std::thread t1([&] { INFO("Writing output file to: %s", quoted(out1).c_str()); compress_to(out_codec, tmp1, out1, threads); });
-        std::thread t2([&] { INFO("Writing output file to: %s", quoted(out2).c_str()); compress_to(out_codec, tmp2, out2, threads); });
-        t1.join();
-        t2.join();
+    if (paired && args.threads / 2 > 1) {  // the reference announces both files before its two compress threads run
+        INFO("Writing output file to: %s", quoted(out1).c_str());
+        INFO("Writing output file to: %s", quoted(out2).c_str());
     } else {
-        compress_to(out_codec, tmp1, out1, threads);
         INFO("Output file written to: %s", quoted(out1).c_str());
-        if (paired) {
-            compress_to(out_codec, tmp2, out2, threads);
-            INFO("Output file written to: %s", quoted(out2).c_str());
-        }
+        if (paired) INFO("Output file written to: %s", quoted(out2).c_str());
     }
     if (!args.kraken_output.empty() && args.kraken_output != "/dev/null")
         INFO("Kraken output file written to: %s", quoted(args.kraken_output).c_str());
     if (!args.kraken_report.empty()) INFO("Kraken report file written to: %s", quoted(args.kraken_report).c_str());
-    unlink(tmp1.c_str());
-    if (paired) unlink(tmp2.c_str());
-    if (rmdir(tmpdir.c_str()) != 0) WARN("Failed to remove temporary output directory: %s", strerror(errno));
     INFO("Done.");
     return 0;
 }

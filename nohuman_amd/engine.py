@@ -221,7 +221,8 @@ class Engine:
 
     # -- whole run -----------------------------------------------------------------------------
     def run(self, in1, out1, in2=None, out2=None, kraken_output=None, report=None,
-            confidence: float = 0.0, threads: int = 1, keep_human: bool = False) -> _lib.nh_stats:
+            confidence: float = 0.0, threads: int = 1, keep_human: bool = False, out_codec: int = 0,
+            codec_threads: int = 0) -> _lib.nh_stats:
         a = _lib.nh_run_args()
         a.db_dir = None
         a.in1 = os.fsencode(in1)
@@ -235,6 +236,8 @@ class Engine:
         a.keep_human = int(bool(keep_human))
         a.n_devices = 1
         a.device_ids = None
+        a.out_codec = int(out_codec)
+        a.codec_threads = int(codec_threads)
         s = _lib.nh_stats()
         _check(self._L.nh_run_engine(self._h, C.byref(a), C.byref(s)))
         return s

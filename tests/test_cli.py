@@ -163,3 +163,43 @@ def test_database_resolution_errors_and_env(tmp_path):
     assert r.returncode == 0, r.stderr
     assert "Using database version HPRC.rX at" in r.stderr
     assert (tmp_path / "in.nohuman.fq").exists()
+
+
+@pytest.mark.gpu
+def test_no_temporary_files_kept_reads_stream_into_the_encoder(tmp_path):
+    """the reference has kraken2 write kraken_out*.fq into a temp dir "nohuman*" in the
+    current directory and compresses them afterwards (main.rs:248-257,342-368).  Here the writer feeds the
+    encoder directly: the run works from a current directory nothing can be created in, and leaves
+    nothing but the outputs."""
+    exp = json.load(open(os.path.join(GOLD, "expected_pe.json")))
+    calls = [r["by_conf"]["0.0"][0] for r in exp["records"]]
+    r1 = read_fastq(os.path.join(GOLD, "reads_pe_1.fq"))
+    r2 = read_fastq(os.path.join(GOLD, "reads_pe_2.fq"))
+    work = tmp_path / "readonly_cwd"
+    work.mkdir()
+    outd = tmp_path / "out"
+    outd.mkdir()
+    os.chmod(work, 0o555)
+    try:
+        r = run(["-D", DB, "-t", "4", "-o", str(outd / "a_1.fq.gz"), "-O", str(outd / "a_2.fq.gz"),
+                 os.path.join(GOLD, "reads_pe_1.fq"), os.path.join(GOLD, "reads_pe_2.fq")], cwd=work)
+    finally:
+        os.chmod(work, 0o755)
+    assert r.returncode == 0, r.stderr
+    assert os.listdir(work) == []
+    assert sorted(os.listdir(outd)) == ["a_1.fq.gz", "a_2.fq.gz"]
+    for path, reads in ((outd / "a_1.fq.gz", r1), (outd / "a_2.fq.gz", r2)):
+        want = b"".join(h + b"\n" + s + b"\n+\n" + q + b"\n" for (h, _i, s, q), c in zip(reads, calls) if not c)
+        assert gzip.open(path, "rb").read() == want
+
+
+@pytest.mark.gpu
+def test_failed_run_leaves_nothing_behind(tmp_path):
+    """a failing run must not leave a temp dir or half-written outputs in the cwd."""
+    bad = tmp_path / "bad.fq.gz"
+    with open(os.path.join(GOLD, "reads_se.fq"), "rb") as f:
+        data = gzip.compress(f.read())
+    bad.write_bytes(data[:-40])  # truncated member: the reader reports it after most reads went through
+    r = run(["-D", DB, str(bad)], cwd=tmp_path)
+    assert r.returncode == 1 and "Failed to run kraken2" in r.stderr
+    assert sorted(os.listdir(tmp_path)) == ["bad.fq.gz"]

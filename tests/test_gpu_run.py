@@ -303,3 +303,24 @@ def test_count_allreduce_over_rccl_single_device(tmp_path, monkeypatch, capfd):
     assert st.classified == sum(1 for c in calls if c)
     err = capfd.readouterr().err
     assert "counters reduced by RCCL" in err
+
+
+@pytest.mark.parametrize("codec", [1, 2, 3, 4])
+def test_run_streams_kept_pairs_into_the_output_codec(tmp_path, codec):
+    """nh_run_args.out_codec (ABI 2): the writer's spans go through a streaming encoder; what comes out
+    decompresses to exactly the plain-text outputs."""
+    import bz2
+    import lzma
+    from nohuman_amd import Engine
+    from tests.test_codec import _zstd_decompress
+    ins = [os.path.join(GOLD, "reads_pe_1.fq"), os.path.join(GOLD, "reads_pe_2.fq")]
+    with Engine.open(DB) as eng:
+        eng.run(ins[0], str(tmp_path / "p_1.fq"), in2=ins[1], out2=str(tmp_path / "p_2.fq"), confidence=0.1)
+        eng.run(ins[0], str(tmp_path / "c_1"), in2=ins[1], out2=str(tmp_path / "c_2"), confidence=0.1,
+                out_codec=codec, codec_threads=3)
+    for m in ("1", "2"):
+        want = (tmp_path / ("p_%s.fq" % m)).read_bytes()
+        raw = (tmp_path / ("c_" + m)).read_bytes()
+        got = {1: bz2.decompress, 2: gzip.decompress, 3: lzma.decompress,
+               4: lambda b: _zstd_decompress(b, len(want))}[codec](raw)
+        assert got == want and len(want) > 1000

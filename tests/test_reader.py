@@ -143,3 +143,25 @@ def test_reader_errors(tmp_path):
     assert "malformed FASTQ" in str(ei.value)
     with pytest.raises(RuntimeError):
         scan(tmp_path / "missing.fq")
+
+
+def test_bzip2_input_damage_is_an_error_not_a_short_read(tmp_path):
+    """a truncated or corrupt .bz2 used to end the stream quietly (popen + ignored exit status):
+    reads went missing from a decontamination run without a word.  The in-process decoder reports it;
+    concatenated streams still decode like `bzip2 -dc`."""
+    data = open(os.path.join(GOLD, "reads_se.fq"), "rb").read() * 10
+    whole = bz2.compress(data)
+    two = tmp_path / "two.fq.bz2"
+    two.write_bytes(bz2.compress(data[:len(data) // 2], 1) + bz2.compress(data[len(data) // 2:], 9))
+    assert scan(two) == expect(data)
+    cut = tmp_path / "cut.fq.bz2"
+    cut.write_bytes(whole[:len(whole) // 2])
+    with pytest.raises(RuntimeError) as ei:
+        scan(cut)
+    assert "bzip2" in str(ei.value)
+    bad = bytearray(whole)
+    bad[len(bad) // 2] ^= 0x55
+    (tmp_path / "bad.fq.bz2").write_bytes(bytes(bad))
+    with pytest.raises(RuntimeError) as ei:
+        scan(tmp_path / "bad.fq.bz2")
+    assert "bzip2" in str(ei.value)
