@@ -160,3 +160,57 @@ def test_long_reads_at_byte_offsets_beyond_4_gib(big):
     assert torch.equal(out[n - tail_n:], tout)
     assert (out[:, 1] == ln - 35 + 1).all()
     assert int((tout[:, 0] != 0).sum()) >= 10  # the planted sequence was found
+
+
+def test_ont_lognormal_batch_at_bench_size_equals_the_oracle(big, oracle_db):
+    """configs[3] at bench.py --ont shape: 400 k reads, length ~ lognormal(8.8, 0.85) clipped to
+    [200, 200000] (N50 ~ 10 kb, ~3.7 Gbases in ONE launch, fragments handed out one by one), a slice of
+    them carrying sequence that is in the table, 0.1 % N: every record equals the CPU oracle's."""
+    from nohuman_amd.dist import usable_cpu_count
+    torch = big["torch"]
+    dev = big["dev"]
+    n = 400_000
+    g = torch.Generator(device=dev)
+    g.manual_seed(4)
+    lens = torch.exp(torch.randn(n, generator=g, device=dev, dtype=torch.float64) * 0.85 + 8.8)
+    lens = lens.clamp(200, 200000).to(torch.int64)
+    offs = torch.zeros(n + 1, dtype=torch.int64, device=dev)
+    offs[1:] = torch.cumsum(lens, 0)
+    total = int(offs[-1])
+    assert 2.5e9 < total < 5e9
+    bases = torch.empty(total + 64, dtype=torch.uint8, device=dev)
+    step = 200_000_000
+    for i in range(0, total, step):
+        m = min(step, total - i)
+        bases[i:i + m] = big["acgt"][torch.randint(0, 4, (m,), generator=g, device=dev)]
+        nm = torch.rand(m, generator=g, device=dev) < 0.001
+        bases[i:i + m][nm] = 78
+    bases[total:] = 65
+    # every 40th read gets 3 kb of sequence whose minimizers are in the table, at a random place
+    src = big["bases"][: 150 * 20_000]  # the fixture's inserted reads, back to back
+    starts = offs[:-1][::40]
+    room = (lens[::40] - 3000).clamp(min=0)
+    at = starts + (torch.rand(starts.numel(), generator=g, device=dev, dtype=torch.float64) * room.double()).long()
+    ok = lens[::40] >= 3000
+    sel = torch.randint(0, src.numel() - 3000, (starts.numel(),), generator=g, device=dev)
+    idx = torch.arange(3000, device=dev)[None, :]
+    dst = (at[ok][:, None] + idx).reshape(-1)
+    bases[dst] = src[(sel[ok][:, None] + idx).reshape(-1)]
+    offs = offs.contiguous()
+    out = torch.zeros((n, 4), dtype=torch.int32, device=dev)
+    cnt = torch.zeros(4, dtype=torch.int64, device=dev)
+    big["eng"].classify_device(bases.data_ptr(), offs.data_ptr(), n, False, 0.0, out.data_ptr(), cnt.data_ptr(),
+                               long_reads=True)
+    torch.cuda.synchronize()
+    exp, lookups = oracle_db.classify(bases[:total].cpu().numpy(), offs.cpu().numpy().astype(np.uint64), False, 0.0,
+                                      threads=usable_cpu_count())
+    rec = out.cpu().numpy().view(np.uint32)
+    for i, f in enumerate(("call", "total_kmers", "clade_hits", "hit_groups")):
+        bad = np.nonzero(rec[:, i] != exp[f])[0]
+        assert bad.size == 0, "%s differs at %s" % (f, bad[:5])
+    c = cnt.tolist()
+    assert c[0] == n and c[2] == total and c[3] == int(lookups.sum())
+    assert c[1] == int((exp["call"] != 0).sum()) and 0.01 * n < c[1] < 0.1 * n
+    srt = torch.sort(lens, descending=True).values
+    n50 = int(srt[torch.searchsorted(torch.cumsum(srt, 0), total // 2)])
+    assert 8_000 < n50 < 20_000
