@@ -49,7 +49,12 @@ struct Result {
 struct KArgs {
     DevDB db;
     const uint8_t *bases;
+    // sequence i = bases[seq_off[i], seq_off[i+1])  (seq_len == NULL, n_seq + 1 offsets), or
+    //            = bases[seq_off[i], seq_off[i] + seq_len[i])  (n_seq offsets: records classified in place
+    //              inside their FASTQ / FASTA text, which is bases_end bytes long)
     const uint64_t *seq_off;
+    const uint32_t *seq_len;
+    uint64_t bases_end;
     uint64_t n_frag;
     int32_t mates;
     uint32_t frag_chunk;
@@ -60,7 +65,36 @@ struct KArgs {
     unsigned long long *counters;
     int *error_flag;  // sticky error bits of the engine (1: > 2048 distinct taxa, 2: sequence too long)
     int *pending;     // per launch slot: fragments were left to the BIG variant
+    // short-read kernel -> generic kernel: chunks that hold a sequence of more than one tile (one bit per
+    // chunk of frag_chunk fragments), and "there are such chunks"
+    uint32_t *defer_bits;
+    int *pending_long;
+    int32_t only_deferred;  // generic kernel: classify only the chunks marked in defer_bits
     unsigned long long *work;
+};
+
+// ---- host side of a launch ----
+// what one classify launch reads and writes (device pointers)
+struct LaunchIO {
+    const void *d_bases = nullptr;
+    const void *d_seq_off = nullptr;   // n_seq + 1 offsets, or n_seq starts when d_seq_len is set
+    const void *d_seq_len = nullptr;   // NULL, or n_seq uint32 lengths (sequences in place inside their records' text)
+    uint64_t bases_end = 0;            // with d_seq_len: bytes of d_bases (readable for 8 more)
+    uint64_t n_frag = 0;
+    int mates = 1;
+    bool long_reads = false;           // hint: skip the short-read kernel
+    void *d_out = nullptr, *d_kmer_taxa = nullptr;
+    const void *d_kmer_taxa_off = nullptr;
+    void *d_counters = nullptr;
+};
+// the per-launch words of one of the engine's LAUNCH_SLOTS
+struct LaunchSlot {
+    int *d_error = nullptr;             // sticky error bits of the engine
+    int *d_pending = nullptr;           // fragments were left to the BIG variant
+    int *d_pending_long = nullptr;      // chunks were left to the generic kernel
+    unsigned long long *d_work = nullptr;
+    uint32_t *d_defer = nullptr;        // one bit per chunk
+    uint64_t defer_cap_bits = 0;
 };
 
 constexpr uint32_t TAXON_AMBIGUOUS = 0xFFFFFFFFu;

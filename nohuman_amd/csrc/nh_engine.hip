@@ -207,9 +207,11 @@ static int common_open(Engine *e, int device) {
     HIP_TRY(hipMalloc((void **)&e->d_counters, (CNT_N + 12) * sizeof(uint64_t)));
     HIP_TRY(hipMemset(e->d_counters, 0, (CNT_N + 12) * sizeof(uint64_t)));
     HIP_TRY(hipMalloc((void **)&e->d_work, LAUNCH_SLOTS * sizeof(unsigned long long)));
-    // [0, LAUNCH_SLOTS) "fragments left to the BIG variant" per launch slot, then the sticky error bits
-    HIP_TRY(hipMalloc((void **)&e->d_error, (LAUNCH_SLOTS + 1) * sizeof(int)));
-    HIP_TRY(hipMemset(e->d_error, 0, (LAUNCH_SLOTS + 1) * sizeof(int)));
+    // [0, LAUNCH_SLOTS) "fragments left to the BIG variant" per launch slot, then the sticky error bits,
+    // then [LAUNCH_SLOTS + 1, 2 LAUNCH_SLOTS + 1) "chunks left to the generic kernel" per launch slot
+    HIP_TRY(hipMalloc((void **)&e->d_error, (2 * LAUNCH_SLOTS + 1) * sizeof(int)));
+    HIP_TRY(hipMemset(e->d_error, 0, (2 * LAUNCH_SLOTS + 1) * sizeof(int)));
+    HIP_TRY(hipMalloc((void **)&e->d_defer, LAUNCH_SLOTS * DEFER_WORDS * sizeof(uint32_t)));
     return NH_OK;
 }
 
@@ -228,6 +230,7 @@ void destroy(Engine *e) {
     if (e->d_counters) (void)hipFree(e->d_counters);
     if (e->d_error) (void)hipFree(e->d_error);
     if (e->d_work) (void)hipFree(e->d_work);
+    if (e->d_defer) (void)hipFree(e->d_defer);
     for (void *p : {e->st.d_bases, e->st.d_offsets, e->st.d_results, e->st.d_taxa, e->st.d_taxa_off})
         if (p) (void)hipFree(p);
     if (e->stream) (void)hipStreamDestroy(e->stream);
@@ -526,7 +529,8 @@ static uint32_t frag_chunk_for(const Engine *e, uint32_t flags, uint64_t n_frag)
 
 int classify_device(Engine *e, const void *d_bases, const void *d_seq_off, uint64_t n_frag,
                          uint32_t flags, double confidence, void *d_results, void *d_kmer_taxa,
-                         const void *d_kmer_taxa_off, void *d_counters, hipStream_t stream) {
+                         const void *d_kmer_taxa_off, void *d_counters, hipStream_t stream,
+                         const void *d_seq_len, uint64_t bases_end) {
     const unsigned slot = e->launch_seq.fetch_add(1) % LAUNCH_SLOTS;
     if (!(confidence >= 0.0 && confidence <= 1.0))
         return set_error(NH_EINVAL, "Confidence score must be in the closed interval [0, 1]");
@@ -539,12 +543,26 @@ int classify_device(Engine *e, const void *d_bases, const void *d_seq_off, uint6
         finish_devdb(e);
         db = e->dev;
     }
-    hipError_t he = launch_classify(db, d_bases, d_seq_off, n_frag,
-                                    (flags & NH_FLAG_PAIRED) ? 2 : 1, confidence, d_results,
-                                    d_kmer_taxa, d_kmer_taxa_off, d_counters, e->d_error + LAUNCH_SLOTS, e->d_error + slot,
-                                    e->d_work + slot,
-                                    frag_chunk_for(e, flags, n_frag), e->grid_blocks,
-                                    stream);
+    LaunchIO io;
+    io.d_bases = d_bases;
+    io.d_seq_off = d_seq_off;
+    io.d_seq_len = d_seq_len;
+    io.bases_end = bases_end;
+    io.n_frag = n_frag;
+    io.mates = (flags & NH_FLAG_PAIRED) ? 2 : 1;
+    io.long_reads = (flags & NH_FLAG_LONG) != 0;
+    io.d_out = d_results;
+    io.d_kmer_taxa = d_kmer_taxa;
+    io.d_kmer_taxa_off = d_kmer_taxa_off;
+    io.d_counters = d_counters;
+    LaunchSlot sl;
+    sl.d_error = e->d_error + LAUNCH_SLOTS;
+    sl.d_pending = e->d_error + slot;
+    sl.d_pending_long = e->d_error + LAUNCH_SLOTS + 1 + slot;
+    sl.d_work = e->d_work + slot;
+    sl.d_defer = e->d_defer + (size_t)slot * DEFER_WORDS;
+    sl.defer_cap_bits = DEFER_WORDS * 32;
+    hipError_t he = launch_classify(db, io, confidence, sl, frag_chunk_for(e, flags, n_frag), e->grid_blocks, stream);
     if (he != hipSuccess) return set_error(NH_EDEVICE, "classify launch: %s", hipGetErrorString(he));
     return NH_OK;
 }

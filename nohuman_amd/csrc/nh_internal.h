@@ -13,6 +13,7 @@
 
 namespace nh {
 constexpr unsigned LAUNCH_SLOTS = 16;  // launches of one engine that may be in flight at once
+constexpr uint64_t DEFER_WORDS = 1u << 15;  // 1 Mi chunks per launch (24 M pairs); larger launches skip the short-read kernel
 }
 
 namespace nh {
@@ -39,6 +40,7 @@ struct Engine {
     uint64_t *d_counters = nullptr;
     int *d_error = nullptr;
     unsigned long long *d_work = nullptr;  // dynamic fragment-chunk counters of k_classify, one per launch slot
+    uint32_t *d_defer = nullptr;           // per launch slot DEFER_WORDS words: chunks the short-read kernel left behind
     std::atomic<unsigned> launch_seq{0};
     hipStream_t stream = nullptr;
     std::vector<uint32_t> parent;
@@ -53,11 +55,8 @@ struct Engine {
 extern thread_local std::string g_last_error;
 int set_error(int code, const char *fmt, ...) __attribute__((format(printf, 2, 3)));
 
-hipError_t launch_classify(const DevDB &db, const void *d_bases, const void *d_seq_off,
-                           uint64_t n_frag, int mates, double confidence, void *d_out,
-                           void *d_kmer_taxa, const void *d_kmer_taxa_off, void *d_counters,
-                           int *d_error, int *d_pending, unsigned long long *d_work, uint32_t frag_chunk,
-                           int grid_blocks, hipStream_t stream);
+hipError_t launch_classify(const DevDB &db, const LaunchIO &io, double confidence, const LaunchSlot &sl,
+                           uint32_t frag_chunk, int grid_blocks, hipStream_t stream);
 int classify_blocks_per_cu();
 hipError_t launch_insert_sequences(const DevDB &db, const void *d_bases, const void *d_seq_off,
                                    uint64_t n_seq, uint32_t value, unsigned long long *d_inserted,
@@ -77,7 +76,8 @@ int refresh_table_copies(Engine *e);  // after the cells of copy 0 changed (load
 int resolve_db_dir(const char *db_dir, std::string &resolved);
 int classify_device(Engine *e, const void *d_bases, const void *d_seq_off, uint64_t n_frag,
                     uint32_t flags, double confidence, void *d_results, void *d_kmer_taxa,
-                    const void *d_kmer_taxa_off, void *d_counters, hipStream_t stream);
+                    const void *d_kmer_taxa_off, void *d_counters, hipStream_t stream,
+                    const void *d_seq_len = nullptr, uint64_t bases_end = 0);
 int classify_host(Engine *e, const uint8_t *bases, const uint64_t *seq_offsets, uint64_t n_frag,
                   uint32_t flags, double confidence, nh_result *results, uint32_t *kmer_taxa,
                   uint64_t *kmer_taxa_offsets, uint64_t kmer_taxa_cap);

@@ -51,11 +51,13 @@ template <bool STD> struct CandPad { static constexpr int value = STD ? 6 : 66; 
 #define NH_NSLOT 4
 #endif
 #ifndef NH_QCAP
-#define NH_QCAP 288  // 5 waves per SIMD with groups of 4 tiles: +6 % over 4 waves / 320 entries (profiles/r02_tuning.txt)
+#define NH_QCAP 256  // 5 waves per SIMD need <= 31 KB of LDS per workgroup (a 32 KB one fits only 4 times: profiles/r02_tuning.txt)
 #endif
 constexpr int NSLOT = NH_NSLOT;  // tiles scanned before one shared probe phase
 constexpr int QCAP = NH_QCAP;  // queue entries per group: a tile joins only if it is sure to fit (< 512)
 constexpr uint32_t QTAX_SKIP = 0xFFFFFFFFu;  // queue entry dropped by the min-hash filter
+
+constexpr int PKW = 18;  // words of a tile's packed stream: 16 of data + the 2 zero words a funnel read may touch
 
 struct alignas(16) SlotLds {  // a scanned tile waiting for its probe results (written by lane 0)
     uint32_t f_lo, f_hi;    // fragment
@@ -81,8 +83,15 @@ struct WaveLdsT {
     uint4 frag_state;        // FragState between post_group calls: nlist, hit_groups, carry_tax, overflow
     SlotLds slot[2][NSLOT];  // [parity of the group][tile]
     uint16_t ps[2][NSLOT][WAVE];  // per-lane packed k-mer state of the tiles in flight
-    uint32_t pk[24];  // 2-bit packed bases: base i' of the tile frame at bit 2*(255-i'); 64 B + zero pad
-    uint32_t pa[24];  // same layout, value 1 where the base is ambiguous
+    // 2-bit packed bases of a tile: base i' of the tile frame at bit 2*(255-i'); 64 B + zero pad.  One per
+    // tile of a group: the short-read kernel encodes a whole batch of tiles before it scans them
+    uint32_t pk[NSLOT][PKW];
+    uint32_t pa[NSLOT][PKW];  // same layout, value 1 where the base is ambiguous
+    // result records of the fragments the last post_group finished: stored to global memory by the next
+    // turn, right before its probe phase (flush_records)
+    uint4 stage_rec[NSLOT];
+    uint64_t stage_f[NSLOT];
+    uint32_t stage_n;
     uint64_t cand[TL + CandPad<STD>::value];
     uint64_t q[2][QCAP];  // [parity] queue: run-start minimizers, hashed in place (see probe_queue)
     QTax<STD> qtax;       // taxon found for each queued run (generic kernel only, see tax_at)
@@ -181,15 +190,15 @@ __device__ __forceinline__ uint32_t wave_max(uint32_t v) {
     return v;
 }
 
-// 4 ASCII bytes -> one byte of packed 2-bit codes (first base in bits 7:6); `suspect` is set when
-// any of the 4 bytes is not one of ACGTacgt (SWAR, no per-byte work on the common path)
-__device__ __forceinline__ uint32_t encode4(uint32_t w, bool &suspect) {
+// 4 ASCII bytes -> one byte of packed 2-bit codes (first base in bits 7:6); `diff` is non-zero in
+// every byte that is not one of ACGTacgt (SWAR, no per-byte work on the common path)
+__device__ __forceinline__ uint32_t encode4(uint32_t w, uint32_t &diff) {
     const uint32_t up = w & 0xDFDFDFDFu;          // fold case
     const uint32_t x = (up >> 1) & 0x03030303u;   // A0 C1 G3 T2
     const uint32_t code = x ^ ((x >> 1) & 0x01010101u);  // A0 C1 G2 T3
     const uint32_t tbit = (x >> 1) & ~x & 0x01010101u;   // 1 where the byte decodes as T
     const uint32_t recon = (0x41414141u | (x << 1)) ^ (tbit * 0x11u);  // canonical letter of code
-    suspect = recon != up;
+    diff = recon ^ up;
     return (code * 0x40100401u) >> 24;
 }
 
@@ -223,8 +232,6 @@ struct FragState {
     bool overflow;
 };
 
-// One tile: l-mers [q0, q0+nlt) / k-mers [q0, q0+nqt) of a sequence whose tile frame starts `sh`
-// bytes into the dword stream `w` (4 bases per lane).  kt = index in kmer_taxa of k-mer q0.
 #define NH_STAMP(i)                                        \
     do {                                                   \
         if (PROF) {                                        \
@@ -234,20 +241,41 @@ struct FragState {
         }                                                  \
     } while (0)
 
-// SCAN one tile: l-mers [q0, q0+nlt) / k-mers [q0, q0+nqt) of a sequence whose tile frame starts
-// `sh` bytes into the dword stream `w` (4 bases per lane).  Appends the run-start minimizers to
+// ENCODE one tile into the packed streams of `slot`: 4 bases per lane (dword stream `w`, tile frame
+// starting `sh` bytes in), of which bytes [sh, sh + nbases) belong to this sequence.  What follows them
+// is whatever lies behind the sequence in the caller's buffer (the next read, or -- when records are
+// classified in place inside their FASTQ text -- a newline and the quality line): it must neither count
+// as ambiguous nor send the tile down the slow path.  Returns "the tile has an ambiguous base".
+template <bool STD>
+__device__ __forceinline__ bool encode_tile(WaveLdsT<STD> &S, const int lane, const uint32_t slot, const uint32_t w,
+                                            const uint32_t sh, const uint32_t nbases) {
+    uint32_t diff;
+    const uint32_t codes = encode4(w, diff);
+    reinterpret_cast<uint8_t *>(S.pk[slot])[63 - lane] = (uint8_t)codes;
+    // bytes of this lane's dword that are bases of the sequence: frame positions [4 lane, 4 lane + 4) cut to [sh, hi)
+    const uint32_t p0 = 4u * (uint32_t)lane, hi = sh + nbases;
+    uint32_t m = 0xFFFFFFFFu;
+    if (p0 < sh) m = sh - p0 >= 4u ? 0u : m << (8u * (sh - p0));
+    if (p0 + 4u > hi) m = hi <= p0 ? 0u : m & (0xFFFFFFFFu >> (8u * (p0 + 4u - hi)));
+    bool has_amb = __ballot((diff & m) != 0) != 0;
+    if (has_amb) {  // exact flags, restricted to the bases of this tile
+        const uint32_t bad = ambig4(w, p0, sh, hi);
+        reinterpret_cast<uint8_t *>(S.pa[slot])[63 - lane] = (uint8_t)bad;
+    }
+    return has_amb;
+}
+
+// SCAN one encoded tile (streams of `slot`): l-mers [q0, q0+nlt) / k-mers [q0, q0+nqt) of a sequence
+// whose tile frame starts `sh` bytes into its dword stream.  Appends the run-start minimizers to
 // S.q[par][qbase ...], returns their number, and leaves in `ps` the lane's packed per-k-mer state
 // (bit0/1 = k-mer 2t / 2t+1 is valid and unambiguous, bit 2 = k-mer 2t+1 starts a run, bits 3-10 = 1 + index of the run
 // that covers k-mer 2t, 0 = continuation of the run that entered the tile).
 template <bool STD, bool PROF>
-__device__ __forceinline__ uint32_t scan_tile(KArgsP ap, WaveLdsT<STD> &S, const int lane,
-                                              const uint32_t w,
-                                              const uint32_t sh, const uint32_t nlt,
+__device__ __forceinline__ uint32_t scan_body(KArgsP ap, WaveLdsT<STD> &S, const int lane, const uint32_t slot,
+                                              const bool has_amb, const uint32_t sh, const uint32_t nlt,
                                               const uint32_t nqt, const uint32_t par,
                                               const uint32_t qbase, uint64_t &carry_min,
                                               uint32_t &ps, int &last_lane,
-                                              const uint32_t *pf_ptr, const bool pf_on,
-                                              uint32_t &w_pref,
                                               uint64_t (&prof)[12], uint64_t &tprev) {
     ap = launder(ap);
     const uint32_t L = STD ? 31u : ap->db.l;
@@ -256,27 +284,11 @@ __device__ __forceinline__ uint32_t scan_tile(KArgsP ap, WaveLdsT<STD> &S, const
     const int RV = STD ? 1 : ap->db.revcom_version;
     const uint64_t SPACED = ap->db.spaced_mask, TOGGLE = ap->db.toggle;
 
-    // ---- 1. bases -> packed 2-bit stream -------------------------------------------------------
-    bool suspect;
-    const uint32_t codes = encode4(w, suspect);
-    reinterpret_cast<uint8_t *>(S.pk)[63 - lane] = (uint8_t)codes;
-    bool has_amb = __ballot(suspect) != 0;
-    if (has_amb) {  // exact flags, restricted to the bases of this tile
-        const uint32_t bad = ambig4(w, 4u * lane, sh, sh + nlt + L - 1);
-        has_amb = __ballot(bad != 0) != 0;
-        reinterpret_cast<uint8_t *>(S.pa)[63 - lane] = (uint8_t)bad;
-    }
-    wave_sync();
-    // `w` has been consumed: start the load of the next tile's bases now, so that no wait for
-    // `w` can be widened into a wait for the prefetch (vmcnt retires loads in issue order)
-    if (pf_on) w_pref = *pf_ptr;
-    NH_STAMP(1);
-
     // ---- 2. two l-mers per lane -> candidates --------------------------------------------------
     {
         const uint32_t j1 = sh + 2u * lane + L;  // frame index of the last base of l-mer 2t+1
         const uint32_t s = 2u * (255u - j1);
-        const uint64_t wv = funnel_read(S.pk, s);
+        const uint64_t wv = funnel_read(S.pk[slot], s);
         const uint64_t lm1 = wv & LMASK;
         const uint64_t lm0 = (wv >> 2) & LMASK;
         uint64_t rc0, rc1;
@@ -292,7 +304,7 @@ __device__ __forceinline__ uint32_t scan_tile(KArgsP ap, WaveLdsT<STD> &S, const
         const uint64_t c1 = (umin64(lm1, rc1) & SPACED) ^ TOGGLE;
         bool dead0 = 2u * lane >= nlt, dead1 = 2u * lane + 1 >= nlt;
         if (has_amb) {
-            const uint64_t wa = funnel_read(S.pa, s);
+            const uint64_t wa = funnel_read(S.pa[slot], s);
             dead1 |= (wa & LMASK) != 0;
             dead0 |= ((wa >> 2) & LMASK) != 0;
         }
@@ -406,6 +418,29 @@ __device__ __forceinline__ uint32_t scan_tile(KArgsP ap, WaveLdsT<STD> &S, const
     }
     NH_STAMP(3);
     return nruns;
+}
+
+
+// One tile of the generic kernel: encode (slot 0), start the prefetch of a later tile, scan.
+template <bool STD, bool PROF>
+__device__ __forceinline__ uint32_t scan_tile(KArgsP ap, WaveLdsT<STD> &S, const int lane,
+                                              const uint32_t w,
+                                              const uint32_t sh, const uint32_t nlt,
+                                              const uint32_t nqt, const uint32_t par,
+                                              const uint32_t qbase, uint64_t &carry_min,
+                                              uint32_t &ps, int &last_lane,
+                                              const uint32_t *pf_ptr, const bool pf_on,
+                                              uint32_t &w_pref,
+                                              uint64_t (&prof)[12], uint64_t &tprev) {
+    const uint32_t L = STD ? 31u : launder(ap)->db.l;
+    const bool has_amb = encode_tile<STD>(S, lane, 0u, w, sh, nlt + L - 1);
+    wave_sync();
+    // `w` has been consumed: start the load of the next tile's bases now, so that no wait for
+    // `w` can be widened into a wait for the prefetch (vmcnt retires loads in issue order)
+    if (pf_on) w_pref = *pf_ptr;
+    NH_STAMP(1);
+    return scan_body<STD, PROF>(ap, S, lane, 0u, has_amb, sh, nlt, nqt, par, qbase, carry_min, ps, last_lane, prof,
+                                tprev);
 }
 
 // Where the taxon of queued run r is stored: the generic kernel has its own array (it also marks
@@ -844,83 +879,41 @@ __device__ __forceinline__ uint32_t resolve_tree(KArgsP ap, WaveLdsT<STD> &S, co
     return call;
 }
 
-constexpr uint32_t PREF_LANES = 42;  // dwords a tile can need: (3 + 128 + 30 + 3) / 4 <= 41
-
-__device__ __forceinline__ uint32_t uni(uint32_t v) { return __builtin_amdgcn_readfirstlane(v); }
-
-template <bool LINEAR, bool STD, bool CAP32, bool PROF, bool BIG>
-__global__ __launch_bounds__(WAVE * WAVES_PER_BLOCK, BIG ? 1 : (STD ? NH_MIN_WAVES : 3)) void k_classify(const KArgs args_by_kernarg_pointer) {
-    KArgsP ap = (KArgsP)__builtin_amdgcn_kernarg_segment_ptr();
-    // BIG variant: only runs when some fragment overflowed the 64-entry list of the hot variant
-    if (BIG && ap->pending[0] == 0) return;
-    __shared__ WaveLdsT<STD> lds_all[WAVES_PER_BLOCK];
-    __shared__ uint32_t big_lists[BIG ? WAVES_PER_BLOCK * 3 * BIG_LIST_CAP : 1];
-    const int lane = threadIdx.x & 63;
-    const int wib = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    WaveLdsT<STD> &S = lds_all[wib];
-    TaxList TLI = {nullptr, nullptr, nullptr, 0};  // used by the BIG variant only
-    if constexpr (BIG) {
-        TLI.tax = &big_lists[(wib * 3 + 0) * BIG_LIST_CAP];
-        TLI.cnt = &big_lists[(wib * 3 + 1) * BIG_LIST_CAP];
-        TLI.score = &big_lists[(wib * 3 + 2) * BIG_LIST_CAP];
-        TLI.cap = BIG_LIST_CAP;
-    }
-
-    // one-time LDS init: zero pads of the packed streams, sentinel tail of the candidate array
-    if (lane < 24) {
-        S.pk[lane] = 0;
-        S.pa[lane] = 0;
+// one-time LDS init of a wave: zero pads of the packed streams, sentinel tail of the candidate array
+template <bool STD>
+__device__ __forceinline__ void init_wave_lds(WaveLdsT<STD> &S, const int lane) {
+    if (lane == 0) S.stage_n = 0;
+    for (int i = lane; i < NSLOT * PKW; i += 64) {
+        (&S.pk[0][0])[i] = 0;
+        (&S.pa[0][0])[i] = 0;
     }
     for (int i = lane; i < CandPad<STD>::value; i += 64) S.cand[TL + i] = NH_FULL;
     wave_sync();
+}
 
-    const uint32_t K = STD ? 35u : ap->db.k;
-    const uint32_t L = STD ? 31u : ap->db.l;
-    const uint32_t TQ = TL - (STD ? 4u : ap->db.window);  // k-mers per tile
-    const int mates = ap->mates;
-    const uint64_t n_frag = ap->n_frag;
-    const bool reset_per_mate = ap->db.reset_per_mate != 0;
-    // dword index of the last dword the caller guarantees readable (8 bytes of slack, see ABI),
-    // parked in LDS: it is needed once per tile, not worth two SGPRs for the whole kernel
-    if (lane == 0) S.last_dw = (ap->seq_off[n_frag * (uint64_t)mates] + 4) >> 2;
-    const uint32_t pl = (uint32_t)lane < PREF_LANES ? (uint32_t)lane : PREF_LANES - 1;
+__device__ __forceinline__ uint32_t uni(uint32_t v) { return __builtin_amdgcn_readfirstlane(v); }
 
-    // the dword stream of the tile that starts at byte g0: 4 bases per lane, coalesced
-    auto tile_ptr = [&](uint64_t g0) -> const uint32_t * {
-        KArgsP a3 = launder(ap);
-        const uint64_t last_dw = S.last_dw;
-        uint64_t dw = (g0 >> 2) + pl;
-        dw = dw < last_dw ? dw : last_dw;
-        return reinterpret_cast<const uint32_t *>(a3->bases) + dw;
-    };
+// Stores the records staged by the last post_group (lane i = record i).  Called right before a probe
+// phase: the stores complete in the shadow of the first probe round trip.
+template <bool STD>
+__device__ __forceinline__ void flush_records(KArgsP ap, WaveLdsT<STD> &S, const int lane) {
+    const uint32_t n = uni(S.stage_n);
+    if (n == 0) return;
+    if ((uint32_t)lane < n) {
+        const uint64_t f = S.stage_f[lane];
+        *reinterpret_cast<uint4 *>(&launder(ap)->out[f]) = S.stage_rec[lane];
+    }
+    wave_sync();
+    if (lane == 0) S.stage_n = 0;
+}
 
-    if (lane < 4) S.acc[lane] = 0;
-    bool bad_input = false;
-    uint64_t prof[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-    uint64_t tprev = PROF ? __builtin_readcyclecounter() : 0;
-
-    // speculative prefetch of the bases of the next two tiles (byte offset tags, loaded dwords)
-    uint32_t tag1 = 0, tag2 = 0;  // 1 + byte offset relative to the chunk's first base; 0 = nothing loaded
-    uint32_t w1 = 0, w2 = 0;
-
-    // Two groups of tiles are in flight: the one being scanned / probed (parity `par`) and the
-    // previous one, which is post-processed only after the probe phase of its successor.
-    uint32_t par = 0;
-    uint32_t nslot_new = 0;     // tiles scanned into the current group (descriptors in S.slot[par])
-    uint32_t nslot_old = 0;     // tiles of the previous group still to be post-processed
-    uint32_t qn = 0;            // queue entries of the current group
-    LaneLookup lk;
-    lk.busy = 0;
-    lk.r = 0;
-    lk.pos = lk.first_pos = lk.step = 0;
-    lk.ckey = 0;
-    lk.budget = 0;
-
-    // accumulation state of the fragment being post-processed: parked in LDS between post_group calls
-    // (it is wave-uniform and idle during scan and probe: four scalar registers less to keep there)
-    if (lane == 0) S.frag_state = make_uint4(0, 0, 0, 0);
-    // finish the tiles of group `pp` (and each fragment whose last tile is among them)
-    auto post_group = [&](const uint32_t pp, const uint32_t nslot) {
+// POST a group: finish the tiles of group `pp` (and each fragment whose last tile is among them).
+// The accumulation state of the fragment being post-processed is parked in LDS between calls (it is
+// wave-uniform and idle during scan and probe: four scalar registers less to keep there).
+template <bool STD, bool BIG, bool PROF>
+__device__ __forceinline__ void post_group(KArgsP ap, WaveLdsT<STD> &S, const TaxList &TLI, const int lane,
+                                           const int mates, const bool reset_per_mate, const uint32_t pp,
+                                           const uint32_t nslot, uint64_t (&prof)[12], uint64_t &tprev) {
         KArgsP a2 = launder(ap);
         FragState st;
         {
@@ -979,7 +972,12 @@ __global__ __launch_bounds__(WAVE * WAVES_PER_BLOCK, BIG ? 1 : (STD ? NH_MIN_WAV
                     rec.y = total_kmers;
                     rec.z = clade_hits;
                     rec.w = st.hit_groups;
-                    *reinterpret_cast<uint4 *>(&a2->out[f]) = rec;
+                    // staged: a store issued here would still be in flight when the next scan waits for
+                    // its bases (vmcnt counts stores too) -- a whole memory round trip per group
+                    const uint32_t sn = S.stage_n;
+                    S.stage_rec[sn] = rec;
+                    S.stage_f[sn] = f;
+                    S.stage_n = sn + 1;
                     if (kmer_taxa && mates == 2)
                         kmer_taxa[a2->kmer_taxa_off[f] + d_nk0] = TAXON_MATE_BORDER;
                     if (defer) atomicMax(&a2->pending[0], 1);               // work for the BIG variant
@@ -991,13 +989,83 @@ __global__ __launch_bounds__(WAVE * WAVES_PER_BLOCK, BIG ? 1 : (STD ? NH_MIN_WAV
         }
         if (lane == 0) S.frag_state = make_uint4(st.nlist, st.hit_groups, st.carry_tax, st.overflow ? 1u : 0u);
         NH_STAMP(7);
+    }
+
+constexpr uint32_t PREF_LANES = 42;  // dwords a tile can need: (3 + 128 + 30 + 3) / 4 <= 41
+
+template <bool LINEAR, bool STD, bool CAP32, bool PROF, bool BIG>
+__global__ __launch_bounds__(WAVE * WAVES_PER_BLOCK, BIG ? 1 : (STD ? NH_MIN_WAVES : 3)) void k_classify(const KArgs args_by_kernarg_pointer) {
+    KArgsP ap = (KArgsP)__builtin_amdgcn_kernarg_segment_ptr();
+    // BIG variant: only runs when some fragment overflowed the 64-entry list of the hot variant
+    if (BIG && ap->pending[0] == 0) return;
+    // after the short-read kernel: only the chunks it left behind (none: nothing to do)
+    const bool only_deferred = ap->only_deferred != 0;
+    if (only_deferred && ap->pending_long[0] == 0) return;
+    __shared__ WaveLdsT<STD> lds_all[WAVES_PER_BLOCK];
+    __shared__ uint32_t big_lists[BIG ? WAVES_PER_BLOCK * 3 * BIG_LIST_CAP : 1];
+    const int lane = threadIdx.x & 63;
+    const int wib = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    WaveLdsT<STD> &S = lds_all[wib];
+    TaxList TLI = {nullptr, nullptr, nullptr, 0};  // used by the BIG variant only
+    if constexpr (BIG) {
+        TLI.tax = &big_lists[(wib * 3 + 0) * BIG_LIST_CAP];
+        TLI.cnt = &big_lists[(wib * 3 + 1) * BIG_LIST_CAP];
+        TLI.score = &big_lists[(wib * 3 + 2) * BIG_LIST_CAP];
+        TLI.cap = BIG_LIST_CAP;
+    }
+
+    init_wave_lds<STD>(S, lane);
+
+    const uint32_t K = STD ? 35u : ap->db.k;
+    const uint32_t L = STD ? 31u : ap->db.l;
+    const uint32_t TQ = TL - (STD ? 4u : ap->db.window);  // k-mers per tile
+    const int mates = ap->mates;
+    const uint64_t n_frag = ap->n_frag;
+    const bool reset_per_mate = ap->db.reset_per_mate != 0;
+    // dword index of the last dword the caller guarantees readable (8 bytes of slack, see ABI),
+    // parked in LDS: it is needed once per tile, not worth two SGPRs for the whole kernel
+    const bool inplace = ap->seq_len != nullptr;
+    if (lane == 0) S.last_dw = ((inplace ? ap->bases_end : ap->seq_off[n_frag * (uint64_t)mates]) + 4) >> 2;
+    const uint32_t pl = (uint32_t)lane < PREF_LANES ? (uint32_t)lane : PREF_LANES - 1;
+
+    // the dword stream of the tile that starts at byte g0: 4 bases per lane, coalesced
+    auto tile_ptr = [&](uint64_t g0) -> const uint32_t * {
+        KArgsP a3 = launder(ap);
+        const uint64_t last_dw = S.last_dw;
+        uint64_t dw = (g0 >> 2) + pl;
+        dw = dw < last_dw ? dw : last_dw;
+        return reinterpret_cast<const uint32_t *>(a3->bases) + dw;
     };
 
+    if (lane < 4) S.acc[lane] = 0;
+    bool bad_input = false;
+    uint64_t prof[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    uint64_t tprev = PROF ? __builtin_readcyclecounter() : 0;
+
+    // speculative prefetch of the bases of the next two tiles (byte offset tags, loaded dwords)
+    uint32_t tag1 = 0, tag2 = 0;  // 1 + byte offset relative to the chunk's first base; 0 = nothing loaded
+    uint32_t w1 = 0, w2 = 0;
+
+    // Two groups of tiles are in flight: the one being scanned / probed (parity `par`) and the
+    // previous one, which is post-processed only after the probe phase of its successor.
+    uint32_t par = 0;
+    uint32_t nslot_new = 0;     // tiles scanned into the current group (descriptors in S.slot[par])
+    uint32_t nslot_old = 0;     // tiles of the previous group still to be post-processed
+    uint32_t qn = 0;            // queue entries of the current group
+    LaneLookup lk;
+    lk.busy = 0;
+    lk.r = 0;
+    lk.pos = lk.first_pos = lk.step = 0;
+    lk.ckey = 0;
+    lk.budget = 0;
+
+    if (lane == 0) S.frag_state = make_uint4(0, 0, 0, 0);
     // group complete (or input exhausted): hash + probe it -- which also resolves what is left of
     // the previous group -- then post-process the previous group and switch buffers
     auto turn = [&]() {
+        flush_records<STD>(ap, S, lane);
         probe_queue<LINEAR, STD, CAP32, PROF>(ap, S, lane, par, qn, lk, !BIG, prof, tprev);
-        if (nslot_old) post_group(par ^ 1u, nslot_old);
+        if (nslot_old) post_group<STD, BIG, PROF>(ap, S, TLI, lane, mates, reset_per_mate, par ^ 1u, nslot_old, prof, tprev);
         nslot_old = nslot_new;
         par ^= 1u;
         nslot_new = 0;
@@ -1015,18 +1083,30 @@ __global__ __launch_bounds__(WAVE * WAVES_PER_BLOCK, BIG ? 1 : (STD ? NH_MIN_WAV
         if (cbeg >= n_frag) break;
         if (lane == 0) next_chunk = atomicAdd(ap->work, (unsigned long long)frag_chunk);
         const uint32_t ncf = cbeg + frag_chunk <= n_frag ? frag_chunk : (uint32_t)(n_frag - cbeg);
+        if (only_deferred) {  // second pass: only what the short-read kernel left behind
+            const uint64_t chunk = cbeg / frag_chunk;
+            if (!((launder(ap)->defer_bits[chunk >> 5] >> (chunk & 31)) & 1u)) continue;
+        }
         // all sequence offsets of the chunk with ONE coalesced load (lane i = offset i), kept
         // relative to the chunk's first byte so that everything per fragment is 32-bit
-        const uint32_t nof = ncf * (uint32_t)mates + 1;
-        const uint64_t off64 = launder(ap)->seq_off[cbeg * (uint64_t)mates + ((uint32_t)lane < nof ? (uint32_t)lane : nof - 1)];
+        const uint32_t nseq = ncf * (uint32_t)mates;
+        const uint32_t nof = inplace ? nseq : nseq + 1;
+        const uint64_t sidx = cbeg * (uint64_t)mates + ((uint32_t)lane < nof ? (uint32_t)lane : nof - 1);
+        const uint64_t off64 = launder(ap)->seq_off[sidx];
         const uint64_t cbase = readlane64(off64, 0);
         const uint64_t crel = off64 - cbase;
         if (__ballot((crel >> 32) != 0)) bad_input = true;  // a chunk of 4 Gbases and more
-        if (!BIG && (uint32_t)lane == nof - 1) {  // this lane holds the chunk's last offset = its bases
-            S.acc[CNT_FRAGMENTS] += ncf;
-            S.acc[CNT_BASES] += crel;
-        }
         const uint32_t off_v = (uint32_t)crel;
+        // lane i: length of sequence i of the chunk
+        uint32_t len_v = inplace ? launder(ap)->seq_len[sidx] : (uint32_t)__shfl_down((int)off_v, 1, 64) - off_v;
+        if ((uint32_t)lane >= nseq) len_v = 0;
+        if (!BIG) {
+            const uint32_t cb = wave_sum(len_v);
+            if (lane == 0) {
+                S.acc[CNT_FRAGMENTS] += ncf;
+                S.acc[CNT_BASES] += cb;
+            }
+        }
         tag1 = tag2 = 0;  // tags are relative to the chunk
         for (uint32_t fc = 0; fc < ncf; fc++) {
             NH_STAMP(8);
@@ -1034,8 +1114,9 @@ __global__ __launch_bounds__(WAVE * WAVES_PER_BLOCK, BIG ? 1 : (STD ? NH_MIN_WAV
             const int oi = (int)fc * mates;
             const uint32_t o0 = __builtin_amdgcn_readlane(off_v, oi);
             const uint32_t o1 = __builtin_amdgcn_readlane(off_v, oi + 1);
-            const uint32_t o2 = mates == 2 ? __builtin_amdgcn_readlane(off_v, oi + 2) : o1;
-            const uint32_t n0 = o1 - o0, n1 = o2 - o1;
+            const uint32_t o2 = mates == 2 ? __builtin_amdgcn_readlane(off_v, oi + 2) : o1;  // prefetch only
+            const uint32_t n0 = __builtin_amdgcn_readlane(len_v, oi);
+            const uint32_t n1 = mates == 2 ? __builtin_amdgcn_readlane(len_v, oi + 1) : 0u;
             const uint32_t nk0 = n0 >= K ? n0 - K + 1 : 0;
             const uint32_t nk1 = n1 >= K ? n1 - K + 1 : 0;
             if (BIG) {  // only the fragments the hot variant gave up on
@@ -1140,6 +1221,230 @@ __global__ __launch_bounds__(WAVE * WAVES_PER_BLOCK, BIG ? 1 : (STD ? NH_MIN_WAV
     // drain: probe what is left, post-process the last two groups
     turn();
     turn();
+    flush_records<STD>(ap, S, lane);
+
+    wave_sync();
+    if (lane == 0) {
+        unsigned long long *const counters = ap->counters;
+        int *const error_flag = ap->error_flag;
+        if (PROF && counters)
+            for (int i = 0; i < 12; i++) atomicAdd(&counters[CNT_N + i], (unsigned long long)prof[i]);
+        if (counters) {
+            atomicAdd(&counters[CNT_FRAGMENTS], S.acc[CNT_FRAGMENTS]);
+            atomicAdd(&counters[CNT_CLASSIFIED], S.acc[CNT_CLASSIFIED]);
+            atomicAdd(&counters[CNT_BASES], S.acc[CNT_BASES]);
+            atomicAdd(&counters[CNT_LOOKUPS], S.acc[CNT_LOOKUPS]);
+        }
+        if (bad_input) atomicOr(&error_flag[0], 2);
+    }
+}
+
+// ---- short-read kernel --------------------------------------------------------------------------------
+// The same path for the case nohuman meets most: every sequence of a chunk fits ONE tile (<= 158 bases
+// at k=35/l=31: Illumina reads), default database geometry, linear probing, 32-bit cell positions.
+// What that buys over the generic loop nest (fragment x mate x tile, any length):
+//   * tile i of a chunk IS sequence i: geometry, descriptors and the prefetch address come straight from
+//     the lanes that hold the chunk's offsets and lengths -- no iterator state in scalar registers;
+//   * tiles are taken in batches of NSLOT: all of a batch are encoded first, and the moment a tile's
+//     dword is consumed the load of the tile NSLOT further on is issued into the same register -- it has
+//     a whole probe phase to arrive, and no scan ever waits for bases;
+//   * one call site of the probe / post code (the drain of the pipeline runs through it as well).
+// A chunk that holds a longer sequence is not touched: its bit is set in defer_bits and the generic
+// kernel, launched right behind, classifies exactly those chunks (none: it returns at once).
+constexpr uint32_t SHORT_MAX = 158;  // TQ + K - 1 bases: at most one tile of 124 k-mers
+
+template <bool PROF>
+__global__ __launch_bounds__(WAVE * WAVES_PER_BLOCK, PROF ? 4 : NH_MIN_WAVES) void k_classify_short(const KArgs args_by_kernarg_pointer) {
+    constexpr bool STD = true;
+    KArgsP ap = (KArgsP)__builtin_amdgcn_kernarg_segment_ptr();
+    __shared__ WaveLdsT<STD> lds_all[WAVES_PER_BLOCK];
+    const int lane = threadIdx.x & 63;
+    const int wib = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    WaveLdsT<STD> &S = lds_all[wib];
+    const TaxList TLI = {nullptr, nullptr, nullptr, 0};
+    init_wave_lds<STD>(S, lane);
+
+    constexpr uint32_t K = 35, L = 31;
+    const int mates = ap->mates;
+    const uint64_t n_frag = ap->n_frag;
+    const bool reset_per_mate = ap->db.reset_per_mate != 0;
+    const bool inplace = ap->seq_len != nullptr;
+    if (lane == 0) S.last_dw = ((inplace ? ap->bases_end : ap->seq_off[n_frag * (uint64_t)mates]) + 4) >> 2;
+    const uint32_t pl = (uint32_t)lane < PREF_LANES ? (uint32_t)lane : PREF_LANES - 1;
+    auto tile_ptr = [&](uint64_t g0) -> const uint32_t * {
+        KArgsP a3 = launder(ap);
+        const uint64_t last_dw = S.last_dw;
+        uint64_t dw = (g0 >> 2) + pl;
+        dw = dw < last_dw ? dw : last_dw;
+        return reinterpret_cast<const uint32_t *>(a3->bases) + dw;
+    };
+    if (lane < 4) S.acc[lane] = 0;
+    bool bad_input = false;
+    uint64_t prof[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    uint64_t tprev = PROF ? __builtin_readcyclecounter() : 0;
+
+    uint32_t par = 0, nslot_new = 0, nslot_old = 0, qn = 0;
+    LaneLookup lk;
+    lk.busy = 0;
+    lk.r = 0;
+    lk.pos = lk.first_pos = lk.step = 0;
+    lk.ckey = 0;
+    lk.budget = 0;
+    if (lane == 0) S.frag_state = make_uint4(0, 0, 0, 0);
+
+    const uint32_t frag_chunk = ap->frag_chunk;
+    unsigned long long next_chunk = 0;  // lane 0: first fragment of the chunk claimed ahead
+    if (lane == 0) next_chunk = atomicAdd(ap->work, (unsigned long long)frag_chunk);
+
+    // the chunk being worked on
+    uint64_t cbeg = 0, cbase = 0;
+    uint32_t nseq = 0, t = 0;   // sequences of the chunk, first sequence of the next batch
+    uint32_t off_v = 0, len_v = 0;  // lane i: offset (relative to cbase) and length of sequence i
+    uint32_t w[NSLOT];          // dword streams of the next batch's tiles, loaded one batch ahead
+#pragma unroll
+    for (int j = 0; j < NSLOT; j++) w[j] = 0;
+    uint64_t carry_min = NH_FULL;
+    uint32_t drain = 0;         // input exhausted: two more turns empty the group pipeline
+    for (;;) {
+        bool batch = true;
+        if (t >= nseq) {  // next chunk
+            NH_STAMP(8);
+            const uint64_t c0 = readlane64(next_chunk, 0);
+            if (c0 >= n_frag) {
+                if (drain == 2) break;
+                drain++;
+                batch = false;
+            } else {
+                if (lane == 0) next_chunk = atomicAdd(ap->work, (unsigned long long)frag_chunk);
+                cbeg = c0;
+                const uint32_t ncf = cbeg + frag_chunk <= n_frag ? frag_chunk : (uint32_t)(n_frag - cbeg);
+                const uint32_t ns = ncf * (uint32_t)mates;
+                const uint32_t nof = inplace ? ns : ns + 1;
+                const uint64_t sidx = cbeg * (uint64_t)mates + ((uint32_t)lane < nof ? (uint32_t)lane : nof - 1);
+                const uint64_t off64 = launder(ap)->seq_off[sidx];
+                cbase = readlane64(off64, 0);
+                const uint64_t crel = off64 - cbase;
+                if (__ballot((crel >> 32) != 0)) bad_input = true;
+                off_v = (uint32_t)crel;
+                len_v = inplace ? launder(ap)->seq_len[sidx] : (uint32_t)__shfl_down((int)off_v, 1, 64) - off_v;
+                if ((uint32_t)lane >= ns) len_v = 0;
+                if (__ballot(len_v > SHORT_MAX)) {  // a longer sequence: the whole chunk goes to the generic kernel
+                    if (lane == 0) {
+                        const uint64_t chunk = cbeg / frag_chunk;
+                        atomicOr(&launder(ap)->defer_bits[chunk >> 5], 1u << (chunk & 31));
+                        atomicMax(launder(ap)->pending_long, 1);
+                    }
+                    nseq = 0;
+                    t = 0;
+                    continue;
+                }
+                const uint32_t cb = wave_sum(len_v);
+                if (lane == 0) {
+                    S.acc[CNT_FRAGMENTS] += ncf;
+                    S.acc[CNT_BASES] += cb;
+                }
+                nseq = ns;
+                t = 0;
+                // the first batch of a chunk is the only one whose bases are not loaded a batch ahead
+#pragma unroll
+                for (int j = 0; j < NSLOT; j++)
+                    if ((uint32_t)j < nseq) w[j] = *tile_ptr(cbase + __builtin_amdgcn_readlane(off_v, j));
+            }
+        }
+        uint32_t ambmask = 0;
+        if (batch) {
+            NH_STAMP(0);
+            // ---- batch prologue: encode tiles t .. t+NSLOT-1, start the loads of the batch after ----
+#pragma unroll
+            for (int j = 0; j < NSLOT; j++) {
+                const uint32_t i = t + (uint32_t)j;
+                if (i < nseq) {
+                    const uint32_t o = __builtin_amdgcn_readlane(off_v, i), n = __builtin_amdgcn_readlane(len_v, i);
+                    const bool amb = encode_tile<STD>(S, lane, (uint32_t)j, w[j], (uint32_t)(cbase + o) & 3u, n);
+                    ambmask |= (amb ? 1u : 0u) << j;
+                }
+                const uint32_t i2 = i + NSLOT;
+                if (i2 < nseq) w[j] = *tile_ptr(cbase + __builtin_amdgcn_readlane(off_v, i2));
+            }
+            wave_sync();
+            NH_STAMP(1);
+        }
+        // ---- the batch's tiles; j == NSLOT is the end-of-batch turn --------------------------------
+        for (uint32_t j = 0; j <= (uint32_t)NSLOT; j++) {
+            const uint32_t i = t + j;
+            if (batch && j < (uint32_t)NSLOT && i < nseq) {
+                const uint32_t o = __builtin_amdgcn_readlane(off_v, i), n = __builtin_amdgcn_readlane(len_v, i);
+                const uint32_t nk = n >= K ? n - K + 1 : 0;
+                const uint32_t m = mates == 2 ? (i & 1u) : 0u;
+                const uint64_t f = cbeg + (mates == 2 ? i >> 1 : i);
+                uint32_t nk_other = 0;
+                if (mates == 2) {
+                    const uint32_t no = __builtin_amdgcn_readlane(len_v, i ^ 1u);
+                    nk_other = no >= K ? no - K + 1 : 0;
+                }
+                const uint32_t nk0 = m ? nk_other : nk, nk1 = mates == 2 ? (m ? nk : nk_other) : 0u;
+                if (nk0 + nk1 == 0) {  // no k-mer at all: all-zero record, only the mate border
+                    if (lane == 0 && m == (uint32_t)mates - 1) {
+                        KArgsP a2 = launder(ap);
+                        uint4 rec = {0, 0, 0, 0};
+                        *reinterpret_cast<uint4 *>(&a2->out[f]) = rec;
+                        uint32_t *const kmer_taxa = a2->kmer_taxa;
+                        if (kmer_taxa && mates == 2) kmer_taxa[a2->kmer_taxa_off[f]] = TAXON_MATE_BORDER;
+                    }
+                } else if (nk != 0) {
+                    // kraken2's last_minimizer: fresh per fragment, and per mate when the DB says so
+                    if (m == 0 || nk0 == 0 || reset_per_mate) carry_min = NH_FULL;
+                    const bool frag_first = m == 0 || nk0 == 0;
+                    const bool frag_end = m == (uint32_t)mates - 1 || nk1 == 0;
+                    const bool mate_end = m == 0 && mates == 2 && nk1 != 0;
+                    uint32_t ps;
+                    int last_lane;
+                    const uint32_t nruns = scan_body<STD, PROF>(ap, S, lane, j, (ambmask >> j) & 1u,
+                                                                (uint32_t)(cbase + o) & 3u, n - L + 1, nk, par, qn,
+                                                                carry_min, ps, last_lane, prof, tprev);
+                    if (lane == 0) {
+                        uint4 d0, d1, d2;  // layout of SlotLds
+                        d0.x = (uint32_t)f;
+                        d0.y = (uint32_t)(f >> 32);
+                        d0.z = m ? nk0 + 1 : 0;  // k-mer index of the tile within its fragment
+                        d0.w = 0;
+                        d1.x = nk;
+                        d1.y = qn;
+                        d1.z = nruns;
+                        d1.w = 0;
+                        d2.x = (uint32_t)last_lane;
+                        d2.y = (frag_end ? 1u : 0u) | (mate_end ? 2u : 0u) | (frag_first ? 4u : 0u);
+                        d2.z = nk0;
+                        d2.w = nk0 + nk1;
+                        uint4 *dp = reinterpret_cast<uint4 *>(&S.slot[par][nslot_new]);
+                        dp[0] = d0;
+                        dp[1] = d1;
+                        dp[2] = d2;
+                    }
+                    S.ps[par][nslot_new][lane] = (uint16_t)ps;
+                    NH_STAMP(10);
+                    qn += nruns;
+                    nslot_new++;
+                }
+            }
+            // group complete -- no room for another tile's run starts, or the batch is over -- or the
+            // pipeline is being drained: hash + probe it (which also resolves what is left of the previous
+            // group), post-process the previous group, switch buffers
+            const bool full = nslot_new == (uint32_t)NSLOT || qn + TL > (uint32_t)QCAP;
+            if ((nslot_new != 0 && (full || j == (uint32_t)NSLOT)) || (!batch && j == (uint32_t)NSLOT)) {
+                flush_records<STD>(ap, S, lane);
+                probe_queue<true, STD, true, PROF>(ap, S, lane, par, qn, lk, true, prof, tprev);
+                if (nslot_old)
+                    post_group<STD, false, PROF>(ap, S, TLI, lane, mates, reset_per_mate, par ^ 1u, nslot_old, prof, tprev);
+                nslot_old = nslot_new;
+                par ^= 1u;
+                nslot_new = 0;
+                qn = 0;
+            }
+        }
+        if (batch) t += NSLOT;
+    }
+    flush_records<STD>(ap, S, lane);
 
     wave_sync();
     if (lane == 0) {
@@ -1204,12 +1509,7 @@ __global__ __launch_bounds__(WAVE * WAVES_PER_BLOCK) void k_insert_sequences(con
     const int lane = threadIdx.x & 63;
     const int wib = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     WaveLdsT<true> &S = lds_all[wib];
-    if (lane < 24) {
-        S.pk[lane] = 0;
-        S.pa[lane] = 0;
-    }
-    for (int i = lane; i < CandPad<true>::value; i += 64) S.cand[TL + i] = NH_FULL;
-    wave_sync();
+    init_wave_lds<true>(S, lane);
     const uint32_t TQ = TL - 4u;
     const uint64_t n_seq = ap->n_frag;
     const uint64_t *const seq_off = ap->seq_off;
@@ -1276,55 +1576,77 @@ static void launch_variant(const KArgs &ka, dim3 g, dim3 b, hipStream_t stream, 
     hipLaunchKernelGGL((k_classify<LINEAR, STD, CAP32, PROF, false>), g, b, 0, stream, ka);
     if (may_overflow) {
         // second pass for fragments with more than 64 distinct taxa: exits at once if there are none
+        KArgs kb = ka;
+        kb.only_deferred = 0;
         (void)hipMemsetAsync(d_work, 0, sizeof(unsigned long long), stream);
-        hipLaunchKernelGGL((k_classify<LINEAR, STD, CAP32, false, true>), g, b, 0, stream, ka);
+        hipLaunchKernelGGL((k_classify<LINEAR, STD, CAP32, false, true>), g, b, 0, stream, kb);
         (void)hipMemsetAsync(ka.pending, 0, sizeof(int), stream);
     }
 }
 
-hipError_t launch_classify(const DevDB &db, const void *d_bases, const void *d_seq_off,
-                           uint64_t n_frag, int mates, double confidence, void *d_out,
-                           void *d_kmer_taxa, const void *d_kmer_taxa_off, void *d_counters,
-                           int *d_error, int *d_pending, unsigned long long *d_work, uint32_t frag_chunk,
-                           int grid_blocks, hipStream_t stream) {
+hipError_t launch_classify(const DevDB &db, const LaunchIO &io, double confidence, const LaunchSlot &sl,
+                           uint32_t frag_chunk, int grid_blocks, hipStream_t stream) {
+    const uint64_t n_frag = io.n_frag;
     if (n_frag == 0) return hipSuccess;
     if (frag_chunk == 0) frag_chunk = 1;
-    hipError_t me = hipMemsetAsync(d_work, 0, sizeof(unsigned long long), stream);
+    hipError_t me = hipMemsetAsync(sl.d_work, 0, sizeof(unsigned long long), stream);
     if (me != hipSuccess) return me;
     uint64_t need = (n_frag + (uint64_t)WAVES_PER_BLOCK * frag_chunk - 1) / ((uint64_t)WAVES_PER_BLOCK * frag_chunk);
     int grid = (int)(need < (uint64_t)grid_blocks ? need : (uint64_t)grid_blocks);
     dim3 g(grid), b(WAVE * WAVES_PER_BLOCK);
     const bool std_geom = is_std(db);
     KArgs ka;
+    memset(&ka, 0, sizeof ka);
     ka.db = db;
-    ka.bases = (const uint8_t *)d_bases;
-    ka.seq_off = (const uint64_t *)d_seq_off;
+    ka.bases = (const uint8_t *)io.d_bases;
+    ka.seq_off = (const uint64_t *)io.d_seq_off;
+    ka.seq_len = (const uint32_t *)io.d_seq_len;
+    ka.bases_end = io.bases_end;
     ka.n_frag = n_frag;
-    ka.mates = mates;
+    ka.mates = io.mates;
     ka.frag_chunk = frag_chunk;
     ka.confidence = confidence;
-    ka.out = (Result *)d_out;
-    ka.kmer_taxa = (uint32_t *)d_kmer_taxa;
-    ka.kmer_taxa_off = (const uint64_t *)d_kmer_taxa_off;
-    ka.counters = (unsigned long long *)d_counters;
-    ka.error_flag = d_error;
-    ka.pending = d_pending;
-    ka.work = d_work;
+    ka.out = (Result *)io.d_out;
+    ka.kmer_taxa = (uint32_t *)io.d_kmer_taxa;
+    ka.kmer_taxa_off = (const uint64_t *)io.d_kmer_taxa_off;
+    ka.counters = (unsigned long long *)io.d_counters;
+    ka.error_flag = sl.d_error;
+    ka.pending = sl.d_pending;
+    ka.work = sl.d_work;
+    ka.defer_bits = sl.d_defer;
+    ka.pending_long = sl.d_pending_long;
     // tables of 2^32 - 256 cells or more take the variant with 64-bit cell positions;
     // NOHUMAN_FORCE_WIDE=1 selects it for any table (tests: small tables through the wide path)
     static const bool force_wide = getenv("NOHUMAN_FORCE_WIDE") != nullptr;
+    static const bool no_short = getenv("NOHUMAN_NO_SHORT") != nullptr;  // tuning / test knob
+    static const bool phase_prof = getenv("NH_PHASE_PROF") != nullptr;
     const bool cap32 = db.capacity < 0xFFFFFF00ull && !force_wide;
     const bool may_overflow = db.node_count > LIST_CAP;  // <= 64 taxa can never overflow the list
-    if (db.linear_probing && std_geom && cap32 && getenv("NH_PHASE_PROF"))
-        launch_variant<true, true, true, true>(ka, g, b, stream, may_overflow, d_work);  // d_counters: CNT_N + 12 words
-    else if (db.linear_probing && std_geom && cap32)
-        launch_variant<true, true, true>(ka, g, b, stream, may_overflow, d_work);
+    const bool hot = db.linear_probing && std_geom && cap32;
+    // Short reads first: the one-tile-per-sequence kernel takes every chunk whose sequences fit a tile and
+    // marks the others for the generic kernel launched right behind it (which returns at once when
+    // nothing was marked).  Skipped when the caller says the reads are long.
+    const uint64_t n_chunks = (n_frag + frag_chunk - 1) / frag_chunk;
+    if (hot && !io.long_reads && !no_short && n_chunks <= sl.defer_cap_bits) {
+        (void)hipMemsetAsync(sl.d_defer, 0, (size_t)((n_chunks + 31) / 32) * 4, stream);
+        if (phase_prof)
+            hipLaunchKernelGGL((k_classify_short<true>), g, b, 0, stream, ka);
+        else
+            hipLaunchKernelGGL((k_classify_short<false>), g, b, 0, stream, ka);
+        ka.only_deferred = 1;
+        (void)hipMemsetAsync(sl.d_work, 0, sizeof(unsigned long long), stream);
+    }
+    if (hot && phase_prof)
+        launch_variant<true, true, true, true>(ka, g, b, stream, may_overflow, sl.d_work);  // d_counters: CNT_N + 12 words
+    else if (hot)
+        launch_variant<true, true, true>(ka, g, b, stream, may_overflow, sl.d_work);
     else if (db.linear_probing && std_geom)
-        launch_variant<true, true, false>(ka, g, b, stream, may_overflow, d_work);
+        launch_variant<true, true, false>(ka, g, b, stream, may_overflow, sl.d_work);
     else if (db.linear_probing)
-        launch_variant<true, false, false>(ka, g, b, stream, may_overflow, d_work);
+        launch_variant<true, false, false>(ka, g, b, stream, may_overflow, sl.d_work);
     else
-        launch_variant<false, false, false>(ka, g, b, stream, may_overflow, d_work);
+        launch_variant<false, false, false>(ka, g, b, stream, may_overflow, sl.d_work);
+    if (ka.only_deferred) (void)hipMemsetAsync(sl.d_pending_long, 0, sizeof(int), stream);
     return hipGetLastError();
 }
 
@@ -1347,7 +1669,7 @@ hipError_t launch_insert_sequences(const DevDB &db, const void *d_bases, const v
 
 int classify_blocks_per_cu() {
     int nb = 0;
-    hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_classify<true, true, true, false, false>,
+    hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_classify_short<false>,
                                                                 WAVE * WAVES_PER_BLOCK, 0);
     if (e != hipSuccess || nb < 1) nb = 4;
     return nb > 8 ? 8 : nb;
