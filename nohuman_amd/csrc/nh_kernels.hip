@@ -54,7 +54,11 @@ template <bool STD> struct CandPad { static constexpr int value = STD ? 6 : 66; 
 #define NH_QCAP 256  // 5 waves per SIMD need <= 31 KB of LDS per workgroup (a 32 KB one fits only 4 times: profiles/r02_tuning.txt)
 #endif
 constexpr int NSLOT = NH_NSLOT;  // tiles scanned before one shared probe phase
-constexpr int QCAP = NH_QCAP;  // queue entries per group: a tile joins only if it is sure to fit (< 512)
+constexpr int QCAP_SHORT = NH_QCAP;  // queue entries per group: a tile joins only if it is sure to fit (< 512)
+#ifndef NH_QCAP_GENERIC
+#define NH_QCAP_GENERIC 288  // the generic kernel keeps one packed stream instead of NSLOT: room for a longer queue
+#endif
+constexpr int QCAP_GENERIC = NH_QCAP_GENERIC;
 constexpr uint32_t QTAX_SKIP = 0xFFFFFFFFu;  // queue entry dropped by the min-hash filter
 
 constexpr int PKW = 18;  // words of a tile's packed stream: 16 of data + the 2 zero words a funnel read may touch
@@ -70,11 +74,15 @@ struct alignas(16) SlotLds {  // a scanned tile waiting for its probe results (w
 };
 
 // the generic kernel keeps the probe results apart from the queue entries; STD aliases them
-template <bool STD> struct QTax { uint32_t v[2][QCAP]; };
-template <> struct QTax<true> {};
+template <bool STD, int QC> struct QTax { uint32_t v[2][QC]; };
+template <int QC> struct QTax<true, QC> {};
 
-template <bool STD>
+// LDS slice of one wave.  NPK = tiles whose packed streams exist at a time (1: the generic kernel encodes
+// and scans tile by tile; NSLOT: the short-read kernel encodes a batch first), QC = queue entries per
+// group.  Both kernels are sized to 31 KB per workgroup: five workgroups per CU.
+template <bool STD, int NPK, int QC>
 struct WaveLdsT {
+    static constexpr int QCAP = QC;
 #if defined(NH_LDS_PAD) && NH_LDS_PAD > 0
     uint32_t occupancy_pad[NH_LDS_PAD / 4];  // tuning aid: lowers the number of resident workgroups
 #endif
@@ -85,16 +93,16 @@ struct WaveLdsT {
     uint16_t ps[2][NSLOT][WAVE];  // per-lane packed k-mer state of the tiles in flight
     // 2-bit packed bases of a tile: base i' of the tile frame at bit 2*(255-i'); 64 B + zero pad.  One per
     // tile of a group: the short-read kernel encodes a whole batch of tiles before it scans them
-    uint32_t pk[NSLOT][PKW];
-    uint32_t pa[NSLOT][PKW];  // same layout, value 1 where the base is ambiguous
+    uint32_t pk[NPK][PKW];
+    uint32_t pa[NPK][PKW];  // same layout, value 1 where the base is ambiguous
     // result records of the fragments the last post_group finished: stored to global memory by the next
     // turn, right before its probe phase (flush_records)
     uint4 stage_rec[NSLOT];
     uint64_t stage_f[NSLOT];
     uint32_t stage_n;
     uint64_t cand[TL + CandPad<STD>::value];
-    uint64_t q[2][QCAP];  // [parity] queue: run-start minimizers, hashed in place (see probe_queue)
-    QTax<STD> qtax;       // taxon found for each queued run (generic kernel only, see tax_at)
+    uint64_t q[2][QC];  // [parity] queue: run-start minimizers, hashed in place (see probe_queue)
+    QTax<STD, QC> qtax;       // taxon found for each queued run (generic kernel only, see tax_at)
     // (taxon, count) list of the fragment being post-processed: tiles are post-processed strictly
     // in input order, so one list (and one FragState, kept in registers) serves all fragments
     uint32_t list_tax[LIST_CAP];
@@ -246,8 +254,8 @@ struct FragState {
 // is whatever lies behind the sequence in the caller's buffer (the next read, or -- when records are
 // classified in place inside their FASTQ text -- a newline and the quality line): it must neither count
 // as ambiguous nor send the tile down the slow path.  Returns "the tile has an ambiguous base".
-template <bool STD>
-__device__ __forceinline__ bool encode_tile(WaveLdsT<STD> &S, const int lane, const uint32_t slot, const uint32_t w,
+template <bool STD, class WL>
+__device__ __forceinline__ bool encode_tile(WL &S, const int lane, const uint32_t slot, const uint32_t w,
                                             const uint32_t sh, const uint32_t nbases) {
     uint32_t diff;
     const uint32_t codes = encode4(w, diff);
@@ -270,8 +278,8 @@ __device__ __forceinline__ bool encode_tile(WaveLdsT<STD> &S, const int lane, co
 // S.q[par][qbase ...], returns their number, and leaves in `ps` the lane's packed per-k-mer state
 // (bit0/1 = k-mer 2t / 2t+1 is valid and unambiguous, bit 2 = k-mer 2t+1 starts a run, bits 3-10 = 1 + index of the run
 // that covers k-mer 2t, 0 = continuation of the run that entered the tile).
-template <bool STD, bool PROF>
-__device__ __forceinline__ uint32_t scan_body(KArgsP ap, WaveLdsT<STD> &S, const int lane, const uint32_t slot,
+template <bool STD, bool PROF, class WL>
+__device__ __forceinline__ uint32_t scan_body(KArgsP ap, WL &S, const int lane, const uint32_t slot,
                                               const bool has_amb, const uint32_t sh, const uint32_t nlt,
                                               const uint32_t nqt, const uint32_t par,
                                               const uint32_t qbase, uint64_t &carry_min,
@@ -422,8 +430,8 @@ __device__ __forceinline__ uint32_t scan_body(KArgsP ap, WaveLdsT<STD> &S, const
 
 
 // One tile of the generic kernel: encode (slot 0), start the prefetch of a later tile, scan.
-template <bool STD, bool PROF>
-__device__ __forceinline__ uint32_t scan_tile(KArgsP ap, WaveLdsT<STD> &S, const int lane,
+template <bool STD, bool PROF, class WL>
+__device__ __forceinline__ uint32_t scan_tile(KArgsP ap, WL &S, const int lane,
                                               const uint32_t w,
                                               const uint32_t sh, const uint32_t nlt,
                                               const uint32_t nqt, const uint32_t par,
@@ -446,8 +454,8 @@ __device__ __forceinline__ uint32_t scan_tile(KArgsP ap, WaveLdsT<STD> &S, const
 // Where the taxon of queued run r is stored: the generic kernel has its own array (it also marks
 // entries dropped by the min-hash filter there); the STD kernel reuses the low dword of the queue
 // entry itself, which the owning lane has copied to registers before it writes the result.
-template <bool STD>
-__device__ __forceinline__ uint32_t &tax_at(WaveLdsT<STD> &S, uint32_t par, uint32_t r) {
+template <bool STD, class WL>
+__device__ __forceinline__ uint32_t &tax_at(WL &S, uint32_t par, uint32_t r) {
     if constexpr (STD)
         return reinterpret_cast<uint32_t *>(&S.q[par][r])[0];
     else
@@ -505,8 +513,8 @@ __device__ __forceinline__ void scan4(const uint4 &c, uint32_t ckey, uint32_t vm
 // in flight per lane.  Half the round trips per group, 10 % fewer instructions -- and 16 % slower:
 // on this chip a random gather runs fastest with ONE load in flight per lane and many waves
 // (profiles/r02_pair_study.txt, tools/gather_bench: deep per-wave queues lower the line rate).)
-template <bool LINEAR, bool STD, bool CAP32, bool PROF>
-__device__ __forceinline__ void probe_queue(KArgsP ap, WaveLdsT<STD> &S, const int lane,
+template <bool LINEAR, bool STD, bool CAP32, bool PROF, class WL>
+__device__ __forceinline__ void probe_queue(KArgsP ap, WL &S, const int lane,
                                             const uint32_t par,
                                             const uint32_t qn, LaneLookup &lk, const bool count_lookups,
                                             uint64_t (&prof)[12],
@@ -706,8 +714,8 @@ struct TaxList {
 };
 
 // POST one tile: per-k-mer taxa from the probe results, hit groups, (taxon, count) list.
-template <bool STD, bool BIG, bool PROF>
-__device__ __forceinline__ void post_tile(WaveLdsT<STD> &S, const TaxList &TLI, const int lane, const uint32_t ps,
+template <bool STD, bool BIG, bool PROF, class WL>
+__device__ __forceinline__ void post_tile(WL &S, const TaxList &TLI, const int lane, const uint32_t ps,
                                           const uint32_t nqt, const uint32_t par,
                                           const uint32_t qbase, const uint32_t nruns,
                                           const int last_lane, FragState &st,
@@ -837,8 +845,8 @@ __device__ __forceinline__ uint32_t resolve_tree_big(KArgsP ap, const TaxList &T
 }
 
 // ResolveTree (A.5) on the wave: lane i owns list entry i.  Returns the call; sets clade_hits.
-template <bool STD>
-__device__ __forceinline__ uint32_t resolve_tree(KArgsP ap, WaveLdsT<STD> &S, const int lane,
+template <bool STD, class WL>
+__device__ __forceinline__ uint32_t resolve_tree(KArgsP ap, WL &S, const int lane,
                                                  const FragState &st, const uint32_t total_kmers,
                                                  uint32_t &clade_hits) {
     ap = launder(ap);
@@ -880,10 +888,10 @@ __device__ __forceinline__ uint32_t resolve_tree(KArgsP ap, WaveLdsT<STD> &S, co
 }
 
 // one-time LDS init of a wave: zero pads of the packed streams, sentinel tail of the candidate array
-template <bool STD>
-__device__ __forceinline__ void init_wave_lds(WaveLdsT<STD> &S, const int lane) {
+template <bool STD, class WL>
+__device__ __forceinline__ void init_wave_lds(WL &S, const int lane) {
     if (lane == 0) S.stage_n = 0;
-    for (int i = lane; i < NSLOT * PKW; i += 64) {
+    for (int i = lane; i < (int)(sizeof(S.pk) / 4); i += 64) {
         (&S.pk[0][0])[i] = 0;
         (&S.pa[0][0])[i] = 0;
     }
@@ -895,8 +903,8 @@ __device__ __forceinline__ uint32_t uni(uint32_t v) { return __builtin_amdgcn_re
 
 // Stores the records staged by the last post_group (lane i = record i).  Called right before a probe
 // phase: the stores complete in the shadow of the first probe round trip.
-template <bool STD>
-__device__ __forceinline__ void flush_records(KArgsP ap, WaveLdsT<STD> &S, const int lane) {
+template <bool STD, class WL>
+__device__ __forceinline__ void flush_records(KArgsP ap, WL &S, const int lane) {
     const uint32_t n = uni(S.stage_n);
     if (n == 0) return;
     if ((uint32_t)lane < n) {
@@ -910,8 +918,8 @@ __device__ __forceinline__ void flush_records(KArgsP ap, WaveLdsT<STD> &S, const
 // POST a group: finish the tiles of group `pp` (and each fragment whose last tile is among them).
 // The accumulation state of the fragment being post-processed is parked in LDS between calls (it is
 // wave-uniform and idle during scan and probe: four scalar registers less to keep there).
-template <bool STD, bool BIG, bool PROF>
-__device__ __forceinline__ void post_group(KArgsP ap, WaveLdsT<STD> &S, const TaxList &TLI, const int lane,
+template <bool STD, bool BIG, bool PROF, class WL>
+__device__ __forceinline__ void post_group(KArgsP ap, WL &S, const TaxList &TLI, const int lane,
                                            const int mates, const bool reset_per_mate, const uint32_t pp,
                                            const uint32_t nslot, uint64_t (&prof)[12], uint64_t &tprev) {
         KArgsP a2 = launder(ap);
@@ -960,7 +968,7 @@ __device__ __forceinline__ void post_group(KArgsP ap, WaveLdsT<STD> &S, const Ta
                         if (call && st.hit_groups < a2->db.min_hit_groups) call = 0;
                         clade_hits = call ? cnt : 0u;
                     } else {
-                        call = resolve_tree(ap, S, lane, st, total_kmers, clade_hits);
+                        call = resolve_tree<STD>(ap, S, lane, st, total_kmers, clade_hits);
                     }
                 }
                 // hot variant: a fragment with more than 64 distinct taxa is left to the BIG variant
@@ -1001,11 +1009,12 @@ __global__ __launch_bounds__(WAVE * WAVES_PER_BLOCK, BIG ? 1 : (STD ? NH_MIN_WAV
     // after the short-read kernel: only the chunks it left behind (none: nothing to do)
     const bool only_deferred = ap->only_deferred != 0;
     if (only_deferred && ap->pending_long[0] == 0) return;
-    __shared__ WaveLdsT<STD> lds_all[WAVES_PER_BLOCK];
+    typedef WaveLdsT<STD, 1, QCAP_GENERIC> WL;
+    __shared__ WL lds_all[WAVES_PER_BLOCK];
     __shared__ uint32_t big_lists[BIG ? WAVES_PER_BLOCK * 3 * BIG_LIST_CAP : 1];
     const int lane = threadIdx.x & 63;
     const int wib = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    WaveLdsT<STD> &S = lds_all[wib];
+    WL &S = lds_all[wib];
     TaxList TLI = {nullptr, nullptr, nullptr, 0};  // used by the BIG variant only
     if constexpr (BIG) {
         TLI.tax = &big_lists[(wib * 3 + 0) * BIG_LIST_CAP];
@@ -1213,7 +1222,7 @@ __global__ __launch_bounds__(WAVE * WAVES_PER_BLOCK, BIG ? 1 : (STD ? NH_MIN_WAV
                     qn += nruns;
                     nslot_new++;
                     // another tile joins this group only if its run starts are sure to fit the queue
-                    if (nslot_new == NSLOT || qn + TL > (uint32_t)QCAP) turn();
+                    if (nslot_new == NSLOT || qn + TL > (uint32_t)QCAP_GENERIC) turn();
                 }
             }
         }
@@ -1257,10 +1266,11 @@ template <bool PROF>
 __global__ __launch_bounds__(WAVE * WAVES_PER_BLOCK, PROF ? 4 : NH_MIN_WAVES) void k_classify_short(const KArgs args_by_kernarg_pointer) {
     constexpr bool STD = true;
     KArgsP ap = (KArgsP)__builtin_amdgcn_kernarg_segment_ptr();
-    __shared__ WaveLdsT<STD> lds_all[WAVES_PER_BLOCK];
+    typedef WaveLdsT<STD, NSLOT, QCAP_SHORT> WL;
+    __shared__ WL lds_all[WAVES_PER_BLOCK];
     const int lane = threadIdx.x & 63;
     const int wib = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    WaveLdsT<STD> &S = lds_all[wib];
+    WL &S = lds_all[wib];
     const TaxList TLI = {nullptr, nullptr, nullptr, 0};
     init_wave_lds<STD>(S, lane);
 
@@ -1430,7 +1440,7 @@ __global__ __launch_bounds__(WAVE * WAVES_PER_BLOCK, PROF ? 4 : NH_MIN_WAVES) vo
             // group complete -- no room for another tile's run starts, or the batch is over -- or the
             // pipeline is being drained: hash + probe it (which also resolves what is left of the previous
             // group), post-process the previous group, switch buffers
-            const bool full = nslot_new == (uint32_t)NSLOT || qn + TL > (uint32_t)QCAP;
+            const bool full = nslot_new == (uint32_t)NSLOT || qn + TL > (uint32_t)QCAP_SHORT;
             if ((nslot_new != 0 && (full || j == (uint32_t)NSLOT)) || (!batch && j == (uint32_t)NSLOT)) {
                 flush_records<STD>(ap, S, lane);
                 probe_queue<true, STD, true, PROF>(ap, S, lane, par, qn, lk, true, prof, tprev);
@@ -1505,10 +1515,11 @@ __global__ void k_synth_insert(uint32_t *table, uint64_t capacity, uint64_t cap_
 __global__ __launch_bounds__(WAVE * WAVES_PER_BLOCK) void k_insert_sequences(const KArgs args_by_kernarg_pointer,
                                                                             const uint32_t value) {
     KArgsP ap = (KArgsP)__builtin_amdgcn_kernarg_segment_ptr();
-    __shared__ WaveLdsT<true> lds_all[WAVES_PER_BLOCK];
+    typedef WaveLdsT<true, 1, QCAP_GENERIC> WL;
+    __shared__ WL lds_all[WAVES_PER_BLOCK];
     const int lane = threadIdx.x & 63;
     const int wib = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    WaveLdsT<true> &S = lds_all[wib];
+    WL &S = lds_all[wib];
     init_wave_lds<true>(S, lane);
     const uint32_t TQ = TL - 4u;
     const uint64_t n_seq = ap->n_frag;
