@@ -75,13 +75,24 @@ struct RecRef {  // offsets into HalfBatch::text
     uint32_t raw_end;
 };
 
-// Growable byte buffer that never zero-fills (batches are ~100 MB and recycled between reads).
+// Growable byte buffer that never zero-fills (batches are ~100 MB and recycled between reads).  The
+// memory can come from a caller-supplied allocator: nh_run hands out page-locked memory, so that the raw
+// text of a batch goes to the device by an asynchronous copy straight from here.
 class RawBuf {
 public:
+    typedef void *(*AllocFn)(size_t);
+    typedef void (*FreeFn)(void *);
     RawBuf() = default;
     RawBuf(const RawBuf &) = delete;
     RawBuf &operator=(const RawBuf &) = delete;
-    ~RawBuf() { free(p_); }
+    ~RawBuf() { release(); }
+    // only before the first allocation; alloc returns nullptr on failure
+    void set_allocator(AllocFn a, FreeFn f) {
+        if (!p_) {
+            alloc_ = a;
+            free_ = f;
+        }
+    }
     char *data() { return p_; }
     const char *data() const { return p_; }
     size_t size() const { return len_; }
@@ -92,8 +103,16 @@ public:
         if (n <= cap_) return true;
         size_t c = cap_ ? cap_ : 4096;
         while (c < n) c += c / 2 + 4096;
-        char *q = (char *)realloc(p_, c);
-        if (!q) return false;
+        char *q;
+        if (alloc_) {
+            q = (char *)alloc_(c);
+            if (!q) return false;
+            if (len_) memcpy(q, p_, len_);
+            if (p_) free_(p_);
+        } else {
+            q = (char *)realloc(p_, c);
+            if (!q) return false;
+        }
         p_ = q;
         cap_ = c;
         return true;
@@ -106,8 +125,17 @@ public:
     }
 
 private:
+    void release() {
+        if (p_) {
+            if (alloc_) free_(p_);
+            else free(p_);
+        }
+        p_ = nullptr;
+    }
     char *p_ = nullptr;
     size_t len_ = 0, cap_ = 0;
+    AllocFn alloc_ = nullptr;
+    FreeFn free_ = nullptr;
 };
 
 struct HalfBatch {  // the records one input file contributes to a batch

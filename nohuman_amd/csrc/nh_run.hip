@@ -12,6 +12,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <sys/stat.h>
 #include <sys/uio.h>
 #include <unistd.h>
 
@@ -227,13 +228,15 @@ static int write_report(const Engine *e, const char *path, const std::vector<uin
 
 // ---- the pipeline -----------------------------------------------------------------------------------
 // reader thread(s): inflate + parse one input file each into HalfBatches (bounded queue)
-// main thread:      pair the halves, gather the sequence bytes into pinned memory, H2D + classify +
+// main thread:      pair the halves, copy their raw text (page-locked batch buffers) to the device as it
+//                   is and classify the sequences in place: (start, length) per sequence; H2D + classify +
 //                   D2H asynchronously on one of two stream slots per device (batch b -> device
 //                   b mod G, database replicated per device: SURVEY.md section 8e)
 // writer thread:    format and write the outputs of finished batches in input order
-static size_t estimate_batch_frags(const char *path) {
+static size_t estimate_batch_frags(const char *path, size_t *mean_record_bytes) {
     BlockReader r;
     std::string err;
+    *mean_record_bytes = 0;
     if (r.open(path, err) != 0) return 1u << 18;
     HalfBatch hb;
     r.next_batch(hb, 256, 64u << 20);
@@ -241,6 +244,10 @@ static size_t estimate_batch_frags(const char *path) {
     uint64_t sum = 0;
     for (const RecRef &x : hb.recs) sum += x.slen;
     const uint64_t mean = sum / hb.recs.size() + 1;
+    const RecRef &lastr = hb.recs.back();
+    *mean_record_bytes = (size_t)((lastr.q + lastr.qlen + 2 > lastr.s + lastr.slen + 2 ? lastr.q + lastr.qlen + 2
+                                                                                   : lastr.s + lastr.slen + 2) /
+                                  hb.recs.size() + 1);
     uint64_t frags = (96ull << 20) / mean;
     if (frags < 256) frags = 256;
     if (frags > (1u << 18)) frags = 1u << 18;
@@ -292,41 +299,40 @@ struct Slot {  // pinned host + device buffers of one in-flight batch
     Engine *e = nullptr;
     hipStream_t stream = nullptr;
     int work_slot = 0;
-    uint8_t *h_bases = nullptr;
-    uint64_t *h_off = nullptr;
+    // The sequences are classified IN PLACE: the raw text of the batch (both mate files' record text, as
+    // read) is copied to the device as it is, and the kernel gets (start, length) of every sequence.
+    uint64_t *h_off = nullptr;   // n_seq starts into d_text
+    uint32_t *h_len = nullptr;   // n_seq lengths
     nh_result *h_res = nullptr;
     uint32_t *h_taxa = nullptr;
     uint64_t *h_taxa_off = nullptr;
-    void *d_bases = nullptr, *d_off = nullptr, *d_res = nullptr, *d_taxa = nullptr, *d_taxa_off = nullptr;
-    size_t cap_bases = 0, cap_frag = 0, cap_taxa = 0;
+    void *d_text = nullptr, *d_off = nullptr, *d_len = nullptr, *d_res = nullptr, *d_taxa = nullptr, *d_taxa_off = nullptr;
+    size_t cap_text = 0, cap_frag = 0, cap_taxa = 0;
     uint64_t n_taxa = 0;
     bool busy = false;
 };
 
-static int slot_reserve(Slot &s, size_t nbases, size_t nseq, size_t nfrag, size_t ntaxa) {
+static int slot_reserve(Slot &s, size_t ntext, size_t nfrag, size_t ntaxa) {
     if (hipSetDevice(s.e->device) != hipSuccess) return set_error(NH_EDEVICE, "hipSetDevice failed");
     auto grow = [](size_t need) { return need + need / 4 + 4096; };
-    if (nbases + 64 > s.cap_bases) {
-        if (s.h_bases) (void)hipHostFree(s.h_bases);
-        if (s.d_bases) (void)hipFree(s.d_bases);
-        s.cap_bases = grow(nbases + 64);
-        if (hipHostMalloc((void **)&s.h_bases, s.cap_bases, hipHostMallocDefault) != hipSuccess ||
-            hipMalloc(&s.d_bases, s.cap_bases) != hipSuccess)
-            return set_error(NH_EOOM, "cannot allocate batch buffers (%zu bytes)", s.cap_bases);
+    if (ntext + 64 > s.cap_text) {
+        if (s.d_text) (void)hipFree(s.d_text);
+        s.cap_text = grow(ntext + 64);
+        if (hipMalloc(&s.d_text, s.cap_text) != hipSuccess)
+            return set_error(NH_EOOM, "cannot allocate batch buffers (%zu bytes)", s.cap_text);
     }
-    if (nfrag > s.cap_frag || nseq + 1 > 2 * s.cap_frag + 1) {
-        if (s.h_off) (void)hipHostFree(s.h_off);
-        if (s.h_res) (void)hipHostFree(s.h_res);
-        if (s.h_taxa_off) (void)hipHostFree(s.h_taxa_off);
-        if (s.d_off) (void)hipFree(s.d_off);
-        if (s.d_res) (void)hipFree(s.d_res);
-        if (s.d_taxa_off) (void)hipFree(s.d_taxa_off);
+    if (nfrag > s.cap_frag) {
+        for (void *p : {(void *)s.h_off, (void *)s.h_len, (void *)s.h_res, (void *)s.h_taxa_off})
+            if (p) (void)hipHostFree(p);
+        for (void *p : {s.d_off, s.d_len, s.d_res, s.d_taxa_off})
+            if (p) (void)hipFree(p);
         s.cap_frag = grow(nfrag);
-        const size_t no = 2 * s.cap_frag + 2;
-        if (hipHostMalloc((void **)&s.h_off, no * 8, hipHostMallocDefault) != hipSuccess ||
+        const size_t ns = 2 * s.cap_frag + 2;
+        if (hipHostMalloc((void **)&s.h_off, ns * 8, hipHostMallocDefault) != hipSuccess ||
+            hipHostMalloc((void **)&s.h_len, ns * 4, hipHostMallocDefault) != hipSuccess ||
             hipHostMalloc((void **)&s.h_res, s.cap_frag * sizeof(nh_result), hipHostMallocDefault) != hipSuccess ||
             hipHostMalloc((void **)&s.h_taxa_off, (s.cap_frag + 1) * 8, hipHostMallocDefault) != hipSuccess ||
-            hipMalloc(&s.d_off, no * 8) != hipSuccess ||
+            hipMalloc(&s.d_off, ns * 8) != hipSuccess || hipMalloc(&s.d_len, ns * 4) != hipSuccess ||
             hipMalloc(&s.d_res, s.cap_frag * sizeof(nh_result)) != hipSuccess ||
             hipMalloc(&s.d_taxa_off, (s.cap_frag + 1) * 8) != hipSuccess)
             return set_error(NH_EOOM, "cannot allocate batch buffers (%zu fragments)", s.cap_frag);
@@ -345,12 +351,24 @@ static int slot_reserve(Slot &s, size_t nbases, size_t nseq, size_t nfrag, size_
 static void slot_free(Slot &s) {
     if (!s.e) return;
     (void)hipSetDevice(s.e->device);
-    for (void *p : {(void *)s.h_bases, (void *)s.h_off, (void *)s.h_res, (void *)s.h_taxa, (void *)s.h_taxa_off})
+    for (void *p : {(void *)s.h_off, (void *)s.h_len, (void *)s.h_res, (void *)s.h_taxa, (void *)s.h_taxa_off})
         if (p) (void)hipHostFree(p);
-    for (void *p : {s.d_bases, s.d_off, s.d_res, s.d_taxa, s.d_taxa_off})
+    for (void *p : {s.d_text, s.d_off, s.d_len, s.d_res, s.d_taxa, s.d_taxa_off})
         if (p) (void)hipFree(p);
     if (s.stream) (void)hipStreamDestroy(s.stream);
 }
+
+// page-locked text buffers of the batches (RawBuf allocator): the H2D copy of a batch's raw text runs
+// asynchronously straight from where the reader inflated / read it
+static void *pinned_alloc(size_t n) {
+    void *p = nullptr;
+    if (hipHostMalloc(&p, n, hipHostMallocPortable) != hipSuccess) {
+        (void)hipGetLastError();
+        return nullptr;
+    }
+    return p;
+}
+static void pinned_free(void *p) { (void)hipHostFree(p); }
 
 struct RunState {
     const nh_run_args *a;
@@ -381,6 +399,9 @@ struct RunState {
 // neither allocates nor page-faults.
 class BatchPool {
 public:
+    ~BatchPool() {
+        if (filler_.joinable()) filler_.join();
+    }
     std::unique_ptr<HalfBatch> get() {
         {
             std::lock_guard<std::mutex> lk(mu_);
@@ -390,17 +411,34 @@ public:
                 return hb;
             }
         }
-        return std::unique_ptr<HalfBatch>(new HalfBatch());
+        return make();
     }
     void put(std::unique_ptr<HalfBatch> hb) {
         if (!hb) return;
         std::lock_guard<std::mutex> lk(mu_);
         free_.push_back(std::move(hb));
     }
+    // Page-locking ~100 MB takes tens of milliseconds: a helper makes the first buffers while the reader
+    // already fills the ones it has, instead of the reader stopping for each of them.
+    void start_prefill(int n) {
+        filler_ = std::thread([this, n] {
+            for (int i = 0; i < n && !stop_.load(); i++) put(make());
+        });
+    }
+    void stop() { stop_.store(true); }
+    size_t first_reserve = 0;
 
 private:
+    std::unique_ptr<HalfBatch> make() {
+        std::unique_ptr<HalfBatch> hb(new HalfBatch());
+        hb->text.set_allocator(pinned_alloc, pinned_free);
+        if (first_reserve) hb->text.reserve(first_reserve);  // one allocation instead of a dozen growing ones
+        return hb;
+    }
     std::mutex mu_;
     std::vector<std::unique_ptr<HalfBatch>> free_;
+    std::thread filler_;
+    std::atomic<bool> stop_{false};
 };
 
 struct StageClock {  // NOHUMAN_TRACE=1: where the wall time of a run goes, per thread
@@ -555,7 +593,8 @@ int run_engines(const std::vector<Engine *> &engines, const nh_run_args *a, nh_s
 
     // fragments per batch: ~96 MB of sequence, at most 262144; both readers cut at the same record
     // count so that paired batches stay aligned (a byte budget only cuts single-end batches)
-    size_t BATCH_FRAGS = estimate_batch_frags(a->in1);
+    size_t mean_rec = 0;
+    size_t BATCH_FRAGS = estimate_batch_frags(a->in1, &mean_rec);
     if (const char *env = getenv("NOHUMAN_BATCH_FRAGS")) {  // tuning / test knob
         const long v = atol(env);
         if (v > 0) BATCH_FRAGS = (size_t)v;
@@ -579,6 +618,22 @@ int run_engines(const std::vector<Engine *> &engines, const nh_run_args *a, nh_s
 
     BoundedQueue<std::unique_ptr<HalfBatch>> q1(3), q2(3);
     BatchPool pool1, pool2;
+    int prefill = 4 + 2 * G;
+    if (mean_rec) {  // size the page-locked text buffers once: a batch of records plus one read chunk
+        size_t want = BATCH_FRAGS * mean_rec + BATCH_FRAGS * mean_rec / 8 + (8u << 20);
+        if (want > BATCH_TEXT + (8u << 20)) want = BATCH_TEXT + (8u << 20);
+        // small inputs: no more (and no larger) buffers than the text they can hold, compressed 12:1 at most
+        struct stat st1;
+        if (stat(a->in1, &st1) == 0 && S_ISREG(st1.st_mode)) {
+            const uint64_t est = (uint64_t)st1.st_size * 12 + (1u << 20);
+            if (est < want) want = (size_t)est;
+            const uint64_t nb = est / want + 1;
+            if (nb < (uint64_t)prefill) prefill = (int)nb;
+        }
+        if (want < (1ull << 31)) pool1.first_reserve = pool2.first_reserve = want;
+    }
+    pool1.start_prefill(prefill);
+    if (rs.paired) pool2.start_prefill(prefill);
     StageClock clk;
     // gzip inputs are inflated by `threads` workers in all, shared between the files
     unsigned gz_threads = (a->threads ? a->threads : 1) / (unsigned)mates;
@@ -701,12 +756,19 @@ int run_engines(const std::vector<Engine *> &engines, const nh_run_args *a, nh_s
             uint64_t m2 = StageClock::now();
             clk.ns[ST_MSLOT] += m2 - m1;
             b.slot = si;
-            size_t nbases = 0;
-            for (size_t i = 0; i < b.n; i++)
-                nbases += b.h1->recs[i].slen + (rs.paired ? b.h2->recs[i].slen : 0);
+            // (start, length) of every sequence inside the raw text: text of file 1 at byte 0 of the device
+            // buffer, text of file 2 behind it
+            const size_t len1 = b.h1->text.size(), len2 = rs.paired ? b.h2->text.size() : 0;
+            const size_t base2 = (len1 + 8 + 255) & ~(size_t)255;
+            const size_t ntext = rs.paired ? base2 + len2 : len1;
+            if (ntext >= (1ull << 32)) {
+                rs.fail(NH_EINVAL, "a batch of more than 4 GB of record text; lower NOHUMAN_BATCH_FRAGS");
+                wq.push(std::move(b));
+                break;
+            }
             uint64_t ntaxa = 0;
+            const uint64_t k = s.e->info.k;
             if (rs.want_k) {
-                const uint64_t k = s.e->info.k;
                 for (size_t i = 0; i < b.n; i++) {
                     const uint64_t l1 = b.h1->recs[i].slen;
                     ntaxa += l1 >= k ? l1 - k + 1 : 0;
@@ -716,55 +778,53 @@ int run_engines(const std::vector<Engine *> &engines, const nh_run_args *a, nh_s
                     }
                 }
             }
-            rc = slot_reserve(s, nbases, b.n * mates, b.n, ntaxa + 1);
+            rc = slot_reserve(s, ntext, b.n, ntaxa + 1);
             if (rc) {
                 rs.fail(rc, g_last_error);
                 wq.push(std::move(b));
                 break;
             }
-            // gather the sequence bytes of the batch into pinned memory
-            uint64_t off = 0, toff = 0;
-            const uint64_t k = s.e->info.k;
-            const char *txt1 = b.h1->text.data();
-            const char *txt2 = rs.paired ? b.h2->text.data() : nullptr;
+            uint64_t nbases = 0, toff = 0;
             for (size_t i = 0; i < b.n; i++) {
                 const RecRef &r1 = b.h1->recs[i];
-                s.h_off[i * mates] = off;
-                memcpy(s.h_bases + off, txt1 + r1.s, r1.slen);
-                off += r1.slen;
+                s.h_off[i * mates] = r1.s;
+                s.h_len[i * mates] = r1.slen;
+                nbases += r1.slen;
                 if (rs.want_k) {
                     s.h_taxa_off[i] = toff;
                     toff += r1.slen >= k ? r1.slen - k + 1 : 0;
                 }
                 if (rs.paired) {
                     const RecRef &r2 = b.h2->recs[i];
-                    s.h_off[i * mates + 1] = off;
-                    memcpy(s.h_bases + off, txt2 + r2.s, r2.slen);
-                    off += r2.slen;
+                    s.h_off[i * mates + 1] = base2 + r2.s;
+                    s.h_len[i * mates + 1] = r2.slen;
+                    nbases += r2.slen;
                     if (rs.want_k) toff += (r2.slen >= k ? r2.slen - k + 1 : 0) + 1;
                 }
             }
-            s.h_off[b.n * mates] = off;
-            memset(s.h_bases + off, 'A', 64);
             if (rs.want_k) s.h_taxa_off[b.n] = toff;
             s.n_taxa = toff;
             // H2D, classify, D2H: all asynchronous on the slot's stream
             uint64_t m3 = StageClock::now();
             clk.ns[ST_MGATHER] += m3 - m2;
             hipError_t he = hipSetDevice(s.e->device);
+            if (he == hipSuccess && len1)
+                he = hipMemcpyAsync(s.d_text, b.h1->text.data(), len1, hipMemcpyHostToDevice, s.stream);
+            if (he == hipSuccess && len2)
+                he = hipMemcpyAsync((char *)s.d_text + base2, b.h2->text.data(), len2, hipMemcpyHostToDevice, s.stream);
             if (he == hipSuccess)
-                he = hipMemcpyAsync(s.d_bases, s.h_bases, off + 64, hipMemcpyHostToDevice, s.stream);
+                he = hipMemcpyAsync(s.d_off, s.h_off, b.n * mates * 8, hipMemcpyHostToDevice, s.stream);
             if (he == hipSuccess)
-                he = hipMemcpyAsync(s.d_off, s.h_off, (b.n * mates + 1) * 8, hipMemcpyHostToDevice, s.stream);
+                he = hipMemcpyAsync(s.d_len, s.h_len, b.n * mates * 4, hipMemcpyHostToDevice, s.stream);
             if (he == hipSuccess && rs.want_k)
                 he = hipMemcpyAsync(s.d_taxa_off, s.h_taxa_off, (b.n + 1) * 8, hipMemcpyHostToDevice, s.stream);
             if (he != hipSuccess) {
                 rs.fail(NH_EDEVICE, std::string("H2D: ") + hipGetErrorString(he));
             } else {
-                rc = classify_device(s.e, s.d_bases, s.d_off, b.n,
-                                          flags | (nbases / b.n > 2000 ? NH_FLAG_LONG : 0u), a->confidence, s.d_res,
-                                          rs.want_k ? s.d_taxa : nullptr, rs.want_k ? s.d_taxa_off : nullptr,
-                                          s.e->d_counters, s.stream);
+                rc = classify_device(s.e, s.d_text, s.d_off, b.n,
+                                     flags | (nbases / b.n > 2000 ? NH_FLAG_LONG : 0u), a->confidence, s.d_res,
+                                     rs.want_k ? s.d_taxa : nullptr, rs.want_k ? s.d_taxa_off : nullptr,
+                                     s.e->d_counters, s.stream, s.d_len, ntext);
                 if (rc) rs.fail(rc, g_last_error);
             }
             if (!rs.failed()) {
@@ -780,6 +840,8 @@ int run_engines(const std::vector<Engine *> &engines, const nh_run_args *a, nh_s
         if (last) break;
     }
     // shut the pipeline down (also on errors): unblock readers, drain the writer
+    pool1.stop();
+    pool2.stop();
     q1.close();
     q2.close();
     wq.close();
