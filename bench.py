@@ -224,7 +224,7 @@ def measure(cx, args, *, steps, warmup, single_end=False, ont=False, hit_frac=0.
             "traffic_source": "profiles/traffic.json (static: rocprofv3 --pmc passes of this workload, "
                               "not measured in this run)",
             "fabric_request_frac": request_rate_frac(n_frag, paired, L, info.capacity, kernel_ms, variant),
-            "kernel": "k_classify",
+            "kernel": "k_classify_short" if not (ont or L > 158) else "k_classify",
             "kernel_ms": round(kernel_ms, 4),
             "kernel_ms_per_rank": [round(x, 4) for x in rank_kernel_ms],
             "algorithmic_bytes_per_launch": int(alg_bytes_launch),

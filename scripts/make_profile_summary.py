@@ -4,6 +4,7 @@ profiles/<round>_summary.txt, profiles/<round>_kernel_stats.csv and profiles/tra
     python scripts/make_profile_summary.py gpurun_out/prof_r01c r01"""
 import csv, glob, json, os, sys
 src, rnd = sys.argv[1], sys.argv[2]
+KERNEL = 'k_classify_short'  # the kernel the bench workload (150 bp pairs) runs in; the generic k_classify behind it returns at once
 LOOKUPS = 77.43e6 * 2.5  # 2.5 M pairs per launch
 
 
@@ -18,8 +19,8 @@ def mean_counter(pattern, kernel_sub, counter):
 
 out = []
 out.append("# profiles/%s_summary.txt -- rocprofv3 summaries of bench.py on 1 x MI355X" % rnd)
-out.append("# command: bash scripts/profile.sh <tag>   (trace pass: bench.py --no-cpu-baseline, 20 + 3 launches;")
-out.append("#          PMC passes: bench.py --steps 5 --warmup 2 --no-cpu-baseline)")
+out.append("# command: bash scripts/profile.sh <tag>   (trace pass: bench.py --no-cpu-baseline --no-e2e --no-variants, 20 + 3 launches;")
+out.append("#          PMC passes: the same with --steps 5 --warmup 2)")
 try:
     bj = json.loads(open(os.path.join(src, 'bench_trace.json')).read().strip().splitlines()[-1])
     out.append("# bench.py's own line in the trace pass: value %.1f %s, ms_per_step %.4f, roofline.kernel_ms %.4f" % (
@@ -34,19 +35,19 @@ for row in csv.reader(open(os.path.join(src, 'trace/trace_kernel_stats.csv'))):
     if row and (row[0] == 'Name' or 'nh::' in row[0]):
         out.append("  " + ", ".join(c[:70] for c in row))
 out.append("")
-out.append("== PMC passes (separate runs), k_classify, mean per launch")
+out.append("== PMC passes (separate runs), %s, mean per launch" % KERNEL)
 for pat, cs in (('pmc1/*counter_collection.csv', ['SQ_WAVES', 'SQ_INSTS_VALU', 'SQ_INSTS_SALU', 'SQ_INSTS_LDS', 'SQ_INSTS_VMEM_RD', 'SQ_WAVE_CYCLES', 'SQ_WAIT_ANY', 'SQ_BUSY_CYCLES']),
                 ('pmc2/*counter_collection.csv', ['SQ_ACTIVE_INST_ANY', 'SQ_ACTIVE_INST_VALU', 'SQ_ACTIVE_INST_SCA', 'SQ_ACTIVE_INST_LDS', 'SQ_WAIT_INST_ANY', 'SQ_WAIT_INST_LDS']),
                 ('pmc3/*counter_collection.csv', ['FETCH_SIZE']),
                 ('pmc4/*counter_collection.csv', ['TCC_EA0_RDREQ_sum', 'TCC_EA0_RDREQ_32B_sum', 'TCC_HIT_sum', 'TCC_MISS_sum']),
                 ('pmc5/*counter_collection.csv', ['WRITE_SIZE'])):
     for c in cs:
-        v, n = mean_counter(pat, 'k_classify', c)
+        v, n = mean_counter(pat, KERNEL, c)
         if v is not None:
             out.append("  %-26s %.6g   (n=%d)" % (c, v, n))
-fs, _ = mean_counter('pmc3/*counter_collection.csv', 'k_classify', 'FETCH_SIZE')
-ws, _ = mean_counter('pmc5/*counter_collection.csv', 'k_classify', 'WRITE_SIZE')
-rq, _ = mean_counter('pmc4/*counter_collection.csv', 'k_classify', 'TCC_EA0_RDREQ_sum')
+fs, _ = mean_counter('pmc3/*counter_collection.csv', KERNEL, 'FETCH_SIZE')
+ws, _ = mean_counter('pmc5/*counter_collection.csv', KERNEL, 'WRITE_SIZE')
+rq, _ = mean_counter('pmc4/*counter_collection.csv', KERNEL, 'TCC_EA0_RDREQ_sum')
 cf, _ = mean_counter('calib/*counter_collection.csv', 'k_gather_mode<0>', 'FETCH_SIZE')
 cr, _ = mean_counter('calib/*counter_collection.csv', 'k_gather_mode<0>', 'TCC_EA0_RDREQ_sum')
 if cf is not None:
@@ -69,10 +70,11 @@ with open('profiles/%s_kernel_stats.csv' % rnd, 'w') as g:
     for row in csv.reader(open(os.path.join(src, 'trace/trace_kernel_stats.csv'))):
         g.write(",".join('"%s"' % c[:120] for c in row) + "\n")
 json.dump({"workload": {"fragments_per_step": 2500000, "paired": True, "read_len": 150, "capacity": 1431655765},
-           "source": "profiles/%s_summary.txt (rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE, separate passes, k_classify mean per launch)" % rnd,
+           "source": "profiles/%s_summary.txt (rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE, separate passes, k_classify_short mean per launch)" % rnd,
            "fetch_size_kb": fs, "write_size_kb": ws,
-           "note": "FETCH_SIZE calibrated at 64 B per fabric read request on a random 16-byte gather (one request per probe); "
-                   "if every request moved a full 128-byte line, HBM bytes are twice this",
+           "note": "FETCH_SIZE as counted = 64 B x TCC_EA0_RDREQ (calibrated on a random 16-byte gather: one request per probe). "
+                   "The guide's gfx950 correction for streaming reads (x2: 128-byte requests tallied at 64) would double it; "
+                   "profiles/r02_pair_study.txt shows that the unit the fabric really charges for is the 128-byte line",
            "traffic_bytes_per_launch": int(fs * 1024 + ws * 1024),
            "fabric_read_requests_per_launch": int(rq),
            "fabric_request_ceiling_per_s": 50e9,

@@ -8,11 +8,11 @@ REPO=$(pwd)
 OUT=$REPO/gpurun_out/prof_$TAG
 mkdir -p "$OUT"
 export TMPDIR=/tmp
-BENCH="python3 $REPO/bench.py --steps 5 --warmup 2 --no-cpu-baseline"
+BENCH="python3 $REPO/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-e2e --no-variants"
 cd /tmp
 # the trace pass runs bench.py's default step counts (20 timed + 3 warm-up launches), so that the
 # average duration of k_classify is the steady-state one bench.py reports
-rocprofv3 --output-format csv --kernel-trace --stats -d "$OUT/trace" -o trace -- python3 $REPO/bench.py --no-cpu-baseline > "$OUT/bench_trace.json" 2> "$OUT/trace.err"
+rocprofv3 --output-format csv --kernel-trace --stats -d "$OUT/trace" -o trace -- python3 $REPO/bench.py --no-cpu-baseline --no-e2e --no-variants > "$OUT/bench_trace.json" 2> "$OUT/trace.err"
 rocprofv3 --output-format csv --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_WAIT_ANY -d "$OUT/pmc1" -o pmc1 -- $BENCH > /dev/null 2> "$OUT/pmc1.err"
 rocprofv3 --output-format csv --pmc SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM SQ_INST_CYCLES_VMEM SQ_ACTIVE_INST_SCA SQ_WAIT_INST_LDS -d "$OUT/pmc2" -o pmc2 -- $BENCH > /dev/null 2> "$OUT/pmc2.err"
 rocprofv3 --output-format csv --pmc FETCH_SIZE -d "$OUT/pmc3" -o pmc3 -- $BENCH > /dev/null 2> "$OUT/pmc3.err"
@@ -24,7 +24,7 @@ if [ -x "$REPO/tools/gather_bench" ]; then
   rocprofv3 --output-format csv --pmc FETCH_SIZE TCC_EA0_RDREQ_sum -d "$OUT/calib" -o calib -- "$REPO/tools/gather_bench" 6 64 > "$OUT/calib_stdout.txt" 2> "$OUT/calib.err"
 fi
 cd "$REPO"
-python3 scripts/summarize_prof.py "$OUT" > "$OUT/summary.txt" 2>&1
+python3 scripts/make_profile_summary.py "$OUT" "$TAG" > "$OUT/summary.txt" 2>&1
 cat "$OUT/summary.txt"
 find "$OUT" -name "*.db" -delete 2>/dev/null
 du -sh "$OUT"
