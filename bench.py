@@ -54,8 +54,8 @@ def parse_args(argv=None):
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-variants", action="store_true", help="skip the hit-path / single-end legs")
     ap.add_argument("--no-e2e", action="store_true", help="skip the nh_run files-in -> files-out leg")
-    ap.add_argument("--e2e-pairs", type=int, default=4_000_000, help="pairs per gzip member of the e2e inputs")
-    ap.add_argument("--e2e-reps", type=int, default=4, help="members per e2e input file")
+    ap.add_argument("--e2e-pairs", type=int, default=5_000_000, help="pairs per gzip member of the e2e inputs")
+    ap.add_argument("--e2e-reps", type=int, default=10, help="members per e2e input file")
     ap.add_argument("--confidence", type=float, default=0.0)
     ap.add_argument("--hit-frac", type=float, default=0.0,
                     help="fraction of the fragments of every batch made 'human': their minimizers are "

@@ -157,6 +157,20 @@ int nh_classify_batch_device(nh_engine *e, const void *d_bases, const void *d_se
                              void *d_kmer_taxa, const void *d_kmer_taxa_offsets, void *d_counters,
                              void *stream);
 
+/*
+ * The same launch with the sequences classified IN PLACE inside a device-resident buffer of record text
+ * (what nh_run does with the FASTQ / FASTA text of a batch, copied to the device as read -- no pass that
+ * gathers the sequence lines): sequence i is d_text[d_seq_starts[i], +d_seq_lens[i]) (uint64 / uint32,
+ * n_frag * (paired ? 2 : 1) entries each; pairs: entries 2f and 2f+1; the first sequence must be the
+ * one at the lowest address and all of a launch must lie within 4 GB).  Whatever surrounds a sequence
+ * (header, '+' line, qualities, newlines) is never interpreted.  d_text must be 4-byte aligned and readable
+ * for 8 bytes past text_len.
+ */
+int nh_classify_records_device(nh_engine *e, const void *d_text, uint64_t text_len, const void *d_seq_starts,
+                               const void *d_seq_lens, uint64_t n_frag, uint32_t flags, double confidence,
+                               void *d_results, void *d_kmer_taxa, const void *d_kmer_taxa_offsets,
+                               void *d_counters, void *stream);
+
 /* running totals over every nh_classify_batch* call on this engine since open / reset */
 int nh_stats_get(nh_engine *e, nh_stats *s);
 int nh_stats_reset(nh_engine *e);

@@ -68,6 +68,8 @@ SYMBOLS = {
     "nh_kmer_taxa_entries": (C.c_uint64, [_P, _P, C.c_uint64, C.c_uint32]),
     "nh_classify_batch_device": (C.c_int, [_P, _P, _P, C.c_uint64, C.c_uint32, C.c_double, _P, _P,
                                            _P, _P, _P]),
+    "nh_classify_records_device": (C.c_int, [_P, _P, C.c_uint64, _P, _P, C.c_uint64, C.c_uint32, C.c_double, _P,
+                                             _P, _P, _P, _P]),
     "nh_stats_get": (C.c_int, [_P, C.POINTER(nh_stats)]),
     "nh_stats_reset": (C.c_int, [_P]),
     "nh_compress_file": (C.c_int, [C.c_char_p, C.c_char_p, C.c_int, C.c_uint32]),

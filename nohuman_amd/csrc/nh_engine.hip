@@ -782,6 +782,16 @@ int nh_classify_batch_device(nh_engine *e_, const void *d_bases, const void *d_s
                                d_kmer_taxa, d_kmer_taxa_offsets, d_counters, (hipStream_t)stream);
 }
 
+int nh_classify_records_device(nh_engine *e_, const void *d_text, uint64_t text_len, const void *d_seq_starts,
+                               const void *d_seq_lens, uint64_t n_frag, uint32_t flags, double confidence,
+                               void *d_results, void *d_kmer_taxa, const void *d_kmer_taxa_offsets,
+                               void *d_counters, void *stream) {
+    Engine *e = (Engine *)e_;
+    if (!e || !d_text || !d_seq_starts || !d_seq_lens || !d_results) return set_error(NH_EINVAL, "null argument");
+    return nh::classify_device(e, d_text, d_seq_starts, n_frag, flags, confidence, d_results, d_kmer_taxa,
+                               d_kmer_taxa_offsets, d_counters, (hipStream_t)stream, d_seq_lens, text_len);
+}
+
 int nh_synthetic_add_sequences(nh_engine *e_, const void *d_bases, const void *d_seq_offsets,
                                uint64_t n_seq, uint32_t value, void *stream) {
     Engine *e = (Engine *)e_;

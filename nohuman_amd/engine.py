@@ -206,6 +206,16 @@ class Engine:
             float(confidence), d_results, d_kmer_taxa or None, d_kmer_taxa_offsets or None,
             d_counters or None, stream or None))
 
+    def classify_records_device(self, d_text: int, text_len: int, d_seq_starts: int, d_seq_lens: int, n_frag: int,
+                                paired: bool, confidence: float, d_results: int, d_counters: int = 0,
+                                stream: int = 0, d_kmer_taxa: int = 0, d_kmer_taxa_offsets: int = 0,
+                                long_reads: bool = False):
+        """Sequences in place inside a device buffer of record text: (start, length) per sequence."""
+        _check(self._L.nh_classify_records_device(
+            self._h, d_text, text_len, d_seq_starts, d_seq_lens, n_frag,
+            (FLAG_PAIRED if paired else 0) | (FLAG_LONG if long_reads else 0), float(confidence), d_results,
+            d_kmer_taxa or None, d_kmer_taxa_offsets or None, d_counters or None, stream or None))
+
     def add_sequences(self, d_bases: int, d_seq_offsets: int, n_seq: int, value: int, stream: int = 0):
         """Bench/test support: insert the minimizers of device-resident sequences into the table."""
         _check(self._L.nh_synthetic_add_sequences(self._h, d_bases, d_seq_offsets, n_seq, value,

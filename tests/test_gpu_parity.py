@@ -326,3 +326,62 @@ def test_window_wider_than_lmer_with_ambiguous_bases(k, l):
         _assert_same(got, exp, "k=%d l=%d paired=%s" % (k, l, paired))
         assert np.array_equal(taxa, etaxa)
         assert st.table_lookups == int(lookups.sum())
+
+
+@pytest.mark.parametrize("paired", [False, True])
+def test_sequences_in_place_inside_their_record_text(toy, toy_oracle, paired):
+    """nh_classify_records_device: the sequences stay where the reader put them -- inside FASTQ text with
+    headers of every length (so the sequences start at every byte alignment), '+' lines, qualities that
+    look like bases ('A', 'N', '@'), CRLF -- and the kernel gets (start, length) per sequence.  Mixed
+    lengths: chunks of short reads go through the short-read kernel, chunks holding a longer read are
+    left to the generic one.  Records, per-k-mer taxa and counters equal the oracle's on the packed reads."""
+    import torch
+    from nohuman_amd import Engine
+    ob, tb, hb, genomes, _ = toy
+    rng = np.random.default_rng(31 + paired)
+    reads = synth.sample_reads(rng, genomes, 3000, paired=paired, len_jitter=60, n_rate=0.004)
+    longr = synth.sample_reads(rng, genomes, 40, length=700, paired=paired, len_jitter=300, n_rate=0.002)
+    order = rng.permutation(len(reads) + len(longr))
+    allr = [(reads + longr)[i] for i in order]
+    allr[7] = (b"", b"ACGT") if paired else b""  # no k-mer at all
+    seqs = [s for fr in allr for s in (fr if paired else (fr,))]
+    text = bytearray()
+    starts, lens = [], []
+    texts = [bytearray(), bytearray()]
+    pos = [[], []]
+    for i, fr in enumerate(allr):
+        for m, s in enumerate(fr if paired else (fr,)):
+            t = texts[m]
+            t += b"@r%d%s/%d\n" % (i, b"x" * int(rng.integers(0, 9)), m + 1)
+            pos[m].append((len(t), len(s)))
+            q = bytes(rng.choice(np.frombuffer(b"ANI@#ACGT", dtype=np.uint8), size=len(s)))
+            t += s + (b"\r\n+\r\n" if i % 50 == 0 else b"\n+\n") + q + b"\n"
+    base2 = (len(texts[0]) + 8 + 255) & ~255
+    blob = bytes(texts[0]) + b"\0" * (base2 - len(texts[0])) + (bytes(texts[1]) if paired else b"")
+    for i in range(len(allr)):
+        for m in range(2 if paired else 1):
+            st, ln = pos[m][i]
+            starts.append(st + (base2 if m else 0))
+            lens.append(ln)
+    bases, offs = orc.pack_reads(allr, paired)
+    exp, lookups, etaxa, etoff = toy_oracle.classify(bases, offs, paired, 0.05, want_taxa=True)
+    dev = torch.device("cuda:0")
+    d_text = torch.frombuffer(bytearray(blob + b"\0" * 64), dtype=torch.uint8).to(dev)
+    d_st = torch.tensor(starts, dtype=torch.int64, device=dev)
+    d_ln = torch.tensor(lens, dtype=torch.int32, device=dev)
+    n = len(allr)
+    out = torch.zeros((n, 4), dtype=torch.int32, device=dev)
+    cnt = torch.zeros(4, dtype=torch.int64, device=dev)
+    taxa = torch.zeros(len(etaxa) + 1, dtype=torch.int32, device=dev)
+    toff = torch.tensor(np.asarray(etoff, dtype=np.int64), device=dev)
+    with Engine.from_images(ob, tb, hb) as eng:
+        eng.classify_records_device(d_text.data_ptr(), len(blob), d_st.data_ptr(), d_ln.data_ptr(), n, paired, 0.05,
+                                    out.data_ptr(), cnt.data_ptr(), 0, taxa.data_ptr(), toff.data_ptr())
+        torch.cuda.synchronize()
+    got = out.cpu().numpy().view(np.uint32)
+    for i, f in enumerate(("call", "total_kmers", "clade_hits", "hit_groups")):
+        bad = np.nonzero(got[:, i] != exp[f])[0]
+        assert bad.size == 0, "%s differs at %s" % (f, bad[:5])
+    assert np.array_equal(taxa.cpu().numpy().view(np.uint32)[: len(etaxa)], etaxa)
+    c = cnt.tolist()
+    assert c == [n, int((exp["call"] != 0).sum()), sum(len(s) for s in seqs), int(lookups.sum())]
