@@ -493,6 +493,11 @@ def e2e_leg(cx, args, eng):
             if best is None or dt < best[0]:
                 best = (dt, st.total_sequences, st.classified)
                 trace = open(tr_path).read().strip()
+        # the input side alone: same run with --classified-out semantics (nothing is kept, nothing written)
+        t = time.perf_counter()
+        st_in = eng.run(files[0], os.path.join(tmp, "h_1.fq"), in2=files[1], out2=os.path.join(tmp, "h_2.fq"),
+                        threads=threads, keep_human=True)
+        dt_in = time.perf_counter() - t
         dt, nfr, ncl = best
         expect = 2 * (nfr - ncl) * (len(b"@syn.000000000/1\n") + 2 * L + 4)
         written = os.path.getsize(o1) + os.path.getsize(o2)
@@ -509,6 +514,10 @@ def e2e_leg(cx, args, eng):
             "classified": int(ncl),
             "output_bytes_ok": bool(written == expect and nfr == n * reps),
             "stages": trace,
+            "input_side_only": {"value": round(2 * st_in.total_sequences / dt_in / 1e6, 3), "unit": "Mreads/s",
+                                "wall_s": round(dt_in, 4),
+                                "what": "same inputs, keep_human=1 (no read is kept: inflate + parse + H2D + "
+                                        "classify + D2H, no output bytes)"},
             "setup_seconds": round(t_setup, 1),
         }
     finally:
