@@ -39,6 +39,9 @@ namespace nh {
 #ifndef NH_WIDE_AFTER
 #define NH_WIDE_AFTER 2  // rounds after which a lookup examines 16 cells per round instead of 4
 #endif
+#ifndef NH_R2_CELLS
+#define NH_R2_CELLS 4    // cells of a lookup's second round
+#endif
 
 // window reads of idle lanes stay inside the candidate array: k-l+2 pad entries (k-l = 4 for
 // kraken2's default geometry, <= 64 in general)
@@ -630,18 +633,23 @@ __device__ __forceinline__ void probe_queue(KArgsP ap, WL &S, const int lane,
                 // lookup is in a long probe run -- linear probing at load 0.7 is heavy-tailed, and
                 // the slowest lookup of a group decides when the group can be post-processed -- so
                 // it examines up to 16 cells per round from then on.
-                const bool wide = max_rounds - budget >= (uint32_t)NH_WIDE_AFTER;
-                const uint32_t lim = wide ? (uint32_t)NH_WIDE_CELLS : 4u;
+                const uint32_t age = max_rounds - budget;  // rounds this lookup has had
+                const uint32_t lim = age >= (uint32_t)NH_WIDE_AFTER ? (uint32_t)NH_WIDE_CELLS
+                                     : age == 1u                    ? (uint32_t)NH_R2_CELLS
+                                                                    : 4u;
+                const bool wide = lim > 4u;
                 nvalid = nvalid < lim ? nvalid : lim;
                 lo = (!wide && in_line < 4u) ? 4u - in_line : 0u;
                 const uint4 c0 = *reinterpret_cast<const uint4 *>(src - lo);
                 constexpr int WCH = NH_WIDE_CELLS / 4;  // 16-byte chunks of a wide round
                 uint4 cw[WCH];
-                if (wide) {  // chunks past the last useful one re-read it (no new line is touched)
-                    const uint32_t last_chunk = (nvalid - 1) >> 2;
+                if (wide) {  // only the chunks that hold eligible cells are loaded (every lane-load costs the L1 a cycle)
+                    const uint32_t nch = (nvalid + 3u) >> 2;
 #pragma unroll
-                    for (int q = 1; q < WCH; q++)
-                        cw[q] = *reinterpret_cast<const uint4 *>(src + 4 * (last_chunk < (uint32_t)q ? last_chunk : (uint32_t)q));
+                    for (int q = 1; q < WCH; q++) {
+                        cw[q] = make_uint4(0, 0, 0, 0);  // (a stop found in an unloaded chunk lies beyond nvalid: ignored)
+                        if ((uint32_t)q < nch) cw[q] = *reinterpret_cast<const uint4 *>(src + 4 * q);
+                    }
                 }
                 if (wide) {
 #pragma unroll

@@ -63,6 +63,7 @@ out.append("== derived, per launch")
 out.append("  lookups D                   %.4g   (38.7 per read)" % LOOKUPS)
 out.append("  fabric read requests        %.4g   (%.2f per lookup, incl. ~1.2e7 for the streamed bases)" % (rq, rq / LOOKUPS))
 out.append("  FETCH_SIZE as counted       %.4g bytes ; WRITE_SIZE %.4g bytes" % (fs * 1024, ws * 1024))
+out.append("  HBM bytes (128 B/request)   %.4g   = 2 x FETCH_SIZE + WRITE_SIZE (every fabric read is a 128-byte request: r02_mem_study.txt)" % (2 * fs * 1024 + ws * 1024))
 out.append("  algorithmic bytes           1.318e10  (sum len + 64*D + 16 per fragment, BASELINE.md section 4)")
 os.makedirs('profiles', exist_ok=True)
 open('profiles/%s_summary.txt' % rnd, 'w').write("\n".join(out) + "\n")
@@ -72,13 +73,17 @@ with open('profiles/%s_kernel_stats.csv' % rnd, 'w') as g:
 json.dump({"workload": {"fragments_per_step": 2500000, "paired": True, "read_len": 150, "capacity": 1431655765},
            "source": "profiles/%s_summary.txt (rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE, separate passes, k_classify_short mean per launch)" % rnd,
            "fetch_size_kb": fs, "write_size_kb": ws,
-           "note": "FETCH_SIZE as counted = 64 B x TCC_EA0_RDREQ (calibrated on a random 16-byte gather: one request per probe). "
-                   "The guide's gfx950 correction for streaming reads (x2: 128-byte requests tallied at 64) would double it; "
-                   "profiles/r02_pair_study.txt shows that the unit the fabric really charges for is the 128-byte line",
-           "traffic_bytes_per_launch": int(fs * 1024 + ws * 1024),
+           "note": "HBM bytes = 2 x FETCH_SIZE + WRITE_SIZE: the guide's gfx950 correction (FETCH_SIZE tallies 128-byte requests "
+                   "at 64 B), confirmed for THIS access pattern by profiles/r02_mem_study.txt: TCC_EA0_RDREQ_128B_sum == "
+                   "TCC_EA0_RDREQ_sum, every fabric read of the kernel (and of the random-gather microbenchmark) is a "
+                   "128-byte request",
+           "traffic_bytes_per_launch": int(2 * fs * 1024 + ws * 1024),
+           "fetch_size_as_counted_bytes": int(fs * 1024),
            "fabric_read_requests_per_launch": int(rq),
            "fabric_request_ceiling_per_s": 50e9,
-           "ceiling_source": "tools/gather_bench (profiles/%s_gather_bench.txt, %s_phase_prof.txt): a pure random gather "
-                             "sustains ~50e9 fabric read requests/s on this chip whatever the table size" % (rnd, rnd)},
+           "hbm_achievable_gbs": 6290.0,
+           "ceiling_source": "tools/gather_bench (profiles/%s_gather_bench.txt): a pure random gather sustains ~50e9 "
+                             "128-byte fabric reads/s = 6.4 TB/s, the HBM bandwidth the chip reaches on a copy "
+                             "(6.29 TB/s, MI355X_MICROARCH.md)" % rnd},
           open('profiles/traffic.json', 'w'), indent=1)
 print("\n".join(out))
