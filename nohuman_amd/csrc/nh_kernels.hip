@@ -711,6 +711,129 @@ __device__ __forceinline__ void probe_queue(KArgsP ap, WL &S, const int lane,
     NH_STAMP(5);
 }
 
+// ---- quad-cooperative probing (default geometry, linear probing, 32-bit positions) -------------------
+// What binds the probe phase is measured (profiles/r02_mem_study.txt, tools/gather_bench mode 2): every
+// L2 miss moves a whole 128-byte line over the fabric, a lookup whose 2nd / 3rd round comes microseconds
+// later fetches its line AGAIN, and the L1 takes a wave-load at ~2.4 cycles per DISTINCT LINE -- lanes
+// that read neighbouring bytes of one line ride for free.  So a round fetches 64 contiguous bytes (16
+// cells) of a lookup's line with FOUR lanes: one wave-load instruction serves the lookups of 16 owner
+// lanes (lane l loads chunk l&3 of owner 16k + l/4), four such instructions serve all 64 owners and are
+// in flight together (one line per owner, as before).  91 % of the lookups at load 0.7 end in their
+// first round (62 % with 4 cells), the line is fetched once, and the L1 sees 1.1 line-visits per lookup
+// instead of 2.4.  Owners keep their state in registers; addresses and keys travel by ds_bpermute, the
+// verdict of a quad comes back through a ballot.
+template <bool PROF, class WL>
+__device__ __forceinline__ void probe_queue_quad(KArgsP ap, WL &S, const int lane, const uint32_t par,
+                                                 const uint32_t qn, LaneLookup &lk, const bool count_lookups,
+                                                 uint64_t (&prof)[12], uint64_t &tprev) {
+    constexpr bool STD = true;
+    ap = launder(ap);
+    const uint32_t vbits = ap->db.value_bits;
+    const uint32_t vmask = ap->db.vmask;
+    const uint64_t cap = ap->db.capacity;
+    const uint64_t magic = ap->db.cap_magic;
+    const uint32_t max_rounds = ap->db.max_chunks;
+    const uint32_t *const table = ap->db.table;
+    const uint64_t copy_stride = ap->db.copy_stride;
+    const uint32_t copy_shift = ap->db.copy_shift;
+
+    // ---- dense hash pass -----------------------------------------------------------------------------
+    for (uint32_t r0 = 0; r0 < qn; r0 += 64) {
+        const uint32_t r = r0 + lane;
+        const bool act = r < qn;
+        const uint64_t hc = fmix64(S.q[par][act ? r : 0u]);
+        const uint64_t home = mod_capacity(hc, cap, magic);
+        const uint32_t compacted = (uint32_t)(hc >> (32 + vbits));
+        if (act) S.q[par][r] = ((uint64_t)(compacted << vbits) << 32) | (uint32_t)home;
+    }
+    if (lane == 0 && count_lookups) S.acc[CNT_LOOKUPS] += qn;
+    wave_sync();
+    NH_STAMP(4);
+
+    uint32_t qhead = 0;  // next queue entry to hand out (uniform)
+    uint32_t busy = lk.busy, r = lk.r, ckey = lk.ckey, budget = lk.budget;
+    uint32_t pos = (uint32_t)lk.pos;
+    const uint32_t q4 = ((uint32_t)lane & 3u) * 4u;         // first cell of the chunk this lane loads
+    const uint32_t own_sub = (uint32_t)lane >> 2;            // which of an instruction's 16 owners it loads for
+    for (;;) {
+        if (qhead < qn) {
+            const uint64_t idle_mask = __ballot(busy == 0);
+            if (idle_mask) {
+                const uint32_t my = qhead + below(idle_mask);
+                if (busy == 0 && my < qn) {
+                    const uint64_t e = S.q[par][my];
+                    pos = (uint32_t)e;
+                    ckey = (uint32_t)(e >> 32);
+                    r = my | (par << 9) | (pick_copy((uint32_t)e, copy_shift) << 10);
+                    budget = max_rounds;
+                    busy = 1;
+                }
+                const uint32_t taken = __popcll(idle_mask);
+                qhead = qhead + taken < qn ? qhead + taken : qn;
+            }
+        }
+        // done when everything is handed out and no lane still works for the previous group
+        if (qhead >= qn && __ballot(busy != 0 && ((r >> 9) & 1u) != par) == 0) break;
+        if (PROF) prof[11] += 1;
+        // owner side: cells of this round = from pos to the end of its line / of the table, 16 at most
+        const uint32_t cj = (r >> 10) & 3u;
+        uint32_t nv = 0;
+        if (busy) {
+            const uint32_t in_line = 32u - ((pos - (cj << copy_shift)) & 31u);
+            const uint32_t room = (uint32_t)cap - pos;
+            nv = in_line < room ? in_line : room;
+            nv = nv < 16u ? nv : 16u;
+        }
+        const uint32_t meta = nv | (cj << 8);
+        uint4 c[4];
+        uint32_t ck[4], nvk[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) {  // instruction k: the lookups of owner lanes 16k .. 16k+15, a quad of lanes each
+            const int src = (int)(4u * (16u * (uint32_t)k + own_sub));
+            const uint32_t p = (uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)pos);
+            ck[k] = (uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)ckey);
+            const uint32_t m = (uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)meta);
+            nvk[k] = m & 0xFFu;
+            c[k] = make_uint4(0, 0, 0, 0);
+            if (q4 < nvk[k])  // (a chunk without eligible cells is not loaded: every line-visit costs the L1)
+                c[k] = *reinterpret_cast<const uint4 *>(table + (uint64_t)(m >> 8) * copy_stride + p + q4);
+        }
+        bool found = false;
+        uint32_t val = 0;
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            uint32_t res = 0, resj = 64;
+            scan4(c[k], ck[k], vmask, 0u, res, resj);
+            const bool hit = q4 + resj < nvk[k];  // (resj = 64: no stopping cell in this chunk)
+            const uint64_t hm = __ballot(hit);
+            // the owner reads its quad's nibble: lowest set bit = first chunk with an eligible stopping cell
+            const uint32_t nib = (uint32_t)(hm >> (4u * ((uint32_t)lane & 15u))) & 0xFu;
+            const uint32_t win = 4u * ((uint32_t)lane & 15u) + (nib ? (uint32_t)__builtin_ctz(nib) : 0u);
+            const uint32_t rv = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(4u * win), (int)res);
+            if (((uint32_t)lane >> 4) == (uint32_t)k && nib != 0) {
+                found = true;
+                val = rv;
+            }
+        }
+        if (busy) {
+            const uint32_t np = pos + nv;
+            pos = np >= (uint32_t)cap ? 0u : np;
+            budget--;
+            if (found | (budget == 0)) {
+                tax_at<STD>(S, (r >> 9) & 1u, r & 0x1FFu) = (found && val <= vmask) ? val : 0u;
+                busy = 0;
+            }
+        }
+    }
+    lk.busy = busy;
+    lk.r = r;
+    lk.ckey = ckey;
+    lk.budget = budget;
+    lk.pos = pos;
+    wave_sync();
+    NH_STAMP(5);
+}
+
 // The (taxon, count) list of the fragment being post-processed.  The hot kernel keeps 64 entries in
 // the wave's LDS slice (enough whenever the taxonomy has <= 64 nodes, e.g. every human-only
 // database); the BIG kernel variant re-runs the few fragments that overflowed it with 2048 entries.
@@ -1081,7 +1204,12 @@ __global__ __launch_bounds__(WAVE * WAVES_PER_BLOCK, BIG ? 1 : (STD ? NH_MIN_WAV
     // the previous group -- then post-process the previous group and switch buffers
     auto turn = [&]() {
         flush_records<STD>(ap, S, lane);
-        probe_queue<LINEAR, STD, CAP32, PROF>(ap, S, lane, par, qn, lk, !BIG, prof, tprev);
+#ifndef NH_NO_QUAD
+        if constexpr (LINEAR && STD && CAP32)
+            probe_queue_quad<PROF>(ap, S, lane, par, qn, lk, !BIG, prof, tprev);
+        else
+#endif
+            probe_queue<LINEAR, STD, CAP32, PROF>(ap, S, lane, par, qn, lk, !BIG, prof, tprev);
         if (nslot_old) post_group<STD, BIG, PROF>(ap, S, TLI, lane, mates, reset_per_mate, par ^ 1u, nslot_old, prof, tprev);
         nslot_old = nslot_new;
         par ^= 1u;
@@ -1451,7 +1579,11 @@ __global__ __launch_bounds__(WAVE * WAVES_PER_BLOCK, PROF ? 4 : NH_MIN_WAVES) vo
             const bool full = nslot_new == (uint32_t)NSLOT || qn + TL > (uint32_t)QCAP_SHORT;
             if ((nslot_new != 0 && (full || j == (uint32_t)NSLOT)) || (!batch && j == (uint32_t)NSLOT)) {
                 flush_records<STD>(ap, S, lane);
+#ifdef NH_NO_QUAD
                 probe_queue<true, STD, true, PROF>(ap, S, lane, par, qn, lk, true, prof, tprev);
+#else
+                probe_queue_quad<PROF>(ap, S, lane, par, qn, lk, true, prof, tprev);
+#endif
                 if (nslot_old)
                     post_group<STD, false, PROF>(ap, S, TLI, lane, mates, reset_per_mate, par ^ 1u, nslot_old, prof, tprev);
                 nslot_old = nslot_new;

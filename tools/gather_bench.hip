@@ -197,6 +197,49 @@ static void run_pair(const char *name, const uint32_t *d_table, uint64_t bytes, 
     }
 }
 
+// TA study (round 2): how fast does the vector memory pipeline take a wave-load whose lanes form groups of G
+// consecutive lanes reading G x 16 contiguous bytes of one random line (G = 1: fully divergent)?  Small table
+// (L2-resident) so that neither HBM nor the fabric is the limit.  ALIGNED: the group's bytes start on a
+// (16 G)-byte boundary.
+template <int G, bool ALIGNED>
+__global__ __launch_bounds__(256) void k_groups(const uint32_t *__restrict__ table, uint64_t n_lines, int iters,
+                                                uint32_t *__restrict__ sink) {
+    const uint32_t lane = threadIdx.x & 63;
+    const uint32_t grp = (blockIdx.x * blockDim.x + threadIdx.x) / G;
+    uint64_t s = mix((uint64_t)grp * 0x9E3779B97F4A7C15ull + 1);
+    uint32_t acc = 0;
+    const char *base = reinterpret_cast<const char *>(table);
+    for (int it = 0; it < iters; it++) {
+        s = mix(s + 1);
+        const uint64_t line = __umul64hi(s, n_lines);
+        uint32_t off = (uint32_t)(s >> 3) & (128u - 16u * G) & ~15u;  // start of the group's bytes within the line
+        if (ALIGNED) off &= ~(16u * G - 1u);
+        const uint4 v = *reinterpret_cast<const uint4 *>(base + line * 128 + off + 16u * (lane % G));
+        acc += v.x ^ v.y ^ v.z ^ v.w;
+        s += acc & 1;  // dependent: one load in flight per lane
+    }
+    if (acc == 0x12345678u) sink[0] = acc;
+}
+
+template <int G, bool ALIGNED>
+static void run_groups(const uint32_t *d_table, uint64_t bytes, uint32_t *d_sink) {
+    const int iters = 2048, blocks = 256 * 5;  // 20 waves per CU
+    hipEvent_t e0, e1;
+    CK(hipEventCreate(&e0));
+    CK(hipEventCreate(&e1));
+    hipLaunchKernelGGL((k_groups<G, ALIGNED>), dim3(blocks), dim3(256), 0, 0, d_table, bytes / 128, iters, d_sink);
+    CK(hipDeviceSynchronize());
+    CK(hipEventRecord(e0));
+    hipLaunchKernelGGL((k_groups<G, ALIGNED>), dim3(blocks), dim3(256), 0, 0, d_table, bytes / 128, iters, d_sink);
+    CK(hipEventRecord(e1));
+    CK(hipEventSynchronize(e1));
+    float ms = 0;
+    CK(hipEventElapsedTime(&ms, e0, e1));
+    const double wl = (double)blocks * 4 * iters;  // wave-loads
+    printf("  groups of %d lanes x 16 B %-9s: %7.2f G wave-loads/s chip = %6.1f cycles per wave-load per CU (2.4 GHz), %7.2f G groups/s\n",
+           G, ALIGNED ? "aligned" : "unaligned", wl / ms / 1e6, 2.4e9 / (wl / ms * 1e3 / 256), wl * (64 / G) / ms / 1e6);
+}
+
 static void curve(const uint32_t *d_table, uint64_t n_chunks, uint32_t *d_sink) {
     printf("latency/throughput curve: every lane keeps exactly ONE dependent 16-B probe in flight\n");
     const int iters = 256;
@@ -232,6 +275,17 @@ int main(int argc, char **argv) {
     uint64_t n_chunks = bytes / 16;
     printf("table %.2f GiB, %d loads per thread\n", gib, iters);
 
+
+    if (argc > 3 && atoi(argv[3]) == 2) {  // TA study: table should be small (L2-resident), e.g. 0.002 GiB
+        printf("TA study: dependent 16-byte loads, lanes grouped on contiguous bytes of one random line\n");
+        run_groups<1, true>(d_table, bytes, d_sink);
+        run_groups<2, true>(d_table, bytes, d_sink);
+        run_groups<2, false>(d_table, bytes, d_sink);
+        run_groups<4, true>(d_table, bytes, d_sink);
+        run_groups<4, false>(d_table, bytes, d_sink);
+        run_groups<8, true>(d_table, bytes, d_sink);
+        return 0;
+    }
     if (argc > 3 && atoi(argv[3]) == 1) {  // pair study only
         printf("pair study: two 16-B probes per lane per round (one dependent round in flight per lane)\n");
         run_pair<2>("random + random", d_table, bytes, 0, d_sink);
