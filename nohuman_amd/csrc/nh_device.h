@@ -8,7 +8,7 @@ namespace nh {
 // argument (lives in SGPRs / the kernarg segment; no global loads for it).
 struct DevDB {
     const uint32_t *table;  // hash.k2d cells, capacity entries (+ padding to a multiple of 4, +32); 128-byte aligned
-    // The table is resident n_copies times (1, 2 or 4).  Copy j starts copy_stride cells after copy
+    // The table is resident n_copies times (1, 2, 4 or 8).  Copy j starts copy_stride cells after copy
     // j-1 and lies 32/n_copies cells (mod 32) further to the LEFT on the 128-byte line grid, so cell i
     // of copy j sits (i - j * 32/n_copies) mod 32 cells into its line.  A probe round at cell p uses
     // copy (p mod 32) / (32/n_copies): there p lies in the first 32/n_copies cells of a line and the
@@ -16,7 +16,7 @@ struct DevDB {
     // fetches (profiles/r02_pair_study.txt: the gather ceiling is a rate of 128-byte lines).
     uint64_t copy_stride;   // cells from one copy to the next
     uint32_t n_copies;
-    uint32_t copy_shift;    // log2(32 / n_copies): 5, 4 or 3
+    uint32_t copy_shift;    // log2(32 / n_copies): 5, 4, 3 or 2
     uint64_t capacity;
     uint64_t cap_magic;     // floor((2^64 - 1) / capacity): exact `hc % capacity` without a divide
     const uint32_t *parent; // taxonomy: internal parent ids [node_count]

@@ -125,7 +125,7 @@ static void finish_devdb(Engine *e) {
     d.table = e->d_table;
     d.copy_stride = e->copy_stride;
     d.n_copies = e->n_copies;
-    d.copy_shift = e->n_copies == 4 ? 3u : e->n_copies == 2 ? 4u : 5u;
+    d.copy_shift = e->n_copies == 8 ? 2u : e->n_copies == 4 ? 3u : e->n_copies == 2 ? 4u : 5u;
     d.capacity = i.capacity;
     d.cap_magic = ~0ull / i.capacity;
     d.parent = e->d_parent;
@@ -155,11 +155,11 @@ static int alloc_table(Engine *e, uint64_t capacity) {
     // Staggered copies (DevDB::copy_stride): the gather ceiling of the chip is a rate of 128-byte lines,
     // and a probe run that starts in the first half of its line leaves it 3.5x less often than one
     // that starts anywhere (tools/probe_cost_model.py: 1.158 -> 1.045 lines per lookup at load 0.7).  HBM is not the scarce resource here (4 x 5.7 GB on a 288 GB device).  Only for tables with
-    // 32-bit cell positions (the kernel variant that uses them); NOHUMAN_TABLE_COPIES=1|2|4.
-    uint32_t want = 2;  // 4 measured the same as 2 (profiles/r02_tuning.txt): not worth another 11 GB
+    // 32-bit cell positions (the kernel variant that uses them); NOHUMAN_TABLE_COPIES=1|2|4|8.
+    uint32_t want = 4;  // with quad probing: 787 / 964 / 1000 Mreads/s for 1 / 2 / 4 copies (profiles/r02_tuning.txt)
     if (const char *env = getenv("NOHUMAN_TABLE_COPIES")) {
         const int v = atoi(env);
-        want = v >= 4 ? 4u : v >= 2 ? 2u : 1u;
+        want = v >= 8 ? 8u : v >= 4 ? 4u : v >= 2 ? 2u : 1u;
     }
     if (capacity >= 0xFFFFFF00ull) want = 1;
     for (;; want >>= 1) {
@@ -170,6 +170,9 @@ static int alloc_table(Engine *e, uint64_t capacity) {
             e->d_table = (uint32_t *)(((uintptr_t)e->d_table_raw + 127) & ~(uintptr_t)127);
             e->n_copies = want;
             e->copy_stride = stride;
+            if (getenv("NOHUMAN_TRACE"))
+                fprintf(stderr, "[nohuman trace] hash table: %u staggered cop%s of %.2f GB\n", want, want == 1 ? "y" : "ies",
+                        (double)e->table_cells_alloc * 4 / 1e9);
             return NH_OK;
         }
         (void)hipGetLastError();

@@ -616,7 +616,7 @@ __device__ __forceinline__ void probe_queue(KArgsP ap, WL &S, const int lane,
                 const uint32_t *src;
                 if (CAP32) {
                     const uint32_t p32 = (uint32_t)pos;
-                    src = probe_src(table, copy_stride, copy_shift, (r >> 10) & 3u, p32, in_line);
+                    src = probe_src(table, copy_stride, copy_shift, (r >> 10) & 7u, p32, in_line);
                     const uint32_t room = (uint32_t)cap - p32;
                     nvalid = in_line < room ? in_line : room;
                 } else {
@@ -776,7 +776,7 @@ __device__ __forceinline__ void probe_queue_quad(KArgsP ap, WL &S, const int lan
         if (qhead >= qn && __ballot(busy != 0 && ((r >> 9) & 1u) != par) == 0) break;
         if (PROF) prof[11] += 1;
         // owner side: cells of this round = from pos to the end of its line / of the table, 16 at most
-        const uint32_t cj = (r >> 10) & 3u;
+        const uint32_t cj = (r >> 10) & 7u;
         uint32_t nv = 0;
         if (busy) {
             const uint32_t in_line = 32u - ((pos - (cj << copy_shift)) & 31u);
