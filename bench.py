@@ -224,6 +224,8 @@ def measure(cx, args, *, steps, warmup, single_end=False, ont=False, hit_frac=0.
             "traffic_source": "profiles/traffic.json (static: rocprofv3 --pmc passes of this workload, "
                               "not measured in this run)",
             "fabric_request_frac": request_rate_frac(n_frag, paired, L, info.capacity, kernel_ms, variant),
+            # the same static traffic over THIS run's kernel time, against the 6.29 TB/s the chip reaches on a copy
+            "hbm_achievable_frac": hbm_frac(n_frag, paired, L, info.capacity, kernel_ms, variant),
             "kernel": "k_classify_short" if not (ont or L > 158) else "k_classify",
             "kernel_ms": round(kernel_ms, 4),
             "kernel_ms_per_rank": [round(x, 4) for x in rank_kernel_ms],
@@ -371,6 +373,13 @@ def request_rate_frac(n_frag, paired, read_len, capacity, kernel_ms, variant=Fal
     if not t or not t.get("fabric_read_requests_per_launch") or kernel_ms <= 0:
         return None
     return round(t["fabric_read_requests_per_launch"] / (kernel_ms * 1e-3) / t["fabric_request_ceiling_per_s"], 4)
+
+
+def hbm_frac(n_frag, paired, read_len, capacity, kernel_ms, variant=False):
+    t = _traffic_record(n_frag, paired, read_len, capacity, variant)
+    if not t or not t.get("traffic_bytes_per_launch") or kernel_ms <= 0:
+        return None
+    return round(t["traffic_bytes_per_launch"] / (kernel_ms * 1e-3) / 1e9 / t.get("hbm_achievable_gbs", 6290.0), 4)
 
 
 def cpu_baseline(cx, args, live, budget_s):
