@@ -15,9 +15,10 @@
 //     -> canonical/spaced/toggled candidates in LDS -> per lane two k-mer minimizers (window min)
 //     -> run starts (minimizer != previous non-ambiguous minimizer) appended to the LDS queue
 //   HASH the queue densely (fmix64, exact hc % capacity), then PROBE it with lane refill: a lane
-//     owns one lookup at a time, walks its 128-byte line in 16-byte chunks, and pulls the next
-//     queued lookup the moment it resolves -- the wave does not idle on the longest probe sequence
-//     (linear probing at load 0.7 is heavy-tailed: the max over 39 lookups is ~10 chunks)
+//     owns one lookup at a time and pulls the next queued lookup the moment it resolves -- the wave
+//     does not idle on the longest probe sequence (linear probing at load 0.7 is heavy-tailed).  On
+//     the hot variants a round's bytes are fetched quad-cooperatively: four lanes read 64 contiguous
+//     bytes (16 cells) of the owner's 128-byte line (probe_queue_quad)
 //   POST each tile: taxa back from LDS -> per-taxon hit counts, hit groups; at the end of a
 //     fragment ResolveTree runs on the wave.
 // The kernel is instruction-issue and latency sensitive (profiles/): tile-local arithmetic is
@@ -513,9 +514,10 @@ __device__ __forceinline__ void scan4(const uint4 &c, uint32_t ckey, uint32_t vm
 //   otherwise:                      home cell << key_bits | compacted key   (<= 63 bits, checked at open)
 // Double hashing keeps the hash code itself.
 // (Tried in round 2 and dropped: issuing the first round of EVERY queue entry from the hash pass, 2.4 loads
-// in flight per lane.  Half the round trips per group, 10 % fewer instructions -- and 16 % slower:
-// on this chip a random gather runs fastest with ONE load in flight per lane and many waves
-// (profiles/r02_pair_study.txt, tools/gather_bench: deep per-wave queues lower the line rate).)
+// in flight per lane.  Half the round trips per group, 10 % fewer instructions -- and 16 % slower: a fully
+// divergent wave-load occupies the CU's L1 path for ~152 cycles (2.4 per distinct line,
+// profiles/r02_mem_study.txt), and that path was the second wall next to HBM.  probe_queue_quad below is
+// what came of it.)
 template <bool LINEAR, bool STD, bool CAP32, bool PROF, class WL>
 __device__ __forceinline__ void probe_queue(KArgsP ap, WL &S, const int lane,
                                             const uint32_t par,
