@@ -10,7 +10,76 @@
 #include <string.h>
 #include <zlib.h>
 
+#include <condition_variable>
+#include <mutex>
+#include <thread>
+
 namespace nh {
+
+// One outstanding src.read() at a time, executed by a helper thread: the reader thread parses the stretch it
+// already has while the next one is inflated / read straight into the same batch buffer (the copy out of the
+// decoder's chunk buffers and the record parse each stream the whole text once; serialised on one thread they
+// were the longest stage of a gzip run).
+class ReadAhead {
+public:
+    explicit ReadAhead(ByteSource *src) : src_(src), th_([this] { loop(); }) {}
+    ~ReadAhead() {
+        {
+            std::lock_guard<std::mutex> lk(mu_);
+            quit_ = true;
+        }
+        cv_.notify_all();
+        th_.join();
+    }
+    void issue(uint8_t *dst, size_t cap) {
+        std::lock_guard<std::mutex> lk(mu_);
+        dst_ = dst;
+        cap_ = cap;
+        state_ = 1;
+        cv_.notify_all();
+    }
+    bool pending() {
+        std::lock_guard<std::mutex> lk(mu_);
+        return state_ != 0;
+    }
+    long wait() {  // result of the issued read
+        std::unique_lock<std::mutex> lk(mu_);
+        cv_.wait(lk, [&] { return state_ == 2; });
+        state_ = 0;
+        return n_;
+    }
+
+private:
+    void loop() {
+        for (;;) {
+            uint8_t *d;
+            size_t c;
+            {
+                std::unique_lock<std::mutex> lk(mu_);
+                cv_.wait(lk, [&] { return quit_ || state_ == 1; });
+                if (quit_) return;
+                d = dst_;
+                c = cap_;
+            }
+            const long n = src_->read(d, c);
+            {
+                std::lock_guard<std::mutex> lk(mu_);
+                n_ = n;
+                state_ = 2;
+            }
+            cv_.notify_all();
+        }
+    }
+    ByteSource *src_;
+    std::mutex mu_;
+    std::condition_variable cv_;
+    uint8_t *dst_ = nullptr;
+    size_t cap_ = 0;
+    long n_ = 0;
+    int state_ = 0;  // 0 idle, 1 issued, 2 done
+    bool quit_ = false;
+    std::thread th_;
+};
 
 // bzip2 inputs (kraken2's wrapper pipes them through `bzip2 -dc`): decoded in process with the
 // system's libbz2.so.1 -- the image has the library but not bzlib.h.  Concatenated streams are decoded
@@ -459,6 +528,14 @@ int BlockReader::parse_one(HalfBatch &hb, size_t &pos, size_t len) {
     return 1;
 }
 
+BlockReader::~BlockReader() { close(); }
+
+void BlockReader::close() {
+    delete ahead_;  // joins the helper: no read may be in flight when the source goes away
+    ahead_ = nullptr;
+    src_.close();
+}
+
 void BlockReader::next_batch(HalfBatch &hb, size_t max_recs, size_t max_text) {
     const size_t CHUNK = chunk_;
     const size_t LIMIT = 0xFFF00000ull;  // offsets are 32-bit
@@ -473,38 +550,59 @@ void BlockReader::next_batch(HalfBatch &hb, size_t max_recs, size_t max_text) {
     hb.text.set_size(tail_.size());
     tail_.clear();
     if (fa_resume_rec_ != (size_t)-1) fa_resume_rec_ = (size_t)-1;  // offsets changed: rescan
+    if (!ahead_) ahead_ = new ReadAhead(&src_);
     size_t pos = 0;
-    bool done = false;
-    while (!done) {
-        int r = 1;
-        while (hb.recs.size() < max_recs && pos < max_text) {
-            r = parse_one(hb, pos, hb.text.size());
-            if (r != 1) break;
-        }
-        if (r < 0) {  // end of input or malformed
-            hb.text.set_size(pos);
-            return;
-        }
-        if (r == 1) break;  // batch full
-        // more input needed
+    bool inflight = false;
+    // the next stretch of input is read into the buffer (by the helper) while this thread parses what is there
+    auto issue = [&]() -> bool {
+        if (eof_ || inflight) return true;
         if (hb.text.size() + CHUNK > LIMIT) {
             hb.error = "sequence record larger than 4 GB";
-            return;
+            return false;
         }
-        if (!hb.text.reserve(hb.text.size() + CHUNK)) {
+        if (!hb.text.reserve(hb.text.size() + CHUNK)) {  // (never while a read is in flight: it may move the buffer)
             hb.error = "out of memory";
-            return;
+            return false;
         }
-        long n = src_.read((uint8_t *)hb.text.data() + hb.text.size(), CHUNK);
+        ahead_->issue((uint8_t *)hb.text.data() + hb.text.size(), CHUNK);
+        inflight = true;
+        return true;
+    };
+    auto collect = [&]() -> bool {  // waits for the read in flight and appends what it brought
+        if (!inflight) return true;
+        inflight = false;
+        const long n = ahead_->wait();
         if (n < 0) {
             hb.error = src_.error().empty() ? std::string("read error on input file") : src_.error();
-            return;
+            return false;
         }
         if (n == 0)
             eof_ = true;
         else
             hb.text.set_size(hb.text.size() + (size_t)n);
+        return true;
+    };
+    for (;;) {
+        if (!issue()) break;
+        int r = 1;
+        const size_t avail = hb.text.size();  // (the helper writes beyond it)
+        while (hb.recs.size() < max_recs && pos < max_text) {
+            r = parse_one(hb, pos, avail);
+            if (r != 1) break;
+        }
+        if (r < 0) {  // end of input or malformed
+            if (inflight) (void)ahead_->wait();
+            hb.text.set_size(pos);
+            return;
+        }
+        if (r == 1) break;  // batch full
+        if (!collect()) return;  // more input needed
     }
+    if (!hb.error.empty()) {
+        if (inflight) (void)ahead_->wait();
+        return;
+    }
+    if (!collect()) return;
     // keep what follows the last complete record for the next batch
     if (!tail_.append(hb.text.data() + pos, hb.text.size() - pos)) {
         hb.error = "out of memory";

@@ -156,13 +156,19 @@ struct HalfBatch {  // the records one input file contributes to a batch
 // Same record semantics as FastxReader (kraken2 seqreader.cc).  The input is read
 // (inflated) straight into the batch's text buffer and parsed in place: a RecRef is a set of offsets
 // into the raw bytes, nothing is copied per record (multi-line FASTA sequences are joined in place).
+class ReadAhead;  // helper thread that fills the next stretch of a batch's text while the previous one is parsed
+
 class BlockReader {
 public:
+    BlockReader() = default;
+    BlockReader(const BlockReader &) = delete;
+    BlockReader &operator=(const BlockReader &) = delete;
+    ~BlockReader();
     int open(const char *path, std::string &err, unsigned gz_threads = 0);
     // parses up to max_recs records (or about max_text bytes) into hb (which is reset first);
     // sets hb.eof at end of input.  Text offsets are 32-bit: max_text is clamped below 2^32.
     void next_batch(HalfBatch &hb, size_t max_recs, size_t max_text);
-    void close() { src_.close(); }
+    void close();
 
 private:
     // one record at text[pos..len): 1 parsed, 0 more input needed, -1 end of input reached
@@ -175,6 +181,7 @@ private:
     size_t chunk_ = 4u << 20;  // bytes per read of the source
     size_t fa_resume_ = 0;  // FASTA: the scan of the record at `pos` may resume here (long records)
     size_t fa_resume_rec_ = (size_t)-1;
+    ReadAhead *ahead_ = nullptr;
 };
 
 }  // namespace nh
