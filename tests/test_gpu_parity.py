@@ -1,4 +1,6 @@
 """GPU parity tests proper: the HIP path (through the C ABI) against the CPU oracle, bit-exact."""
+import os
+
 import numpy as np
 import pytest
 
@@ -385,3 +387,38 @@ def test_sequences_in_place_inside_their_record_text(toy, toy_oracle, paired):
     assert np.array_equal(taxa.cpu().numpy().view(np.uint32)[: len(etaxa)], etaxa)
     c = cnt.tolist()
     assert c == [n, int((exp["call"] != 0).sum()), sum(len(s) for s in seqs), int(lookups.sum())]
+
+
+@pytest.mark.parametrize("capacity", [1, 2, 3, 5, 15, 16, 17, 31, 32, 33, 47, 64, 100, 257])
+def test_tiny_tables_wrap_around_and_full_cycles(toy, capacity):
+    """Tables smaller than one probe round, one line, two lines: probe runs wrap around the end of the table
+    (several times inside one 16-cell quad round), and on a FULL table a miss must stop after exactly one
+    cycle.  Cells are random (taxa of the toy tree), so every lookup is a miss or a chance
+    match (6 key bits): GPU == oracle on records, per-k-mer taxa and lookup counts, single copy and staggered copies."""
+    import struct
+    from nohuman_amd import Engine
+    ob, tb, _, genomes, tax = toy
+    vb = 26  # 6 key bits: unrelated minimizers match by chance all the time
+    rng = np.random.default_rng(capacity)
+    for fill in (0.5, 0.9, 1.0):
+        cells = np.zeros(capacity, dtype=np.uint32)
+        occ = rng.random(capacity) < fill if fill < 1.0 else np.ones(capacity, bool)
+        keys = rng.integers(0, 1 << 6, size=capacity, dtype=np.uint32)
+        vals = rng.integers(1, 10, size=capacity, dtype=np.uint32)
+        cells[occ] = ((keys[occ] << vb) | vals[occ]).astype(np.uint32)
+        hb = struct.pack("<4Q", capacity, int(occ.sum()), 32 - vb, vb) + cells.tobytes()
+        reads = [synth.random_seq(rng, int(n)) for n in rng.integers(35, 200, size=300)]
+        bases, offs = orc.pack_reads(reads, False)
+        odb = orc.OracleDB(ob, tb, hb)
+        exp, lookups, etaxa, _ = odb.classify(bases, offs, False, 0.0, want_taxa=True)
+        for copies in ("1", "4"):
+            os.environ["NOHUMAN_TABLE_COPIES"] = copies
+            try:
+                with Engine.from_images(ob, tb, hb) as eng:
+                    got, taxa, _ = eng.classify(bases, offs, False, 0.0, want_taxa=True)
+                    st = eng.stats()
+            finally:
+                os.environ.pop("NOHUMAN_TABLE_COPIES", None)
+            _assert_same(got, exp, "capacity %d fill %.1f copies %s" % (capacity, fill, copies))
+            assert np.array_equal(taxa, etaxa)
+            assert st.table_lookups == int(lookups.sum())
