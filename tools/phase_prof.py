@@ -13,6 +13,11 @@ mates = 2 if paired else 1
 acgt = torch.tensor([65, 67, 71, 84], dtype=torch.uint8, device=dev)
 bases = acgt[torch.randint(0, 4, (n * mates * L + 64,), device=dev)].contiguous()
 offs = (torch.arange(n * mates + 1, dtype=torch.int64, device=dev) * L).contiguous()
+if "--hit" in sys.argv:  # every read "human": its minimizers are in the table (1 % of the bases mutated afterwards)
+    eng.add_sequences(bases.data_ptr(), offs.data_ptr(), n * mates, 30)
+    m = torch.rand(n * mates * L, device=dev) < 0.01
+    sub = acgt[torch.randint(0, 4, (n * mates * L,), device=dev)]
+    bases[: n * mates * L] = torch.where(m, sub, bases[: n * mates * L])
 res = torch.empty((n, 4), dtype=torch.int32, device=dev)
 cnt = torch.zeros(16, dtype=torch.int64, device=dev)
 st = torch.cuda.current_stream().cuda_stream
