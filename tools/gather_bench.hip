@@ -276,6 +276,26 @@ int main(int argc, char **argv) {
     printf("table %.2f GiB, %d loads per thread\n", gib, iters);
 
 
+
+    if (argc > 3 && atoi(argv[3]) == 3) {  // memory-type study: does an uncached / fine-grained table fetch less than 128 B per probe?
+        static const unsigned flags[] = {0u, hipDeviceMallocFinegrained, hipDeviceMallocUncached};
+        static const char *names[] = {"hipMalloc (default)", "hipDeviceMallocFinegrained", "hipDeviceMallocUncached"};
+        for (int f = 0; f < 3; f++) {
+            uint32_t *t = nullptr;
+            hipError_t e = f == 0 ? hipMalloc((void **)&t, bytes) : hipExtMallocWithFlags((void **)&t, bytes, flags[f]);
+            if (e != hipSuccess) {
+                printf("%s: allocation failed (%s)\n", names[f], hipGetErrorString(e));
+                (void)hipGetLastError();
+                continue;
+            }
+            CK(hipMemset(t, 1, bytes));
+            printf("%s:\n", names[f]);
+            run_groups<1, true>(t, bytes, d_sink);
+            run_groups<4, true>(t, bytes, d_sink);
+            CK(hipFree(t));
+        }
+        return 0;
+    }
     if (argc > 3 && atoi(argv[3]) == 2) {  // TA study: table should be small (L2-resident), e.g. 0.002 GiB
         printf("TA study: dependent 16-byte loads, lanes grouped on contiguous bytes of one random line\n");
         run_groups<1, true>(d_table, bytes, d_sink);
