@@ -520,7 +520,7 @@ uint64_t kmer_taxa_entries(const Engine *e, const uint64_t *seq_offsets, uint64_
 // small batch is cut finer so that every resident wave still gets about two chunks.
 static uint32_t frag_chunk_for(const Engine *e, uint32_t flags, uint64_t n_frag) {
     if (flags & NH_FLAG_LONG) return 1;
-    static const char *env = getenv("NOHUMAN_FRAG_CHUNK");  // tuning knob
+    const char *env = getenv("NOHUMAN_FRAG_CHUNK");  // tuning / test knob (read at every launch)
     const bool paired = (flags & NH_FLAG_PAIRED) != 0;
     uint32_t c = env ? (uint32_t)atoi(env) : (paired ? 24u : 32u);
     const uint64_t waves = (uint64_t)e->grid_blocks * 4;

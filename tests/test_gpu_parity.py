@@ -422,3 +422,47 @@ def test_tiny_tables_wrap_around_and_full_cycles(toy, capacity):
             _assert_same(got, exp, "capacity %d fill %.1f copies %s" % (capacity, fill, copies))
             assert np.array_equal(taxa, etaxa)
             assert st.table_lookups == int(lookups.sum())
+
+
+@pytest.mark.parametrize("seed", range(16))
+def test_default_geometry_length_mixtures_around_the_tile_boundary(toy, toy_oracle, seed):
+    """Default k=35/l=31 database, reads whose lengths straddle every boundary the two kernels care about:
+    no k-mer (< 35), one tile exactly (158), one base more (159: the chunk is left to the generic kernel),
+    multi-tile reads, empty mates -- shuffled, so that chunks of 24 pairs / 32 reads mix short-only and
+    deferred chunks; paired or not, with N and lower case, several confidences and chunk sizes."""
+    from nohuman_amd import Engine
+    ob, tb, hb, genomes, _ = toy
+    rng = np.random.default_rng(9000 + seed)
+    paired = bool(seed & 1)
+    pools = [np.arange(0, 40), np.arange(150, 171), np.array([157, 158, 159, 160]), np.arange(280, 330),
+             np.arange(600, 1400, 37)]
+    weights = [0.1, 0.45, 0.2, 0.15, 0.1] if seed % 4 else [0.1, 0.7, 0.2, 0.0, 0.0]  # some seeds: short reads only
+    n = 1500
+    lens = [int(rng.choice(pools[int(rng.choice(5, p=weights))])) for _ in range(n * (2 if paired else 1))]
+    g = sorted(genomes)
+    seqs = []
+    for ln in lens:
+        src = genomes[g[int(rng.integers(0, len(g)))]]
+        if rng.random() < 0.3 or len(src) <= ln:
+            s = synth.random_seq(rng, ln)
+        else:
+            st = int(rng.integers(0, len(src) - ln))
+            s = src[st:st + ln]
+            if rng.random() < 0.5:
+                s = synth.revcomp(s)
+        seqs.append(synth.mutate(rng, s, 0.01, float(rng.choice([0.0, 0.003, 0.03])), 0.05))
+    reads = list(zip(seqs[0::2], seqs[1::2])) if paired else seqs
+    bases, offs = orc.pack_reads(reads, paired)
+    conf = float(rng.choice([0.0, 0.1, 0.6]))
+    exp, lookups, etaxa, _ = toy_oracle.classify(bases, offs, paired, conf, want_taxa=True)
+    chunk = str(int(rng.choice([1, 3, 7, 24, 31]))) if paired else str(int(rng.choice([1, 5, 32, 63])))
+    os.environ["NOHUMAN_FRAG_CHUNK"] = chunk
+    try:
+        with Engine.from_images(ob, tb, hb) as eng:
+            got, taxa, _ = eng.classify(bases, offs, paired, conf, want_taxa=True)
+            st = eng.stats()
+    finally:
+        os.environ.pop("NOHUMAN_FRAG_CHUNK", None)
+    _assert_same(got, exp, "seed %d paired %s conf %s chunk %s" % (seed, paired, conf, chunk))
+    assert np.array_equal(taxa, etaxa)
+    assert st.table_lookups == int(lookups.sum()) and st.total_bases == sum(lens)
