@@ -17,8 +17,9 @@ Prints ONE JSON line on rank 0 (contract in the round brief), including
                   launch / average kernel duration measured with HIP events on the launch stream,
   "cpu_baseline": the CPU oracle (oracle/k2_oracle.c, kind "port": kraken2 itself is not on the
                   box) timed on the host cores on a bounded sample of the same workload,
-  "variants":     N=1 only, reduced step counts: the hit path (half of the fragments "human") and the
-                  single-end shape of BASELINE.json configs[1], each checked against the oracle,
+  "variants":     N=1 only, reduced step counts: the hit path (half of the fragments "human"), the
+                  single-end shape of BASELINE.json configs[1] and ONT-like long reads (configs[3] shape,
+                  200 k reads per launch), each checked against the oracle on a sample,
   "e2e":          N=1 only: nh_run() files-in -> files-out on gzip pairs (configs[2] shape at a stated
                   scale), wall clock and per-stage times; never mixed into `value`.
 """
@@ -233,7 +234,7 @@ def measure(cx, args, *, steps, warmup, single_end=False, ont=False, hit_frac=0.
         },
     }
     live = dict(eng=eng, pool=pool, offsets=offsets, results=results, step=step, mates=mates, paired=paired,
-                n_frag=n_frag)
+                n_frag=n_frag, ont=ont)
     if keep:
         return m, live
     eng.close()
@@ -327,7 +328,8 @@ def main():
     if solo and not args.no_variants and not (args.ont or args.single_end or args.hit_frac):
         out["variants"] = {}
         for name, kw in (("hit_frac_0.5_PE", dict(hit_frac=0.5, pairs=1_000_000)),
-                         ("single_end_config1", dict(single_end=True, pairs=1_000_000))):
+                         ("single_end_config1", dict(single_end=True, pairs=1_000_000)),
+                         ("ont_config3_scaled", dict(ont=True, pairs=200_000))):
             vm, vlive = measure(cx, args, steps=6, warmup=2, keep=True, **kw)
             chk = cpu_baseline(cx, args, vlive, 1.5)
             vlive["eng"].close()
@@ -396,6 +398,8 @@ def cpu_baseline(cx, args, live, budget_s):
                        header=(info.capacity, info.size, info.key_bits, info.value_bits))
     del cells
     chunk = 65536 if budget_s < 5 else 262144
+    if live.get("ont"):
+        chunk = 8192  # ~80 Mbases per oracle call
     done = 0
     spent = 0.0
     n_frag = live["n_frag"]
