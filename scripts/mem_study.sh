@@ -1,5 +1,7 @@
 #!/bin/bash
-# memory-side counters of k_classify_short next to the pure gather microbenchmark
+# memory-side counters of k_classify_short next to the pure gather microbenchmark.
+# NOTE: tools/gather_bench under rocprofv3 --pmc is SLOW (minutes per pass: hundreds of launches with counters); the
+# first two counter sets took 30 GPU-minutes in round 2.  Run single sets with scripts/pmc_one.sh when in doubt.
 REPO=$(pwd); OUT=$REPO/gpurun_out/mem; rm -rf "$OUT"; mkdir -p "$OUT"; export TMPDIR=/tmp
 BENCH="python3 $REPO/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-e2e --no-variants"
 cd /tmp
