@@ -447,6 +447,19 @@ def e2e_leg(cx, args, eng):
     threads = min(16, usable_cpu_count())
     n, L, reps = args.e2e_pairs, args.read_len, args.e2e_reps
     base = "/dev/shm" if os.path.isdir("/dev/shm") and os.access("/dev/shm", os.W_OK) else None
+    # inputs and outputs live in memory (tmpfs): scale the leg down on a host that cannot hold them
+    try:
+        free = shutil.disk_usage(base or tempfile.gettempdir()).free
+        with open("/proc/meminfo") as f:
+            avail = [int(x.split()[1]) * 1024 for x in f if x.startswith("MemAvailable:")][0]
+        room = min(free, avail)
+    except (OSError, IndexError, ValueError):
+        room = 1 << 62
+    per_rep = n * 2 * (18 + 2 * L + 4) * 1.25  # text out + compressed in, per member pair
+    while reps > 1 and per_rep * reps + (6 << 30) > 0.6 * room:
+        reps -= 1
+    if per_rep + (6 << 30) > 0.6 * room:
+        return {"skipped": "not enough memory-backed space for the e2e inputs and outputs (%.1f GB usable)" % (room / 1e9)}
     tmp = tempfile.mkdtemp(prefix="nh_bench_e2e_", dir=base)
     try:
         dev = cx.dev
