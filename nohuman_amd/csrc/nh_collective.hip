@@ -44,7 +44,7 @@ int phdr_cb(struct dl_phdr_info *info, size_t, void *data) {
     return 0;
 }
 
-int load_rccl(Rccl &r, std::string &why) {
+int load_rccl_once(Rccl &r, std::string &why) {
     Loaded l;
     dl_iterate_phdr(phdr_cb, &l);
     std::vector<std::string> cand;
@@ -89,19 +89,34 @@ int load_rccl(Rccl &r, std::string &why) {
     return ok ? 0 : -1;
 }
 
-}  // namespace
-
-// rows: n_dev x 4 uint64, row g = the counters of device ids[g]; on success every row holds the sum.
-int allreduce_counters(const int *ids, int n_dev, uint64_t *rows, std::string &backend) {
-    if (!ids || !rows || n_dev <= 0) return set_error(NH_EINVAL, "allreduce_counters: bad argument");
+// RCCL is resolved once per process and stays loaded (a handle per call leaked)
+struct RcclOnce {
     Rccl r;
     std::string why;
-    if (load_rccl(r, why) != 0) return set_error(NH_EDEVICE, "RCCL unavailable: %s", why.c_str());
+    int rc;
+    RcclOnce() { rc = load_rccl_once(r, why); }
+};
+const RcclOnce &rccl() {
+    static const RcclOnce once;
+    return once;
+}
+
+}  // namespace
+
+// rows: n_dev x 4 uint64.  d_src == NULL: row g holds the counters of device ids[g] (uploaded for the
+// reduction); d_src[g] != NULL: the counters are the four uint64 the classify kernels of the run have
+// been adding to in device ids[g]'s HBM -- they are reduced where they lie (out of place into a scratch
+// row per device), nothing is uploaded.  On success every row holds the sum.
+int allreduce_counters(const int *ids, int n_dev, uint64_t *rows, std::string &backend, const uint64_t *const *d_src) {
+    if (!ids || !rows || n_dev <= 0) return set_error(NH_EINVAL, "allreduce_counters: bad argument");
+    const RcclOnce &once = rccl();
+    if (once.rc != 0) return set_error(NH_EDEVICE, "RCCL unavailable: %s", once.why.c_str());
+    const Rccl &r = once.r;
     int version = 0;
     (void)r.GetVersion(&version);
     std::vector<ncclComm_t> comms((size_t)n_dev, nullptr);
     int rc = r.CommInitAll(comms.data(), n_dev, ids);
-    if (rc != 0) return set_error(NH_EDEVICE, "ncclCommInitAll: %s", r.GetErrorString(rc));
+    if (rc != 0) return set_error(NH_EDEVICE, "ncclCommInitAll over %d device(s): %s", n_dev, r.GetErrorString(rc));
     std::vector<uint64_t *> d((size_t)n_dev, nullptr);
     std::vector<hipStream_t> st((size_t)n_dev, nullptr);
     hipError_t he = hipSuccess;
@@ -109,7 +124,8 @@ int allreduce_counters(const int *ids, int n_dev, uint64_t *rows, std::string &b
         he = hipSetDevice(ids[g]);
         if (he == hipSuccess) he = hipStreamCreateWithFlags(&st[g], hipStreamNonBlocking);
         if (he == hipSuccess) he = hipMalloc((void **)&d[g], 4 * sizeof(uint64_t));
-        if (he == hipSuccess) he = hipMemcpyAsync(d[g], rows + 4 * g, 4 * sizeof(uint64_t), hipMemcpyHostToDevice, st[g]);
+        if (he == hipSuccess && !(d_src && d_src[g]))
+            he = hipMemcpyAsync(d[g], rows + 4 * g, 4 * sizeof(uint64_t), hipMemcpyHostToDevice, st[g]);
     }
     int nrc = 0;
     if (he == hipSuccess) {
@@ -117,7 +133,8 @@ int allreduce_counters(const int *ids, int n_dev, uint64_t *rows, std::string &b
         for (int g = 0; g < n_dev && nrc == 0; g++) {
             he = hipSetDevice(ids[g]);
             if (he != hipSuccess) break;
-            nrc = r.AllReduce(d[g], d[g], 4, kNcclUint64, kNcclSum, comms[g], st[g]);  // in place
+            const void *send = (d_src && d_src[g]) ? (const void *)d_src[g] : (const void *)d[g];
+            nrc = r.AllReduce(send, d[g], 4, kNcclUint64, kNcclSum, comms[g], st[g]);
         }
         const int erc = r.GroupEnd();
         if (nrc == 0) nrc = erc;
@@ -136,8 +153,9 @@ int allreduce_counters(const int *ids, int n_dev, uint64_t *rows, std::string &b
     if (nrc != 0) return set_error(NH_EDEVICE, "ncclAllReduce: %s", r.GetErrorString(nrc));
     if (he != hipSuccess) return set_error(NH_EDEVICE, "allreduce_counters: %s", hipGetErrorString(he));
     char buf[512];
-    snprintf(buf, sizeof buf, "RCCL %d.%d.%d (%s), ncclCommInitAll over %d device(s), ncclAllReduce(4 x uint64, sum)",
-             version / 10000, (version / 100) % 100, version % 100, r.path.c_str(), n_dev);
+    snprintf(buf, sizeof buf, "RCCL %d.%d.%d (%s), ncclCommInitAll over %d device(s), ncclAllReduce(4 x uint64, sum)%s",
+             version / 10000, (version / 100) % 100, version % 100, r.path.c_str(), n_dev,
+             d_src ? " of the device-resident counters" : "");
     backend = buf;
     return NH_OK;
 }
@@ -152,7 +170,7 @@ extern "C" int nh_allreduce_counters(const int32_t *device_ids, int32_t n_device
         ids.assign(device_ids, device_ids + (n_devices > 0 ? n_devices : 0));
     else
         for (int i = 0; i < n_devices; i++) ids.push_back(i);
-    const int rc = nh::allreduce_counters(ids.data(), (int)ids.size(), counters, b);
+    const int rc = nh::allreduce_counters(ids.data(), (int)ids.size(), counters, b, nullptr);
     if (backend && backend_len) snprintf(backend, backend_len, "%s", rc ? nh::g_last_error.c_str() : b.c_str());
     return rc;
 }

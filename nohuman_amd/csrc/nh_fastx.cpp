@@ -100,14 +100,25 @@ public:
         if (live_) end_(&bs_);
         if (fd_ >= 0) ::close(fd_);
     }
-    int open(const char *path, std::string &err) {
-        void *h = dlopen("libbz2.so.1.0", RTLD_NOW | RTLD_LOCAL);
-        if (!h) h = dlopen("libbz2.so.1", RTLD_NOW | RTLD_LOCAL);
-        if (h) {
-            init_ = (int (*)(Stream *, int, int))dlsym(h, "BZ2_bzDecompressInit");
-            run_ = (int (*)(Stream *))dlsym(h, "BZ2_bzDecompress");
-            end_ = (int (*)(Stream *))dlsym(h, "BZ2_bzDecompressEnd");
+    // libbz2 is resolved once per process (never unloaded)
+    struct Api {
+        int (*init)(Stream *, int, int) = nullptr;
+        int (*run)(Stream *) = nullptr;
+        int (*end)(Stream *) = nullptr;
+        Api() {
+            void *h = dlopen("libbz2.so.1.0", RTLD_NOW | RTLD_LOCAL);
+            if (!h) h = dlopen("libbz2.so.1", RTLD_NOW | RTLD_LOCAL);
+            if (!h) return;
+            init = (int (*)(Stream *, int, int))dlsym(h, "BZ2_bzDecompressInit");
+            run = (int (*)(Stream *))dlsym(h, "BZ2_bzDecompress");
+            end = (int (*)(Stream *))dlsym(h, "BZ2_bzDecompressEnd");
         }
+    };
+    int open(const char *path, std::string &err) {
+        static const Api api;
+        init_ = api.init;
+        run_ = api.run;
+        end_ = api.end;
         if (!init_ || !run_ || !end_) {
             err = std::string("bzip2 input needs libbz2.so.1, which could not be loaded (") + path + ")";
             return -1;
@@ -160,9 +171,25 @@ public:
             if (r == 4) {  // BZ_STREAM_END: another stream may follow
                 end_(&bs_);
                 live_ = false;
+                streams_++;
+            } else if (r == -5 && streams_ > 0) {
+                // BZ_DATA_ERROR_MAGIC at the start of a follow-on stream: bytes behind the last stream that
+                // are no bzip2 stream.  `bzip2 -dc` (kraken2's pipe) warns "trailing garbage after EOF
+                // ignored" and delivers the data: so does this reader
+                fprintf(stderr, "nohuman: %s: trailing garbage after the last bzip2 stream ignored\n", path_.c_str());
+                end_(&bs_);
+                live_ = false;
+                done_ = true;
             } else if (r != 0) {
                 err = "bzip2: damaged input " + path_;
                 return -1;
+            } else if (bs_.avail_in == 0 && in_eof_ && bs_.avail_out != 0 && streams_ > 0 && bs_.total_in_lo32 < 4 &&
+                       bs_.total_in_hi32 == 0 && bs_.total_out_lo32 == 0) {
+                // the file ends inside what could have been the magic of another stream: trailing garbage too
+                fprintf(stderr, "nohuman: %s: trailing garbage after the last bzip2 stream ignored\n", path_.c_str());
+                end_(&bs_);
+                live_ = false;
+                done_ = true;
             } else if (bs_.avail_in == 0 && in_eof_ && bs_.avail_out != 0) {
                 err = "bzip2: unexpected end of " + path_;
                 return -1;
@@ -180,6 +207,7 @@ private:
     std::string path_;
     int fd_ = -1;
     bool live_ = false, in_eof_ = false, done_ = false;
+    unsigned streams_ = 0;  // complete streams decoded so far
 };
 
 ByteSource::~ByteSource() { close(); }

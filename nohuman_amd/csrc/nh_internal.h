@@ -83,7 +83,9 @@ int classify_host(Engine *e, const uint8_t *bases, const uint64_t *seq_offsets, 
                   uint64_t *kmer_taxa_offsets, uint64_t kmer_taxa_cap);
 int check_error_flag(Engine *e);
 // the path's only collective: rows[g] = counters of device ids[g] -> every row = the sum (RCCL, nh_collective.hip)
-int allreduce_counters(const int *ids, int n_dev, uint64_t *rows, std::string &backend);
+// (d_src[g] != NULL: the four counters lie in device ids[g]'s memory and are reduced from there)
+int allreduce_counters(const int *ids, int n_dev, uint64_t *rows, std::string &backend,
+                       const uint64_t *const *d_src = nullptr);
 uint64_t kmer_taxa_entries(const Engine *e, const uint64_t *seq_offsets, uint64_t n_frag, int mates,
                            uint64_t *offsets_out);
 

@@ -360,15 +360,32 @@ static void slot_free(Slot &s) {
 
 // page-locked text buffers of the batches (RawBuf allocator): the H2D copy of a batch's raw text runs
 // asynchronously straight from where the reader inflated / read it
+// A host that cannot page-lock that much (memlock / cgroup limits) gets pageable memory instead -- the
+// asynchronous copy accepts it and merely stages it itself; a 64-byte header says which kind a block is.
+static std::atomic<int> g_pageable_batches{0};
 static void *pinned_alloc(size_t n) {
     void *p = nullptr;
-    if (hipHostMalloc(&p, n, hipHostMallocPortable) != hipSuccess) {
-        (void)hipGetLastError();
-        return nullptr;
+    static const bool no_pin = getenv("NOHUMAN_NO_PINNED") != nullptr;  // test knob: exercise the fallback
+    if (!no_pin && hipHostMalloc(&p, n + 64, hipHostMallocPortable) == hipSuccess) {
+        *(uint64_t *)p = 1;
+        return (char *)p + 64;
     }
-    return p;
+    (void)hipGetLastError();
+    if (posix_memalign(&p, 64, n + 64) != 0) return nullptr;
+    *(uint64_t *)p = 2;
+    g_pageable_batches++;
+    return (char *)p + 64;
 }
-static void pinned_free(void *p) { (void)hipHostFree(p); }
+static void pinned_free(void *q) {
+    void *p = (char *)q - 64;
+    if (*(uint64_t *)p == 1) (void)hipHostFree(p);
+    else free(p);
+}
+
+// folds the counters of one run into the engine's running totals (nh_stats_get)
+__global__ void k_add_counters(unsigned long long *dst, const unsigned long long *src) {
+    atomicAdd(&dst[threadIdx.x], src[threadIdx.x]);
+}
 
 struct RunState {
     const nh_run_args *a;
@@ -376,7 +393,8 @@ struct RunState {
     bool paired, want_k;
     // results of the run
     uint64_t total = 0, classified = 0, total_bases = 0;
-    std::vector<uint64_t> dev_counts;  // per device {fragments, classified, bases, 0}: input of the all-reduce
+    std::vector<uint64_t> dev_counts;  // per device {fragments, classified, bases, 0} as the writer saw them (checker)
+    std::vector<uint64_t *> d_run_counters;  // per device: the counters the classify kernels of THIS run add to (HBM)
     std::vector<uint64_t> call_counts;
     // first error of any thread
     std::mutex err_mu;
@@ -583,6 +601,17 @@ int run_engines(const std::vector<Engine *> &engines, const nh_run_args *a, nh_s
         if (!f) return set_error(NH_EIO, "cannot open %s", p);
         fclose(f);
     }
+    // outputs are created with O_TRUNC before the first input byte is read: an output that IS an input
+    // (same device and inode) would be emptied -- refuse (the CLI host stages its outputs and renames)
+    for (const char *o : {a->out1, a->out2, rs.want_k ? a->kraken_output : nullptr, a->report}) {
+        struct stat so;
+        if (!o || !o[0] || stat(o, &so) != 0 || !S_ISREG(so.st_mode)) continue;
+        for (const char *p : {a->in1, a->in2}) {
+            struct stat si;
+            if (p && stat(p, &si) == 0 && si.st_dev == so.st_dev && si.st_ino == so.st_ino)
+                return set_error(NH_EINVAL, "nh_run: output %s is the input %s", o, p);
+        }
+    }
     OutFile o1, o2, ok;
     int rc;
     if (a->out_codec < NH_CODEC_NONE || a->out_codec > NH_CODEC_ZSTD)
@@ -599,12 +628,32 @@ int run_engines(const std::vector<Engine *> &engines, const nh_run_args *a, nh_s
         const long v = atol(env);
         if (v > 0) BATCH_FRAGS = (size_t)v;
     }
-    const size_t BATCH_TEXT = rs.paired ? (size_t)-1 : (size_t)(512u << 20);
+    // byte budget of one reader's batch: single-end batches are cut by it; paired batches are cut by record
+    // count (both readers at the same count), and their budget only keeps the text of the two halves together
+    // below the 4 GB a batch's 32-bit sequence positions can address
+    const size_t BATCH_TEXT = rs.paired ? (size_t)0x7F000000u : (size_t)(512u << 20);
     const int G = (int)engines.size();
     const int mates = rs.paired ? 2 : 1;
     const uint32_t flags = rs.paired ? NH_FLAG_PAIRED : 0;
     auto t0 = std::chrono::steady_clock::now();
 
+    rs.d_run_counters.assign((size_t)G, nullptr);
+    auto free_run_counters = [&] {
+        for (int g = 0; g < G; g++)
+            if (rs.d_run_counters[g]) {
+                (void)hipSetDevice(engines[g]->device);
+                (void)hipFree(rs.d_run_counters[g]);
+                rs.d_run_counters[g] = nullptr;
+            }
+    };
+    for (int g = 0; g < G; g++) {
+        const size_t nb = (CNT_N + 12) * sizeof(uint64_t);  // (+12: the words of the instrumented kernel variant)
+        if (hipSetDevice(engines[g]->device) != hipSuccess || hipMalloc((void **)&rs.d_run_counters[g], nb) != hipSuccess ||
+            hipMemset(rs.d_run_counters[g], 0, nb) != hipSuccess) {
+            free_run_counters();
+            return set_error(NH_EDEVICE, "cannot allocate the run's counters on device %d", engines[g]->device);
+        }
+    }
     std::vector<Slot> slots(2 * G);
     for (int i = 0; i < 2 * G; i++) {
         slots[i].e = engines[i / 2];
@@ -612,6 +661,7 @@ int run_engines(const std::vector<Engine *> &engines, const nh_run_args *a, nh_s
         if (hipSetDevice(slots[i].e->device) != hipSuccess ||
             hipStreamCreateWithFlags(&slots[i].stream, hipStreamNonBlocking) != hipSuccess) {
             for (auto &s : slots) slot_free(s);
+            free_run_counters();
             return set_error(NH_EDEVICE, "cannot create streams");
         }
     }
@@ -631,6 +681,9 @@ int run_engines(const std::vector<Engine *> &engines, const nh_run_args *a, nh_s
             if (nb < (uint64_t)prefill) prefill = (int)nb;
         }
         if (want < (1ull << 31)) pool1.first_reserve = pool2.first_reserve = want;
+        if (getenv("NOHUMAN_TRACE"))
+            fprintf(stderr, "[nohuman trace] batch: %zu fragments, text buffers of %zu bytes reserved at once, %d prefilled per file\n",
+                    BATCH_FRAGS, pool1.first_reserve, prefill);
     }
     pool1.start_prefill(prefill);
     if (rs.paired) pool2.start_prefill(prefill);
@@ -740,7 +793,7 @@ int run_engines(const std::vector<Engine *> &engines, const nh_run_args *a, nh_s
             // both readers cut at the same record count, so only a byte-limited cut (the 32-bit text
             // offsets of a batch) can desynchronise them before the end: never drop reads silently
             rs.fail(NH_EIO, "paired inputs lost step before the end of either file (a batch of one mate "
-                            "file exceeded the 4 GB text limit); lower NOHUMAN_BATCH_FRAGS");
+                            "file exceeded its 2 GB text budget); lower NOHUMAN_BATCH_FRAGS");
             break;
         }
         if (b.n > 0) {
@@ -824,7 +877,7 @@ int run_engines(const std::vector<Engine *> &engines, const nh_run_args *a, nh_s
                 rc = classify_device(s.e, s.d_text, s.d_off, b.n,
                                      flags | (nbases / b.n > 2000 ? NH_FLAG_LONG : 0u), a->confidence, s.d_res,
                                      rs.want_k ? s.d_taxa : nullptr, rs.want_k ? s.d_taxa_off : nullptr,
-                                     s.e->d_counters, s.stream, s.d_len, ntext);
+                                     rs.d_run_counters[(size_t)(si / 2)], s.stream, s.d_len, ntext);
                 if (rc) rs.fail(rc, g_last_error);
             }
             if (!rs.failed()) {
@@ -865,32 +918,64 @@ int run_engines(const std::vector<Engine *> &engines, const nh_run_args *a, nh_s
                     std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count());
             for (int i = 0; i < 12; i++) fprintf(stderr, " %s %.3f", names[i], (double)clk.ns[i].load() * 1e-9);
             fprintf(stderr, "\n");
+            if (g_pageable_batches.load())
+                fprintf(stderr, "[nohuman trace] %d batch buffers could not be page-locked (pageable memory used)\n",
+                        g_pageable_batches.load());
         }
     }
-    if (rs.err_code != NH_OK) return set_error(rs.err_code, "%s", rs.err_msg.c_str());
+    if (rs.err_code != NH_OK) {
+        free_run_counters();
+        return set_error(rs.err_code, "%s", rs.err_msg.c_str());
+    }
 
-    // The run's only exchange step: one all-reduce of the per-device counters over
-    // RCCL.  The host-side sum the writer kept is the checker, and the fallback when RCCL cannot be
-    // loaded; NOHUMAN_RCCL=0 skips the collective, =1 also runs it for a single device.
+    // The run's only exchange step: the counters the classify kernels kept in each
+    // device's HBM are summed by ONE all-reduce over RCCL, reduced where they lie.  The sums the writer kept
+    // on the host are the checker.  A collective that cannot run at G > 1 is reported on stderr (one WARN
+    // line; the host sums stand) and fails the run under NOHUMAN_RCCL=strict; NOHUMAN_RCCL=0 skips the
+    // collective, =1 also runs it for a single device.
     {
-        const char *env = getenv("NOHUMAN_RCCL");
-        const bool want = env ? env[0] != '0' : G > 1;
-        if (want && (G > 1 || (env && env[0] == '1'))) {
-            std::vector<int> ids;
-            for (Engine *e : engines) ids.push_back(e->device);
-            std::vector<uint64_t> rows(rs.dev_counts);
-            std::string backend;
-            const int crc = allreduce_counters(ids.data(), G, rows.data(), backend);
-            const bool trace = getenv("NOHUMAN_TRACE") != nullptr;
-            if (crc == NH_OK) {
-                for (int g = 0; g < G; g++)
-                    if (rows[4 * g] != rs.total || rows[4 * g + 1] != rs.classified || rows[4 * g + 2] != rs.total_bases)
-                        return set_error(NH_EDEVICE, "count all-reduce disagrees with the host-side sum on device %d", ids[g]);
-                if (trace) fprintf(stderr, "[nohuman trace] counters reduced by %s\n", backend.c_str());
-            } else if (trace) {
-                fprintf(stderr, "[nohuman trace] %s; counters summed on the host\n", g_last_error.c_str());
+        std::vector<uint64_t> rows(4 * (size_t)G, 0);
+        uint64_t dsum[4] = {0, 0, 0, 0};
+        hipError_t he = hipSuccess;
+        for (int g = 0; g < G && he == hipSuccess; g++) {
+            he = hipSetDevice(engines[g]->device);
+            if (he == hipSuccess) he = hipMemcpy(&rows[4 * g], rs.d_run_counters[g], 32, hipMemcpyDeviceToHost);
+            for (int i = 0; i < 4; i++) dsum[i] += rows[4 * g + i];
+            if (he == hipSuccess) {  // the engine's running totals (nh_stats_get) include this run
+                hipLaunchKernelGGL(k_add_counters, dim3(1), dim3(4), 0, engines[g]->stream,
+                                   (unsigned long long *)engines[g]->d_counters, (const unsigned long long *)rs.d_run_counters[g]);
+                he = hipStreamSynchronize(engines[g]->stream);
             }
         }
+        int crc = NH_OK;
+        if (he != hipSuccess) crc = set_error(NH_EDEVICE, "reading the run's counters: %s", hipGetErrorString(he));
+        else if (dsum[CNT_FRAGMENTS] != rs.total || dsum[CNT_CLASSIFIED] != rs.classified || dsum[CNT_BASES] != rs.total_bases)
+            crc = set_error(NH_EDEVICE, "the devices counted %llu fragments / %llu classified / %llu bases, the writer %llu / %llu / %llu",
+                            (unsigned long long)dsum[0], (unsigned long long)dsum[1], (unsigned long long)dsum[2],
+                            (unsigned long long)rs.total, (unsigned long long)rs.classified, (unsigned long long)rs.total_bases);
+        const char *env = getenv("NOHUMAN_RCCL");
+        const bool strict = env && strcmp(env, "strict") == 0;
+        const bool want = env ? env[0] != '0' : G > 1;
+        if (!crc && want && (G > 1 || env)) {
+            std::vector<int> ids;
+            for (Engine *e : engines) ids.push_back(e->device);
+            std::vector<const uint64_t *> src(rs.d_run_counters.begin(), rs.d_run_counters.end());
+            std::string backend;
+            const int arc = allreduce_counters(ids.data(), G, rows.data(), backend, src.data());
+            if (arc == NH_OK) {
+                for (int g = 0; g < G && !crc; g++)
+                    if (rows[4 * g] != rs.total || rows[4 * g + 1] != rs.classified || rows[4 * g + 2] != rs.total_bases)
+                        crc = set_error(NH_EDEVICE, "count all-reduce disagrees with the host-side sum on device %d", ids[g]);
+                if (getenv("NOHUMAN_TRACE")) fprintf(stderr, "[nohuman trace] counters reduced by %s\n", backend.c_str());
+            } else if (strict) {
+                crc = arc;
+            } else {
+                fprintf(stderr, "nohuman: WARN count all-reduce over %d devices did not run (%s); the counts were summed on the host\n",
+                        G, g_last_error.c_str());
+            }
+        }
+        free_run_counters();
+        if (crc) return crc;
     }
 
     if (a->report && a->report[0] &&

@@ -423,8 +423,19 @@ int main(int argc, char **argv) {
     ra.db_dir = db_path.c_str();
     ra.in1 = args.input[0].c_str();
     ra.in2 = paired ? args.input[1].c_str() : nullptr;
-    ra.out1 = out1.c_str();
-    ra.out2 = paired ? out2.c_str() : nullptr;
+    // The engine writes to "<out>.partial" and the finished file is renamed over the output path: a run
+    // that fails -- before or after it created anything -- leaves a file already at the output path
+    // untouched, and `-o` equal to an input path works as in the reference (the input is replaced after
+    // it has been read: src/main.rs:342-368 compresses the temporary kraken_out*.fq to the output path
+    // last).  Outputs that exist and are not regular files (/dev/stdout, a fifo) are written directly.
+    auto staged = [](const std::string &out) {
+        struct stat sb;
+        if (stat(out.c_str(), &sb) == 0 && !S_ISREG(sb.st_mode)) return out;
+        return out + ".partial";
+    };
+    const std::string part1 = staged(out1), part2 = paired ? staged(out2) : "";
+    ra.out1 = part1.c_str();
+    ra.out2 = paired ? part2.c_str() : nullptr;
     ra.out_codec = codec;
     ra.codec_threads = paired ? (args.threads / 2 ? args.threads / 2 : 1) : args.threads;  // src/main.rs:342-346
     ra.kraken_output = args.kraken_output.empty() ? "/dev/null" : args.kraken_output.c_str();
@@ -445,9 +456,17 @@ int main(int argc, char **argv) {
     nh_stats st;
     if (nh_run(&ra, &st) != 0) {
         std::string msg = nh_last_error();
-        unlink(out1.c_str());  // nothing half-written stays behind (the reference's outputs do not exist yet)
-        if (paired) unlink(out2.c_str());
+        // nothing half-written stays behind, and nothing this run did not create is touched
+        if (part1 != out1) unlink(part1.c_str());
+        if (paired && part2 != out2) unlink(part2.c_str());
         die("Failed to run kraken2\n\nCaused by:\n    kraken2 failed with stderr %s", msg.c_str());
+    }
+    if ((part1 != out1 && rename(part1.c_str(), out1.c_str()) != 0) ||
+        (paired && part2 != out2 && rename(part2.c_str(), out2.c_str()) != 0)) {
+        const std::string why = strerror(errno);
+        if (part1 != out1) unlink(part1.c_str());
+        if (paired && part2 != out2) unlink(part2.c_str());
+        die("Failed to move the output into place: %s", why.c_str());
     }
     // src/lib.rs:38-45 (0/0 prints NaN there as well)
     auto pct = [&](uint64_t a) -> std::string {

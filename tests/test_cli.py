@@ -203,3 +203,37 @@ def test_failed_run_leaves_nothing_behind(tmp_path):
     r = run(["-D", DB, str(bad)], cwd=tmp_path)
     assert r.returncode == 1 and "Failed to run kraken2" in r.stderr
     assert sorted(os.listdir(tmp_path)) == ["bad.fq.gz"]
+
+
+@pytest.mark.gpu
+def test_failed_run_keeps_an_earlier_output_and_output_may_be_the_input(tmp_path):
+    """the host stages its outputs ("<out>.partial", renamed on success).  A run that fails --
+    here on a damaged input, and before that on a database that does not load -- must leave a file that
+    already sits at the output path untouched; `-o` naming the input itself must not empty the input
+    before it is read (the reference compresses its temporary kraken_out.fq to the output path last)."""
+    good = os.path.join(GOLD, "reads_se.fq")
+    out = tmp_path / "kept.fq"
+    out.write_text("result of an earlier run\n")
+    bad = tmp_path / "bad.fq.gz"
+    bad.write_bytes(gzip.compress(open(good, "rb").read())[:-40])
+    r = run(["-D", DB, "-o", str(out), str(bad)], cwd=tmp_path)
+    assert r.returncode == 1
+    assert out.read_text() == "result of an earlier run\n"
+    nodb = tmp_path / "nodb"
+    nodb.mkdir()
+    for n in ("hash.k2d", "opts.k2d", "taxo.k2d"):
+        (nodb / n).write_bytes(b"")
+    r = run(["-D", str(nodb), "-o", str(out), good], cwd=tmp_path)
+    assert r.returncode == 1
+    assert out.read_text() == "result of an earlier run\n"
+    assert sorted(os.listdir(tmp_path)) == ["bad.fq.gz", "kept.fq", "nodb"]
+    # output == input
+    exp = json.load(open(os.path.join(GOLD, "expected_se.json")))
+    calls = [rec["by_conf"]["0.0"][0] for rec in exp["records"]]
+    inout = tmp_path / "inout.fq"
+    shutil.copy(good, inout)
+    r = run(["-D", DB, "-o", str(inout), str(inout)], cwd=tmp_path)
+    assert r.returncode == 0, r.stderr
+    want = b"".join(h + b"\n" + s + b"\n+\n" + q + b"\n" for (h, _i, s, q), c in zip(read_fastq(good), calls) if not c)
+    assert inout.read_bytes() == want and len(want) > 1000
+    assert not (tmp_path / "inout.fq.partial").exists()

@@ -300,9 +300,34 @@ def test_count_allreduce_over_rccl_single_device(tmp_path, monkeypatch, capfd):
     _, _, _, calls = _expected("expected_se.json", 0.0)
     with Engine.open(DB) as eng:
         st = eng.run(os.path.join(GOLD, "reads_se.fq"), str(tmp_path / "o.fq"))
+        folded = eng.stats()
     assert st.classified == sum(1 for c in calls if c)
+    # the run's own device-resident counters were folded into the engine's running totals
+    assert (folded.total_sequences, folded.classified) == (st.total_sequences, st.classified)
+    assert folded.table_lookups > 0
     err = capfd.readouterr().err
-    assert "counters reduced by RCCL" in err
+    assert "counters reduced by RCCL" in err and "device-resident counters" in err
+
+
+def test_count_allreduce_failure_is_loud(tmp_path, monkeypatch, capfd):
+    """at G > 1 a collective that cannot run must not pass silently.  Two engines on the SAME
+    device make ncclCommInitAll fail (duplicate device): by default the run finishes on the host-side sums
+    with one WARN line on stderr; NOHUMAN_RCCL=strict fails the run; NOHUMAN_RCCL=0 skips the collective."""
+    from nohuman_amd import engine
+    in1 = os.path.join(GOLD, "reads_se.fq")
+    monkeypatch.delenv("NOHUMAN_RCCL", raising=False)
+    st = engine.run(DB, in1, str(tmp_path / "a.fq"), device_ids=[0, 0])
+    err = capfd.readouterr().err
+    assert "WARN count all-reduce over 2 devices did not run" in err
+    monkeypatch.setenv("NOHUMAN_RCCL", "0")
+    st0 = engine.run(DB, in1, str(tmp_path / "b.fq"), device_ids=[0, 0])
+    assert "WARN" not in capfd.readouterr().err
+    assert (st0.total_sequences, st0.classified) == (st.total_sequences, st.classified)
+    assert (tmp_path / "a.fq").read_bytes() == (tmp_path / "b.fq").read_bytes()
+    monkeypatch.setenv("NOHUMAN_RCCL", "strict")
+    with pytest.raises(RuntimeError) as ei:
+        engine.run(DB, in1, str(tmp_path / "c.fq"), device_ids=[0, 0])
+    assert "ncclCommInitAll" in str(ei.value)
 
 
 @pytest.mark.parametrize("codec", [1, 2, 3, 4])
@@ -324,3 +349,19 @@ def test_run_streams_kept_pairs_into_the_output_codec(tmp_path, codec):
         got = {1: bz2.decompress, 2: gzip.decompress, 3: lzma.decompress,
                4: lambda b: _zstd_decompress(b, len(want))}[codec](raw)
         assert got == want and len(want) > 1000
+
+
+def test_run_refuses_an_output_that_is_an_input(tmp_path):
+    """outputs are created with O_TRUNC before a byte of input is read; nh_run must refuse an
+    output path that names an input (same inode) instead of emptying it."""
+    import shutil
+    from nohuman_amd import engine
+    src = tmp_path / "reads.fq"
+    shutil.copy(os.path.join(GOLD, "reads_se.fq"), src)
+    size = src.stat().st_size
+    os.link(src, tmp_path / "alias.fq")
+    for out in (src, tmp_path / "alias.fq"):
+        with pytest.raises(RuntimeError) as ei:
+            engine.run(DB, str(src), str(out), device_ids=[0])
+        assert "is the input" in str(ei.value)
+    assert src.stat().st_size == size

@@ -159,6 +159,12 @@ def test_bzip2_input_damage_is_an_error_not_a_short_read(tmp_path):
     with pytest.raises(RuntimeError) as ei:
         scan(cut)
     assert "bzip2" in str(ei.value)
+    # bytes behind the last stream that are no bzip2 stream: `bzip2 -dc` warns and still delivers the data
+    tg = tmp_path / "garbage.fq.bz2"
+    tg.write_bytes(whole + b"\x00" * 100 + b"not a stream")
+    assert scan(tg) == expect(data)
+    tg.write_bytes(whole + b"BZ")
+    assert scan(tg) == expect(data)
     bad = bytearray(whole)
     bad[len(bad) // 2] ^= 0x55
     (tmp_path / "bad.fq.bz2").write_bytes(bytes(bad))
