@@ -43,6 +43,68 @@ struct Result {
     uint32_t call, total_kmers, clade_hits, hit_groups;
 };
 
+// How the fragments of a launch are handed out: claim i of the launch's work counter is a chunk of c0
+// fragments while i < n0, of c1 while i < n01, of c2 up to `total` (a fixed map: a claim index is also the
+// chunk's bit in KArgs::defer_bits).  By default n0 == total: the guided tail (smaller chunks for the waves
+// that finish early) is a tuning knob that measured slower than flat chunks once the claims themselves were
+// fixed (make_sched in nh_kernels.hip, profiles/r03_sched.txt).
+struct Sched {
+    uint64_t n0, n01, total;  // claims in chunks of c0 / up to here in chunks of c1 / all claims
+    uint64_t base1, base2;    // first fragment of the c1 chunks, of the c2 chunks
+    uint32_t c0, c1, c2, pad;
+};
+
+// One hot word is a bottleneck on this chip: a device-scope atomic on ONE address retires at 46-88 per
+// microsecond (profiles/r03_sched.txt), and the memory pipeline of a CU that holds such atomics backs up behind
+// them.  Round 2 had every wave of a launch add its four counters to the caller's four words as it ended:
+// 20480 atomics on one 32-byte stretch in the last ~300 us of every launch, which is where the launches' "tail"
+// came from (a wave's last chunk took 100+ us longer than any other).  Now the waves add to one of
+// COUNTER_SHARDS rows (by workgroup), each in a line of its own, and a one-wave kernel behind the launch folds
+// the rows into the caller's counters: the fixed cost of a launch fell from 0.30 to 0.13 ms.
+// The WORK counter can be sharded the same way (WORK_SHARDS words, one per XCD, claims beyond the static
+// first ones split into equal shares, a wave draws from its XCD's share and moves on to the next XCD's when
+// that is empty): measured, 8 shards take another 15 us off the fixed cost and ADD 3 % to the per-read cost
+// (launches of 1 M reads and more are slower: 4.93 against 4.85 ms for 2.5 M pairs) -- ~27 claims per
+// microsecond in steady state are no problem for one word.  One shard is the default; the mechanism stays
+// as a build knob (-DNH_WORK_SHARDS=8).
+#ifndef NH_WORK_SHARDS
+#define NH_WORK_SHARDS 1
+#endif
+constexpr uint32_t WORK_SHARDS = NH_WORK_SHARDS;  // a power of two
+constexpr uint32_t WORK_STRIDE = 16;      // uint64 words from one shard's counter to the next (128 bytes)
+constexpr uint32_t COUNTER_SHARDS = 64;
+constexpr uint32_t COUNTER_STRIDE = 16;   // uint64 words per row (128 bytes; four are used)
+
+// ---- long reads: work items instead of whole fragments ------------------------------------------------
+// A launch of long single-end reads (NH_FLAG_LONG) is handed out as ITEMS built by a prepass (k_prep_items):
+// a read of more than SPLIT_MIN_TILES tiles is cut into segments of SEG_TILES tiles that any wave can
+// classify -- a 200 kb read is 50 items, not one wave's 10 ms -- and the items go out largest first: all
+// segments, then the whole reads of 8 tiles and more, then the small ones.  A segment (a) finds kraken2's
+// last_minimizer at its start by scanning the tile before it (further back while that one holds no
+// unambiguous k-mer), (b) looks that minimizer up once, uncounted, for last_taxon, (c) leaves its (taxon,
+// count) list and hit groups in a 256-byte PARTIAL slot; the segment that finishes last (a counter per
+// fragment) adds the partials up and resolves the fragment.  More than PART_CAP distinct taxa in one
+// segment: the fragment is left to the BIG variant (whole fragment, one wave), as a list overflow is.
+constexpr uint32_t SEG_TILES = 32;        // tiles per segment: 3968 k-mers at k=35/l=31
+constexpr uint32_t SPLIT_MIN_TILES = 48;  // reads of more tiles than this are cut
+constexpr uint32_t MID_TILES = 8;         // whole reads of at least this many tiles go out before the small ones
+constexpr uint32_t PART_DWORDS = 64;      // a partial: [0] hit groups, [1] entries, [2] overflow, then (taxon, count) pairs from [4]
+constexpr uint32_t PART_CAP = 30;
+struct SplitItem {
+    uint32_t f, seg, nseg, slot;  // fragment, segment, segments of the fragment, first partial slot of the fragment
+};
+struct SplitHdr {
+    uint32_t n_multi, n_mid, n_small, seg_used;
+};
+struct SplitBufs {
+    SplitHdr *hdr;            // NULL: the launch is handed out by fragments (Sched)
+    SplitItem *items_multi;   // [seg_cap]
+    uint32_t *items_single;   // [n_frag]: reads of >= MID_TILES tiles from the front, smaller ones from the back
+    uint32_t *part;           // [seg_cap][PART_DWORDS]
+    uint32_t *part_done;      // [seg_cap]: segments finished, at the fragment's first slot
+    uint32_t seg_cap, pad;
+};
+
 // The one kernel argument of k_classify.  Device code never names the parameter: it reads the
 // fields it needs, phase by phase, through the kernarg-segment pointer, so that the ~50 dwords of
 // arguments are not all kept live in SGPRs for the whole kernel (see nh_kernels.hip).
@@ -57,12 +119,14 @@ struct KArgs {
     uint64_t bases_end;
     uint64_t n_frag;
     int32_t mates;
-    uint32_t frag_chunk;
+    uint32_t frag_chunk;  // = sched.c0: the largest number of fragments a wave claims at a time
+    Sched sched;
     double confidence;
     Result *out;
     uint32_t *kmer_taxa;
     const uint64_t *kmer_taxa_off;
-    unsigned long long *counters;
+    unsigned long long *counters;  // the caller's {fragments, classified, bases, lookups} (may be NULL)
+    unsigned long long *cshard;    // COUNTER_SHARDS rows the waves add to; folded into `counters` behind the launch
     int *error_flag;  // sticky error bits of the engine (1: > 2048 distinct taxa, 2: sequence too long)
     int *pending;     // per launch slot: fragments were left to the BIG variant
     // short-read kernel -> generic kernel: chunks that hold a sequence of more than one tile (one bit per
@@ -71,6 +135,11 @@ struct KArgs {
     int *pending_long;
     int32_t only_deferred;  // generic kernel: classify only the chunks marked in defer_bits
     unsigned long long *work;
+    SplitBufs split;
+    // tuning aid (tools/timeline.py; NULL in normal use): 32 x uint64 per wave of k_classify_short -- 100 MHz
+    // timestamps of start, first claim, first batch encoded, first probe phase done, last claim, end; chunks
+    // taken; XCC id; then (start << 8 | fragments) of the first 24 chunks
+    unsigned long long *timeline;
 };
 
 // ---- host side of a launch ----
@@ -92,9 +161,12 @@ struct LaunchSlot {
     int *d_error = nullptr;             // sticky error bits of the engine
     int *d_pending = nullptr;           // fragments were left to the BIG variant
     int *d_pending_long = nullptr;      // chunks were left to the generic kernel
-    unsigned long long *d_work = nullptr;
+    unsigned long long *d_work = nullptr;    // WORK_SHARDS counters, WORK_STRIDE words apart
+    unsigned long long *d_cshard = nullptr;  // COUNTER_SHARDS rows of COUNTER_STRIDE words
     uint32_t *d_defer = nullptr;        // one bit per chunk
     uint64_t defer_cap_bits = 0;
+    SplitBufs split = {};               // long-read item buffers of this slot (hdr == NULL: none)
+    uint64_t split_single_cap = 0;      // entries of split.items_single
 };
 
 constexpr uint32_t TAXON_AMBIGUOUS = 0xFFFFFFFFu;

@@ -154,14 +154,13 @@ static int alloc_table(Engine *e, uint64_t capacity) {
     e->table_cells_alloc = ((capacity + 3) & ~3ull) + 32;
     // Staggered copies (DevDB::copy_stride): the gather ceiling of the chip is a rate of 128-byte lines,
     // and a probe run that starts in the first half of its line leaves it 3.5x less often than one
-    // that starts anywhere (tools/probe_cost_model.py: 1.158 -> 1.045 lines per lookup at load 0.7).  HBM is not the scarce resource here (4 x 5.7 GB on a 288 GB device).  Only for tables with
-    // 32-bit cell positions (the kernel variant that uses them); NOHUMAN_TABLE_COPIES=1|2|4|8.
+    // that starts anywhere (tools/probe_cost_model.py: 1.158 -> 1.045 lines per lookup at load 0.7).  HBM is not the scarce resource here (4 x 5.7 GB on a 288 GB device): a table too
+    // large for four copies gets as many as fit (the loop below halves on out-of-memory).  NOHUMAN_TABLE_COPIES=1|2|4|8.
     uint32_t want = 4;  // with quad probing: 787 / 964 / 1000 Mreads/s for 1 / 2 / 4 copies (profiles/r02_tuning.txt)
     if (const char *env = getenv("NOHUMAN_TABLE_COPIES")) {
         const int v = atoi(env);
         want = v >= 8 ? 8u : v >= 4 ? 4u : v >= 2 ? 2u : 1u;
     }
-    if (capacity >= 0xFFFFFF00ull) want = 1;
     for (;; want >>= 1) {
         const uint64_t sh = 32 / want;
         const uint64_t stride = ((e->table_cells_alloc + 32 + 31) & ~31ull) - (want > 1 ? sh : 0);
@@ -209,7 +208,9 @@ static int common_open(Engine *e, int device) {
     HIP_TRY(hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking));
     HIP_TRY(hipMalloc((void **)&e->d_counters, (CNT_N + 12) * sizeof(uint64_t)));
     HIP_TRY(hipMemset(e->d_counters, 0, (CNT_N + 12) * sizeof(uint64_t)));
-    HIP_TRY(hipMalloc((void **)&e->d_work, LAUNCH_SLOTS * sizeof(unsigned long long)));
+    HIP_TRY(hipMalloc((void **)&e->d_work, LAUNCH_SLOTS * WORK_SHARDS * WORK_STRIDE * sizeof(unsigned long long)));
+    HIP_TRY(hipMalloc((void **)&e->d_cshard, LAUNCH_SLOTS * COUNTER_SHARDS * COUNTER_STRIDE * sizeof(unsigned long long)));
+    HIP_TRY(hipMemset(e->d_cshard, 0, LAUNCH_SLOTS * COUNTER_SHARDS * COUNTER_STRIDE * sizeof(unsigned long long)));
     // [0, LAUNCH_SLOTS) "fragments left to the BIG variant" per launch slot, then the sticky error bits,
     // then [LAUNCH_SLOTS + 1, 2 LAUNCH_SLOTS + 1) "chunks left to the generic kernel" per launch slot
     HIP_TRY(hipMalloc((void **)&e->d_error, (2 * LAUNCH_SLOTS + 1) * sizeof(int)));
@@ -233,7 +234,11 @@ void destroy(Engine *e) {
     if (e->d_counters) (void)hipFree(e->d_counters);
     if (e->d_error) (void)hipFree(e->d_error);
     if (e->d_work) (void)hipFree(e->d_work);
+    if (e->d_cshard) (void)hipFree(e->d_cshard);
     if (e->d_defer) (void)hipFree(e->d_defer);
+    for (SplitBufs &sb : e->split)
+        for (void *p : {(void *)sb.hdr, (void *)sb.items_multi, (void *)sb.items_single, (void *)sb.part, (void *)sb.part_done})
+            if (p) (void)hipFree(p);
     for (void *p : {e->st.d_bases, e->st.d_offsets, e->st.d_results, e->st.d_taxa, e->st.d_taxa_off})
         if (p) (void)hipFree(p);
     if (e->stream) (void)hipStreamDestroy(e->stream);
@@ -540,6 +545,43 @@ static uint32_t frag_chunk_for(const Engine *e, uint32_t flags, uint64_t n_frag)
     return c < step ? step : c;
 }
 
+// Item buffers of a launch slot for a launch of n_frag long reads: one list entry per read, and items /
+// partial slots for the segments of the reads that get cut (8 per read on average, 2^16 .. 2^20; what does
+// not fit is classified whole).  NOHUMAN_SEG_CAP overrides the number of segments (test knob).
+static int ensure_split(Engine *e, unsigned slot, uint64_t n_frag) {
+    std::lock_guard<std::mutex> lock(e->split_mu);
+    SplitBufs &sb = e->split[slot];
+    uint64_t want_seg = n_frag * 8;
+    if (want_seg < (1u << 16)) want_seg = 1u << 16;
+    if (want_seg > (1u << 20)) want_seg = 1u << 20;
+    if (const char *env = getenv("NOHUMAN_SEG_CAP")) {
+        const long v = atol(env);
+        if (v >= 1) want_seg = (uint64_t)v;
+    }
+    if (sb.hdr && sb.seg_cap >= want_seg && e->split_single_cap[slot] >= n_frag) return NH_OK;
+    if (sb.hdr && getenv("NOHUMAN_SEG_CAP") && e->split_single_cap[slot] >= n_frag) return NH_OK;
+    // (re)allocate: the slot's previous launch, if any, has long finished when its turn comes again
+    for (void *p : {(void *)sb.hdr, (void *)sb.items_multi, (void *)sb.items_single, (void *)sb.part, (void *)sb.part_done})
+        if (p) (void)hipFree(p);
+    sb = SplitBufs{};
+    e->split_single_cap[slot] = 0;
+    const uint64_t nsingle = n_frag + n_frag / 4 + 1024;
+    if (hipMalloc((void **)&sb.hdr, sizeof(SplitHdr)) != hipSuccess ||
+        hipMalloc((void **)&sb.items_multi, want_seg * sizeof(SplitItem)) != hipSuccess ||
+        hipMalloc((void **)&sb.items_single, nsingle * sizeof(uint32_t)) != hipSuccess ||
+        hipMalloc((void **)&sb.part, want_seg * PART_DWORDS * sizeof(uint32_t)) != hipSuccess ||
+        hipMalloc((void **)&sb.part_done, want_seg * sizeof(uint32_t)) != hipSuccess) {
+        (void)hipGetLastError();
+        for (void *p : {(void *)sb.hdr, (void *)sb.items_multi, (void *)sb.items_single, (void *)sb.part, (void *)sb.part_done})
+            if (p) (void)hipFree(p);
+        sb = SplitBufs{};
+        return NH_OK;  // no buffers: the launch goes by whole reads (slower tail, same results)
+    }
+    sb.seg_cap = (uint32_t)want_seg;
+    e->split_single_cap[slot] = nsingle;
+    return NH_OK;
+}
+
 int classify_device(Engine *e, const void *d_bases, const void *d_seq_off, uint64_t n_frag,
                          uint32_t flags, double confidence, void *d_results, void *d_kmer_taxa,
                          const void *d_kmer_taxa_off, void *d_counters, hipStream_t stream,
@@ -572,9 +614,15 @@ int classify_device(Engine *e, const void *d_bases, const void *d_seq_off, uint6
     sl.d_error = e->d_error + LAUNCH_SLOTS;
     sl.d_pending = e->d_error + slot;
     sl.d_pending_long = e->d_error + LAUNCH_SLOTS + 1 + slot;
-    sl.d_work = e->d_work + slot;
+    sl.d_work = e->d_work + (size_t)slot * WORK_SHARDS * WORK_STRIDE;
+    sl.d_cshard = e->d_cshard + (size_t)slot * COUNTER_SHARDS * COUNTER_STRIDE;
     sl.d_defer = e->d_defer + (size_t)slot * DEFER_WORDS;
     sl.defer_cap_bits = DEFER_WORDS * 32;
+    if ((flags & NH_FLAG_LONG) && !(flags & NH_FLAG_PAIRED) && n_frag < 0xFFFFFFFFull) {
+        (void)ensure_split(e, slot, n_frag);
+        sl.split = e->split[slot];
+        sl.split_single_cap = e->split_single_cap[slot];
+    }
     hipError_t he = launch_classify(db, io, confidence, sl, frag_chunk_for(e, flags, n_frag), e->grid_blocks, stream);
     if (he != hipSuccess) return set_error(NH_EDEVICE, "classify launch: %s", hipGetErrorString(he));
     return NH_OK;
@@ -826,6 +874,14 @@ int nh_synthetic_add_sequences(nh_engine *e_, const void *d_bases, const void *d
                          hipGetErrorString(he));
     e->info.size += ins;
     return refresh_table_copies(e);
+}
+
+// test hook (not part of the ABI in include/nohuman_engine.h): the claim map a launch of n_frag fragments
+// would get -- out = {n0, n01, total, base1, base2, c0, c1, c2}
+void nh_debug_sched(uint64_t n_frag, uint32_t c0, int mates, uint64_t waves, uint64_t *out) {
+    const nh::Sched sc = nh::make_sched(n_frag, c0, mates, waves);
+    const uint64_t v[8] = {sc.n0, sc.n01, sc.total, sc.base1, sc.base2, sc.c0, sc.c1, sc.c2};
+    memcpy(out, v, sizeof v);
 }
 
 int nh_stats_get(nh_engine *e_, nh_stats *s) {

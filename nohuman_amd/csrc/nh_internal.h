@@ -39,8 +39,14 @@ struct Engine {
     uint32_t *d_parent = nullptr;
     uint64_t *d_counters = nullptr;
     int *d_error = nullptr;
-    unsigned long long *d_work = nullptr;  // dynamic fragment-chunk counters of k_classify, one per launch slot
+    unsigned long long *d_work = nullptr;  // work counters of k_classify: WORK_SHARDS per launch slot (nh_device.h)
+    unsigned long long *d_cshard = nullptr; // counter rows the waves of a launch add to, COUNTER_SHARDS per launch slot
     uint32_t *d_defer = nullptr;           // per launch slot DEFER_WORDS words: chunks the short-read kernel left behind
+    // long-read item buffers per launch slot (SplitBufs, nh_device.h), allocated when a slot first carries a
+    // launch of long single-end reads and grown when a larger one comes
+    SplitBufs split[LAUNCH_SLOTS] = {};
+    uint64_t split_single_cap[LAUNCH_SLOTS] = {};
+    std::mutex split_mu;
     std::atomic<unsigned> launch_seq{0};
     hipStream_t stream = nullptr;
     std::vector<uint32_t> parent;
@@ -57,6 +63,7 @@ int set_error(int code, const char *fmt, ...) __attribute__((format(printf, 2, 3
 
 hipError_t launch_classify(const DevDB &db, const LaunchIO &io, double confidence, const LaunchSlot &sl,
                            uint32_t frag_chunk, int grid_blocks, hipStream_t stream);
+Sched make_sched(uint64_t n_frag, uint32_t c0, int mates, uint64_t waves);
 int classify_blocks_per_cu();
 hipError_t launch_insert_sequences(const DevDB &db, const void *d_bases, const void *d_seq_off,
                                    uint64_t n_seq, uint32_t value, unsigned long long *d_inserted,

@@ -29,6 +29,8 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <type_traits>
+
 #include "nh_device.h"
 
 namespace nh {
@@ -492,6 +494,18 @@ __device__ __forceinline__ const uint32_t *probe_src(const uint32_t *table, uint
     return table + (uint64_t)j * copy_stride + p32;
 }
 
+// Up to NSLOT entries of a group's queue are look-ups of an inherited minimizer (first tile of a segment
+// of a split long read): 1 + queue index in 16-bit fields of a wave-uniform word, 0 = unused.
+__device__ __forceinline__ bool is_carry_entry(const uint64_t pack, const uint32_t r) {
+    const uint32_t k = r + 1u;
+    return ((uint32_t)pack & 0xFFFFu) == k || ((uint32_t)(pack >> 16) & 0xFFFFu) == k ||
+           ((uint32_t)(pack >> 32) & 0xFFFFu) == k || (uint32_t)(pack >> 48) == k;
+}
+__device__ __forceinline__ uint32_t carry_entries(const uint64_t pack) {
+    return (((uint32_t)pack & 0xFFFFu) != 0) + (((uint32_t)(pack >> 16) & 0xFFFFu) != 0) +
+           (((uint32_t)(pack >> 32) & 0xFFFFu) != 0) + ((uint32_t)(pack >> 48) != 0);
+}
+
 // stopping cell among 4 loaded cells: the lowest j >= lo that is empty or holds the key
 __device__ __forceinline__ void scan4(const uint4 &c, uint32_t ckey, uint32_t vmask, uint32_t lo, uint32_t &res,
                                       uint32_t &resj) {
@@ -522,7 +536,7 @@ template <bool LINEAR, bool STD, bool CAP32, bool PROF, class WL>
 __device__ __forceinline__ void probe_queue(KArgsP ap, WL &S, const int lane,
                                             const uint32_t par,
                                             const uint32_t qn, LaneLookup &lk, const bool count_lookups,
-                                            uint64_t (&prof)[12],
+                                            const uint64_t carry_pack, uint64_t (&prof)[12],
                                             uint64_t &tprev) {
     ap = launder(ap);
     const uint64_t MIN_HASH = STD ? 0ull : ap->db.min_hash;
@@ -556,7 +570,8 @@ __device__ __forceinline__ void probe_queue(KArgsP ap, WL &S, const int lane,
                 S.q[par][r] = e;
                 if constexpr (!STD) S.qtax.v[par][r] = look ? 0u : QTAX_SKIP;
             }
-            const uint32_t nlook = __popcll(__ballot(look));
+            // (a segment's look-up of the minimizer it inherits is not one kraken2 makes: not counted)
+            const uint32_t nlook = __popcll(__ballot(look && !is_carry_entry(carry_pack, r)));
             if (lane == 0 && count_lookups) S.acc[CNT_LOOKUPS] += nlook;
         }
         wave_sync();
@@ -724,13 +739,17 @@ __device__ __forceinline__ void probe_queue(KArgsP ap, WL &S, const int lane,
 // first round (62 % with 4 cells), the line is fetched once, and the L1 sees 1.1 line-visits per lookup
 // instead of 2.4.  Owners keep their state in registers; addresses and keys travel by ds_bpermute, the
 // verdict of a quad comes back through a ballot.
-template <bool PROF, class WL>
+// WIDE: tables of 2^32 - 256 cells and more.  Cell positions are 64-bit in the owner; what travels to the
+// loading lanes is the low dword, and the high dword rides in the spare bits of the round's meta word.
+template <bool PROF, bool WIDE, class WL>
 __device__ __forceinline__ void probe_queue_quad(KArgsP ap, WL &S, const int lane, const uint32_t par,
                                                  const uint32_t qn, LaneLookup &lk, const bool count_lookups,
-                                                 uint64_t (&prof)[12], uint64_t &tprev) {
+                                                 const uint64_t carry_pack, uint64_t (&prof)[12], uint64_t &tprev) {
     constexpr bool STD = true;
+    typedef typename std::conditional<WIDE, uint64_t, uint32_t>::type Pos;
     ap = launder(ap);
     const uint32_t vbits = ap->db.value_bits;
+    const uint32_t kbits = 32 - vbits;
     const uint32_t vmask = ap->db.vmask;
     const uint64_t cap = ap->db.capacity;
     const uint64_t magic = ap->db.cap_magic;
@@ -746,15 +765,16 @@ __device__ __forceinline__ void probe_queue_quad(KArgsP ap, WL &S, const int lan
         const uint64_t hc = fmix64(S.q[par][act ? r : 0u]);
         const uint64_t home = mod_capacity(hc, cap, magic);
         const uint32_t compacted = (uint32_t)(hc >> (32 + vbits));
-        if (act) S.q[par][r] = ((uint64_t)(compacted << vbits) << 32) | (uint32_t)home;
+        // (entry formats as in probe_queue: home | key << 32, or home << key_bits | key for wide tables)
+        if (act) S.q[par][r] = WIDE ? ((home << kbits) | compacted) : (((uint64_t)(compacted << vbits) << 32) | (uint32_t)home);
     }
-    if (lane == 0 && count_lookups) S.acc[CNT_LOOKUPS] += qn;
+    if (lane == 0 && count_lookups) S.acc[CNT_LOOKUPS] += qn - carry_entries(carry_pack);
     wave_sync();
     NH_STAMP(4);
 
     uint32_t qhead = 0;  // next queue entry to hand out (uniform)
     uint32_t busy = lk.busy, r = lk.r, ckey = lk.ckey, budget = lk.budget;
-    uint32_t pos = (uint32_t)lk.pos;
+    Pos pos = (Pos)lk.pos;
     const uint32_t q4 = ((uint32_t)lane & 3u) * 4u;         // first cell of the chunk this lane loads
     const uint32_t own_sub = (uint32_t)lane >> 2;            // which of an instruction's 16 owners it loads for
     for (;;) {
@@ -764,9 +784,14 @@ __device__ __forceinline__ void probe_queue_quad(KArgsP ap, WL &S, const int lan
                 const uint32_t my = qhead + below(idle_mask);
                 if (busy == 0 && my < qn) {
                     const uint64_t e = S.q[par][my];
-                    pos = (uint32_t)e;
-                    ckey = (uint32_t)(e >> 32);
-                    r = my | (par << 9) | (pick_copy((uint32_t)e, copy_shift) << 10);
+                    if (WIDE) {
+                        pos = (Pos)(e >> kbits);
+                        ckey = (uint32_t)(e & ((1ull << kbits) - 1)) << vbits;
+                    } else {
+                        pos = (Pos)(uint32_t)e;
+                        ckey = (uint32_t)(e >> 32);
+                    }
+                    r = my | (par << 9) | (pick_copy((uint32_t)pos, copy_shift) << 10);
                     budget = max_rounds;
                     busy = 1;
                 }
@@ -781,24 +806,26 @@ __device__ __forceinline__ void probe_queue_quad(KArgsP ap, WL &S, const int lan
         const uint32_t cj = (r >> 10) & 7u;
         uint32_t nv = 0;
         if (busy) {
-            const uint32_t in_line = 32u - ((pos - (cj << copy_shift)) & 31u);
-            const uint32_t room = (uint32_t)cap - pos;
-            nv = in_line < room ? in_line : room;
+            const uint32_t in_line = 32u - (((uint32_t)pos - (cj << copy_shift)) & 31u);
+            const Pos room = (Pos)cap - pos;
+            nv = room < (Pos)in_line ? (uint32_t)room : in_line;
             nv = nv < 16u ? nv : 16u;
         }
-        const uint32_t meta = nv | (cj << 8);
+        const uint32_t meta = nv | (cj << 8) | (WIDE ? (uint32_t)((uint64_t)pos >> 32) << 11 : 0u);
         uint4 c[4];
         uint32_t ck[4], nvk[4];
 #pragma unroll
         for (int k = 0; k < 4; k++) {  // instruction k: the lookups of owner lanes 16k .. 16k+15, a quad of lanes each
             const int src = (int)(4u * (16u * (uint32_t)k + own_sub));
-            const uint32_t p = (uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)pos);
+            const uint32_t p = (uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)(uint32_t)pos);
             ck[k] = (uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)ckey);
             const uint32_t m = (uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)meta);
             nvk[k] = m & 0xFFu;
             c[k] = make_uint4(0, 0, 0, 0);
-            if (q4 < nvk[k])  // (a chunk without eligible cells is not loaded: every line-visit costs the L1)
-                c[k] = *reinterpret_cast<const uint4 *>(table + (uint64_t)(m >> 8) * copy_stride + p + q4);
+            if (q4 < nvk[k]) {  // (a chunk without eligible cells is not loaded: every line-visit costs the L1)
+                const uint64_t cell = WIDE ? (((uint64_t)(m >> 11) << 32) | p) : (uint64_t)p;
+                c[k] = *reinterpret_cast<const uint4 *>(table + (uint64_t)((m >> 8) & 7u) * copy_stride + cell + q4);
+            }
         }
         bool found = false;
         uint32_t val = 0;
@@ -818,8 +845,8 @@ __device__ __forceinline__ void probe_queue_quad(KArgsP ap, WL &S, const int lan
             }
         }
         if (busy) {
-            const uint32_t np = pos + nv;
-            pos = np >= (uint32_t)cap ? 0u : np;
+            const Pos np = pos + nv;
+            pos = np >= (Pos)cap ? (Pos)0 : np;
             budget--;
             if (found | (budget == 0)) {
                 tax_at<STD>(S, (r >> 9) & 1u, r & 0x1FFu) = (found && val <= vmask) ? val : 0u;
@@ -845,6 +872,50 @@ struct TaxList {
     uint32_t *tax, *cnt, *score;  // score: BIG only
     uint32_t cap;
 };
+
+// Adds `cnt` hits of taxon T to the (taxon, count) list of the fragment being post-processed.
+template <bool BIG, class WL>
+__device__ __forceinline__ void list_add(WL &S, const TaxList &TLI, const int lane, FragState &st, const uint32_t T,
+                                         const uint32_t cnt) {
+    if constexpr (!BIG) {  // hot variant: at most 64 entries, lane i looks at entry i
+        const bool match = (uint32_t)lane < st.nlist && S.list_tax[lane] == T;
+        const uint64_t mb = __ballot(match);
+        if (mb) {
+            if (match) S.list_cnt[lane] += cnt;
+        } else if (st.nlist < (uint32_t)LIST_CAP) {
+            if (lane == 0) {
+                S.list_tax[st.nlist] = T;
+                S.list_cnt[st.nlist] = cnt;
+            }
+            st.nlist++;
+        } else {
+            st.overflow = true;
+        }
+    } else {
+        bool found = false;
+        for (uint32_t base = 0; base < st.nlist; base += 64) {
+            const uint32_t idx = base + lane;
+            const bool match = idx < st.nlist && TLI.tax[idx] == T;
+            if (__ballot(match)) {
+                if (match) TLI.cnt[idx] += cnt;
+                found = true;
+                break;
+            }
+        }
+        if (!found) {
+            if (st.nlist < TLI.cap) {
+                if (lane == 0) {
+                    TLI.tax[st.nlist] = T;
+                    TLI.cnt[st.nlist] = cnt;
+                }
+                st.nlist++;
+            } else {
+                st.overflow = true;
+            }
+        }
+    }
+    wave_sync();
+}
 
 // POST one tile: per-k-mer taxa from the probe results, hit groups, (taxon, count) list.
 template <bool STD, bool BIG, bool PROF, class WL>
@@ -890,44 +961,7 @@ __device__ __forceinline__ void post_tile(WL &S, const TaxList &TLI, const int l
             const uint32_t cnt = __popcll(__ballot(t0 == T)) + __popcll(__ballot(t1 == T));
             if (t0 == T) t0 = 0;
             if (t1 == T) t1 = 0;
-            if constexpr (!BIG) {  // hot variant: at most 64 entries, lane i looks at entry i
-                const bool match = (uint32_t)lane < st.nlist && S.list_tax[lane] == T;
-                const uint64_t mb = __ballot(match);
-                if (mb) {
-                    if (match) S.list_cnt[lane] += cnt;
-                } else if (st.nlist < (uint32_t)LIST_CAP) {
-                    if (lane == 0) {
-                        S.list_tax[st.nlist] = T;
-                        S.list_cnt[st.nlist] = cnt;
-                    }
-                    st.nlist++;
-                } else {
-                    st.overflow = true;
-                }
-            } else {
-                bool found = false;
-                for (uint32_t base = 0; base < st.nlist; base += 64) {
-                    const uint32_t idx = base + lane;
-                    const bool match = idx < st.nlist && TLI.tax[idx] == T;
-                    if (__ballot(match)) {
-                        if (match) TLI.cnt[idx] += cnt;
-                        found = true;
-                        break;
-                    }
-                }
-                if (!found) {
-                    if (st.nlist < TLI.cap) {
-                        if (lane == 0) {
-                            TLI.tax[st.nlist] = T;
-                            TLI.cnt[st.nlist] = cnt;
-                        }
-                        st.nlist++;
-                    } else {
-                        st.overflow = true;
-                    }
-                }
-            }
-            wave_sync();
+            list_add<BIG>(S, TLI, lane, st, T, cnt);
         }
     }
     NH_STAMP(6);
@@ -1034,6 +1068,77 @@ __device__ __forceinline__ void init_wave_lds(WL &S, const int lane) {
 
 __device__ __forceinline__ uint32_t uni(uint32_t v) { return __builtin_amdgcn_readfirstlane(v); }
 
+// The fragments claim `i` of the launch's work counter stands for (Sched in nh_device.h): large chunks for
+// the body of the launch, smaller ones for its tail.  False when the launch is handed out.  Everything
+// here is wave-uniform (i comes from a readlane).
+__device__ __forceinline__ bool claim_range(KArgsP ap, const uint64_t i, const uint64_t n_frag, uint64_t &beg,
+                                            uint32_t &n) {
+    ap = launder(ap);
+    if (i >= ap->sched.total) return false;
+    uint32_t c;
+    if (i < ap->sched.n0) {
+        c = ap->sched.c0;
+        beg = i * c;
+    } else if (i < ap->sched.n01) {
+        c = ap->sched.c1;
+        beg = ap->sched.base1 + (i - ap->sched.n0) * c;
+    } else {
+        c = ap->sched.c2;
+        beg = ap->sched.base2 + (i - ap->sched.n01) * c;
+    }
+    n = beg + c <= n_frag ? c : (uint32_t)(n_frag - beg);
+    return true;
+}
+
+__device__ __forceinline__ uint32_t xcc_id() {
+    uint32_t x;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(x));
+    return x & (WORK_SHARDS - 1);
+}
+
+// Claims beyond the static first ones (one per wave of the grid) come from WORK_SHARDS counters (nh_device.h):
+// shard x hands out n_static + x * share + [0, share).  draw_raw() bumps the counter of the shard the wave
+// currently draws from (lane 0; the value may be looked at much later); settle() turns it into a claim
+// index, moving on to the next shards when this one is used up -- ~0 when all are.
+struct Draw {
+    unsigned long long raw;  // lane 0: what the atomic returned
+    uint32_t shard;          // wave-uniform: the shard `raw` came from
+};
+__device__ __forceinline__ void draw_raw(KArgsP ap, const int lane, Draw &d) {
+    if (lane == 0) d.raw = atomicAdd(launder(ap)->work + (size_t)d.shard * WORK_STRIDE, 1ull);
+}
+__device__ __forceinline__ uint64_t settle(KArgsP ap, const int lane, Draw &d, const uint64_t total_claims) {
+    const uint64_t n_static = (uint64_t)gridDim.x * WAVES_PER_BLOCK;
+    const uint64_t dyn = total_claims > n_static ? total_claims - n_static : 0;
+    const uint64_t share = (dyn + WORK_SHARDS - 1) / WORK_SHARDS;
+    for (uint32_t tries = 0;; tries++) {
+        const uint64_t c = readlane64(d.raw, 0);
+        const uint64_t claim = n_static + (uint64_t)d.shard * share + c;
+        if (c < share && claim < total_claims) return claim;
+        if (tries == WORK_SHARDS - 1) return ~0ull;
+        d.shard = (d.shard + 1) & (WORK_SHARDS - 1);
+        draw_raw(ap, lane, d);
+    }
+}
+
+// the four counters of a wave go to the row of its workgroup (folded into the caller's behind the launch)
+__device__ __forceinline__ void add_counters(KArgsP ap, const unsigned long long *acc) {
+#ifdef NH_COUNTER_DIRECT  // tuning builds: the round-2 way, four atomics per wave on the caller's own words
+    if (unsigned long long *const c = launder(ap)->counters) {
+        atomicAdd(&c[CNT_FRAGMENTS], acc[CNT_FRAGMENTS]);
+        atomicAdd(&c[CNT_CLASSIFIED], acc[CNT_CLASSIFIED]);
+        atomicAdd(&c[CNT_BASES], acc[CNT_BASES]);
+        atomicAdd(&c[CNT_LOOKUPS], acc[CNT_LOOKUPS]);
+    }
+    return;
+#endif
+    unsigned long long *const row = launder(ap)->cshard + (size_t)(blockIdx.x & (COUNTER_SHARDS - 1)) * COUNTER_STRIDE;
+    atomicAdd(&row[CNT_FRAGMENTS], acc[CNT_FRAGMENTS]);
+    atomicAdd(&row[CNT_CLASSIFIED], acc[CNT_CLASSIFIED]);
+    atomicAdd(&row[CNT_BASES], acc[CNT_BASES]);
+    atomicAdd(&row[CNT_LOOKUPS], acc[CNT_LOOKUPS]);
+}
+
 // Stores the records staged by the last post_group (lane i = record i).  Called right before a probe
 // phase: the stores complete in the shadow of the first probe round trip.
 template <bool STD, class WL>
@@ -1070,22 +1175,74 @@ __device__ __forceinline__ void post_group(KArgsP ap, WL &S, const TaxList &TLI,
             // descriptor: three 16-byte LDS reads (same address in every lane), then scalars
             const uint4 *dp = reinterpret_cast<const uint4 *>(&S.slot[pp][s]);
             const uint4 d0 = dp[0], d1 = dp[1], d2 = dp[2];
-            const uint64_t f = ((uint64_t)uni(d0.y) << 32) | uni(d0.x);   // f_lo, f_hi
+            const uint32_t d_last = uni(d2.x), flags = uni(d2.y);
+            // f_lo, f_hi (a segment of a split read keeps the number of segments in f_hi: such launches have
+            // fewer than 2^32 fragments)
+            const uint64_t f = ((flags & 16u) ? 0ull : ((uint64_t)uni(d0.y) << 32)) | uni(d0.x);
             const uint64_t kt = kmer_taxa ? a2->kmer_taxa_off[f] + uni(d0.z) : 0;  // tile's first k-mer
             const uint32_t d_nqt = uni(d1.x), d_qbase = uni(d1.y), d_nruns = uni(d1.z);
-            const uint32_t d_last = uni(d2.x), flags = uni(d2.y);
             const uint32_t d_nk0 = uni(d2.z), d_total = uni(d2.w);
-            if (flags & 4u) {  // first tile of its fragment: fresh accumulation state
+            if (flags & 4u) {  // first tile of its fragment (or segment): fresh accumulation state
                 st.nlist = 0;
                 st.hit_groups = 0;
                 st.carry_tax = 0;
                 st.overflow = false;
+                // a segment of a split read inherits kraken2's last_taxon: the taxon of the minimizer it
+                // inherited, looked up as entry pad0 - 1 of this group's queue
+                const uint32_t cq = uni(d0.w);
+                if (cq) st.carry_tax = uni(tax_at<STD>(S, pp, cq - 1u));
             }
             const uint32_t ps = S.ps[pp][s][lane];
             post_tile<STD, BIG, PROF>(S, TLI, lane, ps, d_nqt, pp, d_qbase, d_nruns, (int)d_last, st,
                                       kmer_taxa, kt, prof, tprev);
             if ((flags & 2u) && reset_per_mate) st.carry_tax = 0;  // mate 0 ended, mate 1 follows
-            if (flags & 1u) {                                      // fragment ended
+            bool finish = (flags & 1u) != 0;  // fragment ended
+            if (finish && (flags & 16u)) {
+                // ... or rather one SEGMENT of a split read (descriptor: f_hi = segments, nk0 = this segment,
+                // pad1 = first partial slot of the read).  Leave the partial; whoever finishes last adds up.
+                const uint32_t nseg = uni(d0.y), seg = d_nk0, sb = uni(d1.w);
+                KArgsP a4 = launder(ap);
+                const bool over = st.overflow || st.nlist > PART_CAP;
+                uint32_t v = 0;
+                if (lane == 0) v = st.hit_groups;
+                if (lane == 1) v = over ? 0u : st.nlist;
+                if (lane == 2) v = over ? 1u : 0u;
+                if (lane >= 4 && !over) {
+                    const uint32_t idx = ((uint32_t)lane - 4u) >> 1;
+                    if (idx < st.nlist) {
+                        if constexpr (BIG) v = (lane & 1) ? TLI.cnt[idx] : TLI.tax[idx];
+                        else v = (lane & 1) ? S.list_cnt[idx] : S.list_tax[idx];
+                    }
+                }
+                // publish: the partial must be in memory before the counter says so -- another CU, possibly on
+                // another XCD, reads it.  Write-through (sc1) stores, drained, then the agent-scope atomic; the reader
+                // uses sc1 loads (past its L1; its XCD's L2 has never seen these lines).  NOT an agent-scope release /
+                // acquire pair: a release writes back the XCD's whole L2 and an acquire empties the CU's L1, once per
+                // segment on every wave of the chip -- that halved the long-read throughput when it was tried
+                // (MI355X_MICROARCH.md, inter-workgroup visibility: the "sc1 payload, vmcnt(0), flag" form).
+                __hip_atomic_store(&a4->split.part[(uint64_t)(sb + seg) * PART_DWORDS + (uint32_t)lane], v, __ATOMIC_RELAXED,
+                                   __HIP_MEMORY_SCOPE_AGENT);
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                uint32_t old = 0;
+                if (lane == 0) old = atomicAdd(&a4->split.part_done[sb], 1u);
+                old = uni(old);
+                finish = old + 1u == nseg;
+                if (finish) {
+                    for (uint32_t s2 = 0; s2 < nseg; s2++) {
+                        if (s2 == seg) continue;
+                        const uint32_t pv = __hip_atomic_load(&a4->split.part[(uint64_t)(sb + s2) * PART_DWORDS + (uint32_t)lane],
+                                                              __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        st.hit_groups += __builtin_amdgcn_readlane(pv, 0);
+                        const uint32_t n2 = __builtin_amdgcn_readlane(pv, 1);
+                        if (__builtin_amdgcn_readlane(pv, 2)) st.overflow = true;
+                        for (uint32_t i = 0; i < n2; i++)
+                            list_add<BIG>(S, TLI, lane, st, __builtin_amdgcn_readlane(pv, 4 + 2 * (int)i),
+                                          __builtin_amdgcn_readlane(pv, 5 + 2 * (int)i));
+                    }
+                    if (over) st.overflow = true;
+                }
+            }
+            if (finish) {
                 const uint32_t total_kmers = d_total;
                 uint32_t call = 0, clade_hits = 0;
                 if (st.nlist > 0) {
@@ -1202,16 +1359,18 @@ __global__ __launch_bounds__(WAVE * WAVES_PER_BLOCK, BIG ? 1 : (STD ? NH_MIN_WAV
     lk.budget = 0;
 
     if (lane == 0) S.frag_state = make_uint4(0, 0, 0, 0);
+    uint64_t carry_pack = 0;  // queue entries of the current group that are look-ups of an inherited minimizer
     // group complete (or input exhausted): hash + probe it -- which also resolves what is left of
     // the previous group -- then post-process the previous group and switch buffers
     auto turn = [&]() {
         flush_records<STD>(ap, S, lane);
 #ifndef NH_NO_QUAD
-        if constexpr (LINEAR && STD && CAP32)
-            probe_queue_quad<PROF>(ap, S, lane, par, qn, lk, !BIG, prof, tprev);
+        if constexpr (LINEAR && STD)
+            probe_queue_quad<PROF, !CAP32>(ap, S, lane, par, qn, lk, !BIG, carry_pack, prof, tprev);
         else
 #endif
-            probe_queue<LINEAR, STD, CAP32, PROF>(ap, S, lane, par, qn, lk, !BIG, prof, tprev);
+            probe_queue<LINEAR, STD, CAP32, PROF>(ap, S, lane, par, qn, lk, !BIG, carry_pack, prof, tprev);
+        carry_pack = 0;
         if (nslot_old) post_group<STD, BIG, PROF>(ap, S, TLI, lane, mates, reset_per_mate, par ^ 1u, nslot_old, prof, tprev);
         nslot_old = nslot_new;
         par ^= 1u;
@@ -1222,17 +1381,66 @@ __global__ __launch_bounds__(WAVE * WAVES_PER_BLOCK, BIG ? 1 : (STD ? NH_MIN_WAV
     // Fragments are handed out dynamically: every wave pulls chunks of consecutive fragments from
     // one counter (claimed one chunk ahead), so late-starting (non-resident) workgroups of the grid
     // find no work instead of a static share.
-    const uint32_t frag_chunk = ap->frag_chunk;  // mates * frag_chunk + 1 <= 64: the offsets fit the lanes of off_v
-    unsigned long long next_chunk = 0;           // lane 0: first fragment of the chunk claimed ahead
-    if (lane == 0) next_chunk = atomicAdd(ap->work, (unsigned long long)frag_chunk);
+    // (mates * sched.c0 + 1 <= 64: the offsets of a chunk fit the lanes of off_v)
+    // Long-read launches (items != 0) hand out ITEMS instead: whole reads or segments of a split read,
+    // largest first (SplitBufs in nh_device.h; the BIG variant always goes by fragments).
+    const bool items = !BIG && ap->split.hdr != nullptr;
+    // a wave's first claim is its index in the grid, later ones come from the work counter (k_classify_short
+    // says why)
+    Draw dr;
+    dr.raw = 0;
+    dr.shard = xcc_id();
+    bool first_claim = true;
+    auto take_claim = [&]() { draw_raw(ap, lane, dr); };
+    // claims there are in all: items of a long-read launch (known on the device only), else the claim map
+    uint64_t total_claims = launder(ap)->sched.total;
+    if (items) {
+        KArgsP a5 = launder(ap);
+        const SplitHdr *const hdr = a5->split.hdr;
+        const uint32_t used = hdr->seg_used;
+        total_claims = (uint64_t)(used < a5->split.seg_cap ? used : a5->split.seg_cap) + hdr->n_mid + hdr->n_small;
+    }
     for (;;) {
-        const uint64_t cbeg = readlane64(next_chunk, 0);
-        if (cbeg >= n_frag) break;
-        if (lane == 0) next_chunk = atomicAdd(ap->work, (unsigned long long)frag_chunk);
-        const uint32_t ncf = cbeg + frag_chunk <= n_frag ? frag_chunk : (uint32_t)(n_frag - cbeg);
+        uint64_t claim;
+        if (first_claim) {
+            claim = (uint64_t)blockIdx.x * WAVES_PER_BLOCK + (uint32_t)wib;
+            first_claim = false;
+            if (claim >= total_claims) claim = ~0ull;
+        } else {
+            claim = settle(ap, lane, dr, total_claims);
+        }
+        if (claim == ~0ull) break;
+        uint64_t cbeg;
+        uint32_t ncf;
+        uint32_t seg = 0, nseg = 1, seg_slot = 0;  // the claimed segment of a split read (items only)
+        if (items) {
+            KArgsP a5 = launder(ap);
+            const SplitHdr *const hdr = a5->split.hdr;
+            const uint32_t used = hdr->seg_used, n_mid = hdr->n_mid;
+            const uint32_t n_multi = used < a5->split.seg_cap ? used : a5->split.seg_cap;
+            ncf = 1;
+            bool hole = false;
+            if (claim < n_multi) {
+                const uint4 it = *reinterpret_cast<const uint4 *>(&a5->split.items_multi[claim]);
+                cbeg = uni(it.x);
+                seg = uni(it.y);
+                nseg = uni(it.z);
+                seg_slot = uni(it.w);
+                hole = nseg == 0;
+            } else {
+                const uint64_t j = claim - n_multi;
+                cbeg = uni(a5->split.items_single[j < n_mid ? j : n_frag - 1 - (j - n_mid)]);
+            }
+            if (hole) {  // (reserved by a read that is listed whole instead: the buffers were full)
+                take_claim();
+                continue;
+            }
+        } else if (!claim_range(ap, claim, n_frag, cbeg, ncf)) {
+            break;
+        }
+        take_claim();
         if (only_deferred) {  // second pass: only what the short-read kernel left behind
-            const uint64_t chunk = cbeg / frag_chunk;
-            if (!((launder(ap)->defer_bits[chunk >> 5] >> (chunk & 31)) & 1u)) continue;
+            if (!((launder(ap)->defer_bits[claim >> 5] >> (claim & 31)) & 1u)) continue;
         }
         // all sequence offsets of the chunk with ONE coalesced load (lane i = offset i), kept
         // relative to the chunk's first byte so that everything per fragment is 32-bit
@@ -1247,7 +1455,7 @@ __global__ __launch_bounds__(WAVE * WAVES_PER_BLOCK, BIG ? 1 : (STD ? NH_MIN_WAV
         // lane i: length of sequence i of the chunk
         uint32_t len_v = inplace ? launder(ap)->seq_len[sidx] : (uint32_t)__shfl_down((int)off_v, 1, 64) - off_v;
         if ((uint32_t)lane >= nseq) len_v = 0;
-        if (!BIG) {
+        if (!BIG && seg == 0) {  // (a split read is counted by its first segment)
             const uint32_t cb = wave_sum(len_v);
             if (lane == 0) {
                 S.acc[CNT_FRAGMENTS] += ncf;
@@ -1283,11 +1491,42 @@ __global__ __launch_bounds__(WAVE * WAVES_PER_BLOCK, BIG ? 1 : (STD ? NH_MIN_WAV
             uint64_t carry_min = NH_FULL;  // kraken2 last_minimizer of this fragment
             bool frag_first = true;
             NH_STAMP(9);
+            // the k-mers this claim covers: all of them, or those of one segment of a split read (single-end)
+            const bool split = nseg > 1;
+            const uint32_t qbeg = split ? seg * SEG_TILES * TQ : 0u;
+            uint32_t carry_q = 0;  // 1 + queue entry of the inherited minimizer's look-up (first tile of a segment)
+            if (split && seg > 0) {
+                // kraken2's last_minimizer at the start of the segment = the minimizer of the last unambiguous
+                // k-mer before it: scan the tile that ends there (its run starts land beyond the queue's end and
+                // are forgotten), further back while a tile holds none
+                for (uint32_t hq = qbeg; hq > 0 && carry_min == NH_FULL;) {
+                    hq -= TQ;
+                    const uint64_t hg0 = cbase + o0 + hq;
+                    const uint32_t *hp = tile_ptr(hg0);
+                    const uint32_t hw = *hp;
+                    uint32_t hps, hdummy = 0;
+                    int hlast;
+                    (void)scan_tile<STD, PROF>(ap, S, lane, hw, (uint32_t)hg0 & 3u, (uint32_t)TL, TQ, par, qn, carry_min, hps,
+                                               hlast, hp, false, hdummy, prof, tprev);
+                    wave_sync();
+                }
+                // ... and last_taxon = what that minimizer finds in the table: one more entry of this group's
+                // queue, which must then be the group of the segment's first tile as well
+                if (carry_min != NH_FULL) {
+                    if (nslot_new == NSLOT || qn + TL + 1 > (uint32_t)QCAP_GENERIC) turn();
+                    if (lane == 0) S.q[par][qn] = carry_min;
+                    carry_q = qn + 1u;
+                    carry_pack = (carry_pack << 16) | carry_q;
+                    qn++;
+                }
+            }
             for (int m = 0; m < mates; m++) {
                 const uint32_t n = m ? n1 : n0;
-                const uint32_t nk = m ? nk1 : nk0;
+                const uint32_t nk_all = m ? nk1 : nk0;
+                uint32_t nk = nk_all;  // end of the k-mers to scan
+                if (split && qbeg + SEG_TILES * TQ < nk) nk = qbeg + SEG_TILES * TQ;
                 if (m == 1 && reset_per_mate) carry_min = NH_FULL;
-                for (uint32_t q0 = 0; q0 < nk; q0 += TQ) {
+                for (uint32_t q0 = (m == 0 ? qbeg : 0u); q0 < nk; q0 += TQ) {
                     const uint64_t g0 = cbase + (m ? o1 : o0) + q0;
                     NH_STAMP(0);
                     // two-deep prefetch FIFO: (tag1, w1) was loaded for the next tile, (tag2, w2)
@@ -1340,15 +1579,16 @@ __global__ __launch_bounds__(WAVE * WAVES_PER_BLOCK, BIG ? 1 : (STD ? NH_MIN_WAV
                         d0.x = (uint32_t)f;
                         d0.y = (uint32_t)(f >> 32);
                         d0.z = (m ? nk0 + 1 : 0) + q0;  // k-mer index of the tile within its fragment
-                        d0.w = 0;
+                        d0.w = frag_first ? carry_q : 0u;
                         d1.x = nqt;
                         d1.y = qn;
                         d1.z = nruns;
-                        d1.w = 0;
+                        d1.w = seg_slot;
                         d2.x = (uint32_t)last_lane;
-                        d2.y = (frag_end ? 1u : 0u) | (mate_end ? 2u : 0u) | (frag_first ? 4u : 0u);
-                        d2.z = nk0;
+                        d2.y = (frag_end ? 1u : 0u) | (mate_end ? 2u : 0u) | (frag_first ? 4u : 0u) | (split ? 16u : 0u);
+                        d2.z = split ? seg : nk0;
                         d2.w = nk0 + nk1;
+                        if (split) d0.y = nseg;
                         uint4 *dp = reinterpret_cast<uint4 *>(&S.slot[par][nslot_new]);
                         dp[0] = d0;
                         dp[1] = d1;
@@ -1376,12 +1616,7 @@ __global__ __launch_bounds__(WAVE * WAVES_PER_BLOCK, BIG ? 1 : (STD ? NH_MIN_WAV
         int *const error_flag = ap->error_flag;
         if (PROF && counters)
             for (int i = 0; i < 12; i++) atomicAdd(&counters[CNT_N + i], (unsigned long long)prof[i]);
-        if (counters) {
-            atomicAdd(&counters[CNT_FRAGMENTS], S.acc[CNT_FRAGMENTS]);
-            atomicAdd(&counters[CNT_CLASSIFIED], S.acc[CNT_CLASSIFIED]);
-            atomicAdd(&counters[CNT_BASES], S.acc[CNT_BASES]);
-            atomicAdd(&counters[CNT_LOOKUPS], S.acc[CNT_LOOKUPS]);
-        }
+        add_counters(ap, S.acc);
         if (bad_input) atomicOr(&error_flag[0], 2);
     }
 }
@@ -1400,7 +1635,7 @@ __global__ __launch_bounds__(WAVE * WAVES_PER_BLOCK, BIG ? 1 : (STD ? NH_MIN_WAV
 // kernel, launched right behind, classifies exactly those chunks (none: it returns at once).
 constexpr uint32_t SHORT_MAX = 158;  // TQ + K - 1 bases: at most one tile of 124 k-mers
 
-template <bool PROF>
+template <bool PROF, bool WIDE>
 __global__ __launch_bounds__(WAVE * WAVES_PER_BLOCK, PROF ? 4 : NH_MIN_WAVES) void k_classify_short(const KArgs args_by_kernarg_pointer) {
     constexpr bool STD = true;
     KArgsP ap = (KArgsP)__builtin_amdgcn_kernarg_segment_ptr();
@@ -1440,9 +1675,38 @@ __global__ __launch_bounds__(WAVE * WAVES_PER_BLOCK, PROF ? 4 : NH_MIN_WAVES) vo
     lk.budget = 0;
     if (lane == 0) S.frag_state = make_uint4(0, 0, 0, 0);
 
-    const uint32_t frag_chunk = ap->frag_chunk;
-    unsigned long long next_chunk = 0;  // lane 0: first fragment of the chunk claimed ahead
-    if (lane == 0) next_chunk = atomicAdd(ap->work, (unsigned long long)frag_chunk);
+    // tuning aid (KArgs::timeline): looked up again at every stamp, so that nothing of it lives in registers
+    auto tl_row = [&]() -> unsigned long long * {
+        unsigned long long *const base = launder(ap)->timeline;
+        return base ? base + 32ull * ((uint64_t)blockIdx.x * WAVES_PER_BLOCK + (uint32_t)wib) : nullptr;
+    };
+    if (lane == 0) {
+        if (unsigned long long *const tline = tl_row()) {
+            tline[0] = wall_clock64();
+            tline[2] = tline[3] = tline[6] = 0;
+            uint32_t xcc;
+            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+            tline[7] = xcc;
+        }
+    }
+    // Claims (claim_range: which fragments a claim stands for).  The FIRST claim of a wave is its own index in
+    // the grid -- no atomic: 5120 waves bumping one counter at the same moment, and bumping it again for the
+    // claim ahead, kept every wave of a launch waiting ~120 us for its first bases (vmcnt retires in order: the
+    // offsets load sits behind the atomic) -- later ones are n_static + the work counter.  The claim ahead is
+    // taken when the LAST batch of the current chunk has been encoded: early enough to be back when the chunk
+    // ends, and late enough that the chunk it reserves is started soon (a claim taken a whole chunk ahead made
+    // the launch end two chunks after the counter ran out, profiles/r03_timeline.txt).
+    // ... and the later ones come from the counter of the wave's XCD first (Draw, nh_device.h: one hot word
+    // for all 5120 waves was a bottleneck of its own).
+    Draw dr;
+    dr.raw = 0;
+    dr.shard = xcc_id();
+    bool first_claim = true;
+    bool claim_ahead = true;  // a claim has been taken that has not been looked at yet
+    auto take_claim = [&]() {
+        draw_raw(ap, lane, dr);
+        claim_ahead = true;
+    };
 
     // the chunk being worked on
     uint64_t cbeg = 0, cbase = 0;
@@ -1457,15 +1721,29 @@ __global__ __launch_bounds__(WAVE * WAVES_PER_BLOCK, PROF ? 4 : NH_MIN_WAVES) vo
         bool batch = true;
         if (t >= nseq) {  // next chunk
             NH_STAMP(8);
-            const uint64_t c0 = readlane64(next_chunk, 0);
-            if (c0 >= n_frag) {
+            uint64_t claim = ~0ull;
+            if (first_claim) {
+                claim = (uint64_t)blockIdx.x * WAVES_PER_BLOCK + (uint32_t)wib;
+                first_claim = false;
+            } else if (drain == 0) {
+                claim = settle(ap, lane, dr, launder(ap)->sched.total);
+            }
+            uint64_t c0 = 0;
+            uint32_t ncf = 0;
+            if (claim == ~0ull || !claim_range(ap, claim, n_frag, c0, ncf)) {
                 if (drain == 2) break;
                 drain++;
                 batch = false;
             } else {
-                if (lane == 0) next_chunk = atomicAdd(ap->work, (unsigned long long)frag_chunk);
+                claim_ahead = false;
+                if (lane == 0) {
+                    if (unsigned long long *const tline = tl_row()) {
+                        tline[4] = wall_clock64();
+                        if (tline[6] < 24) tline[8 + tline[6]] = (tline[4] << 8) | ncf;  // start and size of every chunk
+                        tline[6] += 1;
+                    }
+                }
                 cbeg = c0;
-                const uint32_t ncf = cbeg + frag_chunk <= n_frag ? frag_chunk : (uint32_t)(n_frag - cbeg);
                 const uint32_t ns = ncf * (uint32_t)mates;
                 const uint32_t nof = inplace ? ns : ns + 1;
                 const uint64_t sidx = cbeg * (uint64_t)mates + ((uint32_t)lane < nof ? (uint32_t)lane : nof - 1);
@@ -1478,12 +1756,12 @@ __global__ __launch_bounds__(WAVE * WAVES_PER_BLOCK, PROF ? 4 : NH_MIN_WAVES) vo
                 if ((uint32_t)lane >= ns) len_v = 0;
                 if (__ballot(len_v > SHORT_MAX)) {  // a longer sequence: the whole chunk goes to the generic kernel
                     if (lane == 0) {
-                        const uint64_t chunk = cbeg / frag_chunk;
-                        atomicOr(&launder(ap)->defer_bits[chunk >> 5], 1u << (chunk & 31));
+                        atomicOr(&launder(ap)->defer_bits[claim >> 5], 1u << (claim & 31));
                         atomicMax(launder(ap)->pending_long, 1);
                     }
                     nseq = 0;
                     t = 0;
+                    take_claim();
                     continue;
                 }
                 const uint32_t cb = wave_sum(len_v);
@@ -1516,6 +1794,11 @@ __global__ __launch_bounds__(WAVE * WAVES_PER_BLOCK, PROF ? 4 : NH_MIN_WAVES) vo
             }
             wave_sync();
             NH_STAMP(1);
+            if (lane == 0) {
+                unsigned long long *const tline = tl_row();
+                if (tline && tline[2] == 0) tline[2] = wall_clock64();
+            }
+            if (!claim_ahead && t + NSLOT >= nseq) take_claim();  // the chunk's last batch: take the claim ahead now
         }
         // ---- the batch's tiles; j == NSLOT is the end-of-batch turn --------------------------------
         for (uint32_t j = 0; j <= (uint32_t)NSLOT; j++) {
@@ -1582,10 +1865,14 @@ __global__ __launch_bounds__(WAVE * WAVES_PER_BLOCK, PROF ? 4 : NH_MIN_WAVES) vo
             if ((nslot_new != 0 && (full || j == (uint32_t)NSLOT)) || (!batch && j == (uint32_t)NSLOT)) {
                 flush_records<STD>(ap, S, lane);
 #ifdef NH_NO_QUAD
-                probe_queue<true, STD, true, PROF>(ap, S, lane, par, qn, lk, true, prof, tprev);
+                probe_queue<true, STD, !WIDE, PROF>(ap, S, lane, par, qn, lk, true, 0ull, prof, tprev);
 #else
-                probe_queue_quad<PROF>(ap, S, lane, par, qn, lk, true, prof, tprev);
+                probe_queue_quad<PROF, WIDE>(ap, S, lane, par, qn, lk, true, 0ull, prof, tprev);
 #endif
+                if (lane == 0) {
+                    unsigned long long *const tline = tl_row();
+                    if (tline && tline[3] == 0) tline[3] = wall_clock64();
+                }
                 if (nslot_old)
                     post_group<STD, false, PROF>(ap, S, TLI, lane, mates, reset_per_mate, par ^ 1u, nslot_old, prof, tprev);
                 nslot_old = nslot_new;
@@ -1604,13 +1891,101 @@ __global__ __launch_bounds__(WAVE * WAVES_PER_BLOCK, PROF ? 4 : NH_MIN_WAVES) vo
         int *const error_flag = ap->error_flag;
         if (PROF && counters)
             for (int i = 0; i < 12; i++) atomicAdd(&counters[CNT_N + i], (unsigned long long)prof[i]);
-        if (counters) {
-            atomicAdd(&counters[CNT_FRAGMENTS], S.acc[CNT_FRAGMENTS]);
-            atomicAdd(&counters[CNT_CLASSIFIED], S.acc[CNT_CLASSIFIED]);
-            atomicAdd(&counters[CNT_BASES], S.acc[CNT_BASES]);
-            atomicAdd(&counters[CNT_LOOKUPS], S.acc[CNT_LOOKUPS]);
-        }
+        add_counters(ap, S.acc);
         if (bad_input) atomicOr(&error_flag[0], 2);
+        if (unsigned long long *const tline = tl_row()) tline[5] = wall_clock64();
+    }
+}
+
+// Folds the COUNTER_SHARDS rows the waves of a launch added to into the caller's four counters, and clears
+// the rows for the slot's next launch.  One wave.
+__global__ __launch_bounds__(64) void k_fold_counters(unsigned long long *cshard, unsigned long long *counters) {
+    const int lane = threadIdx.x;
+    unsigned long long v[4];
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        unsigned long long x = 0;
+        for (uint32_t r = lane; r < COUNTER_SHARDS; r += 64) {
+            x += cshard[(size_t)r * COUNTER_STRIDE + i];
+            cshard[(size_t)r * COUNTER_STRIDE + i] = 0;
+        }
+        for (int d = 32; d >= 1; d >>= 1) x += __shfl_xor(x, d, 64);
+        v[i] = x;
+    }
+    if (lane == 0 && counters)
+        for (int i = 0; i < 4; i++)
+            if (v[i]) atomicAdd(&counters[i], v[i]);
+}
+
+// ---- long-read prepass: the launch's work items (SplitBufs, nh_device.h) -----------------------------------
+// One thread per read.  Reads of more than SPLIT_MIN_TILES tiles reserve one item = one partial slot per
+// segment (one atomic per wave); whole reads are listed by size class.  A wave whose segments no longer fit
+// the buffers lists its reads whole and marks what it had reserved as holes (nseg = 0).
+__device__ __forceinline__ uint32_t wave_scan_incl(uint32_t v, const int lane) {
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const uint32_t o = (uint32_t)__shfl_up((int)v, d, 64);
+        if (lane >= d) v += o;
+    }
+    return v;
+}
+
+__global__ __launch_bounds__(256) void k_prep_items(const KArgs args_by_kernarg_pointer) {
+    KArgsP ap = (KArgsP)__builtin_amdgcn_kernarg_segment_ptr();
+    const int lane = threadIdx.x & 63;
+    const uint64_t n_frag = ap->n_frag;
+    const uint64_t f = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const bool act = f < n_frag;
+    const uint32_t K = ap->db.k, TQ = TL - ap->db.window;
+    uint64_t len = 0;
+    if (act) len = ap->seq_len ? (uint64_t)ap->seq_len[f] : ap->seq_off[f + 1] - ap->seq_off[f];
+    if (len > 0x7FFFFFFFull) len = 0x7FFFFFFFull;  // (the classify kernel reports such a read)
+    const uint32_t nk = len >= K ? (uint32_t)len - K + 1 : 0;
+    const uint32_t nt = (nk + TQ - 1) / TQ;
+    uint32_t nseg = nt > SPLIT_MIN_TILES ? (nt + SEG_TILES - 1) / SEG_TILES : 1u;
+    bool multi = act && nseg > 1;
+    SplitHdr *const hdr = ap->split.hdr;
+    const uint32_t cap = ap->split.seg_cap;
+    {   // segments: item index = partial slot index
+        const uint32_t incl = wave_scan_incl(multi ? nseg : 0u, lane);
+        const uint32_t tot = (uint32_t)__shfl((int)incl, 63, 64);
+        if (tot) {
+            uint32_t base = 0;
+            if (lane == 0) base = atomicAdd(&hdr->seg_used, tot);
+            base = (uint32_t)__shfl((int)base, 0, 64);
+            const uint32_t mine = base + incl - (multi ? nseg : 0u);
+            const bool fits = (uint64_t)base + tot <= cap;
+            if (multi) {
+                SplitItem *const it = ap->split.items_multi;
+                for (uint32_t s = 0; s < nseg; s++) {
+                    if (mine + s >= cap) break;
+                    SplitItem v;
+                    v.f = (uint32_t)f;
+                    v.seg = s;
+                    v.nseg = fits ? nseg : 0u;  // 0: a hole, the read is listed whole below
+                    v.slot = mine;
+                    it[mine + s] = v;
+                }
+                if (fits) ap->split.part_done[mine] = 0;
+                else multi = false;
+            }
+        }
+    }
+    const bool whole = act && !multi;
+    const bool mid = whole && nt >= MID_TILES;
+    const bool small = whole && !mid;
+    {
+        const uint64_t bm = __ballot(mid), bs = __ballot(small);
+        uint32_t base_m = 0, base_s = 0;
+        if (lane == 0) {
+            if (bm) base_m = atomicAdd(&hdr->n_mid, (uint32_t)__popcll(bm));
+            if (bs) base_s = atomicAdd(&hdr->n_small, (uint32_t)__popcll(bs));
+        }
+        base_m = (uint32_t)__shfl((int)base_m, 0, 64);
+        base_s = (uint32_t)__shfl((int)base_s, 0, 64);
+        uint32_t *const single = ap->split.items_single;
+        if (mid) single[base_m + below(bm)] = (uint32_t)f;
+        if (small) single[n_frag - 1 - (base_s + below(bs))] = (uint32_t)f;
     }
 }
 
@@ -1731,10 +2106,58 @@ static void launch_variant(const KArgs &ka, dim3 g, dim3 b, hipStream_t stream, 
         // second pass for fragments with more than 64 distinct taxa: exits at once if there are none
         KArgs kb = ka;
         kb.only_deferred = 0;
-        (void)hipMemsetAsync(d_work, 0, sizeof(unsigned long long), stream);
+        (void)hipMemsetAsync(d_work, 0, WORK_SHARDS * WORK_STRIDE * sizeof(unsigned long long), stream);
         hipLaunchKernelGGL((k_classify<LINEAR, STD, CAP32, false, true>), g, b, 0, stream, kb);
         (void)hipMemsetAsync(ka.pending, 0, sizeof(int), stream);
     }
+}
+
+// The claim map of a launch (Sched, nh_device.h).  Default: everything in chunks of c0 -- measured
+// (profiles/r03_sched.txt): with the first claim static and the claim ahead taken late, a launch already
+// ends within ~1.3 chunks of the counter running out, and smaller chunks at the tail cost more at their
+// starts (two dependent loads with nothing else of the wave in flight) than they level out: 1 M single
+// reads 1.147 ms flat against 1.236 ms with a c0 / 2, then 2-batch tail.  NOHUMAN_SCHED=c1,c2,p1,p2 turns
+// the guided map on: chunks of c1 for p1 percent of half a c0-chunk per resident wave, then chunks of c2
+// for p2 percent of half a c1-chunk per wave (tuning knob, tools/sweep_sched.py).
+Sched make_sched(uint64_t n_frag, uint32_t c0, int mates, uint64_t waves) {
+    Sched sc;
+    memset(&sc, 0, sizeof sc);
+    if (c0 == 0) c0 = 1;
+    const uint32_t step = mates == 2 ? 2u : 4u;  // one batch of four tiles
+    uint32_t c1 = c0 / 2 / step * step, c2 = 2 * step;
+    uint64_t p1 = 100, p2 = 100;
+    bool guided = false;
+    if (const char *env = getenv("NOHUMAN_SCHED")) {
+        unsigned a = 0, b = 0, c = 0, d = 0;
+        if (strcmp(env, "guided") == 0) guided = c0 >= 4 * step;
+        else if (sscanf(env, "%u,%u,%u,%u", &a, &b, &c, &d) == 4 && a >= 1 && b >= 1) {
+            guided = true;
+            c1 = a;
+            c2 = b;
+            p1 = c;
+            p2 = d;
+        }
+    }
+    if (c1 > c0) c1 = c0;
+    if (c2 > c1) c2 = c1;
+    sc.c0 = c0;
+    sc.c1 = guided ? c1 : c0;
+    sc.c2 = guided ? c2 : c0;
+    uint64_t t1 = guided ? waves * c0 / 2 * p1 / 100 : 0, t2 = guided ? waves * c1 / 2 * p2 / 100 : 0;
+    if (t1 + t2 > n_frag / 2) {  // a small launch: the tail is at most half of it
+        const uint64_t cut = n_frag / 2;
+        const uint64_t s = t1 + t2;
+        t1 = t1 * cut / s;
+        t2 = t2 * cut / s;
+    }
+    sc.n0 = (n_frag - t1 - t2) / c0;
+    sc.base1 = sc.n0 * c0;
+    const uint64_t r1 = n_frag - sc.base1;               // fragments left to the smaller chunks
+    const uint64_t n1 = r1 > t2 ? (r1 - t2) / sc.c1 : 0;  // ... of which these many chunks of c1
+    sc.n01 = sc.n0 + n1;
+    sc.base2 = sc.base1 + n1 * sc.c1;
+    sc.total = sc.n01 + (n_frag - sc.base2 + sc.c2 - 1) / sc.c2;
+    return sc;
 }
 
 hipError_t launch_classify(const DevDB &db, const LaunchIO &io, double confidence, const LaunchSlot &sl,
@@ -1742,14 +2165,16 @@ hipError_t launch_classify(const DevDB &db, const LaunchIO &io, double confidenc
     const uint64_t n_frag = io.n_frag;
     if (n_frag == 0) return hipSuccess;
     if (frag_chunk == 0) frag_chunk = 1;
-    hipError_t me = hipMemsetAsync(sl.d_work, 0, sizeof(unsigned long long), stream);
+    hipError_t me = hipMemsetAsync(sl.d_work, 0, WORK_SHARDS * WORK_STRIDE * sizeof(unsigned long long), stream);
     if (me != hipSuccess) return me;
-    uint64_t need = (n_frag + (uint64_t)WAVES_PER_BLOCK * frag_chunk - 1) / ((uint64_t)WAVES_PER_BLOCK * frag_chunk);
+    const Sched sched = make_sched(n_frag, frag_chunk, io.mates, (uint64_t)grid_blocks * WAVES_PER_BLOCK);
+    uint64_t need = (sched.total + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK;
     int grid = (int)(need < (uint64_t)grid_blocks ? need : (uint64_t)grid_blocks);
     dim3 g(grid), b(WAVE * WAVES_PER_BLOCK);
     const bool std_geom = is_std(db);
     KArgs ka;
     memset(&ka, 0, sizeof ka);
+    ka.sched = sched;
     ka.db = db;
     ka.bases = (const uint8_t *)io.d_bases;
     ka.seq_off = (const uint64_t *)io.d_seq_off;
@@ -1763,43 +2188,60 @@ hipError_t launch_classify(const DevDB &db, const LaunchIO &io, double confidenc
     ka.kmer_taxa = (uint32_t *)io.d_kmer_taxa;
     ka.kmer_taxa_off = (const uint64_t *)io.d_kmer_taxa_off;
     ka.counters = (unsigned long long *)io.d_counters;
+    ka.cshard = sl.d_cshard;
     ka.error_flag = sl.d_error;
     ka.pending = sl.d_pending;
     ka.work = sl.d_work;
     ka.defer_bits = sl.d_defer;
     ka.pending_long = sl.d_pending_long;
+    if (const char *tl = getenv("NH_TIMELINE_PTR")) ka.timeline = (unsigned long long *)strtoull(tl, nullptr, 0);
+    // Long single-end reads: a prepass lists the launch's work items -- segments of the reads worth cutting,
+    // then whole reads by size class -- and the generic kernel claims items (SplitBufs, nh_device.h)
+    static const bool no_split = getenv("NOHUMAN_NO_SPLIT") != nullptr;  // tuning / test knob
+    const bool use_items = io.long_reads && io.mates == 1 && sl.split.hdr != nullptr && !no_split &&
+                           n_frag <= sl.split_single_cap && n_frag < 0xFFFFFFFFull;
+    if (use_items) {
+        ka.split = sl.split;
+        (void)hipMemsetAsync(sl.split.hdr, 0, sizeof(SplitHdr), stream);
+        hipLaunchKernelGGL(k_prep_items, dim3((unsigned)((n_frag + 255) / 256)), dim3(256), 0, stream, ka);
+        g = dim3(grid_blocks);  // (the number of items is only known on the device)
+    }
     // tables of 2^32 - 256 cells or more take the variant with 64-bit cell positions;
     // NOHUMAN_FORCE_WIDE=1 selects it for any table (tests: small tables through the wide path)
     static const bool force_wide = getenv("NOHUMAN_FORCE_WIDE") != nullptr;
     static const bool no_short = getenv("NOHUMAN_NO_SHORT") != nullptr;  // tuning / test knob
     static const bool phase_prof = getenv("NH_PHASE_PROF") != nullptr;
     const bool cap32 = db.capacity < 0xFFFFFF00ull && !force_wide;
-    const bool may_overflow = db.node_count > LIST_CAP;  // <= 64 taxa can never overflow the list
-    const bool hot = db.linear_probing && std_geom && cap32;
+    // <= 64 taxa can never overflow the list; a segment of a split read keeps at most PART_CAP
+    const bool may_overflow = db.node_count > LIST_CAP || (use_items && db.node_count > PART_CAP);
+    const bool hot = db.linear_probing && std_geom;  // quad probing, short-read kernel (32- or 64-bit cell positions)
     // Short reads first: the one-tile-per-sequence kernel takes every chunk whose sequences fit a tile and
     // marks the others for the generic kernel launched right behind it (which returns at once when
     // nothing was marked).  Skipped when the caller says the reads are long.
-    const uint64_t n_chunks = (n_frag + frag_chunk - 1) / frag_chunk;
+    const uint64_t n_chunks = sched.total;
     if (hot && !io.long_reads && !no_short && n_chunks <= sl.defer_cap_bits) {
         (void)hipMemsetAsync(sl.d_defer, 0, (size_t)((n_chunks + 31) / 32) * 4, stream);
-        if (phase_prof)
-            hipLaunchKernelGGL((k_classify_short<true>), g, b, 0, stream, ka);
+        if (phase_prof && cap32)
+            hipLaunchKernelGGL((k_classify_short<true, false>), g, b, 0, stream, ka);
+        else if (cap32)
+            hipLaunchKernelGGL((k_classify_short<false, false>), g, b, 0, stream, ka);
         else
-            hipLaunchKernelGGL((k_classify_short<false>), g, b, 0, stream, ka);
+            hipLaunchKernelGGL((k_classify_short<false, true>), g, b, 0, stream, ka);
         ka.only_deferred = 1;
-        (void)hipMemsetAsync(sl.d_work, 0, sizeof(unsigned long long), stream);
+        (void)hipMemsetAsync(sl.d_work, 0, WORK_SHARDS * WORK_STRIDE * sizeof(unsigned long long), stream);
     }
-    if (hot && phase_prof)
+    if (hot && cap32 && phase_prof)
         launch_variant<true, true, true, true>(ka, g, b, stream, may_overflow, sl.d_work);  // d_counters: CNT_N + 12 words
-    else if (hot)
+    else if (hot && cap32)
         launch_variant<true, true, true>(ka, g, b, stream, may_overflow, sl.d_work);
-    else if (db.linear_probing && std_geom)
+    else if (hot)
         launch_variant<true, true, false>(ka, g, b, stream, may_overflow, sl.d_work);
     else if (db.linear_probing)
         launch_variant<true, false, false>(ka, g, b, stream, may_overflow, sl.d_work);
     else
         launch_variant<false, false, false>(ka, g, b, stream, may_overflow, sl.d_work);
     if (ka.only_deferred) (void)hipMemsetAsync(sl.d_pending_long, 0, sizeof(int), stream);
+    hipLaunchKernelGGL(k_fold_counters, dim3(1), dim3(64), 0, stream, sl.d_cshard, (unsigned long long *)io.d_counters);
     return hipGetLastError();
 }
 
@@ -1822,7 +2264,7 @@ hipError_t launch_insert_sequences(const DevDB &db, const void *d_bases, const v
 
 int classify_blocks_per_cu() {
     int nb = 0;
-    hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_classify_short<false>,
+    hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_classify_short<false, false>,
                                                                 WAVE * WAVES_PER_BLOCK, 0);
     if (e != hipSuccess || nb < 1) nb = 4;
     return nb > 8 ? 8 : nb;

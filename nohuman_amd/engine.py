@@ -172,8 +172,9 @@ class Engine:
 
     # -- classify ------------------------------------------------------------------------------
     def classify(self, bases: np.ndarray, seq_offsets: np.ndarray, paired: bool = False,
-                 confidence: float = 0.0, want_taxa: bool = False):
-        """Host buffers in, result records (RESULT_DTYPE) out; optional per-k-mer taxa list."""
+                 confidence: float = 0.0, want_taxa: bool = False, long_reads: bool = False):
+        """Host buffers in, result records (RESULT_DTYPE) out; optional per-k-mer taxa list.  long_reads:
+        NH_FLAG_LONG (the library sets it itself for batches of more than 2000 bases per fragment)."""
         bases = np.ascontiguousarray(bases, dtype=np.uint8)
         seq_offsets = np.ascontiguousarray(seq_offsets, dtype=np.uint64)
         mates = 2 if paired else 1
@@ -181,7 +182,7 @@ class Engine:
         if n_seq % mates:
             raise ValueError("paired input needs an even number of sequences")
         n_frag = n_seq // mates
-        flags = FLAG_PAIRED if paired else 0
+        flags = (FLAG_PAIRED if paired else 0) | (FLAG_LONG if long_reads else 0)
         out = np.zeros(n_frag, dtype=RESULT_DTYPE)
         bptr = bases.ctypes.data if bases.size else None
         if not want_taxa:

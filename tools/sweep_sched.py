@@ -1,0 +1,94 @@
+"""Sweeps launch-scheduling settings (NOHUMAN_SCHED / NOHUMAN_FRAG_CHUNK are read at every launch) on the
+bench shapes in ONE process, interleaved passes (boxes and processes differ by a few percent; only numbers
+of one call compare).  usage: sweep_sched.py [--passes 3] [--steps 20] [shape ...]   shapes: pe se hit ont"""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from nohuman_amd import Engine
+
+dev = torch.device("cuda", 0)
+argv = sys.argv[1:]
+def opt(name, default):
+    if name in argv:
+        i = argv.index(name); v = argv[i + 1]; del argv[i:i + 2]; return type(default)(v)
+    return default
+passes, steps = opt("--passes", 3), opt("--steps", 20)
+shapes = argv or ["pe", "se"]
+cap = 1_431_655_765
+L = 150
+acgt = torch.tensor([65, 67, 71, 84], dtype=torch.uint8, device=dev)
+
+def make(shape):
+    eng = Engine.synthetic(cap, int(cap * 0.7) - (80_000_000 if shape == "hit" else 0), depth=30, seed=20250101)
+    paired = shape in ("pe", "hit", "pechunk")
+    mates = 2 if paired else 1
+    n = {"pe": 2_500_000, "se": 1_000_000, "hit": 1_000_000, "ont": 200_000, "sechunk": 1_000_000, "pechunk": 2_500_000}[shape]
+    g = torch.Generator(device=dev); g.manual_seed(11)
+    if shape == "ont":
+        lens = torch.exp(torch.randn(n, generator=g, device=dev, dtype=torch.float64) * 0.85 + 8.8).clamp(200, 200000).to(torch.int64)
+        offs = torch.zeros(n + 1, dtype=torch.int64, device=dev); offs[1:] = torch.cumsum(lens, 0)
+    else:
+        offs = torch.arange(n * mates + 1, dtype=torch.int64, device=dev) * L
+    offs = offs.contiguous()
+    total = int(offs[-1])
+    pool = []
+    for b in range(2):
+        bases = acgt[torch.randint(0, 4, (total + 64,), generator=g, device=dev)].contiguous()
+        if shape == "hit":
+            nh = n // 2 * mates
+            eng.add_sequences(bases.data_ptr(), offs.data_ptr(), nh, 30)
+            he = nh * L
+            m = torch.rand(he, generator=g, device=dev) < 0.01
+            bases[:he] = torch.where(m, acgt[torch.randint(0, 4, (he,), generator=g, device=dev)], bases[:he])
+        pool.append(bases)
+    res = torch.empty((n, 4), dtype=torch.int32, device=dev)
+    cnt = torch.zeros(4, dtype=torch.int64, device=dev)
+    return dict(eng=eng, paired=paired, mates=mates, n=n, offs=offs, pool=pool, res=res, cnt=cnt, ont=shape == "ont")
+
+def run(w, env):
+    for k in ("NOHUMAN_SCHED", "NOHUMAN_FRAG_CHUNK"):
+        os.environ.pop(k, None)
+    os.environ.update(env)
+    st = torch.cuda.current_stream().cuda_stream
+    def step(i):
+        w["eng"].classify_device(w["pool"][i % 2].data_ptr(), w["offs"].data_ptr(), w["n"], w["paired"], 0.0,
+                                 w["res"].data_ptr(), w["cnt"].data_ptr(), st, long_reads=w["ont"])
+    for i in range(2): step(i)
+    torch.cuda.synchronize()
+    e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for i in range(steps): step(i)
+    e1.record(); torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / steps
+
+settings = {
+    "pe": [("off", {"NOHUMAN_SCHED": "off"}), ("default", {}), ("12,4,50,50", {"NOHUMAN_SCHED": "12,4,50,50"}),
+           ("12,4,150,150", {"NOHUMAN_SCHED": "12,4,150,150"}), ("12,2,100,100", {"NOHUMAN_SCHED": "12,2,100,100"}),
+           ("12,6,100,100", {"NOHUMAN_SCHED": "12,6,100,100"}), ("8,4,100,100", {"NOHUMAN_SCHED": "8,4,100,100"}),
+           ("12,4,100,200", {"NOHUMAN_SCHED": "12,4,100,200"})],
+    "se": [("off", {"NOHUMAN_SCHED": "off"}), ("default", {}), ("16,8,50,50", {"NOHUMAN_SCHED": "16,8,50,50"}),
+           ("16,8,150,150", {"NOHUMAN_SCHED": "16,8,150,150"}), ("16,4,100,100", {"NOHUMAN_SCHED": "16,4,100,100"}),
+           ("16,12,100,100", {"NOHUMAN_SCHED": "16,12,100,100"}), ("12,8,100,100", {"NOHUMAN_SCHED": "12,8,100,100"}),
+           ("16,8,100,200", {"NOHUMAN_SCHED": "16,8,100,200"}),
+           ("chunk28 off", {"NOHUMAN_SCHED": "off", "NOHUMAN_FRAG_CHUNK": "28"}), ("chunk28", {"NOHUMAN_FRAG_CHUNK": "28"})],
+    "hit": [("default", {}), ("chunk16", {"NOHUMAN_FRAG_CHUNK": "16"}), ("chunk20", {"NOHUMAN_FRAG_CHUNK": "20"})],
+    "ont": [("default", {})],
+    "sechunk": [("32", {}), ("28", {"NOHUMAN_FRAG_CHUNK": "28"}), ("24", {"NOHUMAN_FRAG_CHUNK": "24"}),
+                ("20", {"NOHUMAN_FRAG_CHUNK": "20"}), ("16", {"NOHUMAN_FRAG_CHUNK": "16"}), ("12", {"NOHUMAN_FRAG_CHUNK": "12"})],
+    "pechunk": [("24", {}), ("20", {"NOHUMAN_FRAG_CHUNK": "20"}), ("16", {"NOHUMAN_FRAG_CHUNK": "16"}),
+                ("12", {"NOHUMAN_FRAG_CHUNK": "12"}), ("30", {"NOHUMAN_FRAG_CHUNK": "30"})],
+}
+for shape in shapes:
+    w = make(shape)
+    reads = w["n"] * w["mates"]
+    rows = {name: [] for name, _ in settings[shape]}
+    for p in range(passes):
+        for name, env in settings[shape]:
+            rows[name].append(run(w, env))
+    print("shape %s: %d fragments per launch, %d steps per measurement" % (shape, w["n"], steps))
+    for name, _ in settings[shape]:
+        ms = rows[name]
+        print("  %-16s ms/launch %s   Mreads/s %s" % (name, " ".join("%.4f" % x for x in ms),
+                                                     " ".join("%.1f" % (reads / x / 1e3) for x in ms)))
+    sys.stdout.flush()
+    w["eng"].close(); del w; torch.cuda.empty_cache()
