@@ -206,7 +206,16 @@ def measure(cx, args, *, steps, warmup, single_end=False, ont=False, hit_frac=0.
     c = [int(x) for x in counters.tolist()]
     alg_bytes_launch = (c[2] + 64 * c[3] + 16 * c[0]) / max(steps, 1)
     achieved = alg_bytes_launch / (kernel_ms * 1e-3) / 1e9 if kernel_ms > 0 else 0.0
-    variant = bool(ont or hit_frac or n_rate or capacity != args.capacity)
+    # which committed PMC record (profiles/traffic.json) belongs to this shape, if any
+    wide = capacity >= (1 << 32)
+    tkey = None
+    if not n_rate and L == 150 and abs(args.load - 0.7) < 1e-9:
+        if ont:
+            tkey = "ont"
+        elif wide:
+            tkey = "wide" if paired and not hit_frac else None
+        elif capacity == 1_431_655_765:
+            tkey = "hit" if (hit_frac == 0.5 and paired) else None if hit_frac else ("pe" if paired else "se")
     m = {
         "value": round(value, 3),
         "ms_per_step": round(elapsed_max / max(steps, 1) * 1e3, 4),
@@ -237,12 +246,12 @@ def measure(cx, args, *, steps, warmup, single_end=False, ont=False, hit_frac=0.
             "frac": round(achieved / HBM_PEAK_GBS, 4),
             # PMC counters cannot be collected inside this run (the guide wants them in separate
             # rocprofv3 passes): these two come from the committed passes on exactly this workload
-            "traffic": static_traffic(n_frag, paired, L, info.capacity, variant, "traffic_bytes_per_launch"),
-            "traffic_source": "profiles/traffic.json (static: rocprofv3 --pmc passes of this workload, "
-                              "not measured in this run)",
-            "fabric_request_frac": request_rate_frac(n_frag, paired, L, info.capacity, kernel_ms, variant),
+            "traffic": static_traffic(tkey, n_frag, "traffic_bytes_per_launch"),
+            "traffic_source": "profiles/traffic.json workloads.%s (static: rocprofv3 --pmc passes of this workload, "
+                              "not measured in this run)" % tkey,
+            "fabric_request_frac": request_rate_frac(tkey, n_frag, kernel_ms),
             # the same static traffic over THIS run's kernel time, against the 6.29 TB/s the chip reaches on a copy
-            "hbm_achievable_frac": hbm_frac(n_frag, paired, L, info.capacity, kernel_ms, variant),
+            "hbm_achievable_frac": hbm_frac(tkey, n_frag, kernel_ms),
             "kernel": "k_classify_short" if not (ont or L > 158) else "k_classify",
             "kernel_ms": round(kernel_ms, 4),
             "kernel_ms_per_rank": [round(x, 4) for x in rank_kernel_ms],
@@ -359,6 +368,8 @@ def main():
                 "fragments_per_step": vm["fragments_per_step"], "paired": vm["paired"],
                 "classified_fraction": vm["classified_fraction"], "lookups_per_read": vm["lookups_per_read"],
                 "roofline_frac": vm["roofline"]["frac"], "kernel_ms": vm["roofline"]["kernel_ms"],
+                "traffic": vm["roofline"]["traffic"], "hbm_achievable_frac": vm["roofline"]["hbm_achievable_frac"],
+                "algorithmic_bytes_per_launch": vm["roofline"]["algorithmic_bytes_per_launch"],
                 "gpu_equals_oracle_on_sample": chk["gpu_equals_oracle"], "oracle_sample_fragments": chk["fragments"],
                 "workload": vm["workload"],
             }
@@ -368,39 +379,41 @@ def main():
         dist.destroy_process_group()
 
 
-def _traffic_record(n_frag, paired, read_len, capacity, variant):
+def _traffic_record(key, n_frag):
+    """The committed rocprofv3 PMC record of a workload (profiles/traffic.json, written by scripts/profile.sh +
+    make_profile_summary.py), if it was taken on exactly this shape."""
     try:
         t = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
     except (OSError, ValueError):
-        return None
-    key = {"fragments_per_step": n_frag, "paired": paired, "read_len": read_len, "capacity": capacity}
-    if variant or t.get("workload") != key:
-        return None
-    return t
+        return None, None
+    w = t.get("workloads", {}).get(key) if key else None
+    if not w or w.get("workload", {}).get("fragments_per_step") != n_frag:
+        return None, t
+    return w, t
 
 
-def static_traffic(n_frag, paired, read_len, capacity, variant, field):
-    """HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/traffic.json), if
-    they were taken on exactly this workload; null otherwise.  bench.py cannot host the counter
-    passes itself: the guide requires them in separate profiler runs."""
-    t = _traffic_record(n_frag, paired, read_len, capacity, variant)
-    return t.get(field) if t else None
+def static_traffic(key, n_frag, field):
+    """HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/traffic.json), if they were taken
+    on exactly this workload; null otherwise.  bench.py cannot host the counter passes itself: the guide
+    requires them in separate profiler runs."""
+    w, _ = _traffic_record(key, n_frag)
+    return w.get(field) if w else None
 
 
-def request_rate_frac(n_frag, paired, read_len, capacity, kernel_ms, variant=False):
-    """Fabric read requests per second of k_classify (PMC count per launch from profiles/traffic.json over
+def request_rate_frac(key, n_frag, kernel_ms):
+    """Fabric read requests per second of the classify kernel (PMC count per launch from profiles/traffic.json over
     the kernel time measured here) as a fraction of the rate a pure random gather sustains on the chip."""
-    t = _traffic_record(n_frag, paired, read_len, capacity, variant)
-    if not t or not t.get("fabric_read_requests_per_launch") or kernel_ms <= 0:
+    w, t = _traffic_record(key, n_frag)
+    if not w or not w.get("fabric_read_requests_per_launch") or kernel_ms <= 0:
         return None
-    return round(t["fabric_read_requests_per_launch"] / (kernel_ms * 1e-3) / t["fabric_request_ceiling_per_s"], 4)
+    return round(w["fabric_read_requests_per_launch"] / (kernel_ms * 1e-3) / t["fabric_request_ceiling_per_s"], 4)
 
 
-def hbm_frac(n_frag, paired, read_len, capacity, kernel_ms, variant=False):
-    t = _traffic_record(n_frag, paired, read_len, capacity, variant)
-    if not t or not t.get("traffic_bytes_per_launch") or kernel_ms <= 0:
+def hbm_frac(key, n_frag, kernel_ms):
+    w, t = _traffic_record(key, n_frag)
+    if not w or not w.get("traffic_bytes_per_launch") or kernel_ms <= 0:
         return None
-    return round(t["traffic_bytes_per_launch"] / (kernel_ms * 1e-3) / 1e9 / t.get("hbm_achievable_gbs", 6290.0), 4)
+    return round(w["traffic_bytes_per_launch"] / (kernel_ms * 1e-3) / 1e9 / t.get("hbm_achievable_gbs", 6290.0), 4)
 
 
 def cpu_baseline(cx, args, live, budget_s):

@@ -1,11 +1,14 @@
 #!/usr/bin/env python3
-"""Turns a gpurun_out/prof_<tag>/ directory (scripts/profile.sh) into the committed summary
-profiles/<round>_summary.txt, profiles/<round>_kernel_stats.csv and profiles/traffic.json.
-    python scripts/make_profile_summary.py gpurun_out/prof_r01c r01"""
+"""Turns a gpurun_out/prof_<tag>_<workload>/ directory (scripts/profile.sh) into the committed records:
+profiles/<tag>_<workload>_summary.txt, profiles/<tag>_<workload>_kernel_stats.csv and the workload's entry of
+profiles/traffic.json (which bench.py reads for `roofline.traffic` of the headline AND of its variants).
+    python scripts/make_profile_summary.py gpurun_out/prof_r03_pe r03 pe"""
 import csv, glob, json, os, sys
 src, rnd = sys.argv[1], sys.argv[2]
-KERNEL = 'k_classify_short'  # the kernel the bench workload (150 bp pairs) runs in; the generic k_classify behind it returns at once
-LOOKUPS = 77.43e6 * 2.5  # 2.5 M pairs per launch
+wl = sys.argv[3] if len(sys.argv) > 3 else "pe"
+# the kernel the workload's fragments are classified in (the other one, launched with it, returns at once)
+KERNEL = 'k_classify<' if wl == "ont" else 'k_classify_short'
+WARMUP = 3  # launches of the trace pass before bench.py's timed region
 
 
 def mean_counter(pattern, kernel_sub, counter):
@@ -13,29 +16,57 @@ def mean_counter(pattern, kernel_sub, counter):
     for f in glob.glob(os.path.join(src, pattern)):
         for row in csv.DictReader(open(f)):
             if kernel_sub in row['Kernel_Name'] and row['Counter_Name'] == counter:
-                vals.append(float(row['Counter_Value']))
+                v = float(row['Counter_Value'])
+                if wl == "ont" and counter == 'SQ_WAVES' and v < 100:
+                    continue
+                vals.append(v)
+    # (the generic kernel is also launched as the BIG second pass and, for short reads, as the deferred pass:
+    #  those dispatches do nothing; keep the ones that did the work = the larger half by value)
+    if wl == "ont" and vals:
+        big = max(vals)
+        vals = [v for v in vals if v > 0.2 * big]
     return (sum(vals) / len(vals), len(vals)) if vals else (None, 0)
 
 
 out = []
-out.append("# profiles/%s_summary.txt -- rocprofv3 summaries of bench.py on 1 x MI355X" % rnd)
-out.append("# command: bash scripts/profile.sh <tag>   (trace pass: bench.py --no-cpu-baseline --no-e2e --no-variants, 20 + 3 launches;")
-out.append("#          PMC passes: the same with --steps 5 --warmup 2)")
+bj = None
 try:
     bj = json.loads(open(os.path.join(src, 'bench_trace.json')).read().strip().splitlines()[-1])
-    out.append("# bench.py's own line in the trace pass: value %.1f %s, ms_per_step %.4f, roofline.kernel_ms %.4f" % (
-        bj['value'], bj['unit'], bj['ms_per_step'], bj['roofline']['kernel_ms']))
 except Exception as e:
     out.append("# (bench line of the trace pass not available: %s)" % e)
-out.append("# workload: 2,500,000 fragments = 5,000,000 x 150 bp PE reads per launch, synthetic HPRC.r2-like table")
-out.append("#           1,431,655,765 cells (5.73 GB), load 0.70, k=35 l=31")
+out.append("# profiles/%s_%s_summary.txt -- rocprofv3 summaries of bench.py on 1 x MI355X, workload '%s'" % (rnd, wl, wl))
+out.append("# command: bash scripts/profile.sh %s %s   (trace pass: bench.py with its reported step count + %d warm-up launches;" % (rnd, wl, WARMUP))
+out.append("#          PMC passes: the same with --steps 5 --warmup 2, one rocprofv3 run per counter group)")
+if bj:
+    out.append("# bench.py's own line in the trace pass: value %.1f %s, ms_per_step %.4f, roofline.kernel_ms %.4f, frac %.4f" % (
+        bj['value'], bj['unit'], bj['ms_per_step'], bj['roofline']['kernel_ms'], bj['roofline']['frac']))
+    out.append("# workload: " + bj['config']['workload'])
 out.append("")
-out.append("== rocprofv3 --kernel-trace --stats (trace_kernel_stats.csv), our kernels")
+out.append("== rocprofv3 --kernel-trace --stats (trace_kernel_stats.csv), our kernels (ALL dispatches incl. %d warm-ups)" % WARMUP)
 for row in csv.reader(open(os.path.join(src, 'trace/trace_kernel_stats.csv'))):
     if row and (row[0] == 'Name' or 'nh::' in row[0]):
         out.append("  " + ", ".join(c[:70] for c in row))
+# per-dispatch durations of the classify kernel, warm-ups dropped (the stats mean includes them)
+durs = []
+for f in glob.glob(os.path.join(src, 'trace/*kernel_trace.csv')):
+    rows = [r for r in csv.DictReader(open(f)) if KERNEL in r['Kernel_Name']]
+    rows.sort(key=lambda r: int(r['Start_Timestamp']))
+    d = [(int(r['End_Timestamp']) - int(r['Start_Timestamp'])) for r in rows]
+    if wl == "ont" and d:
+        d = [x for x in d if x > 0.2 * max(d)]
+    durs = d[WARMUP:]
+steady = None
+if durs:
+    steady = sum(durs) / len(durs)
+    out.append("")
+    out.append("== %s, the %d dispatches of the timed region (warm-ups dropped): mean %.1f us, min %.1f, max %.1f" % (
+        KERNEL.rstrip('<'), len(durs), steady / 1e3, min(durs) / 1e3, max(durs) / 1e3))
+    if bj:
+        ab = bj['roofline']['algorithmic_bytes_per_launch']
+        out.append("   algorithmic bytes per launch %.4g / that mean = %.1f GB/s = %.4f of 8 TB/s (bench.py's own events: %.4f)" % (
+            ab, ab / steady, ab / steady / 8000.0, bj['roofline']['frac']))
 out.append("")
-out.append("== PMC passes (separate runs), %s, mean per launch" % KERNEL)
+out.append("== PMC passes (separate runs), %s, mean per launch" % KERNEL.rstrip('<'))
 for pat, cs in (('pmc1/*counter_collection.csv', ['SQ_WAVES', 'SQ_INSTS_VALU', 'SQ_INSTS_SALU', 'SQ_INSTS_LDS', 'SQ_INSTS_VMEM_RD', 'SQ_WAVE_CYCLES', 'SQ_WAIT_ANY', 'SQ_BUSY_CYCLES']),
                 ('pmc2/*counter_collection.csv', ['SQ_ACTIVE_INST_ANY', 'SQ_ACTIVE_INST_VALU', 'SQ_ACTIVE_INST_SCA', 'SQ_ACTIVE_INST_LDS', 'SQ_WAIT_INST_ANY', 'SQ_WAIT_INST_LDS']),
                 ('pmc3/*counter_collection.csv', ['FETCH_SIZE']),
@@ -56,34 +87,52 @@ if cf is not None:
     out.append("== FETCH_SIZE calibration on a known pattern (tools/gather_bench under rocprofv3, same run)")
     out.append("  k_gather_mode<0>: %d random 16-byte probes per launch -> TCC_EA0_RDREQ_sum %.6g (%.3f per probe)," % (probes, cr, cr / probes))
     out.append("  FETCH_SIZE %.6g KB (%.1f B per probe): on a random gather FETCH_SIZE = 64 B x fabric read requests," % (cf, cf * 1024 / probes))
-    out.append("  one request per missing line.  The chip sustains ~52e9 such requests/s whatever the cache policy bits")
-    out.append("  (profiles/%s_gather_bench.txt)." % rnd)
-out.append("")
-out.append("== derived, per launch")
-out.append("  lookups D                   %.4g   (38.7 per read)" % LOOKUPS)
-out.append("  fabric read requests        %.4g   (%.2f per lookup, incl. ~1.2e7 for the streamed bases)" % (rq, rq / LOOKUPS))
-out.append("  FETCH_SIZE as counted       %.4g bytes ; WRITE_SIZE %.4g bytes" % (fs * 1024, ws * 1024))
-out.append("  HBM bytes (128 B/request)   %.4g   = 2 x FETCH_SIZE + WRITE_SIZE (every fabric read is a 128-byte request: r02_mem_study.txt)" % (2 * fs * 1024 + ws * 1024))
-out.append("  algorithmic bytes           1.318e10  (sum len + 64*D + 16 per fragment, BASELINE.md section 4)")
+    out.append("  one request per missing line.")
+entry = None
+if fs is not None and ws is not None and rq is not None and bj:
+    frags = bj['config']['fragments_per_step']
+    mates = 2 if bj['config']['paired'] else 1
+    lookups = bj['config']['lookups_per_read'] * frags * mates
+    traffic = 2 * fs * 1024 + ws * 1024
+    ab = bj['roofline']['algorithmic_bytes_per_launch']
+    out.append("")
+    out.append("== derived, per launch")
+    out.append("  lookups D                   %.4g   (%.1f per read)" % (lookups, bj['config']['lookups_per_read']))
+    out.append("  fabric read requests        %.4g   (%.2f per lookup, incl. the streamed bases)" % (rq, rq / lookups))
+    out.append("  FETCH_SIZE as counted       %.4g bytes ; WRITE_SIZE %.4g bytes" % (fs * 1024, ws * 1024))
+    out.append("  HBM bytes (128 B/request)   %.4g   = 2 x FETCH_SIZE + WRITE_SIZE (every fabric read is a 128-byte request: r02_mem_study.txt)" % traffic)
+    out.append("  algorithmic bytes           %.4g   (sum len + 64*D + 16 per fragment, BASELINE.md section 4): traffic / algorithmic = %.2f" % (ab, traffic / ab))
+    if steady:
+        out.append("  HBM bytes / steady kernel time = %.0f GB/s = %.3f of the 6290 GB/s a copy reaches" % (traffic / steady, traffic / steady / 6290.0))
+    entry = {
+        "workload": {"fragments_per_step": frags, "paired": bj['config']['paired'], "what": bj['config']['workload']},
+        "source": "profiles/%s_%s_summary.txt (rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE / TCC_EA0_RDREQ, separate passes, %s mean per launch)" % (rnd, wl, KERNEL.rstrip('<')),
+        "fetch_size_kb": fs, "write_size_kb": ws,
+        "traffic_bytes_per_launch": int(traffic),
+        "fetch_size_as_counted_bytes": int(fs * 1024),
+        "fabric_read_requests_per_launch": int(rq),
+        "algorithmic_bytes_per_launch": int(ab),
+        "kernel_us_steady_rocprof": (steady / 1e3) if steady else None,
+    }
 os.makedirs('profiles', exist_ok=True)
-open('profiles/%s_summary.txt' % rnd, 'w').write("\n".join(out) + "\n")
-with open('profiles/%s_kernel_stats.csv' % rnd, 'w') as g:
+open('profiles/%s_%s_summary.txt' % (rnd, wl), 'w').write("\n".join(out) + "\n")
+with open('profiles/%s_%s_kernel_stats.csv' % (rnd, wl), 'w') as g:
     for row in csv.reader(open(os.path.join(src, 'trace/trace_kernel_stats.csv'))):
         g.write(",".join('"%s"' % c[:120] for c in row) + "\n")
-json.dump({"workload": {"fragments_per_step": 2500000, "paired": True, "read_len": 150, "capacity": 1431655765},
-           "source": "profiles/%s_summary.txt (rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE, separate passes, k_classify_short mean per launch)" % rnd,
-           "fetch_size_kb": fs, "write_size_kb": ws,
-           "note": "HBM bytes = 2 x FETCH_SIZE + WRITE_SIZE: the guide's gfx950 correction (FETCH_SIZE tallies 128-byte requests "
-                   "at 64 B), confirmed for THIS access pattern by profiles/r02_mem_study.txt: TCC_EA0_RDREQ_128B_sum == "
-                   "TCC_EA0_RDREQ_sum, every fabric read of the kernel (and of the random-gather microbenchmark) is a "
-                   "128-byte request",
-           "traffic_bytes_per_launch": int(2 * fs * 1024 + ws * 1024),
-           "fetch_size_as_counted_bytes": int(fs * 1024),
-           "fabric_read_requests_per_launch": int(rq),
-           "fabric_request_ceiling_per_s": 50e9,
-           "hbm_achievable_gbs": 6290.0,
-           "ceiling_source": "tools/gather_bench (profiles/%s_gather_bench.txt): a pure random gather sustains ~50e9 "
-                             "128-byte fabric reads/s = 6.4 TB/s, the HBM bandwidth the chip reaches on a copy "
-                             "(6.29 TB/s, MI355X_MICROARCH.md)" % rnd},
-          open('profiles/traffic.json', 'w'), indent=1)
+if entry:
+    path = 'profiles/traffic.json'
+    try:
+        t = json.load(open(path))
+    except (OSError, ValueError):
+        t = {}
+    if "workloads" not in t:
+        t = {"note": "HBM bytes = 2 x FETCH_SIZE + WRITE_SIZE: the guide's gfx950 correction (FETCH_SIZE tallies 128-byte requests "
+                     "at 64 B), confirmed for THIS access pattern by profiles/r02_mem_study.txt: TCC_EA0_RDREQ_128B_sum == "
+                     "TCC_EA0_RDREQ_sum, every fabric read of the kernel (and of the random-gather microbenchmark) is a 128-byte request",
+             "fabric_request_ceiling_per_s": 50e9, "hbm_achievable_gbs": 6290.0,
+             "ceiling_source": "tools/gather_bench (profiles/r02_gather_bench.txt): a pure random gather sustains ~50e9 128-byte fabric "
+                               "reads/s = 6.4 TB/s, the HBM bandwidth the chip reaches on a copy (6.29 TB/s, MI355X_MICROARCH.md)",
+             "workloads": {}}
+    t["workloads"][wl] = entry
+    json.dump(t, open(path, 'w'), indent=1)
 print("\n".join(out))
