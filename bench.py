@@ -88,15 +88,13 @@ def launch_ranks(args):
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
                                       stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
     out0, _ = procs[0].communicate()
-    rc = procs[0].returncode
-    for p in procs[1:]:
-        p.wait()
-        rc = rc or p.returncode
+    codes = [procs[0].returncode] + [p.wait() for p in procs[1:]]
     sys.stdout.write(out0.decode(errors="replace"))
     sys.stdout.flush()
-    if rc:
-        sys.stderr.write("bench.py: a rank exited with status %d (%d GPUs requested)\n" % (rc, args.gpus))
-    return 1 if rc else 0
+    bad = [(r, c) for r, c in enumerate(codes) if c]
+    for r, c in bad:  # (every rank's stderr went to this process's stderr as it was written)
+        sys.stderr.write("bench.py: rank %d of %d exited with status %d\n" % (r, args.gpus, c))
+    return 1 if bad else 0
 
 
 class Ctx:
@@ -329,7 +327,9 @@ def main():
             "paired": m["paired"],
             "parallelism": "reads sharded over %d GPU(s), DB replicated" % cx.world,
             "world_size_seen": dist.get_world_size() if cx.world > 1 else 1,
-            "collective_backend": ("%s (RCCL)" % backend) if backend else "none (single process)",
+            "collective_backend": ("%s (RCCL %s)" % (backend, ".".join(map(str, torch.cuda.nccl.version()))))
+                                  if backend else "none (single process)",
+            "ranks": rank_table(cx, m["roofline"]["kernel_ms"]),
             "classified_fraction": m["classified_fraction"],
             "lookups_per_read": m["lookups_per_read"],
             "db_build_seconds": m["db_build_seconds"],
@@ -358,13 +358,13 @@ def main():
                          ("ont_config3_scaled", dict(ont=True, pairs=200_000)),
                          # a table of more than 2^32 cells (64-bit cell positions in the kernels): 17.6 GB, four copies
                          ("wide_table_4.4G_cells_PE", dict(pairs=1_000_000, capacity=4_400_000_011))):
-            vm, vlive = measure(cx, args, steps=6, warmup=2, keep=True, **kw)
+            vm, vlive = measure(cx, args, steps=12, warmup=3, keep=True, **kw)
             chk = cpu_baseline(cx, args, vlive, 1.5)
             vlive["eng"].close()
             del vlive
             torch.cuda.empty_cache()
             out["variants"][name] = {
-                "value": vm["value"], "unit": "Mreads/s", "steps": 6, "warmup": 2,
+                "value": vm["value"], "unit": "Mreads/s", "steps": 12, "warmup": 3,
                 "fragments_per_step": vm["fragments_per_step"], "paired": vm["paired"],
                 "classified_fraction": vm["classified_fraction"], "lookups_per_read": vm["lookups_per_read"],
                 "roofline_frac": vm["roofline"]["frac"], "kernel_ms": vm["roofline"]["kernel_ms"],
@@ -377,6 +377,19 @@ def main():
         print(json.dumps(out), flush=True)
     if cx.world > 1:
         dist.destroy_process_group()
+
+
+def rank_table(cx, kernel_ms):
+    """One entry per rank, in rank order: device name, kernel time of the rank's launches, host."""
+    import socket
+    torch, dist = cx.torch, cx.dist
+    mine = {"rank": cx.rank, "device": torch.cuda.get_device_name(cx.dev), "kernel_ms": kernel_ms,
+            "host": socket.gethostname()}
+    if cx.world == 1:
+        return [mine]
+    rows = [None] * cx.world
+    dist.all_gather_object(rows, mine)
+    return rows
 
 
 def _traffic_record(key, n_frag):

@@ -43,11 +43,10 @@ struct Result {
     uint32_t call, total_kmers, clade_hits, hit_groups;
 };
 
-// How the fragments of a launch are handed out: claim i of the launch's work counter is a chunk of c0
-// fragments while i < n0, of c1 while i < n01, of c2 up to `total` (a fixed map: a claim index is also the
-// chunk's bit in KArgs::defer_bits).  By default n0 == total: the guided tail (smaller chunks for the waves
-// that finish early) is a tuning knob that measured slower than flat chunks once the claims themselves were
-// fixed (make_sched in nh_kernels.hip, profiles/r03_sched.txt).
+// How the fragments of a launch are handed out: claim i of the launch's work counters is a chunk of c0
+// fragments while i < n0 (the body), of c1 while i < n01, of c2 up to `total` (the guided tail: smaller chunks
+// for the waves that finish early; a fixed map, a claim index is also the chunk's bit in KArgs::defer_bits).
+// make_sched in nh_kernels.hip says what it is worth; n0 == total is the flat map (NOHUMAN_SCHED=off).
 struct Sched {
     uint64_t n0, n01, total;  // claims in chunks of c0 / up to here in chunks of c1 / all claims
     uint64_t base1, base2;    // first fragment of the c1 chunks, of the c2 chunks
@@ -61,17 +60,17 @@ struct Sched {
 // came from (a wave's last chunk took 100+ us longer than any other).  Now the waves add to one of
 // COUNTER_SHARDS rows (by workgroup), each in a line of its own, and a one-wave kernel behind the launch folds
 // the rows into the caller's counters: the fixed cost of a launch fell from 0.30 to 0.13 ms.
-// The WORK counter can be sharded the same way (WORK_SHARDS words, one per XCD, claims beyond the static
-// first ones split into equal shares, a wave draws from its XCD's share and moves on to the next XCD's when
-// that is empty): measured, 8 shards take another 15 us off the fixed cost and ADD 3 % to the per-read cost
-// (launches of 1 M reads and more are slower: 4.93 against 4.85 ms for 2.5 M pairs) -- ~27 claims per
-// microsecond in steady state are no problem for one word.  One shard is the default; the mechanism stays
-// as a build knob (-DNH_WORK_SHARDS=8).
-#ifndef NH_WORK_SHARDS
-#define NH_WORK_SHARDS 1
-#endif
-constexpr uint32_t WORK_SHARDS = NH_WORK_SHARDS;  // a power of two
-constexpr uint32_t WORK_STRIDE = 16;      // uint64 words from one shard's counter to the next (128 bytes)
+// The WORK counter: one word hands out the claims of the launch's BODY (chunks of c0; ~27 claims per
+// microsecond in steady state are no problem for one word, and one word balances the XCDs, which differ by
+// ~8 % in speed).  Sharding it per XCD for the whole launch was tried and is slower (+3 % per read: the faster
+// XCDs run out of their share early and every later claim of theirs starts with a failed atomic).  The claims
+// of a guided TAIL (Sched: chunks of c1, c2 < c0, NOHUMAN_SCHED) come four times as often in the launch's last
+// moments -- more than one word retires -- so they are dealt from TAIL_SHARDS words: tail claim j belongs to
+// shard j mod TAIL_SHARDS, a wave draws from its XCD's shard and moves on to the next when that is empty.
+constexpr uint32_t TAIL_SHARDS = 8;                 // a power of two
+constexpr uint32_t WORK_WORDS = 1 + TAIL_SHARDS;    // counters of a launch: body, then the tail shards
+constexpr uint32_t WORK_STRIDE = 16;                // uint64 words from one counter to the next (128 bytes)
+constexpr uint32_t WORK_PASSES = 3;                 // short-read / first pass, deferred pass, BIG pass: a set of counters each
 constexpr uint32_t COUNTER_SHARDS = 64;
 constexpr uint32_t COUNTER_STRIDE = 16;   // uint64 words per row (128 bytes; four are used)
 
@@ -161,7 +160,7 @@ struct LaunchSlot {
     int *d_error = nullptr;             // sticky error bits of the engine
     int *d_pending = nullptr;           // fragments were left to the BIG variant
     int *d_pending_long = nullptr;      // chunks were left to the generic kernel
-    unsigned long long *d_work = nullptr;    // WORK_SHARDS counters, WORK_STRIDE words apart
+    unsigned long long *d_work = nullptr;    // WORK_PASSES x WORK_WORDS counters, WORK_STRIDE words apart
     unsigned long long *d_cshard = nullptr;  // COUNTER_SHARDS rows of COUNTER_STRIDE words
     uint32_t *d_defer = nullptr;        // one bit per chunk
     uint64_t defer_cap_bits = 0;

@@ -208,7 +208,9 @@ static int common_open(Engine *e, int device) {
     HIP_TRY(hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking));
     HIP_TRY(hipMalloc((void **)&e->d_counters, (CNT_N + 12) * sizeof(uint64_t)));
     HIP_TRY(hipMemset(e->d_counters, 0, (CNT_N + 12) * sizeof(uint64_t)));
-    HIP_TRY(hipMalloc((void **)&e->d_work, LAUNCH_SLOTS * WORK_SHARDS * WORK_STRIDE * sizeof(unsigned long long)));
+    // launch slots start CLEAN and every launch leaves its slot clean again (k_finish_launch)
+    HIP_TRY(hipMalloc((void **)&e->d_work, LAUNCH_SLOTS * WORK_PASSES * WORK_WORDS * WORK_STRIDE * sizeof(unsigned long long)));
+    HIP_TRY(hipMemset(e->d_work, 0, LAUNCH_SLOTS * WORK_PASSES * WORK_WORDS * WORK_STRIDE * sizeof(unsigned long long)));
     HIP_TRY(hipMalloc((void **)&e->d_cshard, LAUNCH_SLOTS * COUNTER_SHARDS * COUNTER_STRIDE * sizeof(unsigned long long)));
     HIP_TRY(hipMemset(e->d_cshard, 0, LAUNCH_SLOTS * COUNTER_SHARDS * COUNTER_STRIDE * sizeof(unsigned long long)));
     // [0, LAUNCH_SLOTS) "fragments left to the BIG variant" per launch slot, then the sticky error bits,
@@ -216,6 +218,7 @@ static int common_open(Engine *e, int device) {
     HIP_TRY(hipMalloc((void **)&e->d_error, (2 * LAUNCH_SLOTS + 1) * sizeof(int)));
     HIP_TRY(hipMemset(e->d_error, 0, (2 * LAUNCH_SLOTS + 1) * sizeof(int)));
     HIP_TRY(hipMalloc((void **)&e->d_defer, LAUNCH_SLOTS * DEFER_WORDS * sizeof(uint32_t)));
+    HIP_TRY(hipMemset(e->d_defer, 0, LAUNCH_SLOTS * DEFER_WORDS * sizeof(uint32_t)));
     return NH_OK;
 }
 
@@ -577,6 +580,15 @@ static int ensure_split(Engine *e, unsigned slot, uint64_t n_frag) {
         sb = SplitBufs{};
         return NH_OK;  // no buffers: the launch goes by whole reads (slower tail, same results)
     }
+    // the header starts cleared (later launches find it cleared by k_finish_launch).  hipMemset is only ordered
+    // with the legacy stream; the launch that follows runs on a non-blocking stream: wait for it here
+    if (hipMemset(sb.hdr, 0, sizeof(SplitHdr)) != hipSuccess || hipDeviceSynchronize() != hipSuccess) {
+        (void)hipGetLastError();
+        for (void *p : {(void *)sb.hdr, (void *)sb.items_multi, (void *)sb.items_single, (void *)sb.part, (void *)sb.part_done})
+            if (p) (void)hipFree(p);
+        sb = SplitBufs{};
+        return NH_OK;
+    }
     sb.seg_cap = (uint32_t)want_seg;
     e->split_single_cap[slot] = nsingle;
     return NH_OK;
@@ -614,7 +626,7 @@ int classify_device(Engine *e, const void *d_bases, const void *d_seq_off, uint6
     sl.d_error = e->d_error + LAUNCH_SLOTS;
     sl.d_pending = e->d_error + slot;
     sl.d_pending_long = e->d_error + LAUNCH_SLOTS + 1 + slot;
-    sl.d_work = e->d_work + (size_t)slot * WORK_SHARDS * WORK_STRIDE;
+    sl.d_work = e->d_work + (size_t)slot * WORK_PASSES * WORK_WORDS * WORK_STRIDE;
     sl.d_cshard = e->d_cshard + (size_t)slot * COUNTER_SHARDS * COUNTER_STRIDE;
     sl.d_defer = e->d_defer + (size_t)slot * DEFER_WORDS;
     sl.defer_cap_bits = DEFER_WORDS * 32;
@@ -905,6 +917,7 @@ int nh_stats_reset(nh_engine *e_) {
     std::lock_guard<std::mutex> lock(e->mu);
     HIP_TRY(hipSetDevice(e->device));
     HIP_TRY(hipMemset(e->d_counters, 0, (nh::CNT_N + 12) * sizeof(uint64_t)));
+    HIP_TRY(hipDeviceSynchronize());  // (launches run on non-blocking streams, which a legacy-stream memset does not order)
     e->seconds = 0;
     return NH_OK;
 }

@@ -39,7 +39,7 @@ struct Engine {
     uint32_t *d_parent = nullptr;
     uint64_t *d_counters = nullptr;
     int *d_error = nullptr;
-    unsigned long long *d_work = nullptr;  // work counters of k_classify: WORK_SHARDS per launch slot (nh_device.h)
+    unsigned long long *d_work = nullptr;  // work counters of k_classify: WORK_WORDS per launch slot (nh_device.h)
     unsigned long long *d_cshard = nullptr; // counter rows the waves of a launch add to, COUNTER_SHARDS per launch slot
     uint32_t *d_defer = nullptr;           // per launch slot DEFER_WORDS words: chunks the short-read kernel left behind
     // long-read item buffers per launch slot (SplitBufs, nh_device.h), allocated when a slot first carries a

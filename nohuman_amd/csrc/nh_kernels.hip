@@ -1093,30 +1093,40 @@ __device__ __forceinline__ bool claim_range(KArgsP ap, const uint64_t i, const u
 __device__ __forceinline__ uint32_t xcc_id() {
     uint32_t x;
     asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(x));
-    return x & (WORK_SHARDS - 1);
+    return x & (TAIL_SHARDS - 1);
 }
 
-// Claims beyond the static first ones (one per wave of the grid) come from WORK_SHARDS counters (nh_device.h):
-// shard x hands out n_static + x * share + [0, share).  draw_raw() bumps the counter of the shard the wave
-// currently draws from (lane 0; the value may be looked at much later); settle() turns it into a claim
-// index, moving on to the next shards when this one is used up -- ~0 when all are.
+// Claims beyond the static first ones (one per wave of the grid) come from the work counters (nh_device.h):
+// word 0 deals the body, n_static + [0, ...) up to the first tail claim; words 1 .. TAIL_SHARDS deal the tail,
+// claim tail0 + shard + TAIL_SHARDS * c.  draw_raw() bumps the counter the wave currently draws from (lane 0; the
+// value may be looked at much later); settle() turns it into a claim index -- moving from the body to the wave's
+// own tail shard, then on to the next shards as they run empty -- or ~0 when everything is handed out.
 struct Draw {
     unsigned long long raw;  // lane 0: what the atomic returned
-    uint32_t shard;          // wave-uniform: the shard `raw` came from
+    uint32_t word;           // wave-uniform: 0 = body, 1 + shard = a tail shard
 };
 __device__ __forceinline__ void draw_raw(KArgsP ap, const int lane, Draw &d) {
-    if (lane == 0) d.raw = atomicAdd(launder(ap)->work + (size_t)d.shard * WORK_STRIDE, 1ull);
+    if (lane == 0) d.raw = atomicAdd(launder(ap)->work + (size_t)d.word * WORK_STRIDE, 1ull);
 }
-__device__ __forceinline__ uint64_t settle(KArgsP ap, const int lane, Draw &d, const uint64_t total_claims) {
+// tail0 = index of the first tail claim (= total_claims when the launch has no guided tail)
+__device__ __forceinline__ uint64_t settle(KArgsP ap, const int lane, Draw &d, const uint64_t tail0,
+                                           const uint64_t total_claims) {
     const uint64_t n_static = (uint64_t)gridDim.x * WAVES_PER_BLOCK;
-    const uint64_t dyn = total_claims > n_static ? total_claims - n_static : 0;
-    const uint64_t share = (dyn + WORK_SHARDS - 1) / WORK_SHARDS;
-    for (uint32_t tries = 0;; tries++) {
+    const uint64_t t0 = tail0 > n_static ? tail0 : n_static;  // (static claims may reach into the tail of a small launch)
+    uint32_t tried = 0;
+    for (;;) {
         const uint64_t c = readlane64(d.raw, 0);
-        const uint64_t claim = n_static + (uint64_t)d.shard * share + c;
-        if (c < share && claim < total_claims) return claim;
-        if (tries == WORK_SHARDS - 1) return ~0ull;
-        d.shard = (d.shard + 1) & (WORK_SHARDS - 1);
+        if (d.word == 0) {
+            const uint64_t claim = n_static + c;
+            if (claim < t0) return claim;
+            if (t0 >= total_claims) return ~0ull;
+            d.word = 1 + xcc_id();  // the body is handed out: on to the tail, own shard first
+        } else {
+            const uint64_t claim = t0 + (d.word - 1) + (uint64_t)TAIL_SHARDS * c;
+            if (claim < total_claims) return claim;
+            if (++tried == TAIL_SHARDS) return ~0ull;
+            d.word = 1 + (d.word & (TAIL_SHARDS - 1));  // next shard (1 + ((word - 1 + 1) mod TAIL_SHARDS))
+        }
         draw_raw(ap, lane, d);
     }
 }
@@ -1389,16 +1399,18 @@ __global__ __launch_bounds__(WAVE * WAVES_PER_BLOCK, BIG ? 1 : (STD ? NH_MIN_WAV
     // says why)
     Draw dr;
     dr.raw = 0;
-    dr.shard = xcc_id();
+    dr.word = 0;
     bool first_claim = true;
     auto take_claim = [&]() { draw_raw(ap, lane, dr); };
     // claims there are in all: items of a long-read launch (known on the device only), else the claim map
     uint64_t total_claims = launder(ap)->sched.total;
+    uint64_t tail0 = launder(ap)->sched.n0;  // (first claim of a guided tail; == total without one)
     if (items) {
         KArgsP a5 = launder(ap);
         const SplitHdr *const hdr = a5->split.hdr;
         const uint32_t used = hdr->seg_used;
         total_claims = (uint64_t)(used < a5->split.seg_cap ? used : a5->split.seg_cap) + hdr->n_mid + hdr->n_small;
+        tail0 = total_claims;
     }
     for (;;) {
         uint64_t claim;
@@ -1407,7 +1419,7 @@ __global__ __launch_bounds__(WAVE * WAVES_PER_BLOCK, BIG ? 1 : (STD ? NH_MIN_WAV
             first_claim = false;
             if (claim >= total_claims) claim = ~0ull;
         } else {
-            claim = settle(ap, lane, dr, total_claims);
+            claim = settle(ap, lane, dr, tail0, total_claims);
         }
         if (claim == ~0ull) break;
         uint64_t cbeg;
@@ -1696,11 +1708,10 @@ __global__ __launch_bounds__(WAVE * WAVES_PER_BLOCK, PROF ? 4 : NH_MIN_WAVES) vo
     // taken when the LAST batch of the current chunk has been encoded: early enough to be back when the chunk
     // ends, and late enough that the chunk it reserves is started soon (a claim taken a whole chunk ahead made
     // the launch end two chunks after the counter ran out, profiles/r03_timeline.txt).
-    // ... and the later ones come from the counter of the wave's XCD first (Draw, nh_device.h: one hot word
-    // for all 5120 waves was a bottleneck of its own).
+    // ... and the later ones come from the work counters (Draw above).
     Draw dr;
     dr.raw = 0;
-    dr.shard = xcc_id();
+    dr.word = 0;
     bool first_claim = true;
     bool claim_ahead = true;  // a claim has been taken that has not been looked at yet
     auto take_claim = [&]() {
@@ -1726,7 +1737,7 @@ __global__ __launch_bounds__(WAVE * WAVES_PER_BLOCK, PROF ? 4 : NH_MIN_WAVES) vo
                 claim = (uint64_t)blockIdx.x * WAVES_PER_BLOCK + (uint32_t)wib;
                 first_claim = false;
             } else if (drain == 0) {
-                claim = settle(ap, lane, dr, launder(ap)->sched.total);
+                claim = settle(ap, lane, dr, launder(ap)->sched.n0, launder(ap)->sched.total);
             }
             uint64_t c0 = 0;
             uint32_t ncf = 0;
@@ -1897,24 +1908,41 @@ __global__ __launch_bounds__(WAVE * WAVES_PER_BLOCK, PROF ? 4 : NH_MIN_WAVES) vo
     }
 }
 
-// Folds the COUNTER_SHARDS rows the waves of a launch added to into the caller's four counters, and clears
-// the rows for the slot's next launch.  One wave.
-__global__ __launch_bounds__(64) void k_fold_counters(unsigned long long *cshard, unsigned long long *counters) {
+// Behind every launch, one wave: folds the COUNTER_SHARDS rows the waves added to into the caller's four
+// counters, and leaves the launch slot CLEAN for its next launch -- counter rows, the work counters of the
+// three passes, the deferral bitmap words that were used, the "chunks / fragments left" words, the item
+// header of a long-read launch.  (Round 2 cleared these with four hipMemsetAsync calls per launch, each a
+// dependent dispatch of its own: ~20 us of a 1.1 ms launch of 1 M reads.)
+struct FinishArgs {
+    unsigned long long *cshard, *counters, *work;
+    uint32_t *defer;
+    uint32_t n_defer_words;
+    int *pending_long, *pending;
+    SplitHdr *split_hdr;
+};
+__global__ __launch_bounds__(64) void k_finish_launch(const FinishArgs a) {
     const int lane = threadIdx.x;
     unsigned long long v[4];
 #pragma unroll
     for (int i = 0; i < 4; i++) {
         unsigned long long x = 0;
         for (uint32_t r = lane; r < COUNTER_SHARDS; r += 64) {
-            x += cshard[(size_t)r * COUNTER_STRIDE + i];
-            cshard[(size_t)r * COUNTER_STRIDE + i] = 0;
+            x += a.cshard[(size_t)r * COUNTER_STRIDE + i];
+            a.cshard[(size_t)r * COUNTER_STRIDE + i] = 0;
         }
         for (int d = 32; d >= 1; d >>= 1) x += __shfl_xor(x, d, 64);
         v[i] = x;
     }
-    if (lane == 0 && counters)
+    if (lane == 0 && a.counters)
         for (int i = 0; i < 4; i++)
-            if (v[i]) atomicAdd(&counters[i], v[i]);
+            if (v[i]) atomicAdd(&a.counters[i], v[i]);
+    if ((uint32_t)lane < WORK_PASSES * WORK_WORDS) a.work[(size_t)lane * WORK_STRIDE] = 0;
+    for (uint32_t w = lane; w < a.n_defer_words; w += 64) a.defer[w] = 0;
+    if (lane == 0) {
+        *a.pending_long = 0;
+        *a.pending = 0;
+        if (a.split_hdr) *a.split_hdr = SplitHdr{0, 0, 0, 0};
+    }
 }
 
 // ---- long-read prepass: the launch's work items (SplitBufs, nh_device.h) -----------------------------------
@@ -2106,30 +2134,31 @@ static void launch_variant(const KArgs &ka, dim3 g, dim3 b, hipStream_t stream, 
         // second pass for fragments with more than 64 distinct taxa: exits at once if there are none
         KArgs kb = ka;
         kb.only_deferred = 0;
-        (void)hipMemsetAsync(d_work, 0, WORK_SHARDS * WORK_STRIDE * sizeof(unsigned long long), stream);
+        kb.work = d_work + 2 * (size_t)WORK_WORDS * WORK_STRIDE;  // the third pass has work counters of its own
         hipLaunchKernelGGL((k_classify<LINEAR, STD, CAP32, false, true>), g, b, 0, stream, kb);
-        (void)hipMemsetAsync(ka.pending, 0, sizeof(int), stream);
     }
 }
 
-// The claim map of a launch (Sched, nh_device.h).  Default: everything in chunks of c0 -- measured
-// (profiles/r03_sched.txt): with the first claim static and the claim ahead taken late, a launch already
-// ends within ~1.3 chunks of the counter running out, and smaller chunks at the tail cost more at their
-// starts (two dependent loads with nothing else of the wave in flight) than they level out: 1 M single
-// reads 1.147 ms flat against 1.236 ms with a c0 / 2, then 2-batch tail.  NOHUMAN_SCHED=c1,c2,p1,p2 turns
-// the guided map on: chunks of c1 for p1 percent of half a c0-chunk per resident wave, then chunks of c2
-// for p2 percent of half a c1-chunk per wave (tuning knob, tools/sweep_sched.py).
+// The claim map of a launch (Sched, nh_device.h): chunks of c0 fragments for the body; then, for about half a
+// c0-chunk of every resident wave, chunks of c1 = c0 / 2; then, for half a c1-chunk per wave, chunks of c2 =
+// three batches of four tiles -- the waves that finish early fill up on the small ones and the launch ends
+// within ~80 us instead of ~200 (profiles/r03_sched.txt).  It pays little (1 M single reads 1.124 -> 1.107 ms,
+// 2.5 M pairs 4.884 -> 4.858): while the tail of a flat map has idle waves, the others run faster, the kernel
+// being memory-bound.  And it only pays since (a) the waves' counters go to rows of their own -- before, the
+// end of a launch was an atomic storm that no claim map could see through -- and (b) the tail's claims come
+// from TAIL_SHARDS counters: four times the claim rate in the last moments is more than one word retires.
+// NOHUMAN_SCHED=off: flat; NOHUMAN_SCHED=c1,c2,p1,p2: sizes and tail lengths in percent (tuning knob).
 Sched make_sched(uint64_t n_frag, uint32_t c0, int mates, uint64_t waves) {
     Sched sc;
     memset(&sc, 0, sizeof sc);
     if (c0 == 0) c0 = 1;
     const uint32_t step = mates == 2 ? 2u : 4u;  // one batch of four tiles
-    uint32_t c1 = c0 / 2 / step * step, c2 = 2 * step;
+    uint32_t c1 = c0 / 2 / step * step, c2 = 3 * step;
     uint64_t p1 = 100, p2 = 100;
-    bool guided = false;
+    bool guided = c0 >= 4 * step;
     if (const char *env = getenv("NOHUMAN_SCHED")) {
         unsigned a = 0, b = 0, c = 0, d = 0;
-        if (strcmp(env, "guided") == 0) guided = c0 >= 4 * step;
+        if (strcmp(env, "off") == 0) guided = false;
         else if (sscanf(env, "%u,%u,%u,%u", &a, &b, &c, &d) == 4 && a >= 1 && b >= 1) {
             guided = true;
             c1 = a;
@@ -2165,8 +2194,7 @@ hipError_t launch_classify(const DevDB &db, const LaunchIO &io, double confidenc
     const uint64_t n_frag = io.n_frag;
     if (n_frag == 0) return hipSuccess;
     if (frag_chunk == 0) frag_chunk = 1;
-    hipError_t me = hipMemsetAsync(sl.d_work, 0, WORK_SHARDS * WORK_STRIDE * sizeof(unsigned long long), stream);
-    if (me != hipSuccess) return me;
+    // (the launch slot is clean: its previous launch's k_finish_launch, or the engine's start, left it so)
     const Sched sched = make_sched(n_frag, frag_chunk, io.mates, (uint64_t)grid_blocks * WAVES_PER_BLOCK);
     uint64_t need = (sched.total + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK;
     int grid = (int)(need < (uint64_t)grid_blocks ? need : (uint64_t)grid_blocks);
@@ -2202,7 +2230,6 @@ hipError_t launch_classify(const DevDB &db, const LaunchIO &io, double confidenc
                            n_frag <= sl.split_single_cap && n_frag < 0xFFFFFFFFull;
     if (use_items) {
         ka.split = sl.split;
-        (void)hipMemsetAsync(sl.split.hdr, 0, sizeof(SplitHdr), stream);
         hipLaunchKernelGGL(k_prep_items, dim3((unsigned)((n_frag + 255) / 256)), dim3(256), 0, stream, ka);
         g = dim3(grid_blocks);  // (the number of items is only known on the device)
     }
@@ -2219,8 +2246,9 @@ hipError_t launch_classify(const DevDB &db, const LaunchIO &io, double confidenc
     // marks the others for the generic kernel launched right behind it (which returns at once when
     // nothing was marked).  Skipped when the caller says the reads are long.
     const uint64_t n_chunks = sched.total;
+    uint32_t n_defer_words = 0;
     if (hot && !io.long_reads && !no_short && n_chunks <= sl.defer_cap_bits) {
-        (void)hipMemsetAsync(sl.d_defer, 0, (size_t)((n_chunks + 31) / 32) * 4, stream);
+        n_defer_words = (uint32_t)((n_chunks + 31) / 32);
         if (phase_prof && cap32)
             hipLaunchKernelGGL((k_classify_short<true, false>), g, b, 0, stream, ka);
         else if (cap32)
@@ -2228,7 +2256,7 @@ hipError_t launch_classify(const DevDB &db, const LaunchIO &io, double confidenc
         else
             hipLaunchKernelGGL((k_classify_short<false, true>), g, b, 0, stream, ka);
         ka.only_deferred = 1;
-        (void)hipMemsetAsync(sl.d_work, 0, WORK_SHARDS * WORK_STRIDE * sizeof(unsigned long long), stream);
+        ka.work = sl.d_work + (size_t)WORK_WORDS * WORK_STRIDE;  // the second pass has work counters of its own
     }
     if (hot && cap32 && phase_prof)
         launch_variant<true, true, true, true>(ka, g, b, stream, may_overflow, sl.d_work);  // d_counters: CNT_N + 12 words
@@ -2240,8 +2268,16 @@ hipError_t launch_classify(const DevDB &db, const LaunchIO &io, double confidenc
         launch_variant<true, false, false>(ka, g, b, stream, may_overflow, sl.d_work);
     else
         launch_variant<false, false, false>(ka, g, b, stream, may_overflow, sl.d_work);
-    if (ka.only_deferred) (void)hipMemsetAsync(sl.d_pending_long, 0, sizeof(int), stream);
-    hipLaunchKernelGGL(k_fold_counters, dim3(1), dim3(64), 0, stream, sl.d_cshard, (unsigned long long *)io.d_counters);
+    FinishArgs fa;
+    fa.cshard = sl.d_cshard;
+    fa.counters = (unsigned long long *)io.d_counters;
+    fa.work = sl.d_work;
+    fa.defer = sl.d_defer;
+    fa.n_defer_words = n_defer_words;
+    fa.pending_long = sl.d_pending_long;
+    fa.pending = sl.d_pending;
+    fa.split_hdr = use_items ? sl.split.hdr : nullptr;
+    hipLaunchKernelGGL(k_finish_launch, dim3(1), dim3(64), 0, stream, fa);
     return hipGetLastError();
 }
 

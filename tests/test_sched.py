@@ -1,4 +1,4 @@
-"""The claim map of a launch (nh_device.h Sched; flat by default, guided self-scheduling as a tuning knob):
+"""The claim map of a launch (nh_device.h Sched; guided self-scheduling with a fixed map, NOHUMAN_SCHED=off = flat):
 whatever the launch size, chunk size, mate count and grid, the claims tile [0, n_frag) exactly once, in
 order, no chunk larger than c0, the sizes never growing.  Host logic only."""
 import ctypes as C
@@ -27,7 +27,7 @@ def ranges(sc, n):
 
 @pytest.mark.parametrize("mates", [1, 2])
 def test_claims_tile_the_launch(mates, monkeypatch):
-    monkeypatch.setenv("NOHUMAN_SCHED", "guided")
+    monkeypatch.delenv("NOHUMAN_SCHED", raising=False)
     rng = np.random.default_rng(7)
     sizes = [1, 2, 3, 5, 63, 64, 65, 1000, 4096, 99_999, 1_000_000, 2_500_000] + [int(x) for x in rng.integers(1, 300_000, 40)]
     for n in sizes:
@@ -44,15 +44,15 @@ def test_claims_tile_the_launch(mates, monkeypatch):
 
 
 def test_tail_is_fine_grained_for_the_bench_shapes(monkeypatch):
-    monkeypatch.setenv("NOHUMAN_SCHED", "guided")
+    monkeypatch.delenv("NOHUMAN_SCHED", raising=False)
     for n, c0, mates in ((1_000_000, 32, 1), (2_500_000, 24, 2)):
         sc = sched(n, c0, mates, 5120)
         _, cnt = ranges(sc, n)
-        assert sc["c1"] == c0 // 2 and sc["c2"] == (4 if mates == 2 else 8)
+        assert sc["c1"] == c0 // 2 and sc["c2"] == (6 if mates == 2 else 12)
         tail = n - sc["base1"]
         assert 0.5 * 5120 * c0 * 0.7 <= tail <= 5120 * c0  # about three quarters of a chunk per wave
         assert cnt[-2] == sc["c2"]
-    monkeypatch.delenv("NOHUMAN_SCHED")  # the default map is flat
+    monkeypatch.setenv("NOHUMAN_SCHED", "off")  # the flat map
     sc = sched(1_000_000, 32, 1, 5120)
     assert sc["n0"] == sc["total"] - (1 if 1_000_000 % 32 else 0) or sc["c1"] == sc["c2"] == 32
     assert set(np.unique(ranges(sc, 1_000_000)[1]).tolist()) == {32}

@@ -62,16 +62,15 @@ def run(w, env):
     return e0.elapsed_time(e1) / steps
 
 settings = {
-    "pe": [("off", {"NOHUMAN_SCHED": "off"}), ("default", {}), ("12,4,50,50", {"NOHUMAN_SCHED": "12,4,50,50"}),
+    "pe": [("flat (default)", {}), ("guided", {"NOHUMAN_SCHED": "guided"}), ("12,4,50,50", {"NOHUMAN_SCHED": "12,4,50,50"}),
            ("12,4,150,150", {"NOHUMAN_SCHED": "12,4,150,150"}), ("12,2,100,100", {"NOHUMAN_SCHED": "12,2,100,100"}),
            ("12,6,100,100", {"NOHUMAN_SCHED": "12,6,100,100"}), ("8,4,100,100", {"NOHUMAN_SCHED": "8,4,100,100"}),
-           ("12,4,100,200", {"NOHUMAN_SCHED": "12,4,100,200"})],
-    "se": [("off", {"NOHUMAN_SCHED": "off"}), ("default", {}), ("16,8,50,50", {"NOHUMAN_SCHED": "16,8,50,50"}),
+           ("16,8,100,100", {"NOHUMAN_SCHED": "16,8,100,100"})],
+    "se": [("flat (default)", {}), ("guided", {"NOHUMAN_SCHED": "guided"}), ("16,8,50,50", {"NOHUMAN_SCHED": "16,8,50,50"}),
            ("16,8,150,150", {"NOHUMAN_SCHED": "16,8,150,150"}), ("16,4,100,100", {"NOHUMAN_SCHED": "16,4,100,100"}),
-           ("16,12,100,100", {"NOHUMAN_SCHED": "16,12,100,100"}), ("12,8,100,100", {"NOHUMAN_SCHED": "12,8,100,100"}),
-           ("16,8,100,200", {"NOHUMAN_SCHED": "16,8,100,200"}),
-           ("chunk28 off", {"NOHUMAN_SCHED": "off", "NOHUMAN_FRAG_CHUNK": "28"}), ("chunk28", {"NOHUMAN_FRAG_CHUNK": "28"})],
-    "hit": [("default", {}), ("chunk16", {"NOHUMAN_FRAG_CHUNK": "16"}), ("chunk20", {"NOHUMAN_FRAG_CHUNK": "20"})],
+           ("16,12,100,100", {"NOHUMAN_SCHED": "16,12,100,100"}), ("24,12,100,100", {"NOHUMAN_SCHED": "24,12,100,100"}),
+           ("24,8,100,100", {"NOHUMAN_SCHED": "24,8,100,100"}), ("16,8,100,200", {"NOHUMAN_SCHED": "16,8,100,200"})],
+    "hit": [("flat (default)", {}), ("guided", {"NOHUMAN_SCHED": "guided"})],
     "ont": [("default", {})],
     "sechunk": [("32", {}), ("28", {"NOHUMAN_FRAG_CHUNK": "28"}), ("24", {"NOHUMAN_FRAG_CHUNK": "24"}),
                 ("20", {"NOHUMAN_FRAG_CHUNK": "20"}), ("16", {"NOHUMAN_FRAG_CHUNK": "16"}), ("12", {"NOHUMAN_FRAG_CHUNK": "12"})],
