@@ -177,3 +177,39 @@ def test_reader_uses_the_parallel_decoder(tmp_path, monkeypatch):
     gz.write_bytes(bytes(bad))
     with pytest.raises(RuntimeError):
         scan(gz)
+
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_crc_by_carryless_multiply_and_by_tables_agree(tmp_path):
+    """The member CRCs are checked with a PCLMULQDQ CRC-32 where the CPU has it, slicing tables elsewhere
+    (NOHUMAN_NO_CLMUL=1 forces the tables): both must accept what zlib wrote -- odd lengths, several members --
+    and both must reject a flipped bit; the block-parallel gzip ENCODER uses the same routine, so what it writes
+    must pass Python's gzip module."""
+    import subprocess
+    import sys
+    rng = np.random.default_rng(3)
+    data = b"".join(bytes(rng.integers(0, 256, int(n), dtype=np.uint8)) + b"ACGT" * int(n) for n in (1, 63, 64, 65, 4097, 100001))
+    gz = tmp_path / "m.gz"
+    gz.write_bytes(gzip.compress(data[:70000], 6) + gzip.compress(data[70000:], 1))
+    bad = bytearray(gz.read_bytes())
+    bad[len(bad) // 3] ^= 0x10
+    (tmp_path / "bad.gz").write_bytes(bytes(bad))
+    code = ("import sys, ctypes as C; sys.path.insert(0, %r)\n"
+            "from nohuman_amd import _lib\n"
+            "L = _lib.lib()\n"
+            "rc = L.nh_gunzip_file(sys.argv[1].encode(), sys.argv[2].encode(), 3, 65536, None)\n"
+            "sys.exit(0 if rc == 0 else 3)\n") % ROOT
+    for env_extra in ({}, {"NOHUMAN_NO_CLMUL": "1"}):
+        env = dict(os.environ, **env_extra)
+        out = tmp_path / "out.bin"
+        assert subprocess.run([sys.executable, "-c", code, str(gz), str(out)], env=env).returncode == 0
+        assert out.read_bytes() == data
+        assert subprocess.run([sys.executable, "-c", code, str(tmp_path / "bad.gz"), str(out)], env=env).returncode == 3
+        plain = tmp_path / "p.bin"
+        plain.write_bytes(data)
+        code2 = ("import sys; sys.path.insert(0, %r)\nfrom nohuman_amd import _lib\n"
+                 "sys.exit(_lib.lib().nh_compress_file(sys.argv[1].encode(), sys.argv[2].encode(), 2, 3))\n") % ROOT
+        assert subprocess.run([sys.executable, "-c", code2, str(plain), str(tmp_path / "enc.gz")], env=env).returncode == 0
+        assert gzip.decompress((tmp_path / "enc.gz").read_bytes()) == data
