@@ -123,9 +123,9 @@ def measure(cx, args, *, steps, warmup, single_end=False, ont=False, hit_frac=0.
     if pin_db:
         # a REAL database directory (hash.k2d / opts.k2d / taxo.k2d, e.g. HPRC.r2 of /root/reference/config.toml:1-7):
         # loaded as it is and used instead of the synthetic table -- its header is reported in config.database
-        eng = Engine.open(pin_db, device=cx.local_rank)
+        eng = Engine.open(pin_db, device=cx.dev_index)
     else:
-        eng = Engine.synthetic(capacity, n_keys, depth=30, seed=20250101, device=cx.local_rank)
+        eng = Engine.synthetic(capacity, n_keys, depth=30, seed=20250101, device=cx.dev_index)
     t_db = time.time() - t0
 
     # ---- synthetic batches resident in HBM (iid uniform ACGT) -----------
@@ -295,15 +295,23 @@ def main():
         if cx.world > 1:
             dist.destroy_process_group()
         return
-    if cx.local_rank >= torch.cuda.device_count():
-        raise SystemExit("rank %d: no GPU %d on this node (%d visible)" % (cx.rank, cx.local_rank,
+    # NOHUMAN_BENCH_ONE_GPU=1 (test mode for boxes with one GPU): every rank uses device 0 and the counters are
+    # reduced over gloo -- RCCL refuses two ranks on one device.  Everything else of the N > 1 path is the real thing
+    # (rank processes, sharding, barriers, max-over-ranks timing, the reductions, the rank table).
+    cx.one_gpu = bool(os.environ.get("NOHUMAN_BENCH_ONE_GPU"))
+    cx.dev_index = 0 if cx.one_gpu else cx.local_rank
+    if cx.dev_index >= torch.cuda.device_count():
+        raise SystemExit("rank %d: no GPU %d on this node (%d visible)" % (cx.rank, cx.dev_index,
                                                                            torch.cuda.device_count()))
-    torch.cuda.set_device(cx.local_rank)
-    cx.dev = torch.device("cuda", cx.local_rank)
+    torch.cuda.set_device(cx.dev_index)
+    cx.dev = torch.device("cuda", cx.dev_index)
     backend = None
     if cx.world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=cx.dev)
+        if cx.one_gpu:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=cx.dev)
         backend = dist.get_backend()
 
     m, live = measure(cx, args, steps=args.steps, warmup=args.warmup, single_end=args.single_end, ont=args.ont,
@@ -327,7 +335,8 @@ def main():
             "paired": m["paired"],
             "parallelism": "reads sharded over %d GPU(s), DB replicated" % cx.world,
             "world_size_seen": dist.get_world_size() if cx.world > 1 else 1,
-            "collective_backend": ("%s (RCCL %s)" % (backend, ".".join(map(str, torch.cuda.nccl.version()))))
+            "collective_backend": ("gloo (TEST MODE NOHUMAN_BENCH_ONE_GPU: all %d ranks share GPU 0)" % cx.world) if cx.one_gpu and backend
+                                  else ("%s (RCCL %s)" % (backend, ".".join(map(str, torch.cuda.nccl.version()))))
                                   if backend else "none (single process)",
             "ranks": rank_table(cx, m["roofline"]["kernel_ms"]),
             "classified_fraction": m["classified_fraction"],

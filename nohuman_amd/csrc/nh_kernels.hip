@@ -824,7 +824,8 @@ __device__ __forceinline__ void probe_queue_quad(KArgsP ap, WL &S, const int lan
             c[k] = make_uint4(0, 0, 0, 0);
             if (q4 < nvk[k]) {  // (a chunk without eligible cells is not loaded: every line-visit costs the L1)
                 const uint64_t cell = WIDE ? (((uint64_t)(m >> 11) << 32) | p) : (uint64_t)p;
-                c[k] = *reinterpret_cast<const uint4 *>(table + (uint64_t)((m >> 8) & 7u) * copy_stride + cell + q4);
+                const uint32_t copy = WIDE ? ((m >> 8) & 7u) : (m >> 8);
+                c[k] = *reinterpret_cast<const uint4 *>(table + (uint64_t)copy * copy_stride + cell + q4);
             }
         }
         bool found = false;
@@ -1166,7 +1167,8 @@ __device__ __forceinline__ void flush_records(KArgsP ap, WL &S, const int lane) 
 // POST a group: finish the tiles of group `pp` (and each fragment whose last tile is among them).
 // The accumulation state of the fragment being post-processed is parked in LDS between calls (it is
 // wave-uniform and idle during scan and probe: four scalar registers less to keep there).
-template <bool STD, bool BIG, bool PROF, class WL>
+// SPLIT: the tiles may be segments of split long reads (generic kernel); compiled out of the short-read kernel
+template <bool STD, bool BIG, bool PROF, bool SPLIT, class WL>
 __device__ __forceinline__ void post_group(KArgsP ap, WL &S, const TaxList &TLI, const int lane,
                                            const int mates, const bool reset_per_mate, const uint32_t pp,
                                            const uint32_t nslot, uint64_t (&prof)[12], uint64_t &tprev) {
@@ -1188,7 +1190,7 @@ __device__ __forceinline__ void post_group(KArgsP ap, WL &S, const TaxList &TLI,
             const uint32_t d_last = uni(d2.x), flags = uni(d2.y);
             // f_lo, f_hi (a segment of a split read keeps the number of segments in f_hi: such launches have
             // fewer than 2^32 fragments)
-            const uint64_t f = ((flags & 16u) ? 0ull : ((uint64_t)uni(d0.y) << 32)) | uni(d0.x);
+            const uint64_t f = ((SPLIT && (flags & 16u)) ? 0ull : ((uint64_t)uni(d0.y) << 32)) | uni(d0.x);
             const uint64_t kt = kmer_taxa ? a2->kmer_taxa_off[f] + uni(d0.z) : 0;  // tile's first k-mer
             const uint32_t d_nqt = uni(d1.x), d_qbase = uni(d1.y), d_nruns = uni(d1.z);
             const uint32_t d_nk0 = uni(d2.z), d_total = uni(d2.w);
@@ -1199,15 +1201,17 @@ __device__ __forceinline__ void post_group(KArgsP ap, WL &S, const TaxList &TLI,
                 st.overflow = false;
                 // a segment of a split read inherits kraken2's last_taxon: the taxon of the minimizer it
                 // inherited, looked up as entry pad0 - 1 of this group's queue
-                const uint32_t cq = uni(d0.w);
-                if (cq) st.carry_tax = uni(tax_at<STD>(S, pp, cq - 1u));
+                if constexpr (SPLIT) {
+                    const uint32_t cq = uni(d0.w);
+                    if (cq) st.carry_tax = uni(tax_at<STD>(S, pp, cq - 1u));
+                }
             }
             const uint32_t ps = S.ps[pp][s][lane];
             post_tile<STD, BIG, PROF>(S, TLI, lane, ps, d_nqt, pp, d_qbase, d_nruns, (int)d_last, st,
                                       kmer_taxa, kt, prof, tprev);
             if ((flags & 2u) && reset_per_mate) st.carry_tax = 0;  // mate 0 ended, mate 1 follows
             bool finish = (flags & 1u) != 0;  // fragment ended
-            if (finish && (flags & 16u)) {
+            if (SPLIT && finish && (flags & 16u)) {
                 // ... or rather one SEGMENT of a split read (descriptor: f_hi = segments, nk0 = this segment,
                 // pad1 = first partial slot of the read).  Leave the partial; whoever finishes last adds up.
                 const uint32_t nseg = uni(d0.y), seg = d_nk0, sb = uni(d1.w);
@@ -1381,7 +1385,7 @@ __global__ __launch_bounds__(WAVE * WAVES_PER_BLOCK, BIG ? 1 : (STD ? NH_MIN_WAV
 #endif
             probe_queue<LINEAR, STD, CAP32, PROF>(ap, S, lane, par, qn, lk, !BIG, carry_pack, prof, tprev);
         carry_pack = 0;
-        if (nslot_old) post_group<STD, BIG, PROF>(ap, S, TLI, lane, mates, reset_per_mate, par ^ 1u, nslot_old, prof, tprev);
+        if (nslot_old) post_group<STD, BIG, PROF, true>(ap, S, TLI, lane, mates, reset_per_mate, par ^ 1u, nslot_old, prof, tprev);
         nslot_old = nslot_new;
         par ^= 1u;
         nslot_new = 0;
@@ -1647,7 +1651,8 @@ __global__ __launch_bounds__(WAVE * WAVES_PER_BLOCK, BIG ? 1 : (STD ? NH_MIN_WAV
 // kernel, launched right behind, classifies exactly those chunks (none: it returns at once).
 constexpr uint32_t SHORT_MAX = 158;  // TQ + K - 1 bases: at most one tile of 124 k-mers
 
-template <bool PROF, bool WIDE>
+// TLINE: the variant tools/timeline.py runs (per-wave timestamps, KArgs::timeline); compiled out of the others
+template <bool PROF, bool WIDE, bool TLINE>
 __global__ __launch_bounds__(WAVE * WAVES_PER_BLOCK, PROF ? 4 : NH_MIN_WAVES) void k_classify_short(const KArgs args_by_kernarg_pointer) {
     constexpr bool STD = true;
     KArgsP ap = (KArgsP)__builtin_amdgcn_kernarg_segment_ptr();
@@ -1661,10 +1666,10 @@ __global__ __launch_bounds__(WAVE * WAVES_PER_BLOCK, PROF ? 4 : NH_MIN_WAVES) vo
 
     constexpr uint32_t K = 35, L = 31;
     const int mates = ap->mates;
-    const uint64_t n_frag = ap->n_frag;
     const bool reset_per_mate = ap->db.reset_per_mate != 0;
-    const bool inplace = ap->seq_len != nullptr;
-    if (lane == 0) S.last_dw = ((inplace ? ap->bases_end : ap->seq_off[n_frag * (uint64_t)mates]) + 4) >> 2;
+    // (the launch's size and the form of its input are read again where a chunk starts: two scalars less to keep)
+    if (lane == 0)
+        S.last_dw = ((ap->seq_len != nullptr ? ap->bases_end : ap->seq_off[ap->n_frag * (uint64_t)mates]) + 4) >> 2;
     const uint32_t pl = (uint32_t)lane < PREF_LANES ? (uint32_t)lane : PREF_LANES - 1;
     auto tile_ptr = [&](uint64_t g0) -> const uint32_t * {
         KArgsP a3 = launder(ap);
@@ -1689,10 +1694,11 @@ __global__ __launch_bounds__(WAVE * WAVES_PER_BLOCK, PROF ? 4 : NH_MIN_WAVES) vo
 
     // tuning aid (KArgs::timeline): looked up again at every stamp, so that nothing of it lives in registers
     auto tl_row = [&]() -> unsigned long long * {
+        if constexpr (!TLINE) return nullptr;
         unsigned long long *const base = launder(ap)->timeline;
         return base ? base + 32ull * ((uint64_t)blockIdx.x * WAVES_PER_BLOCK + (uint32_t)wib) : nullptr;
     };
-    if (lane == 0) {
+    if (TLINE && lane == 0) {
         if (unsigned long long *const tline = tl_row()) {
             tline[0] = wall_clock64();
             tline[2] = tline[3] = tline[6] = 0;
@@ -1741,13 +1747,13 @@ __global__ __launch_bounds__(WAVE * WAVES_PER_BLOCK, PROF ? 4 : NH_MIN_WAVES) vo
             }
             uint64_t c0 = 0;
             uint32_t ncf = 0;
-            if (claim == ~0ull || !claim_range(ap, claim, n_frag, c0, ncf)) {
+            if (claim == ~0ull || !claim_range(ap, claim, launder(ap)->n_frag, c0, ncf)) {
                 if (drain == 2) break;
                 drain++;
                 batch = false;
             } else {
                 claim_ahead = false;
-                if (lane == 0) {
+                if (TLINE && lane == 0) {
                     if (unsigned long long *const tline = tl_row()) {
                         tline[4] = wall_clock64();
                         if (tline[6] < 24) tline[8 + tline[6]] = (tline[4] << 8) | ncf;  // start and size of every chunk
@@ -1756,6 +1762,7 @@ __global__ __launch_bounds__(WAVE * WAVES_PER_BLOCK, PROF ? 4 : NH_MIN_WAVES) vo
                 }
                 cbeg = c0;
                 const uint32_t ns = ncf * (uint32_t)mates;
+                const bool inplace = launder(ap)->seq_len != nullptr;
                 const uint32_t nof = inplace ? ns : ns + 1;
                 const uint64_t sidx = cbeg * (uint64_t)mates + ((uint32_t)lane < nof ? (uint32_t)lane : nof - 1);
                 const uint64_t off64 = launder(ap)->seq_off[sidx];
@@ -1805,7 +1812,7 @@ __global__ __launch_bounds__(WAVE * WAVES_PER_BLOCK, PROF ? 4 : NH_MIN_WAVES) vo
             }
             wave_sync();
             NH_STAMP(1);
-            if (lane == 0) {
+            if (TLINE && lane == 0) {
                 unsigned long long *const tline = tl_row();
                 if (tline && tline[2] == 0) tline[2] = wall_clock64();
             }
@@ -1880,12 +1887,12 @@ __global__ __launch_bounds__(WAVE * WAVES_PER_BLOCK, PROF ? 4 : NH_MIN_WAVES) vo
 #else
                 probe_queue_quad<PROF, WIDE>(ap, S, lane, par, qn, lk, true, 0ull, prof, tprev);
 #endif
-                if (lane == 0) {
+                if (TLINE && lane == 0) {
                     unsigned long long *const tline = tl_row();
                     if (tline && tline[3] == 0) tline[3] = wall_clock64();
                 }
                 if (nslot_old)
-                    post_group<STD, false, PROF>(ap, S, TLI, lane, mates, reset_per_mate, par ^ 1u, nslot_old, prof, tprev);
+                    post_group<STD, false, PROF, false>(ap, S, TLI, lane, mates, reset_per_mate, par ^ 1u, nslot_old, prof, tprev);
                 nslot_old = nslot_new;
                 par ^= 1u;
                 nslot_new = 0;
@@ -1904,7 +1911,8 @@ __global__ __launch_bounds__(WAVE * WAVES_PER_BLOCK, PROF ? 4 : NH_MIN_WAVES) vo
             for (int i = 0; i < 12; i++) atomicAdd(&counters[CNT_N + i], (unsigned long long)prof[i]);
         add_counters(ap, S.acc);
         if (bad_input) atomicOr(&error_flag[0], 2);
-        if (unsigned long long *const tline = tl_row()) tline[5] = wall_clock64();
+        if constexpr (TLINE)
+            if (unsigned long long *const tline = tl_row()) tline[5] = wall_clock64();
     }
 }
 
@@ -2250,11 +2258,13 @@ hipError_t launch_classify(const DevDB &db, const LaunchIO &io, double confidenc
     if (hot && !io.long_reads && !no_short && n_chunks <= sl.defer_cap_bits) {
         n_defer_words = (uint32_t)((n_chunks + 31) / 32);
         if (phase_prof && cap32)
-            hipLaunchKernelGGL((k_classify_short<true, false>), g, b, 0, stream, ka);
+            hipLaunchKernelGGL((k_classify_short<true, false, false>), g, b, 0, stream, ka);
+        else if (cap32 && ka.timeline)
+            hipLaunchKernelGGL((k_classify_short<false, false, true>), g, b, 0, stream, ka);
         else if (cap32)
-            hipLaunchKernelGGL((k_classify_short<false, false>), g, b, 0, stream, ka);
+            hipLaunchKernelGGL((k_classify_short<false, false, false>), g, b, 0, stream, ka);
         else
-            hipLaunchKernelGGL((k_classify_short<false, true>), g, b, 0, stream, ka);
+            hipLaunchKernelGGL((k_classify_short<false, true, false>), g, b, 0, stream, ka);
         ka.only_deferred = 1;
         ka.work = sl.d_work + (size_t)WORK_WORDS * WORK_STRIDE;  // the second pass has work counters of its own
     }
@@ -2300,7 +2310,7 @@ hipError_t launch_insert_sequences(const DevDB &db, const void *d_bases, const v
 
 int classify_blocks_per_cu() {
     int nb = 0;
-    hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_classify_short<false, false>,
+    hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_classify_short<false, false, false>,
                                                                 WAVE * WAVES_PER_BLOCK, 0);
     if (e != hipSuccess || nb < 1) nb = 4;
     return nb > 8 ? 8 : nb;

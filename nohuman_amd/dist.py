@@ -26,9 +26,12 @@ def reduce_counters(counters, elapsed_seconds: float, group=None):
     ints, max elapsed seconds over ranks).  No-op without an initialised process group."""
     import torch
     import torch.distributed as dist
-    tot = counters.clone()
-    tmax = torch.tensor([float(elapsed_seconds)], dtype=torch.float64, device=counters.device)
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+    on = dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1
+    # (gloo reduces host tensors: the CPU tests, and bench.py's one-GPU test mode)
+    dev = "cpu" if on and dist.get_backend(group) == "gloo" else counters.device
+    tot = counters.clone().to(dev)
+    tmax = torch.tensor([float(elapsed_seconds)], dtype=torch.float64, device=dev)
+    if on:
         dist.all_reduce(tot, op=dist.ReduceOp.SUM, group=group)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX, group=group)
     return [int(x) for x in tot.tolist()], float(tmax.item())
@@ -40,6 +43,8 @@ def gather_floats(value: float, device=None, group=None):
     import torch.distributed as dist
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
         return [float(value)]
+    if dist.get_backend(group) == "gloo":
+        device = "cpu"
     mine = torch.tensor([float(value)], dtype=torch.float64, device=device)
     out = [torch.zeros_like(mine) for _ in range(dist.get_world_size(group))]
     dist.all_gather(out, mine, group=group)

@@ -138,3 +138,33 @@ def test_bench_self_launch_dry_run():
 def test_reduce_without_process_group_is_identity():
     tot, tmax = reduce_counters(torch.tensor([1, 2, 3, 4], dtype=torch.int64), 0.5)
     assert tot == [1, 2, 3, 4] and tmax == 0.5
+
+
+@pytest.mark.gpu
+def test_bench_two_ranks_on_one_gpu(tmp_path):
+    """The N > 1 path of bench.py has never met a multi-GPU node (SCALE skipped twice).  Short of one: two rank
+    PROCESSES sharing GPU 0 (NOHUMAN_BENCH_ONE_GPU=1: RCCL refuses two ranks on one device, so the counters are
+    reduced over gloo) -- self-launch, rendezvous, per-rank sharded batches through the HIP path, barriers,
+    max-over-ranks timing, the counter reduction and the rank table are the real thing.  The line must count
+    both ranks' fragments and look-ups."""
+    import json
+    import subprocess
+    import sys
+    ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, NOHUMAN_BENCH_ONE_GPU="1")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "1", "--pairs", "200000",
+           "--capacity", "200000033", "--pool", "2", "--no-cpu-baseline", "--no-e2e", "--no-variants"]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = json.loads(r.stdout.strip().splitlines()[-1])
+    assert line["n_gpus"] == 2 and line["config"]["world_size_seen"] == 2
+    assert "gloo" in line["config"]["collective_backend"]
+    ranks = line["config"]["ranks"]
+    assert [x["rank"] for x in ranks] == [0, 1] and all(x["kernel_ms"] > 0 for x in ranks)
+    assert len(line["roofline"]["kernel_ms_per_rank"]) == 2
+    # 2 ranks x 4 steps x 200000 pairs, 38.7 look-ups per read: value = reads of BOTH ranks over the slower rank's time
+    assert 37 < line["config"]["lookups_per_read"] < 40
+    per_rank_reads_per_s = 200000 * 2 * 4 / (line["ms_per_step"] * 4 / 1e3)
+    assert abs(line["value"] * 1e6 - 2 * per_rank_reads_per_s) / (2 * per_rank_reads_per_s) < 0.02

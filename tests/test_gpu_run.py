@@ -10,6 +10,7 @@ import pytest
 from tests.fastq_util import read_fastq
 
 pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 GOLD = os.path.join(os.path.dirname(__file__), "golden")
 DB = os.path.join(GOLD, "toy_db")
 
@@ -365,3 +366,25 @@ def test_run_refuses_an_output_that_is_an_input(tmp_path):
             engine.run(DB, str(src), str(out), device_ids=[0])
         assert "is the input" in str(ei.value)
     assert src.stat().st_size == size
+
+
+def test_run_with_pageable_batch_buffers(tmp_path):
+    """a host that will not page-lock the batch text buffers (memlock / cgroup limits) must not fail
+    the run: the buffers fall back to pageable memory (NOHUMAN_NO_PINNED=1 forces it; the switch is read once per
+    process, hence the child) and the outputs stay byte-identical."""
+    import subprocess
+    import sys
+    from nohuman_amd import engine
+    in1, in2 = os.path.join(GOLD, "reads_pe_1.fq"), os.path.join(GOLD, "reads_pe_2.fq")
+    engine.run(DB, in1, str(tmp_path / "a_1.fq"), in2=in2, out2=str(tmp_path / "a_2.fq"), device_ids=[0])
+    code = ("import sys; sys.path.insert(0, %r)\n"
+            "from nohuman_amd import engine\n"
+            "st = engine.run(%r, %r, sys.argv[1], in2=%r, out2=sys.argv[2], device_ids=[0])\n"
+            "print(st.total_sequences, st.classified)\n") % (ROOT, DB, in1, in2)
+    env = dict(os.environ, NOHUMAN_NO_PINNED="1", NOHUMAN_TRACE="1")
+    r = subprocess.run([sys.executable, "-c", code, str(tmp_path / "b_1.fq"), str(tmp_path / "b_2.fq")], env=env,
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    assert "could not be page-locked" in r.stderr
+    for n in ("_1.fq", "_2.fq"):
+        assert (tmp_path / ("a" + n)).read_bytes() == (tmp_path / ("b" + n)).read_bytes()
