@@ -166,6 +166,7 @@ struct LaunchSlot {
     uint64_t defer_cap_bits = 0;
     SplitBufs split = {};               // long-read item buffers of this slot (hdr == NULL: none)
     uint64_t split_single_cap = 0;      // entries of split.items_single
+    bool split_fresh = false;           // split.hdr has never been cleared: the launch clears it first
 };
 
 constexpr uint32_t TAXON_AMBIGUOUS = 0xFFFFFFFFu;

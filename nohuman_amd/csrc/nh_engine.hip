@@ -580,15 +580,10 @@ static int ensure_split(Engine *e, unsigned slot, uint64_t n_frag) {
         sb = SplitBufs{};
         return NH_OK;  // no buffers: the launch goes by whole reads (slower tail, same results)
     }
-    // the header starts cleared (later launches find it cleared by k_finish_launch).  hipMemset is only ordered
-    // with the legacy stream; the launch that follows runs on a non-blocking stream: wait for it here
-    if (hipMemset(sb.hdr, 0, sizeof(SplitHdr)) != hipSuccess || hipDeviceSynchronize() != hipSuccess) {
-        (void)hipGetLastError();
-        for (void *p : {(void *)sb.hdr, (void *)sb.items_multi, (void *)sb.items_single, (void *)sb.part, (void *)sb.part_done})
-            if (p) (void)hipFree(p);
-        sb = SplitBufs{};
-        return NH_OK;
-    }
+    // (the header of fresh buffers is cleared by the first launch that uses them, on ITS stream: a hipMemset here would
+    //  only be ordered with the legacy stream, and the launches run on non-blocking ones; later launches find the
+    //  header cleared by k_finish_launch)
+    e->split_fresh[slot] = true;
     sb.seg_cap = (uint32_t)want_seg;
     e->split_single_cap[slot] = nsingle;
     return NH_OK;
@@ -634,6 +629,11 @@ int classify_device(Engine *e, const void *d_bases, const void *d_seq_off, uint6
         (void)ensure_split(e, slot, n_frag);
         sl.split = e->split[slot];
         sl.split_single_cap = e->split_single_cap[slot];
+        {
+            std::lock_guard<std::mutex> lock(e->split_mu);
+            sl.split_fresh = e->split_fresh[slot];
+            e->split_fresh[slot] = false;
+        }
     }
     hipError_t he = launch_classify(db, io, confidence, sl, frag_chunk_for(e, flags, n_frag), e->grid_blocks, stream);
     if (he != hipSuccess) return set_error(NH_EDEVICE, "classify launch: %s", hipGetErrorString(he));

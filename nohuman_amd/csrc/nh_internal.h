@@ -46,6 +46,7 @@ struct Engine {
     // launch of long single-end reads and grown when a larger one comes
     SplitBufs split[LAUNCH_SLOTS] = {};
     uint64_t split_single_cap[LAUNCH_SLOTS] = {};
+    bool split_fresh[LAUNCH_SLOTS] = {};  // buffers allocated, header not yet cleared (the first launch does it)
     std::mutex split_mu;
     std::atomic<unsigned> launch_seq{0};
     hipStream_t stream = nullptr;

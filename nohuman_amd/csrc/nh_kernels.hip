@@ -2236,6 +2236,7 @@ hipError_t launch_classify(const DevDB &db, const LaunchIO &io, double confidenc
     static const bool no_split = getenv("NOHUMAN_NO_SPLIT") != nullptr;  // tuning / test knob
     const bool use_items = io.long_reads && io.mates == 1 && sl.split.hdr != nullptr && !no_split &&
                            n_frag <= sl.split_single_cap && n_frag < 0xFFFFFFFFull;
+    if (sl.split_fresh && sl.split.hdr) (void)hipMemsetAsync(sl.split.hdr, 0, sizeof(SplitHdr), stream);  // fresh buffers
     if (use_items) {
         ka.split = sl.split;
         hipLaunchKernelGGL(k_prep_items, dim3((unsigned)((n_frag + 255) / 256)), dim3(256), 0, stream, ka);
