@@ -56,6 +56,9 @@ template <bool STD> struct CandPad { static constexpr int value = STD ? 6 : 66; 
 #ifndef NH_NSLOT
 #define NH_NSLOT 4
 #endif
+#ifndef NH_LPO
+#define NH_LPO 4  // lanes that fetch an owner's probe round together (probe_queue_quad): 4 = 16 cells per round, 2 = 8
+#endif
 #ifndef NH_QCAP
 #define NH_QCAP 256  // 5 waves per SIMD need <= 31 KB of LDS per workgroup (a 32 KB one fits only 4 times: profiles/r02_tuning.txt)
 #endif
@@ -775,8 +778,11 @@ __device__ __forceinline__ void probe_queue_quad(KArgsP ap, WL &S, const int lan
     uint32_t qhead = 0;  // next queue entry to hand out (uniform)
     uint32_t busy = lk.busy, r = lk.r, ckey = lk.ckey, budget = lk.budget;
     Pos pos = (Pos)lk.pos;
-    const uint32_t q4 = ((uint32_t)lane & 3u) * 4u;         // first cell of the chunk this lane loads
-    const uint32_t own_sub = (uint32_t)lane >> 2;            // which of an instruction's 16 owners it loads for
+    // LPO lanes fetch an owner's round together (4: a quad, 64 contiguous bytes = 16 cells; 2: a pair, 8 cells):
+    // an instruction serves OPI = 64 / LPO owners, LPO instructions serve all 64
+    constexpr uint32_t LPO = NH_LPO, OPI = 64 / LPO, RCELLS = 4 * LPO;
+    const uint32_t q4 = ((uint32_t)lane % LPO) * 4u;         // first cell of the chunk this lane loads
+    const uint32_t own_sub = (uint32_t)lane / LPO;           // which of an instruction's OPI owners it loads for
     for (;;) {
         if (qhead < qn) {
             const uint64_t idle_mask = __ballot(busy == 0);
@@ -809,14 +815,14 @@ __device__ __forceinline__ void probe_queue_quad(KArgsP ap, WL &S, const int lan
             const uint32_t in_line = 32u - (((uint32_t)pos - (cj << copy_shift)) & 31u);
             const Pos room = (Pos)cap - pos;
             nv = room < (Pos)in_line ? (uint32_t)room : in_line;
-            nv = nv < 16u ? nv : 16u;
+            nv = nv < RCELLS ? nv : RCELLS;
         }
         const uint32_t meta = nv | (cj << 8) | (WIDE ? (uint32_t)((uint64_t)pos >> 32) << 11 : 0u);
-        uint4 c[4];
-        uint32_t ck[4], nvk[4];
+        uint4 c[LPO];
+        uint32_t ck[LPO], nvk[LPO];
 #pragma unroll
-        for (int k = 0; k < 4; k++) {  // instruction k: the lookups of owner lanes 16k .. 16k+15, a quad of lanes each
-            const int src = (int)(4u * (16u * (uint32_t)k + own_sub));
+        for (int k = 0; k < (int)LPO; k++) {  // instruction k: the lookups of owner lanes OPI k .. OPI k + OPI - 1, LPO lanes each
+            const int src = (int)(4u * (OPI * (uint32_t)k + own_sub));
             const uint32_t p = (uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)(uint32_t)pos);
             ck[k] = (uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)ckey);
             const uint32_t m = (uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)meta);
@@ -831,16 +837,16 @@ __device__ __forceinline__ void probe_queue_quad(KArgsP ap, WL &S, const int lan
         bool found = false;
         uint32_t val = 0;
 #pragma unroll
-        for (int k = 0; k < 4; k++) {
+        for (int k = 0; k < (int)LPO; k++) {
             uint32_t res = 0, resj = 64;
             scan4(c[k], ck[k], vmask, 0u, res, resj);
             const bool hit = q4 + resj < nvk[k];  // (resj = 64: no stopping cell in this chunk)
             const uint64_t hm = __ballot(hit);
-            // the owner reads its quad's nibble: lowest set bit = first chunk with an eligible stopping cell
-            const uint32_t nib = (uint32_t)(hm >> (4u * ((uint32_t)lane & 15u))) & 0xFu;
-            const uint32_t win = 4u * ((uint32_t)lane & 15u) + (nib ? (uint32_t)__builtin_ctz(nib) : 0u);
+            // the owner reads its group's bits: lowest set bit = first chunk with an eligible stopping cell
+            const uint32_t nib = (uint32_t)(hm >> (LPO * ((uint32_t)lane % OPI))) & ((1u << LPO) - 1u);
+            const uint32_t win = LPO * ((uint32_t)lane % OPI) + (nib ? (uint32_t)__builtin_ctz(nib) : 0u);
             const uint32_t rv = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(4u * win), (int)res);
-            if (((uint32_t)lane >> 4) == (uint32_t)k && nib != 0) {
+            if (((uint32_t)lane / OPI) == (uint32_t)k && nib != 0) {
                 found = true;
                 val = rv;
             }
