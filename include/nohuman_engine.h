@@ -225,6 +225,13 @@ int nh_fastx_scan(const char *path, uint64_t *n_records, uint64_t *n_bases, uint
  * libzstd.so.1; NH_CODEC_NONE copies.  Parity target is the decompressed content and
  * the container magic (compression.rs:282-288).  Needs no GPU. */
 int nh_compress_file(const char *in, const char *out, int codec, uint32_t threads);
+/* The gzip case of that stage on the GPU (nohuman_amd/csrc/nh_deflate.hip; replaces gzip_compress,
+ * /root/reference/src/compression.rs:214-233): n bytes at `in` (host memory) become ONE ordinary gzip member in
+ * file `out` -- 64 KiB regions of the text, a wave each, dynamic Huffman blocks, regions joined by empty stored
+ * blocks the way gzp / pigz join theirs.  It is what nh_run's writer feeds when out_codec is NH_CODEC_GZIP
+ * (NOHUMAN_GZIP=host selects the host encoder above).  stats (may be NULL): [0] bytes of the file, [1] microseconds
+ * of kernel time (HIP events).  Parity target as above: the decompressed content. */
+int nh_gzip_gpu_file(int32_t device, const void *in, uint64_t n, const char *out, uint64_t *stats);
 /* Test / tool support for the multi-threaded gzip input decoder nh_run reads .gz inputs with
  * (kraken2's wrapper pipes them through `gzip -dc`): decompress `in` to
  * `out` on `threads` workers, cutting the compressed file every chunk_bytes (0 = default).

@@ -15,6 +15,7 @@
 #include <errno.h>
 #include <fcntl.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 #include <unistd.h>
 #include <zlib.h>
@@ -500,12 +501,15 @@ private:
 
 }  // namespace
 
-StreamEncoder *make_encoder(int codec, int fd, unsigned threads, const char *name) {
+StreamEncoder *make_encoder(int codec, int fd, unsigned threads, const char *name, int device) {
     switch (codec) {
         case NH_CODEC_NONE:
             return new PlainEncoder(fd, name);
-        case NH_CODEC_GZIP:
+        case NH_CODEC_GZIP: {
+            const char *how = getenv("NOHUMAN_GZIP");
+            if (device >= 0 && !(how && !strcmp(how, "host"))) return make_gpu_gzip_encoder(fd, device, name);
             return new GzipEncoder(fd, threads, name);
+        }
         case NH_CODEC_ZSTD:
             if (!zstd_api().ok) {
                 set_error(NH_EINVAL, "Zstd output is not available: libzstd.so.1 could not be loaded");

@@ -18,6 +18,9 @@ public:
 
 // codec: nh_codec of the C ABI.  The encoder writes to fd (not closed by it); `name` only labels errors.
 // Returns nullptr with the error set when the codec's library cannot be loaded.
-StreamEncoder *make_encoder(int codec, int fd, unsigned threads, const char *name);
+// device >= 0: gzip is encoded on that GPU (nh_deflate.hip) unless NOHUMAN_GZIP=host asks for the host encoder.
+StreamEncoder *make_encoder(int codec, int fd, unsigned threads, const char *name, int device = -1);
+// the GPU gzip encoder itself (nullptr with the error set when its buffers cannot be had)
+StreamEncoder *make_gpu_gzip_encoder(int fd, int device, const char *name);
 
 }  // namespace nh

@@ -1,0 +1,654 @@
+// nh_deflate.hip -- gzip output on the GPU.  The reference compresses the kept reads with
+// gzp's block-parallel gzip at the default level (/root/reference/src/compression.rs:214-233, called from
+// src/main.rs:342-368) -- on the host cores, at some 15 MB/s per core for FASTQ text, which is what a
+// `nohuman reads.fq.gz` run spends most of its time on once the classifier is a GPU kernel.  Here the text is cut
+// into regions of 64 KiB and ONE WAVE compresses a region:
+//
+//   match finding   64 consecutive positions per step, a lane each: hash of 4 bytes -> an 8-way bucket of earlier
+//                   positions (tagged, in LDS), plus the last match's distance and distances 1..4; the candidate
+//                   that saves most bits under the PREVIOUS block's code lengths wins (find_match, nh_deflate_core.h).
+//   parse           lazy rule by a lane shift, then the chain of tokens through the step with v_readlane; a match
+//                   that reached the scan cap is extended by the whole wave at once (8 bytes a lane).
+//   block           every 32 KiB of input: symbol counts (LDS atomics) -> rank sort by the wave -> code lengths
+//                   (Moffat-Katajainen, length-limited), canonical codes, the run-length coded header; the tokens
+//                   (kept in HBM, 4 bytes each) are then coded 64 at a time: bit lengths -> wave prefix sum ->
+//                   ds_or into a staging row -> coalesced dword stores.  A block that would not shrink is stored.
+//   region end      an empty stored block byte-aligns the stream (what pigz / gzp do between their blocks), so the
+//                   regions' streams concatenate; a small kernel packs them for one D2H copy.
+//
+// The host side (GpuGzipEncoder, a StreamEncoder of nh_codec.h) stages the writer's spans in page-locked chunks,
+// keeps two chunks in flight, computes the member's CRC-32 (carry-less multiply) and writes header, streams and
+// trailer: one ordinary gzip member.  Parity target is the decompressed content (compression.rs:282-288), checked
+// by zlib and by this repo's own reader in tests/test_gpu_deflate.py.
+#include <errno.h>
+#include <fcntl.h>
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <unistd.h>
+
+#include <string>
+#include <vector>
+
+#include "nh_codec.h"
+#include "nh_deflate_core.h"
+#include "nh_inflate.h"
+#include "nh_internal.h"
+#include "nohuman_engine.h"
+
+namespace nh {
+namespace dfl {
+
+constexpr uint32_t BLOCK_IN = 32768;           // input bytes after which a block ends
+constexpr uint32_t TOK_CAP = BLOCK_IN + 512;   // tokens a block can hold (one per byte at worst, plus the last step)
+constexpr uint32_t OB_WORDS = 136;             // staging row of the bit writer
+constexpr uint32_t PRIOR_BYTES = NLIT + NDIST; // code lengths handed from chunk to chunk: the match finder's prices
+
+struct DeflateArgs {
+    const uint8_t *in;      // the text; readable up to n + 64
+    uint64_t n;
+    uint32_t region;        // bytes per region (<= MAX_REGION)
+    uint32_t n_regions;
+    uint8_t *slots;         // n_regions output slots, slot_stride bytes apart (4-byte aligned)
+    uint32_t slot_stride;
+    uint32_t *sizes;        // bytes written per region
+    uint32_t *tok;          // n_regions x TOK_CAP
+    const uint8_t *prior;   // PRIOR_BYTES: literal/length lengths then distance lengths; the starting prices
+    uint8_t *prior_out;     // region 0 leaves its last block's lengths here
+};
+
+__device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v, int lane) {
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const uint32_t t = (uint32_t)__shfl_up((int)v, o);
+        if (lane >= o) v += t;
+    }
+    return v;
+}
+__device__ __forceinline__ uint32_t wave_sum(uint32_t v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += (uint32_t)__shfl_xor((int)v, o);
+    return v;
+}
+__device__ __forceinline__ uint32_t readlane_u(uint32_t v, uint32_t l) {
+    return (uint32_t)__builtin_amdgcn_readlane((int)v, (int)__builtin_amdgcn_readfirstlane((int)l));
+}
+
+struct BitOut {
+    uint32_t *ob;     // LDS staging row, OB_WORDS
+    uint32_t *out;    // the region's slot
+    uint32_t out_dw;  // dwords of the slot already written
+    uint32_t obits;   // bits waiting in ob[0]
+};
+__device__ __forceinline__ void or_bits(uint32_t *ob, uint32_t off, uint32_t v, uint32_t n) {
+    const uint32_t w = off >> 5, sh = off & 31u;
+    const uint64_t vv = (uint64_t)(n >= 32u ? v : (v & ((1u << n) - 1u))) << sh;
+    atomicOr(&ob[w], (uint32_t)vv);
+    if (vv >> 32) atomicOr(&ob[w + 1], (uint32_t)(vv >> 32));
+}
+// every lane appends piece a (na bits) then piece b (nb bits), lanes in order; na, nb <= 32
+__device__ void wave_put2(BitOut &bo, int lane, uint32_t a, uint32_t na, uint32_t b, uint32_t nb) {
+    const uint32_t tot = na + nb;
+    const uint32_t incl = wave_incl_scan(tot, lane);
+    const uint32_t total = readlane_u(incl, 63) + bo.obits;
+    const uint32_t off = bo.obits + incl - tot;
+    if (na) or_bits(bo.ob, off, a, na);
+    if (nb) or_bits(bo.ob, off + na, b, nb);
+    __syncthreads();
+    const uint32_t nfull = total >> 5;
+    for (uint32_t j = (uint32_t)lane; j < nfull; j += 64) bo.out[bo.out_dw + j] = bo.ob[j];
+    const uint32_t rem = bo.ob[nfull];
+    __syncthreads();
+    for (uint32_t j = (uint32_t)lane; j <= nfull; j += 64) bo.ob[j] = j == 0 ? rem : 0u;
+    __syncthreads();
+    bo.out_dw += nfull;
+    bo.obits = total & 31u;
+}
+
+struct TreeLds {  // scratch of the code construction
+    uint32_t key[NLIT];
+    uint32_t a[NLIT];
+    uint16_t ssym[NLIT];
+};
+
+// code lengths and codes of one alphabet from its counts (all in LDS); the wave sorts, lane 0 builds
+__device__ void build_tree_wave(uint32_t *freq, int nsym, int maxbits, uint8_t *lens, uint16_t *codes, TreeLds &t,
+                                int lane) {
+    // a code needs two symbols to be complete
+    uint32_t used = 0;
+    for (int s = lane; s < nsym; s += 64) used += freq[s] != 0;
+    used = wave_sum(used);
+    if (used < 2 && lane == 0)
+        for (int s = 0; used < 2 && s < nsym; s++)
+            if (!freq[s]) {
+                freq[s] = 1;
+                used++;
+            }
+    __syncthreads();
+    for (int s = lane; s < NLIT; s += 64) t.key[s] = (s < nsym && freq[s]) ? ((freq[s] << 9) | (uint32_t)s) : 0xFFFFFFFFu;
+    __syncthreads();
+    uint32_t n = 0;
+    for (int s = lane; s < nsym; s += 64) n += t.key[s] != 0xFFFFFFFFu;
+    n = wave_sum(n);
+    // rank sort: keys are distinct; every lane counts the smaller keys for its symbols (broadcast reads)
+    for (int s = lane; s < nsym; s += 64) {
+        const uint32_t k = t.key[s];
+        if (k == 0xFFFFFFFFu) continue;
+        uint32_t r = 0;
+        for (int j = 0; j < nsym; j++) r += t.key[j] < k;
+        t.a[r] = k >> 9;
+        t.ssym[r] = (uint16_t)s;
+    }
+    __syncthreads();
+    if (lane == 0) {
+        huff_lengths_sorted(t.a, t.ssym, (int)n, nsym, maxbits, lens);
+        huff_codes(lens, nsym, maxbits, codes);
+    }
+    __syncthreads();
+}
+
+template <int WAYS>
+struct __attribute__((aligned(16))) RegionLds {
+    uint32_t bucket[WAYS << BUCKET_BITS];
+    uint32_t lfreq[NLIT];
+    uint32_t dfreq[NDIST];
+    uint32_t clfreq[32];
+    uint8_t llen[NLIT];   // lengths of the last block built: the codes' lengths while coding, the prices while matching
+    uint8_t dlen[NDIST];
+    uint8_t cllen[32];
+    uint16_t lcode[NLIT];
+    uint16_t dcode[NDIST];
+    uint16_t clcode[32];
+    uint8_t all[NLIT + NDIST];     // hlit + hdist lengths in a row
+    uint16_t items[NLIT + NDIST];  // their run-length form
+    TreeLds tree;
+    uint32_t ob[OB_WORDS];
+    int misc[8];
+};
+
+// Ends a block: builds the codes from the counts and writes header + tokens (or the bytes, stored).
+template <int WAYS>
+__device__ void finish_block(RegionLds<WAYS> &S, BitOut &bo, const uint32_t *tok, uint32_t ntok, const uint8_t *src,
+                             uint32_t from, uint32_t to, int lane) {
+    if (lane == 0) S.lfreq[256] = 1;
+    __syncthreads();
+    build_tree_wave(S.lfreq, NLIT_USED, MAXBITS, S.llen, S.lcode, S.tree, lane);
+    build_tree_wave(S.dfreq, NDIST_USED, MAXBITS, S.dlen, S.dcode, S.tree, lane);
+    if (lane == 0) {
+        int hlit = NLIT_USED, hdist = NDIST_USED;
+        while (hlit > 257 && S.llen[hlit - 1] == 0) hlit--;
+        while (hdist > 1 && S.dlen[hdist - 1] == 0) hdist--;
+        for (int i = 0; i < hlit; i++) S.all[i] = S.llen[i];
+        for (int i = 0; i < hdist; i++) S.all[hlit + i] = S.dlen[i];
+        S.misc[0] = hlit;
+        S.misc[1] = hdist;
+        S.misc[2] = rle_lengths(S.all, hlit + hdist, S.items, S.clfreq);
+    }
+    __syncthreads();
+    build_tree_wave(S.clfreq, NCL, MAXBITS_CL, S.cllen, S.clcode, S.tree, lane);
+    const int hlit = S.misc[0], hdist = S.misc[1], ni = S.misc[2];
+    int hclen = NCL;
+    while (hclen > 4 && S.cllen[cl_order(hclen - 1)] == 0) hclen--;
+    // size of the block with these codes
+    uint32_t bits = 0;
+    for (int i = lane; i < ni; i += 64) {
+        const uint32_t s = S.items[i] & 31u;
+        bits += S.cllen[s] + cl_extra_bits(s);
+    }
+    for (int s = lane; s < NLIT_USED; s += 64) bits += S.lfreq[s] * (S.llen[s] + (s > 256 ? len_extra_bits((uint32_t)s) : 0u));
+    for (int s = lane; s < NDIST_USED; s += 64) bits += S.dfreq[s] * (S.dlen[s] + dist_extra_bits((uint32_t)s));
+    bits = wave_sum(bits) + 17u + 3u * (uint32_t)hclen;
+    const uint32_t nbytes = to - from;
+    if (bits >= 8u * nbytes + 40u) {
+        // stored: 3 header bits, padding to a byte, LEN, NLEN, the bytes
+        const uint32_t pos = (bo.out_dw * 32u + bo.obits + 3u) & 7u;
+        const uint32_t pad = pos ? 8u - pos : 0u;
+        wave_put2(bo, lane, 0u, lane == 0 ? 3u + pad : 0u, (nbytes & 0xFFFFu) | ((~nbytes & 0xFFFFu) << 16), lane == 0 ? 32u : 0u);
+        for (uint32_t i = 0; i < nbytes; i += 64) {
+            const bool in = i + (uint32_t)lane < nbytes;
+            wave_put2(bo, lane, in ? src[from + i + lane] : 0u, in ? 8u : 0u, 0u, 0u);
+        }
+        return;
+    }
+    // dynamic block: BFINAL 0, BTYPE 2, hlit, hdist, hclen | the code-length code's lengths | the items
+    {
+        const uint32_t head = 4u | ((uint32_t)(hlit - 257) << 3) | ((uint32_t)(hdist - 1) << 8) | ((uint32_t)(hclen - 4) << 13);
+        wave_put2(bo, lane, head, lane == 0 ? 17u : 0u, 0u, 0u);
+        wave_put2(bo, lane, lane < hclen ? S.cllen[cl_order(lane < NCL ? lane : 0)] : 0u, lane < hclen ? 3u : 0u, 0u, 0u);
+        for (int i = 0; i < ni; i += 64) {
+            const bool in = i + lane < ni;
+            const uint32_t it = in ? S.items[i + lane] : 0u;
+            const uint32_t s = it & 31u;
+            wave_put2(bo, lane, S.clcode[s], in ? S.cllen[s] : 0u, it >> 5, in ? cl_extra_bits(s) : 0u);
+        }
+    }
+    for (uint32_t i = 0; i < ntok; i += 64) {
+        const bool in = i + (uint32_t)lane < ntok;
+        const uint32_t t = in ? __hip_atomic_load(&tok[i + lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
+        uint32_t a = 0, na = 0, b = 0, nb = 0;
+        if (in) {
+            if (t & 0x80000000u) {
+                uint32_t sym, eb, ev, dsym, deb, dev;
+                len_symbol((t >> 16) & 0xFFu, sym, eb, ev);
+                dist_symbol(t & 0x7FFFu, dsym, deb, dev);
+                na = S.llen[sym];
+                a = S.lcode[sym] | (ev << na);
+                na += eb;
+                nb = S.dlen[dsym];
+                b = S.dcode[dsym] | (dev << nb);
+                nb += deb;
+            } else {
+                a = S.lcode[t];
+                na = S.llen[t];
+            }
+        }
+        wave_put2(bo, lane, a, na, b, nb);
+    }
+    wave_put2(bo, lane, S.lcode[256], lane == 0 ? S.llen[256] : 0u, 0u, 0u);
+}
+
+template <int WAYS>
+__global__ __launch_bounds__(64) void k_deflate(DeflateArgs a) {
+    __shared__ RegionLds<WAYS> S;
+    const int lane = (int)threadIdx.x;
+    const uint32_t r = blockIdx.x;
+    const uint64_t base = (uint64_t)r * a.region;
+    const uint32_t n = (uint32_t)((a.n - base) < (uint64_t)a.region ? (a.n - base) : (uint64_t)a.region);
+    const uint8_t *src = a.in + base;
+    uint32_t *tok = a.tok + (size_t)r * TOK_CAP;
+    for (uint32_t i = (uint32_t)lane; i < (uint32_t)(WAYS << BUCKET_BITS); i += 64) S.bucket[i] = EMPTY_ENTRY;
+    for (int i = lane; i < NLIT; i += 64) {
+        S.lfreq[i] = 0;
+        S.llen[i] = a.prior[i];
+    }
+    if (lane < NDIST) {
+        S.dfreq[lane] = 0;
+        S.dlen[lane] = a.prior[NLIT + lane];
+    }
+    for (uint32_t i = (uint32_t)lane; i < OB_WORDS; i += 64) S.ob[i] = 0;
+    __syncthreads();
+    BitOut bo{S.ob, (uint32_t *)(a.slots + (size_t)r * a.slot_stride), 0u, 0u};
+    uint32_t carry = 0, rep = 0, ntok = 0, blk_from = 0;
+    const uint64_t lt_mask = (1ull << lane) - 1ull;
+    for (uint32_t s = 0; s < n; s += 64) {
+        const uint32_t p = s + (uint32_t)lane;
+        const bool inside = p < n;
+        const bool any = carry < s + 64u;
+        uint32_t four = 0;
+        if (inside) {
+            struct __attribute__((packed)) U4 {
+                uint32_t v;
+            };
+            four = ((const U4 *)(src + p))->v;
+        }
+        const bool has4 = p + 4u <= n;
+        const uint32_t h = hash4(four);
+        uint32_t L = 0, D = 0;
+        if (any && inside && p >= carry) {
+            const Costs costs{S.llen, S.dlen};
+            int gain = 0;
+            L = find_match(src, p, n, h, &S.bucket[WAYS * hash_bucket(h)], WAYS, rep, costs, D, gain);
+        }
+        __syncthreads();
+        if (has4) S.bucket[WAYS * hash_bucket(h) + ((p >> 6) % WAYS)] = make_entry(h, p);
+        if (any) {
+            // lazy rule: a longer match one position on wins over a short one here
+            const uint32_t nx = (uint32_t)__shfl_down((int)L, 1);
+            if (L && L < 16u && lane < 63 && nx > L) L = 0;
+            uint64_t sel = 0;
+            uint32_t q = carry > s ? carry - s : 0u;
+            const uint32_t qend = n - s < 64u ? n - s : 64u;
+            while (q < qend) {
+                uint32_t l = readlane_u(L, q);
+                if (l == SCAN_CAP) {  // the wave measures the rest of the match: 8 bytes a lane
+                    const uint32_t d = readlane_u(D, q), cpos = s + q;
+                    const uint32_t maxl = n - cpos < MAX_MATCH ? n - cpos : MAX_MATCH;
+                    const uint32_t off = SCAN_CAP + 8u * (uint32_t)lane;
+                    const bool within = off < maxl;
+                    const uint64_t x = within ? (load8(src + cpos + off) ^ load8(src + cpos - d + off)) : 1ull;
+                    const uint64_t stop = __ballot(x != 0);
+                    const uint32_t f = (uint32_t)__builtin_ctzll(stop);
+                    uint32_t tl = off + (within ? (uint32_t)__builtin_ctzll(x) >> 3 : 0u);
+                    tl = readlane_u(tl, f);
+                    l = tl < maxl ? tl : maxl;
+                    if ((uint32_t)lane == q) L = l;
+                }
+                sel |= 1ull << q;
+                q += l ? l : 1u;
+            }
+            carry = s + q;
+            const uint64_t msel = __ballot(L != 0) & sel;
+            if (msel) rep = readlane_u(D, 63u - (uint32_t)__builtin_clzll(msel));
+            if ((sel >> lane) & 1ull) {
+                const uint32_t idx = ntok + (uint32_t)__popcll(sel & lt_mask);
+                if (L) {
+                    uint32_t sym, eb, ev, dsym, deb, dev;
+                    len_symbol(L - 3u, sym, eb, ev);
+                    dist_symbol(D - 1u, dsym, deb, dev);
+                    tok[idx] = tok_match(L, D);
+                    atomicAdd(&S.lfreq[sym], 1u);
+                    atomicAdd(&S.dfreq[dsym], 1u);
+                } else {
+                    tok[idx] = four & 0xFFu;
+                    atomicAdd(&S.lfreq[four & 0xFFu], 1u);
+                }
+            }
+            ntok += (uint32_t)__popcll(sel);
+        }
+        __syncthreads();
+        if (carry - blk_from >= BLOCK_IN || s + 64u >= n) {
+            const uint32_t to = carry < n ? carry : n;
+            __threadfence_block();
+            finish_block<WAYS>(S, bo, tok, ntok, src, blk_from, to, lane);
+            for (int i = lane; i < NLIT; i += 64) S.lfreq[i] = 0;
+            if (lane < NDIST) S.dfreq[lane] = 0;
+            __syncthreads();
+            blk_from = to;
+            ntok = 0;
+        }
+    }
+    // the region ends on a byte boundary: an empty stored block (BFINAL 0, BTYPE 0, padding, LEN 0, NLEN 0xFFFF)
+    {
+        const uint32_t pos = (bo.out_dw * 32u + bo.obits + 3u) & 7u;
+        const uint32_t pad = pos ? 8u - pos : 0u;
+        wave_put2(bo, lane, 0u, lane == 0 ? 3u + pad : 0u, 0xFFFF0000u, lane == 0 ? 32u : 0u);
+    }
+    if (lane == 0) {
+        if (bo.obits) bo.out[bo.out_dw] = S.ob[0];
+        a.sizes[r] = bo.out_dw * 4u + (bo.obits >> 3);
+    }
+    if (r == 0 && a.prior_out) {
+        for (int i = lane; i < NLIT; i += 64) a.prior_out[i] = S.llen[i];
+        if (lane < NDIST) a.prior_out[NLIT + lane] = S.dlen[lane];
+    }
+}
+
+// offsets[i] = bytes of the regions before i; offsets[n] = all
+__global__ void k_deflate_offsets(const uint32_t *sizes, uint32_t n, uint64_t *offsets) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        uint64_t acc = 0;
+        for (uint32_t i = 0; i < n; i++) {
+            offsets[i] = acc;
+            acc += sizes[i];
+        }
+        offsets[n] = acc;
+    }
+}
+__global__ __launch_bounds__(256) void k_deflate_pack(const uint8_t *slots, uint32_t slot_stride, const uint32_t *sizes,
+                                                       const uint64_t *offsets, uint8_t *out) {
+    const uint32_t r = blockIdx.x;
+    const uint8_t *s = slots + (size_t)r * slot_stride;
+    uint8_t *d = out + offsets[r];
+    const uint32_t n = sizes[r];
+    for (uint32_t i = threadIdx.x; i < n; i += 256) d[i] = s[i];
+}
+
+}  // namespace dfl
+
+// ---- host side --------------------------------------------------------------------------------------------------
+namespace {
+
+using dfl::DeflateArgs;
+
+int gzip_ways() {
+    static const int w = [] {
+        const char *e = getenv("NOHUMAN_GZIP_WAYS");
+        const int v = e ? atoi(e) : 8;
+        return v == 4 ? 4 : 8;
+    }();
+    return w;
+}
+
+struct DeflateDev {  // device side of one encoder: buffers for chunks in flight
+    static constexpr size_t CHUNK = 64u << 20;
+    static constexpr uint32_t REGION = 65536;
+    static constexpr int NBUF = 2;
+    int device = -1;
+    hipStream_t stream = nullptr;
+    struct Buf {
+        uint8_t *h_in = nullptr;   // page-locked staging of the text
+        uint8_t *d_in = nullptr;
+        uint8_t *d_slots = nullptr;
+        uint32_t *d_sizes = nullptr;
+        uint64_t *d_offsets = nullptr;
+        uint8_t *d_out = nullptr;
+        uint8_t *h_out = nullptr;  // page-locked
+        uint64_t *h_total = nullptr;
+        hipEvent_t done = nullptr, k0 = nullptr, k1 = nullptr;
+        size_t fill = 0;
+        uint32_t n_regions = 0;
+        bool in_flight = false;
+    } buf[NBUF];
+    uint32_t *d_tok = nullptr;
+    uint8_t *d_prior = nullptr;  // two rows, alternating
+    uint32_t slot_stride = 0, max_regions = 0;
+    uint64_t chunks = 0;
+    double kernel_ms = 0;
+
+    int fail(hipError_t e, const char *what) { return set_error(NH_EDEVICE, "gzip encoder: %s: %s", what, hipGetErrorString(e)); }
+
+    int init(int dev) {
+        device = dev;
+        hipError_t e = hipSetDevice(device);
+        if (e != hipSuccess) return fail(e, "hipSetDevice");
+        if ((e = hipStreamCreateWithFlags(&stream, hipStreamNonBlocking)) != hipSuccess) return fail(e, "stream");
+        max_regions = (uint32_t)((CHUNK + REGION - 1) / REGION);
+        slot_stride = REGION + 256;
+        for (Buf &b : buf) {
+            if ((e = hipHostMalloc((void **)&b.h_in, CHUNK + 64, hipHostMallocDefault)) != hipSuccess) return fail(e, "pinned input");
+            if ((e = hipMalloc((void **)&b.d_in, CHUNK + 256)) != hipSuccess) return fail(e, "device input");
+            if ((e = hipMemset(b.d_in, 0, CHUNK + 256)) != hipSuccess) return fail(e, "memset");
+            if ((e = hipMalloc((void **)&b.d_slots, (size_t)max_regions * slot_stride)) != hipSuccess) return fail(e, "slots");
+            if ((e = hipMalloc((void **)&b.d_sizes, max_regions * sizeof(uint32_t))) != hipSuccess) return fail(e, "sizes");
+            if ((e = hipMalloc((void **)&b.d_offsets, (max_regions + 1) * sizeof(uint64_t))) != hipSuccess) return fail(e, "offsets");
+            if ((e = hipMalloc((void **)&b.d_out, (size_t)max_regions * slot_stride)) != hipSuccess) return fail(e, "packed output");
+            if ((e = hipHostMalloc((void **)&b.h_out, (size_t)max_regions * slot_stride, hipHostMallocDefault)) != hipSuccess)
+                return fail(e, "pinned output");
+            if ((e = hipHostMalloc((void **)&b.h_total, 64, hipHostMallocDefault)) != hipSuccess) return fail(e, "pinned total");
+            if ((e = hipEventCreate(&b.done)) != hipSuccess) return fail(e, "event");
+            if ((e = hipEventCreate(&b.k0)) != hipSuccess) return fail(e, "event");
+            if ((e = hipEventCreate(&b.k1)) != hipSuccess) return fail(e, "event");
+        }
+        if ((e = hipMalloc((void **)&d_tok, (size_t)max_regions * dfl::TOK_CAP * sizeof(uint32_t))) != hipSuccess) return fail(e, "tokens");
+        if ((e = hipMalloc((void **)&d_prior, 2 * dfl::PRIOR_BYTES)) != hipSuccess) return fail(e, "prior");
+        // the first chunk's prices: literals 6 bits, lengths 7, distances 5 -- and 2 bits for A C G T N: FASTQ text
+        // compresses best when the bases stay literals and only long repeats among them become matches, a state the
+        // block-to-block price feedback keeps once it is in it but does not find from zlib's uniform start
+        uint8_t prior[dfl::PRIOR_BYTES];
+        for (int s = 0; s < dfl::NLIT; s++) prior[s] = s < 256 ? 6 : 7;
+        for (const char *c = "ACGTN"; *c; c++) prior[(int)*c] = 2;
+        for (int s = 0; s < dfl::NDIST; s++) prior[dfl::NLIT + s] = 5;
+        if ((e = hipMemcpy(d_prior, prior, sizeof prior, hipMemcpyHostToDevice)) != hipSuccess) return fail(e, "prior copy");
+        if ((e = hipMemcpy(d_prior + dfl::PRIOR_BYTES, prior, sizeof prior, hipMemcpyHostToDevice)) != hipSuccess) return fail(e, "prior copy");
+        return NH_OK;
+    }
+    void destroy() {
+        if (device < 0) return;
+        (void)hipSetDevice(device);
+        if (stream) (void)hipStreamSynchronize(stream);
+        for (Buf &b : buf) {
+            if (b.h_in) (void)hipHostFree(b.h_in);
+            if (b.d_in) (void)hipFree(b.d_in);
+            if (b.d_slots) (void)hipFree(b.d_slots);
+            if (b.d_sizes) (void)hipFree(b.d_sizes);
+            if (b.d_offsets) (void)hipFree(b.d_offsets);
+            if (b.d_out) (void)hipFree(b.d_out);
+            if (b.h_out) (void)hipHostFree(b.h_out);
+            if (b.h_total) (void)hipHostFree(b.h_total);
+            if (b.done) (void)hipEventDestroy(b.done);
+            if (b.k0) (void)hipEventDestroy(b.k0);
+            if (b.k1) (void)hipEventDestroy(b.k1);
+        }
+        if (d_tok) (void)hipFree(d_tok);
+        if (d_prior) (void)hipFree(d_prior);
+        if (stream) (void)hipStreamDestroy(stream);
+        device = -1;
+    }
+    // queues the compression of buf[i] (fill bytes staged in h_in)
+    int submit(int i) {
+        Buf &b = buf[i];
+        hipError_t e = hipSetDevice(device);
+        if (e != hipSuccess) return fail(e, "hipSetDevice");
+        b.n_regions = (uint32_t)((b.fill + REGION - 1) / REGION);
+        if ((e = hipMemcpyAsync(b.d_in, b.h_in, b.fill, hipMemcpyHostToDevice, stream)) != hipSuccess) return fail(e, "H2D");
+        DeflateArgs a{};
+        a.in = b.d_in;
+        a.n = b.fill;
+        a.region = REGION;
+        a.n_regions = b.n_regions;
+        a.slots = b.d_slots;
+        a.slot_stride = slot_stride;
+        a.sizes = b.d_sizes;
+        a.tok = d_tok;
+        a.prior = d_prior + (chunks & 1) * dfl::PRIOR_BYTES;
+        a.prior_out = d_prior + ((chunks + 1) & 1) * dfl::PRIOR_BYTES;
+        (void)hipEventRecord(b.k0, stream);
+        if (gzip_ways() == 4)
+            hipLaunchKernelGGL(dfl::k_deflate<4>, dim3(b.n_regions), dim3(64), 0, stream, a);
+        else
+            hipLaunchKernelGGL(dfl::k_deflate<8>, dim3(b.n_regions), dim3(64), 0, stream, a);
+        hipLaunchKernelGGL(dfl::k_deflate_offsets, dim3(1), dim3(64), 0, stream, b.d_sizes, b.n_regions, b.d_offsets);
+        hipLaunchKernelGGL(dfl::k_deflate_pack, dim3(b.n_regions), dim3(256), 0, stream, b.d_slots, slot_stride, b.d_sizes,
+                           b.d_offsets, b.d_out);
+        (void)hipEventRecord(b.k1, stream);
+        if ((e = hipGetLastError()) != hipSuccess) return fail(e, "launch");
+        if ((e = hipMemcpyAsync(b.h_total, b.d_offsets + b.n_regions, sizeof(uint64_t), hipMemcpyDeviceToHost, stream)) != hipSuccess)
+            return fail(e, "D2H");
+        if ((e = hipEventRecord(b.done, stream)) != hipSuccess) return fail(e, "event");
+        b.in_flight = true;
+        chunks++;
+        return NH_OK;
+    }
+    // waits for buf[i] and brings its stream to h_out; *len = its bytes
+    int collect(int i, size_t *len) {
+        Buf &b = buf[i];
+        hipError_t e = hipSetDevice(device);
+        if (e != hipSuccess) return fail(e, "hipSetDevice");
+        if ((e = hipEventSynchronize(b.done)) != hipSuccess) return fail(e, "kernel");
+        float ms = 0;
+        if (hipEventElapsedTime(&ms, b.k0, b.k1) == hipSuccess) kernel_ms += ms;
+        const uint64_t total = *b.h_total;
+        if (total > (uint64_t)max_regions * slot_stride) return set_error(NH_EDEVICE, "gzip encoder: impossible stream size");
+        if ((e = hipMemcpyAsync(b.h_out, b.d_out, total, hipMemcpyDeviceToHost, stream)) != hipSuccess) return fail(e, "D2H");
+        if ((e = hipStreamSynchronize(stream)) != hipSuccess) return fail(e, "D2H");
+        b.in_flight = false;
+        b.fill = 0;
+        *len = (size_t)total;
+        return NH_OK;
+    }
+};
+
+bool write_fd(int fd, const void *p, size_t n) {
+    const char *c = (const char *)p;
+    while (n) {
+        ssize_t w = ::write(fd, c, n);
+        if (w < 0) {
+            if (errno == EINTR) continue;
+            return false;
+        }
+        c += w;
+        n -= (size_t)w;
+    }
+    return true;
+}
+
+class GpuGzipEncoder : public StreamEncoder {
+public:
+    GpuGzipEncoder(int fd, const char *name) : fd_(fd), name_(name) {}
+    ~GpuGzipEncoder() override { dev_.destroy(); }
+    int init(int device) {
+        const int rc = dev_.init(device);
+        if (rc != NH_OK) return rc;
+        static const unsigned char header[10] = {0x1f, 0x8b, 8, 0, 0, 0, 0, 0, 0, 3};  // no name, no mtime, unix
+        if (!write_fd(fd_, header, sizeof header)) return rc_ = set_error(NH_EIO, "write error on %s", name_.c_str());
+        return NH_OK;
+    }
+    int write(const void *p, size_t n) override {
+        const uint8_t *c = (const uint8_t *)p;
+        while (n && rc_ == NH_OK) {
+            DeflateDev::Buf &b = dev_.buf[cur_];
+            const size_t room = DeflateDev::CHUNK - b.fill;
+            const size_t take = n < room ? n : room;
+            memcpy(b.h_in + b.fill, c, take);
+            crc_ = crc32_fast(crc_, c, take);
+            b.fill += take;
+            total_ += take;
+            c += take;
+            n -= take;
+            if (b.fill == DeflateDev::CHUNK) rotate();
+        }
+        return rc_;
+    }
+    int finish() override {
+        if (rc_ == NH_OK && dev_.buf[cur_].fill) rotate();
+        for (int k = 0; k < DeflateDev::NBUF && rc_ == NH_OK; k++) retire((cur_ + k) % DeflateDev::NBUF);
+        if (rc_ != NH_OK) return rc_;
+        unsigned char tail[10] = {0x03, 0x00};  // final block: fixed codes, end-of-block only
+        for (int i = 0; i < 4; i++) {
+            tail[2 + i] = (unsigned char)(crc_ >> (8 * i));
+            tail[6 + i] = (unsigned char)((uint32_t)total_ >> (8 * i));
+        }
+        if (!write_fd(fd_, tail, sizeof tail)) rc_ = set_error(NH_EIO, "write error on %s", name_.c_str());
+        return rc_;
+    }
+    double kernel_ms() const { return dev_.kernel_ms; }
+    uint64_t bytes_out() const { return out_bytes_; }
+
+private:
+    // the current chunk goes to the GPU; the next one is filled while it is compressed -- after the chunk that
+    // used that buffer before has been written
+    void rotate() {
+        if ((rc_ = dev_.submit(cur_)) != NH_OK) return;
+        cur_ = (cur_ + 1) % DeflateDev::NBUF;
+        retire(cur_);
+    }
+    void retire(int i) {
+        if (!dev_.buf[i].in_flight || rc_ != NH_OK) return;
+        size_t len = 0;
+        if ((rc_ = dev_.collect(i, &len)) != NH_OK) return;
+        if (!write_fd(fd_, dev_.buf[i].h_out, len)) rc_ = set_error(NH_EIO, "write error on %s", name_.c_str());
+        out_bytes_ += len;
+    }
+    int fd_;
+    std::string name_;
+    DeflateDev dev_;
+    int cur_ = 0;
+    uint32_t crc_ = 0;
+    uint64_t total_ = 0, out_bytes_ = 0;
+    int rc_ = NH_OK;
+};
+
+}  // namespace
+
+StreamEncoder *make_gpu_gzip_encoder(int fd, int device, const char *name) {
+    GpuGzipEncoder *e = new GpuGzipEncoder(fd, name);
+    if (e->init(device) != NH_OK) {
+        delete e;
+        return nullptr;
+    }
+    return e;
+}
+
+}  // namespace nh
+
+// One gzip member of a host buffer through the GPU encoder, to a file: what tests and bench.py drive.
+// stats: [0] bytes written, [1] kernel microseconds (HIP events around the three kernels of every chunk).
+extern "C" int nh_gzip_gpu_file(int32_t device, const void *in, uint64_t n, const char *out_path, uint64_t *stats) {
+    if ((!in && n) || !out_path) return nh::set_error(NH_EINVAL, "nh_gzip_gpu_file: null argument");
+    int fd = ::open(out_path, O_WRONLY | O_CREAT | O_TRUNC | O_CLOEXEC, 0666);
+    if (fd < 0) return nh::set_error(NH_EIO, "cannot create %s", out_path);
+    int rc = NH_OK;
+    {
+        nh::GpuGzipEncoder enc(fd, out_path);
+        rc = enc.init(device);
+        if (rc == NH_OK) rc = enc.write(in, (size_t)n);
+        if (rc == NH_OK) rc = enc.finish();
+        if (stats) {
+            stats[0] = enc.bytes_out() + 20;
+            stats[1] = (uint64_t)(enc.kernel_ms() * 1000.0);
+        }
+    }
+    if (::close(fd) != 0 && rc == NH_OK) rc = nh::set_error(NH_EIO, "write error on %s", out_path);
+    return rc;
+}

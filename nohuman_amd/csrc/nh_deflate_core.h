@@ -1,0 +1,365 @@
+// nh_deflate_core.h -- the lane-level and sequential pieces of the DEFLATE (RFC 1951) encoder behind the gzip
+// output of nh_run (the reference's stage is gzip_compress,
+// /root/reference/src/compression.rs:214-233: gzp's block-parallel encoder at the default level).  Everything here
+// is plain integer code that compiles for the device (nh_deflate.hip: one wave per region of the text) and for the
+// host (tools/deflate_model.cpp, tests/test_deflate_core.py: the same functions driven by a 64-lane loop), so that
+// the format logic -- symbol mapping, code construction, the block header -- is checked on a CPU against zlib's
+// inflate before a GPU sees it.  Written from RFC 1951; the code-length construction is the in-place minimum
+// redundancy algorithm of Moffat and Katajainen (1995), the length limit a Kraft-sum repair.
+#pragma once
+#include <stdint.h>
+
+#if defined(__HIPCC__)
+#define NH_HD __host__ __device__
+#else
+#define NH_HD
+#endif
+
+namespace nh {
+namespace dfl {
+
+constexpr int NLIT = 288;   // literal / length alphabet (286 used; 288 keeps tables a multiple of 32)
+constexpr int NLIT_USED = 286;
+constexpr int NDIST = 32;   // distance alphabet (30 used)
+constexpr int NDIST_USED = 30;
+constexpr int NCL = 19;     // code-length alphabet
+constexpr int MAXBITS = 15, MAXBITS_CL = 7;
+constexpr uint32_t MIN_MATCH = 3, MAX_MATCH = 258, WINDOW = 32768;
+
+// a token: literal = the byte; match = bit 31 | (length - 3) << 16 | (distance - 1)
+NH_HD inline uint32_t tok_match(uint32_t len, uint32_t dist) { return 0x80000000u | ((len - 3u) << 16) | (dist - 1u); }
+
+NH_HD inline uint32_t ilog2(uint32_t v) { return 31u - (uint32_t)__builtin_clz(v); }
+
+// length - 3 -> symbol 257.., number of extra bits and their value (RFC 1951 3.2.5)
+NH_HD inline void len_symbol(uint32_t lc, uint32_t &sym, uint32_t &eb, uint32_t &ev) {
+    if (lc < 8u) {
+        sym = 257u + lc;
+        eb = 0;
+        ev = 0;
+    } else if (lc == 255u) {
+        sym = 285u;
+        eb = 0;
+        ev = 0;
+    } else {
+        eb = ilog2(lc) - 2u;
+        sym = 261u + 4u * eb + ((lc - (4u << eb)) >> eb);
+        ev = lc & ((1u << eb) - 1u);
+    }
+}
+// distance - 1 -> symbol 0..29
+NH_HD inline void dist_symbol(uint32_t d, uint32_t &sym, uint32_t &eb, uint32_t &ev) {
+    if (d < 4u) {
+        sym = d;
+        eb = 0;
+        ev = 0;
+    } else {
+        const uint32_t hb = ilog2(d);
+        eb = hb - 1u;
+        sym = 2u * hb + ((d >> (hb - 1u)) & 1u);
+        ev = d & ((1u << eb) - 1u);
+    }
+}
+NH_HD inline uint32_t len_extra_bits(uint32_t sym) {  // sym 257..285
+    return (sym < 265u || sym == 285u) ? 0u : (sym - 261u) >> 2;
+}
+NH_HD inline uint32_t dist_extra_bits(uint32_t dsym) { return dsym < 4u ? 0u : (dsym >> 1) - 1u; }
+
+NH_HD inline uint32_t bitrev(uint32_t v, uint32_t n) {  // the low n bits of v, reversed
+    uint32_t r = 0;
+    for (uint32_t i = 0; i < n; i++) r |= ((v >> i) & 1u) << (n - 1u - i);
+    return r;
+}
+
+// In: a[0..n) = the frequencies of the n >= 2 used symbols in ascending order.  Out: a[i] = the code length of the
+// i-th of them in an unrestricted Huffman code (non-increasing in i).  Three passes, in place.
+NH_HD inline void huff_depths_sorted(uint32_t *a, int n) {
+    if (n == 2) {
+        a[0] = a[1] = 1;
+        return;
+    }
+    a[0] += a[1];
+    int root = 0, leaf = 2;
+    for (int next = 1; next < n - 1; next++) {
+        if (leaf >= n || a[root] < a[leaf]) {
+            a[next] = a[root];
+            a[root++] = (uint32_t)next;
+        } else {
+            a[next] = a[leaf++];
+        }
+        if (leaf >= n || (root < next && a[root] < a[leaf])) {
+            a[next] += a[root];
+            a[root++] = (uint32_t)next;
+        } else {
+            a[next] += a[leaf++];
+        }
+    }
+    a[n - 2] = 0;
+    for (int next = n - 3; next >= 0; next--) a[next] = a[a[next]] + 1u;
+    int avail = 1, used = 0, depth = 0;
+    int r = n - 2, next = n - 1;
+    while (avail > 0) {
+        while (r >= 0 && (int)a[r] == depth) {
+            used++;
+            r--;
+        }
+        while (avail > used) {
+            a[next--] = (uint32_t)depth;
+            avail--;
+        }
+        avail = 2 * used;
+        depth++;
+        used = 0;
+    }
+}
+
+// Lengths of a code over nsym symbols, none longer than maxbits, from the used symbols sorted by ascending
+// frequency: sorted_sym[i] with frequency a[i] (a is overwritten).  lens[] gets 0 for unused symbols.
+NH_HD inline void huff_lengths_sorted(uint32_t *a, const uint16_t *sorted_sym, int n, int nsym, int maxbits,
+                                      uint8_t *lens) {
+    for (int s = 0; s < nsym; s++) lens[s] = 0;
+    huff_depths_sorted(a, n);
+    uint32_t cnt[MAXBITS + 2];
+    for (int l = 0; l <= maxbits + 1; l++) cnt[l] = 0;
+    for (int i = 0; i < n; i++) cnt[a[i] > (uint32_t)maxbits ? (uint32_t)maxbits : a[i]]++;
+    // Kraft sum in units of 2^-maxbits; while it is above one: a code of the longest length is given up and a
+    // shorter code is lengthened by one bit to take its sibling's place -- one unit less each time
+    uint32_t total = 0;
+    for (int l = 1; l <= maxbits; l++) total += cnt[l] << (maxbits - l);
+    while (total > (1u << maxbits)) {
+        cnt[maxbits]--;
+        for (int l = maxbits - 1; l > 0; l--)
+            if (cnt[l]) {
+                cnt[l]--;
+                cnt[l + 1] += 2;
+                break;
+            }
+        total--;
+    }
+    int i = 0;  // the rarest symbols take the longest codes
+    for (int l = maxbits; l >= 1; l--)
+        for (uint32_t c = 0; c < cnt[l]; c++) lens[sorted_sym[i++]] = (uint8_t)l;
+}
+
+// canonical codes (RFC 1951 3.2.2), stored bit-reversed: ready to be emitted least significant bit first
+NH_HD inline void huff_codes(const uint8_t *lens, int nsym, int maxbits, uint16_t *codes) {
+    uint32_t cnt[MAXBITS + 2], next[MAXBITS + 2];
+    for (int l = 0; l <= maxbits; l++) cnt[l] = 0;
+    for (int s = 0; s < nsym; s++) cnt[lens[s]]++;
+    cnt[0] = 0;
+    uint32_t code = 0;
+    next[0] = 0;
+    for (int l = 1; l <= maxbits; l++) {
+        code = (code + cnt[l - 1]) << 1;
+        next[l] = code;
+    }
+    for (int s = 0; s < nsym; s++) {
+        const uint32_t l = lens[s];
+        codes[s] = l ? (uint16_t)bitrev(next[l]++, l) : (uint16_t)0;
+    }
+}
+
+// Run-length form of the hlit + hdist code lengths (RFC 1951 3.2.7): item i = symbol 0..18 in the low 5 bits, the
+// value of its extra bits above.  Returns the number of items (at most n) and counts the symbols into clfreq[19].
+NH_HD inline int rle_lengths(const uint8_t *lens, int n, uint16_t *items, uint32_t *clfreq) {
+    for (int s = 0; s < NCL; s++) clfreq[s] = 0;
+    int ni = 0, i = 0;
+    while (i < n) {
+        const uint32_t v = lens[i];
+        int run = 1;
+        while (i + run < n && lens[i + run] == v) run++;
+        i += run;
+        if (v == 0) {
+            while (run >= 11) {
+                const int r = run > 138 ? 138 : run;
+                items[ni++] = (uint16_t)(18u | ((uint32_t)(r - 11) << 5));
+                clfreq[18]++;
+                run -= r;
+            }
+            if (run >= 3) {
+                items[ni++] = (uint16_t)(17u | ((uint32_t)(run - 3) << 5));
+                clfreq[17]++;
+                run = 0;
+            }
+        } else {
+            items[ni++] = (uint16_t)v;  // the length itself, then copies of it
+            clfreq[v]++;
+            run--;
+            while (run >= 3) {
+                const int r = run > 6 ? 6 : run;
+                items[ni++] = (uint16_t)(16u | ((uint32_t)(r - 3) << 5));
+                clfreq[16]++;
+                run -= r;
+            }
+        }
+        for (; run > 0; run--) {
+            items[ni++] = (uint16_t)v;
+            clfreq[v]++;
+        }
+    }
+    return ni;
+}
+NH_HD inline uint32_t cl_extra_bits(uint32_t sym) { return sym == 16u ? 2u : sym == 17u ? 3u : sym == 18u ? 7u : 0u; }
+// the order in which the code-length code's own lengths are stored
+NH_HD inline uint32_t cl_order(int i) {
+    const uint8_t o[NCL] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15};
+    return o[i];
+}
+
+// ---- match finding, one position ------------------------------------------------------------------------------
+// the bucket and the tag of the four bytes at a position
+NH_HD inline uint32_t hash4(uint32_t four) { return four * 2654435761u; }
+constexpr uint32_t BUCKET_BITS = 10, TAG_BITS = 15, POS_BITS = 17;
+constexpr uint32_t EMPTY_ENTRY = 0xFFFFFFFFu;  // position 2^17 - 1: never below a position of a region (regions are shorter)
+constexpr uint32_t MAX_REGION = (1u << POS_BITS) - 1u;
+NH_HD inline uint32_t hash_bucket(uint32_t h) { return h >> (32u - BUCKET_BITS); }
+NH_HD inline uint32_t hash_tag(uint32_t h) { return (h >> (32u - BUCKET_BITS - TAG_BITS)) & ((1u << TAG_BITS) - 1u); }
+NH_HD inline uint32_t make_entry(uint32_t h, uint32_t pos) { return (hash_tag(h) << POS_BITS) | pos; }
+
+NH_HD inline uint64_t load8(const uint8_t *p) {  // eight bytes at any address (little endian)
+    struct __attribute__((packed)) U {
+        uint64_t v;
+    };
+    return ((const U *)p)->v;
+}
+// number of equal leading bytes of the strings at a and b, at most cap (reads up to 7 bytes past cap)
+NH_HD inline uint32_t common_prefix(const uint8_t *a, const uint8_t *b, uint32_t from, uint32_t cap) {
+    uint32_t len = from;
+    while (len < cap) {
+        const uint64_t x = load8(a + len) ^ load8(b + len);
+        if (x) {
+            len += (uint32_t)__builtin_ctzll(x) >> 3;
+            break;
+        }
+        len += 8;
+    }
+    return len < cap ? len : cap;
+}
+
+constexpr uint32_t SCAN_CAP = 32;  // match lengths are measured up to here for every position; a match the parse takes is extended
+
+// what a match costs and what it saves, in bits, under the code lengths of the previous block (lit_cost: 288 + 32
+// entries, 0 = the symbol did not occur there)
+struct Costs {
+    const uint8_t *llen;  // literal / length lengths
+    const uint8_t *dlen;
+};
+NH_HD inline uint32_t cost_or(uint32_t len_bits, uint32_t absent) { return len_bits ? len_bits : absent; }
+// prices of the first eight literals at a position as eight running sums, one per byte of the result
+NH_HD inline uint64_t literal_prices8(const Costs &c, uint64_t cur8) {
+    uint64_t packed = 0;
+    uint32_t acc = 0;
+    for (uint32_t j = 0; j < 8; j++) {
+        acc += cost_or(c.llen[(cur8 >> (8u * j)) & 0xFFu], 12u);
+        packed |= (uint64_t)acc << (8u * j);
+    }
+    return packed;
+}
+// bits saved by coding `len` bytes as a match at `dist` instead of literals (the literals behind the eighth are
+// priced like the first eight on average)
+NH_HD inline int match_gain(const Costs &c, uint64_t lit8, uint32_t len, uint32_t dist) {
+    uint32_t sym, eb, ev, dsym, deb, dev;
+    len_symbol(len - 3u, sym, eb, ev);
+    dist_symbol(dist - 1u, dsym, deb, dev);
+    const int cost = (int)(cost_or(c.llen[sym], 10u) + eb + cost_or(c.dlen[dsym], 8u) + deb);
+    const uint32_t lit = len <= 8u ? (uint32_t)(lit8 >> (8u * (len - 1u))) & 0xFFu : ((uint32_t)(lit8 >> 56) * len) >> 3;
+    return (int)lit - cost;
+}
+
+// The best match for position p of the region src[0..n): candidates are the `ways` entries of the position's
+// bucket (older positions with the same hash tag), the distance of the last match taken (rep) and distances
+// 1..4; the one that saves most bits under `costs` wins.  Returns the length (0: none worth taking, else
+// 3..SCAN_CAP, SCAN_CAP meaning "at least") and sets dist and gain.
+NH_HD inline uint32_t find_match(const uint8_t *src, uint32_t p, uint32_t n, uint32_t h, const uint32_t *entries,
+                                 uint32_t ways, uint32_t rep, const Costs &costs, uint32_t &dist_out, int &gain_out) {
+    const uint32_t room = n - p;
+    const uint32_t cap = room < SCAN_CAP ? room : SCAN_CAP;
+    if (cap < MIN_MATCH) return 0;
+    const uint8_t *cur = src + p;
+    const uint64_t cur8 = load8(cur);
+    const uint64_t lit8 = literal_prices8(costs, cur8);
+    uint32_t best = 0, bdist = 0;
+    int bgain = 0;
+    // distances 1..4 and the repeated distance
+    for (uint32_t k = 0; k < 5; k++) {
+        const uint32_t d = k < 4 ? k + 1u : rep;
+        if (d == 0 || d > p || d > WINDOW || (k == 4 && d <= 4u)) continue;
+        const uint64_t x = load8(cur - d) ^ cur8;
+        uint32_t len = x ? (uint32_t)__builtin_ctzll(x) >> 3 : 8u;
+        if (len >= 8u) len = common_prefix(cur - d, cur, 8, cap);
+        if (len > cap) len = cap;
+        if (len < MIN_MATCH) continue;
+        const int g = match_gain(costs, lit8, len, d);
+        if (g > bgain) {
+            bgain = g;
+            best = len;
+            bdist = d;
+        }
+    }
+    const uint32_t tag = hash_tag(h);
+    if (room >= 4u)
+        for (uint32_t k = 0; k < ways; k++) {
+            const uint32_t e = entries[k];
+            const uint32_t c = e & ((1u << POS_BITS) - 1u);
+            if ((e >> POS_BITS) != tag || c >= p || p - c > WINDOW) continue;
+            const uint32_t len = common_prefix(src + c, cur, 0, cap);
+            if (len < MIN_MATCH) continue;
+            const int g = match_gain(costs, lit8, len, p - c);
+            if (g > bgain) {
+                bgain = g;
+                best = len;
+                bdist = p - c;
+            }
+        }
+    if (best < MIN_MATCH) return 0;
+    dist_out = bdist;
+    gain_out = bgain;
+    return best;
+}
+
+// The two candidates the parse chooses from at position p: the longest match among distances 1..4 and the
+// repeated distance (near) and the longest among the bucket's entries (far); lengths 0 or 3..SCAN_CAP.
+NH_HD inline void find_candidates(const uint8_t *src, uint32_t p, uint32_t n, uint32_t h, const uint32_t *entries,
+                                  uint32_t ways, uint32_t rep, uint32_t &near_len, uint32_t &near_dist,
+                                  uint32_t &far_len, uint32_t &far_dist) {
+    near_len = far_len = 0;
+    near_dist = far_dist = 0;
+    const uint32_t room = n - p;
+    const uint32_t cap = room < SCAN_CAP ? room : SCAN_CAP;
+    if (cap < MIN_MATCH) return;
+    const uint8_t *cur = src + p;
+    const uint64_t cur8 = load8(cur);
+    for (uint32_t k = 0; k < 5; k++) {
+        const uint32_t d = k < 4 ? k + 1u : rep;
+        if (d == 0 || d > p || d > WINDOW || (k == 4 && d <= 4u)) continue;
+        const uint64_t x = load8(cur - d) ^ cur8;
+        uint32_t len = x ? (uint32_t)__builtin_ctzll(x) >> 3 : 8u;
+        if (len >= 8u) len = common_prefix(cur - d, cur, 8, cap);
+        if (len > cap) len = cap;
+        if (len >= MIN_MATCH && len > near_len) {
+            near_len = len;
+            near_dist = d;
+        }
+    }
+    const uint32_t tag = hash_tag(h);
+    if (room >= 4u)
+        for (uint32_t k = 0; k < ways; k++) {
+            const uint32_t e = entries[k];
+            const uint32_t c = e & ((1u << POS_BITS) - 1u);
+            if ((e >> POS_BITS) != tag || c >= p || p - c > WINDOW) continue;
+            const uint32_t len = common_prefix(src + c, cur, 0, cap);
+            if (len >= MIN_MATCH && (len > far_len || (len == far_len && p - c < far_dist))) {
+                far_len = len;
+                far_dist = p - c;
+            }
+        }
+}
+NH_HD inline uint32_t match_price(const Costs &c, uint32_t len, uint32_t dist) {
+    uint32_t sym, eb, ev, dsym, deb, dev;
+    len_symbol(len - 3u, sym, eb, ev);
+    dist_symbol(dist - 1u, dsym, deb, dev);
+    return cost_or(c.llen[sym], 10u) + eb + cost_or(c.dlen[dsym], 8u) + deb;
+}
+
+}  // namespace dfl
+}  // namespace nh

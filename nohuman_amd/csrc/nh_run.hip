@@ -44,12 +44,12 @@ struct OutFile {
     std::vector<char> is_scratch;  // per span: iov_base is an offset into scratch
     std::string scratch;
     std::unique_ptr<StreamEncoder> enc;  // set: the spans go through a streaming encoder
-    int open(const char *p, int codec = NH_CODEC_NONE, unsigned codec_threads = 1) {
+    int open(const char *p, int codec = NH_CODEC_NONE, unsigned codec_threads = 1, int device = -1) {
         path = p;
         fd = ::open(p, O_WRONLY | O_CREAT | O_TRUNC | O_CLOEXEC, 0666);
         if (fd < 0) return set_error(NH_EIO, "cannot create %s", p);
         if (codec != NH_CODEC_NONE) {
-            enc.reset(make_encoder(codec, fd, codec_threads ? codec_threads : 1, p));
+            enc.reset(make_encoder(codec, fd, codec_threads ? codec_threads : 1, p, device));
             if (!enc) return NH_EINVAL;  // message set by make_encoder
         }
         return NH_OK;
@@ -616,8 +616,9 @@ int run_engines(const std::vector<Engine *> &engines, const nh_run_args *a, nh_s
     int rc;
     if (a->out_codec < NH_CODEC_NONE || a->out_codec > NH_CODEC_ZSTD)
         return set_error(NH_EINVAL, "nh_run: unknown out_codec %d", a->out_codec);
-    if ((rc = o1.open(a->out1, a->out_codec, a->codec_threads))) return rc;
-    if (rs.paired && (rc = o2.open(a->out2, a->out_codec, a->codec_threads))) return rc;
+    // gzip output is encoded on the GPU (nh_deflate.hip); with two devices each mate file has its own
+    if ((rc = o1.open(a->out1, a->out_codec, a->codec_threads, engines[0]->device))) return rc;
+    if (rs.paired && (rc = o2.open(a->out2, a->out_codec, a->codec_threads, engines[engines.size() > 1 ? 1 : 0]->device))) return rc;
     if (rs.want_k && (rc = ok.open(a->kraken_output))) return rc;
 
     // fragments per batch: ~96 MB of sequence, at most 262144; both readers cut at the same record

@@ -1,0 +1,95 @@
+"""gzip output encoded on the GPU (nohuman_amd/csrc/nh_deflate.hip; SURVEY.md 8f-4, the reference's stage is
+compression.rs:214-233).  Parity target is the decompressed content (compression.rs:282-288): every stream is
+inflated by zlib -- which also checks the member's CRC-32 and length -- and by this repo's own parallel reader."""
+import ctypes as C
+import gzip
+import os
+import sys
+import zlib
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from nohuman_amd import _lib  # noqa: E402
+
+pytestmark = pytest.mark.gpu
+
+
+def gpu_gzip(data, path):
+    L = _lib.lib()
+    stats = (C.c_uint64 * 2)()
+    buf = (C.c_char * max(1, len(data))).from_buffer_copy(data if data else b"\0")
+    rc = L.nh_gzip_gpu_file(0, buf, len(data), os.fsencode(path), stats)
+    assert rc == 0, _lib.lib().nh_last_error().decode()
+    assert os.path.getsize(path) == stats[0]
+    return stats[0], stats[1]
+
+
+def fastq_text(n_reads, seed):
+    rng = np.random.default_rng(seed)
+    out = []
+    for i in range(n_reads):
+        L = 150
+        seq = "".join("ACGT"[c] for c in rng.integers(0, 4, L))
+        q = np.where(rng.random(L) < 0.06, ord(":"), ord("F")).astype(np.uint8)
+        cut = int(L * (0.3 + 0.7 * rng.random() ** 0.4))
+        q[cut:] = rng.choice(np.frombuffer(b"F:,#", dtype=np.uint8), L - cut)
+        out.append("@NH1:7:HGF2YDSXX:1:%d:%d:%d 1:N:0:GATTACAG\n%s\n+\n%s\n"
+                   % (1101 + i // 5000, 10000 + int(rng.integers(0, 25000)), 10000 + (i * 17) // 10, seq,
+                      q.tobytes().decode()))
+    return "".join(out).encode()
+
+
+def check(data, path):
+    size, _ = gpu_gzip(data, path)
+    raw = open(path, "rb").read()
+    assert raw[:3] == b"\x1f\x8b\x08"
+    assert gzip.decompress(raw) == data          # zlib: content, CRC-32, ISIZE
+    d = zlib.decompressobj(31)                    # one member, nothing behind it
+    assert d.decompress(raw) == data and d.eof and d.unused_data == b""
+    return size
+
+
+@pytest.mark.parametrize("n", [0, 1, 2, 3, 4, 5, 63, 64, 65, 257, 258, 259, 4095, 65535, 65536, 65537, 131072, 200001])
+def test_sizes_around_step_block_and_region_edges(tmp_path, n):
+    rng = np.random.default_rng(n)
+    text = fastq_text(max(1, n // 300 + 1), n)
+    data = (text * (n // len(text) + 1))[:n]
+    check(data, str(tmp_path / "a.gz"))
+    # and bytes with no structure at all: stored blocks
+    check(rng.integers(0, 256, n, dtype=np.uint8).tobytes(), str(tmp_path / "b.gz"))
+
+
+def test_fastq_text_ratio_and_own_reader(tmp_path):
+    data = fastq_text(40000, 7)
+    size = check(data, str(tmp_path / "a.gz"))
+    z6 = len(zlib.compress(data, 6))
+    print("GPU gzip %.3f : 1, zlib -6 %.3f : 1" % (len(data) / size, len(data) / z6))
+    assert size < 1.12 * z6, "ratio fell behind zlib -6 by more than 12 %"
+    # the repo's own reader (speculative parallel inflate) takes the stream as well
+    out = str(tmp_path / "a.txt")
+    st = (C.c_uint64 * 3)()
+    rc = _lib.lib().nh_gunzip_file(os.fsencode(str(tmp_path / "a.gz")), os.fsencode(out), 4, 1 << 20, st)
+    assert rc == 0, _lib.lib().nh_last_error().decode()
+    assert open(out, "rb").read() == data
+
+
+def test_runs_long_matches_and_every_byte_value(tmp_path):
+    rng = np.random.default_rng(3)
+    parts = [b"\0" * 100000, bytes(range(256)) * 300, b"A" * 70000, b"ACGT" * 20000,
+             rng.integers(0, 256, 50000, dtype=np.uint8).tobytes(), b"F" * 258, b"F" * 259, b"xyz" * 5,
+             rng.integers(0, 4, 90000, dtype=np.uint8).tobytes()]
+    check(b"".join(parts), str(tmp_path / "a.gz"))
+    # a block whose symbols force long codes: geometric counts
+    geo = b"".join(bytes([i]) * (1 << min(i, 14)) for i in range(24))
+    check(geo + bytes(rng.permutation(np.frombuffer(geo, dtype=np.uint8))), str(tmp_path / "b.gz"))
+
+
+def test_several_chunks(tmp_path):
+    """More than one 64 MiB chunk: two buffers in flight, the prices handed from chunk to chunk."""
+    unit = fastq_text(20000, 11)
+    data = unit * (150_000_000 // len(unit))
+    size = check(data, str(tmp_path / "a.gz"))
+    assert size < len(data) / 3
