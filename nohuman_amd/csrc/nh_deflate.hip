@@ -5,7 +5,7 @@
 // into regions of 64 KiB and ONE WAVE compresses a region:
 //
 //   match finding   64 consecutive positions per step, a lane each: hash of 4 bytes -> an 8-way bucket of earlier
-//                   positions (tagged, in LDS), plus the last match's distance and distances 1..4; the candidate
+//                   positions (16 bits each, in LDS), plus the last match's distance and distances 1..4; the candidate
 //                   that saves most bits under the PREVIOUS block's code lengths wins (find_match, nh_deflate_core.h).
 //   parse           lazy rule by a lane shift, then the chain of tokens through the step with v_readlane; a match
 //                   that reached the scan cap is extended by the whole wave at once (8 bytes a lane).
@@ -56,6 +56,7 @@ struct DeflateArgs {
     uint32_t *tok;          // n_regions x TOK_CAP
     const uint8_t *prior;   // PRIOR_BYTES: literal/length lengths then distance lengths; the starting prices
     uint8_t *prior_out;     // region 0 leaves its last block's lengths here
+    unsigned long long *prof;  // NULL, or 8 counters the waves add their phase times to (NOHUMAN_GZIP_PROF)
 };
 
 __device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v, int lane) {
@@ -150,7 +151,7 @@ __device__ void build_tree_wave(uint32_t *freq, int nsym, int maxbits, uint8_t *
 
 template <int WAYS>
 struct __attribute__((aligned(16))) RegionLds {
-    uint32_t bucket[WAYS << BUCKET_BITS];
+    uint16_t bucket[WAYS << BUCKET_BITS];
     uint32_t lfreq[NLIT];
     uint32_t dfreq[NDIST];
     uint32_t clfreq[32];
@@ -257,7 +258,7 @@ __global__ __launch_bounds__(64) void k_deflate(DeflateArgs a) {
     const uint32_t n = (uint32_t)((a.n - base) < (uint64_t)a.region ? (a.n - base) : (uint64_t)a.region);
     const uint8_t *src = a.in + base;
     uint32_t *tok = a.tok + (size_t)r * TOK_CAP;
-    for (uint32_t i = (uint32_t)lane; i < (uint32_t)(WAYS << BUCKET_BITS); i += 64) S.bucket[i] = EMPTY_ENTRY;
+    for (uint32_t i = (uint32_t)lane; i < (uint32_t)(WAYS << BUCKET_BITS); i += 64) S.bucket[i] = (uint16_t)EMPTY_ENTRY;
     for (int i = lane; i < NLIT; i += 64) {
         S.lfreq[i] = 0;
         S.llen[i] = a.prior[i];
@@ -271,27 +272,28 @@ __global__ __launch_bounds__(64) void k_deflate(DeflateArgs a) {
     BitOut bo{S.ob, (uint32_t *)(a.slots + (size_t)r * a.slot_stride), 0u, 0u};
     uint32_t carry = 0, rep = 0, ntok = 0, blk_from = 0;
     const uint64_t lt_mask = (1ull << lane) - 1ull;
+    Bytes16 next16 = load16(src + lane);
+    unsigned long long t_match = 0, t_parse = 0, t_block = 0, t_all = __builtin_amdgcn_s_memtime();
     for (uint32_t s = 0; s < n; s += 64) {
+        const unsigned long long c0 = a.prof ? __builtin_amdgcn_s_memtime() : 0ull;
         const uint32_t p = s + (uint32_t)lane;
         const bool inside = p < n;
         const bool any = carry < s + 64u;
-        uint32_t four = 0;
-        if (inside) {
-            struct __attribute__((packed)) U4 {
-                uint32_t v;
-            };
-            four = ((const U4 *)(src + p))->v;
-        }
+        // the sixteen bytes at this lane's position were loaded during the previous step
+        const Bytes16 cur16 = next16;
+        if (s + 64u < n) next16 = load16(src + p + 64u);
+        const uint32_t four = (uint32_t)cur16.lo;
         const bool has4 = p + 4u <= n;
         const uint32_t h = hash4(four);
         uint32_t L = 0, D = 0;
         if (any && inside && p >= carry) {
             const Costs costs{S.llen, S.dlen};
             int gain = 0;
-            L = find_match(src, p, n, h, &S.bucket[WAYS * hash_bucket(h)], WAYS, rep, costs, D, gain);
+            L = find_match<WAYS>(src, p, n, cur16, &S.bucket[WAYS * hash_bucket(h)], rep, costs, D, gain);
         }
         __syncthreads();
-        if (has4) S.bucket[WAYS * hash_bucket(h) + ((p >> 6) % WAYS)] = make_entry(h, p);
+        const unsigned long long c1 = a.prof ? __builtin_amdgcn_s_memtime() : 0ull;
+        if (has4) S.bucket[WAYS * hash_bucket(h) + ((p >> 6) % WAYS)] = make_entry(p);
         if (any) {
             // lazy rule: a longer match one position on wins over a short one here
             const uint32_t nx = (uint32_t)__shfl_down((int)L, 1);
@@ -299,7 +301,17 @@ __global__ __launch_bounds__(64) void k_deflate(DeflateArgs a) {
             uint64_t sel = 0;
             uint32_t q = carry > s ? carry - s : 0u;
             const uint32_t qend = n - s < 64u ? n - s : 64u;
+            const uint64_t mm = __ballot(L != 0);
             while (q < qend) {
+                // literals up to the next position with a match are taken in one go
+                const uint64_t ahead = mm >> q;
+                const uint32_t m = ahead ? q + (uint32_t)__builtin_ctzll(ahead) : 64u;
+                const uint32_t stop = m < qend ? m : qend;
+                if (stop > q) {
+                    sel |= (stop >= 64u ? ~0ull : (1ull << stop) - 1ull) & ~((1ull << q) - 1ull);
+                    q = stop;
+                    continue;
+                }
                 uint32_t l = readlane_u(L, q);
                 if (l == SCAN_CAP) {  // the wave measures the rest of the match: 8 bytes a lane
                     const uint32_t d = readlane_u(D, q), cpos = s + q;
@@ -307,15 +319,15 @@ __global__ __launch_bounds__(64) void k_deflate(DeflateArgs a) {
                     const uint32_t off = SCAN_CAP + 8u * (uint32_t)lane;
                     const bool within = off < maxl;
                     const uint64_t x = within ? (load8(src + cpos + off) ^ load8(src + cpos - d + off)) : 1ull;
-                    const uint64_t stop = __ballot(x != 0);
-                    const uint32_t f = (uint32_t)__builtin_ctzll(stop);
+                    const uint64_t stopm = __ballot(x != 0);
+                    const uint32_t f = (uint32_t)__builtin_ctzll(stopm);
                     uint32_t tl = off + (within ? (uint32_t)__builtin_ctzll(x) >> 3 : 0u);
                     tl = readlane_u(tl, f);
                     l = tl < maxl ? tl : maxl;
                     if ((uint32_t)lane == q) L = l;
                 }
                 sel |= 1ull << q;
-                q += l ? l : 1u;
+                q += l;
             }
             carry = s + q;
             const uint64_t msel = __ballot(L != 0) & sel;
@@ -337,6 +349,9 @@ __global__ __launch_bounds__(64) void k_deflate(DeflateArgs a) {
             ntok += (uint32_t)__popcll(sel);
         }
         __syncthreads();
+        const unsigned long long c2 = a.prof ? __builtin_amdgcn_s_memtime() : 0ull;
+        t_match += c1 - c0;
+        t_parse += c2 - c1;
         if (carry - blk_from >= BLOCK_IN || s + 64u >= n) {
             const uint32_t to = carry < n ? carry : n;
             __threadfence_block();
@@ -346,7 +361,15 @@ __global__ __launch_bounds__(64) void k_deflate(DeflateArgs a) {
             __syncthreads();
             blk_from = to;
             ntok = 0;
+            if (a.prof) t_block += __builtin_amdgcn_s_memtime() - c2;
         }
+    }
+    if (a.prof && lane == 0) {
+        atomicAdd(&a.prof[0], t_match);
+        atomicAdd(&a.prof[1], t_parse);
+        atomicAdd(&a.prof[2], t_block);
+        atomicAdd(&a.prof[3], __builtin_amdgcn_s_memtime() - t_all);
+        atomicAdd(&a.prof[4], 1ull);
     }
     // the region ends on a byte boundary: an empty stored block (BFINAL 0, BTYPE 0, padding, LEN 0, NLEN 0xFFFF)
     {
@@ -402,7 +425,15 @@ int gzip_ways() {
 
 struct DeflateDev {  // device side of one encoder: buffers for chunks in flight
     static constexpr size_t CHUNK = 64u << 20;
-    static constexpr uint32_t REGION = 65536;
+    static uint32_t region_bytes() {  // NOHUMAN_GZIP_REGION: tuning (bytes of text a wave compresses)
+        static const uint32_t r = [] {
+            const char *e = getenv("NOHUMAN_GZIP_REGION");
+            const long v = e ? atol(e) : 65536;
+            return (uint32_t)(v < 4096 ? 4096 : v > (long)dfl::MAX_REGION ? (long)dfl::MAX_REGION : v);
+        }();
+        return r;
+    }
+    const uint32_t REGION = region_bytes();
     static constexpr int NBUF = 2;
     int device = -1;
     hipStream_t stream = nullptr;
@@ -422,6 +453,7 @@ struct DeflateDev {  // device side of one encoder: buffers for chunks in flight
     } buf[NBUF];
     uint32_t *d_tok = nullptr;
     uint8_t *d_prior = nullptr;  // two rows, alternating
+    unsigned long long *d_prof = nullptr;
     uint32_t slot_stride = 0, max_regions = 0;
     uint64_t chunks = 0;
     double kernel_ms = 0;
@@ -461,6 +493,10 @@ struct DeflateDev {  // device side of one encoder: buffers for chunks in flight
         for (int s = 0; s < dfl::NDIST; s++) prior[dfl::NLIT + s] = 5;
         if ((e = hipMemcpy(d_prior, prior, sizeof prior, hipMemcpyHostToDevice)) != hipSuccess) return fail(e, "prior copy");
         if ((e = hipMemcpy(d_prior + dfl::PRIOR_BYTES, prior, sizeof prior, hipMemcpyHostToDevice)) != hipSuccess) return fail(e, "prior copy");
+        if (getenv("NOHUMAN_GZIP_PROF")) {
+            if ((e = hipMalloc((void **)&d_prof, 64)) != hipSuccess) return fail(e, "prof");
+            (void)hipMemset(d_prof, 0, 64);
+        }
         return NH_OK;
     }
     void destroy() {
@@ -482,6 +518,14 @@ struct DeflateDev {  // device side of one encoder: buffers for chunks in flight
         }
         if (d_tok) (void)hipFree(d_tok);
         if (d_prior) (void)hipFree(d_prior);
+        if (d_prof) {
+            unsigned long long h[8] = {};
+            (void)hipMemcpy(h, d_prof, 64, hipMemcpyDeviceToHost);
+            if (h[4])
+                fprintf(stderr, "[gzip prof] %llu regions: per region (100 MHz ticks) match %.0f  insert+parse+tokens %.0f  blocks %.0f  all %.0f\n",
+                        h[4], (double)h[0] / h[4], (double)h[1] / h[4], (double)h[2] / h[4], (double)h[3] / h[4]);
+            (void)hipFree(d_prof);
+        }
         if (stream) (void)hipStreamDestroy(stream);
         device = -1;
     }
@@ -503,6 +547,7 @@ struct DeflateDev {  // device side of one encoder: buffers for chunks in flight
         a.tok = d_tok;
         a.prior = d_prior + (chunks & 1) * dfl::PRIOR_BYTES;
         a.prior_out = d_prior + ((chunks + 1) & 1) * dfl::PRIOR_BYTES;
+        a.prof = d_prof;
         (void)hipEventRecord(b.k0, stream);
         if (gzip_ways() == 4)
             hipLaunchKernelGGL(dfl::k_deflate<4>, dim3(b.n_regions), dim3(64), 0, stream, a);

@@ -65,10 +65,14 @@ NH_HD inline uint32_t len_extra_bits(uint32_t sym) {  // sym 257..285
 }
 NH_HD inline uint32_t dist_extra_bits(uint32_t dsym) { return dsym < 4u ? 0u : (dsym >> 1) - 1u; }
 
-NH_HD inline uint32_t bitrev(uint32_t v, uint32_t n) {  // the low n bits of v, reversed
+NH_HD inline uint32_t bitrev(uint32_t v, uint32_t n) {  // the low n bits of v, reversed (n >= 1)
+#if defined(__clang__)
+    return __builtin_bitreverse32(v) >> (32u - n);
+#else
     uint32_t r = 0;
     for (uint32_t i = 0; i < n; i++) r |= ((v >> i) & 1u) << (n - 1u - i);
     return r;
+#endif
 }
 
 // In: a[0..n) = the frequencies of the n >= 2 used symbols in ascending order.  Out: a[i] = the code length of the
@@ -209,18 +213,33 @@ NH_HD inline uint32_t cl_order(int i) {
 // ---- match finding, one position ------------------------------------------------------------------------------
 // the bucket and the tag of the four bytes at a position
 NH_HD inline uint32_t hash4(uint32_t four) { return four * 2654435761u; }
-constexpr uint32_t BUCKET_BITS = 10, TAG_BITS = 15, POS_BITS = 17;
-constexpr uint32_t EMPTY_ENTRY = 0xFFFFFFFFu;  // position 2^17 - 1: never below a position of a region (regions are shorter)
-constexpr uint32_t MAX_REGION = (1u << POS_BITS) - 1u;
+constexpr uint32_t BUCKET_BITS = 10;
+// a bucket entry is a position of the region in 16 bits (regions are at most 64 KiB); 0xFFFF = empty: the last
+// position of a full region can never be a candidate (candidates lie before the position that asks)
+constexpr uint32_t EMPTY_ENTRY = 0xFFFFu;
+constexpr uint32_t MAX_REGION = 65536u;
 NH_HD inline uint32_t hash_bucket(uint32_t h) { return h >> (32u - BUCKET_BITS); }
-NH_HD inline uint32_t hash_tag(uint32_t h) { return (h >> (32u - BUCKET_BITS - TAG_BITS)) & ((1u << TAG_BITS) - 1u); }
-NH_HD inline uint32_t make_entry(uint32_t h, uint32_t pos) { return (hash_tag(h) << POS_BITS) | pos; }
+NH_HD inline uint16_t make_entry(uint32_t pos) { return (uint16_t)pos; }
 
 NH_HD inline uint64_t load8(const uint8_t *p) {  // eight bytes at any address (little endian)
     struct __attribute__((packed)) U {
         uint64_t v;
     };
     return ((const U *)p)->v;
+}
+struct Bytes16 {
+    uint64_t lo, hi;
+};
+NH_HD inline Bytes16 load16(const uint8_t *p) {  // sixteen bytes at any address
+    struct __attribute__((packed)) U {
+        uint64_t lo, hi;
+    };
+    const U *u = (const U *)p;
+    return Bytes16{u->lo, u->hi};
+}
+NH_HD inline uint32_t equal_bytes16(const Bytes16 &a, const Bytes16 &b) {  // 0..16 equal leading bytes
+    const uint64_t x0 = a.lo ^ b.lo, x1 = a.hi ^ b.hi;
+    return x0 ? (uint32_t)__builtin_ctzll(x0) >> 3 : x1 ? 8u + ((uint32_t)__builtin_ctzll(x1) >> 3) : 16u;
 }
 // number of equal leading bytes of the strings at a and b, at most cap (reads up to 7 bytes past cap)
 NH_HD inline uint32_t common_prefix(const uint8_t *a, const uint8_t *b, uint32_t from, uint32_t cap) {
@@ -266,94 +285,82 @@ NH_HD inline int match_gain(const Costs &c, uint64_t lit8, uint32_t len, uint32_
     return (int)lit - cost;
 }
 
-// The best match for position p of the region src[0..n): candidates are the `ways` entries of the position's
-// bucket (older positions with the same hash tag), the distance of the last match taken (rep) and distances
-// 1..4; the one that saves most bits under `costs` wins.  Returns the length (0: none worth taking, else
-// 3..SCAN_CAP, SCAN_CAP meaning "at least") and sets dist and gain.
-NH_HD inline uint32_t find_match(const uint8_t *src, uint32_t p, uint32_t n, uint32_t h, const uint32_t *entries,
-                                 uint32_t ways, uint32_t rep, const Costs &costs, uint32_t &dist_out, int &gain_out) {
+// The best match for position p of the region src[0..n): candidates are the WAYS entries of the position's
+// bucket (older positions with the same hash), the distance of the last match taken (rep) and distances 1..4; the
+// one that saves most bits under `costs` wins.  cur16 = the sixteen bytes at p (the caller has them from its
+// previous step).  All candidates are compared sixteen bytes at a time in lockstep and the loads of a round are
+// unconditional -- issued back to back, waited for once: on a GPU the rounds' latency is what a step costs.
+// Returns the length (0: none worth taking, else 3..SCAN_CAP, SCAN_CAP meaning "at least") and sets dist and gain.
+template <int WAYS, typename EntryPtr>
+NH_HD inline uint32_t find_match(const uint8_t *src, uint32_t p, uint32_t n, const Bytes16 &cur16, EntryPtr entries,
+                                 uint32_t rep, const Costs &costs, uint32_t &dist_out, int &gain_out) {
+    constexpr int NC = 5 + WAYS;
     const uint32_t room = n - p;
     const uint32_t cap = room < SCAN_CAP ? room : SCAN_CAP;
     if (cap < MIN_MATCH) return 0;
     const uint8_t *cur = src + p;
-    const uint64_t cur8 = load8(cur);
-    const uint64_t lit8 = literal_prices8(costs, cur8);
-    uint32_t best = 0, bdist = 0;
-    int bgain = 0;
-    // distances 1..4 and the repeated distance
-    for (uint32_t k = 0; k < 5; k++) {
-        const uint32_t d = k < 4 ? k + 1u : rep;
-        if (d == 0 || d > p || d > WINDOW || (k == 4 && d <= 4u)) continue;
-        const uint64_t x = load8(cur - d) ^ cur8;
-        uint32_t len = x ? (uint32_t)__builtin_ctzll(x) >> 3 : 8u;
-        if (len >= 8u) len = common_prefix(cur - d, cur, 8, cap);
-        if (len > cap) len = cap;
-        if (len < MIN_MATCH) continue;
-        const int g = match_gain(costs, lit8, len, d);
-        if (g > bgain) {
-            bgain = g;
-            best = len;
-            bdist = d;
+    uint32_t d[NC], len[NC];
+    for (int k = 0; k < 4; k++) d[k] = (uint32_t)(k + 1) <= p ? (uint32_t)(k + 1) : 0u;
+    d[4] = (rep > 4u && rep <= p && rep <= WINDOW) ? rep : 0u;
+    for (int k = 0; k < WAYS; k++) {
+        const uint32_t c = entries[k];
+        const bool ok = room >= 4u && c < p && p - c <= WINDOW && p - c > 4u && p - c != d[4];
+        d[5 + k] = ok ? p - c : 0u;
+    }
+    Bytes16 x[NC];
+    for (int k = 0; k < NC; k++) x[k] = load16(cur - d[k]);  // (distance 0 reads the position itself)
+    for (int k = 0; k < NC; k++) len[k] = d[k] == 0u ? 0u : equal_bytes16(x[k], cur16);
+    if (cap > 16u) {
+        bool any = false;
+        for (int k = 0; k < NC; k++) any |= len[k] == 16u;
+        if (any) {
+            const Bytes16 c2 = load16(cur + 16);
+            for (int k = 0; k < NC; k++) x[k] = load16(cur - d[k] + 16);
+            for (int k = 0; k < NC; k++)
+                if (len[k] == 16u) len[k] += equal_bytes16(x[k], c2);
         }
     }
-    const uint32_t tag = hash_tag(h);
-    if (room >= 4u)
-        for (uint32_t k = 0; k < ways; k++) {
-            const uint32_t e = entries[k];
-            const uint32_t c = e & ((1u << POS_BITS) - 1u);
-            if ((e >> POS_BITS) != tag || c >= p || p - c > WINDOW) continue;
-            const uint32_t len = common_prefix(src + c, cur, 0, cap);
-            if (len < MIN_MATCH) continue;
-            const int g = match_gain(costs, lit8, len, p - c);
-            if (g > bgain) {
-                bgain = g;
-                best = len;
-                bdist = p - c;
-            }
+    // the longest near candidate (distances 1..4, rep) and the longest far one (nearest among equals) are priced;
+    // pricing every candidate finds the same matches on FASTQ text and costs three times the instructions
+    uint32_t nl = 0, nd = 0, fl = 0, fd = 0;
+    for (int k = 0; k < 5; k++)
+        if (len[k] > nl) {
+            nl = len[k];
+            nd = d[k];
         }
+    for (int k = 5; k < NC; k++)
+        if (len[k] > fl || (len[k] == fl && fl != 0u && d[k] < fd)) {
+            fl = len[k];
+            fd = d[k];
+        }
+    nl = nl < cap ? nl : cap;
+    fl = fl < cap ? fl : cap;
+    const uint64_t lit8 = literal_prices8(costs, cur16.lo);
+    uint32_t best = 0, bdist = 0;
+    int bgain = 0;
+    if (nl >= MIN_MATCH) {
+        bgain = match_gain(costs, lit8, nl, nd);
+        if (bgain > 0) {
+            best = nl;
+            bdist = nd;
+        } else {
+            bgain = 0;
+        }
+    }
+    if (fl >= MIN_MATCH) {
+        const int g = match_gain(costs, lit8, fl, fd);
+        if (g > bgain) {
+            bgain = g;
+            best = fl;
+            bdist = fd;
+        }
+    }
     if (best < MIN_MATCH) return 0;
     dist_out = bdist;
     gain_out = bgain;
     return best;
 }
 
-// The two candidates the parse chooses from at position p: the longest match among distances 1..4 and the
-// repeated distance (near) and the longest among the bucket's entries (far); lengths 0 or 3..SCAN_CAP.
-NH_HD inline void find_candidates(const uint8_t *src, uint32_t p, uint32_t n, uint32_t h, const uint32_t *entries,
-                                  uint32_t ways, uint32_t rep, uint32_t &near_len, uint32_t &near_dist,
-                                  uint32_t &far_len, uint32_t &far_dist) {
-    near_len = far_len = 0;
-    near_dist = far_dist = 0;
-    const uint32_t room = n - p;
-    const uint32_t cap = room < SCAN_CAP ? room : SCAN_CAP;
-    if (cap < MIN_MATCH) return;
-    const uint8_t *cur = src + p;
-    const uint64_t cur8 = load8(cur);
-    for (uint32_t k = 0; k < 5; k++) {
-        const uint32_t d = k < 4 ? k + 1u : rep;
-        if (d == 0 || d > p || d > WINDOW || (k == 4 && d <= 4u)) continue;
-        const uint64_t x = load8(cur - d) ^ cur8;
-        uint32_t len = x ? (uint32_t)__builtin_ctzll(x) >> 3 : 8u;
-        if (len >= 8u) len = common_prefix(cur - d, cur, 8, cap);
-        if (len > cap) len = cap;
-        if (len >= MIN_MATCH && len > near_len) {
-            near_len = len;
-            near_dist = d;
-        }
-    }
-    const uint32_t tag = hash_tag(h);
-    if (room >= 4u)
-        for (uint32_t k = 0; k < ways; k++) {
-            const uint32_t e = entries[k];
-            const uint32_t c = e & ((1u << POS_BITS) - 1u);
-            if ((e >> POS_BITS) != tag || c >= p || p - c > WINDOW) continue;
-            const uint32_t len = common_prefix(src + c, cur, 0, cap);
-            if (len >= MIN_MATCH && (len > far_len || (len == far_len && p - c < far_dist))) {
-                far_len = len;
-                far_dist = p - c;
-            }
-        }
-}
 NH_HD inline uint32_t match_price(const Costs &c, uint32_t len, uint32_t dist) {
     uint32_t sym, eb, ev, dsym, deb, dev;
     len_symbol(len - 3u, sym, eb, ev);

@@ -165,16 +165,16 @@ static void emit_block(BitWriter &bw, Block &b, const uint8_t *src, uint32_t in_
 
 // one region, as one wave would do it
 static void deflate_region(BitWriter &bw, const uint8_t *src, uint32_t n, uint32_t block_bytes) {
-    static const uint32_t WAYS = getenv("DFL_WAYS") ? atoi(getenv("DFL_WAYS")) : 4;
+    static const uint32_t WAYS = getenv("DFL_WAYS") ? atoi(getenv("DFL_WAYS")) : 8;
     static const uint32_t BB = getenv("DFL_BB") ? atoi(getenv("DFL_BB")) : BUCKET_BITS;
     static const int keep_prices = getenv("DFL_KEEP") ? atoi(getenv("DFL_KEEP")) : 0;
     static const int lazy_gain = getenv("DFL_LAZYG") ? atoi(getenv("DFL_LAZYG")) : 0;
-    std::vector<uint32_t> bucket((size_t)WAYS << BB, EMPTY_ENTRY);
+    std::vector<uint16_t> bucket((size_t)WAYS << BB, (uint16_t)EMPTY_ENTRY);
     static Tree lt, dt;
     static bool have_prices = false;
     if (!(keep_prices && have_prices)) {
     // before the first block: literals 6 bits, lengths 7, distances 5 -- roughly what zlib's rules assume
-    static const int init = getenv("DFL_INIT") ? atoi(getenv("DFL_INIT")) : 0;
+    static const int init = getenv("DFL_INIT") ? atoi(getenv("DFL_INIT")) : 1;
     for (int s = 0; s < NLIT; s++) lt.lens[s] = s < 256 ? 6 : 7;
     for (int s = 0; s < NDIST; s++) dt.lens[s] = 5;
     if (init == 1)
@@ -210,57 +210,19 @@ static void deflate_region(BitWriter &bw, const uint8_t *src, uint32_t n, uint32
             }
             if (!any || p < carry) continue;
             G[lane] = 0;
-            const uint32_t *e = &bucket[WAYS * (H[lane] >> (32 - BB))];
-            L[lane] = find_match(src, p, n, H[lane], e, WAYS, rep, costs, D[lane], G[lane]);
+            const uint16_t *e = &bucket[WAYS * (H[lane] >> (32 - BB))];
+            const Bytes16 c16 = load16(src + p);
+            L[lane] = WAYS == 4    ? find_match<4>(src, p, n, c16, e, rep, costs, D[lane], G[lane])
+                      : WAYS == 16 ? find_match<16>(src, p, n, c16, e, rep, costs, D[lane], G[lane])
+                                   : find_match<8>(src, p, n, c16, e, rep, costs, D[lane], G[lane]);
             static const int seq_insert = getenv("DFL_SEQ") ? atoi(getenv("DFL_SEQ")) : 0;
-            if (seq_insert && p + 4 <= n) bucket[WAYS * (H[lane] >> (32 - BB)) + (p % WAYS)] = make_entry(H[lane], p);
+            if (seq_insert && p + 4 <= n) bucket[WAYS * (H[lane] >> (32 - BB)) + (p % WAYS)] = make_entry(p);
         }
         for (uint32_t lane = 0; lane < 64; lane++) {  // insert
             const uint32_t p = s + lane;
-            if (p + 4 <= n) bucket[WAYS * (H[lane] >> (32 - BB)) + ((p >> 6) % WAYS)] = make_entry(H[lane], p);
+            if (p + 4 <= n) bucket[WAYS * (H[lane] >> (32 - BB)) + ((p >> 6) % WAYS)] = make_entry(p);
         }
-        static const int use_dp = getenv("DFL_DP") ? atoi(getenv("DFL_DP")) : 0;
-        static const int credit = getenv("DFL_CREDIT") ? atoi(getenv("DFL_CREDIT")) : 2;
-        if (any && use_dp) {
-            // candidates again (the model keeps find_match for the greedy path), then a backward pass over the step
-            uint32_t NL[64], ND[64], FL[64], FD[64];
-            for (uint32_t lane = 0; lane < 64; lane++) {
-                const uint32_t p = s + lane;
-                NL[lane] = FL[lane] = ND[lane] = FD[lane] = 0;
-                if (p >= n || p < carry) continue;
-                // (bucket state: already holds this step's insertions; entries at or behind p are skipped by the finder)
-                const uint32_t *e = &bucket[WAYS * (H[lane] >> (32 - BB))];
-                find_candidates(src, p, n, H[lane], e, WAYS, rep, NL[lane], ND[lane], FL[lane], FD[lane]);
-            }
-            int best[64 + SCAN_CAP + 1];
-            uint32_t cl[64], cd[64];
-            for (uint32_t x = 64; x <= 64 + SCAN_CAP; x++) best[x] = -credit * (int)(x - 64);
-            const uint32_t q0 = carry > s ? carry - s : 0;
-            const uint32_t qend = n - s < 64 ? n - s : 64;
-            for (uint32_t x = qend; x < 64; x++) best[x] = 0;
-            for (int q = (int)qend - 1; q >= (int)q0; q--) {
-                const uint32_t p = s + q;
-                best[q] = (int)cost_or(costs.llen[src[p]], 12u) + best[q + 1];
-                cl[q] = 0;
-                cd[q] = 0;
-                for (int c = 0; c < 2; c++) {
-                    const uint32_t Lc = c ? FL[q] : NL[q], Dc = c ? FD[q] : ND[q];
-                    for (uint32_t l = 3; l <= Lc; l++) {
-                        const int v = (int)match_price(costs, l, Dc) + best[q + l];
-                        if (v < best[q]) {
-                            best[q] = v;
-                            cl[q] = l;
-                            cd[q] = Dc;
-                        }
-                    }
-                }
-            }
-            for (uint32_t lane = 0; lane < 64; lane++) {
-                L[lane] = lane >= q0 && lane < qend ? cl[lane] : 0;
-                D[lane] = lane >= q0 && lane < qend ? cd[lane] : 0;
-            }
-        }
-        if (any && !use_dp) {
+        if (any) {
             uint32_t adv[64];
             for (uint32_t lane = 0; lane < 64; lane++) {  // lazy rule: a longer match one position on wins
                 uint32_t l = L[lane];
