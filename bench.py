@@ -561,6 +561,7 @@ def e2e_leg(cx, args, eng):
     per mate file (level 6, the library's own block-parallel encoder), Illumina-like ids and qualities, in
     tmpfs.  Every read is kept (random reads against a human table), so the outputs must be the input text
     byte for byte: checked member by member with xxh3-64, not by size."""
+    import ctypes
     import shutil
     import tempfile
     import threading
@@ -592,11 +593,15 @@ def e2e_leg(cx, args, eng):
         dist_len = {1: [0] * distinct, 2: [0] * distinct}
         errors = []
 
+        host_gz = []  # (bytes of text, seconds) of the host encoder at work on the inputs
+
         def compress_member(plain, tag, k):  # member k is compressed while member k+1 is generated
             try:
                 dist_hash[tag][k] = _hash_file_ranges(plain, [(0, os.path.getsize(plain))])[0]
+                tc = time.perf_counter()
                 if _lib.lib().nh_compress_file(os.fsencode(plain), os.fsencode(plain + ".gz"), 2, max(1, threads // 2)) != 0:
                     raise RuntimeError("nh_compress_file failed")
+                host_gz.append((os.path.getsize(plain), time.perf_counter() - tc))
                 os.remove(plain)
             except Exception as ex:  # surfaced after the join
                 errors.append(ex)
@@ -675,6 +680,60 @@ def e2e_leg(cx, args, eng):
         ok = ok and checked.get(1) is True and checked.get(2) is True
         for p in (o1, o2):
             os.remove(p)
+        # the same run with gzip outputs, the reference's default for gzip inputs (main.rs:238-245): the kept reads
+        # are compressed on the GPU (nh_deflate.hip) as the writer hands them over; the files are inflated again
+        # by the library's own reader and compared with the generated text like the plain outputs
+        gz = {}
+        try:
+            g1, g2 = os.path.join(tmp, "o_1.fq.gz"), os.path.join(tmp, "o_2.fq.gz")
+            tr_path = os.path.join(tmp, "trace_gz.txt")
+            saved = os.dup(2)
+            fd = os.open(tr_path, os.O_WRONLY | os.O_CREAT | os.O_TRUNC, 0o600)
+            os.environ["NOHUMAN_TRACE"] = "1"
+            try:
+                os.dup2(fd, 2)
+                t = time.perf_counter()
+                st_gz = eng.run(files[0], g1, in2=files[1], out2=g2, threads=threads, out_codec=2,
+                                codec_threads=max(1, threads // 2))
+                dt_gz = time.perf_counter() - t
+            finally:
+                os.dup2(saved, 2)
+                os.close(saved)
+                os.close(fd)
+                os.environ.pop("NOHUMAN_TRACE", None)
+            trace_gz = " | ".join(x.strip() for x in open(tr_path).read().strip().splitlines() if "wall" in x)
+            out_gz = os.path.getsize(g1) + os.path.getsize(g2)
+            gz_ok = {}
+
+            def verify_gz(tag, gzpath, plain):
+                st3 = (ctypes.c_uint64 * 3)()
+                rc = _lib.lib().nh_gunzip_file(os.fsencode(gzpath), os.fsencode(plain), max(1, threads // 2), 0, st3)
+                os.remove(gzpath)
+                offs, pos = [], 0
+                for ln in member_len[tag]:
+                    offs.append((pos, ln))
+                    pos += ln
+                gz_ok[tag] = rc == 0 and os.path.getsize(plain) == pos and _hash_file_ranges(plain, offs) == member_hash[tag]
+                os.remove(plain)
+
+            vt = [threading.Thread(target=verify_gz, args=(1, g1, o1)), threading.Thread(target=verify_gz, args=(2, g2, o2))]
+            for th in vt:
+                th.start()
+            for th in vt:
+                th.join()
+            host_rate = sum(b for b, _ in host_gz) / max(1e-9, sum(sec for _, sec in host_gz)) if host_gz else 0.0
+            gz = {"value": round(2 * st_gz.total_sequences / dt_gz / 1e6, 3), "unit": "Mreads/s", "wall_s": round(dt_gz, 4),
+                  "what": "same inputs, outputs written as gzip (out_codec 2): one ordinary member per file, encoded on the "
+                          "GPU, 64 KiB of text per wave",
+                  "output_ratio": round(text_bytes / max(out_gz, 1), 3),
+                  "stages": trace_gz,
+                  "outputs_equal_inputs": bool(gz_ok.get(1) is True and gz_ok.get(2) is True and st_gz.total_sequences == n * reps),
+                  "outputs_check": "both files inflated by nh_gunzip_file, xxh3-64 per member range == the generated text",
+                  "host_encoder_GBps": round(host_rate / 1e9, 3),
+                  "host_encoder_what": "nh_compress_file (zlib -6 blocks on %d workers, what gzp does in the reference) on this "
+                                       "leg's own input members, two files at a time" % max(1, threads // 2)}
+        except Exception as ex:  # reported, not fatal for the line
+            gz = {"error": str(ex)[:300]}
         # the input side alone: same run with --classified-out semantics (nothing is kept, nothing written)
         t = time.perf_counter()
         st_in = eng.run(files[0], os.path.join(tmp, "h_1.fq"), in2=files[1], out2=os.path.join(tmp, "h_2.fq"),
@@ -700,6 +759,7 @@ def e2e_leg(cx, args, eng):
                                 "wall_s": round(dt_in, 4),
                                 "what": "same inputs, keep_human=1 (no read is kept: inflate + parse + H2D + "
                                         "classify + D2H, no output bytes)"},
+            "gzip_output": gz,
             "setup_seconds": round(t_setup, 1),
         }
     finally:

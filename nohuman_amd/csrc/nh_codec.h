@@ -14,6 +14,13 @@ public:
     virtual int write(const void *p, size_t n) = 0;
     // flushes everything and writes the container's trailer; the file descriptor stays open
     virtual int finish() = 0;
+    // Optional: the host bytes [host, host + len) also lie at `dev` in the memory of GPU `device` until the next
+    // settle() returns -- an encoder that works on that GPU may take spans of them from there.
+    virtual void map_device(const void *host, size_t len, const void *dev, int device) {
+        (void)host, (void)len, (void)dev, (void)device;
+    }
+    // every byte handed to write() so far has been taken over: the caller's memory (host and mapped) is free again
+    virtual int settle() { return 0; }
 };
 
 // codec: nh_codec of the C ABI.  The encoder writes to fd (not closed by it); `name` only labels errors.

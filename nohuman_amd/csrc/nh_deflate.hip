@@ -5,7 +5,7 @@
 // into regions of 64 KiB and ONE WAVE compresses a region:
 //
 //   match finding   64 consecutive positions per step, a lane each: hash of 4 bytes -> an 8-way bucket of earlier
-//                   positions (16 bits each, in LDS), plus the last match's distance and distances 1..4; the candidate
+//                   positions (in LDS, each with a tag of the eight bytes behind the four), plus the last match's distance and distances 1..4; the candidate
 //                   that saves most bits under the PREVIOUS block's code lengths wins (find_match, nh_deflate_core.h).
 //   parse           lazy rule by a lane shift, then the chain of tokens through the step with v_readlane; a match
 //                   that reached the scan cap is extended by the whole wave at once (8 bytes a lane).
@@ -151,7 +151,7 @@ __device__ void build_tree_wave(uint32_t *freq, int nsym, int maxbits, uint8_t *
 
 template <int WAYS>
 struct __attribute__((aligned(16))) RegionLds {
-    uint16_t bucket[WAYS << BUCKET_BITS];
+    uint32_t bucket[WAYS << BUCKET_BITS];
     uint32_t lfreq[NLIT];
     uint32_t dfreq[NDIST];
     uint32_t clfreq[32];
@@ -258,7 +258,7 @@ __global__ __launch_bounds__(64) void k_deflate(DeflateArgs a) {
     const uint32_t n = (uint32_t)((a.n - base) < (uint64_t)a.region ? (a.n - base) : (uint64_t)a.region);
     const uint8_t *src = a.in + base;
     uint32_t *tok = a.tok + (size_t)r * TOK_CAP;
-    for (uint32_t i = (uint32_t)lane; i < (uint32_t)(WAYS << BUCKET_BITS); i += 64) S.bucket[i] = (uint16_t)EMPTY_ENTRY;
+    for (uint32_t i = (uint32_t)lane; i < (uint32_t)(WAYS << BUCKET_BITS); i += 64) S.bucket[i] = EMPTY_ENTRY;
     for (int i = lane; i < NLIT; i += 64) {
         S.lfreq[i] = 0;
         S.llen[i] = a.prior[i];
@@ -293,7 +293,7 @@ __global__ __launch_bounds__(64) void k_deflate(DeflateArgs a) {
         }
         __syncthreads();
         const unsigned long long c1 = a.prof ? __builtin_amdgcn_s_memtime() : 0ull;
-        if (has4) S.bucket[WAYS * hash_bucket(h) + ((p >> 6) % WAYS)] = make_entry(p);
+        if (has4) S.bucket[WAYS * hash_bucket(h) + ((p >> 6) % WAYS)] = make_entry(p, p + 12u <= n ? context_tag(cur16.lo, cur16.hi) : 0u);
         if (any) {
             // lazy rule: a longer match one position on wins over a short one here
             const uint32_t nx = (uint32_t)__shfl_down((int)L, 1);
@@ -437,6 +437,7 @@ struct DeflateDev {  // device side of one encoder: buffers for chunks in flight
     static constexpr int NBUF = 2;
     int device = -1;
     hipStream_t stream = nullptr;
+    hipStream_t copy_stream = nullptr;  // brings the text into d_in while the kernels of earlier chunks run
     struct Buf {
         uint8_t *h_in = nullptr;   // page-locked staging of the text
         uint8_t *d_in = nullptr;
@@ -446,8 +447,9 @@ struct DeflateDev {  // device side of one encoder: buffers for chunks in flight
         uint8_t *d_out = nullptr;
         uint8_t *h_out = nullptr;  // page-locked
         uint64_t *h_total = nullptr;
-        hipEvent_t done = nullptr, k0 = nullptr, k1 = nullptr;
+        hipEvent_t done = nullptr, k0 = nullptr, k1 = nullptr, filled = nullptr;
         size_t fill = 0;
+        size_t staged_from = 0;    // [staged_from, fill) of h_in is not on the device yet
         uint32_t n_regions = 0;
         bool in_flight = false;
     } buf[NBUF];
@@ -465,6 +467,7 @@ struct DeflateDev {  // device side of one encoder: buffers for chunks in flight
         hipError_t e = hipSetDevice(device);
         if (e != hipSuccess) return fail(e, "hipSetDevice");
         if ((e = hipStreamCreateWithFlags(&stream, hipStreamNonBlocking)) != hipSuccess) return fail(e, "stream");
+        if ((e = hipStreamCreateWithFlags(&copy_stream, hipStreamNonBlocking)) != hipSuccess) return fail(e, "stream");
         max_regions = (uint32_t)((CHUNK + REGION - 1) / REGION);
         slot_stride = REGION + 256;
         for (Buf &b : buf) {
@@ -481,6 +484,7 @@ struct DeflateDev {  // device side of one encoder: buffers for chunks in flight
             if ((e = hipEventCreate(&b.done)) != hipSuccess) return fail(e, "event");
             if ((e = hipEventCreate(&b.k0)) != hipSuccess) return fail(e, "event");
             if ((e = hipEventCreate(&b.k1)) != hipSuccess) return fail(e, "event");
+            if ((e = hipEventCreateWithFlags(&b.filled, hipEventDisableTiming)) != hipSuccess) return fail(e, "event");
         }
         if ((e = hipMalloc((void **)&d_tok, (size_t)max_regions * dfl::TOK_CAP * sizeof(uint32_t))) != hipSuccess) return fail(e, "tokens");
         if ((e = hipMalloc((void **)&d_prior, 2 * dfl::PRIOR_BYTES)) != hipSuccess) return fail(e, "prior");
@@ -502,8 +506,10 @@ struct DeflateDev {  // device side of one encoder: buffers for chunks in flight
     void destroy() {
         if (device < 0) return;
         (void)hipSetDevice(device);
+        if (copy_stream) (void)hipStreamSynchronize(copy_stream);
         if (stream) (void)hipStreamSynchronize(stream);
         for (Buf &b : buf) {
+            if (b.filled) (void)hipEventDestroy(b.filled);
             if (b.h_in) (void)hipHostFree(b.h_in);
             if (b.d_in) (void)hipFree(b.d_in);
             if (b.d_slots) (void)hipFree(b.d_slots);
@@ -527,15 +533,44 @@ struct DeflateDev {  // device side of one encoder: buffers for chunks in flight
             (void)hipFree(d_prof);
         }
         if (stream) (void)hipStreamDestroy(stream);
+        if (copy_stream) (void)hipStreamDestroy(copy_stream);
         device = -1;
     }
-    // queues the compression of buf[i] (fill bytes staged in h_in)
+    // the staged bytes of buf[i] that are not on the device yet go there (one copy)
+    int upload_staged(int i) {
+        Buf &b = buf[i];
+        if (b.staged_from == b.fill) return NH_OK;
+        const hipError_t e = hipMemcpyAsync(b.d_in + b.staged_from, b.h_in + b.staged_from, b.fill - b.staged_from,
+                                            hipMemcpyHostToDevice, copy_stream);
+        if (e != hipSuccess) return fail(e, "H2D");
+        b.staged_from = b.fill;
+        return NH_OK;
+    }
+    // `take` bytes that already lie in this GPU's memory are appended to buf[i]
+    int append_device(int i, const void *dev, size_t take) {
+        Buf &b = buf[i];
+        int rc = upload_staged(i);
+        if (rc != NH_OK) return rc;
+        const hipError_t e = hipMemcpyAsync(b.d_in + b.fill, dev, take, hipMemcpyDeviceToDevice, copy_stream);
+        if (e != hipSuccess) return fail(e, "D2D");
+        b.fill += take;
+        b.staged_from = b.fill;
+        return NH_OK;
+    }
+    int settle() {
+        const hipError_t e = hipStreamSynchronize(copy_stream);
+        return e == hipSuccess ? NH_OK : fail(e, "copy");
+    }
+    // queues the compression of buf[i]
     int submit(int i) {
         Buf &b = buf[i];
         hipError_t e = hipSetDevice(device);
         if (e != hipSuccess) return fail(e, "hipSetDevice");
         b.n_regions = (uint32_t)((b.fill + REGION - 1) / REGION);
-        if ((e = hipMemcpyAsync(b.d_in, b.h_in, b.fill, hipMemcpyHostToDevice, stream)) != hipSuccess) return fail(e, "H2D");
+        const int urc = upload_staged(i);
+        if (urc != NH_OK) return urc;
+        if ((e = hipEventRecord(b.filled, copy_stream)) != hipSuccess) return fail(e, "event");
+        if ((e = hipStreamWaitEvent(stream, b.filled, 0)) != hipSuccess) return fail(e, "wait");
         DeflateArgs a{};
         a.in = b.d_in;
         a.n = b.fill;
@@ -579,6 +614,7 @@ struct DeflateDev {  // device side of one encoder: buffers for chunks in flight
         if ((e = hipStreamSynchronize(stream)) != hipSuccess) return fail(e, "D2H");
         b.in_flight = false;
         b.fill = 0;
+        b.staged_from = 0;
         *len = (size_t)total;
         return NH_OK;
     }
@@ -609,19 +645,36 @@ public:
         if (!write_fd(fd_, header, sizeof header)) return rc_ = set_error(NH_EIO, "write error on %s", name_.c_str());
         return NH_OK;
     }
+    void map_device(const void *host, size_t len, const void *dev, int device) override {
+        map_host_ = (const uint8_t *)host;
+        map_len_ = device == dev_.device ? len : 0;
+        map_dev_ = (const uint8_t *)dev;
+    }
+    int settle() override {
+        if (rc_ == NH_OK && hipSetDevice(dev_.device) == hipSuccess) rc_ = dev_.settle();
+        map_len_ = 0;
+        return rc_;
+    }
     int write(const void *p, size_t n) override {
         const uint8_t *c = (const uint8_t *)p;
+        if (n && hipSetDevice(dev_.device) != hipSuccess) rc_ = set_error(NH_EDEVICE, "gzip encoder: hipSetDevice failed");
         while (n && rc_ == NH_OK) {
             DeflateDev::Buf &b = dev_.buf[cur_];
             const size_t room = DeflateDev::CHUNK - b.fill;
             const size_t take = n < room ? n : room;
-            memcpy(b.h_in + b.fill, c, take);
             crc_ = crc32_fast(crc_, c, take);
-            b.fill += take;
+            // a long span of text that is on this GPU already (the batch the classifier worked on) is copied
+            // there; everything else is staged in page-locked memory and uploaded in one piece
+            if (take >= DEVICE_SPAN_MIN && c >= map_host_ && c + take <= map_host_ + map_len_) {
+                rc_ = dev_.append_device(cur_, map_dev_ + (c - map_host_), take);
+            } else {
+                memcpy(b.h_in + b.fill, c, take);
+                b.fill += take;
+            }
             total_ += take;
             c += take;
             n -= take;
-            if (b.fill == DeflateDev::CHUNK) rotate();
+            if (rc_ == NH_OK && b.fill == DeflateDev::CHUNK) rotate();
         }
         return rc_;
     }
@@ -655,9 +708,12 @@ private:
         if (!write_fd(fd_, dev_.buf[i].h_out, len)) rc_ = set_error(NH_EIO, "write error on %s", name_.c_str());
         out_bytes_ += len;
     }
+    static constexpr size_t DEVICE_SPAN_MIN = 32u << 10;
     int fd_;
     std::string name_;
     DeflateDev dev_;
+    const uint8_t *map_host_ = nullptr, *map_dev_ = nullptr;
+    size_t map_len_ = 0;
     int cur_ = 0;
     uint32_t crc_ = 0;
     uint64_t total_ = 0, out_bytes_ = 0;

@@ -214,12 +214,25 @@ NH_HD inline uint32_t cl_order(int i) {
 // the bucket and the tag of the four bytes at a position
 NH_HD inline uint32_t hash4(uint32_t four) { return four * 2654435761u; }
 constexpr uint32_t BUCKET_BITS = 10;
-// a bucket entry is a position of the region in 16 bits (regions are at most 64 KiB); 0xFFFF = empty: the last
-// position of a full region can never be a candidate (candidates lie before the position that asks)
-constexpr uint32_t EMPTY_ENTRY = 0xFFFFu;
+// a bucket entry: the position within the region in the low 16 bits (regions are at most 64 KiB), above it 16 bits
+// of a hash of the eight bytes that FOLLOW the four hashed ones -- an entry whose context tag equals the asking
+// position's matches it for twelve bytes (or the tags collide).  Empty = position 0xFFFF: the last position of a
+// full region can never be a candidate (candidates lie before the position that asks).
+constexpr uint32_t EMPTY_ENTRY = 0xFFFFFFFFu;
 constexpr uint32_t MAX_REGION = 65536u;
 NH_HD inline uint32_t hash_bucket(uint32_t h) { return h >> (32u - BUCKET_BITS); }
-NH_HD inline uint16_t make_entry(uint32_t pos) { return (uint16_t)pos; }
+NH_HD inline uint32_t context_tag(uint64_t lo, uint64_t hi) {  // of bytes 4..11 of the sixteen at a position
+    const uint64_t ctx = (lo >> 32) | (hi << 32);
+    return (uint32_t)((ctx * 0x9E3779B97F4A7C15ull) >> 48);
+}
+NH_HD inline uint32_t make_entry(uint32_t pos, uint32_t tag) { return (tag << 16) | (pos & 0xFFFFu); }
+// Where the next eight literals are this cheap (in bits, under the current prices) a far match has to be long to
+// pay: only bucket entries with the position's own context tag are looked at -- bases of reads, mostly, whose
+// 4-mers recur everywhere and whose real repeats are long.
+#ifndef NH_CHEAP_BITS
+#define NH_CHEAP_BITS 28
+#endif
+constexpr uint32_t CHEAP_BITS = NH_CHEAP_BITS;
 
 NH_HD inline uint64_t load8(const uint8_t *p) {  // eight bytes at any address (little endian)
     struct __attribute__((packed)) U {
@@ -255,7 +268,10 @@ NH_HD inline uint32_t common_prefix(const uint8_t *a, const uint8_t *b, uint32_t
     return len < cap ? len : cap;
 }
 
-constexpr uint32_t SCAN_CAP = 32;  // match lengths are measured up to here for every position; a match the parse takes is extended
+#ifndef NH_SCAN_CAP
+#define NH_SCAN_CAP 32
+#endif
+constexpr uint32_t SCAN_CAP = NH_SCAN_CAP;  // match lengths are measured up to here for every position; a match the parse takes is extended
 
 // what a match costs and what it saves, in bits, under the code lengths of the previous block (lit_cost: 288 + 32
 // entries, 0 = the symbol did not occur there)
@@ -302,9 +318,14 @@ NH_HD inline uint32_t find_match(const uint8_t *src, uint32_t p, uint32_t n, con
     uint32_t d[NC], len[NC];
     for (int k = 0; k < 4; k++) d[k] = (uint32_t)(k + 1) <= p ? (uint32_t)(k + 1) : 0u;
     d[4] = (rep > 4u && rep <= p && rep <= WINDOW) ? rep : 0u;
+    const uint64_t lit8 = literal_prices8(costs, cur16.lo);
+    const bool cheap = (uint32_t)(lit8 >> 56) < CHEAP_BITS;
+    const uint32_t tag = context_tag(cur16.lo, cur16.hi);
     for (int k = 0; k < WAYS; k++) {
-        const uint32_t c = entries[k];
-        const bool ok = room >= 4u && c < p && p - c <= WINDOW && p - c > 4u && p - c != d[4];
+        const uint32_t e = entries[k];
+        const uint32_t c = e & 0xFFFFu;
+        const bool ok = room >= 12u ? (c < p && p - c <= WINDOW && p - c > 4u && p - c != d[4] && (!cheap || (e >> 16) == tag))
+                                    : (room >= 4u && !cheap && c < p && p - c <= WINDOW && p - c > 4u && p - c != d[4]);
         d[5 + k] = ok ? p - c : 0u;
     }
     Bytes16 x[NC];
@@ -315,7 +336,7 @@ NH_HD inline uint32_t find_match(const uint8_t *src, uint32_t p, uint32_t n, con
         for (int k = 0; k < NC; k++) any |= len[k] == 16u;
         if (any) {
             const Bytes16 c2 = load16(cur + 16);
-            for (int k = 0; k < NC; k++) x[k] = load16(cur - d[k] + 16);
+            for (int k = 0; k < NC; k++) x[k] = load16(cur - (len[k] == 16u ? d[k] : 0u) + 16);  // (the others: lines the wave reads anyway)
             for (int k = 0; k < NC; k++)
                 if (len[k] == 16u) len[k] += equal_bytes16(x[k], c2);
         }
@@ -335,7 +356,6 @@ NH_HD inline uint32_t find_match(const uint8_t *src, uint32_t p, uint32_t n, con
         }
     nl = nl < cap ? nl : cap;
     fl = fl < cap ? fl : cap;
-    const uint64_t lit8 = literal_prices8(costs, cur16.lo);
     uint32_t best = 0, bdist = 0;
     int bgain = 0;
     if (nl >= MIN_MATCH) {

@@ -82,6 +82,8 @@ struct OutFile {
         if (enc) {
             for (; i < iov.size() && rc == NH_OK; i++) rc = enc->write(iov[i].iov_base, iov[i].iov_len);
             i = iov.size();
+            const int src = enc->settle();  // the batch's buffers (host and device) go back to the pipeline after this
+            if (rc == NH_OK) rc = src;
         }
         while (i < iov.size()) {
             const int cnt = (int)std::min<size_t>(iov.size() - i, 512);
@@ -741,6 +743,13 @@ int run_engines(const std::vector<Engine *> &engines, const nh_run_args *a, nh_s
                 if (he != hipSuccess) wrc = set_error(NH_EDEVICE, "classify: %s", hipGetErrorString(he));
                 if (!wrc) wrc = check_error_flag(s.e);
                 if (!wrc) {
+                    // the batch's raw text is still in the slot's device buffer: an encoder on that GPU takes
+                    // the kept records from there instead of a second trip over PCIe
+                    if (o1.enc) o1.enc->map_device(b.h1->text.data(), b.h1->text.size(), s.d_text, s.e->device);
+                    if (rs.paired && o2.enc) {
+                        const size_t base2 = (b.h1->text.size() + 8 + 255) & ~(size_t)255;
+                        o2.enc->map_device(b.h2->text.data(), b.h2->text.size(), (const char *)s.d_text + base2, s.e->device);
+                    }
                     format_batch(&rs, b, s, o1, o2, ok);
                     uint64_t c3 = StageClock::now();
                     clk.ns[ST_WFORMAT] += c3 - c2;

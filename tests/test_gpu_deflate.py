@@ -93,3 +93,37 @@ def test_several_chunks(tmp_path):
     data = unit * (150_000_000 // len(unit))
     size = check(data, str(tmp_path / "a.gz"))
     assert size < len(data) / 3
+
+
+def test_run_takes_long_spans_from_the_device_copy_of_the_batch(tmp_path, monkeypatch):
+    """nh_run with gzip outputs: kept records in spans of 32 KiB and more are compressed from the copy of the batch's
+    text that the classifier worked on (no second trip over PCIe), shorter spans and reformatted records are
+    staged -- the two mixed in one stream, several batches, both mate files.  Decompressed bytes == plain outputs,
+    for the GPU encoder and for the host encoder (NOHUMAN_GZIP=host)."""
+    from nohuman_amd import Engine
+    gold = os.path.join(os.path.dirname(__file__), "golden")
+    rng = np.random.default_rng(5)
+    files = []
+    for m in ("1", "2"):
+        fixture = open(os.path.join(gold, "reads_pe_%s.fq" % m), "rb").read()   # human and other reads, mixed
+        parts = []
+        for block in range(6):
+            parts.append(fixture * 3)                                            # short spans between removed reads
+            for i in range(1500):                                                # a long run of kept reads
+                seq = bytes(rng.choice(np.frombuffer(b"ACGT", dtype=np.uint8), 150))
+                parts.append(b"@r%d_%d/%s\n%s\n+\n%s\n" % (block, i, m.encode(), seq, b"F" * 150))
+        p = tmp_path / ("in_%s.fq" % m)
+        p.write_bytes(b"".join(parts))
+        files.append(str(p))
+    monkeypatch.setenv("NOHUMAN_BATCH_FRAGS", "4000")
+    with Engine.open(os.path.join(gold, "toy_db")) as eng:
+        st = eng.run(files[0], str(tmp_path / "p_1.fq"), in2=files[1], out2=str(tmp_path / "p_2.fq"))
+        eng.run(files[0], str(tmp_path / "g_1.gz"), in2=files[1], out2=str(tmp_path / "g_2.gz"), out_codec=2)
+        monkeypatch.setenv("NOHUMAN_GZIP", "host")
+        eng.run(files[0], str(tmp_path / "h_1.gz"), in2=files[1], out2=str(tmp_path / "h_2.gz"), out_codec=2, codec_threads=2)
+    assert 0 < st.classified < st.total_sequences
+    for m in ("1", "2"):
+        want = (tmp_path / ("p_%s.fq" % m)).read_bytes()
+        assert len(want) > 2_000_000
+        assert gzip.decompress((tmp_path / ("g_%s.gz" % m)).read_bytes()) == want
+        assert gzip.decompress((tmp_path / ("h_%s.gz" % m)).read_bytes()) == want

@@ -169,7 +169,7 @@ static void deflate_region(BitWriter &bw, const uint8_t *src, uint32_t n, uint32
     static const uint32_t BB = getenv("DFL_BB") ? atoi(getenv("DFL_BB")) : BUCKET_BITS;
     static const int keep_prices = getenv("DFL_KEEP") ? atoi(getenv("DFL_KEEP")) : 0;
     static const int lazy_gain = getenv("DFL_LAZYG") ? atoi(getenv("DFL_LAZYG")) : 0;
-    std::vector<uint16_t> bucket((size_t)WAYS << BB, (uint16_t)EMPTY_ENTRY);
+    std::vector<uint32_t> bucket((size_t)WAYS << BB, EMPTY_ENTRY);
     static Tree lt, dt;
     static bool have_prices = false;
     if (!(keep_prices && have_prices)) {
@@ -203,24 +203,28 @@ static void deflate_region(BitWriter &bw, const uint8_t *src, uint32_t n, uint32
             D[lane] = 0;
             H[lane] = 0;
             if (p >= n) continue;
-            if (p + 4 <= n) {
-                uint32_t four;
-                memcpy(&four, src + p, 4);
-                H[lane] = hash4(four);
+            static const int HL = getenv("DFL_HASHLEN") ? atoi(getenv("DFL_HASHLEN")) : 4;
+            if (p + HL <= n) {
+                uint64_t v = 0;
+                memcpy(&v, src + p, HL);
+                H[lane] = HL == 4 ? hash4((uint32_t)v) : (uint32_t)((v * 0x9E3779B97F4A7C15ull) >> 32);
             }
             if (!any || p < carry) continue;
             G[lane] = 0;
-            const uint16_t *e = &bucket[WAYS * (H[lane] >> (32 - BB))];
+            const uint32_t *e = &bucket[WAYS * (H[lane] >> (32 - BB))];
             const Bytes16 c16 = load16(src + p);
             L[lane] = WAYS == 4    ? find_match<4>(src, p, n, c16, e, rep, costs, D[lane], G[lane])
                       : WAYS == 16 ? find_match<16>(src, p, n, c16, e, rep, costs, D[lane], G[lane])
                                    : find_match<8>(src, p, n, c16, e, rep, costs, D[lane], G[lane]);
             static const int seq_insert = getenv("DFL_SEQ") ? atoi(getenv("DFL_SEQ")) : 0;
-            if (seq_insert && p + 4 <= n) bucket[WAYS * (H[lane] >> (32 - BB)) + (p % WAYS)] = make_entry(p);
+            
         }
         for (uint32_t lane = 0; lane < 64; lane++) {  // insert
             const uint32_t p = s + lane;
-            if (p + 4 <= n) bucket[WAYS * (H[lane] >> (32 - BB)) + ((p >> 6) % WAYS)] = make_entry(p);
+            if (p + 4 <= n) {
+                const Bytes16 c16 = load16(src + p);
+                bucket[WAYS * (H[lane] >> (32 - BB)) + ((p >> 6) % WAYS)] = make_entry(p, p + 12 <= n ? context_tag(c16.lo, c16.hi) : 0u);
+            }
         }
         if (any) {
             uint32_t adv[64];
