@@ -5,7 +5,7 @@
 // into regions of 64 KiB and ONE WAVE compresses a region:
 //
 //   match finding   64 consecutive positions per step, a lane each: hash of 4 bytes -> an 8-way bucket of earlier
-//                   positions (in LDS, each with a tag of the eight bytes behind the four), plus the last match's distance and distances 1..4; the candidate
+//                   positions (16 bits each, in LDS), plus the last match's distance and distances 1..4; the candidate
 //                   that saves most bits under the PREVIOUS block's code lengths wins (find_match, nh_deflate_core.h).
 //   parse           lazy rule by a lane shift, then the chain of tokens through the step with v_readlane; a match
 //                   that reached the scan cap is extended by the whole wave at once (8 bytes a lane).
@@ -107,43 +107,52 @@ __device__ void wave_put2(BitOut &bo, int lane, uint32_t a, uint32_t na, uint32_
     bo.obits = total & 31u;
 }
 
-struct TreeLds {  // scratch of the code construction
-    uint32_t key[NLIT];
-    uint32_t a[NLIT];
+// symbol counts of a block: two 16-bit counters a word (a block has fewer than 65536 tokens), bumped by LDS atomics
+struct PackedCounts {
+    uint32_t *w;
+    __device__ __forceinline__ uint32_t get(int s) const { return (w[s >> 1] >> (16 * (s & 1))) & 0xFFFFu; }
+    __device__ __forceinline__ void bump(int s) const { atomicAdd(&w[s >> 1], 1u << (16 * (s & 1))); }
+};
+struct PlainCounts {
+    uint32_t *w;
+    __device__ __forceinline__ uint32_t get(int s) const { return w[s]; }
+    __device__ __forceinline__ void bump(int s) const { atomicAdd(&w[s], 1u); }
+};
+struct TreeLds {  // scratch of the code construction: the used symbols in ascending order of their counts
+    uint16_t a[NLIT];
     uint16_t ssym[NLIT];
 };
 
 // code lengths and codes of one alphabet from its counts (all in LDS); the wave sorts, lane 0 builds
-__device__ void build_tree_wave(uint32_t *freq, int nsym, int maxbits, uint8_t *lens, uint16_t *codes, TreeLds &t,
-                                int lane) {
+template <typename Counts>
+__device__ void build_tree_wave(const Counts &freq, int nsym, int maxbits, uint8_t *lens, uint16_t *codes, uint16_t *ta,
+                                uint16_t *tsym, int lane) {
     // a code needs two symbols to be complete
     uint32_t used = 0;
-    for (int s = lane; s < nsym; s += 64) used += freq[s] != 0;
+    for (int s = lane; s < nsym; s += 64) used += freq.get(s) != 0;
     used = wave_sum(used);
     if (used < 2 && lane == 0)
         for (int s = 0; used < 2 && s < nsym; s++)
-            if (!freq[s]) {
-                freq[s] = 1;
+            if (!freq.get(s)) {
+                freq.bump(s);
                 used++;
             }
     __syncthreads();
-    for (int s = lane; s < NLIT; s += 64) t.key[s] = (s < nsym && freq[s]) ? ((freq[s] << 9) | (uint32_t)s) : 0xFFFFFFFFu;
-    __syncthreads();
-    uint32_t n = 0;
-    for (int s = lane; s < nsym; s += 64) n += t.key[s] != 0xFFFFFFFFu;
-    n = wave_sum(n);
-    // rank sort: keys are distinct; every lane counts the smaller keys for its symbols (broadcast reads)
+    // rank sort by (count, symbol): every lane counts the smaller pairs for its symbols (broadcast reads)
     for (int s = lane; s < nsym; s += 64) {
-        const uint32_t k = t.key[s];
-        if (k == 0xFFFFFFFFu) continue;
+        const uint32_t f = freq.get(s);
+        if (!f) continue;
         uint32_t r = 0;
-        for (int j = 0; j < nsym; j++) r += t.key[j] < k;
-        t.a[r] = k >> 9;
-        t.ssym[r] = (uint16_t)s;
+        for (int j = 0; j < nsym; j++) {
+            const uint32_t g = freq.get(j);
+            r += g != 0u && (g < f || (g == f && j < s));
+        }
+        ta[r] = (uint16_t)f;
+        tsym[r] = (uint16_t)s;
     }
     __syncthreads();
     if (lane == 0) {
-        huff_lengths_sorted(t.a, t.ssym, (int)n, nsym, maxbits, lens);
+        huff_lengths_sorted(ta, tsym, (int)used, nsym, maxbits, lens);
         huff_codes(lens, nsym, maxbits, codes);
     }
     __syncthreads();
@@ -151,9 +160,9 @@ __device__ void build_tree_wave(uint32_t *freq, int nsym, int maxbits, uint8_t *
 
 template <int WAYS>
 struct __attribute__((aligned(16))) RegionLds {
-    uint32_t bucket[WAYS << BUCKET_BITS];
-    uint32_t lfreq[NLIT];
-    uint32_t dfreq[NDIST];
+    uint16_t bucket[WAYS << BUCKET_BITS];
+    uint32_t lfreq2[NLIT / 2];  // PackedCounts
+    uint32_t dfreq2[NDIST / 2];
     uint32_t clfreq[32];
     uint8_t llen[NLIT];   // lengths of the last block built: the codes' lengths while coding, the prices while matching
     uint8_t dlen[NDIST];
@@ -161,9 +170,14 @@ struct __attribute__((aligned(16))) RegionLds {
     uint16_t lcode[NLIT];
     uint16_t dcode[NDIST];
     uint16_t clcode[32];
-    uint8_t all[NLIT + NDIST];     // hlit + hdist lengths in a row
-    uint16_t items[NLIT + NDIST];  // their run-length form
-    TreeLds tree;
+    union {
+        TreeLds tree;                     // while a code is built
+        struct {
+            uint8_t all[NLIT + NDIST];     // afterwards: hlit + hdist lengths in a row
+            uint16_t items[NLIT + NDIST];  // and their run-length form
+        } hdr;
+    } u;
+    uint16_t cl_a[32], cl_sym[32];        // the code-length code is built while hdr is live
     uint32_t ob[OB_WORDS];
     int misc[8];
 };
@@ -172,33 +186,34 @@ struct __attribute__((aligned(16))) RegionLds {
 template <int WAYS>
 __device__ void finish_block(RegionLds<WAYS> &S, BitOut &bo, const uint32_t *tok, uint32_t ntok, const uint8_t *src,
                              uint32_t from, uint32_t to, int lane) {
-    if (lane == 0) S.lfreq[256] = 1;
+    const PackedCounts lfreq{S.lfreq2}, dfreq{S.dfreq2};
+    if (lane == 0) lfreq.bump(256);
     __syncthreads();
-    build_tree_wave(S.lfreq, NLIT_USED, MAXBITS, S.llen, S.lcode, S.tree, lane);
-    build_tree_wave(S.dfreq, NDIST_USED, MAXBITS, S.dlen, S.dcode, S.tree, lane);
+    build_tree_wave(lfreq, NLIT_USED, MAXBITS, S.llen, S.lcode, S.u.tree.a, S.u.tree.ssym, lane);
+    build_tree_wave(dfreq, NDIST_USED, MAXBITS, S.dlen, S.dcode, S.u.tree.a, S.u.tree.ssym, lane);
     if (lane == 0) {
         int hlit = NLIT_USED, hdist = NDIST_USED;
         while (hlit > 257 && S.llen[hlit - 1] == 0) hlit--;
         while (hdist > 1 && S.dlen[hdist - 1] == 0) hdist--;
-        for (int i = 0; i < hlit; i++) S.all[i] = S.llen[i];
-        for (int i = 0; i < hdist; i++) S.all[hlit + i] = S.dlen[i];
+        for (int i = 0; i < hlit; i++) S.u.hdr.all[i] = S.llen[i];
+        for (int i = 0; i < hdist; i++) S.u.hdr.all[hlit + i] = S.dlen[i];
         S.misc[0] = hlit;
         S.misc[1] = hdist;
-        S.misc[2] = rle_lengths(S.all, hlit + hdist, S.items, S.clfreq);
+        S.misc[2] = rle_lengths(S.u.hdr.all, hlit + hdist, S.u.hdr.items, S.clfreq);
     }
     __syncthreads();
-    build_tree_wave(S.clfreq, NCL, MAXBITS_CL, S.cllen, S.clcode, S.tree, lane);
+    build_tree_wave(PlainCounts{S.clfreq}, NCL, MAXBITS_CL, S.cllen, S.clcode, S.cl_a, S.cl_sym, lane);
     const int hlit = S.misc[0], hdist = S.misc[1], ni = S.misc[2];
     int hclen = NCL;
     while (hclen > 4 && S.cllen[cl_order(hclen - 1)] == 0) hclen--;
     // size of the block with these codes
     uint32_t bits = 0;
     for (int i = lane; i < ni; i += 64) {
-        const uint32_t s = S.items[i] & 31u;
+        const uint32_t s = S.u.hdr.items[i] & 31u;
         bits += S.cllen[s] + cl_extra_bits(s);
     }
-    for (int s = lane; s < NLIT_USED; s += 64) bits += S.lfreq[s] * (S.llen[s] + (s > 256 ? len_extra_bits((uint32_t)s) : 0u));
-    for (int s = lane; s < NDIST_USED; s += 64) bits += S.dfreq[s] * (S.dlen[s] + dist_extra_bits((uint32_t)s));
+    for (int s = lane; s < NLIT_USED; s += 64) bits += lfreq.get(s) * (S.llen[s] + (s > 256 ? len_extra_bits((uint32_t)s) : 0u));
+    for (int s = lane; s < NDIST_USED; s += 64) bits += dfreq.get(s) * (S.dlen[s] + dist_extra_bits((uint32_t)s));
     bits = wave_sum(bits) + 17u + 3u * (uint32_t)hclen;
     const uint32_t nbytes = to - from;
     if (bits >= 8u * nbytes + 40u) {
@@ -219,7 +234,7 @@ __device__ void finish_block(RegionLds<WAYS> &S, BitOut &bo, const uint32_t *tok
         wave_put2(bo, lane, lane < hclen ? S.cllen[cl_order(lane < NCL ? lane : 0)] : 0u, lane < hclen ? 3u : 0u, 0u, 0u);
         for (int i = 0; i < ni; i += 64) {
             const bool in = i + lane < ni;
-            const uint32_t it = in ? S.items[i + lane] : 0u;
+            const uint32_t it = in ? S.u.hdr.items[i + lane] : 0u;
             const uint32_t s = it & 31u;
             wave_put2(bo, lane, S.clcode[s], in ? S.cllen[s] : 0u, it >> 5, in ? cl_extra_bits(s) : 0u);
         }
@@ -258,15 +273,16 @@ __global__ __launch_bounds__(64) void k_deflate(DeflateArgs a) {
     const uint32_t n = (uint32_t)((a.n - base) < (uint64_t)a.region ? (a.n - base) : (uint64_t)a.region);
     const uint8_t *src = a.in + base;
     uint32_t *tok = a.tok + (size_t)r * TOK_CAP;
-    for (uint32_t i = (uint32_t)lane; i < (uint32_t)(WAYS << BUCKET_BITS); i += 64) S.bucket[i] = EMPTY_ENTRY;
+    for (uint32_t i = (uint32_t)lane; i < (uint32_t)(WAYS << BUCKET_BITS); i += 64) S.bucket[i] = (uint16_t)EMPTY_ENTRY;
     for (int i = lane; i < NLIT; i += 64) {
-        S.lfreq[i] = 0;
+        if (i < NLIT / 2) S.lfreq2[i] = 0;
         S.llen[i] = a.prior[i];
     }
     if (lane < NDIST) {
-        S.dfreq[lane] = 0;
+        if (lane < NDIST / 2) S.dfreq2[lane] = 0;
         S.dlen[lane] = a.prior[NLIT + lane];
     }
+    const PackedCounts lfreq{S.lfreq2}, dfreq{S.dfreq2};
     for (uint32_t i = (uint32_t)lane; i < OB_WORDS; i += 64) S.ob[i] = 0;
     __syncthreads();
     BitOut bo{S.ob, (uint32_t *)(a.slots + (size_t)r * a.slot_stride), 0u, 0u};
@@ -293,7 +309,7 @@ __global__ __launch_bounds__(64) void k_deflate(DeflateArgs a) {
         }
         __syncthreads();
         const unsigned long long c1 = a.prof ? __builtin_amdgcn_s_memtime() : 0ull;
-        if (has4) S.bucket[WAYS * hash_bucket(h) + ((p >> 6) % WAYS)] = make_entry(p, p + 12u <= n ? context_tag(cur16.lo, cur16.hi) : 0u);
+        if (has4) S.bucket[WAYS * hash_bucket(h) + ((p >> 6) % WAYS)] = make_entry(p);
         if (any) {
             // lazy rule: a longer match one position on wins over a short one here
             const uint32_t nx = (uint32_t)__shfl_down((int)L, 1);
@@ -339,11 +355,11 @@ __global__ __launch_bounds__(64) void k_deflate(DeflateArgs a) {
                     len_symbol(L - 3u, sym, eb, ev);
                     dist_symbol(D - 1u, dsym, deb, dev);
                     tok[idx] = tok_match(L, D);
-                    atomicAdd(&S.lfreq[sym], 1u);
-                    atomicAdd(&S.dfreq[dsym], 1u);
+                    lfreq.bump((int)sym);
+                    dfreq.bump((int)dsym);
                 } else {
                     tok[idx] = four & 0xFFu;
-                    atomicAdd(&S.lfreq[four & 0xFFu], 1u);
+                    lfreq.bump((int)(four & 0xFFu));
                 }
             }
             ntok += (uint32_t)__popcll(sel);
@@ -356,8 +372,8 @@ __global__ __launch_bounds__(64) void k_deflate(DeflateArgs a) {
             const uint32_t to = carry < n ? carry : n;
             __threadfence_block();
             finish_block<WAYS>(S, bo, tok, ntok, src, blk_from, to, lane);
-            for (int i = lane; i < NLIT; i += 64) S.lfreq[i] = 0;
-            if (lane < NDIST) S.dfreq[lane] = 0;
+            for (int i = lane; i < NLIT / 2; i += 64) S.lfreq2[i] = 0;
+            if (lane < NDIST / 2) S.dfreq2[lane] = 0;
             __syncthreads();
             blk_from = to;
             ntok = 0;
@@ -424,7 +440,7 @@ int gzip_ways() {
 }
 
 struct DeflateDev {  // device side of one encoder: buffers for chunks in flight
-    static constexpr size_t CHUNK = 64u << 20;
+    static constexpr size_t CHUNK = 128u << 20;
     static uint32_t region_bytes() {  // NOHUMAN_GZIP_REGION: tuning (bytes of text a wave compresses)
         static const uint32_t r = [] {
             const char *e = getenv("NOHUMAN_GZIP_REGION");

@@ -75,31 +75,33 @@ NH_HD inline uint32_t bitrev(uint32_t v, uint32_t n) {  // the low n bits of v, 
 #endif
 }
 
-// In: a[0..n) = the frequencies of the n >= 2 used symbols in ascending order.  Out: a[i] = the code length of the
+// In: a[0..n) = the frequencies of the n >= 2 used symbols in ascending order (T holds their sum: 16 bits do for
+// a block of up to 65535 tokens).  Out: a[i] = the code length of the
 // i-th of them in an unrestricted Huffman code (non-increasing in i).  Three passes, in place.
-NH_HD inline void huff_depths_sorted(uint32_t *a, int n) {
+template <typename T>
+NH_HD inline void huff_depths_sorted(T *a, int n) {
     if (n == 2) {
         a[0] = a[1] = 1;
         return;
     }
-    a[0] += a[1];
+    a[0] = (T)(a[0] + a[1]);
     int root = 0, leaf = 2;
     for (int next = 1; next < n - 1; next++) {
         if (leaf >= n || a[root] < a[leaf]) {
             a[next] = a[root];
-            a[root++] = (uint32_t)next;
+            a[root++] = (T)next;
         } else {
             a[next] = a[leaf++];
         }
         if (leaf >= n || (root < next && a[root] < a[leaf])) {
-            a[next] += a[root];
-            a[root++] = (uint32_t)next;
+            a[next] = (T)(a[next] + a[root]);
+            a[root++] = (T)next;
         } else {
-            a[next] += a[leaf++];
+            a[next] = (T)(a[next] + a[leaf++]);
         }
     }
     a[n - 2] = 0;
-    for (int next = n - 3; next >= 0; next--) a[next] = a[a[next]] + 1u;
+    for (int next = n - 3; next >= 0; next--) a[next] = (T)(a[a[next]] + 1u);
     int avail = 1, used = 0, depth = 0;
     int r = n - 2, next = n - 1;
     while (avail > 0) {
@@ -108,7 +110,7 @@ NH_HD inline void huff_depths_sorted(uint32_t *a, int n) {
             r--;
         }
         while (avail > used) {
-            a[next--] = (uint32_t)depth;
+            a[next--] = (T)depth;
             avail--;
         }
         avail = 2 * used;
@@ -119,8 +121,8 @@ NH_HD inline void huff_depths_sorted(uint32_t *a, int n) {
 
 // Lengths of a code over nsym symbols, none longer than maxbits, from the used symbols sorted by ascending
 // frequency: sorted_sym[i] with frequency a[i] (a is overwritten).  lens[] gets 0 for unused symbols.
-NH_HD inline void huff_lengths_sorted(uint32_t *a, const uint16_t *sorted_sym, int n, int nsym, int maxbits,
-                                      uint8_t *lens) {
+template <typename T>
+NH_HD inline void huff_lengths_sorted(T *a, const uint16_t *sorted_sym, int n, int nsym, int maxbits, uint8_t *lens) {
     for (int s = 0; s < nsym; s++) lens[s] = 0;
     huff_depths_sorted(a, n);
     uint32_t cnt[MAXBITS + 2];
@@ -214,25 +216,12 @@ NH_HD inline uint32_t cl_order(int i) {
 // the bucket and the tag of the four bytes at a position
 NH_HD inline uint32_t hash4(uint32_t four) { return four * 2654435761u; }
 constexpr uint32_t BUCKET_BITS = 10;
-// a bucket entry: the position within the region in the low 16 bits (regions are at most 64 KiB), above it 16 bits
-// of a hash of the eight bytes that FOLLOW the four hashed ones -- an entry whose context tag equals the asking
-// position's matches it for twelve bytes (or the tags collide).  Empty = position 0xFFFF: the last position of a
-// full region can never be a candidate (candidates lie before the position that asks).
-constexpr uint32_t EMPTY_ENTRY = 0xFFFFFFFFu;
+// a bucket entry is a position of the region in 16 bits (regions are at most 64 KiB); 0xFFFF = empty: the last
+// position of a full region can never be a candidate (candidates lie before the position that asks)
+constexpr uint32_t EMPTY_ENTRY = 0xFFFFu;
 constexpr uint32_t MAX_REGION = 65536u;
 NH_HD inline uint32_t hash_bucket(uint32_t h) { return h >> (32u - BUCKET_BITS); }
-NH_HD inline uint32_t context_tag(uint64_t lo, uint64_t hi) {  // of bytes 4..11 of the sixteen at a position
-    const uint64_t ctx = (lo >> 32) | (hi << 32);
-    return (uint32_t)((ctx * 0x9E3779B97F4A7C15ull) >> 48);
-}
-NH_HD inline uint32_t make_entry(uint32_t pos, uint32_t tag) { return (tag << 16) | (pos & 0xFFFFu); }
-// Where the next eight literals are this cheap (in bits, under the current prices) a far match has to be long to
-// pay: only bucket entries with the position's own context tag are looked at -- bases of reads, mostly, whose
-// 4-mers recur everywhere and whose real repeats are long.
-#ifndef NH_CHEAP_BITS
-#define NH_CHEAP_BITS 28
-#endif
-constexpr uint32_t CHEAP_BITS = NH_CHEAP_BITS;
+NH_HD inline uint16_t make_entry(uint32_t pos) { return (uint16_t)pos; }
 
 NH_HD inline uint64_t load8(const uint8_t *p) {  // eight bytes at any address (little endian)
     struct __attribute__((packed)) U {
@@ -318,14 +307,9 @@ NH_HD inline uint32_t find_match(const uint8_t *src, uint32_t p, uint32_t n, con
     uint32_t d[NC], len[NC];
     for (int k = 0; k < 4; k++) d[k] = (uint32_t)(k + 1) <= p ? (uint32_t)(k + 1) : 0u;
     d[4] = (rep > 4u && rep <= p && rep <= WINDOW) ? rep : 0u;
-    const uint64_t lit8 = literal_prices8(costs, cur16.lo);
-    const bool cheap = (uint32_t)(lit8 >> 56) < CHEAP_BITS;
-    const uint32_t tag = context_tag(cur16.lo, cur16.hi);
     for (int k = 0; k < WAYS; k++) {
-        const uint32_t e = entries[k];
-        const uint32_t c = e & 0xFFFFu;
-        const bool ok = room >= 12u ? (c < p && p - c <= WINDOW && p - c > 4u && p - c != d[4] && (!cheap || (e >> 16) == tag))
-                                    : (room >= 4u && !cheap && c < p && p - c <= WINDOW && p - c > 4u && p - c != d[4]);
+        const uint32_t c = entries[k];
+        const bool ok = room >= 4u && c < p && p - c <= WINDOW && p - c > 4u && p - c != d[4];
         d[5 + k] = ok ? p - c : 0u;
     }
     Bytes16 x[NC];
@@ -356,6 +340,7 @@ NH_HD inline uint32_t find_match(const uint8_t *src, uint32_t p, uint32_t n, con
         }
     nl = nl < cap ? nl : cap;
     fl = fl < cap ? fl : cap;
+    const uint64_t lit8 = literal_prices8(costs, cur16.lo);
     uint32_t best = 0, bdist = 0;
     int bgain = 0;
     if (nl >= MIN_MATCH) {

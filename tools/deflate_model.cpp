@@ -169,7 +169,7 @@ static void deflate_region(BitWriter &bw, const uint8_t *src, uint32_t n, uint32
     static const uint32_t BB = getenv("DFL_BB") ? atoi(getenv("DFL_BB")) : BUCKET_BITS;
     static const int keep_prices = getenv("DFL_KEEP") ? atoi(getenv("DFL_KEEP")) : 0;
     static const int lazy_gain = getenv("DFL_LAZYG") ? atoi(getenv("DFL_LAZYG")) : 0;
-    std::vector<uint32_t> bucket((size_t)WAYS << BB, EMPTY_ENTRY);
+    std::vector<uint16_t> bucket((size_t)WAYS << BB, (uint16_t)EMPTY_ENTRY);
     static Tree lt, dt;
     static bool have_prices = false;
     if (!(keep_prices && have_prices)) {
@@ -211,7 +211,7 @@ static void deflate_region(BitWriter &bw, const uint8_t *src, uint32_t n, uint32
             }
             if (!any || p < carry) continue;
             G[lane] = 0;
-            const uint32_t *e = &bucket[WAYS * (H[lane] >> (32 - BB))];
+            const uint16_t *e = &bucket[WAYS * (H[lane] >> (32 - BB))];
             const Bytes16 c16 = load16(src + p);
             L[lane] = WAYS == 4    ? find_match<4>(src, p, n, c16, e, rep, costs, D[lane], G[lane])
                       : WAYS == 16 ? find_match<16>(src, p, n, c16, e, rep, costs, D[lane], G[lane])
@@ -221,10 +221,7 @@ static void deflate_region(BitWriter &bw, const uint8_t *src, uint32_t n, uint32
         }
         for (uint32_t lane = 0; lane < 64; lane++) {  // insert
             const uint32_t p = s + lane;
-            if (p + 4 <= n) {
-                const Bytes16 c16 = load16(src + p);
-                bucket[WAYS * (H[lane] >> (32 - BB)) + ((p >> 6) % WAYS)] = make_entry(p, p + 12 <= n ? context_tag(c16.lo, c16.hi) : 0u);
-            }
+            if (p + 4 <= n) bucket[WAYS * (H[lane] >> (32 - BB)) + ((p >> 6) % WAYS)] = make_entry(p);
         }
         if (any) {
             uint32_t adv[64];
