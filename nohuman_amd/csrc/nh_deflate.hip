@@ -5,8 +5,9 @@
 // into regions of 64 KiB and ONE WAVE compresses a region:
 //
 //   match finding   64 consecutive positions per step, a lane each: hash of 4 bytes -> an 8-way bucket of earlier
-//                   positions (16 bits each, in LDS), plus the last match's distance and distances 1..4; the candidate
-//                   that saves most bits under the PREVIOUS block's code lengths wins (find_match, nh_deflate_core.h).
+//                   positions (16 bits each, in LDS), plus distance 1 (runs); compared in lockstep rounds of 16 bytes,
+//                   the longest is taken if it saves bits under the PREVIOUS block's code lengths (find_match,
+//                   nh_deflate_core.h).
 //   parse           lazy rule by a lane shift, then the chain of tokens through the step with v_readlane; a match
 //                   that reached the scan cap is extended by the whole wave at once (8 bytes a lane).
 //   block           every 32 KiB of input: symbol counts (LDS atomics) -> rank sort by the wave -> code lengths
@@ -17,7 +18,7 @@
 //                   regions' streams concatenate; a small kernel packs them for one D2H copy.
 //
 // The host side (GpuGzipEncoder, a StreamEncoder of nh_codec.h) stages the writer's spans in page-locked chunks,
-// keeps two chunks in flight, computes the member's CRC-32 (carry-less multiply) and writes header, streams and
+// keeps two chunks in flight, joins the regions' CRC-32s (computed by the same waves) and writes header, streams and
 // trailer: one ordinary gzip member.  Parity target is the decompressed content (compression.rs:282-288), checked
 // by zlib and by this repo's own reader in tests/test_gpu_deflate.py.
 #include <errno.h>
@@ -53,6 +54,7 @@ struct DeflateArgs {
     uint8_t *slots;         // n_regions output slots, slot_stride bytes apart (4-byte aligned)
     uint32_t slot_stride;
     uint32_t *sizes;        // bytes written per region
+    uint32_t *crcs;         // CRC-32 of every region's text
     uint32_t *tok;          // n_regions x TOK_CAP
     const uint8_t *prior;   // PRIOR_BYTES: literal/length lengths then distance lengths; the starting prices
     uint8_t *prior_out;     // region 0 leaves its last block's lengths here
@@ -239,9 +241,13 @@ __device__ void finish_block(RegionLds<WAYS> &S, BitOut &bo, const uint32_t *tok
             wave_put2(bo, lane, S.clcode[s], in ? S.cllen[s] : 0u, it >> 5, in ? cl_extra_bits(s) : 0u);
         }
     }
+    // (the tokens were written by this wave's own stores: read past the L1; the next round's are fetched a round early)
+    uint32_t t_next = (uint32_t)lane < ntok ? __hip_atomic_load(&tok[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
     for (uint32_t i = 0; i < ntok; i += 64) {
         const bool in = i + (uint32_t)lane < ntok;
-        const uint32_t t = in ? __hip_atomic_load(&tok[i + lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
+        const uint32_t t = t_next;
+        if (i + 64u + (uint32_t)lane < ntok)
+            t_next = __hip_atomic_load(&tok[i + 64u + lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         uint32_t a = 0, na = 0, b = 0, nb = 0;
         if (in) {
             if (t & 0x80000000u) {
@@ -285,8 +291,37 @@ __global__ __launch_bounds__(64) void k_deflate(DeflateArgs a) {
     const PackedCounts lfreq{S.lfreq2}, dfreq{S.dfreq2};
     for (uint32_t i = (uint32_t)lane; i < OB_WORDS; i += 64) S.ob[i] = 0;
     __syncthreads();
+    // CRC-32 of the region's text: a slice per lane, bit by bit (0.7 % of the region's time; it also brings the
+    // text into the L2 before the match finder asks for it), the slices joined by one multiplication each
+    {
+        const uint32_t slice = (((n + 63u) >> 6) + 15u) & ~15u;
+        const uint32_t start = (uint32_t)lane * slice;
+        const uint32_t len = start >= n ? 0u : (n - start < slice ? n - start : slice);
+        uint32_t crc = 0xFFFFFFFFu;
+        const uint8_t *sp = src + start;
+        uint32_t i = 0;
+        for (; i + 16u <= len; i += 16u) {
+            const uint4 v = *(const uint4 *)(sp + i);  // (region bases and slices are multiples of 16)
+            const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                crc ^= w[q];
+#pragma unroll 8
+                for (int k = 0; k < 32; k++) crc = (crc >> 1) ^ (CRC_POLY & (0u - (crc & 1u)));
+            }
+        }
+        for (; i < len; i++) {
+            crc ^= sp[i];
+            for (int k = 0; k < 8; k++) crc = (crc >> 1) ^ (CRC_POLY & (0u - (crc & 1u)));
+        }
+        crc = len ? ~crc : 0u;
+        uint32_t t = len ? gf2_mul(crc, gf2_xpow8((uint64_t)(n - (start + len)))) : 0u;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) t ^= (uint32_t)__shfl_xor((int)t, o);
+        if (lane == 0) a.crcs[r] = t;
+    }
     BitOut bo{S.ob, (uint32_t *)(a.slots + (size_t)r * a.slot_stride), 0u, 0u};
-    uint32_t carry = 0, rep = 0, ntok = 0, blk_from = 0;
+    uint32_t carry = 0, ntok = 0, blk_from = 0;
     const uint64_t lt_mask = (1ull << lane) - 1ull;
     Bytes16 next16 = load16(src + lane);
     unsigned long long t_match = 0, t_parse = 0, t_block = 0, t_all = __builtin_amdgcn_s_memtime();
@@ -305,7 +340,7 @@ __global__ __launch_bounds__(64) void k_deflate(DeflateArgs a) {
         if (any && inside && p >= carry) {
             const Costs costs{S.llen, S.dlen};
             int gain = 0;
-            L = find_match<WAYS>(src, p, n, cur16, &S.bucket[WAYS * hash_bucket(h)], rep, costs, D, gain);
+            L = find_match<WAYS>(src, p, n, cur16, &S.bucket[WAYS * hash_bucket(h)], costs, D, gain);
         }
         __syncthreads();
         const unsigned long long c1 = a.prof ? __builtin_amdgcn_s_memtime() : 0ull;
@@ -346,8 +381,6 @@ __global__ __launch_bounds__(64) void k_deflate(DeflateArgs a) {
                 q += l;
             }
             carry = s + q;
-            const uint64_t msel = __ballot(L != 0) & sel;
-            if (msel) rep = readlane_u(D, 63u - (uint32_t)__builtin_clzll(msel));
             if ((sel >> lane) & 1ull) {
                 const uint32_t idx = ntok + (uint32_t)__popcll(sel & lt_mask);
                 if (L) {
@@ -445,7 +478,7 @@ struct DeflateDev {  // device side of one encoder: buffers for chunks in flight
         static const uint32_t r = [] {
             const char *e = getenv("NOHUMAN_GZIP_REGION");
             const long v = e ? atol(e) : 65536;
-            return (uint32_t)(v < 4096 ? 4096 : v > (long)dfl::MAX_REGION ? (long)dfl::MAX_REGION : v);
+            return (uint32_t)(v < 4096 ? 4096 : v > (long)dfl::MAX_REGION ? (long)dfl::MAX_REGION : (v & ~63L));
         }();
         return r;
     }
@@ -459,6 +492,8 @@ struct DeflateDev {  // device side of one encoder: buffers for chunks in flight
         uint8_t *d_in = nullptr;
         uint8_t *d_slots = nullptr;
         uint32_t *d_sizes = nullptr;
+        uint32_t *d_crcs = nullptr;
+        uint32_t *h_crcs = nullptr;  // page-locked
         uint64_t *d_offsets = nullptr;
         uint8_t *d_out = nullptr;
         uint8_t *h_out = nullptr;  // page-locked
@@ -466,6 +501,7 @@ struct DeflateDev {  // device side of one encoder: buffers for chunks in flight
         hipEvent_t done = nullptr, k0 = nullptr, k1 = nullptr, filled = nullptr;
         size_t fill = 0;
         size_t staged_from = 0;    // [staged_from, fill) of h_in is not on the device yet
+        size_t submitted = 0;      // bytes of text in the chunk that is in flight
         uint32_t n_regions = 0;
         bool in_flight = false;
     } buf[NBUF];
@@ -492,6 +528,8 @@ struct DeflateDev {  // device side of one encoder: buffers for chunks in flight
             if ((e = hipMemset(b.d_in, 0, CHUNK + 256)) != hipSuccess) return fail(e, "memset");
             if ((e = hipMalloc((void **)&b.d_slots, (size_t)max_regions * slot_stride)) != hipSuccess) return fail(e, "slots");
             if ((e = hipMalloc((void **)&b.d_sizes, max_regions * sizeof(uint32_t))) != hipSuccess) return fail(e, "sizes");
+            if ((e = hipMalloc((void **)&b.d_crcs, max_regions * sizeof(uint32_t))) != hipSuccess) return fail(e, "crcs");
+            if ((e = hipHostMalloc((void **)&b.h_crcs, max_regions * sizeof(uint32_t), hipHostMallocDefault)) != hipSuccess) return fail(e, "pinned crcs");
             if ((e = hipMalloc((void **)&b.d_offsets, (max_regions + 1) * sizeof(uint64_t))) != hipSuccess) return fail(e, "offsets");
             if ((e = hipMalloc((void **)&b.d_out, (size_t)max_regions * slot_stride)) != hipSuccess) return fail(e, "packed output");
             if ((e = hipHostMalloc((void **)&b.h_out, (size_t)max_regions * slot_stride, hipHostMallocDefault)) != hipSuccess)
@@ -530,6 +568,8 @@ struct DeflateDev {  // device side of one encoder: buffers for chunks in flight
             if (b.d_in) (void)hipFree(b.d_in);
             if (b.d_slots) (void)hipFree(b.d_slots);
             if (b.d_sizes) (void)hipFree(b.d_sizes);
+            if (b.d_crcs) (void)hipFree(b.d_crcs);
+            if (b.h_crcs) (void)hipHostFree(b.h_crcs);
             if (b.d_offsets) (void)hipFree(b.d_offsets);
             if (b.d_out) (void)hipFree(b.d_out);
             if (b.h_out) (void)hipHostFree(b.h_out);
@@ -595,6 +635,7 @@ struct DeflateDev {  // device side of one encoder: buffers for chunks in flight
         a.slots = b.d_slots;
         a.slot_stride = slot_stride;
         a.sizes = b.d_sizes;
+        a.crcs = b.d_crcs;
         a.tok = d_tok;
         a.prior = d_prior + (chunks & 1) * dfl::PRIOR_BYTES;
         a.prior_out = d_prior + ((chunks + 1) & 1) * dfl::PRIOR_BYTES;
@@ -611,13 +652,16 @@ struct DeflateDev {  // device side of one encoder: buffers for chunks in flight
         if ((e = hipGetLastError()) != hipSuccess) return fail(e, "launch");
         if ((e = hipMemcpyAsync(b.h_total, b.d_offsets + b.n_regions, sizeof(uint64_t), hipMemcpyDeviceToHost, stream)) != hipSuccess)
             return fail(e, "D2H");
+        if ((e = hipMemcpyAsync(b.h_crcs, b.d_crcs, b.n_regions * sizeof(uint32_t), hipMemcpyDeviceToHost, stream)) != hipSuccess)
+            return fail(e, "D2H");
         if ((e = hipEventRecord(b.done, stream)) != hipSuccess) return fail(e, "event");
+        b.submitted = b.fill;
         b.in_flight = true;
         chunks++;
         return NH_OK;
     }
     // waits for buf[i] and brings its stream to h_out; *len = its bytes
-    int collect(int i, size_t *len) {
+    int collect(int i, size_t *len, uint32_t *crc) {
         Buf &b = buf[i];
         hipError_t e = hipSetDevice(device);
         if (e != hipSuccess) return fail(e, "hipSetDevice");
@@ -628,6 +672,18 @@ struct DeflateDev {  // device side of one encoder: buffers for chunks in flight
         if (total > (uint64_t)max_regions * slot_stride) return set_error(NH_EDEVICE, "gzip encoder: impossible stream size");
         if ((e = hipMemcpyAsync(b.h_out, b.d_out, total, hipMemcpyDeviceToHost, stream)) != hipSuccess) return fail(e, "D2H");
         if ((e = hipStreamSynchronize(stream)) != hipSuccess) return fail(e, "D2H");
+        // the member's CRC-32 grows by the chunk's regions (computed on the GPU, joined here: a multiplication each)
+        {
+            static const uint32_t full = dfl::gf2_xpow8(REGION);
+            uint32_t c = *crc;
+            size_t left = b.submitted;
+            for (uint32_t r = 0; r < b.n_regions; r++) {
+                const size_t rl = left < REGION ? left : REGION;
+                c = dfl::gf2_mul(c, rl == REGION ? full : dfl::gf2_xpow8(rl)) ^ b.h_crcs[r];
+                left -= rl;
+            }
+            *crc = c;
+        }
         b.in_flight = false;
         b.fill = 0;
         b.staged_from = 0;
@@ -678,7 +734,6 @@ public:
             DeflateDev::Buf &b = dev_.buf[cur_];
             const size_t room = DeflateDev::CHUNK - b.fill;
             const size_t take = n < room ? n : room;
-            crc_ = crc32_fast(crc_, c, take);
             // a long span of text that is on this GPU already (the batch the classifier worked on) is copied
             // there; everything else is staged in page-locked memory and uploaded in one piece
             if (take >= DEVICE_SPAN_MIN && c >= map_host_ && c + take <= map_host_ + map_len_) {
@@ -720,7 +775,7 @@ private:
     void retire(int i) {
         if (!dev_.buf[i].in_flight || rc_ != NH_OK) return;
         size_t len = 0;
-        if ((rc_ = dev_.collect(i, &len)) != NH_OK) return;
+        if ((rc_ = dev_.collect(i, &len, &crc_)) != NH_OK) return;
         if (!write_fd(fd_, dev_.buf[i].h_out, len)) rc_ = set_error(NH_EIO, "write error on %s", name_.c_str());
         out_bytes_ += len;
     }

@@ -291,26 +291,27 @@ NH_HD inline int match_gain(const Costs &c, uint64_t lit8, uint32_t len, uint32_
 }
 
 // The best match for position p of the region src[0..n): candidates are the WAYS entries of the position's
-// bucket (older positions with the same hash), the distance of the last match taken (rep) and distances 1..4; the
-// one that saves most bits under `costs` wins.  cur16 = the sixteen bytes at p (the caller has them from its
-// previous step).  All candidates are compared sixteen bytes at a time in lockstep and the loads of a round are
-// unconditional -- issued back to back, waited for once: on a GPU the rounds' latency is what a step costs.
-// Returns the length (0: none worth taking, else 3..SCAN_CAP, SCAN_CAP meaning "at least") and sets dist and gain.
+// bucket (older positions with the same hash) and distance 1 (a run: the one short distance the bucket cannot
+// hold, because a step's own positions enter it after the look-ups; distances 2..4 and the last match's distance
+// were candidates too and found 0.03 % on FASTQ text).  cur16 = the sixteen bytes at p (the caller has them from
+// its previous step).  All candidates are compared sixteen bytes at a time in lockstep and the loads of a round are
+// unconditional -- issued back to back, waited for once: on a GPU the rounds' latency is what a step costs.  The
+// longest far candidate (the nearest among equals) and the run are priced under `costs`; the one that saves more
+// bits wins.  Returns the length (0: none worth taking, else 3..SCAN_CAP, SCAN_CAP meaning "at least").
 template <int WAYS, typename EntryPtr>
 NH_HD inline uint32_t find_match(const uint8_t *src, uint32_t p, uint32_t n, const Bytes16 &cur16, EntryPtr entries,
-                                 uint32_t rep, const Costs &costs, uint32_t &dist_out, int &gain_out) {
-    constexpr int NC = 5 + WAYS;
+                                 const Costs &costs, uint32_t &dist_out, int &gain_out) {
+    constexpr int NC = 1 + WAYS;
     const uint32_t room = n - p;
     const uint32_t cap = room < SCAN_CAP ? room : SCAN_CAP;
     if (cap < MIN_MATCH) return 0;
     const uint8_t *cur = src + p;
     uint32_t d[NC], len[NC];
-    for (int k = 0; k < 4; k++) d[k] = (uint32_t)(k + 1) <= p ? (uint32_t)(k + 1) : 0u;
-    d[4] = (rep > 4u && rep <= p && rep <= WINDOW) ? rep : 0u;
+    d[0] = p >= 1u ? 1u : 0u;
     for (int k = 0; k < WAYS; k++) {
         const uint32_t c = entries[k];
-        const bool ok = room >= 4u && c < p && p - c <= WINDOW && p - c > 4u && p - c != d[4];
-        d[5 + k] = ok ? p - c : 0u;
+        const bool ok = room >= 4u && c < p && p - c <= WINDOW && p - c > 1u;
+        d[1 + k] = ok ? p - c : 0u;
     }
     Bytes16 x[NC];
     for (int k = 0; k < NC; k++) x[k] = load16(cur - d[k]);  // (distance 0 reads the position itself)
@@ -325,15 +326,8 @@ NH_HD inline uint32_t find_match(const uint8_t *src, uint32_t p, uint32_t n, con
                 if (len[k] == 16u) len[k] += equal_bytes16(x[k], c2);
         }
     }
-    // the longest near candidate (distances 1..4, rep) and the longest far one (nearest among equals) are priced;
-    // pricing every candidate finds the same matches on FASTQ text and costs three times the instructions
-    uint32_t nl = 0, nd = 0, fl = 0, fd = 0;
-    for (int k = 0; k < 5; k++)
-        if (len[k] > nl) {
-            nl = len[k];
-            nd = d[k];
-        }
-    for (int k = 5; k < NC; k++)
+    uint32_t nl = len[0], fl = 0, fd = 0;
+    for (int k = 1; k < NC; k++)
         if (len[k] > fl || (len[k] == fl && fl != 0u && d[k] < fd)) {
             fl = len[k];
             fd = d[k];
@@ -344,10 +338,10 @@ NH_HD inline uint32_t find_match(const uint8_t *src, uint32_t p, uint32_t n, con
     uint32_t best = 0, bdist = 0;
     int bgain = 0;
     if (nl >= MIN_MATCH) {
-        bgain = match_gain(costs, lit8, nl, nd);
+        bgain = match_gain(costs, lit8, nl, 1u);
         if (bgain > 0) {
             best = nl;
-            bdist = nd;
+            bdist = 1u;
         } else {
             bgain = 0;
         }
@@ -371,6 +365,41 @@ NH_HD inline uint32_t match_price(const Costs &c, uint32_t len, uint32_t dist) {
     len_symbol(len - 3u, sym, eb, ev);
     dist_symbol(dist - 1u, dsym, deb, dev);
     return cost_or(c.llen[sym], 10u) + eb + cost_or(c.dlen[dsym], 8u) + deb;
+}
+
+// ---- CRC-32 of the text (the gzip member's check value), computed where the text is ---------------------------
+// Reflected polynomial 0xEDB88320 as in RFC 1952.  A wave's lanes each take a slice of the region; slices and
+// regions are joined by crc(A || B) = crc(A) * x^(8 |B|) + crc(B) over GF(2)[x] mod P.
+constexpr uint32_t CRC_POLY = 0xEDB88320u;
+NH_HD inline uint32_t crc32_bytes(uint32_t crc, const uint8_t *p, uint32_t n) {  // one bit at a time, no table
+    crc = ~crc;
+    for (uint32_t i = 0; i < n; i++) {
+        crc ^= p[i];
+        for (int k = 0; k < 8; k++) crc = (crc >> 1) ^ (CRC_POLY & (0u - (crc & 1u)));
+    }
+    return ~crc;
+}
+// a(x) * b(x) mod P, both in the reflected representation (bit 31 = x^0)
+NH_HD inline uint32_t gf2_mul(uint32_t a, uint32_t b) {
+    uint32_t p = 0;
+    for (int i = 0; i < 32; i++) {
+        p ^= b & (0u - ((a >> (31 - i)) & 1u));
+        b = (b >> 1) ^ (CRC_POLY & (0u - (b & 1u)));
+    }
+    return p;
+}
+NH_HD inline uint32_t gf2_xpow8(uint64_t n_bytes) {  // x^(8 n) mod P
+    uint32_t r = 0x80000000u;        // x^0
+    uint32_t sq = 0x00800000u;       // x^8
+    while (n_bytes) {
+        if (n_bytes & 1u) r = gf2_mul(r, sq);
+        sq = gf2_mul(sq, sq);
+        n_bytes >>= 1;
+    }
+    return r;
+}
+NH_HD inline uint32_t crc32_join(uint32_t crc_a, uint32_t crc_b, uint64_t len_b) {
+    return gf2_mul(crc_a, gf2_xpow8(len_b)) ^ crc_b;
 }
 
 }  // namespace dfl

@@ -191,7 +191,7 @@ static void deflate_region(BitWriter &bw, const uint8_t *src, uint32_t n, uint32
     }
     Block b;
     b.reset(0);
-    uint32_t carry = 0, rep = 0;
+    uint32_t carry = 0;
     for (uint32_t s = 0; s < n; s += 64) {
         uint32_t L[64], D[64], H[64];
         int G[64];
@@ -213,9 +213,9 @@ static void deflate_region(BitWriter &bw, const uint8_t *src, uint32_t n, uint32
             G[lane] = 0;
             const uint16_t *e = &bucket[WAYS * (H[lane] >> (32 - BB))];
             const Bytes16 c16 = load16(src + p);
-            L[lane] = WAYS == 4    ? find_match<4>(src, p, n, c16, e, rep, costs, D[lane], G[lane])
-                      : WAYS == 16 ? find_match<16>(src, p, n, c16, e, rep, costs, D[lane], G[lane])
-                                   : find_match<8>(src, p, n, c16, e, rep, costs, D[lane], G[lane]);
+            L[lane] = WAYS == 4    ? find_match<4>(src, p, n, c16, e, costs, D[lane], G[lane])
+                      : WAYS == 16 ? find_match<16>(src, p, n, c16, e, costs, D[lane], G[lane])
+                                   : find_match<8>(src, p, n, c16, e, costs, D[lane], G[lane]);
             static const int seq_insert = getenv("DFL_SEQ") ? atoi(getenv("DFL_SEQ")) : 0;
             
         }
@@ -251,7 +251,6 @@ static void deflate_region(BitWriter &bw, const uint8_t *src, uint32_t n, uint32
                     b.tok.push_back(tok_match(l, D[q]));
                     b.lfreq[sym]++;
                     b.dfreq[dsym]++;
-                    rep = D[q];
                     g_match++;
                     g_match_bytes += l;
                 } else {
