@@ -60,15 +60,24 @@ try:
         assert _lib.lib().nh_compress_file(os.fsencode(fo), os.fsencode(fo + ".gz"), 2, threads) == 0
         print("gzip took %.1fs, ratio %.2f" % (time.time() - t, os.path.getsize(fo) / os.path.getsize(fo + ".gz")))
         with Engine.open(db) as e:
-            for label, path in (("ONT plain", fo), ("ONT plain", fo), ("ONT gzip", fo + ".gz"), ("ONT gzip", fo + ".gz")):
-                out = os.path.join(tmp, "o.fq")
+            for label, path, codec in (("ONT plain", fo, 0), ("ONT plain", fo, 0), ("ONT gzip", fo + ".gz", 0),
+                                       ("ONT gzip", fo + ".gz", 0), ("ONT gzip > gzip", fo + ".gz", 2), ("ONT gzip > gzip", fo + ".gz", 2)):
+                out = os.path.join(tmp, "o.fq.gz" if codec else "o.fq")
                 if os.path.exists(out):
                     os.remove(out)
                 t = time.time()
-                st = e.run(path, out, threads=threads)
+                st = e.run(path, out, threads=threads, out_codec=codec, codec_threads=threads)
                 dt = time.time() - t
-                print("%-10s %6.2fs wall  %6.3f Mreads/s  %6.2f Gbases/s e2e  (%d reads, %d classified)" % (
-                    label, dt, st.total_sequences / dt / 1e6, st.total_bases / dt / 1e9, st.total_sequences, st.classified))
+                print("%-16s %6.2fs wall  %6.3f Mreads/s  %6.2f Gbases/s e2e  (%d reads, %d classified)" % (
+                    label, dt, st.total_sequences / dt / 1e6, st.total_bases / dt / 1e9, st.total_sequences, st.classified), flush=True)
+            # the gzip output (encoded on the GPU) inflates to the plain output
+            import ctypes, filecmp
+            back = os.path.join(tmp, "back.fq")
+            st3 = (ctypes.c_uint64 * 3)()
+            rc = _lib.lib().nh_gunzip_file(os.fsencode(os.path.join(tmp, "o.fq.gz")), os.fsencode(back), threads, 0, st3)
+            print("gzip output: %.2f GB, ratio %.2f, inflates to the plain output: %s" % (
+                os.path.getsize(os.path.join(tmp, "o.fq.gz")) / 1e9, os.path.getsize(back) / os.path.getsize(os.path.join(tmp, "o.fq.gz")),
+                rc == 0 and filecmp.cmp(back, os.path.join(tmp, "o.fq"), shallow=False)))
         raise SystemExit(0)
     f1, f2 = os.path.join(tmp, "r_1.fq"), os.path.join(tmp, "r_2.fq")
     write_fastq(f1, 1); write_fastq(f2, 2)
