@@ -472,6 +472,29 @@ int gzip_ways() {
     return w;
 }
 
+// page-locked host memory; a host that will not lock that much gets pageable memory (the copies accept it and stage
+// it themselves).  A 64-byte header says which kind a block is.  NOHUMAN_NO_PINNED exercises the fallback.
+void *host_alloc(size_t n) {
+    void *p = nullptr;
+    static const bool no_pin = getenv("NOHUMAN_NO_PINNED") != nullptr;
+    if (!no_pin && hipHostMalloc(&p, n + 64, hipHostMallocDefault) == hipSuccess) {
+        *(uint64_t *)p = 1;
+        return (char *)p + 64;
+    }
+    (void)hipGetLastError();
+    if (posix_memalign(&p, 64, n + 64) != 0) return nullptr;
+    *(uint64_t *)p = 2;
+    return (char *)p + 64;
+}
+void host_free(void *q) {
+    if (!q) return;
+    void *p = (char *)q - 64;
+    if (*(uint64_t *)p == 1)
+        (void)hipHostFree(p);
+    else
+        free(p);
+}
+
 struct DeflateDev {  // device side of one encoder: buffers for chunks in flight
     static constexpr size_t CHUNK = 128u << 20;
     static uint32_t region_bytes() {  // NOHUMAN_GZIP_REGION: tuning (bytes of text a wave compresses)
@@ -523,18 +546,17 @@ struct DeflateDev {  // device side of one encoder: buffers for chunks in flight
         max_regions = (uint32_t)((CHUNK + REGION - 1) / REGION);
         slot_stride = REGION + 256;
         for (Buf &b : buf) {
-            if ((e = hipHostMalloc((void **)&b.h_in, CHUNK + 64, hipHostMallocDefault)) != hipSuccess) return fail(e, "pinned input");
+            if (!(b.h_in = (uint8_t *)host_alloc(CHUNK + 64))) return set_error(NH_EOOM, "gzip encoder: no memory for the staging buffers");
             if ((e = hipMalloc((void **)&b.d_in, CHUNK + 256)) != hipSuccess) return fail(e, "device input");
             if ((e = hipMemset(b.d_in, 0, CHUNK + 256)) != hipSuccess) return fail(e, "memset");
             if ((e = hipMalloc((void **)&b.d_slots, (size_t)max_regions * slot_stride)) != hipSuccess) return fail(e, "slots");
             if ((e = hipMalloc((void **)&b.d_sizes, max_regions * sizeof(uint32_t))) != hipSuccess) return fail(e, "sizes");
             if ((e = hipMalloc((void **)&b.d_crcs, max_regions * sizeof(uint32_t))) != hipSuccess) return fail(e, "crcs");
-            if ((e = hipHostMalloc((void **)&b.h_crcs, max_regions * sizeof(uint32_t), hipHostMallocDefault)) != hipSuccess) return fail(e, "pinned crcs");
+            if (!(b.h_crcs = (uint32_t *)host_alloc(max_regions * sizeof(uint32_t)))) return set_error(NH_EOOM, "gzip encoder: no memory for the staging buffers");
             if ((e = hipMalloc((void **)&b.d_offsets, (max_regions + 1) * sizeof(uint64_t))) != hipSuccess) return fail(e, "offsets");
             if ((e = hipMalloc((void **)&b.d_out, (size_t)max_regions * slot_stride)) != hipSuccess) return fail(e, "packed output");
-            if ((e = hipHostMalloc((void **)&b.h_out, (size_t)max_regions * slot_stride, hipHostMallocDefault)) != hipSuccess)
-                return fail(e, "pinned output");
-            if ((e = hipHostMalloc((void **)&b.h_total, 64, hipHostMallocDefault)) != hipSuccess) return fail(e, "pinned total");
+            if (!(b.h_out = (uint8_t *)host_alloc((size_t)max_regions * slot_stride)) || !(b.h_total = (uint64_t *)host_alloc(64)))
+                return set_error(NH_EOOM, "gzip encoder: no memory for the staging buffers");
             if ((e = hipEventCreate(&b.done)) != hipSuccess) return fail(e, "event");
             if ((e = hipEventCreate(&b.k0)) != hipSuccess) return fail(e, "event");
             if ((e = hipEventCreate(&b.k1)) != hipSuccess) return fail(e, "event");
@@ -564,16 +586,16 @@ struct DeflateDev {  // device side of one encoder: buffers for chunks in flight
         if (stream) (void)hipStreamSynchronize(stream);
         for (Buf &b : buf) {
             if (b.filled) (void)hipEventDestroy(b.filled);
-            if (b.h_in) (void)hipHostFree(b.h_in);
+            host_free(b.h_in);
             if (b.d_in) (void)hipFree(b.d_in);
             if (b.d_slots) (void)hipFree(b.d_slots);
             if (b.d_sizes) (void)hipFree(b.d_sizes);
             if (b.d_crcs) (void)hipFree(b.d_crcs);
-            if (b.h_crcs) (void)hipHostFree(b.h_crcs);
+            host_free(b.h_crcs);
             if (b.d_offsets) (void)hipFree(b.d_offsets);
             if (b.d_out) (void)hipFree(b.d_out);
-            if (b.h_out) (void)hipHostFree(b.h_out);
-            if (b.h_total) (void)hipHostFree(b.h_total);
+            host_free(b.h_out);
+            host_free(b.h_total);
             if (b.done) (void)hipEventDestroy(b.done);
             if (b.k0) (void)hipEventDestroy(b.k0);
             if (b.k1) (void)hipEventDestroy(b.k1);

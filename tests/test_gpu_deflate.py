@@ -127,3 +127,35 @@ def test_run_takes_long_spans_from_the_device_copy_of_the_batch(tmp_path, monkey
         assert len(want) > 2_000_000
         assert gzip.decompress((tmp_path / ("g_%s.gz" % m)).read_bytes()) == want
         assert gzip.decompress((tmp_path / ("h_%s.gz" % m)).read_bytes()) == want
+
+
+def test_encoder_with_pageable_staging_buffers(tmp_path):
+    """A host that will not page-lock the encoder's staging buffers gets pageable ones (NOHUMAN_NO_PINNED forces it;
+    read once per process, hence the child): same stream contents."""
+    import subprocess
+    data = fastq_text(3000, 21)
+    src = tmp_path / "in.fq"
+    src.write_bytes(data)
+    code = ("import sys, ctypes as C; sys.path.insert(0, %r)\n"
+            "from nohuman_amd import _lib\n"
+            "d = open(sys.argv[1], 'rb').read()\n"
+            "buf = (C.c_char * len(d)).from_buffer_copy(d)\n"
+            "rc = _lib.lib().nh_gzip_gpu_file(0, buf, len(d), sys.argv[2].encode(), None)\n"
+            "sys.exit(rc)\n") % ROOT
+    r = subprocess.run([sys.executable, "-c", code, str(src), str(tmp_path / "o.gz")],
+                       env=dict(os.environ, NOHUMAN_NO_PINNED="1"), capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    assert gzip.decompress((tmp_path / "o.gz").read_bytes()) == data
+
+
+def test_system_gzip_accepts_the_stream(tmp_path):
+    """Interoperability: the system's gzip tool tests and expands the member."""
+    import shutil
+    import subprocess
+    if not shutil.which("gzip"):
+        pytest.skip("no gzip tool on this box")
+    data = fastq_text(5000, 22)
+    gpu_gzip(data, str(tmp_path / "a.gz"))
+    assert subprocess.run(["gzip", "-t", str(tmp_path / "a.gz")]).returncode == 0
+    out = subprocess.run(["gzip", "-dc", str(tmp_path / "a.gz")], capture_output=True)
+    assert out.returncode == 0 and out.stdout == data
