@@ -4,7 +4,7 @@
 // `nohuman reads.fq.gz` run spends most of its time on once the classifier is a GPU kernel.  Here the text is cut
 // into regions of 64 KiB and ONE WAVE compresses a region:
 //
-//   match finding   64 consecutive positions per step, a lane each: hash of 4 bytes -> an 8-way bucket of earlier
+//   match finding   64 consecutive positions per step, a lane each: hash of 5 bytes -> an 8-way bucket of earlier
 //                   positions (16 bits each, in LDS), plus distance 1 (runs); compared in lockstep rounds of 16 bytes,
 //                   the longest is taken if it saves bits under the PREVIOUS block's code lengths (find_match,
 //                   nh_deflate_core.h).
@@ -334,8 +334,8 @@ __global__ __launch_bounds__(64) void k_deflate(DeflateArgs a) {
         const Bytes16 cur16 = next16;
         if (s + 64u < n) next16 = load16(src + p + 64u);
         const uint32_t four = (uint32_t)cur16.lo;
-        const bool has4 = p + 4u <= n;
-        const uint32_t h = hash4(four);
+        const bool has4 = p + HASH_BYTES <= n;
+        const uint32_t h = hash_at(cur16.lo);
         uint32_t L = 0, D = 0;
         if (any && inside && p >= carry) {
             const Costs costs{S.llen, S.dlen};

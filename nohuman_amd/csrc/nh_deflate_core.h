@@ -214,7 +214,13 @@ NH_HD inline uint32_t cl_order(int i) {
 
 // ---- match finding, one position ------------------------------------------------------------------------------
 // the bucket and the tag of the four bytes at a position
-NH_HD inline uint32_t hash4(uint32_t four) { return four * 2654435761u; }
+// the hash of the HASH_BYTES bytes at a position (lo = its first eight bytes).  Five bytes: on FASTQ text a 5-gram
+// bucket holds fewer useless candidates among the bases than a 4-gram one and the header fields still fit (six and
+// more lose them): 0.6 % smaller files than with four.
+constexpr uint32_t HASH_BYTES = 5;
+NH_HD inline uint32_t hash_at(uint64_t lo) {
+    return (uint32_t)(((lo & ((1ull << (8u * HASH_BYTES)) - 1ull)) * 0x9E3779B97F4A7C15ull) >> 32);
+}
 constexpr uint32_t BUCKET_BITS = 10;
 // a bucket entry is a position of the region in 16 bits (regions are at most 64 KiB); 0xFFFF = empty: the last
 // position of a full region can never be a candidate (candidates lie before the position that asks)
@@ -310,7 +316,7 @@ NH_HD inline uint32_t find_match(const uint8_t *src, uint32_t p, uint32_t n, con
     d[0] = p >= 1u ? 1u : 0u;
     for (int k = 0; k < WAYS; k++) {
         const uint32_t c = entries[k];
-        const bool ok = room >= 4u && c < p && p - c <= WINDOW && p - c > 1u;
+        const bool ok = room >= HASH_BYTES && c < p && p - c <= WINDOW && p - c > 1u;
         d[1 + k] = ok ? p - c : 0u;
     }
     Bytes16 x[NC];

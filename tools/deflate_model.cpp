@@ -203,12 +203,7 @@ static void deflate_region(BitWriter &bw, const uint8_t *src, uint32_t n, uint32
             D[lane] = 0;
             H[lane] = 0;
             if (p >= n) continue;
-            static const int HL = getenv("DFL_HASHLEN") ? atoi(getenv("DFL_HASHLEN")) : 4;
-            if (p + HL <= n) {
-                uint64_t v = 0;
-                memcpy(&v, src + p, HL);
-                H[lane] = HL == 4 ? hash4((uint32_t)v) : (uint32_t)((v * 0x9E3779B97F4A7C15ull) >> 32);
-            }
+            if (p + HASH_BYTES <= n) H[lane] = hash_at(load8(src + p));
             if (!any || p < carry) continue;
             G[lane] = 0;
             const uint16_t *e = &bucket[WAYS * (H[lane] >> (32 - BB))];
@@ -221,7 +216,7 @@ static void deflate_region(BitWriter &bw, const uint8_t *src, uint32_t n, uint32
         }
         for (uint32_t lane = 0; lane < 64; lane++) {  // insert
             const uint32_t p = s + lane;
-            if (p + 4 <= n) bucket[WAYS * (H[lane] >> (32 - BB)) + ((p >> 6) % WAYS)] = make_entry(p);
+            if (p + HASH_BYTES <= n) bucket[WAYS * (H[lane] >> (32 - BB)) + ((p >> 6) % WAYS)] = make_entry(p);
         }
         if (any) {
             uint32_t adv[64];
