@@ -125,7 +125,10 @@ struct TreeLds {  // scratch of the code construction: the used symbols in ascen
     uint16_t ssym[NLIT];
 };
 
-// code lengths and codes of one alphabet from its counts (all in LDS); the wave sorts, lane 0 builds
+// Code lengths and codes of one alphabet from its counts (all in LDS).  The wave rank-sorts the used symbols; lane 0
+// runs the three passes of the minimum-redundancy construction over them (the only serial part: a few dozen symbols
+// on FASTQ text); the histogram of depths, the Kraft repair, the lengths' way back to the symbols and the canonical
+// codes are wave-parallel, with lane l holding what belongs to length l.
 template <typename Counts>
 __device__ void build_tree_wave(const Counts &freq, int nsym, int maxbits, uint8_t *lens, uint16_t *codes, uint16_t *ta,
                                 uint16_t *tsym, int lane) {
@@ -139,10 +142,12 @@ __device__ void build_tree_wave(const Counts &freq, int nsym, int maxbits, uint8
                 freq.bump(s);
                 used++;
             }
+    used = used < 2 ? 2 : used;
     __syncthreads();
     // rank sort by (count, symbol): every lane counts the smaller pairs for its symbols (broadcast reads)
-    for (int s = lane; s < nsym; s += 64) {
-        const uint32_t f = freq.get(s);
+    for (int s = lane; s < NLIT; s += 64) {
+        if (s < nsym) lens[s] = 0;
+        const uint32_t f = s < nsym ? freq.get(s) : 0u;
         if (!f) continue;
         uint32_t r = 0;
         for (int j = 0; j < nsym; j++) {
@@ -153,9 +158,68 @@ __device__ void build_tree_wave(const Counts &freq, int nsym, int maxbits, uint8
         tsym[r] = (uint16_t)s;
     }
     __syncthreads();
-    if (lane == 0) {
-        huff_lengths_sorted(ta, tsym, (int)used, nsym, maxbits, lens);
-        huff_codes(lens, nsym, maxbits, codes);
+    const int n = (int)used;
+    if (lane == 0) huff_depths_sorted(ta, n);  // ta[i] = depth of the i-th rarest symbol
+    __syncthreads();
+    // lane l: how many symbols have depth l (deeper ones counted at maxbits)
+    uint32_t my_cnt = 0;
+    for (int base = 0; base < n; base += 64) {
+        const int i = base + lane;
+        const uint32_t dep = i < n ? (ta[i] > (uint32_t)maxbits ? (uint32_t)maxbits : (uint32_t)ta[i]) : 0u;
+#pragma unroll
+        for (int l = 1; l <= MAXBITS; l++) {
+            const uint64_t b = __ballot(dep == (uint32_t)l);
+            if (lane == l) my_cnt += (uint32_t)__popcll(b);
+        }
+    }
+    // Kraft sum in units of 2^-maxbits; while it is above one: a code of the longest length is given up and the
+    // longest shorter code is lengthened by one bit to take its sibling's place -- one unit less each time
+    uint32_t total = wave_sum((lane >= 1 && lane <= maxbits) ? my_cnt << (maxbits - lane) : 0u);
+    while (total > (1u << maxbits)) {
+        if (lane == maxbits) my_cnt--;
+        const uint64_t have = __ballot(my_cnt != 0u && lane >= 1 && lane < maxbits);
+        const int l = 63 - __builtin_clzll(have);
+        if (lane == l) my_cnt--;
+        if (lane == l + 1) my_cnt += 2;
+        total--;
+    }
+    // the rarest symbols take the longest codes: sorted index i lies in the stretch of its length
+    for (int base = 0; base < n; base += 64) {
+        const int i = base + lane;
+        uint32_t cum = 0, mine = 0;
+#pragma unroll
+        for (int l = MAXBITS; l >= 1; l--) {
+            const uint32_t c = readlane_u(my_cnt, (uint32_t)l);
+            if ((uint32_t)i >= cum && (uint32_t)i < cum + c) mine = (uint32_t)l;
+            cum += c;
+        }
+        if (i < n) lens[tsym[i]] = (uint8_t)mine;
+    }
+    __syncthreads();
+    // canonical codes (RFC 1951 3.2.2): lane l holds the first code of length l and the symbols seen so far with it
+    uint32_t my_next = 0, my_run = 0;
+    {
+        uint32_t code = 0, prev = 0;
+#pragma unroll
+        for (int l = 1; l <= MAXBITS; l++) {
+            code = (code + prev) << 1;
+            if (lane == l) my_next = code;
+            prev = readlane_u(my_cnt, (uint32_t)l);
+        }
+    }
+    const uint64_t lt = (1ull << lane) - 1ull;
+    for (int base = 0; base < nsym; base += 64) {
+        const int s = base + lane;
+        const uint32_t ln = s < nsym ? lens[s] : 0u;
+        const uint32_t first = (uint32_t)__shfl((int)my_next, (int)ln), before = (uint32_t)__shfl((int)my_run, (int)ln);
+        uint32_t rank = 0;
+#pragma unroll
+        for (int l = 1; l <= MAXBITS; l++) {
+            const uint64_t b = __ballot(ln == (uint32_t)l);
+            if (ln == (uint32_t)l) rank = (uint32_t)__popcll(b & lt);
+            if (lane == l) my_run += (uint32_t)__popcll(b);
+        }
+        if (s < nsym) codes[s] = ln ? (uint16_t)bitrev(first + before + rank, ln) : (uint16_t)0;
     }
     __syncthreads();
 }
@@ -187,24 +251,38 @@ struct __attribute__((aligned(16))) RegionLds {
 // Ends a block: builds the codes from the counts and writes header + tokens (or the bytes, stored).
 template <int WAYS>
 __device__ void finish_block(RegionLds<WAYS> &S, BitOut &bo, const uint32_t *tok, uint32_t ntok, const uint8_t *src,
-                             uint32_t from, uint32_t to, int lane) {
+                             uint32_t from, uint32_t to, int lane, unsigned long long *prof) {
+    const unsigned long long f0 = prof ? __builtin_amdgcn_s_memtime() : 0ull;
     const PackedCounts lfreq{S.lfreq2}, dfreq{S.dfreq2};
     if (lane == 0) lfreq.bump(256);
     __syncthreads();
     build_tree_wave(lfreq, NLIT_USED, MAXBITS, S.llen, S.lcode, S.u.tree.a, S.u.tree.ssym, lane);
     build_tree_wave(dfreq, NDIST_USED, MAXBITS, S.dlen, S.dcode, S.u.tree.a, S.u.tree.ssym, lane);
-    if (lane == 0) {
-        int hlit = NLIT_USED, hdist = NDIST_USED;
-        while (hlit > 257 && S.llen[hlit - 1] == 0) hlit--;
-        while (hdist > 1 && S.dlen[hdist - 1] == 0) hdist--;
-        for (int i = 0; i < hlit; i++) S.u.hdr.all[i] = S.llen[i];
-        for (int i = 0; i < hdist; i++) S.u.hdr.all[hlit + i] = S.dlen[i];
-        S.misc[0] = hlit;
-        S.misc[1] = hdist;
-        S.misc[2] = rle_lengths(S.u.hdr.all, hlit + hdist, S.u.hdr.items, S.clfreq);
+    {
+        // hlit / hdist: one past the last used symbol; the two rows of lengths in a row, then their run-length form
+        uint32_t top_l = 0, top_d = 0;
+        for (int s0 = lane; s0 < NLIT_USED; s0 += 64)
+            if (S.llen[s0]) top_l = (uint32_t)s0 + 1u;
+        if (lane < NDIST_USED && S.dlen[lane]) top_d = (uint32_t)lane + 1u;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const uint32_t a1 = (uint32_t)__shfl_xor((int)top_l, o), a2 = (uint32_t)__shfl_xor((int)top_d, o);
+            top_l = a1 > top_l ? a1 : top_l;
+            top_d = a2 > top_d ? a2 : top_d;
+        }
+        const int hlit_ = (int)(top_l < 257u ? 257u : top_l), hdist_ = (int)(top_d < 1u ? 1u : top_d);
+        for (int i0 = lane; i0 < hlit_; i0 += 64) S.u.hdr.all[i0] = S.llen[i0];
+        if (lane < hdist_) S.u.hdr.all[hlit_ + lane] = S.dlen[lane];
+        __syncthreads();
+        if (lane == 0) {
+            S.misc[0] = hlit_;
+            S.misc[1] = hdist_;
+            S.misc[2] = rle_lengths(S.u.hdr.all, hlit_ + hdist_, S.u.hdr.items, S.clfreq);
+        }
     }
     __syncthreads();
     build_tree_wave(PlainCounts{S.clfreq}, NCL, MAXBITS_CL, S.cllen, S.clcode, S.cl_a, S.cl_sym, lane);
+    if (prof && lane == 0) atomicAdd(&prof[5], __builtin_amdgcn_s_memtime() - f0);
     const int hlit = S.misc[0], hdist = S.misc[1], ni = S.misc[2];
     int hclen = NCL;
     while (hclen > 4 && S.cllen[cl_order(hclen - 1)] == 0) hclen--;
@@ -404,7 +482,7 @@ __global__ __launch_bounds__(64) void k_deflate(DeflateArgs a) {
         if (carry - blk_from >= BLOCK_IN || s + 64u >= n) {
             const uint32_t to = carry < n ? carry : n;
             __threadfence_block();
-            finish_block<WAYS>(S, bo, tok, ntok, src, blk_from, to, lane);
+            finish_block<WAYS>(S, bo, tok, ntok, src, blk_from, to, lane, a.prof);
             for (int i = lane; i < NLIT / 2; i += 64) S.lfreq2[i] = 0;
             if (lane < NDIST / 2) S.dfreq2[lane] = 0;
             __syncthreads();
@@ -606,8 +684,8 @@ struct DeflateDev {  // device side of one encoder: buffers for chunks in flight
             unsigned long long h[8] = {};
             (void)hipMemcpy(h, d_prof, 64, hipMemcpyDeviceToHost);
             if (h[4])
-                fprintf(stderr, "[gzip prof] %llu regions: per region (100 MHz ticks) match %.0f  insert+parse+tokens %.0f  blocks %.0f  all %.0f\n",
-                        h[4], (double)h[0] / h[4], (double)h[1] / h[4], (double)h[2] / h[4], (double)h[3] / h[4]);
+                fprintf(stderr, "[gzip prof] %llu regions: per region (cycles) match %.0f  insert+parse+tokens %.0f  blocks %.0f (codes %.0f)  all %.0f\n",
+                        h[4], (double)h[0] / h[4], (double)h[1] / h[4], (double)h[2] / h[4], (double)h[5] / h[4], (double)h[3] / h[4]);
             (void)hipFree(d_prof);
         }
         if (stream) (void)hipStreamDestroy(stream);
