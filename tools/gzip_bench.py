@@ -32,6 +32,11 @@ for rep in range(3):
     assert rc == 0, L.nh_last_error().decode()
     print("GPU gzip: %.3f : 1   wall %.3f s = %.2f GB/s   kernels %.1f ms = %.1f GB/s"
           % (len(data) / st[0], dt, len(data) / dt / 1e9, st[1] / 1e3, len(data) / (st[1] / 1e6) / 1e9), flush=True)
+tiny = (C.c_char * 1000).from_buffer_copy(data[:1000])
+t = time.time()
+for _ in range(5):
+    assert L.nh_gzip_gpu_file(0, tiny, 1000, os.fsencode(out + ".tiny"), None) == 0
+print("a call on 1000 bytes (buffers allocated, one region, torn down): %.1f ms" % ((time.time() - t) / 5 * 1e3), flush=True)
 t = time.time()
 ok = zlib.decompress(open(out, "rb").read(), 31) == data
 print("zlib inflates it to the text: %s (%.1f s)" % (ok, time.time() - t))
