@@ -232,6 +232,10 @@ int nh_compress_file(const char *in, const char *out, int codec, uint32_t thread
  * (NOHUMAN_GZIP=host selects the host encoder above).  stats (may be NULL): [0] bytes of the file, [1] microseconds
  * of kernel time (HIP events).  Parity target as above: the decompressed content. */
 int nh_gzip_gpu_file(int32_t device, const void *in, uint64_t n, const char *out, uint64_t *stats);
+/* nh_compress_file for a host that keeps the reference's two stages (kraken2-style temporary file, then compress,
+ * src/main.rs:342-368) but has the GPU at hand: NH_CODEC_GZIP is encoded on `device` as above, the other codecs as in
+ * nh_compress_file. */
+int nh_compress_file_device(const char *in, const char *out, int codec, uint32_t threads, int32_t device);
 /* Test / tool support for the multi-threaded gzip input decoder nh_run reads .gz inputs with
  * (kraken2's wrapper pipes them through `gzip -dc`): decompress `in` to
  * `out` on `threads` workers, cutting the compressed file every chunk_bytes (0 = default).

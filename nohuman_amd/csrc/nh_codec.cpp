@@ -534,7 +534,7 @@ StreamEncoder *make_encoder(int codec, int fd, unsigned threads, const char *nam
     }
 }
 
-int compress_file(const char *in, const char *out, int codec, unsigned threads) {
+int compress_file(const char *in, const char *out, int codec, unsigned threads, int device = -1) {
     if (!in || !out) return set_error(NH_EINVAL, "nh_compress_file: null path");
     if (codec != NH_CODEC_NONE && codec != NH_CODEC_GZIP && codec != NH_CODEC_BZIP2 && codec != NH_CODEC_XZ &&
         codec != NH_CODEC_ZSTD)
@@ -548,7 +548,7 @@ int compress_file(const char *in, const char *out, int codec, unsigned threads) 
     }
     int rc = NH_OK;
     {
-        std::unique_ptr<StreamEncoder> enc(make_encoder(codec, fout, threads, out));
+        std::unique_ptr<StreamEncoder> enc(make_encoder(codec, fout, threads, out, device));
         if (!enc) {
             rc = NH_EINVAL;  // message set by make_encoder
         } else {
@@ -598,4 +598,9 @@ extern "C" int nh_gunzip_file(const char *in, const char *out, uint32_t threads,
 
 extern "C" int nh_compress_file(const char *in, const char *out, int codec, uint32_t threads) {
     return nh::compress_file(in, out, codec, threads);
+}
+
+extern "C" int nh_compress_file_device(const char *in, const char *out, int codec, uint32_t threads, int32_t device) {
+    if (device < 0) return nh::set_error(NH_EINVAL, "nh_compress_file_device: no device");
+    return nh::compress_file(in, out, codec, threads, device);
 }

@@ -245,9 +245,16 @@ NH_HD inline Bytes16 load16(const uint8_t *p) {  // sixteen bytes at any address
     const U *u = (const U *)p;
     return Bytes16{u->lo, u->hi};
 }
+NH_HD inline uint32_t tz32(uint32_t x) { return x ? (uint32_t)__builtin_ctz(x) : 32u; }
 NH_HD inline uint32_t equal_bytes16(const Bytes16 &a, const Bytes16 &b) {  // 0..16 equal leading bytes
-    const uint64_t x0 = a.lo ^ b.lo, x1 = a.hi ^ b.hi;
-    return x0 ? (uint32_t)__builtin_ctzll(x0) >> 3 : x1 ? 8u + ((uint32_t)__builtin_ctzll(x1) >> 3) : 16u;
+    // straight-line code: trailing zeros of the four words of the difference, chained by selects (a GPU runs
+    // thirteen of these per position; branches here cost more than the arithmetic)
+    const uint64_t xl = a.lo ^ b.lo, xh = a.hi ^ b.hi;
+    const uint32_t t0 = tz32((uint32_t)xl), t1 = tz32((uint32_t)(xl >> 32)), t2 = tz32((uint32_t)xh), t3 = tz32((uint32_t)(xh >> 32));
+    uint32_t bits = t2 + (t2 == 32u ? t3 : 0u);
+    bits = t1 + (t1 == 32u ? bits : 0u);
+    bits = t0 + (t0 == 32u ? bits : 0u);
+    return bits >> 3;
 }
 // number of equal leading bytes of the strings at a and b, at most cap (reads up to 7 bytes past cap)
 NH_HD inline uint32_t common_prefix(const uint8_t *a, const uint8_t *b, uint32_t from, uint32_t cap) {
@@ -328,8 +335,10 @@ NH_HD inline uint32_t find_match(const uint8_t *src, uint32_t p, uint32_t n, con
         if (any) {
             const Bytes16 c2 = load16(cur + 16);
             for (int k = 0; k < NC; k++) x[k] = load16(cur - (len[k] == 16u ? d[k] : 0u) + 16);  // (the others: lines the wave reads anyway)
-            for (int k = 0; k < NC; k++)
-                if (len[k] == 16u) len[k] += equal_bytes16(x[k], c2);
+            for (int k = 0; k < NC; k++) {
+                const uint32_t more = equal_bytes16(x[k], c2);
+                len[k] += len[k] == 16u ? more : 0u;
+            }
         }
     }
     uint32_t nl = len[0], fl = 0, fd = 0;

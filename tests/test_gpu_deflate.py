@@ -159,3 +159,15 @@ def test_system_gzip_accepts_the_stream(tmp_path):
     assert subprocess.run(["gzip", "-t", str(tmp_path / "a.gz")]).returncode == 0
     out = subprocess.run(["gzip", "-dc", str(tmp_path / "a.gz")], capture_output=True)
     assert out.returncode == 0 and out.stdout == data
+
+
+def test_compress_file_on_the_device(tmp_path):
+    """nh_compress_file_device: the reference's compress stage (file -> file) with the gzip case on the GPU."""
+    data = fastq_text(8000, 23)
+    src = tmp_path / "kraken_out.fq"
+    src.write_bytes(data)
+    L = _lib.lib()
+    assert L.nh_compress_file_device(os.fsencode(str(src)), os.fsencode(str(tmp_path / "o.gz")), 2, 4, 0) == 0
+    assert gzip.decompress((tmp_path / "o.gz").read_bytes()) == data
+    assert L.nh_compress_file_device(os.fsencode(str(src)), os.fsencode(str(tmp_path / "o.zst")), 4, 2, 0) == 0   # others: as on the host
+    assert (tmp_path / "o.zst").read_bytes()[:4] == bytes([0x28, 0xB5, 0x2F, 0xFD])
