@@ -375,13 +375,6 @@ NH_HD inline uint32_t find_match(const uint8_t *src, uint32_t p, uint32_t n, con
     return best;
 }
 
-NH_HD inline uint32_t match_price(const Costs &c, uint32_t len, uint32_t dist) {
-    uint32_t sym, eb, ev, dsym, deb, dev;
-    len_symbol(len - 3u, sym, eb, ev);
-    dist_symbol(dist - 1u, dsym, deb, dev);
-    return cost_or(c.llen[sym], 10u) + eb + cost_or(c.dlen[dsym], 8u) + deb;
-}
-
 // ---- CRC-32 of the text (the gzip member's check value), computed where the text is ---------------------------
 // Reflected polynomial 0xEDB88320 as in RFC 1952.  A wave's lanes each take a slice of the region; slices and
 // regions are joined by crc(A || B) = crc(A) * x^(8 |B|) + crc(B) over GF(2)[x] mod P.

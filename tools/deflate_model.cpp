@@ -163,38 +163,29 @@ static void emit_block(BitWriter &bw, Block &b, const uint8_t *src, uint32_t in_
     bw.put(lt.codes[256], lt.lens[256]);
 }
 
-// one region, as one wave would do it
+// one region, as one wave would do it.  Knobs (environment, tuning only): DFL_WAYS = 4 | 8 | 16 bucket width, DFL_BB =
+// bucket bits, DFL_INIT = the first prices (0: literals 6 bits like zlib's rules assume, 1: A C G T N 2 bits -- what the
+// encoder uses), DFL_KEEP = 1: the prices carry over from region to region (as from chunk to chunk on the GPU).
 static void deflate_region(BitWriter &bw, const uint8_t *src, uint32_t n, uint32_t block_bytes) {
     static const uint32_t WAYS = getenv("DFL_WAYS") ? atoi(getenv("DFL_WAYS")) : 8;
     static const uint32_t BB = getenv("DFL_BB") ? atoi(getenv("DFL_BB")) : BUCKET_BITS;
     static const int keep_prices = getenv("DFL_KEEP") ? atoi(getenv("DFL_KEEP")) : 0;
-    static const int lazy_gain = getenv("DFL_LAZYG") ? atoi(getenv("DFL_LAZYG")) : 0;
+    static const int init = getenv("DFL_INIT") ? atoi(getenv("DFL_INIT")) : 1;
     std::vector<uint16_t> bucket((size_t)WAYS << BB, (uint16_t)EMPTY_ENTRY);
     static Tree lt, dt;
     static bool have_prices = false;
     if (!(keep_prices && have_prices)) {
-    // before the first block: literals 6 bits, lengths 7, distances 5 -- roughly what zlib's rules assume
-    static const int init = getenv("DFL_INIT") ? atoi(getenv("DFL_INIT")) : 1;
-    for (int s = 0; s < NLIT; s++) lt.lens[s] = s < 256 ? 6 : 7;
-    for (int s = 0; s < NDIST; s++) dt.lens[s] = 5;
-    if (init == 1)
-        for (const char *c = "ACGTN"; *c; c++) lt.lens[(int)*c] = 2;
-    if (init == 4) {
-        for (const char *c = "ACGTN"; *c; c++) lt.lens[(int)*c] = 2;
-        for (int s = 0; s < NDIST; s++) dt.lens[s] = s < 4 ? 2 : 9;
-    }
-    if (init == 2)
-        for (int s = 0; s < 256; s++) lt.lens[s] = 3;
-    if (init == 3)
-        for (int s = 0; s < 256; s++) lt.lens[s] = 2;
-    have_prices = true;
+        for (int s = 0; s < NLIT; s++) lt.lens[s] = s < 256 ? 6 : 7;
+        for (int s = 0; s < NDIST; s++) dt.lens[s] = 5;
+        if (init == 1)
+            for (const char *c = "ACGTN"; *c; c++) lt.lens[(int)*c] = 2;
+        have_prices = true;
     }
     Block b;
     b.reset(0);
     uint32_t carry = 0;
     for (uint32_t s = 0; s < n; s += 64) {
         uint32_t L[64], D[64], H[64];
-        int G[64];
         const Costs costs{lt.lens, dt.lens};
         const bool any = carry < s + 64;
         for (uint32_t lane = 0; lane < 64; lane++) {  // every lane: hash, bucket, match
@@ -205,32 +196,22 @@ static void deflate_region(BitWriter &bw, const uint8_t *src, uint32_t n, uint32
             if (p >= n) continue;
             if (p + HASH_BYTES <= n) H[lane] = hash_at(load8(src + p));
             if (!any || p < carry) continue;
-            G[lane] = 0;
+            int gain = 0;
             const uint16_t *e = &bucket[WAYS * (H[lane] >> (32 - BB))];
             const Bytes16 c16 = load16(src + p);
-            L[lane] = WAYS == 4    ? find_match<4>(src, p, n, c16, e, costs, D[lane], G[lane])
-                      : WAYS == 16 ? find_match<16>(src, p, n, c16, e, costs, D[lane], G[lane])
-                                   : find_match<8>(src, p, n, c16, e, costs, D[lane], G[lane]);
-            static const int seq_insert = getenv("DFL_SEQ") ? atoi(getenv("DFL_SEQ")) : 0;
-            
+            L[lane] = WAYS == 4    ? find_match<4>(src, p, n, c16, e, costs, D[lane], gain)
+                      : WAYS == 16 ? find_match<16>(src, p, n, c16, e, costs, D[lane], gain)
+                                   : find_match<8>(src, p, n, c16, e, costs, D[lane], gain);
         }
-        for (uint32_t lane = 0; lane < 64; lane++) {  // insert
+        for (uint32_t lane = 0; lane < 64; lane++) {  // the step's positions enter the buckets after the look-ups
             const uint32_t p = s + lane;
             if (p + HASH_BYTES <= n) bucket[WAYS * (H[lane] >> (32 - BB)) + ((p >> 6) % WAYS)] = make_entry(p);
         }
         if (any) {
-            uint32_t adv[64];
             for (uint32_t lane = 0; lane < 64; lane++) {  // lazy rule: a longer match one position on wins
-                uint32_t l = L[lane];
                 const uint32_t nx = lane < 63 ? L[lane + 1] : 0;
-                if (lazy_gain) {
-                    if (l && l < 16 && lane < 63 && L[lane + 1] && G[lane + 1] > G[lane] + lazy_gain) l = 0;
-                } else if (l && l < 16 && nx > l) l = 0;
-                L[lane] = l;
-                adv[lane] = l ? l : 1;
+                if (L[lane] && L[lane] < 16 && nx > L[lane]) L[lane] = 0;  // (the kernel: all lanes at once, L[lane + 1] as found)
             }
-        }
-        if (any) {
             uint32_t q = carry > s ? carry - s : 0;
             while (q < 64 && s + q < n) {
                 const uint32_t p = s + q;
