@@ -69,3 +69,9 @@ def test_model_ratio_on_fastq_text_is_near_zlib_6(model, tmp_path):
     z6 = len(zlib.compress(data, 6))
     assert size < 1.10 * z6, (size, z6)
     assert gzip.decompress(open(str(tmp_path / "out.gz"), "rb").read()) == data
+
+
+@pytest.mark.parametrize("period", [32767, 32768, 32769, 40000, 65535])
+def test_model_repeats_at_and_beyond_the_window(model, tmp_path, period):
+    unit = np.random.default_rng(period).integers(0, 256, period, dtype=np.uint8).tobytes()
+    run_model(model, unit * 5 + unit[:1000], tmp_path)

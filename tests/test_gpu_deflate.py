@@ -171,3 +171,48 @@ def test_compress_file_on_the_device(tmp_path):
     assert gzip.decompress((tmp_path / "o.gz").read_bytes()) == data
     assert L.nh_compress_file_device(os.fsencode(str(src)), os.fsencode(str(tmp_path / "o.zst")), 4, 2, 0) == 0   # others: as on the host
     assert (tmp_path / "o.zst").read_bytes()[:4] == bytes([0x28, 0xB5, 0x2F, 0xFD])
+
+
+@pytest.mark.parametrize("period", [32767, 32768, 32769, 40000, 65535])
+def test_repeats_at_and_beyond_the_window(tmp_path, period):
+    """A match may reach back 32768 bytes and not one more: blocks of random bytes repeated at distances around
+    the window (inside one region and across regions)."""
+    rng = np.random.default_rng(period)
+    unit = rng.integers(0, 256, period, dtype=np.uint8).tobytes()
+    check(unit * 5 + unit[:1000], str(tmp_path / "a.gz"))
+
+
+def _mixture(seed):
+    """Segments of many kinds glued together: what a generic encoder must survive."""
+    rng = np.random.default_rng(seed)
+    parts = []
+    for _ in range(int(rng.integers(3, 12))):
+        kind = int(rng.integers(0, 8))
+        n = int(rng.integers(1, 60000))
+        if kind == 0:
+            parts.append(rng.integers(0, 256, n, dtype=np.uint8).tobytes())
+        elif kind == 1:
+            parts.append(bytes([int(rng.integers(0, 256))]) * n)
+        elif kind == 2:
+            k = int(rng.integers(2, 17))
+            parts.append(rng.integers(0, k, n, dtype=np.uint8).tobytes())
+        elif kind == 3:
+            unit = rng.integers(0, 256, int(rng.integers(1, 700)), dtype=np.uint8).tobytes()
+            parts.append((unit * (n // len(unit) + 1))[:n])
+        elif kind == 4:
+            parts.append(fastq_text(n // 350 + 1, seed + n)[:n])
+        elif kind == 5:
+            p = np.cumsum(rng.random(256) ** 8)  # a very skewed alphabet
+            parts.append(np.searchsorted(p / p[-1], rng.random(n)).astype(np.uint8).tobytes())
+        elif kind == 6 and parts:
+            prev = b"".join(parts)
+            a = int(rng.integers(0, len(prev)))
+            parts.append(prev[a:a + n])                     # an old stretch again: long matches at any distance
+        else:
+            parts.append(b"".join(b"%d\t%d\n" % (i, i * i) for i in range(n // 12 + 1)))
+    return b"".join(parts)
+
+
+@pytest.mark.parametrize("seed", range(24))
+def test_random_mixtures(tmp_path, seed):
+    check(_mixture(seed), str(tmp_path / "a.gz"))
