@@ -28,6 +28,7 @@
 #include <stdlib.h>
 #include <string.h>
 #include <unistd.h>
+#include <zlib.h>
 
 #include <string>
 #include <vector>
@@ -540,6 +541,7 @@ __global__ __launch_bounds__(256) void k_deflate_pack(const uint8_t *slots, uint
 namespace {
 
 using dfl::DeflateArgs;
+using dfl::crc32_join;
 
 int gzip_ways() {
     static const int w = [] {
@@ -772,7 +774,10 @@ struct DeflateDev {  // device side of one encoder: buffers for chunks in flight
         if (total > (uint64_t)max_regions * slot_stride) return set_error(NH_EDEVICE, "gzip encoder: impossible stream size");
         if ((e = hipMemcpyAsync(b.h_out, b.d_out, total, hipMemcpyDeviceToHost, stream)) != hipSuccess) return fail(e, "D2H");
         if ((e = hipStreamSynchronize(stream)) != hipSuccess) return fail(e, "D2H");
-        // the member's CRC-32 grows by the chunk's regions (computed on the GPU, joined here: a multiplication each)
+        // NOHUMAN_GZIP_VERIFY=1: the chunk's stream is inflated again on the host (zlib, raw deflate) and its length and
+        // CRC-32 are compared with the text's -- a paranoid mode, one core at ~0.5 GB/s of text
+        static const bool verify = getenv("NOHUMAN_GZIP_VERIFY") != nullptr;
+        uint32_t crc_before = *crc;
         {
             static const uint32_t full = dfl::gf2_xpow8(REGION);
             uint32_t c = *crc;
@@ -783,6 +788,31 @@ struct DeflateDev {  // device side of one encoder: buffers for chunks in flight
                 left -= rl;
             }
             *crc = c;
+        }
+        if (verify) {
+            z_stream zs;
+            memset(&zs, 0, sizeof zs);
+            if (inflateInit2(&zs, -15) != Z_OK) return set_error(NH_EIO, "gzip encoder: verify: inflateInit2 failed");
+            std::vector<unsigned char> back(1u << 20);
+            uint32_t vcrc = 0;
+            uint64_t got = 0;
+            zs.next_in = b.h_out;
+            zs.avail_in = (uInt)total;
+            int zrc = Z_OK;
+            while (zrc == Z_OK || zrc == Z_BUF_ERROR) {
+                zs.next_out = back.data();
+                zs.avail_out = (uInt)back.size();
+                zrc = inflate(&zs, Z_NO_FLUSH);
+                const size_t have = back.size() - zs.avail_out;
+                vcrc = crc32_fast(vcrc, back.data(), have);
+                got += have;
+                if (have == 0 && zs.avail_in == 0) break;
+            }
+            inflateEnd(&zs);
+            const uint32_t want = crc32_join(crc_before, vcrc, got);
+            if ((zrc != Z_OK && zrc != Z_BUF_ERROR) || zs.avail_in != 0 || got != b.submitted || want != *crc)
+                return set_error(NH_EDEVICE, "gzip encoder: verification failed (zlib %d, %llu of %llu bytes, CRC %08x / %08x)",
+                                 zrc, (unsigned long long)got, (unsigned long long)b.submitted, want, *crc);
         }
         b.in_flight = false;
         b.fill = 0;

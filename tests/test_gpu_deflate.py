@@ -216,3 +216,23 @@ def _mixture(seed):
 @pytest.mark.parametrize("seed", range(24))
 def test_random_mixtures(tmp_path, seed):
     check(_mixture(seed), str(tmp_path / "a.gz"))
+
+
+def test_verify_mode_inflates_every_chunk_on_the_host(tmp_path):
+    """NOHUMAN_GZIP_VERIFY=1: every chunk's stream is inflated again by zlib and its length and CRC-32 compared with
+    the text's before it is written (read once per process, hence the child)."""
+    import subprocess
+    data = _mixture(101) + fastq_text(4000, 9) + _mixture(102)
+    src = tmp_path / "in.bin"
+    src.write_bytes(data)
+    code = ("import sys, ctypes as C; sys.path.insert(0, %r)\n"
+            "from nohuman_amd import _lib\n"
+            "d = open(sys.argv[1], 'rb').read()\n"
+            "buf = (C.c_char * len(d)).from_buffer_copy(d)\n"
+            "rc = _lib.lib().nh_gzip_gpu_file(0, buf, len(d), sys.argv[2].encode(), None)\n"
+            "print(_lib.lib().nh_last_error().decode() if rc else 'ok')\n"
+            "sys.exit(rc != 0)\n") % ROOT
+    r = subprocess.run([sys.executable, "-c", code, str(src), str(tmp_path / "o.gz")],
+                       env=dict(os.environ, NOHUMAN_GZIP_VERIFY="1"), capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert gzip.decompress((tmp_path / "o.gz").read_bytes()) == data
