@@ -10,6 +10,9 @@
 #include <string.h>
 #if defined(__x86_64__)
 #include <immintrin.h>
+
+#include <atomic>
+#include <chrono>
 #endif
 #include <sys/mman.h>
 #include <sys/stat.h>
@@ -583,7 +586,23 @@ int decode_markers(BitIn &in, const Tables &T, uint16_t *start, uint16_t *&op_re
             } else {
                 const uint16_t *src = op - dist;
                 uint64_t acc = 0;
-                if (dist >= 4) {  // four symbols at a time: the source word ends before the target word
+                if (dist >= 8) {
+                    // eight symbols at a time, past the end of the match like the byte decoder (the buffer has the
+                    // slack; what is written beyond the match is overwritten by the next symbols; a marker among the
+                    // extra symbols only makes marker_end conservative)
+                    __m128i a = _mm_setzero_si128();
+                    const uint16_t *s2 = src;
+                    uint16_t *o = op, *stop = op + len;
+                    do {
+                        const __m128i w = _mm_loadu_si128((const __m128i *)s2);
+                        a = _mm_or_si128(a, w);
+                        _mm_storeu_si128((__m128i *)o, w);
+                        s2 += 8;
+                        o += 8;
+                    } while (o < stop);
+                    if (_mm_movemask_epi8(a) & 0xAAAA) marker_end = produced + len;
+                    i = len;
+                } else if (dist >= 4) {  // four symbols at a time: the source word ends before the target word
                     for (; i + 4 <= len; i += 4) {
                         uint64_t w;
                         memcpy(&w, src + i, 8);
@@ -928,9 +947,12 @@ void resolve_chunk(Chunk &c) {
             size_t e = pos + BLK < seg_end ? pos + BLK : seg_end;
             if (pos < n16) {
                 if (e > n16) e = n16;
+                // (the window byte is loaded whether the symbol is a marker or not -- the index is always inside the
+                // window -- so that the choice is a conditional move: markers and literals alternate without a pattern)
                 for (size_t i = pos; i < e; i++) {
                     const uint16_t v = s[i];
-                    d[i] = v & 0x8000u ? w[v & 0x7fffu] : (uint8_t)v;
+                    const uint8_t from_window = w[v & 0x7fffu];
+                    d[i] = v & 0x8000u ? from_window : (uint8_t)v;
                 }
                 crc = crc32_fast(crc, d + pos, e - pos);
             } else {
@@ -1003,6 +1025,14 @@ public:
     }
 
     void close() {
+        if ((t_wait_ns_ || t_copy_ns_) && getenv("NOHUMAN_TRACE"))
+            fprintf(stderr, "[nohuman trace] gunzip consumer: waited %.3f s for chunks, copied for %.3f s; workers: decoded for %.3f s, "
+                            "replaced markers + CRC for %.3f s (accepted %llu, rejected %llu chunks)\n",
+                    t_wait_ns_ / 1e9, t_copy_ns_ / 1e9, t_spec_ns_.load() / 1e9, t_resolve_ns_.load() / 1e9,
+                    (unsigned long long)accepted_, (unsigned long long)rejected_);
+        t_wait_ns_ = t_copy_ns_ = 0;
+        t_spec_ns_ = 0;
+        t_resolve_ns_ = 0;
         {
             std::lock_guard<std::mutex> lk(mu_);
             quit_ = true;
@@ -1038,6 +1068,7 @@ public:
             }
             if (failed_) return -1;
             Chunk &c = *pieces_.front();
+            const auto w0 = std::chrono::steady_clock::now();
             {
                 std::unique_lock<std::mutex> lk(mu_);
                 cv_done_.wait(lk, [&] { return c.resolved; });
@@ -1046,12 +1077,16 @@ public:
                 if (!verify(c)) return -1;
                 c.verified = true;
             }
+            const auto w1 = std::chrono::steady_clock::now();
             const size_t total = c.dec.total();
             const size_t n = std::min(cap - got, total - c.read_off);
             for_ranges(c, c.read_off, c.read_off + n, [&](const uint8_t *p, size_t k) {
                 memcpy(dst + got, p, k);
                 got += k;
             });
+            const auto w2 = std::chrono::steady_clock::now();
+            t_wait_ns_ += (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(w1 - w0).count();
+            t_copy_ns_ += (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(w2 - w1).count();
             c.read_off += n;
             if (c.read_off == total) {
                 spare_.push_back(std::move(pieces_.front()));
@@ -1091,10 +1126,13 @@ private:
                 j = q.front();
                 q.pop_front();
             }
+            const auto j0 = std::chrono::steady_clock::now();
             if (j.kind == 0)
                 speculate(*j.c);
             else
                 resolve_chunk(*j.c);
+            (j.kind == 0 ? t_spec_ns_ : t_resolve_ns_) +=
+                (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - j0).count();
             std::shared_ptr<TailInfo> tail;
             if (j.kind == 0 && j.c->chained && j.c->dec.stop != STOP_ERROR) {
                 tail = make_tail(*j.c);
@@ -1432,6 +1470,8 @@ private:
     std::mutex mu_;
     std::condition_variable cv_work_, cv_done_;
     std::deque<Job> jobs_, resolve_jobs_;
+    std::atomic<uint64_t> t_spec_ns_{0}, t_resolve_ns_{0};  // the workers' time decoding / replacing markers + CRC (NOHUMAN_TRACE)
+    uint64_t t_wait_ns_ = 0, t_copy_ns_ = 0;  // the consumer's time waiting for the head chunk / copying it out (NOHUMAN_TRACE)
     std::map<size_t, std::shared_ptr<TailInfo>> tails_;
     bool quit_ = false;
     std::vector<std::thread> workers_;
