@@ -767,7 +767,7 @@ def e2e_leg(cx, args, eng):
                 os.close(saved)
                 os.close(fd)
                 os.environ.pop("NOHUMAN_TRACE", None)
-            trace_gz = " | ".join(x.strip() for x in open(tr_path).read().strip().splitlines() if "wall" in x)
+            trace_gz = " | ".join(x.strip() for x in open(tr_path).read().strip().splitlines() if "wall" in x or "gzip encoder" in x)
             out_gz = os.path.getsize(g1) + os.path.getsize(g2)
             gz_ok = {}
 

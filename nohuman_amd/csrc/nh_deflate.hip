@@ -30,6 +30,7 @@
 #include <unistd.h>
 #include <zlib.h>
 
+#include <chrono>
 #include <string>
 #include <vector>
 
@@ -590,6 +591,7 @@ struct DeflateDev {  // device side of one encoder: buffers for chunks in flight
     int device = -1;
     hipStream_t stream = nullptr;
     hipStream_t copy_stream = nullptr;  // brings the text into d_in while the kernels of earlier chunks run
+    hipStream_t out_stream = nullptr;   // brings a finished chunk's stream to the host (never behind a later chunk's kernels)
     struct Buf {
         uint8_t *h_in = nullptr;   // page-locked staging of the text
         uint8_t *d_in = nullptr;
@@ -623,6 +625,7 @@ struct DeflateDev {  // device side of one encoder: buffers for chunks in flight
         if (e != hipSuccess) return fail(e, "hipSetDevice");
         if ((e = hipStreamCreateWithFlags(&stream, hipStreamNonBlocking)) != hipSuccess) return fail(e, "stream");
         if ((e = hipStreamCreateWithFlags(&copy_stream, hipStreamNonBlocking)) != hipSuccess) return fail(e, "stream");
+        if ((e = hipStreamCreateWithFlags(&out_stream, hipStreamNonBlocking)) != hipSuccess) return fail(e, "stream");
         max_regions = (uint32_t)((CHUNK + REGION - 1) / REGION);
         slot_stride = REGION + 256;
         for (Buf &b : buf) {
@@ -692,6 +695,7 @@ struct DeflateDev {  // device side of one encoder: buffers for chunks in flight
         }
         if (stream) (void)hipStreamDestroy(stream);
         if (copy_stream) (void)hipStreamDestroy(copy_stream);
+        if (out_stream) (void)hipStreamDestroy(out_stream);
         device = -1;
     }
     // the staged bytes of buf[i] that are not on the device yet go there (one copy)
@@ -772,8 +776,8 @@ struct DeflateDev {  // device side of one encoder: buffers for chunks in flight
         if (hipEventElapsedTime(&ms, b.k0, b.k1) == hipSuccess) kernel_ms += ms;
         const uint64_t total = *b.h_total;
         if (total > (uint64_t)max_regions * slot_stride) return set_error(NH_EDEVICE, "gzip encoder: impossible stream size");
-        if ((e = hipMemcpyAsync(b.h_out, b.d_out, total, hipMemcpyDeviceToHost, stream)) != hipSuccess) return fail(e, "D2H");
-        if ((e = hipStreamSynchronize(stream)) != hipSuccess) return fail(e, "D2H");
+        if ((e = hipMemcpyAsync(b.h_out, b.d_out, total, hipMemcpyDeviceToHost, out_stream)) != hipSuccess) return fail(e, "D2H");
+        if ((e = hipStreamSynchronize(out_stream)) != hipSuccess) return fail(e, "D2H");
         // NOHUMAN_GZIP_VERIFY=1: the chunk's stream is inflated again on the host (zlib, raw deflate) and its length and
         // CRC-32 are compared with the text's -- a paranoid mode, one core at ~0.5 GB/s of text
         static const bool verify = getenv("NOHUMAN_GZIP_VERIFY") != nullptr;
@@ -853,11 +857,18 @@ public:
         map_dev_ = (const uint8_t *)dev;
     }
     int settle() override {
+        const uint64_t t0 = now_ns();
         if (rc_ == NH_OK && hipSetDevice(dev_.device) == hipSuccess) rc_ = dev_.settle();
         map_len_ = 0;
+        t_settle_ += now_ns() - t0;
         return rc_;
     }
     int write(const void *p, size_t n) override {
+        const uint64_t tw0 = now_ns();
+        struct Acc {
+            uint64_t &t, t0;
+            ~Acc() { t += now_ns() - t0; }
+        } acc{t_write_, tw0};
         const uint8_t *c = (const uint8_t *)p;
         if (n && hipSetDevice(dev_.device) != hipSuccess) rc_ = set_error(NH_EDEVICE, "gzip encoder: hipSetDevice failed");
         while (n && rc_ == NH_OK) {
@@ -889,6 +900,11 @@ public:
             tail[6 + i] = (unsigned char)((uint32_t)total_ >> (8 * i));
         }
         if (!write_fd(fd_, tail, sizeof tail)) rc_ = set_error(NH_EIO, "write error on %s", name_.c_str());
+        if (getenv("NOHUMAN_TRACE"))
+            fprintf(stderr, "[nohuman trace] gzip encoder %s: write() %.3f s (of it: waiting for chunks + D2H %.3f, file %.3f), settle %.3f s, "
+                            "kernels %.3f s, %.2f GB in, %.2f GB out\n",
+                    name_.c_str(), t_write_ / 1e9, t_collect_ / 1e9, t_file_ / 1e9, t_settle_ / 1e9, dev_.kernel_ms / 1e3, total_ / 1e9,
+                    out_bytes_ / 1e9);
         return rc_;
     }
     double kernel_ms() const { return dev_.kernel_ms; }
@@ -905,10 +921,18 @@ private:
     void retire(int i) {
         if (!dev_.buf[i].in_flight || rc_ != NH_OK) return;
         size_t len = 0;
+        const uint64_t t0 = now_ns();
         if ((rc_ = dev_.collect(i, &len, &crc_)) != NH_OK) return;
+        const uint64_t t1 = now_ns();
         if (!write_fd(fd_, dev_.buf[i].h_out, len)) rc_ = set_error(NH_EIO, "write error on %s", name_.c_str());
+        t_collect_ += t1 - t0;
+        t_file_ += now_ns() - t1;
         out_bytes_ += len;
     }
+    static uint64_t now_ns() {
+        return (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now().time_since_epoch()).count();
+    }
+    uint64_t t_settle_ = 0, t_collect_ = 0, t_file_ = 0, t_write_ = 0;
     static constexpr size_t DEVICE_SPAN_MIN = 32u << 10;
     int fd_;
     std::string name_;

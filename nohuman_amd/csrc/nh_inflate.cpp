@@ -495,13 +495,22 @@ int decode_bytes(BitIn &in, const Tables &T, const uint8_t *min_src, uint8_t *&o
             const uint8_t *src = op - dist;
             uint8_t *stop = op + len;
             if (dist >= 8) {
-                do {
-                    uint64_t w;
-                    memcpy(&w, src, 8);
-                    memcpy(op, &w, 8);
-                    src += 8;
-                    op += 8;
-                } while (op < stop);
+                // sixteen bytes without a question (most matches end there: no loop exit to mispredict), then the rest
+                uint64_t w;
+                memcpy(&w, src, 8);
+                memcpy(op, &w, 8);
+                memcpy(&w, src + 8, 8);
+                memcpy(op + 8, &w, 8);
+                if (len > 16) {
+                    src += 16;
+                    op += 16;
+                    do {
+                        memcpy(&w, src, 8);
+                        memcpy(op, &w, 8);
+                        src += 8;
+                        op += 8;
+                    } while (op < stop);
+                }
             } else if (dist == 1) {
                 memset(op, *src, len);
             } else {
@@ -590,16 +599,23 @@ int decode_markers(BitIn &in, const Tables &T, uint16_t *start, uint16_t *&op_re
                     // eight symbols at a time, past the end of the match like the byte decoder (the buffer has the
                     // slack; what is written beyond the match is overwritten by the next symbols; a marker among the
                     // extra symbols only makes marker_end conservative)
-                    __m128i a = _mm_setzero_si128();
-                    const uint16_t *s2 = src;
-                    uint16_t *o = op, *stop = op + len;
-                    do {
-                        const __m128i w = _mm_loadu_si128((const __m128i *)s2);
-                        a = _mm_or_si128(a, w);
-                        _mm_storeu_si128((__m128i *)o, w);
-                        s2 += 8;
-                        o += 8;
-                    } while (o < stop);
+                    // (sixteen symbols without a question: most matches end there)
+                    const __m128i w0 = _mm_loadu_si128((const __m128i *)src);
+                    _mm_storeu_si128((__m128i *)op, w0);
+                    const __m128i w1 = _mm_loadu_si128((const __m128i *)(src + 8));
+                    _mm_storeu_si128((__m128i *)(op + 8), w1);
+                    __m128i a = _mm_or_si128(w0, w1);
+                    if (len > 16) {
+                        const uint16_t *s2 = src + 16;
+                        uint16_t *o = op + 16, *stop = op + len;
+                        do {
+                            const __m128i w = _mm_loadu_si128((const __m128i *)s2);
+                            a = _mm_or_si128(a, w);
+                            _mm_storeu_si128((__m128i *)o, w);
+                            s2 += 8;
+                            o += 8;
+                        } while (o < stop);
+                    }
                     if (_mm_movemask_epi8(a) & 0xAAAA) marker_end = produced + len;
                     i = len;
                 } else if (dist >= 4) {  // four symbols at a time: the source word ends before the target word
