@@ -588,6 +588,7 @@ struct DeflateDev {  // device side of one encoder: buffers for chunks in flight
     }
     const uint32_t REGION = region_bytes();
     static constexpr int NBUF = 2;
+    static constexpr uint32_t PILOT_REGIONS = 16;
     int device = -1;
     hipStream_t stream = nullptr;
     hipStream_t copy_stream = nullptr;  // brings the text into d_in while the kernels of earlier chunks run
@@ -646,16 +647,22 @@ struct DeflateDev {  // device side of one encoder: buffers for chunks in flight
             if ((e = hipEventCreateWithFlags(&b.filled, hipEventDisableTiming)) != hipSuccess) return fail(e, "event");
         }
         if ((e = hipMalloc((void **)&d_tok, (size_t)max_regions * dfl::TOK_CAP * sizeof(uint32_t))) != hipSuccess) return fail(e, "tokens");
-        if ((e = hipMalloc((void **)&d_prior, 2 * dfl::PRIOR_BYTES)) != hipSuccess) return fail(e, "prior");
-        // the first chunk's prices: literals 6 bits, lengths 7, distances 5 -- and 2 bits for A C G T N: FASTQ text
-        // compresses best when the bases stay literals and only long repeats among them become matches, a state the
-        // block-to-block price feedback keeps once it is in it but does not find from zlib's uniform start
-        uint8_t prior[dfl::PRIOR_BYTES];
-        for (int s = 0; s < dfl::NLIT; s++) prior[s] = s < 256 ? 6 : 7;
-        for (const char *c = "ACGTN"; *c; c++) prior[(int)*c] = 2;
-        for (int s = 0; s < dfl::NDIST; s++) prior[dfl::NLIT + s] = 5;
-        if ((e = hipMemcpy(d_prior, prior, sizeof prior, hipMemcpyHostToDevice)) != hipSuccess) return fail(e, "prior copy");
-        if ((e = hipMemcpy(d_prior + dfl::PRIOR_BYTES, prior, sizeof prior, hipMemcpyHostToDevice)) != hipSuccess) return fail(e, "prior copy");
+        // d_prior: two rows that alternate from chunk to chunk, then the two candidates for the first prices of a stream
+        if ((e = hipMalloc((void **)&d_prior, 4 * dfl::PRIOR_BYTES)) != hipSuccess) return fail(e, "prior");
+        // The price feedback from block to block has two stable states on FASTQ text: bases matched wherever four of
+        // them repeat and their literals dear (where zlib's rules lead), or bases literal and cheap with only long
+        // repeats matched.  Which one is smaller depends on the qualities (few distinct values: the second, by 7 %;
+        // forty values or a long-read spread: the first, by 1-5 %), and neither is left once entered.  So a stream
+        // starts from both -- literals 6 bits, lengths 7, distances 5, with and without 2 bits for A C G T N -- on
+        // its first regions and goes on with the one that came out smaller (submit(), chunk 0).
+        uint8_t prior[2][dfl::PRIOR_BYTES];
+        for (int c = 0; c < 2; c++) {
+            for (int s = 0; s < dfl::NLIT; s++) prior[c][s] = s < 256 ? 6 : 7;
+            for (int s = 0; s < dfl::NDIST; s++) prior[c][dfl::NLIT + s] = 5;
+        }
+        for (const char *c = "ACGTN"; *c; c++) prior[1][(int)*c] = 2;
+        if ((e = hipMemcpy(d_prior + 2 * dfl::PRIOR_BYTES, prior, sizeof prior, hipMemcpyHostToDevice)) != hipSuccess) return fail(e, "prior copy");
+        if ((e = hipMemcpy(d_prior, prior[1], dfl::PRIOR_BYTES, hipMemcpyHostToDevice)) != hipSuccess) return fail(e, "prior copy");
         if (getenv("NOHUMAN_GZIP_PROF")) {
             if ((e = hipMalloc((void **)&d_prof, 64)) != hipSuccess) return fail(e, "prof");
             (void)hipMemset(d_prof, 0, 64);
@@ -723,6 +730,50 @@ struct DeflateDev {  // device side of one encoder: buffers for chunks in flight
         const hipError_t e = hipStreamSynchronize(copy_stream);
         return e == hipSuccess ? NH_OK : fail(e, "copy");
     }
+    // the first regions of a stream under both candidate price sets; the smaller result's prices start the stream
+    int pilot(Buf &b) {
+        static const char *force = getenv("NOHUMAN_GZIP_PRICES");  // "0" / "1": no pilot, that candidate (tuning)
+        int pick = 1;
+        if (force && (force[0] == '0' || force[0] == '1')) {
+            pick = force[0] - '0';
+        } else {
+            const uint32_t nr = b.n_regions < PILOT_REGIONS ? b.n_regions : PILOT_REGIONS;
+            const uint64_t n = b.fill < (uint64_t)nr * REGION ? b.fill : (uint64_t)nr * REGION;
+            for (int c = 0; c < 2; c++) {
+                DeflateArgs a{};
+                a.in = b.d_in;
+                a.n = n;
+                a.region = REGION;
+                a.n_regions = nr;
+                a.slots = b.d_slots;
+                a.slot_stride = slot_stride;
+                a.sizes = b.d_sizes + c * PILOT_REGIONS;
+                a.crcs = b.d_crcs;
+                a.tok = d_tok;
+                a.prior = d_prior + (2 + c) * dfl::PRIOR_BYTES;
+                a.prior_out = nullptr;
+                a.prof = nullptr;
+                if (gzip_ways() == 4)
+                    hipLaunchKernelGGL(dfl::k_deflate<4>, dim3(nr), dim3(64), 0, stream, a);
+                else
+                    hipLaunchKernelGGL(dfl::k_deflate<8>, dim3(nr), dim3(64), 0, stream, a);
+            }
+            hipError_t e = hipGetLastError();
+            if (e != hipSuccess) return fail(e, "launch");
+            uint32_t sz[2 * PILOT_REGIONS];
+            if ((e = hipMemcpyAsync(sz, b.d_sizes, sizeof sz, hipMemcpyDeviceToHost, stream)) != hipSuccess) return fail(e, "D2H");
+            if ((e = hipStreamSynchronize(stream)) != hipSuccess) return fail(e, "pilot");
+            uint64_t tot[2] = {0, 0};
+            for (int c = 0; c < 2; c++)
+                for (uint32_t r = 0; r < nr; r++) tot[c] += sz[c * PILOT_REGIONS + r];
+            pick = tot[1] <= tot[0] ? 1 : 0;
+            if (getenv("NOHUMAN_TRACE"))
+                fprintf(stderr, "[nohuman trace] gzip encoder: first %u regions under the two starting price sets: %llu / %llu bytes -> %s\n",
+                        nr, (unsigned long long)tot[0], (unsigned long long)tot[1], pick ? "bases literal" : "zlib-like");
+        }
+        const hipError_t e = hipMemcpyAsync(d_prior, d_prior + (2 + pick) * dfl::PRIOR_BYTES, dfl::PRIOR_BYTES, hipMemcpyDeviceToDevice, stream);
+        return e == hipSuccess ? NH_OK : fail(e, "prior copy");
+    }
     // queues the compression of buf[i]
     int submit(int i) {
         Buf &b = buf[i];
@@ -733,6 +784,10 @@ struct DeflateDev {  // device side of one encoder: buffers for chunks in flight
         if (urc != NH_OK) return urc;
         if ((e = hipEventRecord(b.filled, copy_stream)) != hipSuccess) return fail(e, "event");
         if ((e = hipStreamWaitEvent(stream, b.filled, 0)) != hipSuccess) return fail(e, "wait");
+        if (chunks == 0) {
+            const int prc = pilot(b);
+            if (prc != NH_OK) return prc;
+        }
         DeflateArgs a{};
         a.in = b.d_in;
         a.n = b.fill;

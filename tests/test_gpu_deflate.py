@@ -236,3 +236,33 @@ def test_verify_mode_inflates_every_chunk_on_the_host(tmp_path):
                        env=dict(os.environ, NOHUMAN_GZIP_VERIFY="1"), capture_output=True, text=True)
     assert r.returncode == 0, r.stdout + r.stderr
     assert gzip.decompress((tmp_path / "o.gz").read_bytes()) == data
+
+
+def _reads_with_qualities(kind, n, seed):
+    rng = np.random.default_rng(seed)
+    out = []
+    for i in range(n):
+        L = 150
+        seq = bytes(rng.choice(np.frombuffer(b"ACGT", dtype=np.uint8), L))
+        if kind == "forty":      # forty quality values: a random walk around a falling mean
+            base = 38 - np.linspace(0, 12, L) * rng.random()
+            q = np.clip(base + rng.normal(0, 3, L) + np.cumsum(rng.normal(0, 0.6, L)), 2, 41).astype(np.uint8) + 33
+        elif kind == "spread":   # long-read-like: a wide spread, no structure
+            q = np.clip(rng.normal(20, 7, L), 1, 50).astype(np.uint8) + 33
+        else:                    # eight bins
+            bins = np.array([2, 6, 15, 22, 27, 33, 37, 40], dtype=np.uint8)
+            idx = np.clip((7 - np.linspace(0, 3, L) * rng.random() + rng.normal(0, 0.8, L)).round(), 0, 7).astype(int)
+            q = bins[idx] + 33
+        out.append(b"@SRR1234567.%d %d/1\n%s\n+\n%s\n" % (i + 1, i + 1, seq, q.tobytes()))
+    return b"".join(out)
+
+
+@pytest.mark.parametrize("kind,slack", [("forty", 1.04), ("spread", 1.02), ("bins", 1.10)])
+def test_starting_prices_are_chosen_per_stream(tmp_path, kind, slack):
+    """The encoder tries both starting price sets on a stream's first regions (bases literal and cheap / zlib-like)
+    and goes on with the smaller: texts whose qualities have many values want the second.  Sizes against zlib -6."""
+    data = _reads_with_qualities(kind, 12000, 31)
+    size = check(data, str(tmp_path / "a.gz"))
+    z6 = len(zlib.compress(data, 6))
+    print("%s: GPU %.3f : 1, zlib -6 %.3f : 1" % (kind, len(data) / size, len(data) / z6))
+    assert size < slack * z6
