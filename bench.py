@@ -746,6 +746,11 @@ def e2e_leg(cx, args, eng):
         ok = ok and checked.get(1) is True and checked.get(2) is True
         for p in (o1, o2):
             os.remove(p)
+        # the input side alone: same run with --classified-out semantics (nothing is kept, nothing written)
+        t = time.perf_counter()
+        st_in = eng.run(files[0], os.path.join(tmp, "h_1.fq"), in2=files[1], out2=os.path.join(tmp, "h_2.fq"),
+                        threads=threads, keep_human=True)
+        dt_in = time.perf_counter() - t
         # the same run with gzip outputs, the reference's default for gzip inputs (main.rs:238-245): the kept reads
         # are compressed on the GPU (nh_deflate.hip) as the writer hands them over; the files are inflated again
         # by the library's own reader and compared with the generated text like the plain outputs
@@ -800,11 +805,6 @@ def e2e_leg(cx, args, eng):
                                        "leg's own input members, two files at a time" % max(1, threads // 2)}
         except Exception as ex:  # reported, not fatal for the line
             gz = {"error": str(ex)[:300]}
-        # the input side alone: same run with --classified-out semantics (nothing is kept, nothing written)
-        t = time.perf_counter()
-        st_in = eng.run(files[0], os.path.join(tmp, "h_1.fq"), in2=files[1], out2=os.path.join(tmp, "h_2.fq"),
-                        threads=threads, keep_human=True)
-        dt_in = time.perf_counter() - t
         return {
             "workload": "%d pairs of %d bp = 2 gzip FASTQ files of %d members x %d pairs (%d distinct members in rotation; "
                         "level 6; Illumina-style ids, binned qualities; %.2f GB compressed, %.2f GB of text: %.2f:1), every read "
