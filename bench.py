@@ -722,7 +722,7 @@ def e2e_leg(cx, args, eng):
                 os.environ.pop("NOHUMAN_TRACE", None)
             if best is None or dt < best[0]:
                 best = (dt, st.total_sequences, st.classified)
-                trace = " | ".join(x.strip() for x in open(tr_path).read().strip().splitlines() if "wall" in x)
+                trace = " | ".join(x.strip() for x in open(tr_path).read().strip().splitlines() if "wall" in x or "gunzip consumer" in x)
         dt, nfr, ncl = best
         # every read was kept: the outputs are the generated text, member by member (byte-exact, by digest)
         ok = nfr == n * reps and ncl == 0
