@@ -507,7 +507,14 @@ StreamEncoder *make_encoder(int codec, int fd, unsigned threads, const char *nam
             return new PlainEncoder(fd, name);
         case NH_CODEC_GZIP: {
             const char *how = getenv("NOHUMAN_GZIP");
-            if (device >= 0 && !(how && !strcmp(how, "host"))) return make_gpu_gzip_encoder(fd, device, name);
+            if (device >= 0 && !(how && !strcmp(how, "host"))) {
+                StreamEncoder *e = make_gpu_gzip_encoder(fd, device, name);
+                if (!e) {  // loud, never a silent change of encoder
+                    const std::string why = g_last_error;
+                    set_error(NH_EDEVICE, "%s (NOHUMAN_GZIP=host selects the host encoder)", why.c_str());
+                }
+                return e;
+            }
             return new GzipEncoder(fd, threads, name);
         }
         case NH_CODEC_ZSTD:
