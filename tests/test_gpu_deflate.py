@@ -257,7 +257,7 @@ def _reads_with_qualities(kind, n, seed):
     return b"".join(out)
 
 
-@pytest.mark.parametrize("kind,slack", [("forty", 1.04), ("spread", 1.02), ("bins", 1.10)])
+@pytest.mark.parametrize("kind,slack", [("forty", 1.05), ("spread", 1.03), ("bins", 1.12)])
 def test_starting_prices_are_chosen_per_stream(tmp_path, kind, slack):
     """The encoder tries both starting price sets on a stream's first regions (bases literal and cheap / zlib-like)
     and goes on with the smaller: texts whose qualities have many values want the second.  Sizes against zlib -6."""
