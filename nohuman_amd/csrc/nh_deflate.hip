@@ -413,8 +413,8 @@ __global__ __launch_bounds__(64) void k_deflate(DeflateArgs a) {
         // the sixteen bytes at this lane's position were loaded during the previous step
         const Bytes16 cur16 = next16;
         if (s + 64u < n) next16 = load16(src + p + 64u);
-        const uint32_t four = (uint32_t)cur16.lo;
-        const bool has4 = p + HASH_BYTES <= n;
+        const uint32_t lit = (uint32_t)cur16.lo & 0xFFu;  // the byte at this lane's position
+        const bool hashed = p + HASH_BYTES <= n;  // positions with a full hash context enter the buckets
         const uint32_t h = hash_at(cur16.lo);
         uint32_t L = 0, D = 0;
         if (any && inside && p >= carry) {
@@ -424,7 +424,7 @@ __global__ __launch_bounds__(64) void k_deflate(DeflateArgs a) {
         }
         __syncthreads();
         const unsigned long long c1 = a.prof ? __builtin_amdgcn_s_memtime() : 0ull;
-        if (has4) S.bucket[WAYS * hash_bucket(h) + ((p >> 6) % WAYS)] = make_entry(p);
+        if (hashed) S.bucket[WAYS * hash_bucket(h) + ((p >> 6) % WAYS)] = make_entry(p);
         if (any) {
             // lazy rule: a longer match one position on wins over a short one here
             const uint32_t nx = (uint32_t)__shfl_down((int)L, 1);
@@ -471,8 +471,8 @@ __global__ __launch_bounds__(64) void k_deflate(DeflateArgs a) {
                     lfreq.bump((int)sym);
                     dfreq.bump((int)dsym);
                 } else {
-                    tok[idx] = four & 0xFFu;
-                    lfreq.bump((int)(four & 0xFFu));
+                    tok[idx] = lit;
+                    lfreq.bump((int)lit);
                 }
             }
             ntok += (uint32_t)__popcll(sel);
