@@ -516,16 +516,27 @@ __global__ __launch_bounds__(64) void k_deflate(DeflateArgs a) {
     }
 }
 
-// offsets[i] = bytes of the regions before i; offsets[n] = all
-__global__ void k_deflate_offsets(const uint32_t *sizes, uint32_t n, uint64_t *offsets) {
-    if (threadIdx.x == 0 && blockIdx.x == 0) {
-        uint64_t acc = 0;
-        for (uint32_t i = 0; i < n; i++) {
-            offsets[i] = acc;
-            acc += sizes[i];
-        }
-        offsets[n] = acc;
+// offsets[i] = bytes of the regions before i; offsets[n] = all.  One wave: a stretch of regions per lane, the
+// stretches' sums scanned across the lanes.
+__global__ __launch_bounds__(64) void k_deflate_offsets(const uint32_t *sizes, uint32_t n, uint64_t *offsets) {
+    if (blockIdx.x != 0) return;
+    const uint32_t lane = threadIdx.x;
+    const uint32_t per = (n + 63u) / 64u;
+    const uint32_t lo = lane * per < n ? lane * per : n, hi = lo + per < n ? lo + per : n;
+    uint64_t sum = 0;
+    for (uint32_t i = lo; i < hi; i++) sum += sizes[i];
+    uint64_t incl = sum;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const uint64_t t = (uint64_t)__shfl_up((long long)incl, o);
+        if ((int)lane >= o) incl += t;
     }
+    uint64_t acc = incl - sum;
+    for (uint32_t i = lo; i < hi; i++) {
+        offsets[i] = acc;
+        acc += sizes[i];
+    }
+    if (lane == 63) offsets[n] = incl;
 }
 __global__ __launch_bounds__(256) void k_deflate_pack(const uint8_t *slots, uint32_t slot_stride, const uint32_t *sizes,
                                                        const uint64_t *offsets, uint8_t *out) {
