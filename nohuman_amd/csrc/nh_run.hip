@@ -619,8 +619,21 @@ int run_engines(const std::vector<Engine *> &engines, const nh_run_args *a, nh_s
     if (a->out_codec < NH_CODEC_NONE || a->out_codec > NH_CODEC_ZSTD)
         return set_error(NH_EINVAL, "nh_run: unknown out_codec %d", a->out_codec);
     // gzip output is encoded on the GPU (nh_deflate.hip); with two devices each mate file has its own
-    if ((rc = o1.open(a->out1, a->out_codec, a->codec_threads, engines[0]->device))) return rc;
-    if (rs.paired && (rc = o2.open(a->out2, a->out_codec, a->codec_threads, engines[engines.size() > 1 ? 1 : 0]->device))) return rc;
+    // (the two are opened side by side: a GPU encoder takes 70 ms to set up -- page-locked buffers, a trial of its prices)
+    {
+        int rc2 = NH_OK;
+        std::string err2;
+        std::thread t2;
+        if (rs.paired)
+            t2 = std::thread([&] {
+                rc2 = o2.open(a->out2, a->out_codec, a->codec_threads, engines[engines.size() > 1 ? 1 : 0]->device);
+                if (rc2) err2 = g_last_error;
+            });
+        rc = o1.open(a->out1, a->out_codec, a->codec_threads, engines[0]->device);
+        if (t2.joinable()) t2.join();
+        if (rc) return rc;
+        if (rc2) return set_error(rc2, "%s", err2.c_str());
+    }
     if (rs.want_k && (rc = ok.open(a->kraken_output))) return rc;
 
     // fragments per batch: ~96 MB of sequence, at most 262144; both readers cut at the same record
@@ -991,8 +1004,20 @@ int run_engines(const std::vector<Engine *> &engines, const nh_run_args *a, nh_s
     if (a->report && a->report[0] &&
         (rc = write_report(engines[0], a->report, rs.call_counts, rs.total, rs.total - rs.classified)))
         return rc;
-    if ((rc = o1.close())) return rc;
-    if (rs.paired && (rc = o2.close())) return rc;
+    {  // (side by side as well: the last chunks of two GPU encoders, their buffers' release)
+        int rc2 = NH_OK;
+        std::string err2;
+        std::thread t2;
+        if (rs.paired)
+            t2 = std::thread([&] {
+                rc2 = o2.close();
+                if (rc2) err2 = g_last_error;
+            });
+        rc = o1.close();
+        if (t2.joinable()) t2.join();
+        if (rc) return rc;
+        if (rc2) return set_error(rc2, "%s", err2.c_str());
+    }
     if (rs.want_k && (rc = ok.close())) return rc;
     if (stats) {
         nh_stats st;
