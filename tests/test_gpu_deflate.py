@@ -95,7 +95,8 @@ def test_several_chunks(tmp_path):
     assert size < len(data) / 3
 
 
-def test_run_takes_long_spans_from_the_device_copy_of_the_batch(tmp_path, monkeypatch):
+@pytest.mark.parametrize("batch_frags", [700, 4000, 50000])
+def test_run_takes_long_spans_from_the_device_copy_of_the_batch(tmp_path, monkeypatch, batch_frags):
     """nh_run with gzip outputs: kept records in spans of 32 KiB and more are compressed from the copy of the batch's
     text that the classifier worked on (no second trip over PCIe), shorter spans and reformatted records are
     staged -- the two mixed in one stream, several batches, both mate files.  Decompressed bytes == plain outputs,
@@ -115,7 +116,7 @@ def test_run_takes_long_spans_from_the_device_copy_of_the_batch(tmp_path, monkey
         p = tmp_path / ("in_%s.fq" % m)
         p.write_bytes(b"".join(parts))
         files.append(str(p))
-    monkeypatch.setenv("NOHUMAN_BATCH_FRAGS", "4000")
+    monkeypatch.setenv("NOHUMAN_BATCH_FRAGS", str(batch_frags))
     with Engine.open(os.path.join(gold, "toy_db")) as eng:
         st = eng.run(files[0], str(tmp_path / "p_1.fq"), in2=files[1], out2=str(tmp_path / "p_2.fq"))
         eng.run(files[0], str(tmp_path / "g_1.gz"), in2=files[1], out2=str(tmp_path / "g_2.gz"), out_codec=2)
