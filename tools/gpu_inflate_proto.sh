@@ -1,0 +1,16 @@
+# builds the test input of tools/gpu_inflate_proto (bench.py's FASTQ text, gzip -6 by zlib) and runs the prototype
+set -e
+mkdir -p /dev/shm/gip
+python - <<'PY'
+import sys, types, zlib, torch
+sys.path.insert(0, '.')
+import bench
+cx = types.SimpleNamespace(torch=torch, dev=torch.device('cuda', 0))
+bench.e2e_member(cx, 1_000_000, 150, 1, 0, '/dev/shm/gip/m.fq')
+d = open('/dev/shm/gip/m.fq', 'rb').read()
+c = zlib.compressobj(6, zlib.DEFLATED, 31)
+open('/dev/shm/gip/m.fq.gz', 'wb').write(c.compress(d) + c.flush())
+print(len(d), 'bytes of text')
+PY
+for kib in 4096 256 160 128 64; do timeout 300 ./tools/gpu_inflate_proto /dev/shm/gip/m.fq.gz $kib; done
+rm -rf /dev/shm/gip
