@@ -70,6 +70,9 @@ __constant__ uint8_t CLORDER[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12,
 // stores of the copy before it -- most of a token's time in the first version of this file)
 #define LDS_ORDER() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
 
+__device__ __forceinline__ uint32_t uni(uint32_t v) {  // a value all lanes hold: to a scalar register, so that what is computed from it runs on the scalar unit
+    return (uint32_t)__builtin_amdgcn_readfirstlane((int)v);
+}
 __device__ __forceinline__ uint32_t rl(uint32_t v, uint32_t lane) {
     return (uint32_t)__builtin_amdgcn_readlane((int)v, (int)__builtin_amdgcn_readfirstlane((int)lane));
 }
@@ -257,7 +260,7 @@ __global__ __launch_bounds__(64) void k_inflate(const uint32_t *in, ChunkDesc *d
             uint32_t prev = 0;
             while (i < nlit + ndist) {
                 w = bi.fetch(bitpos, lane);
-                const uint32_t e = S.clt[w & 127];
+                const uint32_t e = uni(S.clt[w & 127]);
                 const uint32_t l = e & 15u, sym = e >> 8;
                 if (l == 0) {
                     status = 4;
@@ -297,7 +300,7 @@ __global__ __launch_bounds__(64) void k_inflate(const uint32_t *in, ChunkDesc *d
         // ---- the symbols of the block
         for (;;) {
             w = bi.fetch(bitpos, lane);
-            uint32_t e = S.lit[w & ((1u << ROOT) - 1u)];
+            uint32_t e = uni(S.lit[w & ((1u << ROOT) - 1u)]);
             if (e == 0) {  // a code longer than the root
                 uint32_t l;
                 const uint32_t sym = slow_symbol(w, S.lcount, S.lsym, l);
@@ -329,7 +332,7 @@ __global__ __launch_bounds__(64) void k_inflate(const uint32_t *in, ChunkDesc *d
             const uint32_t len = ((e >> 8) & 0xFFFFu) + ((uint32_t)w & ((1u << lext) - 1u));
             bitpos += lext;
             w >>= lext;
-            uint32_t de = S.dist[w & ((1u << DROOT) - 1u)];
+            uint32_t de = uni(S.dist[w & ((1u << DROOT) - 1u)]);
             if (de == 0) {
                 uint32_t dl;
                 const uint32_t dsymv = slow_symbol(w, S.dcount, S.dsym, dl);

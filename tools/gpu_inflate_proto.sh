@@ -12,5 +12,5 @@ c = zlib.compressobj(6, zlib.DEFLATED, 31)
 open('/dev/shm/gip/m.fq.gz', 'wb').write(c.compress(d) + c.flush())
 print(len(d), 'bytes of text')
 PY
-for kib in 4096 256 160 128 64; do timeout 300 ./tools/gpu_inflate_proto /dev/shm/gip/m.fq.gz $kib; done
+for kib in 4096 256 160 64; do timeout 300 ./tools/gpu_inflate_proto /dev/shm/gip/m.fq.gz $kib; done
 rm -rf /dev/shm/gip
