@@ -42,9 +42,13 @@ struct ChunkDesc {
 
 constexpr int ROOT = 10, DROOT = 8;
 constexpr uint32_t WSIZE = 32768;
+#ifndef NEAR
+#define NEAR 8192  // symbols of the window kept in LDS (a power of two <= 32768); older ones are read back from the output in HBM
+#endif
+constexpr uint32_t NEARSZ = NEAR;
 
 struct Lds {
-    uint16_t window[WSIZE];
+    uint16_t window[NEARSZ];
     // root tables: 0 = code longer than the root; else code length (4 bits) | extra bits (4) | base or literal (16) |
     // kind << 28 (0 literal, 1 length, 2 end of block; distances: always 1)
     uint32_t lit[1 << ROOT];
@@ -180,7 +184,9 @@ __global__ __launch_bounds__(64) void k_inflate(const uint32_t *in, ChunkDesc *d
     const int lane = (int)threadIdx.x;
     ChunkDesc &cd = desc[blockIdx.x];
     const unsigned long long t0 = __builtin_amdgcn_s_memtime();
-    for (uint32_t i = (uint32_t)lane; i < WSIZE; i += 64) S.window[i] = (uint16_t)(0x8000u | i);
+    // the unknown 32 KiB before the chunk as markers: the newest NEARSZ of them in the LDS ring (position q of the
+    // stream, counted from 32768 before the chunk, lives at q & (NEARSZ - 1))
+    for (uint32_t i = (uint32_t)lane; i < NEARSZ; i += 64) S.window[(WSIZE - NEARSZ + i) & (NEARSZ - 1)] = (uint16_t)(0x8000u | (WSIZE - NEARSZ + i));
     if (lane < 29) {
         S.lbase[lane] = LBASE[lane];
         S.lext[lane] = LEXT[lane];
@@ -219,7 +225,7 @@ __global__ __launch_bounds__(64) void k_inflate(const uint32_t *in, ChunkDesc *d
             const uint8_t *bytes = (const uint8_t *)in + (bitpos >> 3);
             for (uint32_t i = (uint32_t)lane; i < len; i += 64) {
                 const uint16_t v = bytes[i];
-                S.window[(op + i) & (WSIZE - 1)] = v;
+                S.window[(op + WSIZE + i) & (NEARSZ - 1)] = v;
                 o[op + i] = v;
             }
             LDS_ORDER();
@@ -321,7 +327,7 @@ __global__ __launch_bounds__(64) void k_inflate(const uint32_t *in, ChunkDesc *d
                 }
                 const uint16_t v = (uint16_t)(e >> 8);
                 if (lane == 0) {
-                    S.window[op & (WSIZE - 1)] = v;
+                    S.window[(op + WSIZE) & (NEARSZ - 1)] = v;
                     o[op] = v;
                 }
                 op++;
@@ -355,18 +361,20 @@ __global__ __launch_bounds__(64) void k_inflate(const uint32_t *in, ChunkDesc *d
             // the copy: every lane a symbol; with dist < len the pattern repeats.  (LDS operations of one wave execute
             // in order: the literal lane 0 wrote, the symbols of the last copy are there for this one)
             asm volatile("" ::: "memory");
-            if (dist >= len) {
-                for (uint32_t i = (uint32_t)lane; i < len; i += 64) {
-                    const uint16_t v = S.window[(op + WSIZE - dist + i) & (WSIZE - 1)];
-                    o[op + i] = v;
-                    S.window[(op + i) & (WSIZE - 1)] = v;
+            for (uint32_t i = (uint32_t)lane; i < len; i += 64) {
+                const uint32_t from = dist >= len ? i : i % dist;
+                uint16_t v;
+                // (a ring slot is overwritten by the position NEARSZ later: a source this copy could reach with its own
+                //  writes -- up to 258 symbols ahead -- is not taken from the ring)
+                if (dist - from + 320u <= NEARSZ) {
+                    v = S.window[(op + WSIZE - dist + from) & (NEARSZ - 1)];
+                } else if (op + from >= dist) {  // older than the ring, inside the chunk: from the output (written long ago)
+                    v = __hip_atomic_load(&o[op + from - dist], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                } else {                         // older than the ring, before the chunk: the marker itself
+                    v = (uint16_t)(0x8000u | (op + WSIZE - dist + from));
                 }
-            } else {
-                for (uint32_t i = (uint32_t)lane; i < len; i += 64) {
-                    const uint16_t v = S.window[(op + WSIZE - dist + i % dist) & (WSIZE - 1)];
-                    o[op + i] = v;
-                    S.window[(op + i) & (WSIZE - 1)] = v;  // (never a position this copy reads: those lie before op)
-                }
+                o[op + i] = v;
+                S.window[(op + WSIZE + i) & (NEARSZ - 1)] = v;
             }
             asm volatile("" ::: "memory");
             op += len;

@@ -1,4 +1,5 @@
-# builds the test input of tools/gpu_inflate_proto (bench.py's FASTQ text, gzip -6 by zlib) and runs the prototype
+# builds the test input of tools/gpu_inflate_proto (bench.py's FASTQ text, gzip -6 by zlib) and runs the prototype;
+# with tools/gpu_inflate_proto_<NEAR> present (built with -DNEAR=...), those variants too
 set -e
 mkdir -p /dev/shm/gip
 python - <<'PY'
@@ -12,5 +13,9 @@ c = zlib.compressobj(6, zlib.DEFLATED, 31)
 open('/dev/shm/gip/m.fq.gz', 'wb').write(c.compress(d) + c.flush())
 print(len(d), 'bytes of text')
 PY
-for kib in 4096 256 160 64; do timeout 300 ./tools/gpu_inflate_proto /dev/shm/gip/m.fq.gz $kib; done
+for exe in tools/gpu_inflate_proto tools/gpu_inflate_proto_*[0-9]; do
+  [ -x $exe ] || continue
+  echo "== $exe"
+  for kib in 4096 160 64 32; do timeout 300 ./$exe /dev/shm/gip/m.fq.gz $kib || true; done
+done
 rm -rf /dev/shm/gip
