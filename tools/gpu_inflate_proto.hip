@@ -178,6 +178,60 @@ __device__ __forceinline__ uint32_t slow_symbol(uint64_t w, const uint16_t *coun
     return 0xFFFFu;
 }
 
+// the header of a dynamic block behind its three type bits: the code lengths of both alphabets into S.lens[0 .. nlit + ndist)
+__device__ uint32_t parse_dynamic(Lds &S, BitIn &bi, uint64_t &bitpos, int lane, int &nlit, int &ndist) {
+    uint64_t w = bi.fetch(bitpos, lane);
+    nlit = (int)(w & 31) + 257;
+    ndist = (int)((w >> 5) & 31) + 1;
+    const int ncl = (int)((w >> 10) & 15) + 4;
+    if (nlit > 286 || ndist > 30) return 4;
+    bitpos += 14;
+    LDS_ORDER();
+    if (lane < 19) S.lens[lane] = 0;
+    LDS_ORDER();
+    for (int i = 0; i < ncl; i++) {  // (uniform; 3 bits each)
+        if ((i & 15) == 0) w = bi.fetch(bitpos, lane);
+        if (lane == 0) S.lens[CLORDER[i]] = (uint8_t)(w & 7);
+        w >>= 3;
+        bitpos += 3;
+    }
+    // the code-length code: all codes fit the 7-bit root
+    build(S, S.lens, 19, S.lcount, S.lsym, S.clt, 7, 0, lane);
+    int i = 0;
+    uint32_t prev = 0;
+    while (i < nlit + ndist) {
+        w = bi.fetch(bitpos, lane);
+        const uint32_t e = uni(S.clt[w & 127]);
+        const uint32_t l = e & 15u, sym = e >> 8;
+        if (l == 0) return 4;
+        bitpos += l;
+        w >>= l;
+        uint32_t rep = 1, val = sym;
+        if (sym == 16) {
+            if (i == 0) return 4;
+            rep = 3 + ((uint32_t)w & 3);
+            bitpos += 2;
+            val = prev;
+        } else if (sym == 17) {
+            rep = 3 + ((uint32_t)w & 7);
+            bitpos += 3;
+            val = 0;
+        } else if (sym == 18) {
+            rep = 11 + ((uint32_t)w & 127);
+            bitpos += 7;
+            val = 0;
+        }
+        if (i + (int)rep > nlit + ndist) return 4;
+        for (uint32_t k = (uint32_t)lane; k < rep; k += 64) S.code[i + k] = (uint16_t)val;
+        i += (int)rep;
+        prev = val;
+    }
+    LDS_ORDER();
+    for (int s = lane; s < nlit + ndist; s += 64) S.lens[s] = (uint8_t)S.code[s];
+    LDS_ORDER();
+    return 0;
+}
+
 __global__ __launch_bounds__(64) void k_inflate(const uint32_t *in, ChunkDesc *desc, uint16_t *out) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];  // 70 KB: more than a static array may have
     Lds &S = *(Lds *)smem;
@@ -246,60 +300,8 @@ __global__ __launch_bounds__(64) void k_inflate(const uint32_t *in, ChunkDesc *d
             nlit = 288;
             ndist = 30;
         } else {
-            w = bi.fetch(bitpos, lane);
-            nlit = (int)(w & 31) + 257;
-            ndist = (int)((w >> 5) & 31) + 1;
-            const int ncl = (int)((w >> 10) & 15) + 4;
-            bitpos += 14;
-            LDS_ORDER();
-            if (lane < 19) S.lens[lane] = 0;
-            LDS_ORDER();
-            for (int i = 0; i < ncl; i++) {  // (uniform; 3 bits each)
-                if ((i & 15) == 0) w = bi.fetch(bitpos, lane);
-                if (lane == 0) S.lens[CLORDER[i]] = (uint8_t)(w & 7);
-                w >>= 3;
-                bitpos += 3;
-            }
-            // the code-length code: all codes fit the 7-bit root
-            build(S, S.lens, 19, S.lcount, S.lsym, S.clt, 7, 0, lane);
-            int i = 0;
-            uint32_t prev = 0;
-            while (i < nlit + ndist) {
-                w = bi.fetch(bitpos, lane);
-                const uint32_t e = uni(S.clt[w & 127]);
-                const uint32_t l = e & 15u, sym = e >> 8;
-                if (l == 0) {
-                    status = 4;
-                    break;
-                }
-                bitpos += l;
-                w >>= l;
-                uint32_t rep = 1, val = sym;
-                if (sym == 16) {
-                    rep = 3 + ((uint32_t)w & 3);
-                    bitpos += 2;
-                    val = prev;
-                } else if (sym == 17) {
-                    rep = 3 + ((uint32_t)w & 7);
-                    bitpos += 3;
-                    val = 0;
-                } else if (sym == 18) {
-                    rep = 11 + ((uint32_t)w & 127);
-                    bitpos += 7;
-                    val = 0;
-                }
-                if (i + (int)rep > nlit + ndist) {
-                    status = 4;
-                    break;
-                }
-                // lengths go to lens[32 ...) while the code-length code's own lengths occupy lens[0..19)
-                for (uint32_t k = (uint32_t)lane; k < rep; k += 64) S.code[i + k] = (uint16_t)val;
-                i += (int)rep;
-                prev = val;
-            }
+            status = parse_dynamic(S, bi, bitpos, lane, nlit, ndist);
             if (status) break;
-            LDS_ORDER();
-            for (int s = lane; s < nlit + ndist; s += 64) S.lens[s] = (uint8_t)S.code[s];
         }
         build(S, S.lens, nlit, S.lcount, S.lsym, S.lit, ROOT, 1, lane);
         build(S, S.lens + nlit, ndist, S.dcount, S.dsym, S.dist, DROOT, 2, lane);
@@ -388,12 +390,455 @@ __global__ __launch_bounds__(64) void k_inflate(const uint32_t *in, ChunkDesc *d
     }
 }
 
+// ================================================================================================================
+// The whole reader on the device ("full" mode): block search per chunk, decode, the window chain, marker replacement.
+// ================================================================================================================
+constexpr uint64_t NONE = ~0ull;
+
+__device__ __forceinline__ uint32_t wsum(uint32_t v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += (uint32_t)__shfl_xor((int)v, o);
+    return v;
+}
+__device__ __forceinline__ uint64_t bits_at(const uint8_t *bytes, uint64_t b) {  // >= 57 valid bits at bit position b
+    struct __attribute__((packed)) U {
+        uint64_t v;
+    };
+    return ((const U *)(bytes + (b >> 3)))->v >> (b & 7);
+}
+
+// Does a non-final dynamic block header start at bit `cand`?  The seam test of the host reader: the code lengths must
+// decode, both codes must be complete (the distance code may have a single symbol), end-of-block must have a code.
+__device__ bool plausible_block(Lds &S, const uint32_t *in, uint64_t cand, int lane) {
+    BitIn bi;
+    bi.init(in, cand, lane);
+    uint64_t bp = cand + 3;
+    int nlit, ndist;
+    if (parse_dynamic(S, bi, bp, lane, nlit, ndist)) return false;
+    uint32_t sl = 0, sd = 0, cd = 0;
+    for (int k = lane; k < nlit; k += 64) sl += S.lens[k] ? 32768u >> S.lens[k] : 0u;
+    for (int k = lane; k < ndist; k += 64) {
+        const uint32_t l = S.lens[nlit + k];
+        sd += l ? 32768u >> l : 0u;
+        cd += l != 0;
+    }
+    sl = wsum(sl);
+    sd = wsum(sd);
+    cd = wsum(cd);
+    if (!(S.lens[256] != 0 && sl == 32768u && (sd == 32768u || cd <= 1u))) return false;
+    // a header that passes by chance decodes into nonsense soon: the first tokens of the block are walked as well
+    // (the host reader gets there by running into the error and searching on)
+    build(S, S.lens, nlit, S.lcount, S.lsym, S.lit, ROOT, 1, lane);
+    build(S, S.lens + nlit, ndist, S.dcount, S.dsym, S.dist, DROOT, 2, lane);
+    uint32_t produced = 0;
+    for (int tok = 0; tok < 256; tok++) {
+        uint64_t w = bi.fetch(bp, lane);
+        uint32_t e = uni(S.lit[w & ((1u << ROOT) - 1u)]);
+        if (e == 0) {
+            uint32_t l;
+            const uint32_t sym = slow_symbol(w, S.lcount, S.lsym, l);
+            if (l == 0 || sym >= 286u) return false;
+            e = entry_of(S, 1, sym, l);
+        }
+        const uint32_t l = e & 15u;
+        bp += l;
+        w >>= l;
+        const uint32_t kind = e >> 28;
+        if (kind == 2) break;
+        if (kind == 0) {
+            produced++;
+            continue;
+        }
+        const uint32_t lext = (e >> 4) & 15u;
+        const uint32_t len = ((e >> 8) & 0xFFFFu) + ((uint32_t)w & ((1u << lext) - 1u));
+        bp += lext;
+        w >>= lext;
+        uint32_t de = uni(S.dist[w & ((1u << DROOT) - 1u)]);
+        if (de == 0) {
+            uint32_t dl;
+            const uint32_t dsymv = slow_symbol(w, S.dcount, S.dsym, dl);
+            if (dl == 0 || dsymv >= 30u) return false;
+            de = entry_of(S, 2, dsymv, dl);
+        }
+        const uint32_t dext = (de >> 4) & 15u;
+        const uint32_t dist = ((de >> 8) & 0xFFFFu) + ((uint32_t)(w >> (de & 15u)) & ((1u << dext) - 1u));
+        if (dist > produced + WSIZE) return false;
+        bp += (de & 15u) + dext;
+        produced += len;
+    }
+    return true;
+}
+
+// start[c] = the first bit position in chunk c's stretch of the file that passes the seam test (NONE: none)
+__global__ __launch_bounds__(64) void k_search(const uint32_t *in, uint64_t total_bits, uint64_t chunk_bits, uint64_t first_bit,
+                                               uint64_t *start) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    Lds &S = *(Lds *)smem;
+    const int lane = (int)threadIdx.x;
+    const uint32_t c = blockIdx.x;
+    if (c == 0) {
+        if (lane == 0) start[0] = first_bit;
+        return;
+    }
+    uint64_t from = (uint64_t)c * chunk_bits, to = from + chunk_bits;
+    if (from <= first_bit) from = first_bit + 1;
+    if (to + 160 > total_bits) to = total_bits > 160 ? total_bits - 160 : 0;
+    const uint8_t *bytes = (const uint8_t *)in;
+    uint64_t found = NONE;
+    for (uint64_t b0 = from; b0 < to && found == NONE; b0 += 64) {
+        const uint64_t b = b0 + (uint64_t)lane;
+        const uint64_t w = bits_at(bytes, b), w2 = bits_at(bytes + 7, b);  // w2: bits 56.. of the window
+        bool pre = b < to && (w & 7) == 4 && ((w >> 3) & 31) <= 29 && ((w >> 8) & 31) <= 29;
+        const int ncl = (int)((w >> 13) & 15) + 4;
+        int left = 128, any = 0;
+        for (int i = 0; i < 19; i++) {
+            const unsigned at = 17 + 3 * (unsigned)i;
+            const unsigned l = i < ncl ? (at + 3 <= 56 ? (unsigned)(w >> at) & 7 : (unsigned)(w2 >> (at - 56)) & 7) : 0u;
+            if (l) {
+                left -= 128 >> l;
+                any = 1;
+            }
+        }
+        pre = pre && any && left == 0;
+        uint64_t m = __ballot(pre);
+        while (m && found == NONE) {
+            const uint64_t cand = b0 + (uint64_t)__builtin_ctzll(m);
+            if (plausible_block(S, in, cand, lane)) found = cand;
+            m &= m - 1;
+        }
+    }
+    if (lane == 0) start[c] = found;
+}
+
+// the chunks in order: does c end where c + 1 starts?  the 32 KiB behind c, markers replaced, are c + 1's window
+__global__ __launch_bounds__(1024) void k_chain(ChunkDesc *d, uint32_t n, const uint16_t *sym, uint8_t *windows, uint32_t *broken) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    uint8_t *w = smem, *nw = smem + WSIZE;  // this chunk's window and the next one's
+    const uint32_t t = threadIdx.x;
+    for (uint32_t j = t; j < WSIZE; j += 1024) w[j] = 0;
+    __syncthreads();
+    for (uint32_t c = 0; c < n; c++) {
+        for (uint32_t j = t; j < WSIZE / 16; j += 1024) ((uint4 *)(windows + (size_t)c * WSIZE))[j] = ((const uint4 *)w)[j];
+        if (c + 1 < n && (d[c].status != 0 || d[c].bit_end != d[c + 1].bit_start)) {
+            if (t == 0) *broken = c + 1;
+            return;
+        }
+        const uint32_t nsym = (uint32_t)(d[c].out_end - d[c].out_start);
+        const uint16_t *src = sym + d[c].out_start;
+        for (uint32_t j = t; j < WSIZE; j += 1024) {
+            uint8_t v;
+            if (nsym >= WSIZE) {
+                const uint16_t x = src[nsym - WSIZE + j];
+                v = x & 0x8000u ? w[x & 0x7FFFu] : (uint8_t)x;
+            } else if (j < WSIZE - nsym) {
+                v = w[j + nsym];
+            } else {
+                const uint16_t x = src[j - (WSIZE - nsym)];
+                v = x & 0x8000u ? w[x & 0x7FFFu] : (uint8_t)x;
+            }
+            nw[j] = v;
+        }
+        __syncthreads();
+        uint8_t *sw = w;
+        w = nw;
+        nw = sw;
+    }
+    if (t == 0) *broken = 0;
+}
+
+// every chunk's symbols become bytes at their place in the text
+__global__ __launch_bounds__(256) void k_resolve(const ChunkDesc *d, const uint16_t *sym, const uint8_t *windows, const uint64_t *text_off,
+                                                 uint8_t *text) {
+    const uint32_t c = blockIdx.x;
+    const uint32_t nsym = (uint32_t)(d[c].out_end - d[c].out_start);
+    const uint16_t *src = sym + d[c].out_start;
+    const uint8_t *w = windows + (size_t)c * WSIZE;
+    uint8_t *dst = text + text_off[c];
+    for (uint32_t i = blockIdx.y * 256 + threadIdx.x; i < nsym; i += gridDim.y * 256) {
+        const uint16_t x = src[i];
+        dst[i] = x & 0x8000u ? w[x & 0x7FFFu] : (uint8_t)x;
+    }
+}
+
+// decode kernel of the full mode: k_inflate, but the chunk's end and output length are results (bit_end on entry = where
+// to stop: the first block boundary at or behind it)
+__global__ __launch_bounds__(64) void k_inflate_open(const uint32_t *in, ChunkDesc *desc, uint16_t *out);
+
+static int full_mode(const std::vector<uint8_t> &gz, const std::vector<uint8_t> &text, uint64_t first_bit, uint64_t end_bit, size_t chunk) {
+    const uint64_t chunk_bits = 8 * (uint64_t)chunk;
+    const uint32_t nchunk = (uint32_t)((end_bit + chunk_bits - 1) / chunk_bits);
+    uint32_t *d_in;
+    uint64_t *d_start;
+    CK(hipMalloc(&d_in, gz.size() + 4096));
+    CK(hipMemset(d_in, 0, gz.size() + 4096));
+    CK(hipMemcpy(d_in, gz.data(), gz.size(), hipMemcpyHostToDevice));
+    CK(hipMalloc(&d_start, nchunk * sizeof(uint64_t)));
+    CK(hipFuncSetAttribute((const void *)k_search, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(Lds)));
+    CK(hipFuncSetAttribute((const void *)k_inflate_open, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(Lds)));
+    CK(hipFuncSetAttribute((const void *)k_chain, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(2 * WSIZE)));
+    hipEvent_t ev[6];
+    for (auto &evt : ev) CK(hipEventCreate(&evt));
+    float t_search = 1e30f, t_decode = 1e30f, t_chain = 1e30f, t_resolve = 1e30f;
+    std::vector<uint64_t> start(nchunk);
+    for (int rep = 0; rep < 2; rep++) {
+        CK(hipEventRecord(ev[0]));
+        hipLaunchKernelGGL(k_search, dim3(nchunk), dim3(64), sizeof(Lds), 0, d_in, end_bit, chunk_bits, first_bit, d_start);
+        CK(hipEventRecord(ev[1]));
+        CK(hipEventSynchronize(ev[1]));
+        float ms;
+        CK(hipEventElapsedTime(&ms, ev[0], ev[1]));
+        if (ms < t_search) t_search = ms;
+    }
+    CK(hipMemcpy(start.data(), d_start, nchunk * sizeof(uint64_t), hipMemcpyDeviceToHost));
+    // the chunks that have a start; each runs to the next one's start
+    std::vector<ChunkDesc> cd;
+    for (uint32_t c = 0; c < nchunk; c++)
+        if (start[c] != NONE) {
+            ChunkDesc x{};
+            x.bit_start = start[c];
+            cd.push_back(x);
+        }
+    uint64_t slots = 0;
+    for (size_t k = 0; k < cd.size(); k++) {
+        cd[k].bit_end = k + 1 < cd.size() ? cd[k + 1].bit_start : end_bit;
+        const uint64_t cap = (cd[k].bit_end - cd[k].bit_start) / 8 * 16 + 65536;  // symbols this chunk may write
+        cd[k].out_start = slots;
+        cd[k].out_end = slots + cap;
+        slots += cap;
+    }
+    printf("search: %u stretches of %zu KiB, %zu block starts found; %.1f M symbols of room\n", nchunk, chunk >> 10, cd.size(), slots / 1e6);
+    ChunkDesc *d_desc;
+    uint16_t *d_sym;
+    uint8_t *d_windows, *d_text;
+    uint64_t *d_toff;
+    uint32_t *d_broken;
+    CK(hipMalloc(&d_desc, cd.size() * sizeof(ChunkDesc)));
+    CK(hipMalloc(&d_sym, (slots + 64) * 2));
+    CK(hipMalloc(&d_windows, cd.size() * (size_t)WSIZE));
+    CK(hipMalloc(&d_text, text.size() + 64));
+    CK(hipMalloc(&d_toff, cd.size() * sizeof(uint64_t)));
+    CK(hipMalloc(&d_broken, 4));
+    std::vector<ChunkDesc> res(cd.size());
+    std::vector<uint64_t> toff(cd.size());
+    uint32_t broken = 0;
+    for (int rep = 0; rep < 2; rep++) {
+        CK(hipMemcpy(d_desc, cd.data(), cd.size() * sizeof(ChunkDesc), hipMemcpyHostToDevice));
+        CK(hipEventRecord(ev[0]));
+        hipLaunchKernelGGL(k_inflate_open, dim3((unsigned)cd.size()), dim3(64), sizeof(Lds), 0, d_in, d_desc, d_sym);
+        CK(hipEventRecord(ev[1]));
+        hipLaunchKernelGGL(k_chain, dim3(1), dim3(1024), 2 * WSIZE, 0, d_desc, (uint32_t)cd.size(), d_sym, d_windows, d_broken);
+        CK(hipEventRecord(ev[2]));
+        CK(hipEventSynchronize(ev[2]));
+        // (the text offsets: a prefix sum over the chunks' lengths -- on the host here, a scan kernel in the real thing)
+        CK(hipMemcpy(res.data(), d_desc, cd.size() * sizeof(ChunkDesc), hipMemcpyDeviceToHost));
+        uint64_t acc = 0;
+        for (size_t k = 0; k < res.size(); k++) {
+            toff[k] = acc;
+            acc += res[k].out_end - res[k].out_start;
+        }
+        if (acc != text.size()) fprintf(stderr, "lengths add up to %llu, the text has %zu bytes\n", (unsigned long long)acc, text.size());
+        CK(hipMemcpy(d_toff, toff.data(), toff.size() * sizeof(uint64_t), hipMemcpyHostToDevice));
+        CK(hipEventRecord(ev[3]));
+        hipLaunchKernelGGL(k_resolve, dim3((unsigned)cd.size(), 8), dim3(256), 0, 0, d_desc, d_sym, d_windows, d_toff, d_text);
+        CK(hipEventRecord(ev[4]));
+        CK(hipEventSynchronize(ev[4]));
+        float a, b, c2;
+        CK(hipEventElapsedTime(&a, ev[0], ev[1]));
+        CK(hipEventElapsedTime(&b, ev[1], ev[2]));
+        CK(hipEventElapsedTime(&c2, ev[3], ev[4]));
+        if (a < t_decode) t_decode = a;
+        if (b < t_chain) t_chain = b;
+        if (c2 < t_resolve) t_resolve = c2;
+        CK(hipMemcpy(&broken, d_broken, 4, hipMemcpyDeviceToHost));
+    }
+    size_t bad_status = 0;
+    for (size_t k = 0; k < res.size(); k++)
+        if (res[k].status) {
+            if (bad_status < 4)
+                fprintf(stderr, "chunk %zu of %zu: status %u after %u blocks, bits %llu .. %llu (asked to stop at %llu), %llu symbols of %llu\n", k,
+                        res.size(), res[k].status, res[k].blocks, (unsigned long long)cd[k].bit_start, (unsigned long long)res[k].bit_end,
+                        (unsigned long long)cd[k].bit_end, (unsigned long long)(res[k].out_end - res[k].out_start),
+                        (unsigned long long)(cd[k].out_end - cd[k].out_start));
+            bad_status++;
+        }
+    std::vector<uint8_t> back(text.size());
+    CK(hipMemcpy(back.data(), d_text, text.size(), hipMemcpyDeviceToHost));
+    const bool same = broken == 0 && bad_status == 0 && memcmp(back.data(), text.data(), text.size()) == 0;
+    const double tot = t_search + t_decode + t_chain + t_resolve;
+    printf("search %.2f ms, decode %.2f ms, chain %.2f ms, resolve %.2f ms: %.2f ms = %.2f GB/s of text (%.2f GB/s of gzip)\n", t_search, t_decode,
+           t_chain, t_resolve, tot, text.size() / (tot * 1e-3) / 1e9, gz.size() / (tot * 1e-3) / 1e9);
+    printf("check: %zu chunks with an error status, chain %s, text %s\n", bad_status, broken ? "BROKEN" : "whole", same ? "identical to zlib's" : "DIFFERS");
+    return same ? 0 : 1;
+}
+
+__global__ __launch_bounds__(64) void k_inflate_open(const uint32_t *in, ChunkDesc *desc, uint16_t *out) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];  // 70 KB: more than a static array may have
+    Lds &S = *(Lds *)smem;
+    const int lane = (int)threadIdx.x;
+    ChunkDesc &cd = desc[blockIdx.x];
+    const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+    // the unknown 32 KiB before the chunk as markers: the newest NEARSZ of them in the LDS ring (position q of the
+    // stream, counted from 32768 before the chunk, lives at q & (NEARSZ - 1))
+    for (uint32_t i = (uint32_t)lane; i < NEARSZ; i += 64) S.window[(WSIZE - NEARSZ + i) & (NEARSZ - 1)] = (uint16_t)(0x8000u | (WSIZE - NEARSZ + i));
+    if (lane < 29) {
+        S.lbase[lane] = LBASE[lane];
+        S.lext[lane] = LEXT[lane];
+    }
+    if (lane < 30) {
+        S.dbase[lane] = DBASE[lane];
+        S.dext[lane] = DEXT[lane];
+    }
+    LDS_ORDER();
+    uint64_t bitpos = cd.bit_start;
+    const uint64_t bit_end = cd.bit_end;
+    uint16_t *o = out + cd.out_start;
+    uint32_t op = 0;  // symbols written; window position = op & (WSIZE - 1)
+    const uint32_t cap = (uint32_t)(cd.out_end - cd.out_start);
+    BitIn bi;
+    bi.init(in, bitpos, lane);
+    uint32_t status = 0, blocks = 0;
+    while (bitpos < bit_end && status == 0) {
+        uint64_t w = bi.fetch(bitpos, lane);
+        const uint32_t bfinal = (uint32_t)w & 1u, btype = (uint32_t)(w >> 1) & 3u;
+        bitpos += 3;
+        blocks++;
+        if (btype == 0) {  // stored
+            bitpos = (bitpos + 7) & ~7ull;
+            w = bi.fetch(bitpos, lane);
+            const uint32_t len = (uint32_t)w & 0xFFFFu, nlen = (uint32_t)(w >> 16) & 0xFFFFu;
+            if ((len ^ nlen) != 0xFFFFu) {
+                status = 2;
+                break;
+            }
+            bitpos += 32;
+            if (op + len > cap) {
+                status = 5;
+                break;
+            }
+            const uint8_t *bytes = (const uint8_t *)in + (bitpos >> 3);
+            for (uint32_t i = (uint32_t)lane; i < len; i += 64) {
+                const uint16_t v = bytes[i];
+                S.window[(op + WSIZE + i) & (NEARSZ - 1)] = v;
+                o[op + i] = v;
+            }
+            LDS_ORDER();
+            op += len;
+            bitpos += 8ull * len;
+            bi.init(in, bitpos, lane);
+            if (bfinal) break;
+            continue;
+        }
+        if (btype == 3) {
+            status = 3;
+            break;
+        }
+        int nlit, ndist;
+        if (btype == 1) {  // fixed codes
+            for (int s = lane; s < 288; s += 64) S.lens[s] = s < 144 ? 8 : s < 256 ? 9 : s < 280 ? 7 : 8;
+            if (lane < 32) S.lens[288 + lane] = 5;
+            nlit = 288;
+            ndist = 30;
+        } else {
+            status = parse_dynamic(S, bi, bitpos, lane, nlit, ndist);
+            if (status) break;
+        }
+        build(S, S.lens, nlit, S.lcount, S.lsym, S.lit, ROOT, 1, lane);
+        build(S, S.lens + nlit, ndist, S.dcount, S.dsym, S.dist, DROOT, 2, lane);
+        // ---- the symbols of the block
+        for (;;) {
+            w = bi.fetch(bitpos, lane);
+            uint32_t e = uni(S.lit[w & ((1u << ROOT) - 1u)]);
+            if (e == 0) {  // a code longer than the root
+                uint32_t l;
+                const uint32_t sym = slow_symbol(w, S.lcount, S.lsym, l);
+                if (l == 0 || sym >= 286u) {
+                    status = 6;
+                    break;
+                }
+                e = entry_of(S, 1, sym, l);
+            }
+            const uint32_t l = e & 15u;
+            bitpos += l;
+            w >>= l;
+            const uint32_t kind = e >> 28;
+            if (kind == 0) {
+                if (op >= cap) {
+                    status = 5;
+                    break;
+                }
+                const uint16_t v = (uint16_t)(e >> 8);
+                if (lane == 0) {
+                    S.window[(op + WSIZE) & (NEARSZ - 1)] = v;
+                    o[op] = v;
+                }
+                op++;
+                continue;
+            }
+            if (kind == 2) break;
+            const uint32_t lext = (e >> 4) & 15u;
+            const uint32_t len = ((e >> 8) & 0xFFFFu) + ((uint32_t)w & ((1u << lext) - 1u));
+            bitpos += lext;
+            w >>= lext;
+            uint32_t de = uni(S.dist[w & ((1u << DROOT) - 1u)]);
+            if (de == 0) {
+                uint32_t dl;
+                const uint32_t dsymv = slow_symbol(w, S.dcount, S.dsym, dl);
+                if (dl == 0 || dsymv >= 30u) {
+                    status = 8;
+                    break;
+                }
+                de = entry_of(S, 2, dsymv, dl);
+            }
+            const uint32_t dl = de & 15u;
+            bitpos += dl;
+            w >>= dl;
+            const uint32_t dext = (de >> 4) & 15u;
+            const uint32_t dist = ((de >> 8) & 0xFFFFu) + ((uint32_t)w & ((1u << dext) - 1u));
+            bitpos += dext;
+            if (op + len > cap) {
+                status = 5;
+                break;
+            }
+            // the copy: every lane a symbol; with dist < len the pattern repeats.  (LDS operations of one wave execute
+            // in order: the literal lane 0 wrote, the symbols of the last copy are there for this one)
+            asm volatile("" ::: "memory");
+            for (uint32_t i = (uint32_t)lane; i < len; i += 64) {
+                const uint32_t from = dist >= len ? i : i % dist;
+                uint16_t v;
+                // (a ring slot is overwritten by the position NEARSZ later: a source this copy could reach with its own
+                //  writes -- up to 258 symbols ahead -- is not taken from the ring)
+                if (dist - from + 320u <= NEARSZ) {
+                    v = S.window[(op + WSIZE - dist + from) & (NEARSZ - 1)];
+                } else if (op + from >= dist) {  // older than the ring, inside the chunk: from the output (written long ago)
+                    v = __hip_atomic_load(&o[op + from - dist], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                } else {                         // older than the ring, before the chunk: the marker itself
+                    v = (uint16_t)(0x8000u | (op + WSIZE - dist + from));
+                }
+                o[op + i] = v;
+                S.window[(op + WSIZE + i) & (NEARSZ - 1)] = v;
+            }
+            asm volatile("" ::: "memory");
+            op += len;
+        }
+        if (bfinal) break;
+    }
+    if (lane == 0) {  // where the chunk ended and how much it wrote are results here
+        cd.status = status;
+        cd.blocks = blocks;
+        cd.bit_end = bitpos;
+        cd.out_end = cd.out_start + op;
+        cd.cycles = __builtin_amdgcn_s_memtime() - t0;
+    }
+}
+
+
 int main(int argc, char **argv) {
     if (argc < 2) {
         fprintf(stderr, "usage: gpu_inflate_proto file.gz [chunk KiB]\n");
         return 2;
     }
     const size_t chunk = (argc > 2 ? (size_t)atol(argv[2]) : 4096) << 10;
+    const bool full = argc > 3 && !strcmp(argv[3], "full");
     FILE *f = fopen(argv[1], "rb");
     if (!f) return 1;
     std::vector<uint8_t> gz;
@@ -439,6 +884,7 @@ int main(int argc, char **argv) {
         bounds.push_back({((uint64_t)zs.total_in - 8) * 8, (uint64_t)zs.total_out});
         inflateEnd(&zs);
     }
+    if (full) return full_mode(gz, text, bounds.front().bit, bounds.back().bit, chunk);
     // (a boundary recorded while the LAST block is being decoded is flagged 64 and skipped above, so the last pair is
     //  the start of the final block or of the block before it; the chunk that holds it runs to the end of the data)
     std::vector<ChunkDesc> chunks;

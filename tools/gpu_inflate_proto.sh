@@ -16,6 +16,8 @@ PY
 for exe in tools/gpu_inflate_proto tools/gpu_inflate_proto_*[0-9]; do
   [ -x $exe ] || continue
   echo "== $exe"
-  for kib in 4096 160 64 32; do timeout 300 ./$exe /dev/shm/gip/m.fq.gz $kib || true; done
+  for kib in 4096 32; do timeout 300 ./$exe /dev/shm/gip/m.fq.gz $kib || true; done
+  echo "-- the whole reader: search, decode, chain, marker replacement"
+  for kib in 256 64 32 16; do timeout 300 ./$exe /dev/shm/gip/m.fq.gz $kib full || true; done
 done
 rm -rf /dev/shm/gip
