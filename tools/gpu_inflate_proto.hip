@@ -12,9 +12,13 @@
 //            64 lanes through a 32 Ki-symbol circular window in LDS that starts out as the markers themselves, so that a
 //            copy out of the unknown window is a copy like any other.  Dynamic, fixed and stored blocks.
 //   check    markers replaced from the true window on the host, every byte compared with zlib's text
+//   full     (third argument "full") the whole reader on the device: k_search finds the block starts itself, k_inflate_open
+//            decodes from each to the next, the chunks' windows come from a serial walk (k_chain) and -- the same bytes,
+//            twenty times faster -- from a prefix scan over the chunks' index maps (k_maps, k_scan_round, k_windows),
+//            k_resolve replaces the markers; the text is compared with zlib's.  profiles/r03_gpu_inflate_proto.txt
 //
 //   hipcc --offload-arch=gfx950 -O3 tools/gpu_inflate_proto.hip -o tools/gpu_inflate_proto -lz
-//   ./gpu_inflate_proto file.gz [chunk KiB = 4096]
+//   ./gpu_inflate_proto file.gz [chunk KiB = 4096] [full]
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
@@ -480,6 +484,15 @@ __global__ __launch_bounds__(64) void k_search(const uint32_t *in, uint64_t tota
         if (lane == 0) start[0] = first_bit;
         return;
     }
+    if (lane < 29) {  // (the trial walk reads the base / extra-bit tables through entry_of)
+        S.lbase[lane] = LBASE[lane];
+        S.lext[lane] = LEXT[lane];
+    }
+    if (lane < 30) {
+        S.dbase[lane] = DBASE[lane];
+        S.dext[lane] = DEXT[lane];
+    }
+    LDS_ORDER();
     uint64_t from = (uint64_t)c * chunk_bits, to = from + chunk_bits;
     if (from <= first_bit) from = first_bit + 1;
     if (to + 160 > total_bits) to = total_bits > 160 ? total_bits - 160 : 0;
@@ -546,6 +559,56 @@ __global__ __launch_bounds__(1024) void k_chain(ChunkDesc *d, uint32_t n, const 
     if (t == 0) *broken = 0;
 }
 
+// ---- the same windows without the serial walk: a chunk's effect on the window is an index map (a byte of the next
+// window is a literal, or the byte at some index of this one: 0x8000 | index, the symbols' own form), maps compose
+// associatively, and a parallel prefix scan over the chunks' maps gives every chunk's window.
+__global__ __launch_bounds__(256) void k_maps(const ChunkDesc *d, const uint16_t *sym, uint16_t *maps) {
+    const uint32_t c = blockIdx.x;
+    const uint32_t nsym = (uint32_t)(d[c].out_end - d[c].out_start);
+    const uint16_t *src = sym + d[c].out_start;
+    uint16_t *m = maps + (size_t)c * WSIZE;
+    for (uint32_t j = blockIdx.y * 256 + threadIdx.x; j < WSIZE; j += gridDim.y * 256) {
+        uint16_t v;
+        if (nsym >= WSIZE) v = src[nsym - WSIZE + j];
+        else if (j < WSIZE - nsym) v = (uint16_t)(0x8000u | (j + nsym));  // the old window moves up
+        else v = src[j - (WSIZE - nsym)];
+        m[j] = v;
+    }
+}
+// one round of the scan: dst[c] = src[c] o src[c - stride] (first through the earlier map, then through c's)
+__global__ __launch_bounds__(256) void k_scan_round(const uint16_t *src, uint16_t *dst, uint32_t n, uint32_t stride) {
+    const uint32_t c = blockIdx.x;
+    const uint16_t *b = src + (size_t)c * WSIZE;
+    uint16_t *o = dst + (size_t)c * WSIZE;
+    if (c < stride) {
+        for (uint32_t j = blockIdx.y * 256 + threadIdx.x; j < WSIZE; j += gridDim.y * 256) o[j] = b[j];
+        return;
+    }
+    const uint16_t *a = src + (size_t)(c - stride) * WSIZE;
+    for (uint32_t j = blockIdx.y * 256 + threadIdx.x; j < WSIZE; j += gridDim.y * 256) {
+        const uint16_t v = b[j];
+        o[j] = v & 0x8000u ? a[v & 0x7FFFu] : v;
+    }
+}
+// windows[c + 1] = the scanned map of chunk c applied to the window before chunk 0 (zeros); windows[0] = that window
+__global__ __launch_bounds__(256) void k_windows(const uint16_t *scanned, uint32_t n, uint8_t *windows) {
+    const uint32_t c = blockIdx.x;  // the window of chunk c
+    uint8_t *w = windows + (size_t)c * WSIZE;
+    for (uint32_t j = blockIdx.y * 256 + threadIdx.x; j < WSIZE; j += gridDim.y * 256) {
+        uint8_t v = 0;
+        if (c > 0) {
+            const uint16_t x = scanned[(size_t)(c - 1) * WSIZE + j];
+            v = x & 0x8000u ? 0 : (uint8_t)x;
+        }
+        w[j] = v;
+    }
+}
+__global__ void k_seams(const ChunkDesc *d, uint32_t n, uint32_t *broken) {
+    const uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c + 1 < n && (d[c].status != 0 || d[c].bit_end != d[c + 1].bit_start)) atomicMin(broken, c + 1);
+    if (c + 1 == n && d[c].status != 0) atomicMin(broken, c + 1);
+}
+
 // every chunk's symbols become bytes at their place in the text
 __global__ __launch_bounds__(256) void k_resolve(const ChunkDesc *d, const uint16_t *sym, const uint8_t *windows, const uint64_t *text_off,
                                                  uint8_t *text) {
@@ -578,7 +641,7 @@ static int full_mode(const std::vector<uint8_t> &gz, const std::vector<uint8_t> 
     CK(hipFuncSetAttribute((const void *)k_chain, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(2 * WSIZE)));
     hipEvent_t ev[6];
     for (auto &evt : ev) CK(hipEventCreate(&evt));
-    float t_search = 1e30f, t_decode = 1e30f, t_chain = 1e30f, t_resolve = 1e30f;
+    float t_search = 1e30f, t_decode = 1e30f, t_chain = 1e30f, t_resolve = 1e30f, t_scan = 0;
     std::vector<uint64_t> start(nchunk);
     for (int rep = 0; rep < 2; rep++) {
         CK(hipEventRecord(ev[0]));
@@ -629,6 +692,49 @@ static int full_mode(const std::vector<uint8_t> &gz, const std::vector<uint8_t> 
         hipLaunchKernelGGL(k_chain, dim3(1), dim3(1024), 2 * WSIZE, 0, d_desc, (uint32_t)cd.size(), d_sym, d_windows, d_broken);
         CK(hipEventRecord(ev[2]));
         CK(hipEventSynchronize(ev[2]));
+        if (rep == 1) {  // the windows once more by the scan over the chunks' index maps: same bytes, parallel
+            const uint32_t n = (uint32_t)cd.size();
+            uint16_t *d_m0, *d_m1;
+            uint8_t *d_w2;
+            uint32_t *d_b2;
+            CK(hipMalloc(&d_m0, (size_t)n * WSIZE * 2));
+            CK(hipMalloc(&d_m1, (size_t)n * WSIZE * 2));
+            CK(hipMalloc(&d_w2, (size_t)n * WSIZE));
+            CK(hipMalloc(&d_b2, 4));
+            float best_scan = 1e30f;
+            for (int r2 = 0; r2 < 2; r2++) {
+                const uint32_t big = 0xFFFFFFFFu;
+                CK(hipMemcpy(d_b2, &big, 4, hipMemcpyHostToDevice));
+                CK(hipEventRecord(ev[3]));
+                hipLaunchKernelGGL(k_seams, dim3((n + 255) / 256), dim3(256), 0, 0, d_desc, n, d_b2);
+                hipLaunchKernelGGL(k_maps, dim3(n, 4), dim3(256), 0, 0, d_desc, d_sym, d_m0);
+                uint16_t *a = d_m0, *b = d_m1;
+                for (uint32_t stride = 1; stride < n; stride <<= 1) {
+                    hipLaunchKernelGGL(k_scan_round, dim3(n, 4), dim3(256), 0, 0, a, b, n, stride);
+                    uint16_t *t = a;
+                    a = b;
+                    b = t;
+                }
+                hipLaunchKernelGGL(k_windows, dim3(n, 4), dim3(256), 0, 0, a, n, d_w2);
+                CK(hipEventRecord(ev[4]));
+                CK(hipEventSynchronize(ev[4]));
+                float ms;
+                CK(hipEventElapsedTime(&ms, ev[3], ev[4]));
+                if (ms < best_scan) best_scan = ms;
+            }
+            std::vector<uint8_t> w1((size_t)n * WSIZE), w2((size_t)n * WSIZE);
+            CK(hipMemcpy(w1.data(), d_windows, w1.size(), hipMemcpyDeviceToHost));
+            CK(hipMemcpy(w2.data(), d_w2, w2.size(), hipMemcpyDeviceToHost));
+            uint32_t b2 = 0;
+            CK(hipMemcpy(&b2, d_b2, 4, hipMemcpyDeviceToHost));
+            printf("windows by a prefix scan over the chunks' index maps: %.2f ms (the serial walk: %.2f ms), %s, seams %s\n", best_scan, t_chain,
+                   w1 == w2 ? "the same bytes" : "DIFFERENT", b2 == 0xFFFFFFFFu ? "whole" : "BROKEN");
+            t_scan = best_scan;
+            CK(hipFree(d_m0));
+            CK(hipFree(d_m1));
+            CK(hipFree(d_w2));
+            CK(hipFree(d_b2));
+        }
         // (the text offsets: a prefix sum over the chunks' lengths -- on the host here, a scan kernel in the real thing)
         CK(hipMemcpy(res.data(), d_desc, cd.size() * sizeof(ChunkDesc), hipMemcpyDeviceToHost));
         uint64_t acc = 0;
@@ -645,6 +751,7 @@ static int full_mode(const std::vector<uint8_t> &gz, const std::vector<uint8_t> 
         float a, b, c2;
         CK(hipEventElapsedTime(&a, ev[0], ev[1]));
         CK(hipEventElapsedTime(&b, ev[1], ev[2]));
+        if (rep == 1) b = t_chain;  // (ev[3] was reused by the scan above: keep the first round's chain time)
         CK(hipEventElapsedTime(&c2, ev[3], ev[4]));
         if (a < t_decode) t_decode = a;
         if (b < t_chain) t_chain = b;
@@ -667,6 +774,8 @@ static int full_mode(const std::vector<uint8_t> &gz, const std::vector<uint8_t> 
     const double tot = t_search + t_decode + t_chain + t_resolve;
     printf("search %.2f ms, decode %.2f ms, chain %.2f ms, resolve %.2f ms: %.2f ms = %.2f GB/s of text (%.2f GB/s of gzip)\n", t_search, t_decode,
            t_chain, t_resolve, tot, text.size() / (tot * 1e-3) / 1e9, gz.size() / (tot * 1e-3) / 1e9);
+    const double tot2 = t_search + t_decode + t_scan + t_resolve;
+    printf("with the scan instead of the walk: %.2f ms = %.2f GB/s of text\n", tot2, text.size() / (tot2 * 1e-3) / 1e9);
     printf("check: %zu chunks with an error status, chain %s, text %s\n", bad_status, broken ? "BROKEN" : "whole", same ? "identical to zlib's" : "DIFFERS");
     return same ? 0 : 1;
 }
