@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define NH_ABI_VERSION 2
+#define NH_ABI_VERSION 3
 
 typedef enum {
     NH_OK = 0,
@@ -82,8 +82,21 @@ typedef struct {
     uint32_t minimum_hit_groups; /* default 2 */
     int32_t linear_probing;      /* default 1 (kraken2 builds with -DLINEAR_PROBING) */
     int32_t reset_per_mate;      /* default 1 (last minimizer/taxon reset for each mate) */
-    int32_t reserved;
+    /* ABI 3 (was `reserved`, 0): which k-mers next to an ambiguous base count as ambiguous ("A:n" in the hit list,
+     * no look-up) -- the two recollections of kraken2's scanner, switchable until a binary has been diffed
+     * (BASELINE.md section 2):
+     *   NH_AMBIGUITY_LAST_LMER (0)  the bool* flag of MinimizerScanner::NextMinimizer: an ambiguous byte among the
+     *                               k-mer's last l bases; an isolated N costs l = 31 k-mers, the next three are
+     *                               looked up with windows of 1, 2, 3 l-mers;
+     *   NH_AMBIGUITY_QUEUE (1)      mmscanner.h is_ambiguous() = (queue_pos_ < k_ - l_) || !!last_ambig_, what
+     *                               classify.cc / build_db.cc ask: also ambiguous until k - l l-mers have been queued
+     *                               behind the base, i.e. an ambiguous byte among the last k - 1 bases; an isolated N
+     *                               costs k - 1 = 34 k-mers.  Default. */
+    int32_t ambiguity_rule;
 } nh_options;
+#define NH_AMBIGUITY_LAST_LMER 0
+#define NH_AMBIGUITY_QUEUE 1
+#define NH_AMBIGUITY_DEFAULT NH_AMBIGUITY_QUEUE
 
 /* flags of nh_classify_* */
 #define NH_FLAG_PAIRED 1u /* sequences 2f and 2f+1 are the mates of fragment f (--paired) */
@@ -117,6 +130,9 @@ int nh_synthetic_add_sequences(nh_engine *e, const void *d_bases, const void *d_
 int nh_close(nh_engine *e);
 
 int nh_db_info_get(const nh_engine *e, nh_db_info *info);
+/* The defaults of a freshly opened engine can be overridden per process by NOHUMAN_OPT_AMBIGUITY_RULE,
+ * NOHUMAN_OPT_LINEAR_PROBING, NOHUMAN_OPT_RESET_PER_MATE, NOHUMAN_OPT_MIN_HIT_GROUPS (integers): how
+ * scripts/parity_vs_kraken2.sh walks the switch lattice through nh_run and the CLI host. */
 int nh_options_get(const nh_engine *e, nh_options *o);
 int nh_options_set(nh_engine *e, const nh_options *o);
 /* internal taxon id -> external (NCBI) id, as printed in kraken2's output / "kraken:taxid|N" */

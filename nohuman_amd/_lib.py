@@ -31,7 +31,7 @@ class nh_db_info(C.Structure):
 
 class nh_options(C.Structure):
     _fields_ = [("minimum_hit_groups", C.c_uint32), ("linear_probing", C.c_int32),
-                ("reset_per_mate", C.c_int32), ("reserved", C.c_int32)]
+                ("reset_per_mate", C.c_int32), ("ambiguity_rule", C.c_int32)]
 
 
 class nh_run_args(C.Structure):

@@ -509,11 +509,17 @@ StreamEncoder *make_encoder(int codec, int fd, unsigned threads, const char *nam
             const char *how = getenv("NOHUMAN_GZIP");
             if (device >= 0 && !(how && !strcmp(how, "host"))) {
                 StreamEncoder *e = make_gpu_gzip_encoder(fd, device, name);
-                if (!e) {  // loud, never a silent change of encoder
-                    const std::string why = g_last_error;
-                    set_error(NH_EDEVICE, "%s (NOHUMAN_GZIP=host selects the host encoder)", why.c_str());
+                if (e) return e;
+                // The encoder's buffers (about 1 GiB of HBM, 0.5 GiB page-locked) could not be had -- a large database
+                // or a small host.  Loud, never silent: one WARN line and the host encoder (the same gzip container,
+                // zlib blocks), or a failed run when the GPU encoder was asked for by name (NOHUMAN_GZIP=gpu).
+                const std::string why = g_last_error;
+                if (how && !strcmp(how, "gpu")) {
+                    set_error(NH_EDEVICE, "%s (NOHUMAN_GZIP=gpu: no fallback to the host encoder)", why.c_str());
+                    return nullptr;
                 }
-                return e;
+                fprintf(stderr, "nohuman: WARN gzip output %s: the GPU encoder could not be set up (%s); encoding on the host\n",
+                        name ? name : "", why.c_str());
             }
             return new GzipEncoder(fd, threads, name);
         }

@@ -33,6 +33,7 @@ struct DevDB {
     int32_t linear_probing;
     int32_t reset_per_mate;
     uint32_t min_hit_groups;
+    int32_t ambig_rule;     // nh_options.ambiguity_rule: 0 = ambiguous byte in the last l bases, 1 = in the last k-1 (scan_body)
     uint32_t max_chunks;    // bound of the linear-probe loop in rounds (>= 1 cell per round)
 };
 

@@ -143,6 +143,7 @@ static void finish_devdb(Engine *e) {
     d.linear_probing = e->options.linear_probing;
     d.reset_per_mate = e->options.reset_per_mate;
     d.min_hit_groups = e->options.minimum_hit_groups;
+    d.ambig_rule = e->options.ambiguity_rule;
     // bound of the probe loop: every round advances by at least one cell
     d.max_chunks = i.capacity + 1 > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)(i.capacity + 1);
 }
@@ -160,6 +161,18 @@ static int alloc_table(Engine *e, uint64_t capacity) {
     if (const char *env = getenv("NOHUMAN_TABLE_COPIES")) {
         const int v = atoi(env);
         want = v >= 8 ? 8u : v >= 4 ? 4u : v >= 2 ? 2u : 1u;
+    }
+    // Tables of 2^32 - 256 cells and more: only the quad-probing rounds (default geometry, linear probing) read the copies
+    // through 64-bit positions; the per-lane rounds every other configuration takes read copy 0 alone (three
+    // copies of >= 16 GiB allocated and refreshed for nothing, and the batch buffers or the gzip encoder starved)
+    {
+        const nh_db_info &i = e->info;
+        const bool std_geom = i.k == 35 && i.l == 31 && i.revcom_version != 0 && i.minimum_acceptable_hash_value == 0;
+        bool quad = std_geom && e->options.linear_probing != 0;
+#ifdef NH_NO_QUAD
+        quad = false;
+#endif
+        if (capacity >= 0xFFFFFF00ull && !quad) want = 1;
     }
     for (;; want >>= 1) {
         const uint64_t sh = 32 / want;
@@ -205,6 +218,12 @@ static int common_open(Engine *e, int device) {
     e->options.minimum_hit_groups = 2;
     e->options.linear_probing = 1;
     e->options.reset_per_mate = 1;
+    e->options.ambiguity_rule = NH_AMBIGUITY_DEFAULT;
+    // per-process overrides of the "verify first" switches (parity_vs_kraken2.sh walks their lattice through the CLI)
+    if (const char *v = getenv("NOHUMAN_OPT_AMBIGUITY_RULE")) e->options.ambiguity_rule = atoi(v) != 0;
+    if (const char *v = getenv("NOHUMAN_OPT_LINEAR_PROBING")) e->options.linear_probing = atoi(v) != 0;
+    if (const char *v = getenv("NOHUMAN_OPT_RESET_PER_MATE")) e->options.reset_per_mate = atoi(v) != 0;
+    if (const char *v = getenv("NOHUMAN_OPT_MIN_HIT_GROUPS")) e->options.minimum_hit_groups = (uint32_t)atoi(v);
     HIP_TRY(hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking));
     HIP_TRY(hipMalloc((void **)&e->d_counters, (CNT_N + 12) * sizeof(uint64_t)));
     HIP_TRY(hipMemset(e->d_counters, 0, (CNT_N + 12) * sizeof(uint64_t)));
@@ -793,6 +812,8 @@ int nh_options_get(const nh_engine *e, nh_options *o) {
 }
 int nh_options_set(nh_engine *e, const nh_options *o) {
     if (!e || !o) return set_error(NH_EINVAL, "null argument");
+    if (o->ambiguity_rule != NH_AMBIGUITY_LAST_LMER && o->ambiguity_rule != NH_AMBIGUITY_QUEUE)
+        return set_error(NH_EINVAL, "nh_options.ambiguity_rule must be 0 or 1");
     std::lock_guard<std::mutex> lock(((Engine *)e)->db_mu);
     ((Engine *)e)->options = *o;
     return NH_OK;

@@ -10,10 +10,10 @@
 #include <string.h>
 #if defined(__x86_64__)
 #include <immintrin.h>
+#endif
 
 #include <atomic>
 #include <chrono>
-#endif
 #include <sys/mman.h>
 #include <sys/stat.h>
 #include <unistd.h>
@@ -595,6 +595,7 @@ int decode_markers(BitIn &in, const Tables &T, uint16_t *start, uint16_t *&op_re
             } else {
                 const uint16_t *src = op - dist;
                 uint64_t acc = 0;
+#if defined(__x86_64__)
                 if (dist >= 8) {
                     // eight symbols at a time, past the end of the match like the byte decoder (the buffer has the
                     // slack; what is written beyond the match is overwritten by the next symbols; a marker among the
@@ -618,7 +619,9 @@ int decode_markers(BitIn &in, const Tables &T, uint16_t *start, uint16_t *&op_re
                     }
                     if (_mm_movemask_epi8(a) & 0xAAAA) marker_end = produced + len;
                     i = len;
-                } else if (dist >= 4) {  // four symbols at a time: the source word ends before the target word
+                } else
+#endif
+                if (dist >= 4) {  // four symbols at a time: the source word ends before the target word
                     for (; i + 4 <= len; i += 4) {
                         uint64_t w;
                         memcpy(&w, src + i, 8);

@@ -63,6 +63,7 @@ template <bool STD> struct CandPad { static constexpr int value = STD ? 6 : 66; 
 #define NH_QCAP 256  // 5 waves per SIMD need <= 31 KB of LDS per workgroup (a 32 KB one fits only 4 times: profiles/r02_tuning.txt)
 #endif
 constexpr int NSLOT = NH_NSLOT;  // tiles scanned before one shared probe phase
+static_assert(NSLOT <= 4, "carry_pack holds four 16-bit queue indices per group: one inherited-minimizer entry per tile");
 constexpr int QCAP_SHORT = NH_QCAP;  // queue entries per group: a tile joins only if it is sure to fit (< 512)
 #ifndef NH_QCAP_GENERIC
 #define NH_QCAP_GENERIC 288  // the generic kernel keeps one packed stream instead of NSLOT: room for a longer queue
@@ -379,6 +380,24 @@ __device__ __forceinline__ uint32_t scan_body(KArgsP ap, WL &S, const int lane, 
         }
         v0 = (qi0 < nqt) & (last0 != NH_FULL);
         v1 = (qi1 < nqt) & (last1 != NH_FULL);
+        if (has_amb && ap->db.ambig_rule != 0) {
+            // nh_options.ambiguity_rule 1 (mmscanner.h is_ambiguous(): queue_pos < k-l || last_ambig): a k-mer counts
+            // only when k-l l-mers have been queued since the last ambiguous base, i.e. when every l-mer of its window
+            // but the first is alive (the first may be dead: the window of the first clean k-mer holds k-l l-mers;
+            // +inf drops out of the min by itself).  Rule 0 asks for the last l-mer only.
+            if (STD) {
+                const ulonglong2 a = *reinterpret_cast<const ulonglong2 *>(&S.cand[qi0]);
+                const ulonglong2 b = *reinterpret_cast<const ulonglong2 *>(&S.cand[qi0 + 2]);
+                const bool mid_alive = (b.x != NH_FULL) & (b.y != NH_FULL);
+                v0 &= mid_alive & (a.y != NH_FULL);
+                v1 &= mid_alive & (last0 != NH_FULL);
+            } else {
+                for (uint32_t i = 1; i < W; i++) {  // (i == W is last0 / last1)
+                    v0 &= S.cand[qi0 + i] != NH_FULL;
+                    v1 &= S.cand[qi1 + i] != NH_FULL;
+                }
+            }
+        }
         mz0 = m0 ^ TOGGLE;
         mz1 = m1 ^ TOGGLE;
     }
@@ -1247,6 +1266,12 @@ __device__ __forceinline__ void post_group(KArgsP ap, WL &S, const TaxList &TLI,
                 if (lane == 0) old = atomicAdd(&a4->split.part_done[sb], 1u);
                 old = uni(old);
                 finish = old + 1u == nseg;
+                // The partial loads below must not move above the counter's atomic: relaxed operations
+                // carry no order of their own, the control dependency on `finish` is all the compiler is held by.  A
+                // compiler-only fence pins the program order; the hardware side (in-order issue from one wave, sc1
+                // loads that bypass the L1, lines this XCD's L2 has never held) is the gfx942 / gfx950 behaviour this
+                // file is built for -- the Makefile's ARCH list is the assumption.
+                __atomic_signal_fence(__ATOMIC_SEQ_CST);
                 if (finish) {
                     for (uint32_t s2 = 0; s2 < nseg; s2++) {
                         if (s2 == seg) continue;
@@ -2236,7 +2261,9 @@ hipError_t launch_classify(const DevDB &db, const LaunchIO &io, double confidenc
     ka.work = sl.d_work;
     ka.defer_bits = sl.d_defer;
     ka.pending_long = sl.d_pending_long;
+#ifdef NH_TIMELINE  // tuning builds only (tools/timeline.py): a raw device pointer from the environment has no place in the product
     if (const char *tl = getenv("NH_TIMELINE_PTR")) ka.timeline = (unsigned long long *)strtoull(tl, nullptr, 0);
+#endif
     // Long single-end reads: a prepass lists the launch's work items -- segments of the reads worth cutting,
     // then whole reads by size class -- and the generic kernel claims items (SplitBufs, nh_device.h)
     static const bool no_split = getenv("NOHUMAN_NO_SPLIT") != nullptr;  // tuning / test knob

@@ -136,8 +136,11 @@ class Engine:
         _check(self._L.nh_options_get(self._h, C.byref(o)))
         return o
 
-    def set_options(self, *, minimum_hit_groups=None, linear_probing=None, reset_per_mate=None):
+    def set_options(self, *, minimum_hit_groups=None, linear_probing=None, reset_per_mate=None,
+                    ambiguity_rule=None):
         o = self.options()
+        if ambiguity_rule is not None:
+            o.ambiguity_rule = int(ambiguity_rule)
         if minimum_hit_groups is not None:
             o.minimum_hit_groups = int(minimum_hit_groups)
         if linear_probing is not None:

@@ -14,6 +14,7 @@ kraken2 pin: /root/reference/Dockerfile:15,35-38.
 from __future__ import annotations
 
 import math
+import os
 import struct
 from dataclasses import dataclass, field
 
@@ -70,6 +71,9 @@ class DB:
     linear_probing: bool = True
     reset_per_mate: bool = True
     minimum_hit_groups: int = 2
+    # 0: a k-mer is ambiguous iff an ambiguous byte lies in its last l bases; 1 (default): mmscanner.h
+    # is_ambiguous() = queue_pos < k-l || last_ambig, in closed form: in its last max(l, k-1) bases
+    ambiguity_rule: int = int(os.environ.get("K2O_AMBIGUITY_RULE", "1") != "0")
     names: list = field(default_factory=list)
 
     @classmethod
@@ -151,16 +155,17 @@ def kmer_minimizers(db: DB, seq: bytes):
             canon &= db.spaced_seed_mask
         cand[j] = canon ^ toggle
     out = []
+    span = l if db.ambiguity_rule == 0 else max(l, k - 1)
     for e in range(k - 1, n):
-        if cand[e] is None:  # ambiguous byte within the last l bases
-            out.append((True, None))
-            continue
         # last ambiguous byte at or before e
         p = -1
         for i in range(e, -1, -1):
             if codes[i] < 0:
                 p = i
                 break
+        if p > e - span:  # ambiguous byte within the last `span` bases
+            out.append((True, None))
+            continue
         lo = max(e - (k - l), p + l)
         best = min(cand[j] for j in range(lo, e + 1))
         out.append((False, best ^ toggle))

@@ -89,6 +89,7 @@ typedef struct {
     uint64_t lmer, lmer_mask, last_ambig, spaced_mask, toggle;
     int64_t loaded_ch, queue_pos;
     int rv;
+    int ambig_rule; /* k2o_db.ambiguity_rule */
     uint64_t last_minimizer;
     /* monotone deque as a ring; never holds more than k-l+2 live entries */
     mm_entry *q;
@@ -114,6 +115,7 @@ static void mm_init(mm_scanner *sc, const k2o_db *db) {
     sc->spaced_mask = db->opts.spaced_seed_mask;
     sc->toggle = db->opts.toggle_mask & sc->lmer_mask;
     sc->rv = db->opts.revcom_version;
+    sc->ambig_rule = db->ambiguity_rule;
     sc->qcap = sc->k - sc->l + 4;
     sc->q = (mm_entry *)malloc((size_t)sc->qcap * sizeof(mm_entry));
 }
@@ -133,6 +135,16 @@ static void mm_load(mm_scanner *sc, const uint8_t *seq, size_t len) {
 }
 
 #define QAT(sc, i) ((sc)->q[((sc)->qhead + (i)) % (sc)->qcap])
+
+/* Is the k-mer NextMinimizer just returned ambiguous?  Two recollections of upstream (SURVEY.md A.3 (i)/(ii),
+ * VERDICT r3), switchable until a kraken2 binary has been diffed:
+ *   rule 0  the flag NextMinimizer hands back through its bool* argument: an ambiguous byte among the last l bases;
+ *   rule 1  mmscanner.h is_ambiguous(): (queue_pos_ < k_ - l_) || !!last_ambig_ -- also ambiguous until k - l l-mers
+ *           have been queued since the reset, i.e. an ambiguous byte among the last k - 1 bases (isolated N: A:34). */
+static inline int mm_is_ambiguous(const mm_scanner *sc) {
+    if (sc->ambig_rule == 0) return sc->last_ambig != 0;
+    return sc->queue_pos < sc->k - sc->l || sc->last_ambig != 0;
+}
 
 /* returns 1 and sets *minimizer, *ambig for the next k-mer; 0 at end of sequence */
 static int mm_next(mm_scanner *sc, uint64_t *minimizer, int *ambig) {
@@ -158,7 +170,7 @@ static int mm_next(mm_scanner *sc, uint64_t *minimizer, int *ambig) {
             sc->lmer &= sc->lmer_mask;
             sc->last_ambig &= sc->lmer_mask;
             if ((int64_t)sc->str_pos >= sc->k && sc->loaded_ch < sc->l) {
-                *ambig = sc->last_ambig != 0;
+                *ambig = mm_is_ambiguous(sc);
                 *minimizer = sc->last_minimizer;
                 return 1;
             }
@@ -169,7 +181,7 @@ static int mm_next(mm_scanner *sc, uint64_t *minimizer, int *ambig) {
         uint64_t cand = canon ^ sc->toggle;
         if (sc->k == sc->l) {
             sc->last_minimizer = cand ^ sc->toggle;
-            *ambig = sc->last_ambig != 0;
+            *ambig = mm_is_ambiguous(sc); /* (queue_pos stays 0 on this path: 0 < k - l is false) */
             *minimizer = sc->last_minimizer;
             return 1;
         }
@@ -188,7 +200,7 @@ static int mm_next(mm_scanner *sc, uint64_t *minimizer, int *ambig) {
         if ((int64_t)sc->str_pos >= sc->k) break;
     }
     sc->last_minimizer = QAT(sc, 0).cand ^ sc->toggle;
-    *ambig = sc->last_ambig != 0;
+    *ambig = mm_is_ambiguous(sc);
     *minimizer = sc->last_minimizer;
     return 1;
 }
@@ -464,6 +476,11 @@ int k2o_db_from_images(k2o_db *db, const void *opts, size_t opts_len, const void
     db->linear_probing = 1;
     db->reset_per_mate = 1;
     db->minimum_hit_groups = 2;
+    db->ambiguity_rule = K2O_AMBIG_DEFAULT;
+    { /* tests run whole suites under the other rule in a child process (the engine reads NOHUMAN_OPT_AMBIGUITY_RULE) */
+        const char *env = getenv("K2O_AMBIGUITY_RULE");
+        if (env && *env) db->ambiguity_rule = atoi(env) != 0;
+    }
     /* opts.k2d: read min(filesize, sizeof IndexOptions) bytes into a zeroed struct */
     uint8_t ob[64];
     memset(ob, 0, sizeof ob);

@@ -52,6 +52,8 @@ typedef struct {
     int linear_probing;      /* 1 = -DLINEAR_PROBING build (default), 0 = double hashing */
     int reset_per_mate;      /* 1 = last_minimizer/last_taxon reset per mate (default) */
     uint32_t minimum_hit_groups; /* default 2 */
+    int ambiguity_rule;      /* 0 = ambiguous byte in the last l bases; 1 = mmscanner.h is_ambiguous():
+                              * queue_pos < k-l || last_ambig, i.e. in the last k-1 bases (default) */
     void *own_cells;         /* malloc'd copy of the cells when loaded from a directory */
 } k2o_db;
 
@@ -63,6 +65,7 @@ typedef struct {
     uint32_t hit_groups;  /* minimizer_hit_groups */
 } k2o_result;
 
+#define K2O_AMBIG_DEFAULT 1
 #define K2O_TAXON_AMBIGUOUS 0xFFFFFFFFu /* kraken2 AMBIGUOUS_SPAN_TAXON, "A:n" in the hit list */
 #define K2O_TAXON_MATE_BORDER 0xFFFFFFFEu /* kraken2 MATE_PAIR_BORDER_TAXON, "|:|" */
 

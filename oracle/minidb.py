@@ -103,8 +103,10 @@ def value_bits_for(node_count: int) -> int:
 
 def build_hash(taxonomy: Taxonomy, genomes, capacity: int, *, k=DEFAULT_K, l=DEFAULT_L,
                spaced_mask=None, toggle=DEFAULT_TOGGLE, revcom_version=1, value_bits=None,
-               linear_probing=True, min_hash=0):
-    """genomes: iterable of (external_taxid, bytes).  Returns (hash_bytes, size)."""
+               linear_probing=True, min_hash=0, ambiguity_rule=0):
+    """genomes: iterable of (external_taxid, bytes).  Returns (hash_bytes, size).
+    ambiguity_rule: which k-mers next to an ambiguous base the builder skips (k2_literal.DB.ambiguity_rule); 0 keeps
+    the committed toy database byte-stable -- a table is a table, whichever rule its builder followed."""
     if spaced_mask is None:
         spaced_mask = default_spaced_mask(l) if l == DEFAULT_L else 0
     vb = value_bits if value_bits is not None else value_bits_for(taxonomy.node_count)
@@ -113,7 +115,8 @@ def build_hash(taxonomy: Taxonomy, genomes, capacity: int, *, k=DEFAULT_K, l=DEF
     cells = [0] * capacity
     size = 0
     shim = lit.DB(k, l, spaced_mask, toggle, 1, min_hash, revcom_version, capacity, 0, kb, vb,
-                  cells, taxonomy.parent, taxonomy.external, linear_probing=linear_probing)
+                  cells, taxonomy.parent, taxonomy.external, linear_probing=linear_probing,
+                  ambiguity_rule=ambiguity_rule)
     for ext, seq in genomes:
         taxon = taxonomy.internal[ext]
         for ambiguous, minimizer in lit.kmer_minimizers(shim, seq):

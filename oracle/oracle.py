@@ -30,7 +30,7 @@ class _DB(C.Structure):
                 ("node_count", C.c_uint64), ("parent", C.POINTER(C.c_uint32)),
                 ("external_id", C.POINTER(C.c_uint64)), ("linear_probing", C.c_int),
                 ("reset_per_mate", C.c_int), ("minimum_hit_groups", C.c_uint32),
-                ("own_cells", C.c_void_p)]
+                ("ambiguity_rule", C.c_int), ("own_cells", C.c_void_p)]
 
 
 def build(force: bool = False) -> str:
@@ -113,7 +113,9 @@ class OracleDB:
             pass
 
     # switches
-    def set(self, *, linear_probing=None, reset_per_mate=None, minimum_hit_groups=None):
+    def set(self, *, linear_probing=None, reset_per_mate=None, minimum_hit_groups=None, ambiguity_rule=None):
+        if ambiguity_rule is not None:
+            self._db.ambiguity_rule = int(ambiguity_rule)
         if linear_probing is not None:
             self._db.linear_probing = int(linear_probing)
         if reset_per_mate is not None:

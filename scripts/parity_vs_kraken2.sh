@@ -29,6 +29,12 @@ if len(inputs) == 2:
 argv += ["--unclassified-out", out] + inputs
 CommandRunner("kraken2").run(argv)
 PY
-diff -q "$T/ref.k" "$T/eng.k" && echo "kraken output: IDENTICAL"
+if diff -q "$T/ref.k" "$T/eng.k"; then
+  echo "kraken output: IDENTICAL (the engine's default switches are pinned)"
+else
+  # self-diagnosing: the engine over the switch lattice (probing x per-mate reset x ambiguity rule x hit groups);
+  # prints the ONE combination that reproduces kraken2's lines (tests/pin_lattice.py)
+  (cd "$REPO" && python3 -m tests.pin_lattice "$DB" "$T/ref.k" "$CONF" "$IN1" ${IN2:+"$IN2"}) || true
+fi
 for f in "$T"/ref_out*.fq; do diff -q "$f" "${f/ref_out/eng_out}" && echo "$(basename "$f"): IDENTICAL"; done
 grep -E "processed|classified" "$T/ref.err" || true

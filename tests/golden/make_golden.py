@@ -7,7 +7,9 @@
 Outputs (all small):
   toy_db/{opts,taxo,hash}.k2d    mini database written by oracle/minidb.py (toy taxonomy)
   reads_se.fq, reads_pe_1.fq, reads_pe_2.fq   synthetic reads incl. N, lower case, short reads
-  expected_se.json, expected_pe.json          per-fragment records, kraken hit lists, lookups D
+  expected_se.json, expected_pe.json          per-fragment records, kraken hit lists, lookups D under the default
+                                              ambiguity rule (1: mmscanner.h is_ambiguous(), an N costs k-1 k-mers)
+  expected_se_rule0.json, expected_pe_rule0.json   the same under rule 0 (ambiguous byte in the last l bases: A:31)
   kat.json                                    known answers for fmix64 / reverse complement / masks
 There is no reference-held vector for this path (parity unpinned); these
 fixtures pin the two independent restatements and the HIP kernels to each other.
@@ -68,11 +70,13 @@ def main():
     write_fastq(os.path.join(HERE, "reads_se.fq"), se, "se")
     write_fastq(os.path.join(HERE, "reads_pe_1.fq"), [p[0] for p in pe], "pe", 1)
     write_fastq(os.path.join(HERE, "reads_pe_2.fq"), [p[1] for p in pe], "pe", 2)
-    meta = {"external_ids": db.external, "parent": db.parent, "confidences": CONFS}
-    with open(os.path.join(HERE, "expected_se.json"), "w") as f:
-        json.dump({"meta": meta, "records": expected(db, se, False)}, f)
-    with open(os.path.join(HERE, "expected_pe.json"), "w") as f:
-        json.dump({"meta": meta, "records": expected(db, pe, True)}, f)
+    for rule, tag in ((1, ""), (0, "_rule0")):
+        db.ambiguity_rule = rule
+        meta = {"external_ids": db.external, "parent": db.parent, "confidences": CONFS, "ambiguity_rule": rule}
+        with open(os.path.join(HERE, "expected_se%s.json" % tag), "w") as f:
+            json.dump({"meta": meta, "records": expected(db, se, False)}, f)
+        with open(os.path.join(HERE, "expected_pe%s.json" % tag), "w") as f:
+            json.dump({"meta": meta, "records": expected(db, pe, True)}, f)
     # known answers of the primitive functions
     kat = {"fmix64": [], "revcomp": []}
     for x in [0, 1, 2, 0xDEADBEEF, (1 << 62) - 1, 0x123456789ABCDEF, 0xFFFFFFFFFFFFFFFF]:

@@ -108,6 +108,14 @@ def test_engine_equals_real_kraken2(tmp_path, monkeypatch, toy, paired, confiden
     assert (ss.total_sequences, ss.classified, ss.unclassified) == (se.total_sequences, se.classified, se.unclassified)
     ref_lines = open(ds / "k.txt").read().splitlines()
     eng_lines = open(de / "k.txt").read().splitlines()
+    if ref_lines != eng_lines:
+        # self-diagnosing: walk the switch lattice -- probing x per-mate reset x ambiguity rule x hit
+        # groups -- and print the ONE combination that reproduces kraken2's lines, so this single run pins everything
+        from tests import pin_lattice
+        lat = tmp_path / "lattice"
+        lat.mkdir()
+        exact = pin_lattice.diagnose(db, ref_lines, inputs, confidence, workdir=str(lat))
+        pytest.fail("the engine's defaults do not reproduce kraken2; combinations that do: %s (table above)" % (exact or "none"))
     assert len(ref_lines) == len(eng_lines)
     for i, (a, b) in enumerate(zip(ref_lines, eng_lines)):
         assert a == b, "read %d: kraken2 says %r, the engine %r" % (i, a, b)
@@ -116,3 +124,29 @@ def test_engine_equals_real_kraken2(tmp_path, monkeypatch, toy, paired, confiden
         assert open(ds / n, "rb").read() == open(de / n, "rb").read(), n
     assert open(ds / "report.txt").read() == open(de / "report.txt").read()
     print("PINNED: engine == kraken2 on %d fragments (paired=%s, confidence=%s)" % (len(ref_lines), paired, confidence))
+
+
+def test_the_lattice_walker_names_the_combination(tmp_path, toy):
+    """No kraken2 needed: lines made by the engine under a NON-default combination play the binary's part; the walker
+    must name exactly that combination (and say that the defaults are not it)."""
+    import io
+    from nohuman_amd import Engine
+    from oracle import minidb
+    from tests import pin_lattice
+    ob, tb, hb, genomes, _ = toy
+    db = tmp_path / "db"
+    minidb.write_db(str(db), ob, tb, hb)
+    rng = np.random.default_rng(5)
+    reads = synth.sample_reads(rng, genomes, 1500, paired=True, len_jitter=40, n_rate=0.004)
+    p1, p2 = str(tmp_path / "r_1.fq"), str(tmp_path / "r_2.fq")
+    write_fastq(p1, [("lat.%d/1" % i, a) for i, (a, b) in enumerate(reads)])
+    write_fastq(p2, [("lat.%d/2" % i, b) for i, (a, b) in enumerate(reads)])
+    secret = dict(linear_probing=1, reset_per_mate=0, ambiguity_rule=0, minimum_hit_groups=3)
+    with Engine.open(str(db)) as eng:
+        ref = pin_lattice.engine_lines(eng, [p1, p2], "0.05", secret, str(tmp_path))
+    log = io.StringIO()
+    exact = pin_lattice.diagnose(str(db), ref, [p1, p2], "0.05", out=log)
+    print(log.getvalue())
+    assert secret in exact and len(exact) <= 2, exact  # (a second entry could only differ in a switch these reads never exercise)
+    assert all(e["reset_per_mate"] == 0 and e["ambiguity_rule"] == 0 and e["minimum_hit_groups"] == 3 for e in exact)
+    assert "NOT among them" in log.getvalue()

@@ -44,7 +44,35 @@ def test_toy_db_parity(toy, toy_oracle, toy_engine, paired, confidence):
     assert (exp["call"] != 0).sum() > 30  # the hit / LCA paths are really exercised
 
 
-def test_edge_cases(toy, toy_oracle, toy_engine):
+@pytest.fixture(params=[1, 0], ids=["ambig_queue", "ambig_last_lmer"])
+def both_rules(request, toy_oracle, toy_engine):
+    """nh_options.ambiguity_rule on the shared engine and oracle: 1 = mmscanner.h is_ambiguous() (default), 0 = last l bases"""
+    keep = toy_engine.options().ambiguity_rule
+    toy_oracle.set(ambiguity_rule=request.param)
+    toy_engine.set_options(ambiguity_rule=request.param)
+    yield request.param
+    toy_oracle.set(ambiguity_rule=keep)
+    toy_engine.set_options(ambiguity_rule=keep)
+
+
+def test_isolated_n_costs_k_minus_1_or_l_kmers(toy, toy_engine, both_rules):
+    """the hit list of a read with one N: A:34 under rule 1, A:31 under rule 0"""
+    _, _, _, genomes, _ = toy
+    g = genomes[111]
+    read = g[:70] + b"N" + g[71:150]
+    bases, offs = orc.pack_reads([read], False)
+    _, taxa, _ = toy_engine.classify(bases, offs, False, 0.0, want_taxa=True)
+    assert int((taxa == orc.AMBIG).sum()) == (34 if both_rules == 1 else 31)
+    assert taxa[35] != orc.AMBIG and taxa[36] == orc.AMBIG
+
+
+def test_ambiguity_rule_is_validated(toy_engine):
+    with pytest.raises(Exception):
+        toy_engine.set_options(ambiguity_rule=2)
+    assert toy_engine.options().ambiguity_rule in (0, 1)
+
+
+def test_edge_cases(toy, toy_oracle, toy_engine, both_rules):
     """empty reads, reads shorter than l / k, all-N, N at every offset, lower case, long reads."""
     _, _, _, genomes, _ = toy
     g = genomes[111]
@@ -183,6 +211,25 @@ def test_wide_position_variant_on_small_tables():
     assert " passed" in r.stdout
 
 
+def test_parity_suites_under_the_other_ambiguity_rule():
+    """Every oracle-differential test of the parity, split-read and whole-run files once more with BOTH sides switched to
+    ambiguity rule 0 (last l bases; the default is rule 1, mmscanner.h is_ambiguous()): the engine through
+    NOHUMAN_OPT_AMBIGUITY_RULE, the oracle through K2O_AMBIGUITY_RULE, the goldens through their _rule0 files."""
+    import subprocess
+    import sys
+    if os.environ.get("NOHUMAN_OPT_AMBIGUITY_RULE") is not None:
+        pytest.skip("already the child run")
+    env = dict(os.environ, NOHUMAN_OPT_AMBIGUITY_RULE="0", K2O_AMBIGUITY_RULE="0")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-m", "pytest", "tests/test_gpu_parity.py", "tests/test_gpu_split.py",
+                        "tests/test_gpu_run.py", "-m", "gpu", "-q", "-x", "-p", "no:cacheprovider", "-k",
+                        "not 2_pow_32 and not wide_position and not other_ambiguity and not both_rules "
+                        "and not isolated_n and not allreduce and not sched"],
+                       cwd=root, env=env, capture_output=True, text=True, timeout=1500)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+    assert " passed" in r.stdout
+
+
 def test_table_larger_than_2_pow_32_cells():
     """A 4.4 G-cell table (17.6 GB in HBM): cell positions beyond 2^32 are really addressed.  Reads
     cut from sequences whose minimizers were inserted must all classify to the inserted taxon, random
@@ -308,8 +355,9 @@ def test_random_database_geometries(seed):
     assert st.table_lookups == int(lookups.sum())
 
 
+@pytest.mark.parametrize("rule", [1, 0])
 @pytest.mark.parametrize("k,l", [(19, 8), (35, 15), (31, 10), (72, 8), (40, 19)])
-def test_window_wider_than_lmer_with_ambiguous_bases(k, l):
+def test_window_wider_than_lmer_with_ambiguous_bases(k, l, rule):
     """k - l > l: the (k-l+1)-window of a k-mer reaches l-mers that lie wholly BEFORE an ambiguous base
     whose own l-mers are long past.  kraken2's scanner cleared its queue at that base, so they must not
     take part in the minimum (the kernel used a plain min over the window)."""
@@ -317,12 +365,14 @@ def test_window_wider_than_lmer_with_ambiguous_bases(k, l):
     rng = np.random.default_rng(k * 100 + l)
     ob, tb, hb, genomes, _ = synth.toy_db(seed=k + l, k=k, l=l, spaced_mask=0, capacity=9973)
     odb = orc.OracleDB(ob, tb, hb)
+    odb.set(ambiguity_rule=rule)
     for paired in (False, True):
         reads = synth.sample_reads(rng, genomes, 500, length=160, paired=paired, len_jitter=60, n_rate=0.02,
                                    frac_random=0.2)
         bases, offs = orc.pack_reads(reads, paired)
         exp, lookups, etaxa, _ = odb.classify(bases, offs, paired, 0.05, want_taxa=True)
         with Engine.from_images(ob, tb, hb) as eng:
+            eng.set_options(ambiguity_rule=rule)
             got, taxa, _ = eng.classify(bases, offs, paired, 0.05, want_taxa=True)
             st = eng.stats()
         _assert_same(got, exp, "k=%d l=%d paired=%s" % (k, l, paired))

@@ -38,8 +38,12 @@ def test_kat_primitives():
     assert L.k2o_reverse_complement(0, 4, 1) == 0xFF
 
 
-def _check_against_golden(gold_db, fastqs, expected_json, paired):
+def _check_against_golden(gold_db, fastqs, expected_json, paired, rule=1):
+    if rule == 0:
+        expected_json = expected_json.replace(".json", "_rule0.json")
     exp = json.load(open(os.path.join(GOLD, expected_json)))
+    assert exp["meta"]["ambiguity_rule"] == rule
+    gold_db.set(ambiguity_rule=rule)
     recs = [read_fastq(os.path.join(GOLD, f)) for f in fastqs]
     n = len(recs[0])
     assert n == len(exp["records"])
@@ -78,14 +82,33 @@ def _hitlist(ext, taxa):
     return " ".join(parts)
 
 
-def test_golden_single_end(gold_db):
-    exp = _check_against_golden(gold_db, ["reads_se.fq"], "expected_se.json", False)
+@pytest.mark.parametrize("rule", [1, 0])
+def test_golden_single_end(gold_db, rule):
+    exp = _check_against_golden(gold_db, ["reads_se.fq"], "expected_se.json", False, rule)
     calls = {r["by_conf"]["0.0"][0] for r in exp["records"]}
     assert len(calls) >= 6  # LCA calls at several depths are present in the fixture
 
 
-def test_golden_paired_end(gold_db):
-    _check_against_golden(gold_db, ["reads_pe_1.fq", "reads_pe_2.fq"], "expected_pe.json", True)
+@pytest.mark.parametrize("rule", [1, 0])
+def test_golden_paired_end(gold_db, rule):
+    _check_against_golden(gold_db, ["reads_pe_1.fq", "reads_pe_2.fq"], "expected_pe.json", True, rule)
+
+
+def test_isolated_n_costs_k_minus_1_or_l_kmers(toy, toy_oracle):
+    """The two recollections of upstream's ambiguity test: an isolated N in the middle of a
+    read makes k-1 = 34 k-mers ambiguous under rule 1 (mmscanner.h is_ambiguous()), l = 31 under rule 0."""
+    _, _, _, genomes, _ = toy
+    g = genomes[111]
+    read = g[:70] + b"N" + g[71:150]
+    try:
+        for rule, want in ((1, 34), (0, 31)):
+            toy_oracle.set(ambiguity_rule=rule)
+            _, amb = toy_oracle.scan(read)
+            assert int(amb.sum()) == want
+            # k-mer i ends at base i + 34: the first ambiguous one ENDS at the N, the last one is `want` further on
+            assert amb[35] == 0 and amb[36] == 1 and amb[36 + want - 1] == 1 and amb[36 + want] == 0
+    finally:
+        toy_oracle.set(ambiguity_rule=1)
 
 
 def test_multithreaded_equals_serial(toy, toy_oracle):
@@ -102,13 +125,19 @@ _alphabet = st.sampled_from(list(b"ACGTacgtNnRX-"))
 
 
 @settings(max_examples=150, deadline=None)
-@given(st.lists(_alphabet, min_size=0, max_size=260).map(bytes))
-def test_scanner_state_machine_equals_closed_form(toy, toy_oracle, seq):
-    """mmscanner state machine (C) == closed form of SURVEY.md A.3 (Python), incl. ambiguity."""
+@given(st.lists(_alphabet, min_size=0, max_size=260).map(bytes), st.sampled_from([0, 1]))
+def test_scanner_state_machine_equals_closed_form(toy, toy_oracle, seq, rule):
+    """mmscanner state machine (C) == closed form of SURVEY.md A.3 (Python), incl. ambiguity, under both rules."""
     ob, tb, hb, _, _ = toy
     ldb = _literal(ob, tb, hb)
-    mins, amb = toy_oracle.scan(seq)
-    want = lit.kmer_minimizers(ldb, seq)
+    ldb.ambiguity_rule = rule
+    toy_oracle.set(ambiguity_rule=rule)
+    try:
+        mins, amb = toy_oracle.scan(seq)
+        want = lit.kmer_minimizers(ldb, seq)
+    finally:
+        ldb.ambiguity_rule = 1
+        toy_oracle.set(ambiguity_rule=1)
     assert len(want) == len(mins)
     for (wa, wm), m, a in zip(want, mins, amb):
         assert bool(a) == wa
@@ -131,10 +160,13 @@ def _literal(ob, tb, hb):
                                 # k > 2l: the window reaches l-mers BEFORE an ambiguous base; the scanner
                                 # drops them (queue cleared at the base), ADVICE r1
                                 dict(k=19, l=8, spaced_mask=0), dict(k=35, l=15), dict(k=31, l=10)])
-def test_variants_c_equals_literal(kw):
+@pytest.mark.parametrize("rule", [1, 0])
+def test_variants_c_equals_literal(kw, rule):
     ob, tb, hb, genomes, _ = synth.toy_db(seed=5, **kw)
     odb = orc.OracleDB(ob, tb, hb)
+    odb.set(ambiguity_rule=rule)
     ldb = lit.DB.from_images(ob, tb, hb)
+    ldb.ambiguity_rule = rule
     rng = np.random.default_rng(2)
     reads = synth.sample_reads(rng, genomes, 120, paired=False, len_jitter=80,
                                n_rate=0.02 if kw.get("k", 35) > 2 * kw.get("l", 31) else 0.002)

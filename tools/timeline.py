@@ -1,5 +1,7 @@
 """Per-wave timeline of k_classify_short (KArgs::timeline, 100 MHz timestamps): when waves start, get their
-first claim, finish their first probe phase, take their last chunk and end.  usage: timeline.py [pe|se] [reads]"""
+first claim, finish their first probe phase, take their last chunk and end.  usage: timeline.py [pe|se] [reads]
+Needs an engine built with -DNH_TIMELINE (make -C nohuman_amd/csrc CXXFLAGS+=-DNH_TIMELINE): the product build ignores
+NH_TIMELINE_PTR."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
