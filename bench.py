@@ -33,6 +33,9 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
+import datetime
+
+RDZV_TIMEOUT = datetime.timedelta(seconds=120)  # init_process_group / collectives: fail, do not hang
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md:35)
 
 
@@ -74,26 +77,87 @@ def parse_args(argv=None):
 def launch_ranks(args):
     """One child process per GPU with the torch.distributed environment set.  This parent never
     imports torch or calls HIP (a process that has initialised the GPU must not start ranks that
-    replace it), prints what rank 0 printed and returns the worst exit status."""
+    replace it).  It WATCHES all ranks: the first rank that exits non-zero is named, the
+    others are terminated (fresh children of this process -- nothing is re-executed) and the launcher exits
+    non-zero within seconds instead of leaving rank 0 in its rendezvous until torch's timeout.  Every rank's
+    stdout + stderr also go to bench_rank<r>.log (directory NOHUMAN_BENCH_LOGDIR, default: the current one);
+    rank 0's JSON line is relayed to this process's stdout."""
+    import signal
     import socket
+    import threading
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
     port = s.getsockname()[1]
     s.close()
-    procs = []
+    logdir = os.environ.get("NOHUMAN_BENCH_LOGDIR", ".")
+    os.makedirs(logdir, exist_ok=True)
+    procs, logs, threads = [], [], []
+    out0 = []
+
+    def pump(r, stream, is_out):  # tee a rank's stream: log file, and stderr of the launcher / rank 0's stdout buffer
+        for raw in iter(stream.readline, b""):
+            logs[r].write(raw)
+            logs[r].flush()
+            if is_out and r == 0:
+                out0.append(raw)
+            elif not is_out:
+                sys.stderr.buffer.write(raw)
+                sys.stderr.buffer.flush()
+
     for r in range(args.gpus):
         env = dict(os.environ)
         env.update(RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), LOCAL_WORLD_SIZE=str(args.gpus),
                    MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
-        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
-                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
-    out0, _ = procs[0].communicate()
-    codes = [procs[0].returncode] + [p.wait() for p in procs[1:]]
-    sys.stdout.write(out0.decode(errors="replace"))
+        logs.append(open(os.path.join(logdir, "bench_rank%d.log" % r), "wb"))
+        p = subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                             stdout=subprocess.PIPE, stderr=subprocess.PIPE, start_new_session=True)
+        procs.append(p)
+        for stream, is_out in ((p.stdout, True), (p.stderr, False)):
+            t = threading.Thread(target=pump, args=(r, stream, is_out), daemon=True)
+            t.start()
+            threads.append(t)
+    codes = [None] * args.gpus
+    first_bad = None
+    while any(c is None for c in codes):
+        for r, p in enumerate(procs):
+            if codes[r] is None:
+                codes[r] = p.poll()
+                if codes[r] and first_bad is None:
+                    first_bad = r
+        if first_bad is not None:
+            break
+        time.sleep(0.05)
+    if first_bad is not None:
+        sys.stderr.write("bench.py: rank %d of %d exited with status %d (see %s); stopping the other ranks\n"
+                         % (first_bad, args.gpus, codes[first_bad], os.path.join(logdir, "bench_rank%d.log" % first_bad)))
+        for r, p in enumerate(procs):  # exact process groups this launcher started, never a pattern
+            if p.poll() is None:
+                try:
+                    os.killpg(p.pid, signal.SIGTERM)
+                except OSError:
+                    pass
+        deadline = time.time() + 10
+        for r, p in enumerate(procs):
+            try:
+                p.wait(timeout=max(0.1, deadline - time.time()))
+            except subprocess.TimeoutExpired:
+                try:
+                    os.killpg(p.pid, signal.SIGKILL)
+                except OSError:
+                    pass
+                p.wait()
+            if codes[r] is None:
+                codes[r] = p.returncode
+    for t in threads:
+        t.join(timeout=5)
+    for f in logs:
+        f.close()
+    sys.stdout.write(b"".join(out0).decode(errors="replace"))
     sys.stdout.flush()
     bad = [(r, c) for r, c in enumerate(codes) if c]
-    for r, c in bad:  # (every rank's stderr went to this process's stderr as it was written)
-        sys.stderr.write("bench.py: rank %d of %d exited with status %d\n" % (r, args.gpus, c))
+    for r, c in bad:
+        if r != first_bad:
+            sys.stderr.write("bench.py: rank %d of %d ended with status %d\n" % (r, args.gpus, c))
     return 1 if bad else 0
 
 
@@ -247,6 +311,8 @@ def measure(cx, args, *, steps, warmup, single_end=False, ont=False, hit_frac=0.
             "traffic": static_traffic(tkey, n_frag, "traffic_bytes_per_launch"),
             "traffic_source": "profiles/traffic.json workloads.%s (static: rocprofv3 --pmc passes of this workload, "
                               "not measured in this run)" % tkey,
+            # true: the record was taken on other kernel sources than this run's (sha256 of nh_kernels.hip + nh_device.h)
+            "traffic_stale": traffic_stale(tkey, n_frag),
             "fabric_request_frac": request_rate_frac(tkey, n_frag, kernel_ms),
             # the same static traffic over THIS run's kernel time, against the 6.29 TB/s the chip reaches on a copy
             "hbm_achievable_frac": hbm_frac(tkey, n_frag, kernel_ms),
@@ -284,8 +350,10 @@ def main():
         raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, cx.world))
     if os.environ.get("NOHUMAN_BENCH_DRYRUN"):
         # CPU check of the launch plumbing (tests/test_dist.py): rendezvous over gloo, one all-reduce
+        if os.environ.get("NOHUMAN_BENCH_FAIL_RANK") == str(cx.rank):  # test hook: this rank dies before the rendezvous
+            raise SystemExit(7)
         if cx.world > 1:
-            dist.init_process_group("gloo")
+            dist.init_process_group("gloo", timeout=RDZV_TIMEOUT)
         one = torch.ones(1, dtype=torch.int64)
         if cx.world > 1:
             dist.all_reduce(one)
@@ -306,12 +374,15 @@ def main():
     torch.cuda.set_device(cx.dev_index)
     cx.dev = torch.device("cuda", cx.dev_index)
     backend = None
+    if os.environ.get("NOHUMAN_BENCH_FAIL_RANK") == str(cx.rank):  # test hook: this rank dies before the rendezvous
+        raise SystemExit(7)
     if cx.world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        # a rank that never arrives is a diagnosis after two minutes, not torch's default half hour
         if cx.one_gpu:
-            dist.init_process_group("gloo")
+            dist.init_process_group("gloo", timeout=RDZV_TIMEOUT)
         else:
-            dist.init_process_group("nccl", device_id=cx.dev)
+            dist.init_process_group("nccl", device_id=cx.dev, timeout=RDZV_TIMEOUT)
         backend = dist.get_backend()
 
     m, live = measure(cx, args, steps=args.steps, warmup=args.warmup, single_end=args.single_end, ont=args.ont,
@@ -383,7 +454,8 @@ def main():
                 "fragments_per_step": vm["fragments_per_step"], "paired": vm["paired"],
                 "classified_fraction": vm["classified_fraction"], "lookups_per_read": vm["lookups_per_read"],
                 "roofline_frac": vm["roofline"]["frac"], "kernel_ms": vm["roofline"]["kernel_ms"],
-                "traffic": vm["roofline"]["traffic"], "hbm_achievable_frac": vm["roofline"]["hbm_achievable_frac"],
+                "traffic": vm["roofline"]["traffic"], "traffic_stale": vm["roofline"]["traffic_stale"],
+                "hbm_achievable_frac": vm["roofline"]["hbm_achievable_frac"],
                 "algorithmic_bytes_per_launch": vm["roofline"]["algorithmic_bytes_per_launch"],
                 "gpu_equals_oracle_on_sample": chk["gpu_equals_oracle"], "oracle_sample_fragments": chk["fragments"],
                 "workload": vm["workload"],
@@ -418,6 +490,27 @@ def _traffic_record(key, n_frag):
     if not w or w.get("workload", {}).get("fragments_per_step") != n_frag:
         return None, t
     return w, t
+
+
+def kernel_source_sha16():
+    """sha256 of the classify kernels' sources, as scripts/make_profile_summary.py records it next to the PMC numbers"""
+    import hashlib
+    h = hashlib.sha256()
+    try:
+        for f in ("nohuman_amd/csrc/nh_kernels.hip", "nohuman_amd/csrc/nh_device.h"):
+            h.update(open(os.path.join(ROOT, f), "rb").read())
+    except OSError:
+        return None
+    return h.hexdigest()[:16]
+
+
+def traffic_stale(key, n_frag):
+    """True when the committed PMC record was taken on OTHER kernel sources than the ones this run was built from
+    (static traffic from a superseded binary), None when there is no record."""
+    w, _ = _traffic_record(key, n_frag)
+    if not w:
+        return None
+    return w.get("kernel_source_sha16") != kernel_source_sha16()
 
 
 def static_traffic(key, n_frag, field):

@@ -3,8 +3,27 @@
 profiles/<tag>_<workload>_summary.txt, profiles/<tag>_<workload>_kernel_stats.csv and the workload's entry of
 profiles/traffic.json (which bench.py reads for `roofline.traffic` of the headline AND of its variants).
     python scripts/make_profile_summary.py gpurun_out/prof_r03_pe r03 pe"""
-import csv, glob, json, os, sys
+import csv, glob, hashlib, json, os, subprocess, sys
 src, rnd = sys.argv[1], sys.argv[2]
+
+
+def source_id():
+    """What the profiled binary was built from: git HEAD where there is a work tree (the GPU box gets a
+    snapshot without .git: scripts/profile.sh passes NOHUMAN_GIT_HEAD when it knows it) and a hash of the kernel sources,
+    which bench.py recomputes to say whether profiles/traffic.json still belongs to the code it runs."""
+    head = os.environ.get("NOHUMAN_GIT_HEAD", "")
+    if not head:
+        try:
+            head = subprocess.run(["git", "rev-parse", "HEAD"], capture_output=True, text=True, timeout=10).stdout.strip()
+        except Exception:
+            head = ""
+    h = hashlib.sha256()
+    for f in ("nohuman_amd/csrc/nh_kernels.hip", "nohuman_amd/csrc/nh_device.h"):
+        h.update(open(f, "rb").read())
+    return head or "unknown (snapshot without .git)", h.hexdigest()[:16]
+
+
+GIT_HEAD, KERNEL_HASH = source_id()
 wl = sys.argv[3] if len(sys.argv) > 3 else "pe"
 # the kernel the workload's fragments are classified in (the other one, launched with it, returns at once)
 KERNEL = 'k_classify<' if wl == "ont" else 'k_classify_short'
@@ -37,6 +56,7 @@ except Exception as e:
 out.append("# profiles/%s_%s_summary.txt -- rocprofv3 summaries of bench.py on 1 x MI355X, workload '%s'" % (rnd, wl, wl))
 out.append("# command: bash scripts/profile.sh %s %s   (trace pass: bench.py with its reported step count + %d warm-up launches;" % (rnd, wl, WARMUP))
 out.append("#          PMC passes: the same with --steps 5 --warmup 2, one rocprofv3 run per counter group)")
+out.append("# source: git HEAD %s, sha256(nh_kernels.hip + nh_device.h)[:16] = %s" % (GIT_HEAD, KERNEL_HASH))
 if bj:
     out.append("# bench.py's own line in the trace pass: value %.1f %s, ms_per_step %.4f, roofline.kernel_ms %.4f, frac %.4f" % (
         bj['value'], bj['unit'], bj['ms_per_step'], bj['roofline']['kernel_ms'], bj['roofline']['frac']))
@@ -113,6 +133,7 @@ if fs is not None and ws is not None and rq is not None and bj:
         "fabric_read_requests_per_launch": int(rq),
         "algorithmic_bytes_per_launch": int(ab),
         "kernel_us_steady_rocprof": (steady / 1e3) if steady else None,
+        "git_head": GIT_HEAD, "kernel_source_sha16": KERNEL_HASH,
     }
 os.makedirs('profiles', exist_ok=True)
 open('profiles/%s_%s_summary.txt' % (rnd, wl), 'w').write("\n".join(out) + "\n")

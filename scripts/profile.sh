@@ -9,6 +9,10 @@ shift
 WORKLOADS=${*:-pe}
 REPO=$(pwd)
 export TMPDIR=/tmp
+# the GPU box runs a snapshot without .git: the caller passes the commit (NOHUMAN_GIT_HEAD=$(git rev-parse HEAD) in the
+# gpurun command line); make_profile_summary.py writes it and a hash of the kernel sources into every summary and into
+# profiles/traffic.json, and bench.py reports "traffic_stale": true when the sources have changed since
+export NOHUMAN_GIT_HEAD=${NOHUMAN_GIT_HEAD:-$(git rev-parse HEAD 2>/dev/null || true)}
 for W in $WORKLOADS; do
   case $W in
     pe)   WARGS="" ; STEPS=20 ;;

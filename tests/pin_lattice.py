@@ -6,11 +6,12 @@ Every kraken2 rule this build could not verify against a binary is a runtime swi
     linear_probing      1 | 0          compact_hash.cc built with -DLINEAR_PROBING or with double hashing
     reset_per_mate      1 | 0          last_minimizer / last_taxon reset for each mate (A.5)
     ambiguity_rule      1 | 0          mmscanner.h is_ambiguous() | the bool* flag of NextMinimizer (A.3 (i)/(ii))
-    minimum_hit_groups  2 | 0 | 1 | 3  default of the kraken2 wrapper's --minimum-hit-groups (A.5)
+    minimum_hit_groups  2 | 1 | 3      default of the kraken2 wrapper's --minimum-hit-groups (A.5); 0 cannot be told
+                                       from 1 by any input (a call needs a hit, a hit is a hit group)
 
 Given the per-read output of the REAL program (`kraken2 --output`, the reference's argv
 /root/reference/src/main.rs:215-267) and the same inputs, `diagnose()` runs the engine over the whole lattice
-(2 x 2 x 2 x 4 = 32 runs of a small input) and names the combination(s) that reproduce kraken2's lines, or the
+(2 x 2 x 2 x 3 = 24 runs of a small input) and names the combination(s) that reproduce kraken2's lines, or the
 closest ones with their first differing read -- so ONE run on any box that has the binary pins every switch.
 
     python -m tests.pin_lattice <db_dir> <kraken2_output.txt> <confidence> <reads_1.fq> [reads_2.fq]
@@ -26,8 +27,36 @@ LATTICE = {
     "linear_probing": (1, 0),
     "reset_per_mate": (1, 0),
     "ambiguity_rule": (1, 0),
-    "minimum_hit_groups": (2, 0, 1, 3),
+    "minimum_hit_groups": (2, 1, 3),
 }
+
+
+def lattice_reads(genomes, n_plain=300, n_crafted=600, seed=5):
+    """Read pairs on which the switches SHOW: reads drawn from the toy genomes (N at 0.4 %: the ambiguity rule; the
+    table's collision runs: the probing rule) plus pairs crafted around the hit-group threshold -- 0..3 short genome
+    pieces in random sequence (1, 2, 3 hit groups), and every other pair has the SAME 35-mer at the end of mate 1 and
+    at the start of mate 2 (one hit group more iff the scanner's last minimizer is reset per mate).  On these,
+    every combination of the lattice gives different kraken lines except the per-mate reset at minimum_hit_groups
+    = 1, which no input can show (tests/test_oracle.py::test_lattice_reads_separate_the_switches).  Run at confidence 0."""
+    import numpy as np
+    from tests import synth
+    rng = np.random.default_rng(seed)
+    reads = synth.sample_reads(rng, genomes, n_plain, paired=True, len_jitter=40, n_rate=0.004)
+    leaf = sorted(genomes)[2] if 111 not in genomes else 111
+    g = genomes[leaf]
+    own = g.rfind(b"N") + 1  # the leaf's own segment (its ancestors' shared segments come first)
+    lo, hi = own + 7, len(g) - 80
+    for i in range(n_crafted):
+        a = synth.random_seq(rng, 30)
+        for _ in range(int(rng.integers(0, 4))):
+            y = int(rng.integers(lo, hi))
+            a += synth.random_seq(rng, int(rng.integers(20, 40))) + g[y:y + int(rng.integers(35, 38))]
+        x = int(rng.integers(lo, hi))
+        share = i % 2 == 0
+        m1 = a + (g[x:x + 35] if share else synth.random_seq(rng, 20))
+        m2 = (g[x:x + 35] if share else b"") + synth.random_seq(rng, 100)
+        reads.append((m1, m2))
+    return reads
 
 
 def combos():
@@ -86,6 +115,7 @@ def diagnose(db_dir, ref_lines, inputs, confidence, workdir=None, out=sys.stdout
         print("NO combination reproduces kraken2; closest: %s (%d lines differ)" % (opts, nbad), file=out)
         if first is not None:
             print("  first differing read %d:\n    kraken2: %s\n    engine : %s" % (first, ref_lines[first], lines[first]), file=out)
+        print("  (reads whose lines differ under EVERY combination point at a rule outside the lattice)", file=out)
         print("  -> a rule outside the lattice differs (formats, hit-list layout, record parsing): see SURVEY.md Appendix A", file=out)
     if own:
         tmp.cleanup()

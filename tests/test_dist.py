@@ -123,7 +123,8 @@ def test_bench_self_launch_dry_run():
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = dict(os.environ, NOHUMAN_BENCH_DRYRUN="1")
+    import tempfile
+    env = dict(os.environ, NOHUMAN_BENCH_DRYRUN="1", NOHUMAN_BENCH_LOGDIR=tempfile.mkdtemp())
     for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
         env.pop(k, None)
     r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2"], env=env,
@@ -133,6 +134,26 @@ def test_bench_self_launch_dry_run():
     assert len(lines) == 1
     rec = json.loads(lines[0])
     assert rec["n_gpus"] == 2 and rec["ranks_counted"] == 2 and rec["world_size_seen"] == 2
+
+
+def test_bench_launcher_names_a_dead_rank_and_returns_within_seconds(tmp_path):
+    """a rank that dies before the rendezvous used to leave rank 0 in init_process_group until torch's
+    timeout.  The launcher polls all ranks, names the first non-zero exit, terminates the others and returns."""
+    import subprocess
+    import sys
+    import time
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, NOHUMAN_BENCH_DRYRUN="1", NOHUMAN_BENCH_FAIL_RANK="1", NOHUMAN_BENCH_LOGDIR=str(tmp_path))
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    t0 = time.time()
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2"], env=env,
+                       capture_output=True, text=True, timeout=300)
+    took = time.time() - t0
+    assert r.returncode != 0
+    assert "rank 1 of 2 exited with status 7" in r.stderr, r.stderr[-1500:]
+    assert took < 90, took  # (the first `import torch` of a fresh box alone can take a minute; the wait itself is < 1 s)
+    assert os.path.exists(tmp_path / "bench_rank0.log") and os.path.exists(tmp_path / "bench_rank1.log")
 
 
 def test_reduce_without_process_group_is_identity():
@@ -151,7 +172,7 @@ def test_bench_two_ranks_on_one_gpu(tmp_path):
     import subprocess
     import sys
     ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = dict(os.environ, NOHUMAN_BENCH_ONE_GPU="1")
+    env = dict(os.environ, NOHUMAN_BENCH_ONE_GPU="1", NOHUMAN_BENCH_LOGDIR=str(tmp_path))
     for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
         env.pop(k, None)
     cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "1", "--pairs", "200000",

@@ -68,6 +68,9 @@ def _inputs(tmp_path, genomes, paired):
         return parts
     rng = np.random.default_rng(99)
     reads = synth.sample_reads(rng, genomes, 3000, paired=paired, len_jitter=40, n_rate=0.003)
+    if paired:  # plus the pairs on which every switch of the lattice shows (tests/pin_lattice.py)
+        from tests import pin_lattice
+        reads += pin_lattice.lattice_reads(genomes)
     if paired:
         p1, p2 = str(tmp_path / "r_1.fq"), str(tmp_path / "r_2.fq")
         write_fastq(p1, [("pin.%d/1" % i, a) for i, (a, b) in enumerate(reads)])
@@ -136,17 +139,23 @@ def test_the_lattice_walker_names_the_combination(tmp_path, toy):
     ob, tb, hb, genomes, _ = toy
     db = tmp_path / "db"
     minidb.write_db(str(db), ob, tb, hb)
-    rng = np.random.default_rng(5)
-    reads = synth.sample_reads(rng, genomes, 1500, paired=True, len_jitter=40, n_rate=0.004)
+    reads = pin_lattice.lattice_reads(genomes)
     p1, p2 = str(tmp_path / "r_1.fq"), str(tmp_path / "r_2.fq")
     write_fastq(p1, [("lat.%d/1" % i, a) for i, (a, b) in enumerate(reads)])
     write_fastq(p2, [("lat.%d/2" % i, b) for i, (a, b) in enumerate(reads)])
-    secret = dict(linear_probing=1, reset_per_mate=0, ambiguity_rule=0, minimum_hit_groups=3)
+    for secret in (dict(linear_probing=1, reset_per_mate=0, ambiguity_rule=0, minimum_hit_groups=3),
+                   dict(linear_probing=0, reset_per_mate=1, ambiguity_rule=1, minimum_hit_groups=2)):
+        with Engine.open(str(db)) as eng:
+            ref = pin_lattice.engine_lines(eng, [p1, p2], "0", secret, str(tmp_path))
+        log = io.StringIO()
+        exact = pin_lattice.diagnose(str(db), ref, [p1, p2], "0", out=log)
+        print(log.getvalue())
+        assert exact == [secret], exact
+        assert "NOT among them" in log.getvalue()
+    # the defaults reproduce themselves, and the walker says so
     with Engine.open(str(db)) as eng:
-        ref = pin_lattice.engine_lines(eng, [p1, p2], "0.05", secret, str(tmp_path))
+        ref = pin_lattice.engine_lines(eng, [p1, p2], "0", dict(linear_probing=1, reset_per_mate=1, ambiguity_rule=1,
+                                                               minimum_hit_groups=2), str(tmp_path))
     log = io.StringIO()
-    exact = pin_lattice.diagnose(str(db), ref, [p1, p2], "0.05", out=log)
-    print(log.getvalue())
-    assert secret in exact and len(exact) <= 2, exact  # (a second entry could only differ in a switch these reads never exercise)
-    assert all(e["reset_per_mate"] == 0 and e["ambiguity_rule"] == 0 and e["minimum_hit_groups"] == 3 for e in exact)
-    assert "NOT among them" in log.getvalue()
+    exact = pin_lattice.diagnose(str(db), ref, [p1, p2], "0", out=log)
+    assert len(exact) == 1 and "pinned as shipped" in log.getvalue()

@@ -111,6 +111,27 @@ def test_isolated_n_costs_k_minus_1_or_l_kmers(toy, toy_oracle):
         toy_oracle.set(ambiguity_rule=1)
 
 
+def test_lattice_reads_separate_the_switches(toy):
+    """The inputs of the self-diagnosing kraken2 pin (tests/pin_lattice.py) tell every combination of the four
+    unverified switches apart -- except the per-mate reset at minimum_hit_groups = 1, which no input can show."""
+    import itertools
+    from tests import pin_lattice
+    ob, tb, hb, genomes, _ = toy
+    odb = orc.OracleDB(ob, tb, hb)
+    reads = pin_lattice.lattice_reads(genomes)
+    bases, offs = orc.pack_reads(reads, True)
+    sig = {}
+    for lp, rs, ar, mh in itertools.product(*(pin_lattice.LATTICE[k] for k in
+                                              ("linear_probing", "reset_per_mate", "ambiguity_rule", "minimum_hit_groups"))):
+        odb.set(linear_probing=lp, reset_per_mate=rs, ambiguity_rule=ar, minimum_hit_groups=mh)
+        out, _, taxa, _ = odb.classify(bases, offs, True, 0.0, want_taxa=True)
+        sig.setdefault((out["call"].tobytes(), taxa.tobytes()), []).append((lp, rs, ar, mh))
+    for group in sig.values():
+        assert len(group) == 1 or (len(group) == 2 and all(c[3] == 1 for c in group)
+                                   and group[0][0] == group[1][0] and group[0][2] == group[1][2]), group
+    assert len(sig) == 20
+
+
 def test_multithreaded_equals_serial(toy, toy_oracle):
     _, _, _, genomes, _ = toy
     rng = np.random.default_rng(3)
