@@ -258,6 +258,14 @@ int nh_compress_file_device(const char *in, const char *out, int codec, uint32_t
  * stats3 (optional) receives {chunks accepted, chunks rejected, bytes decoded in order by the
  * consumer}.  Needs no GPU. */
 int nh_gunzip_file(const char *in, const char *out, uint32_t threads, uint64_t chunk_bytes, uint64_t *stats3);
+/* The gzip READER on the GPU (nohuman_amd/csrc/nh_gunzip.hip; what nh_run reads .gz inputs with: replaces the `gzip -dc`
+ * pipe of kraken2's wrapper): decompress `in` to `out` on `device` -- block search, decode to
+ * 16-bit symbols with markers, the chunks' windows by a prefix scan, marker replacement and the members' CRC-32 on the
+ * device; seg_bytes / stretch_bytes = compressed bytes per piece / per chunk (0 = defaults).  stats8 (optional):
+ * {pieces, chunks, chunks decoded again after a false block start, pieces the host decoder took over, members, text
+ * bytes, gzip bytes, kernel microseconds (NOHUMAN_TRACE only)}.  Test / tool support like nh_gunzip_file. */
+int nh_gunzip_device_file(const char *in, const char *out, int32_t device, uint64_t seg_bytes, uint64_t stretch_bytes,
+                          uint64_t *stats8);
 /* The one collective of the path: `counters` holds n_devices rows of 4 uint64
  * {fragments, classified, bases, table_lookups}, row g being the totals of device_ids[g] (NULL =
  * 0..n_devices-1); on return every row is the sum over the devices -- one ncclAllReduce(4 x uint64, sum)

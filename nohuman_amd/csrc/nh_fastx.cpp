@@ -1,5 +1,6 @@
 // nh_fastx.cpp -- see nh_fastx.h.  Record semantics follow SURVEY.md A.6 (kraken2 seqreader.cc).
 #include "nh_fastx.h"
+#include "nh_gunzip.h"
 #include "nh_inflate.h"
 
 #include <ctype.h>
@@ -10,6 +11,7 @@
 #include <string.h>
 #include <zlib.h>
 
+#include <algorithm>
 #include <condition_variable>
 #include <mutex>
 #include <thread>
@@ -210,9 +212,74 @@ private:
     unsigned streams_ = 0;  // complete streams decoded so far
 };
 
+// gzip decoded on a GPU: DevGunzip (nh_gunzip.hip) leaves a piece of text in device memory, read() fetches it from
+// there into the caller's buffer (the page-locked text buffer of a batch: one copy over PCIe, no inflate on the host)
+class DevGzSource {
+public:
+    ~DevGzSource() {
+        gz_.close();
+        if (device_ >= 0) (void)hipSetDevice(device_);
+        if (d_text_) (void)hipFree(d_text_);
+        if (stream_) (void)hipStreamDestroy(stream_);
+    }
+    int open(const char *path, int device, std::string &err) {
+        device_ = device;
+        if (hipSetDevice(device) != hipSuccess) {
+            err = "hipSetDevice failed";
+            return -1;
+        }
+        if (gz_.open(path, device, 0, 0, err) != 0) return -1;
+        // text of a piece: 64 MiB of gzip at up to 8 : 1 (a piece that would not fit is cut down by the reader)
+        room_ = (size_t)512u << 20;
+        if (const char *e = getenv("NOHUMAN_GZDEV_ROOM")) room_ = std::max<size_t>((size_t)atol(e), (size_t)1u << 20);
+        if (hipMalloc((void **)&d_text_, room_ + 64) != hipSuccess || hipStreamCreateWithFlags(&stream_, hipStreamNonBlocking) != hipSuccess) {
+            (void)hipGetLastError();
+            err = "the gzip reader's text buffer cannot be had";
+            return -1;
+        }
+        return 0;
+    }
+    long read(uint8_t *buf, size_t cap, std::string &err) {
+        if (hipSetDevice(device_) != hipSuccess) {
+            err = "hipSetDevice failed";
+            return -1;
+        }
+        size_t got = 0;
+        while (got < cap) {
+            if (off_ == len_) {
+                if (gz_.ended()) break;
+                const long n = gz_.next(d_text_, room_, stream_);
+                if (n < 0) {
+                    err = gz_.error();
+                    return -1;
+                }
+                off_ = 0;
+                len_ = (size_t)n;
+                if (n == 0) break;
+            }
+            const size_t k = std::min(cap - got, len_ - off_);
+            if (hipMemcpyAsync(buf + got, d_text_ + off_, k, hipMemcpyDeviceToHost, stream_) != hipSuccess ||
+                hipStreamSynchronize(stream_) != hipSuccess) {
+                err = "gzip reader: fetching the text from the device failed";
+                return -1;
+            }
+            off_ += k;
+            got += k;
+        }
+        return (long)got;
+    }
+
+private:
+    DevGunzip gz_;
+    int device_ = -1;
+    uint8_t *d_text_ = nullptr;
+    size_t room_ = 0, off_ = 0, len_ = 0;
+    hipStream_t stream_ = nullptr;
+};
+
 ByteSource::~ByteSource() { close(); }
 
-int ByteSource::open(const char *path, std::string &err, unsigned gz_threads) {
+int ByteSource::open(const char *path, std::string &err, unsigned gz_threads, int device) {
     close();
     FILE *f = fopen(path, "rb");
     if (!f) {
@@ -240,6 +307,22 @@ int ByteSource::open(const char *path, std::string &err, unsigned gz_threads) {
         (void)posix_fadvise(fd_, 0, 0, POSIX_FADV_SEQUENTIAL);
         return 0;
     }
+    {   // the reader on the GPU (default wherever a device is at hand; NOHUMAN_GZ_READER=host keeps the host decoders)
+        const char *how = getenv("NOHUMAN_GZ_READER");
+        if (device >= 0 && !(how && !strcmp(how, "host")) && dev_gunzip_wants(path)) {
+            dgz_ = new DevGzSource();
+            std::string derr;
+            if (dgz_->open(path, device, derr) == 0) return 0;
+            delete dgz_;
+            dgz_ = nullptr;
+            if (how && !strcmp(how, "device")) {  // asked for by name: no silent change of reader
+                err = derr;
+                return -1;
+            }
+            fprintf(stderr, "nohuman: WARN %s: the gzip reader on GPU %d could not be set up (%s); inflating on the host\n", path, device,
+                    derr.c_str());
+        }
+    }
     if (const char *env = getenv("NOHUMAN_GZ_THREADS")) gz_threads = (unsigned)atoi(env);  // 0 = zlib
     if (gz_threads > 0) {
         size_t chunk = 0;
@@ -261,6 +344,7 @@ int ByteSource::open(const char *path, std::string &err, unsigned gz_threads) {
 }
 
 long ByteSource::read(uint8_t *buf, size_t cap) {
+    if (dgz_) return dgz_->read(buf, cap, pgz_error_);
     if (pgz_) {
         long n = pgz_->read(buf, cap);
         if (n < 0) pgz_error_ = pgz_->error();
@@ -299,6 +383,8 @@ void ByteSource::close() {
     if (fd_ >= 0) ::close(fd_);
     delete pgz_;
     pgz_ = nullptr;
+    delete dgz_;
+    dgz_ = nullptr;
     fd_ = -1;
     gz_ = nullptr;
 }
@@ -401,7 +487,7 @@ int FastxReader::next(SeqRecord &rec, std::string &err) {
 }
 
 // ------------------------------------------------------------------------------------------------
-int BlockReader::open(const char *path, std::string &err, unsigned gz_threads) {
+int BlockReader::open(const char *path, std::string &err, unsigned gz_threads, int device) {
     tail_.clear();
     eof_ = false;
     format_ = FMT_AUTO;
@@ -411,7 +497,7 @@ int BlockReader::open(const char *path, std::string &err, unsigned gz_threads) {
         const long v = atol(env);
         if (v > 0) chunk_ = (size_t)v;
     }
-    return src_.open(path, err, gz_threads);
+    return src_.open(path, err, gz_threads, device);
 }
 
 static inline const char *rstrip(const char *b, const char *e) {

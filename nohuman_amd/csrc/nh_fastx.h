@@ -26,13 +26,15 @@ struct SeqRecord {
 // such inputs through `bzip2 -dc`).
 class ParallelGunzip;
 class Bz2Source;
+class DevGzSource;  // gzip decoded on a GPU (nh_gunzip.h), the text fetched from there
 
 class ByteSource {
 public:
     ~ByteSource();
     // gz_threads > 0: gzip files are decoded by the in-process multi-threaded decoder
-    // (nh_inflate.h) on that many workers; 0: zlib on the calling thread
-    int open(const char *path, std::string &err, unsigned gz_threads = 0);
+    // (nh_inflate.h) on that many workers; 0: zlib on the calling thread.
+    // device >= 0: gzip files are decoded on that GPU (nh_gunzip.h) unless NOHUMAN_GZ_READER=host
+    int open(const char *path, std::string &err, unsigned gz_threads = 0, int device = -1);
     // fills up to cap bytes; returns bytes read, 0 at EOF, -1 on error
     long read(uint8_t *buf, size_t cap);
     void close();
@@ -43,6 +45,7 @@ private:
     Bz2Source *bz_ = nullptr;  // bzip2 (libbz2 by dlopen)
     int fd_ = -1;          // plain text
     ParallelGunzip *pgz_ = nullptr;
+    DevGzSource *dgz_ = nullptr;
     std::string pgz_error_;
 };
 
@@ -164,7 +167,7 @@ public:
     BlockReader(const BlockReader &) = delete;
     BlockReader &operator=(const BlockReader &) = delete;
     ~BlockReader();
-    int open(const char *path, std::string &err, unsigned gz_threads = 0);
+    int open(const char *path, std::string &err, unsigned gz_threads = 0, int device = -1);
     // parses up to max_recs records (or about max_text bytes) into hb (which is reset first);
     // sets hb.eof at end of input.  Text offsets are 32-bit: max_text is clamped below 2^32.
     void next_batch(HalfBatch &hb, size_t max_recs, size_t max_text);

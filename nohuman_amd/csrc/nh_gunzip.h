@@ -1,0 +1,67 @@
+// nh_gunzip.h -- the gzip READER on the GPU (the reference hands .gz inputs straight to the
+// path, /root/reference/src/main.rs:267, where kraken2's wrapper pipes them through `gzip -dc`).
+//
+// The compressed bytes go to the device as they are read; there
+//   k_search    finds, per stretch of the file, the first bit position that parses as a non-final dynamic-Huffman block
+//               header (the seam test of nh_inflate.cpp plus a trial walk of the block's first tokens),
+//   k_inflate   decodes from every start found to the next one, a wavefront per chunk, to 16-bit symbols -- what a match
+//               copies out of the unknown 32 KiB before the chunk is a marker 0x8000 | index --, walking over member
+//               trailers and headers,
+//   k_maps / k_scan_round / k_windows   give every chunk its window by a prefix scan over the chunks' index maps,
+//   k_resolve   turns the symbols into the text, at its place in the caller's device buffer,
+//   k_crc       computes the CRC-32 of every chunk's pieces (the host joins them per member and checks CRC and ISIZE
+//               like gzip does).
+// A false positive of the search (the chunk before does not end where the next one starts) is re-decoded from the true
+// end; what the device cannot decode (a block longer than the look-ahead, text beyond 16 : 1 per chunk, more than four
+// members ending in one chunk, damage) is decoded by the host decoder (nh_inflate.cpp: inflate_from) from the same bit
+// position and window -- loudly: one line on stderr per file and a count in the statistics; damaged data fails there
+// with the host reader's messages.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+#include <stdint.h>
+
+#include <string>
+#include <vector>
+
+namespace nh {
+
+struct DevGunzipStats {
+    uint64_t segments = 0, chunks = 0, redecoded = 0;  // segments decoded, chunks in them, chunks decoded again (broken seam)
+    uint64_t fallback_segments = 0;                    // segments the host decoder took over
+    uint64_t members = 0;
+    uint64_t text_bytes = 0, gzip_bytes = 0;
+    double ms_search = 0, ms_decode = 0, ms_scan = 0, ms_resolve = 0, ms_crc = 0;  // HIP events, NOHUMAN_TRACE / stats only
+    double s_host_copy = 0, s_wait = 0;
+};
+
+class DevGunzipImpl;
+
+// One gzip file (one or many members) decoded on a GPU, piece by piece, into device memory.
+class DevGunzip {
+public:
+    DevGunzip();
+    ~DevGunzip();
+    DevGunzip(const DevGunzip &) = delete;
+    DevGunzip &operator=(const DevGunzip &) = delete;
+    // seg_bytes / stretch_bytes: compressed bytes per piece / per chunk (0 = defaults; test knobs NOHUMAN_GZDEV_SEG,
+    // NOHUMAN_GZDEV_STRETCH).  -1 with err set when the file is no regular gzip file or the buffers cannot be had.
+    int open(const char *path, int device, size_t seg_bytes, size_t stretch_bytes, std::string &err);
+    // Decodes the next piece of the stream to d_dst (device memory, `room` bytes, 16-byte aligned) on `stream` and
+    // waits for it: the number of text bytes (0: the stream has ended), or -1 with error() set.  A piece that would
+    // not fit `room` is cut down; `room` must hold at least 64 MiB.
+    long next(void *d_dst, size_t room, hipStream_t stream);
+    bool ended() const;
+    const std::string &error() const;
+    const DevGunzipStats &stats() const;
+    void close();
+
+private:
+    DevGunzipImpl *impl_;
+};
+
+// Is the file one the device reader takes (a regular gzip file; not BGZF, whose members hold a single final block each
+// and give the block search nothing to find -- the host reader takes those)?
+bool dev_gunzip_wants(const char *path);
+
+}  // namespace nh

@@ -1,0 +1,1408 @@
+// nh_gunzip.hip -- the gzip reader on the GPU: block search, decode, window scan, marker resolve, CRC-32 (nh_gunzip.h).
+//
+// Replaces, for the inputs nohuman passes verbatim to the path (/root/reference/src/main.rs:267), the `gzip -dc` pipe of
+// kraken2's wrapper.  DEFLATE / gzip as RFC 1951 / 1952 define them; the parallel scheme
+// (speculative chunk starts, 16-bit symbols with markers for the unknown window) is the one of pugz / rapidgzip and of
+// this repository's host reader (nh_inflate.cpp); the window chain as a prefix scan over index maps is this file's own.
+// gfx950 only: one wavefront decodes a chunk (all decode state is wave-uniform, a match is copied by the 64 lanes).
+#include "nh_gunzip.h"
+
+#include <errno.h>
+#include <fcntl.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
+
+#include <algorithm>
+#include <chrono>
+
+#include "nh_inflate.h"
+#include "nh_internal.h"
+#include "nohuman_engine.h"
+
+namespace nh {
+namespace gz {
+
+constexpr uint32_t WSIZE = 32768;
+#ifndef NH_GZ_NEAR
+#define NH_GZ_NEAR 8192  // symbols of the window kept in LDS (a power of two <= 32768); older sources come back from the output in HBM
+#endif
+constexpr uint32_t NEARSZ = NH_GZ_NEAR;
+constexpr int ROOT = 10, DROOT = 8;
+constexpr uint32_t MAX_MEMBERS = 4;  // member ends one chunk can record
+constexpr uint64_t NONE = ~0ull;
+constexpr uint32_t NOIDX = 0xFFFFFFFFu;
+
+// status of a chunk
+enum : uint32_t {
+    ST_OK = 0,
+    ST_STORED = 2,    // stored block: LEN / NLEN do not match
+    ST_BTYPE = 3,     // block type 3
+    ST_HEADER = 4,    // invalid code lengths set
+    ST_ROOM = 5,      // more text than the chunk's slots hold (beyond 16 : 1)
+    ST_LITLEN = 6,    // invalid literal / length code
+    ST_INPUT = 7,     // ran past the bytes on the device (a block longer than the look-ahead, or a truncated file)
+    ST_DIST = 8,      // invalid distance code
+    ST_MEMBERS = 9,   // more member ends in one chunk than it can record
+    ST_FAR = 10,      // distance beyond the window
+    ST_GZHEAD = 11,   // a member header runs past the bytes on the device
+};
+
+struct ChunkDesc {  // one per stretch of the piece
+    // plan (k_plan)
+    uint64_t bit_start;  // NONE: no chunk starts in this stretch
+    uint64_t stop_bit;   // decode to the first block boundary at or behind it
+    uint32_t cap;        // symbols of room (the chunk's own slot and those of the empty stretches behind it)
+    uint32_t pad0;
+    // results (k_inflate)
+    uint64_t bit_end;
+    uint32_t out_len;    // symbols written
+    uint32_t status;
+    uint32_t n_members;  // member ends inside the chunk
+    uint32_t flags;      // 1: the stream ended in this chunk
+    uint32_t blocks, pad1;
+    uint32_t m_off[MAX_MEMBERS], m_crc[MAX_MEMBERS], m_isize[MAX_MEMBERS];
+    uint32_t piece_crc[MAX_MEMBERS + 1];  // k_crc: CRC-32 of the text between the chunk's start, its member ends, its end
+    uint32_t pad2;
+};
+
+struct SegResult {  // k_finish
+    uint64_t total;      // text bytes of the piece
+    uint64_t end_bit;    // where the stream goes on
+    uint32_t n_chunks;   // chunks that count (up to the one the stream ended in)
+    uint32_t end_chunk;  // index of the last of them
+    uint32_t broken;     // NOIDX, or the first chunk that does not start where its predecessor ended
+    uint32_t bad_chunk;  // NOIDX, or the first chunk with an error status
+    uint32_t bad_status;
+    uint32_t stream_end;
+    uint32_t members, pad;
+};
+
+struct Lds {
+    uint16_t window[NEARSZ];
+    // root tables: 0 = code longer than the root; else code length (4 bits) | extra bits (4) | base or literal (16) |
+    // kind << 28 (0 literal, 1 length, 2 end of block; distances: always 1)
+    uint32_t lit[1 << ROOT];
+    uint32_t dist[1 << DROOT];
+    uint32_t clt[128];
+    uint16_t lbase[32], dbase[32];
+    uint8_t lext[32], dext[32];
+    uint16_t lsym[288], dsym[32];
+    uint16_t lcount[16], dcount[16];
+    uint16_t code[320];
+    uint8_t lens[320];
+    uint16_t tmp[40];
+};
+
+__constant__ uint16_t LBASE[29] = {3, 4, 5, 6, 7, 8, 9, 10, 11, 13, 15, 17, 19, 23, 27, 31, 35, 43, 51, 59, 67, 83, 99, 115, 131, 163, 195, 227, 258};
+__constant__ uint8_t LEXT[29] = {0, 0, 0, 0, 0, 0, 0, 0, 1, 1, 1, 1, 2, 2, 2, 2, 3, 3, 3, 3, 4, 4, 4, 4, 5, 5, 5, 5, 0};
+__constant__ uint16_t DBASE[30] = {1, 2, 3, 4, 5, 7, 9, 13, 17, 25, 33, 49, 65, 97, 129, 193, 257, 385, 513, 769, 1025, 1537, 2049, 3073, 4097, 6145, 8193, 12289, 16385, 24577};
+__constant__ uint8_t DEXT[30] = {0, 0, 0, 0, 1, 1, 2, 2, 3, 3, 4, 4, 5, 5, 6, 6, 7, 7, 8, 8, 9, 9, 10, 10, 11, 11, 12, 12, 13, 13};
+__constant__ uint8_t CLORDER[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15};
+
+// one wave per workgroup: LDS operations of a wave execute in order, so lanes see each other's LDS writes without a
+// barrier; what is needed is that the compiler keeps the order (and __syncthreads() would also wait for the global
+// stores of the copy before it)
+#define LDS_ORDER() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
+
+__device__ __forceinline__ uint32_t uni(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
+__device__ __forceinline__ uint32_t rl(uint32_t v, uint32_t lane) {
+    return (uint32_t)__builtin_amdgcn_readlane((int)v, (int)__builtin_amdgcn_readfirstlane((int)lane));
+}
+__device__ __forceinline__ uint32_t wsum(uint32_t v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += (uint32_t)__shfl_xor((int)v, o);
+    return v;
+}
+__device__ __forceinline__ uint64_t bits_at(const uint8_t *bytes, uint64_t b) {  // >= 57 valid bits at bit position b
+    struct __attribute__((packed)) U {
+        uint64_t v;
+    };
+    return ((const U *)(bytes + (b >> 3)))->v >> (b & 7);
+}
+
+struct BitIn {  // wave-uniform reader over dwords held in the lanes
+    const uint32_t *in;   // dwords of the piece's buffer
+    uint32_t wbase;       // dword index of winA's lane 0
+    uint32_t winA, winB;  // this lane's dwords: wbase + lane, wbase + 64 + lane
+    __device__ __forceinline__ void init(const uint32_t *p, uint64_t bitpos, int lane) {
+        in = p;
+        wbase = (uint32_t)(bitpos >> 5) & ~63u;
+        winA = in[wbase + lane];
+        winB = in[wbase + 64 + lane];
+        __builtin_amdgcn_s_waitcnt(0x0F70);
+    }
+    __device__ __forceinline__ uint32_t dw(uint32_t d) const { return d < 64u ? rl(winA, d) : rl(winB, d - 64u); }
+    // 64 bits of the stream at bit position bitpos (positions move forward only)
+    __device__ __forceinline__ uint64_t fetch(uint64_t bitpos, int lane) {
+        uint32_t d = (uint32_t)(bitpos >> 5) - wbase;
+        if (d >= 64u) {  // the first register is used up: the second takes its place and is loaded again
+            if (d >= 128u) {  // (a jump: stored blocks, member headers re-initialise; this is the safety net)
+                init(in, bitpos, lane);
+                d = (uint32_t)(bitpos >> 5) - wbase;
+            } else {
+                winA = winB;
+                wbase += 64u;
+                winB = in[wbase + 64 + lane];
+                // waited for HERE, once per 256 bytes of input: left to the compiler, every later use of the registers
+                // waits for vmcnt(0) -- that is, for all the global stores of the copies in between
+                __builtin_amdgcn_s_waitcnt(0x0F70);
+                d -= 64u;
+            }
+        }
+        const uint32_t lo = dw(d), mid = dw(d + 1), hi = dw(d + 2);
+        const uint32_t sh = (uint32_t)bitpos & 31u;
+        const uint64_t lm = ((uint64_t)mid << 32) | lo;
+        return sh ? (lm >> sh) | ((uint64_t)hi << (64u - sh)) : lm;
+    }
+};
+
+__device__ __forceinline__ uint32_t entry_of(const Lds &S, int mode, uint32_t s, uint32_t l) {
+    if (mode == 0) return l | (s << 8);
+    if (mode == 2) return l | ((uint32_t)S.dext[s] << 4) | ((uint32_t)S.dbase[s] << 8) | (1u << 28);
+    if (s < 256u) return l | (s << 8);
+    if (s == 256u) return l | (2u << 28);
+    return l | ((uint32_t)S.lext[s - 257u] << 4) | ((uint32_t)S.lbase[s - 257u] << 8) | (1u << 28);
+}
+// counts, canonical symbol list, codes and root table of one alphabet (lens[0..n) in LDS); mode 0: the code-length
+// code, 1: literals / lengths, 2: distances.  False: the lengths are over-subscribed (no prefix code).
+__device__ bool build(Lds &S, const uint8_t *lens, int n, uint16_t *count, uint16_t *symlist, uint32_t *root, int rootbits, int mode,
+                      int lane) {
+    LDS_ORDER();
+    uint32_t over = 0;
+    if (lane == 0) {
+        uint16_t *offs = S.tmp, *next = S.tmp + 16;
+        for (int l = 0; l < 16; l++) count[l] = 0;
+        for (int s = 0; s < n; s++) count[lens[s]]++;
+        count[0] = 0;
+        uint32_t o = 0, c = 0;
+        int left = 1;
+        for (int l = 1; l < 16; l++) {
+            left = (left << 1) - (int)count[l];
+            if (left < 0) over = 1;
+            offs[l] = (uint16_t)o;
+            o += count[l];
+            c = (c + count[l - 1]) << 1;
+            next[l] = (uint16_t)c;
+        }
+        if (!over)
+            for (int s = 0; s < n; s++) {
+                const int l = lens[s];
+                if (l) {
+                    symlist[offs[l]++] = (uint16_t)s;
+                    S.code[s] = next[l]++;
+                }
+            }
+    }
+    if (uni(over)) return false;
+    for (int k = lane; k < (1 << rootbits); k += 64) root[k] = 0;
+    LDS_ORDER();
+    for (int s = lane; s < n; s += 64) {
+        const int l = lens[s];
+        if (l && l <= rootbits) {
+            const uint32_t r = __builtin_bitreverse32((uint32_t)S.code[s]) >> (32 - l);
+            const uint32_t e = entry_of(S, mode, (uint32_t)s, (uint32_t)l);
+            for (uint32_t k = r; k < (1u << rootbits); k += 1u << l) root[k] = e;
+        }
+    }
+    LDS_ORDER();
+    return true;
+}
+
+// a symbol whose code is longer than the root table: canonical walk, one bit at a time
+__device__ __forceinline__ uint32_t slow_symbol(uint64_t w, const uint16_t *count, const uint16_t *symlist, uint32_t &len_out) {
+    uint32_t code = 0, first = 0, index = 0;
+    for (uint32_t l = 1; l <= 15; l++) {
+        code |= (uint32_t)(w >> (l - 1)) & 1u;
+        const uint32_t c = count[l];
+        if (code < first + c) {
+            len_out = l;
+            return symlist[index + (code - first)];
+        }
+        index += c;
+        first += c;
+        first <<= 1;
+        code <<= 1;
+    }
+    len_out = 0;
+    return 0xFFFFu;
+}
+
+// the header of a dynamic block behind its three type bits: the code lengths of both alphabets into S.lens[0 .. nlit + ndist)
+__device__ uint32_t parse_dynamic(Lds &S, BitIn &bi, uint64_t &bitpos, int lane, int &nlit, int &ndist) {
+    uint64_t w = bi.fetch(bitpos, lane);
+    nlit = (int)(w & 31) + 257;
+    ndist = (int)((w >> 5) & 31) + 1;
+    const int ncl = (int)((w >> 10) & 15) + 4;
+    if (nlit > 286 || ndist > 30) return ST_HEADER;
+    bitpos += 14;
+    LDS_ORDER();
+    if (lane < 19) S.lens[lane] = 0;
+    LDS_ORDER();
+    for (int i = 0; i < ncl; i++) {  // (uniform; 3 bits each)
+        if ((i & 15) == 0) w = bi.fetch(bitpos, lane);
+        if (lane == 0) S.lens[CLORDER[i]] = (uint8_t)(w & 7);
+        w >>= 3;
+        bitpos += 3;
+    }
+    // the code-length code: all codes fit the 7-bit root
+    if (!build(S, S.lens, 19, S.lcount, S.lsym, S.clt, 7, 0, lane)) return ST_HEADER;
+    int i = 0;
+    uint32_t prev = 0;
+    while (i < nlit + ndist) {
+        w = bi.fetch(bitpos, lane);
+        const uint32_t e = uni(S.clt[w & 127]);
+        const uint32_t l = e & 15u, sym = e >> 8;
+        if (l == 0) return ST_HEADER;
+        bitpos += l;
+        w >>= l;
+        uint32_t rep = 1, val = sym;
+        if (sym == 16) {
+            if (i == 0) return ST_HEADER;
+            rep = 3 + ((uint32_t)w & 3);
+            bitpos += 2;
+            val = prev;
+        } else if (sym == 17) {
+            rep = 3 + ((uint32_t)w & 7);
+            bitpos += 3;
+            val = 0;
+        } else if (sym == 18) {
+            rep = 11 + ((uint32_t)w & 127);
+            bitpos += 7;
+            val = 0;
+        }
+        if (i + (int)rep > nlit + ndist) return ST_HEADER;
+        for (uint32_t k = (uint32_t)lane; k < rep; k += 64) S.code[i + k] = (uint16_t)val;
+        i += (int)rep;
+        prev = val;
+    }
+    LDS_ORDER();
+    for (int s = lane; s < nlit + ndist; s += 64) S.lens[s] = (uint8_t)S.code[s];
+    LDS_ORDER();
+    if (S.lens[256] == 0) return ST_HEADER;  // no end-of-block code
+    return 0;
+}
+
+__device__ __forceinline__ void load_bases(Lds &S, int lane) {
+    if (lane < 29) {
+        S.lbase[lane] = LBASE[lane];
+        S.lext[lane] = LEXT[lane];
+    }
+    if (lane < 30) {
+        S.dbase[lane] = DBASE[lane];
+        S.dext[lane] = DEXT[lane];
+    }
+    LDS_ORDER();
+}
+
+// Does a non-final dynamic block header start at bit `cand`?  The seam test of the host reader: the code lengths must
+// decode, both codes must be complete (the distance code may have a single symbol), end-of-block must have a code --
+// and the first tokens of the block must walk (a header that passes by chance decodes into nonsense soon).
+__device__ bool plausible_block(Lds &S, const uint32_t *in, uint64_t cand, uint64_t valid_bits, int lane) {
+    BitIn bi;
+    bi.init(in, cand, lane);
+    uint64_t bp = cand + 3;
+    int nlit, ndist;
+    if (parse_dynamic(S, bi, bp, lane, nlit, ndist)) return false;
+    uint32_t sl = 0, sd = 0, cd = 0;
+    for (int k = lane; k < nlit; k += 64) sl += S.lens[k] ? 32768u >> S.lens[k] : 0u;
+    for (int k = lane; k < ndist; k += 64) {
+        const uint32_t l = S.lens[nlit + k];
+        sd += l ? 32768u >> l : 0u;
+        cd += l != 0;
+    }
+    sl = wsum(sl);
+    sd = wsum(sd);
+    cd = wsum(cd);
+    if (!(sl == 32768u && (sd == 32768u || cd <= 1u))) return false;
+    if (!build(S, S.lens, nlit, S.lcount, S.lsym, S.lit, ROOT, 1, lane)) return false;
+    if (!build(S, S.lens + nlit, ndist, S.dcount, S.dsym, S.dist, DROOT, 2, lane)) return false;
+    uint32_t produced = 0;
+    for (int tok = 0; tok < 256; tok++) {
+        if (bp + 64 > valid_bits) return true;  // (the look-ahead ends here: what was walked was fine)
+        uint64_t w = bi.fetch(bp, lane);
+        uint32_t e = uni(S.lit[w & ((1u << ROOT) - 1u)]);
+        if (e == 0) {
+            uint32_t l;
+            const uint32_t sym = slow_symbol(w, S.lcount, S.lsym, l);
+            if (l == 0 || sym >= 286u) return false;
+            e = entry_of(S, 1, sym, l);
+        }
+        const uint32_t l = e & 15u;
+        bp += l;
+        w >>= l;
+        const uint32_t kind = e >> 28;
+        if (kind == 2) break;
+        if (kind == 0) {
+            produced++;
+            continue;
+        }
+        const uint32_t lext = (e >> 4) & 15u;
+        const uint32_t len = ((e >> 8) & 0xFFFFu) + ((uint32_t)w & ((1u << lext) - 1u));
+        bp += lext;
+        w >>= lext;
+        uint32_t de = uni(S.dist[w & ((1u << DROOT) - 1u)]);
+        if (de == 0) {
+            uint32_t dl;
+            const uint32_t dsymv = slow_symbol(w, S.dcount, S.dsym, dl);
+            if (dl == 0 || dsymv >= 30u) return false;
+            de = entry_of(S, 2, dsymv, dl);
+        }
+        const uint32_t dext = (de >> 4) & 15u;
+        const uint32_t dist = ((de >> 8) & 0xFFFFu) + ((uint32_t)(w >> (de & 15u)) & ((1u << dext) - 1u));
+        if (dist > produced + WSIZE) return false;
+        bp += (de & 15u) + dext;
+        produced += len;
+    }
+    return true;
+}
+
+// start[c] = the first bit position in stretch c of the piece that passes the seam test (NONE: none); stretch 0 starts
+// at the position the stream is known to go on at
+__global__ __launch_bounds__(64) void k_search(const uint32_t *in, uint64_t valid_bits, uint64_t stretch_bits, uint64_t first_bit,
+                                               uint64_t *start) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    Lds &S = *(Lds *)smem;
+    const int lane = (int)threadIdx.x;
+    const uint32_t c = blockIdx.x;
+    if (c == 0) {
+        if (lane == 0) start[0] = first_bit;
+        return;
+    }
+    load_bases(S, lane);  // (the trial walk reads the base / extra-bit tables through entry_of)
+    uint64_t from = (uint64_t)c * stretch_bits, to = from + stretch_bits;
+    if (from <= first_bit) from = first_bit + 1;
+    if (to + 160 > valid_bits) to = valid_bits > 160 ? valid_bits - 160 : 0;
+    const uint8_t *bytes = (const uint8_t *)in;
+    uint64_t found = NONE;
+    for (uint64_t b0 = from; b0 < to && found == NONE; b0 += 64) {
+        const uint64_t b = b0 + (uint64_t)lane;
+        const uint64_t w = bits_at(bytes, b), w2 = bits_at(bytes + 7, b);  // w2: bits 56.. of the window
+        bool pre = b < to && (w & 7) == 4 && ((w >> 3) & 31) <= 29 && ((w >> 8) & 31) <= 29;
+        const int ncl = (int)((w >> 13) & 15) + 4;
+        int left = 128, any = 0;
+        for (int i = 0; i < 19; i++) {
+            const unsigned at = 17 + 3 * (unsigned)i;
+            const unsigned l = i < ncl ? (at + 3 <= 56 ? (unsigned)(w >> at) & 7 : (unsigned)(w2 >> (at - 56)) & 7) : 0u;
+            if (l) {
+                left -= 128 >> l;
+                any = 1;
+            }
+        }
+        pre = pre && any && left == 0;
+        uint64_t m = __ballot(pre);
+        while (m && found == NONE) {
+            const uint64_t cand = b0 + (uint64_t)__builtin_ctzll(m);
+            if (plausible_block(S, in, cand, valid_bits, lane)) found = cand;
+            m &= m - 1;
+        }
+    }
+    if (lane == 0) start[c] = found;
+}
+
+// plan of the piece: chunk c runs from its start to the next start found (the last one to the first block boundary at or
+// behind the end of the piece's stretches) and owns the symbol slots up to the next chunk's
+__global__ __launch_bounds__(1024) void k_plan(const uint64_t *start, uint32_t n, uint64_t end_bit, uint32_t slot_syms, ChunkDesc *desc) {
+    for (uint32_t c = threadIdx.x; c < n; c += 1024) {
+        ChunkDesc &d = desc[c];
+        const uint64_t s = start[c];
+        d.bit_start = s;
+        if (s == NONE) {
+            d.stop_bit = 0;
+            d.cap = 0;
+            continue;
+        }
+        uint32_t nx = c + 1;
+        while (nx < n && start[nx] == NONE) nx++;
+        d.stop_bit = nx < n ? start[nx] : end_bit;
+        const uint64_t cap = (uint64_t)(nx - c) * slot_syms;
+        d.cap = cap > 0xFFFFF000ull ? 0xFFFFF000u : (uint32_t)cap;
+    }
+}
+
+// Decodes chunk c (block index, or `only`) from its start to the first block boundary at or behind its stop position.
+__global__ __launch_bounds__(64) void k_inflate(const uint32_t *in, uint64_t valid_bits, uint32_t at_eof, ChunkDesc *desc, uint16_t *sym,
+                                                uint32_t slot_syms, uint32_t only) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    Lds &S = *(Lds *)smem;
+    const int lane = (int)threadIdx.x;
+    const uint32_t c = only != NOIDX ? only : blockIdx.x;
+    ChunkDesc &cd = desc[c];
+    if (cd.bit_start == NONE) {
+        if (lane == 0) {
+            cd.bit_end = 0;
+            cd.out_len = 0;
+            cd.status = 0;
+            cd.n_members = 0;
+            cd.flags = 0;
+            cd.blocks = 0;
+        }
+        return;
+    }
+    // the unknown 32 KiB before the chunk as markers: the newest NEARSZ of them in the LDS ring (position q of the
+    // stream, counted from 32768 before the chunk, lives at q & (NEARSZ - 1))
+    for (uint32_t i = (uint32_t)lane; i < NEARSZ; i += 64) S.window[(WSIZE - NEARSZ + i) & (NEARSZ - 1)] = (uint16_t)(0x8000u | (WSIZE - NEARSZ + i));
+    load_bases(S, lane);
+    uint64_t bitpos = cd.bit_start;
+    const uint64_t stop_bit = cd.stop_bit;
+    uint16_t *o = sym + (uint64_t)c * slot_syms;
+    uint32_t op = 0;  // symbols written
+    const uint32_t cap = cd.cap;
+    const uint8_t *bytes = (const uint8_t *)in;
+    BitIn bi;
+    bi.init(in, bitpos, lane);
+    uint32_t status = 0, blocks = 0, n_members = 0, flags = 0;
+    uint32_t floor_op = 0;       // sources may not reach before this output position ...
+    bool fresh_member = false;   // ... once a member has started inside the chunk (before: the unknown window)
+    while (status == 0) {
+        if (bitpos >= stop_bit) break;  // a block boundary at or behind the stop position
+        if (bitpos + 3 > valid_bits) {
+            status = ST_INPUT;
+            break;
+        }
+        uint64_t w = bi.fetch(bitpos, lane);
+        const uint32_t bfinal = (uint32_t)w & 1u, btype = (uint32_t)(w >> 1) & 3u;
+        bitpos += 3;
+        blocks++;
+        if (btype == 0) {  // stored
+            bitpos = (bitpos + 7) & ~7ull;
+            if (bitpos + 32 > valid_bits) {
+                status = ST_INPUT;
+                break;
+            }
+            w = bi.fetch(bitpos, lane);
+            const uint32_t len = (uint32_t)w & 0xFFFFu, nlen = (uint32_t)(w >> 16) & 0xFFFFu;
+            if ((len ^ nlen) != 0xFFFFu) {
+                status = ST_STORED;
+                break;
+            }
+            bitpos += 32;
+            if (bitpos + 8ull * len > valid_bits) {
+                status = ST_INPUT;
+                break;
+            }
+            if ((uint64_t)op + len > cap) {
+                status = ST_ROOM;
+                break;
+            }
+            const uint8_t *src = bytes + (bitpos >> 3);
+            asm volatile("" ::: "memory");
+            for (uint32_t i = (uint32_t)lane; i < len; i += 64) {
+                const uint16_t v = src[i];
+                S.window[(op + WSIZE + i) & (NEARSZ - 1)] = v;
+                o[op + i] = v;
+            }
+            LDS_ORDER();
+            op += len;
+            bitpos += 8ull * len;
+            bi.init(in, bitpos, lane);
+        } else if (btype == 3) {
+            status = ST_BTYPE;
+            break;
+        } else {
+            int nlit, ndist;
+            if (btype == 1) {  // fixed codes
+                LDS_ORDER();
+                for (int s = lane; s < 288; s += 64) S.lens[s] = s < 144 ? 8 : s < 256 ? 9 : s < 280 ? 7 : 8;
+                if (lane < 32) S.lens[288 + lane] = 5;
+                nlit = 288;
+                ndist = 30;
+            } else {
+                status = parse_dynamic(S, bi, bitpos, lane, nlit, ndist);
+                if (status) break;
+            }
+            if (!build(S, S.lens, nlit, S.lcount, S.lsym, S.lit, ROOT, 1, lane) ||
+                !build(S, S.lens + nlit, ndist, S.dcount, S.dsym, S.dist, DROOT, 2, lane)) {
+                status = ST_HEADER;
+                break;
+            }
+            // ---- the symbols of the block
+            for (;;) {
+                if (bitpos > valid_bits) {
+                    status = ST_INPUT;
+                    break;
+                }
+                w = bi.fetch(bitpos, lane);
+                uint32_t e = uni(S.lit[w & ((1u << ROOT) - 1u)]);
+                if (e == 0) {  // a code longer than the root
+                    uint32_t l;
+                    const uint32_t sy = slow_symbol(w, S.lcount, S.lsym, l);
+                    if (l == 0 || sy >= 286u) {
+                        status = ST_LITLEN;
+                        break;
+                    }
+                    e = entry_of(S, 1, sy, l);
+                }
+                const uint32_t l = e & 15u;
+                bitpos += l;
+                w >>= l;
+                const uint32_t kind = e >> 28;
+                if (kind == 0) {
+                    if (op >= cap) {
+                        status = ST_ROOM;
+                        break;
+                    }
+                    const uint16_t v = (uint16_t)(e >> 8);
+                    if (lane == 0) {
+                        S.window[(op + WSIZE) & (NEARSZ - 1)] = v;
+                        o[op] = v;
+                    }
+                    op++;
+                    continue;
+                }
+                if (kind == 2) break;
+                const uint32_t lext = (e >> 4) & 15u;
+                const uint32_t len = ((e >> 8) & 0xFFFFu) + ((uint32_t)w & ((1u << lext) - 1u));
+                bitpos += lext;
+                w >>= lext;
+                uint32_t de = uni(S.dist[w & ((1u << DROOT) - 1u)]);
+                if (de == 0) {
+                    uint32_t dl;
+                    const uint32_t dsymv = slow_symbol(w, S.dcount, S.dsym, dl);
+                    if (dl == 0 || dsymv >= 30u) {
+                        status = ST_DIST;
+                        break;
+                    }
+                    de = entry_of(S, 2, dsymv, dl);
+                }
+                const uint32_t dl = de & 15u;
+                bitpos += dl;
+                w >>= dl;
+                const uint32_t dext = (de >> 4) & 15u;
+                const uint32_t dist = ((de >> 8) & 0xFFFFu) + ((uint32_t)w & ((1u << dext) - 1u));
+                bitpos += dext;
+                if ((uint64_t)op + len > cap) {
+                    status = ST_ROOM;
+                    break;
+                }
+                if (fresh_member ? dist > op - floor_op : dist > op + WSIZE) {
+                    status = ST_FAR;
+                    break;
+                }
+                // the copy: every lane a symbol; with dist < len the pattern repeats.  (LDS operations of one wave execute
+                // in order: the literal lane 0 wrote, the symbols of the last copy are there for this one)
+                asm volatile("" ::: "memory");
+                for (uint32_t i = (uint32_t)lane; i < len; i += 64) {
+                    const uint32_t from = dist >= len ? i : i % dist;
+                    uint16_t v;
+                    // (a ring slot is overwritten by the position NEARSZ later: a source this copy could reach with its own
+                    //  writes -- up to 258 symbols ahead -- is not taken from the ring)
+                    if (dist - from + 320u <= NEARSZ) {
+                        v = S.window[(op + WSIZE - dist + from) & (NEARSZ - 1)];
+                    } else if (op + from >= dist) {  // older than the ring, inside the chunk: from the output (written long ago)
+                        v = __hip_atomic_load(&o[op + from - dist], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    } else {                         // older than the ring, before the chunk: the marker itself
+                        v = (uint16_t)(0x8000u | (op + WSIZE - dist + from));
+                    }
+                    o[op + i] = v;
+                    S.window[(op + WSIZE + i) & (NEARSZ - 1)] = v;
+                }
+                asm volatile("" ::: "memory");
+                op += len;
+            }
+            if (status) break;
+        }
+        if (bfinal) {
+            // ---- the member ends: trailer (CRC-32, ISIZE), then another member's header, or the end of the stream
+            bitpos = (bitpos + 7) & ~7ull;
+            uint64_t q = bitpos >> 3;
+            const uint64_t valid_bytes = valid_bits >> 3;
+            if (q + 8 > valid_bytes) {
+                status = ST_INPUT;
+                break;
+            }
+            if (n_members == MAX_MEMBERS) {
+                status = ST_MEMBERS;
+                break;
+            }
+            const uint64_t tr = bits_at(bytes, q * 8);
+            if (lane == 0) {
+                cd.m_off[n_members] = op;
+                cd.m_crc[n_members] = (uint32_t)tr;
+                cd.m_isize[n_members] = (uint32_t)(tr >> 32);
+            }
+            n_members++;
+            q += 8;
+            bitpos = q * 8;
+            // gzip header (RFC 1952): ID1 ID2 CM FLG MTIME(4) XFL OS [XLEN + extra] [name 0] [comment 0] [CRC16]
+            bool member = false, trunc = false;
+            if (q == valid_bytes && at_eof) {
+                member = false;
+            } else if (q + 10 > valid_bytes) {
+                // fewer than ten bytes: at the end of the file gzip ignores them unless they begin like a member
+                const uint64_t hv = bits_at(bytes, q * 8);
+                if (at_eof && !(q + 2 <= valid_bytes && (hv & 0xFFFF) == 0x8B1F)) member = false;
+                else trunc = true;
+            } else {
+                const uint64_t hv = bits_at(bytes, q * 8);
+                const uint32_t flg = (uint32_t)(hv >> 24) & 0xFFu;
+                if ((hv & 0xFFFFFF) != 0x088B1Fu || (flg & 0xE0u)) {
+                    member = false;  // bytes that are no gzip member: ignored like gzip does
+                } else {
+                    member = true;
+                    uint64_t p = q + 10;
+                    if (flg & 4u) {
+                        if (p + 2 > valid_bytes) trunc = true;
+                        else {
+                            const uint32_t xlen = (uint32_t)bits_at(bytes, p * 8) & 0xFFFFu;
+                            p += 2 + xlen;
+                            if (p > valid_bytes) trunc = true;
+                        }
+                    }
+                    for (uint32_t bit = 8; bit <= 16 && !trunc; bit <<= 1)
+                        if (flg & bit) {  // zero-terminated: all lanes look at 64 bytes at a time
+                            for (;;) {
+                                const uint64_t pp = p + (uint64_t)lane;
+                                const bool z = pp < valid_bytes && bytes[pp] == 0;
+                                const uint64_t m = __ballot(z);
+                                if (m) {
+                                    p += (uint64_t)__builtin_ctzll(m) + 1;
+                                    break;
+                                }
+                                p += 64;
+                                if (p >= valid_bytes) {
+                                    trunc = true;
+                                    break;
+                                }
+                            }
+                        }
+                    if (!trunc && (flg & 2u)) {
+                        p += 2;
+                        if (p > valid_bytes) trunc = true;
+                    }
+                    q = p;
+                }
+            }
+            if (trunc) {
+                status = ST_GZHEAD;
+                break;
+            }
+            if (!member) {
+                flags |= 1u;  // the stream ends here
+                break;
+            }
+            bitpos = q * 8;
+            bi.init(in, bitpos, lane);
+            fresh_member = true;
+            floor_op = op;
+        }
+    }
+    if (lane == 0) {
+        cd.status = status;
+        cd.blocks = blocks;
+        cd.bit_end = bitpos;
+        cd.out_len = op;
+        cd.n_members = n_members;
+        cd.flags = flags;
+    }
+}
+
+// After the decode: which chunks count, do they chain, where does the text of each begin
+__global__ __launch_bounds__(1024) void k_finish(ChunkDesc *desc, uint32_t n, uint64_t *toff, SegResult *res) {
+    __shared__ uint32_t s_end, s_broken, s_bad, s_members;
+    __shared__ unsigned long long s_scan[1024];
+    const uint32_t t = threadIdx.x;
+    if (t == 0) {
+        s_end = NOIDX;
+        s_broken = NOIDX;
+        s_bad = NOIDX;
+        s_members = 0;
+    }
+    __syncthreads();
+    // the chunk the stream ended in, or the last one
+    for (uint32_t c = t; c < n; c += 1024)
+        if (desc[c].bit_start != NONE && (desc[c].flags & 1u)) atomicMin(&s_end, c);
+    __syncthreads();
+    uint32_t last = s_end;
+    if (last == NOIDX) {
+        __syncthreads();
+        for (uint32_t c = t; c < n; c += 1024)
+            if (desc[c].bit_start != NONE) atomicMax((int *)&s_end, (int)c);  // (NOIDX is -1 as int: any index is larger)
+        __syncthreads();
+        last = s_end;
+    }
+    const bool stream_end = last != NOIDX && (desc[last].flags & 1u);
+    // chunks behind the end of the stream do not count (what the search found there was never part of it)
+    for (uint32_t c = t; c < n; c += 1024)
+        if (c > last && desc[c].bit_start != NONE) {
+            desc[c].bit_start = NONE;
+            desc[c].out_len = 0;
+            desc[c].n_members = 0;
+        }
+    __syncthreads();
+    // errors and seams
+    for (uint32_t c = t; c <= last && c < n; c += 1024) {
+        const ChunkDesc &d = desc[c];
+        if (d.bit_start == NONE) continue;
+        if (d.status) atomicMin(&s_bad, c);
+        atomicAdd(&s_members, d.n_members);
+        if (c < last) {
+            uint32_t nx = c + 1;
+            while (desc[nx].bit_start == NONE) nx++;
+            if (d.bit_end != desc[nx].bit_start) atomicMin(&s_broken, nx);
+        }
+    }
+    // exclusive prefix sum of the lengths: per thread a run of chunks, then a scan over the threads
+    const uint32_t per = (n + 1023) / 1024;
+    unsigned long long sum = 0;
+    for (uint32_t i = 0; i < per; i++) {
+        const uint32_t c = t * per + i;
+        if (c < n && desc[c].bit_start != NONE) sum += desc[c].out_len;
+    }
+    s_scan[t] = sum;
+    __syncthreads();
+    for (uint32_t o = 1; o < 1024; o <<= 1) {
+        const unsigned long long v = t >= o ? s_scan[t - o] : 0;
+        __syncthreads();
+        s_scan[t] += v;
+        __syncthreads();
+    }
+    unsigned long long run = s_scan[t] - sum;
+    for (uint32_t i = 0; i < per; i++) {
+        const uint32_t c = t * per + i;
+        if (c < n) {
+            toff[c] = run;
+            if (desc[c].bit_start != NONE) run += desc[c].out_len;
+        }
+    }
+    if (t == 1023) res->total = s_scan[1023];
+    if (t == 0) {
+        uint32_t cnt = 0;
+        for (uint32_t c = 0; c < n; c++) cnt += desc[c].bit_start != NONE;
+        res->n_chunks = cnt;
+        res->end_chunk = last;
+        res->end_bit = last != NOIDX ? desc[last].bit_end : 0;
+        res->broken = s_broken;
+        res->bad_chunk = s_bad;
+        res->bad_status = s_bad != NOIDX ? desc[s_bad].status : 0;
+        res->stream_end = stream_end ? 1u : 0u;
+        res->members = s_members;
+    }
+}
+
+// ---- the chunks' windows: a chunk's effect on the window is an index map (a byte of the next window is a literal, or
+// the byte at some index of this one: 0x8000 | index, the symbols' own form), maps compose associatively, and a
+// parallel prefix scan over the chunks' maps gives every chunk's window.
+__global__ __launch_bounds__(256) void k_maps(const ChunkDesc *d, const uint16_t *sym, uint32_t slot_syms, uint16_t *maps) {
+    const uint32_t c = blockIdx.x;
+    const uint32_t nsym = d[c].bit_start == NONE ? 0u : d[c].out_len;
+    const uint16_t *src = sym + (uint64_t)c * slot_syms;
+    uint16_t *m = maps + (size_t)c * WSIZE;
+    // a member that starts inside the chunk cuts the chain: nothing before it can be referred to (its symbols carry no
+    // markers), which the symbols themselves already say
+    for (uint32_t j = blockIdx.y * 256 + threadIdx.x; j < WSIZE; j += gridDim.y * 256) {
+        uint16_t v;
+        if (nsym >= WSIZE) v = src[nsym - WSIZE + j];
+        else if (j < WSIZE - nsym) v = (uint16_t)(0x8000u | (j + nsym));  // the old window moves up
+        else v = src[j - (WSIZE - nsym)];
+        m[j] = v;
+    }
+}
+// one round of the scan: dst[c] = src[c] o src[c - stride] (first through the earlier map, then through c's)
+__global__ __launch_bounds__(256) void k_scan_round(const uint16_t *src, uint16_t *dst, uint32_t n, uint32_t stride) {
+    const uint32_t c = blockIdx.x;
+    const uint16_t *b = src + (size_t)c * WSIZE;
+    uint16_t *o = dst + (size_t)c * WSIZE;
+    if (c < stride) {
+        for (uint32_t j = blockIdx.y * 256 + threadIdx.x; j < WSIZE; j += gridDim.y * 256) o[j] = b[j];
+        return;
+    }
+    const uint16_t *a = src + (size_t)(c - stride) * WSIZE;
+    for (uint32_t j = blockIdx.y * 256 + threadIdx.x; j < WSIZE; j += gridDim.y * 256) {
+        const uint16_t v = b[j];
+        o[j] = v & 0x8000u ? a[v & 0x7FFFu] : v;
+    }
+}
+// windows[c] = the scanned map of chunk c - 1 applied to the window before the piece (w0); windows[0] = w0
+__global__ __launch_bounds__(256) void k_windows(const uint16_t *scanned, const uint8_t *w0, uint8_t *windows) {
+    const uint32_t c = blockIdx.x;  // the window of chunk c
+    uint8_t *w = windows + (size_t)c * WSIZE;
+    for (uint32_t j = blockIdx.y * 256 + threadIdx.x; j < WSIZE; j += gridDim.y * 256) {
+        uint8_t v;
+        if (c == 0) v = w0[j];
+        else {
+            const uint16_t x = scanned[(size_t)(c - 1) * WSIZE + j];
+            v = x & 0x8000u ? w0[x & 0x7FFFu] : (uint8_t)x;
+        }
+        w[j] = v;
+    }
+}
+
+// every chunk's symbols become bytes at their place in the text
+__global__ __launch_bounds__(256) void k_resolve(const ChunkDesc *d, const uint16_t *sym, uint32_t slot_syms, const uint8_t *windows,
+                                                 const uint64_t *toff, uint8_t *text) {
+    const uint32_t c = blockIdx.x;
+    if (d[c].bit_start == NONE) return;
+    const uint32_t nsym = d[c].out_len;
+    const uint16_t *src = sym + (uint64_t)c * slot_syms;
+    const uint8_t *w = windows + (size_t)c * WSIZE;
+    uint8_t *dst = text + toff[c];
+    for (uint32_t i = blockIdx.y * 256 + threadIdx.x; i < nsym; i += gridDim.y * 256) {
+        const uint16_t x = src[i];
+        dst[i] = x & 0x8000u ? w[x & 0x7FFFu] : (uint8_t)x;
+    }
+}
+
+// the window behind the piece: the last 32 KiB of (old window || text of the piece)
+__global__ __launch_bounds__(1024) void k_carry_window(const uint8_t *text, uint64_t total_cap, const SegResult *res, const uint8_t *old_w,
+                                                       uint8_t *new_w) {
+    const uint64_t total = res->total < total_cap ? res->total : total_cap;
+    for (uint32_t j = threadIdx.x; j < WSIZE; j += 1024) {
+        uint8_t v;
+        if (total >= WSIZE) v = text[total - WSIZE + j];
+        else if (j < WSIZE - total) v = old_w[j + total];
+        else v = text[j - (WSIZE - total)];
+        new_w[j] = v;
+    }
+}
+
+// ---- CRC-32 of every chunk's pieces (gzip polynomial, reflected) ---------------------------------------------------
+constexpr uint32_t CRC_POLY = 0xEDB88320u;
+__device__ __forceinline__ uint32_t multmodp(uint32_t a, uint32_t b) {  // a * b mod P in the reflected representation
+    uint32_t m = 1u << 31, p = 0;
+    for (;;) {
+        if (a & m) {
+            p ^= b;
+            if ((a & (m - 1)) == 0) break;
+        }
+        m >>= 1;
+        b = b & 1 ? (b >> 1) ^ CRC_POLY : b >> 1;
+    }
+    return p;
+}
+__device__ uint32_t x8n_modp(uint64_t n) {  // x^(8n) mod P
+    uint32_t p = 1u << 31, sq = 0x00800000u;  // x^0 ; x^8
+    while (n) {
+        if (n & 1) p = multmodp(sq, p);
+        sq = multmodp(sq, sq);
+        n >>= 1;
+    }
+    return p;
+}
+__global__ __launch_bounds__(256) void k_crc(ChunkDesc *d, const uint64_t *toff, const uint8_t *text) {
+    __shared__ uint32_t T[4][256];
+    __shared__ uint32_t part[256];
+    const uint32_t c = blockIdx.x, t = threadIdx.x;
+    if (d[c].bit_start == NONE) return;
+    {
+        uint32_t v = t;
+        for (int k = 0; k < 8; k++) v = v & 1 ? (v >> 1) ^ CRC_POLY : v >> 1;
+        T[0][t] = v;
+    }
+    __syncthreads();
+    for (int k = 1; k < 4; k++) {
+        const uint32_t v = T[k - 1][t];
+        T[k][t] = (v >> 8) ^ T[0][v & 0xFF];
+    }
+    __syncthreads();
+    const uint32_t nm = d[c].n_members, total = d[c].out_len;
+    const uint8_t *base = text + toff[c];
+    uint32_t a = 0;
+    for (uint32_t p = 0; p <= nm; p++) {
+        const uint32_t b = p < nm ? d[c].m_off[p] : total;
+        const uint32_t len = b - a;
+        // slices of L bytes, a thread each (L a multiple of 4); standard CRC-32 per slice
+        uint32_t L = (len + 255) / 256;
+        L = (L + 3) & ~3u;
+        if (L == 0) L = 4;
+        const uint32_t s0 = t * L < len ? t * L : len, s1 = (t + 1) * L < len ? (t + 1) * L : len;
+        uint32_t crc = 0xFFFFFFFFu;
+        const uint8_t *q = base + a + s0;
+        uint32_t k = s1 - s0;
+        while (k >= 4) {
+            struct __attribute__((packed)) U4 {
+                uint32_t v;
+            };
+            const uint32_t x = crc ^ ((const U4 *)q)->v;
+            crc = T[3][x & 0xFF] ^ T[2][(x >> 8) & 0xFF] ^ T[1][(x >> 16) & 0xFF] ^ T[0][x >> 24];
+            q += 4;
+            k -= 4;
+        }
+        while (k--) crc = (crc >> 8) ^ T[0][(crc ^ *q++) & 0xFF];
+        part[t] = ~crc;
+        __syncthreads();
+        if (t == 0) {
+            // crc(A || B) = crc(A) * x^(8|B|) + crc(B): the slices from left to right (all of length L but the last)
+            const uint32_t nsl = len ? (len + L - 1) / L : 0;
+            uint32_t acc = 0;
+            if (nsl) {
+                const uint32_t xl = x8n_modp(L), xlast = x8n_modp(len - (nsl - 1) * L);
+                acc = part[0];
+                for (uint32_t i = 1; i < nsl; i++) acc = multmodp(i + 1 == nsl ? xlast : xl, acc) ^ part[i];
+            }
+            d[c].piece_crc[p] = acc;
+        }
+        __syncthreads();
+        a = b;
+    }
+}
+
+}  // namespace gz
+
+// =====================================================================================================================
+// host side
+// =====================================================================================================================
+using namespace gz;
+
+#define GZ_TRY(x)                                                                             \
+    do {                                                                                      \
+        hipError_t e_ = (x);                                                                  \
+        if (e_ != hipSuccess) return fail(std::string(#x) + ": " + hipGetErrorString(e_)); \
+    } while (0)
+
+class DevGunzipImpl {
+public:
+    ~DevGunzipImpl() { close(); }
+
+    int open(const char *path, int device, size_t seg_bytes, size_t stretch_bytes, std::string &err) {
+        close();
+        path_ = path;
+        device_ = device;
+        fd_ = ::open(path, O_RDONLY | O_CLOEXEC);
+        if (fd_ < 0) {
+            err = std::string("cannot open ") + path;
+            return -1;
+        }
+        struct stat st;
+        if (fstat(fd_, &st) != 0 || !S_ISREG(st.st_mode) || st.st_size < 18) {
+            err = std::string("not a regular gzip file: ") + path;
+            close();
+            return -1;
+        }
+        size_ = (size_t)st.st_size;
+        void *m = mmap(nullptr, size_, PROT_READ, MAP_PRIVATE, fd_, 0);
+        if (m == MAP_FAILED) {
+            err = std::string("cannot map ") + path;
+            close();
+            return -1;
+        }
+        base_ = (const uint8_t *)m;
+        (void)madvise(m, size_, MADV_SEQUENTIAL);
+        bool trunc = false;
+        const uint8_t *d = gzip_member_body(base_, base_ + size_, &trunc);
+        if (!d) {
+            err = std::string("not in gzip format: ") + path;
+            close();
+            return -1;
+        }
+        pos_bit_ = (uint64_t)(d - base_) * 8;
+        if (const char *e = getenv("NOHUMAN_GZDEV_SEG")) seg_bytes = (size_t)atol(e);
+        if (const char *e = getenv("NOHUMAN_GZDEV_STRETCH")) stretch_bytes = (size_t)atol(e);
+        stretch_ = stretch_bytes ? stretch_bytes : (size_t)(32u << 10);
+        if (stretch_ < 1024) stretch_ = 1024;
+        stretch_ = (stretch_ + 63) & ~(size_t)63;
+        seg_ = seg_bytes ? seg_bytes : (size_t)(64u << 20);
+        if (seg_ < stretch_) seg_ = stretch_;
+        seg_ = seg_ / stretch_ * stretch_;
+        n_slots_ = (uint32_t)(seg_ / stretch_);
+        // a chunk's block may run past the piece: that much more of the file is on the device.  zlib's blocks hold at
+        // most 64 KiB (stored) or some 16 K symbols; 2 MiB covers encoders with far larger ones
+        look_ = std::max<size_t>((size_t)2u << 20, stretch_);
+        slot_syms_ = (uint32_t)(16 * stretch_ + 65536);  // symbols a stretch's slot holds: text up to 16 : 1
+        trace_ = getenv("NOHUMAN_TRACE") != nullptr;
+        if (hipSetDevice(device_) != hipSuccess) {
+            err = "hipSetDevice failed";
+            close();
+            return -1;
+        }
+        const size_t in_bytes = seg_ + look_ + ALIGN + 4096;
+        bool ok = hipMalloc((void **)&d_in_, in_bytes) == hipSuccess && hipHostMalloc((void **)&h_in_, in_bytes, hipHostMallocDefault) == hipSuccess &&
+                  hipMalloc((void **)&d_start_, (size_t)n_slots_ * 8) == hipSuccess &&
+                  hipMalloc((void **)&d_desc_, (size_t)n_slots_ * sizeof(ChunkDesc)) == hipSuccess &&
+                  hipHostMalloc((void **)&h_desc_, (size_t)n_slots_ * sizeof(ChunkDesc), hipHostMallocDefault) == hipSuccess &&
+                  hipMalloc((void **)&d_toff_, (size_t)n_slots_ * 8) == hipSuccess &&
+                  hipMalloc((void **)&d_sym_, ((size_t)n_slots_ * slot_syms_ + 1024) * 2) == hipSuccess &&
+                  hipMalloc((void **)&d_maps_[0], (size_t)n_slots_ * WSIZE * 2) == hipSuccess &&
+                  hipMalloc((void **)&d_maps_[1], (size_t)n_slots_ * WSIZE * 2) == hipSuccess &&
+                  hipMalloc((void **)&d_windows_, (size_t)n_slots_ * WSIZE) == hipSuccess &&
+                  hipMalloc((void **)&d_win_[0], WSIZE) == hipSuccess && hipMalloc((void **)&d_win_[1], WSIZE) == hipSuccess &&
+                  hipMalloc((void **)&d_res_, sizeof(SegResult)) == hipSuccess &&
+                  hipHostMalloc((void **)&h_res_, sizeof(SegResult), hipHostMallocDefault) == hipSuccess;
+        if (ok) ok = hipMemset(d_win_[0], 0, WSIZE) == hipSuccess && hipMemset(d_in_, 0, in_bytes) == hipSuccess;
+        if (ok)
+            ok = hipFuncSetAttribute((const void *)k_search, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(Lds)) == hipSuccess &&
+                 hipFuncSetAttribute((const void *)k_inflate, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(Lds)) == hipSuccess;
+        for (auto &e : ev_)
+            if (ok) ok = hipEventCreate(&e) == hipSuccess;
+        if (!ok) {
+            (void)hipGetLastError();
+            err = "the gzip reader's device buffers cannot be had";
+            close();
+            return -1;
+        }
+        if (const char *e = getenv("NOHUMAN_GZDEV_FAKE_START")) fake_start_ = atol(e);  // test knob: a false positive of the search
+        return 0;
+    }
+
+    void close() {
+        if (trace_ && st_.segments)
+            fprintf(stderr,
+                    "[nohuman trace] gzip reader on GPU %d, %s: %llu pieces, %llu chunks (%llu decoded again), %llu pieces by the host decoder, "
+                    "%llu members, %.2f GB -> %.2f GB; kernels ms: search %.1f decode %.1f windows %.1f resolve %.1f crc %.1f; host: copy %.3f s, wait %.3f s\n",
+                    device_, path_.c_str(), (unsigned long long)st_.segments, (unsigned long long)st_.chunks, (unsigned long long)st_.redecoded,
+                    (unsigned long long)st_.fallback_segments, (unsigned long long)st_.members, st_.gzip_bytes / 1e9, st_.text_bytes / 1e9, st_.ms_search,
+                    st_.ms_decode, st_.ms_scan, st_.ms_resolve, st_.ms_crc, st_.s_host_copy, st_.s_wait);
+        if (device_ >= 0) (void)hipSetDevice(device_);
+        for (void *p : {(void *)d_in_, (void *)d_start_, (void *)d_desc_, (void *)d_toff_, (void *)d_sym_, (void *)d_maps_[0], (void *)d_maps_[1],
+                        (void *)d_windows_, (void *)d_win_[0], (void *)d_win_[1], (void *)d_res_})
+            if (p) (void)hipFree(p);
+        for (void *p : {(void *)h_in_, (void *)h_desc_, (void *)h_res_})
+            if (p) (void)hipHostFree(p);
+        d_in_ = nullptr, d_start_ = nullptr, d_desc_ = nullptr, d_toff_ = nullptr, d_sym_ = nullptr, d_maps_[0] = d_maps_[1] = nullptr;
+        d_windows_ = nullptr, d_win_[0] = d_win_[1] = nullptr, d_res_ = nullptr, h_in_ = nullptr, h_desc_ = nullptr, h_res_ = nullptr;
+        for (auto &e : ev_)
+            if (e) {
+                (void)hipEventDestroy(e);
+                e = nullptr;
+            }
+        if (base_) munmap((void *)base_, size_);
+        base_ = nullptr;
+        if (fd_ >= 0) ::close(fd_);
+        fd_ = -1;
+        st_ = DevGunzipStats();
+        ended_ = false;
+    }
+
+    long next(void *d_dst, size_t room, hipStream_t stream) {
+        if (!error_.empty()) return -1;
+        for (;;) {
+            if (ended_) return 0;
+            const long n = piece((uint8_t *)d_dst, room, stream);
+            if (n != 0) return n;  // text, or an error
+        }
+    }
+
+    bool ended_ = false;
+    std::string error_;
+    DevGunzipStats st_;
+
+private:
+    static constexpr size_t ALIGN = 4096;
+
+    long fail(const std::string &m) {
+        if (error_.empty()) error_ = "gzip: " + m + " (" + path_ + ")";
+        return -1;
+    }
+
+    // per-member bookkeeping like gzip's: CRC-32 and length of what was decoded against the trailer
+    bool account(uint32_t crc, uint64_t len) {
+        run_crc_ = crc32_join(run_crc_, crc, len);  // (crc of nothing is 0, and joining to it changes nothing)
+        run_len_ += len;
+        return true;
+    }
+    bool member_end(uint32_t crc, uint32_t isize) {
+        st_.members++;
+        if (crc != run_crc_ || isize != (uint32_t)run_len_) {
+            fail(crc != run_crc_ ? "crc error" : "length error");
+            return false;
+        }
+        run_crc_ = 0;
+        run_len_ = 0;
+        return true;
+    }
+
+    // one piece of the stream: up to n_slots_ stretches from the position the stream goes on at
+    long piece(uint8_t *d_dst, size_t room, hipStream_t stream) {
+        if (hipSetDevice(device_) != hipSuccess) return fail("hipSetDevice failed");
+        const uint64_t a_byte = (pos_bit_ >> 3) / ALIGN * ALIGN;  // the piece's buffer starts here in the file
+        const uint64_t first_bit = pos_bit_ - 8 * a_byte;
+        if (a_byte >= size_) return fail("unexpected end of file");
+        if (host_mode_) {  // the device gave up on this file twice in a row (text beyond 16 : 1, giant blocks): the host decoder reads on
+            SegResult r{};
+            r.bad_status = last_bad_;
+            return host_piece(d_dst, room, stream, a_byte, first_bit, 8ull * (size_ - a_byte), r);
+        }
+        // stretches this piece decodes: what the room holds at the ratio seen so far (a piece that does not fit is cut down)
+        uint32_t n = n_slots_;
+        {
+            const double per_stretch = ratio_ * 1.3 * (double)stretch_ + 4096;
+            const uint64_t fit = (uint64_t)((double)room / per_stretch);
+            if (fit < n) n = fit < 1 ? 1u : (uint32_t)fit;
+        }
+        for (;;) {
+            const size_t want = (size_t)n * stretch_ + look_;
+            const size_t avail = (size_t)std::min<uint64_t>(want, size_ - a_byte);
+            const bool at_eof = a_byte + avail == size_;
+            const uint32_t n_str = (uint32_t)std::min<uint64_t>(n, (avail + stretch_ - 1) / stretch_);
+            const uint64_t valid_bits = 8ull * avail;
+            // the bytes: page cache -> page-locked staging -> device
+            const auto c0 = std::chrono::steady_clock::now();
+            memcpy(h_in_, base_ + a_byte, avail);
+            memset(h_in_ + avail, 0, 1024);
+            st_.s_host_copy += std::chrono::duration<double>(std::chrono::steady_clock::now() - c0).count();
+            GZ_TRY(hipMemcpyAsync(d_in_, h_in_, avail + 1024, hipMemcpyHostToDevice, stream));
+            const uint64_t end_bit = std::min<uint64_t>((uint64_t)n_str * stretch_ * 8, valid_bits);
+            if (trace_) (void)hipEventRecord(ev_[0], stream);
+            hipLaunchKernelGGL(k_search, dim3(n_str), dim3(64), sizeof(Lds), stream, (const uint32_t *)d_in_, valid_bits, (uint64_t)stretch_ * 8,
+                               first_bit, d_start_);
+            if (fake_start_ > 0 && (uint32_t)fake_start_ < n_str) {  // test knob: pretend the search found a start that is none
+                const uint64_t bogus = (uint64_t)fake_start_ * stretch_ * 8 + 13;
+                GZ_TRY(hipMemcpyAsync(d_start_ + fake_start_, &bogus, 8, hipMemcpyHostToDevice, stream));
+                GZ_TRY(hipStreamSynchronize(stream));
+                fake_start_ = -1;
+            }
+            hipLaunchKernelGGL(k_plan, dim3(1), dim3(1024), 0, stream, (const uint64_t *)d_start_, n_str, end_bit, slot_syms_, d_desc_);
+            if (trace_) (void)hipEventRecord(ev_[1], stream);
+            hipLaunchKernelGGL(k_inflate, dim3(n_str), dim3(64), sizeof(Lds), stream, (const uint32_t *)d_in_, valid_bits, at_eof ? 1u : 0u, d_desc_,
+                               d_sym_, slot_syms_, NOIDX);
+            if (trace_) (void)hipEventRecord(ev_[2], stream);
+            uint32_t redo = 0;
+            for (;;) {
+                hipLaunchKernelGGL(k_finish, dim3(1), dim3(1024), 0, stream, d_desc_, n_str, d_toff_, d_res_);
+                GZ_TRY(hipMemcpyAsync(h_res_, d_res_, sizeof(SegResult), hipMemcpyDeviceToHost, stream));
+                const auto w0 = std::chrono::steady_clock::now();
+                GZ_TRY(hipStreamSynchronize(stream));
+                st_.s_wait += std::chrono::duration<double>(std::chrono::steady_clock::now() - w0).count();
+                if (h_res_->bad_chunk != NOIDX && (h_res_->broken == NOIDX || h_res_->bad_chunk < h_res_->broken)) break;
+                if (h_res_->broken == NOIDX) break;
+                // A chunk does not start where its predecessor ended: what the search found there was no block start.
+                // It is struck from the plan and its predecessor decoded again, now to the start after it (the host
+                // reader's "searching on"; costs time, never correctness).
+                const uint32_t bad = h_res_->broken;
+                GZ_TRY(hipMemcpyAsync(d_start_ + bad, &NONE, 8, hipMemcpyHostToDevice, stream));
+                hipLaunchKernelGGL(k_plan, dim3(1), dim3(1024), 0, stream, (const uint64_t *)d_start_, n_str, end_bit, slot_syms_, d_desc_);
+                GZ_TRY(hipMemcpyAsync(h_desc_, d_desc_, (size_t)n_str * sizeof(ChunkDesc), hipMemcpyDeviceToHost, stream));
+                GZ_TRY(hipStreamSynchronize(stream));
+                uint32_t prev = bad;
+                while (prev > 0 && h_desc_[--prev].bit_start == NONE) {
+                }
+                hipLaunchKernelGGL(k_inflate, dim3(1), dim3(64), sizeof(Lds), stream, (const uint32_t *)d_in_, valid_bits, at_eof ? 1u : 0u, d_desc_,
+                                   d_sym_, slot_syms_, prev);
+                redo++;
+                st_.redecoded++;
+                if (redo > n_str) return fail("the chunks of a piece do not chain");
+            }
+            const SegResult r = *h_res_;
+            if (trace_) {
+                float ms = 0;
+                if (hipEventElapsedTime(&ms, ev_[0], ev_[1]) == hipSuccess) st_.ms_search += ms;
+                if (hipEventElapsedTime(&ms, ev_[1], ev_[2]) == hipSuccess) st_.ms_decode += ms;
+            }
+            if (r.bad_chunk != NOIDX || r.end_chunk == NOIDX) {
+                last_bad_ = r.bad_status;
+                if (++failed_in_a_row_ >= 2) host_mode_ = true;
+                return host_piece(d_dst, room, stream, a_byte, first_bit, end_bit, r);
+            }
+            failed_in_a_row_ = 0;
+            if (r.total > room) {
+                if (n_str <= 1) return fail("a chunk's text does not fit the batch buffer");
+                n = std::max<uint32_t>(1u, n_str / 4);  // cut the piece down and decode again
+                ratio_ = std::max(ratio_, (double)r.total / ((double)n_str * stretch_));
+                continue;
+            }
+            // windows by the prefix scan, text, CRCs, the window behind the piece
+            if (trace_) (void)hipEventRecord(ev_[3], stream);
+            const uint32_t gy = 4;
+            hipLaunchKernelGGL(k_maps, dim3(n_str, gy), dim3(256), 0, stream, (const ChunkDesc *)d_desc_, (const uint16_t *)d_sym_, slot_syms_,
+                               d_maps_[0]);
+            int cur = 0;
+            for (uint32_t stride = 1; stride < n_str; stride <<= 1) {
+                hipLaunchKernelGGL(k_scan_round, dim3(n_str, gy), dim3(256), 0, stream, (const uint16_t *)d_maps_[cur], d_maps_[cur ^ 1], n_str, stride);
+                cur ^= 1;
+            }
+            hipLaunchKernelGGL(k_windows, dim3(n_str, gy), dim3(256), 0, stream, (const uint16_t *)d_maps_[cur], (const uint8_t *)d_win_[win_], d_windows_);
+            if (trace_) (void)hipEventRecord(ev_[4], stream);
+            hipLaunchKernelGGL(k_resolve, dim3(n_str, 8), dim3(256), 0, stream, (const ChunkDesc *)d_desc_, (const uint16_t *)d_sym_, slot_syms_,
+                               (const uint8_t *)d_windows_, (const uint64_t *)d_toff_, d_dst);
+            if (trace_) (void)hipEventRecord(ev_[5], stream);
+            hipLaunchKernelGGL(k_crc, dim3(n_str), dim3(256), 0, stream, d_desc_, (const uint64_t *)d_toff_, (const uint8_t *)d_dst);
+            hipLaunchKernelGGL(k_carry_window, dim3(1), dim3(1024), 0, stream, (const uint8_t *)d_dst, (uint64_t)room, (const SegResult *)d_res_,
+                               (const uint8_t *)d_win_[win_], d_win_[win_ ^ 1]);
+            if (trace_) (void)hipEventRecord(ev_[6], stream);
+            GZ_TRY(hipMemcpyAsync(h_desc_, d_desc_, (size_t)n_str * sizeof(ChunkDesc), hipMemcpyDeviceToHost, stream));
+            const auto w0 = std::chrono::steady_clock::now();
+            GZ_TRY(hipStreamSynchronize(stream));
+            st_.s_wait += std::chrono::duration<double>(std::chrono::steady_clock::now() - w0).count();
+            if (trace_) {
+                float ms = 0;
+                if (hipEventElapsedTime(&ms, ev_[3], ev_[4]) == hipSuccess) st_.ms_scan += ms;
+                if (hipEventElapsedTime(&ms, ev_[4], ev_[5]) == hipSuccess) st_.ms_resolve += ms;
+                if (hipEventElapsedTime(&ms, ev_[5], ev_[6]) == hipSuccess) st_.ms_crc += ms;
+            }
+            win_ ^= 1;
+            // members: CRC-32 and ISIZE like gzip checks them
+            for (uint32_t c = 0; c <= r.end_chunk; c++) {
+                const ChunkDesc &d = h_desc_[c];
+                if (d.bit_start == NONE) continue;
+                uint32_t a = 0;
+                for (uint32_t p = 0; p <= d.n_members; p++) {
+                    const uint32_t b = p < d.n_members ? d.m_off[p] : d.out_len;
+                    account(d.piece_crc[p], b - a);
+                    if (p < d.n_members && !member_end(d.m_crc[p], d.m_isize[p])) return -1;
+                    a = b;
+                }
+            }
+            st_.segments++;
+            st_.chunks += r.n_chunks;
+            st_.text_bytes += r.total;
+            st_.gzip_bytes += (a_byte * 8 + r.end_bit - pos_bit_) / 8;
+            if (r.total) ratio_ = std::max(ratio_ * 0.9, (double)r.total / std::max<double>(1.0, (double)(r.end_bit - first_bit) / 8));
+            pos_bit_ = a_byte * 8 + r.end_bit;
+            if (r.stream_end) {
+                if (run_len_) return fail("unexpected end of file");
+                ended_ = true;
+            } else if ((pos_bit_ >> 3) >= size_) {
+                return fail("unexpected end of file");
+            }
+            return (long)r.total;
+        }
+    }
+
+    // The host decoder takes the piece over: from the same bit position, with the same window, to the first block
+    // boundary behind the piece's first stretch (it is one core: the pieces behind go back to the device).
+    long host_piece(uint8_t *d_dst, size_t room, hipStream_t stream, uint64_t a_byte, uint64_t first_bit, uint64_t end_bit, const SegResult &r) {
+        if (!warned_) {
+            fprintf(stderr,
+                    "nohuman: %s: a piece of the gzip stream is decoded on the host (chunk status %u: %s); the GPU reader goes on behind it\n",
+                    path_.c_str(), r.bad_status,
+                    r.bad_status == ST_ROOM      ? "text beyond 16:1"
+                    : r.bad_status == ST_INPUT   ? "a block longer than the look-ahead, or a truncated file"
+                    : r.bad_status == ST_MEMBERS ? "many small members"
+                                                 : "invalid deflate data?");
+            warned_ = true;
+        }
+        std::vector<uint8_t> window(WSIZE);
+        GZ_TRY(hipMemcpyAsync(window.data(), d_win_[win_], WSIZE, hipMemcpyDeviceToHost, stream));
+        GZ_TRY(hipStreamSynchronize(stream));
+        // to the first block boundary behind a megabyte of input (in host mode: sixteen), or with half the room full
+        std::vector<uint8_t> out;
+        std::vector<GzMemberEnd> members;
+        const uint64_t from = a_byte * 8 + first_bit;
+        const uint64_t stop = std::min<uint64_t>(a_byte * 8 + end_bit, from + 8 * (uint64_t)((host_mode_ ? 16u : 1u) << 20));
+        uint64_t eb = 0;
+        bool stream_end = false;
+        std::string err;
+        // (a member that started before this piece keeps its window; one that starts here has none -- the window only
+        //  matters for valid references, which never reach before a member's start)
+        if (inflate_from(base_, base_ + size_, from, stop, window.data(), WSIZE, out, members, &eb, &stream_end, err, room / 2) != 0) {
+            error_ = err + " (" + path_ + ")";
+            return -1;
+        }
+        if (out.size() > room) return fail("a block's text does not fit the batch buffer");
+        if (!out.empty()) GZ_TRY(hipMemcpyAsync(d_dst, out.data(), out.size(), hipMemcpyHostToDevice, stream));
+        // the window behind it
+        std::vector<uint8_t> nw(WSIZE);
+        if (out.size() >= WSIZE) memcpy(nw.data(), out.data() + out.size() - WSIZE, WSIZE);
+        else {
+            memcpy(nw.data(), window.data() + out.size(), WSIZE - out.size());
+            memcpy(nw.data() + WSIZE - out.size(), out.data(), out.size());
+        }
+        GZ_TRY(hipMemcpyAsync(d_win_[win_ ^ 1], nw.data(), WSIZE, hipMemcpyHostToDevice, stream));
+        GZ_TRY(hipStreamSynchronize(stream));
+        win_ ^= 1;
+        uint64_t a = 0;
+        for (const GzMemberEnd &m : members) {
+            account(crc32_fast(0, out.data() + a, (size_t)(m.out_pos - a)), m.out_pos - a);
+            if (!member_end(m.crc, m.isize)) return -1;
+            a = m.out_pos;
+        }
+        account(crc32_fast(0, out.data() + a, out.size() - (size_t)a), out.size() - a);
+        st_.segments++;
+        st_.fallback_segments++;
+        st_.text_bytes += out.size();
+        st_.gzip_bytes += (eb - pos_bit_) / 8;
+        pos_bit_ = eb;
+        if (stream_end) {
+            if (run_len_) return fail("unexpected end of file");
+            ended_ = true;
+        }
+        return (long)out.size();
+    }
+
+    std::string path_;
+    int device_ = -1, fd_ = -1;
+    size_t size_ = 0;
+    const uint8_t *base_ = nullptr;
+    uint64_t pos_bit_ = 0;  // where the stream goes on (a block boundary), bits from the start of the file
+    size_t stretch_ = 0, seg_ = 0, look_ = 0;
+    uint32_t n_slots_ = 0, slot_syms_ = 0;
+    double ratio_ = 6.0;  // text per compressed byte seen lately
+    uint8_t *d_in_ = nullptr, *h_in_ = nullptr;
+    uint64_t *d_start_ = nullptr, *d_toff_ = nullptr;
+    ChunkDesc *d_desc_ = nullptr, *h_desc_ = nullptr;
+    uint16_t *d_sym_ = nullptr, *d_maps_[2] = {nullptr, nullptr};
+    uint8_t *d_windows_ = nullptr, *d_win_[2] = {nullptr, nullptr};
+    int win_ = 0;
+    SegResult *d_res_ = nullptr, *h_res_ = nullptr;
+    hipEvent_t ev_[7] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    uint32_t run_crc_ = 0;
+    uint64_t run_len_ = 0;
+    bool trace_ = false, warned_ = false, host_mode_ = false;
+    uint32_t failed_in_a_row_ = 0, last_bad_ = 0;
+    long fake_start_ = -1;
+};
+
+DevGunzip::DevGunzip() : impl_(new DevGunzipImpl()) {}
+DevGunzip::~DevGunzip() { delete impl_; }
+int DevGunzip::open(const char *path, int device, size_t seg_bytes, size_t stretch_bytes, std::string &err) {
+    return impl_->open(path, device, seg_bytes, stretch_bytes, err);
+}
+long DevGunzip::next(void *d_dst, size_t room, hipStream_t stream) { return impl_->next(d_dst, room, stream); }
+bool DevGunzip::ended() const { return impl_->ended_; }
+const std::string &DevGunzip::error() const { return impl_->error_; }
+const DevGunzipStats &DevGunzip::stats() const { return impl_->st_; }
+void DevGunzip::close() { impl_->close(); }
+
+bool dev_gunzip_wants(const char *path) {
+    int fd = ::open(path, O_RDONLY | O_CLOEXEC);
+    if (fd < 0) return false;
+    struct stat st;
+    uint8_t h[18];
+    bool ok = fstat(fd, &st) == 0 && S_ISREG(st.st_mode) && st.st_size >= 18 && ::read(fd, h, 18) == 18 && h[0] == 0x1f && h[1] == 0x8b && h[2] == 8;
+    // BGZF: FEXTRA with the 'B' 'C' subfield first (every member a single final block: nothing for the block search)
+    if (ok && (h[3] & 4) && h[12] == 'B' && h[13] == 'C') ok = false;
+    ::close(fd);
+    return ok;
+}
+
+}  // namespace nh
+
+extern "C" int nh_gunzip_device_file(const char *in, const char *out, int32_t device, uint64_t seg_bytes, uint64_t stretch_bytes,
+                                     uint64_t *stats8) {
+    if (!in || !out) return nh::set_error(NH_EINVAL, "null argument");
+    nh::DevGunzip gz;
+    std::string err;
+    if (gz.open(in, device, (size_t)seg_bytes, (size_t)stretch_bytes, err) != 0) return nh::set_error(NH_EIO, "%s", err.c_str());
+    const size_t room = (size_t)256u << 20;
+    uint8_t *d_text = nullptr;
+    hipStream_t stream = nullptr;
+    if (hipSetDevice(device) != hipSuccess || hipMalloc((void **)&d_text, room + 64) != hipSuccess ||
+        hipStreamCreateWithFlags(&stream, hipStreamNonBlocking) != hipSuccess) {
+        if (d_text) (void)hipFree(d_text);
+        return nh::set_error(NH_EOOM, "cannot allocate the text buffer on device %d", device);
+    }
+    int rc = NH_OK;
+    FILE *f = fopen(out, "wb");
+    if (!f) rc = nh::set_error(NH_EIO, "cannot create %s", out);
+    std::vector<uint8_t> host;
+    while (rc == NH_OK) {
+        const long n = gz.next(d_text, room, stream);
+        if (n < 0) {
+            rc = nh::set_error(NH_EIO, "%s", gz.error().c_str());
+            break;
+        }
+        if (n == 0) break;
+        host.resize((size_t)n);
+        if (hipMemcpy(host.data(), d_text, (size_t)n, hipMemcpyDeviceToHost) != hipSuccess) rc = nh::set_error(NH_EDEVICE, "D2H of the text failed");
+        else if (fwrite(host.data(), 1, (size_t)n, f) != (size_t)n) rc = nh::set_error(NH_EIO, "write error on %s", out);
+    }
+    if (f && fclose(f) != 0 && rc == NH_OK) rc = nh::set_error(NH_EIO, "write error on %s", out);
+    if (stats8) {
+        const nh::DevGunzipStats &s = gz.stats();
+        stats8[0] = s.segments;
+        stats8[1] = s.chunks;
+        stats8[2] = s.redecoded;
+        stats8[3] = s.fallback_segments;
+        stats8[4] = s.members;
+        stats8[5] = s.text_bytes;
+        stats8[6] = s.gzip_bytes;
+        stats8[7] = (uint64_t)((s.ms_search + s.ms_decode + s.ms_scan + s.ms_resolve + s.ms_crc) * 1000.0);
+    }
+    gz.close();
+    (void)hipStreamDestroy(stream);
+    (void)hipFree(d_text);
+    return rc;
+}

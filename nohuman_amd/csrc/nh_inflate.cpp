@@ -738,6 +738,7 @@ struct ChunkDecoder {
     bool bytes_mode = false;
     size_t marker_end = 0;
     std::vector<MemberEnd> members;
+    size_t out_limit = (size_t)-1;  // stop at the first block boundary with this much output (inflate_from)
     // result
     uint64_t start_bit = 0, end_bit = 0;
     StopKind stop = STOP_NONE;
@@ -904,7 +905,7 @@ struct ChunkDecoder {
                 in.init(base, end, (uint64_t)(d - base) * 8);
             }
             const uint64_t b = in.bitpos();
-            if (b >= hard_bit || (b >= soft_bit && (exact_stop || is_candidate(base, end, b, scratch)))) {
+            if (b >= hard_bit || total() >= out_limit || (b >= soft_bit && (exact_stop || is_candidate(base, end, b, scratch)))) {
                 end_bit = b;
                 stop = STOP_BOUNDARY;
                 return;
@@ -1498,6 +1499,40 @@ private:
 
 ParallelGunzip::ParallelGunzip() : impl_(new GunzipImpl()) {}
 ParallelGunzip::~ParallelGunzip() { delete impl_; }
+const uint8_t *gzip_member_body(const uint8_t *p, const uint8_t *end, bool *truncated) {
+    const uint8_t *d = parse_gzip_header(p, end);
+    if (truncated) *truncated = d == TRUNCATED;
+    return d == TRUNCATED ? nullptr : d;
+}
+
+int inflate_from(const uint8_t *base, const uint8_t *end, uint64_t from_bit, uint64_t stop_bit, const uint8_t *window,
+                 size_t window_len, std::vector<uint8_t> &out, std::vector<GzMemberEnd> &members, uint64_t *end_bit,
+                 bool *stream_end, std::string &err, size_t out_limit) {
+    std::unique_ptr<ChunkDecoder> d(new ChunkDecoder());
+    d->reset(base, end);
+    d->out_limit = out_limit;
+    if (window_len > WSIZE) {
+        window += window_len - WSIZE;
+        window_len = WSIZE;
+    }
+    d->start_bytes(window, window_len);
+    d->run(from_bit, stop_bit, stop_bit, true);
+    if (d->stop == STOP_ERROR || d->stop == STOP_NONE) {
+        err = std::string("gzip: ") + (d->error.empty() ? "invalid deflate data" : d->error);
+        return -1;
+    }
+    out.assign(d->out8.data(), d->out8.data() + d->n8);
+    members.clear();
+    for (const MemberEnd &m : d->members) members.push_back({m.out_pos, m.crc, m.isize});
+    *end_bit = d->end_bit;
+    *stream_end = d->stop == STOP_STREAM_END;
+    return 0;
+}
+
+uint32_t crc32_join(uint32_t crc_a, uint32_t crc_b, uint64_t len_b) {
+    return (uint32_t)crc32_combine(crc_a, crc_b, (z_off_t)len_b);
+}
+
 int ParallelGunzip::open(const char *path, unsigned threads, size_t chunk_bytes, std::string &err) {
     return impl_->open(path, threads, chunk_bytes, err);
 }

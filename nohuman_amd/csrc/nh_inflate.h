@@ -23,8 +23,27 @@
 #include <stdint.h>
 
 #include <string>
+#include <vector>
 
 namespace nh {
+
+// ---- pieces of the host decoder that the device reader (nh_gunzip.hip) falls back on ------------------------------
+struct GzMemberEnd {
+    uint64_t out_pos;  // bytes of output before the end of the member
+    uint32_t crc, isize;
+};
+// First byte of the deflate data of the gzip member whose header starts at p: nullptr when [p, end) does not start
+// with a gzip member header (gzip ignores such trailing bytes), *truncated set when the header runs past `end`.
+const uint8_t *gzip_member_body(const uint8_t *p, const uint8_t *end, bool *truncated);
+// Decodes the gzip file image [base, end) from bit position from_bit -- a block boundary -- with the up to 32 KiB of
+// text before it (window_len 0 at a member start) to the first block boundary at or behind stop_bit, walking over
+// member trailers and headers, or to the end of the stream -- or to the first block boundary with out_limit bytes of
+// text.  0, or -1 with err set (damaged data: the messages of the host reader).
+int inflate_from(const uint8_t *base, const uint8_t *end, uint64_t from_bit, uint64_t stop_bit, const uint8_t *window,
+                 size_t window_len, std::vector<uint8_t> &out, std::vector<GzMemberEnd> &members, uint64_t *end_bit,
+                 bool *stream_end, std::string &err, size_t out_limit = (size_t)-1);
+// crc of A || B from crc(A), crc(B) and the length of B (GF(2) shift; what zlib calls crc32_combine)
+uint32_t crc32_join(uint32_t crc_a, uint32_t crc_b, uint64_t len_b);
 
 class GunzipImpl;
 

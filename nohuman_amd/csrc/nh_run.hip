@@ -476,10 +476,10 @@ enum { ST_READ1 = 0, ST_READ2, ST_RPUSH1, ST_RPUSH2, ST_MPOP, ST_MSLOT, ST_MGATH
 
 static void reader_main(const char *path, BoundedQueue<std::unique_ptr<HalfBatch>> *out, RunState *rs,
                         BatchPool *pool, StageClock *clk, int which, size_t batch_frags, size_t batch_text,
-                        unsigned gz_threads) {
+                        unsigned gz_threads, int gz_device) {
     BlockReader r;
     std::string err;
-    if (r.open(path, err, gz_threads) != 0) {
+    if (r.open(path, err, gz_threads, gz_device) != 0) {
         rs->fail(NH_EIO, err);
         out->close();
         return;
@@ -708,10 +708,12 @@ int run_engines(const std::vector<Engine *> &engines, const nh_run_args *a, nh_s
     unsigned gz_threads = (a->threads ? a->threads : 1) / (unsigned)mates;
     if (gz_threads < 1) gz_threads = 1;
     if (gz_threads > 16) gz_threads = 16;  // beyond that the record parser of the file is the limit
-    std::thread t1(reader_main, a->in1, &q1, &rs, &pool1, &clk, 0, BATCH_FRAGS, BATCH_TEXT, gz_threads);
+    // gzip inputs are read on the GPU (nh_gunzip.hip): file 1 on the first device, file 2 on the second where there is one
+    std::thread t1(reader_main, a->in1, &q1, &rs, &pool1, &clk, 0, BATCH_FRAGS, BATCH_TEXT, gz_threads, engines[0]->device);
     std::thread t2;
     if (rs.paired)
-        t2 = std::thread(reader_main, a->in2, &q2, &rs, &pool2, &clk, 1, BATCH_FRAGS, BATCH_TEXT, gz_threads);
+        t2 = std::thread(reader_main, a->in2, &q2, &rs, &pool2, &clk, 1, BATCH_FRAGS, BATCH_TEXT, gz_threads,
+                         engines[G > 1 ? 1 : 0]->device);
 
     // writer: consumes batches in order; each arrives after its stream was synchronised.  The second
     // mate file is written by a helper so that both files are written at the same time.
