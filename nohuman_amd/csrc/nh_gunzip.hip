@@ -9,6 +9,7 @@
 
 #include <errno.h>
 #include <fcntl.h>
+#include <stddef.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -28,11 +29,18 @@ namespace gz {
 
 constexpr uint32_t WSIZE = 32768;
 #ifndef NH_GZ_NEAR
-#define NH_GZ_NEAR 8192  // symbols of the window kept in LDS (a power of two <= 32768); older sources come back from the output in HBM
+#define NH_GZ_NEAR 4096  // symbols of the window kept in LDS (a power of two, 4096 .. 32768); older sources come back from the output in HBM
 #endif
 constexpr uint32_t NEARSZ = NH_GZ_NEAR;
 constexpr int ROOT = 10, DROOT = 8;
 constexpr uint32_t MAX_MEMBERS = 4;  // member ends one chunk can record
+// k_inflate decodes a BATCH of tokens (at most 64, a lane each) before any of them is expanded: a batch stops growing at
+// SPAN_LIMIT symbols and so writes at most AHEAD symbols beyond its start.  A source at most RING_DMAX symbols back is
+// in the LDS ring whatever the batch has written ahead; older ones were flushed to HBM long ago (static_assert below).
+constexpr uint32_t SPAN_LIMIT = 768, AHEAD = SPAN_LIMIT + 257, FLUSH_AT = 256;
+constexpr uint32_t RING_DMAX = NEARSZ - AHEAD - 64;
+static_assert(NEARSZ >= 4096 && (NEARSZ & (NEARSZ - 1)) == 0 && NEARSZ <= WSIZE, "ring size");
+static_assert(RING_DMAX >= 2 * AHEAD + FLUSH_AT + 258, "a source older than the ring must already be flushed");
 constexpr uint64_t NONE = ~0ull;
 constexpr uint32_t NOIDX = 0xFFFFFFFFu;
 
@@ -67,6 +75,9 @@ struct ChunkDesc {  // one per stretch of the piece
     uint32_t m_off[MAX_MEMBERS], m_crc[MAX_MEMBERS], m_isize[MAX_MEMBERS];
     uint32_t piece_crc[MAX_MEMBERS + 1];  // k_crc: CRC-32 of the text between the chunk's start, its member ends, its end
     uint32_t pad2;
+    // NOHUMAN_GZDEV_PROF (k_inflate3 built with NH_GZ_PROF): cycles (s_memtime) in header + tables, the lanes' decode, the
+    // walk, the expansion, flushes, all; then windows, tokens, matches, generic copies, slow tokens, blocks
+    uint64_t prof[12];
 };
 
 struct SegResult {  // k_finish
@@ -95,6 +106,7 @@ struct Lds {
     uint16_t code[320];
     uint8_t lens[320];
     uint16_t tmp[40];
+    uint32_t inbuf[128];  // k_inflate3: 512 bytes of the input as a ring of dwords (dword d of the buffer at d & 127)
 };
 
 __constant__ uint16_t LBASE[29] = {3, 4, 5, 6, 7, 8, 9, 10, 11, 13, 15, 17, 19, 23, 27, 31, 35, 43, 51, 59, 67, 83, 99, 115, 131, 163, 195, 227, 258};
@@ -167,9 +179,11 @@ __device__ __forceinline__ uint32_t entry_of(const Lds &S, int mode, uint32_t s,
     if (s == 256u) return l | (2u << 28);
     return l | ((uint32_t)S.lext[s - 257u] << 4) | ((uint32_t)S.lbase[s - 257u] << 8) | (1u << 28);
 }
+// (Everything that takes pointers into the LDS is force-inlined: out of line they become flat pointers, and the
+//  LDS-to-flat cast of this compiler version does not survive the machine verifier.)
 // counts, canonical symbol list, codes and root table of one alphabet (lens[0..n) in LDS); mode 0: the code-length
 // code, 1: literals / lengths, 2: distances.  False: the lengths are over-subscribed (no prefix code).
-__device__ bool build(Lds &S, const uint8_t *lens, int n, uint16_t *count, uint16_t *symlist, uint32_t *root, int rootbits, int mode,
+__device__ __forceinline__ bool build(Lds &S, const uint8_t *lens, int n, uint16_t *count, uint16_t *symlist, uint32_t *root, int rootbits, int mode,
                       int lane) {
     LDS_ORDER();
     uint32_t over = 0;
@@ -232,7 +246,7 @@ __device__ __forceinline__ uint32_t slow_symbol(uint64_t w, const uint16_t *coun
 }
 
 // the header of a dynamic block behind its three type bits: the code lengths of both alphabets into S.lens[0 .. nlit + ndist)
-__device__ uint32_t parse_dynamic(Lds &S, BitIn &bi, uint64_t &bitpos, int lane, int &nlit, int &ndist) {
+__device__ __forceinline__ uint32_t parse_dynamic(Lds &S, BitIn &bi, uint64_t &bitpos, int lane, int &nlit, int &ndist) {
     uint64_t w = bi.fetch(bitpos, lane);
     nlit = (int)(w & 31) + 257;
     ndist = (int)((w >> 5) & 31) + 1;
@@ -301,7 +315,7 @@ __device__ __forceinline__ void load_bases(Lds &S, int lane) {
 // Does a non-final dynamic block header start at bit `cand`?  The seam test of the host reader: the code lengths must
 // decode, both codes must be complete (the distance code may have a single symbol), end-of-block must have a code --
 // and the first tokens of the block must walk (a header that passes by chance decodes into nonsense soon).
-__device__ bool plausible_block(Lds &S, const uint32_t *in, uint64_t cand, uint64_t valid_bits, int lane) {
+__device__ __forceinline__ bool plausible_block(Lds &S, const uint32_t *in, uint64_t cand, uint64_t valid_bits, int lane) {
     BitIn bi;
     bi.init(in, cand, lane);
     uint64_t bp = cand + 3;
@@ -700,6 +714,1172 @@ __global__ __launch_bounds__(64) void k_inflate(const uint32_t *in, uint64_t val
     }
 }
 
+// =====================================================================================================================
+// Version 2 of the two heavy kernels (round 4, profiles/r04_inflate_summary.txt).  What version 1 above spends its time on:
+// k_inflate ~1000 cycles a token in a chain of dependent latencies (bit fetch by three v_readlane, root table in LDS,
+// distance table in LDS, the window read of the copy, a store instruction per literal, vmcnt(0) waits behind those
+// stores); k_search nine tenths of its time in the wave-serial header parse of candidates that fail it.
+//   k_inflate2  (1) the root tables live in REGISTERS (1024 + 256 entries = 20 VGPRs, a lookup is s_set_gpr_idx +
+//               v_readlane), the bit buffer in scalars: a token's decode touches neither LDS nor memory; (2) tokens are
+//               parked in lanes (length, distance / literal, position) and expanded a batch at a time: literals by
+//               one store of all their lanes, matches whose sources lie before the group's first output overlapped four
+//               at a time; (3) the ring goes to HBM 64 symbols an instruction, not a store per token.
+//   k_search2   candidates that pass the cheap test are collected 64 at a time and their headers decoded IN PARALLEL,
+//               a lane each (own bit reader, own 7-bit table of the code-length code in LDS); only what survives that
+//               -- block starts, and one chance hit in 10^8 -- goes to the wave-wide parse and trial walk.
+// =====================================================================================================================
+struct BitRd {  // wave-uniform bit reader: 128 dwords of input in two registers a lane, 64 bits of them in scalars
+    const uint32_t *in;
+    uint32_t wbase;  // dword index of winA's lane 0
+    uint32_t winA, winB;
+    uint32_t dwi;    // next dword to take, relative to wbase (< 64 after rotate())
+    uint64_t bb;
+    uint32_t bc;
+    __device__ __forceinline__ void init(const uint32_t *p, uint64_t bitpos, int lane) {
+        in = p;
+        wbase = (uint32_t)(bitpos >> 5) & ~63u;
+        winA = in[wbase + lane];
+        winB = in[wbase + 64 + lane];
+        __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
+        dwi = (uint32_t)(bitpos >> 5) - wbase;
+        bb = 0;
+        bc = 0;
+        ensure32();
+        drop((uint32_t)bitpos & 31u);
+    }
+    __device__ __forceinline__ void rotate(int lane) {  // winA is used up
+        winA = winB;
+        wbase += 64u;
+        dwi -= 64u;
+        winB = in[wbase + 64 + lane];
+        // waited for HERE, once per 256 bytes of input (left to the compiler, every later use would wait for vmcnt(0) too)
+        __builtin_amdgcn_s_waitcnt(0x0F70);
+    }
+    __device__ __forceinline__ void ensure32(int lane = -1) {  // at least 32 valid bits
+        if (bc < 32u) {
+            if (dwi >= 64u) rotate(lane < 0 ? (int)threadIdx.x : lane);
+            const uint32_t v = rl(winA, dwi);
+            dwi++;
+            bb |= (uint64_t)v << bc;
+            bc += 32u;
+        }
+    }
+    __device__ __forceinline__ uint32_t peek(uint32_t n) const { return (uint32_t)bb & ((1u << n) - 1u); }  // n <= 31
+    __device__ __forceinline__ void drop(uint32_t n) {
+        bb >>= n;
+        bc -= n;
+    }
+    __device__ __forceinline__ uint32_t take(uint32_t n) {  // n <= 31, after ensure32()
+        const uint32_t v = peek(n);
+        drop(n);
+        return v;
+    }
+    __device__ __forceinline__ uint64_t bitpos() const { return (uint64_t)(wbase + dwi) * 32u - bc; }
+    __device__ __forceinline__ void align8() { drop(bc & 7u); }  // (dwords are whole bytes: the buffer's bit count mod 8 is the stream's)
+};
+
+// v = its old value, with lane `lane` (uniform) set to `val` (uniform).  (clang has no builtin for v_writelane_b32)
+__device__ __forceinline__ uint32_t wlane(uint32_t old, uint32_t val, uint32_t lane) {
+    // (one scalar operand per VALU instruction on gfx9: the lane select rides in M0)
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tv_writelane_b32 %0, %1, m0" : "+v"(old) : "s"(val), "s"(lane) : "m0");
+    return old;
+}
+__device__ __forceinline__ uint32_t lookup16(const uint32_t (&t)[16], uint32_t idx) {  // idx uniform, < 1024
+    const uint32_t v = t[idx >> 6];
+    return (uint32_t)__builtin_amdgcn_readlane((int)v, (int)(idx & 63u));
+}
+__device__ __forceinline__ uint32_t lookup4(const uint32_t (&t)[4], uint32_t idx) {  // idx uniform, < 256
+    const uint32_t v = t[idx >> 6];
+    return (uint32_t)__builtin_amdgcn_readlane((int)v, (int)(idx & 63u));
+}
+
+// code lengths of a dynamic block through the BitRd (the twin of parse_dynamic above)
+__device__ __forceinline__ uint32_t parse_dynamic2(Lds &S, BitRd &br, int lane, int &nlit, int &ndist) {
+    br.ensure32(lane);
+    nlit = (int)br.take(5) + 257;
+    ndist = (int)br.take(5) + 1;
+    const int ncl = (int)br.take(4) + 4;
+    if (nlit > 286 || ndist > 30) return ST_HEADER;
+    LDS_ORDER();
+    if (lane < 19) S.lens[lane] = 0;
+    LDS_ORDER();
+    for (int i = 0; i < ncl; i++) {
+        br.ensure32(lane);
+        const uint32_t v = br.take(3);
+        if (lane == 0) S.lens[CLORDER[i]] = (uint8_t)v;
+    }
+    if (!build(S, S.lens, 19, S.lcount, S.lsym, S.clt, 7, 0, lane)) return ST_HEADER;
+    const uint32_t c0 = S.clt[lane], c1 = S.clt[64 + lane];  // the 7-bit table of the code-length code: two registers
+    int i = 0;
+    uint32_t prev = 0;
+    while (i < nlit + ndist) {
+        br.ensure32(lane);
+        const uint32_t ix = br.peek(7);
+        const uint32_t e = ix < 64u ? rl(c0, ix) : rl(c1, ix - 64u);
+        const uint32_t l = e & 15u, sym = e >> 8;
+        if (l == 0) return ST_HEADER;
+        br.drop(l);
+        uint32_t rep = 1, val = sym;
+        if (sym == 16) {
+            if (i == 0) return ST_HEADER;
+            rep = 3 + br.take(2);
+            val = prev;
+        } else if (sym == 17) {
+            rep = 3 + br.take(3);
+            val = 0;
+        } else if (sym == 18) {
+            rep = 11 + br.take(7);
+            val = 0;
+        }
+        if (i + (int)rep > nlit + ndist) return ST_HEADER;
+        for (uint32_t k = (uint32_t)lane; k < rep; k += 64) S.lens[i + k] = (uint8_t)val;  // (lens is not read while it is written: the cl code has its own copy in c0 / c1)
+        i += (int)rep;
+        prev = val;
+    }
+    LDS_ORDER();
+    if (S.lens[256] == 0) return ST_HEADER;  // no end-of-block code
+    return 0;
+}
+
+__global__ __launch_bounds__(64) void k_inflate2(const uint32_t *in, uint64_t valid_bits, uint32_t at_eof, ChunkDesc *desc, uint16_t *sym,
+                                                 uint32_t slot_syms, uint32_t only) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    Lds &S = *(Lds *)smem;
+    const int lane = (int)threadIdx.x;
+    const uint32_t c = only != NOIDX ? only : blockIdx.x;
+    ChunkDesc &cd = desc[c];
+    if (cd.bit_start == NONE) {
+        if (lane == 0) {
+            cd.bit_end = 0;
+            cd.out_len = 0;
+            cd.status = 0;
+            cd.n_members = 0;
+            cd.flags = 0;
+            cd.blocks = 0;
+        }
+        return;
+    }
+    constexpr uint32_t M = NEARSZ - 1;
+    // the unknown 32 KiB before the chunk as markers: the newest NEARSZ of them in the ring (position q of the stream,
+    // counted from the chunk's first symbol, lives at q & M; position -k holds marker 0x8000 | (32768 - k))
+    for (uint32_t i = (uint32_t)lane; i < NEARSZ; i += 64) S.window[i] = (uint16_t)(0x8000u | (WSIZE - NEARSZ + i));
+    load_bases(S, lane);
+    const uint64_t stop_bit = cd.stop_bit;
+    uint16_t *o = sym + (uint64_t)c * slot_syms;
+    uint32_t op = 0, flushed = 0;  // symbols decoded; symbols in HBM
+    const uint32_t cap = cd.cap;
+    const uint8_t *bytes = (const uint8_t *)in;
+    BitRd br;
+    br.init(in, cd.bit_start, lane);
+    uint32_t status = 0, blocks = 0, n_members = 0, flags = 0;
+    uint32_t floor_op = 0;
+    bool fresh_member = false;
+    uint32_t TL[16], TD[4];                 // root tables of the block's two codes, in registers
+    uint32_t tlen = 0, tval = 0, tpos = 0;  // this lane's token of the batch: symbols, distance (bit 16: literal, low byte), offset in the batch
+    auto flush_to = [&](uint32_t target) {  // ring -> HBM, 64 symbols an instruction
+        for (uint32_t p = flushed + (uint32_t)lane; p < target; p += 64) o[p] = S.window[p & M];
+        flushed = target;
+    };
+    while (status == 0) {
+        uint64_t bitpos = br.bitpos();
+        if (bitpos >= stop_bit) break;  // a block boundary at or behind the stop position
+        if (bitpos + 3 > valid_bits) {
+            status = ST_INPUT;
+            break;
+        }
+        br.ensure32(lane);
+        const uint32_t bfinal = br.take(1), btype = br.take(2);
+        blocks++;
+        if (btype == 0) {  // stored: the bytes go straight from the input to the output (and the ring)
+            br.align8();
+            br.ensure32(lane);
+            bitpos = br.bitpos();
+            if (bitpos + 32 > valid_bits) {
+                status = ST_INPUT;
+                break;
+            }
+            const uint32_t len = br.take(16);
+            br.ensure32(lane);
+            const uint32_t nlen = br.take(16);
+            if ((len ^ nlen) != 0xFFFFu) {
+                status = ST_STORED;
+                break;
+            }
+            bitpos += 32;
+            if (bitpos + 8ull * len > valid_bits) {
+                status = ST_INPUT;
+                break;
+            }
+            if ((uint64_t)op + len > cap) {
+                status = ST_ROOM;
+                break;
+            }
+            flush_to(op);
+            const uint8_t *src = bytes + (bitpos >> 3);
+            asm volatile("" ::: "memory");
+            for (uint32_t i = (uint32_t)lane; i < len; i += 64) {
+                const uint16_t v = src[i];
+                S.window[(op + i) & M] = v;
+                o[op + i] = v;
+            }
+            LDS_ORDER();
+            op += len;
+            flushed = op;
+            if (len) br.init(in, bitpos + 8ull * len, lane);
+        } else if (btype == 3) {
+            status = ST_BTYPE;
+            break;
+        } else {
+            int nlit, ndist;
+            if (btype == 1) {  // fixed codes
+                LDS_ORDER();
+                for (int s = lane; s < 288; s += 64) S.lens[s] = s < 144 ? 8 : s < 256 ? 9 : s < 280 ? 7 : 8;
+                if (lane < 32) S.lens[288 + lane] = 5;
+                nlit = 288;
+                ndist = 30;
+            } else {
+                status = parse_dynamic2(S, br, lane, nlit, ndist);
+                if (status) break;
+            }
+            if (!build(S, S.lens, nlit, S.lcount, S.lsym, S.lit, ROOT, 1, lane) ||
+                !build(S, S.lens + nlit, ndist, S.dcount, S.dsym, S.dist, DROOT, 2, lane)) {
+                status = ST_HEADER;
+                break;
+            }
+#pragma unroll
+            for (int j = 0; j < 16; j++) TL[j] = S.lit[j * 64 + lane];
+#pragma unroll
+            for (int j = 0; j < 4; j++) TD[j] = S.dist[j * 64 + lane];
+            // ---- the symbols of the block, a batch of tokens at a time
+            bool eob = false;
+            while (!eob && status == 0) {
+                // phase 1: decode (scalar unit; no LDS, no memory)
+                uint32_t n = 0, span = 0;
+                while (n < 64u && span < SPAN_LIMIT) {
+                    br.ensure32(lane);
+                    uint32_t e = lookup16(TL, br.peek(ROOT));
+                    if (e == 0) {  // a code longer than the root
+                        uint32_t l;
+                        const uint32_t sy = slow_symbol(br.bb, S.lcount, S.lsym, l);
+                        if (l == 0 || sy >= 286u) {
+                            status = ST_LITLEN;
+                            break;
+                        }
+                        e = entry_of(S, 1, uni(sy), uni(l));
+                        e = uni(e);
+                    }
+                    br.drop(e & 15u);
+                    const uint32_t kind = e >> 28;
+                    if (kind == 0) {
+                        tlen = wlane(tlen, 1u, n);
+                        tval = wlane(tval, 0x10000u | ((e >> 8) & 0xFFu), n);
+                        tpos = wlane(tpos, span, n);
+                        n++;
+                        span++;
+                        continue;
+                    }
+                    if (kind == 2) {
+                        eob = true;
+                        break;
+                    }
+                    const uint32_t lext = (e >> 4) & 15u;
+                    const uint32_t len = ((e >> 8) & 0xFFFFu) + br.take(lext);  // code <= 15 bits + 5 extra: within the 32 ensured
+                    br.ensure32(lane);
+                    uint32_t de = lookup4(TD, br.peek(DROOT));
+                    if (de == 0) {
+                        uint32_t dl;
+                        const uint32_t dsymv = slow_symbol(br.bb, S.dcount, S.dsym, dl);
+                        if (dl == 0 || dsymv >= 30u) {
+                            status = ST_DIST;
+                            break;
+                        }
+                        de = uni(entry_of(S, 2, uni(dsymv), uni(dl)));
+                    }
+                    br.drop(de & 15u);
+                    const uint32_t dext = (de >> 4) & 15u;
+                    const uint32_t dist = ((de >> 8) & 0xFFFFu) + br.take(dext);
+                    const uint32_t at = op + span;
+                    if (fresh_member ? dist > at - floor_op : dist > at + WSIZE) {
+                        status = ST_FAR;
+                        break;
+                    }
+                    tlen = wlane(tlen, len, n);
+                    tval = wlane(tval, dist, n);
+                    tpos = wlane(tpos, span, n);
+                    n++;
+                    span += len;
+                }
+                if (status) break;
+                if (br.bitpos() > valid_bits) {  // (a batch reads at most 64 x 48 bits past the last valid one: the buffer is padded)
+                    status = ST_INPUT;
+                    break;
+                }
+                if ((uint64_t)op + span > cap) {
+                    status = ST_ROOM;
+                    break;
+                }
+                // phase 2: expand.  LDS operations of one wave execute in order: a read issued behind a write sees it.
+                asm volatile("" ::: "memory");
+                const bool act = (uint32_t)lane < n;
+                const bool isl = act && (tval & 0x10000u);
+                if (isl) S.window[(op + tpos) & M] = (uint16_t)(tval & 0xFFu);
+                uint64_t mm = __ballot(act && !isl);
+                while (mm) {
+                    uint32_t Lg[4], Pg[4];
+                    uint16_t vg[4];
+                    int cnt = 0;
+                    uint32_t pfirst = 0;
+                    bool generic = false;
+                    uint32_t gL = 0, gD = 0, gP = 0;
+#pragma unroll
+                    for (int g = 0; g < 4; g++) {
+                        if (!mm || generic) break;
+                        const uint32_t j = (uint32_t)__builtin_ctzll(mm);
+                        const uint32_t L = rl(tlen, j), D = rl(tval, j), P = op + rl(tpos, j);
+                        const bool fast = D <= RING_DMAX && L <= 64u && D >= L;
+                        if (g == 0) {
+                            if (!fast) {
+                                generic = true;
+                                gL = L, gD = D, gP = P;
+                                mm &= mm - 1;
+                                break;
+                            }
+                            pfirst = P;
+                        } else if (!(fast && P - D + L <= pfirst)) {  // its source may be what the group is about to write
+                            break;
+                        }
+                        vg[g] = S.window[(P - D + (uint32_t)lane) & M];
+                        Lg[g] = L;
+                        Pg[g] = P;
+                        cnt = g + 1;
+                        mm &= mm - 1;
+                    }
+#pragma unroll
+                    for (int g = 0; g < 4; g++)
+                        if (g < cnt && (uint32_t)lane < Lg[g]) S.window[(Pg[g] + (uint32_t)lane) & M] = vg[g];
+                    if (generic) {  // long, overlapping or far: every lane a symbol, 64 at a time; with D < L the pattern repeats
+                        if (gD > RING_DMAX) __builtin_amdgcn_s_waitcnt(0x0F70);  // what was flushed is in HBM
+                        for (uint32_t i = (uint32_t)lane; i < gL; i += 64) {
+                            const uint32_t from = gD >= gL ? i : i % gD;
+                            uint16_t v;
+                            if (gD <= RING_DMAX) {
+                                v = S.window[(gP - gD + from) & M];
+                            } else if (gP + from >= gD) {  // older than the ring, inside the chunk: from the output
+                                v = __hip_atomic_load(&o[gP + from - gD], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            } else {  // older than the ring, before the chunk: the marker itself
+                                v = (uint16_t)(0x8000u | (gP + WSIZE - gD + from));
+                            }
+                            S.window[(gP + i) & M] = v;
+                        }
+                    }
+                }
+                asm volatile("" ::: "memory");
+                op += span;
+                if (op - flushed >= FLUSH_AT) flush_to(op);
+            }
+            if (status) break;
+        }
+        if (bfinal) {
+            // ---- the member ends: trailer (CRC-32, ISIZE), then another member's header, or the end of the stream
+            br.align8();
+            bitpos = br.bitpos();
+            uint64_t q = bitpos >> 3;
+            const uint64_t valid_bytes = valid_bits >> 3;
+            if (q + 8 > valid_bytes) {
+                status = ST_INPUT;
+                break;
+            }
+            if (n_members == MAX_MEMBERS) {
+                status = ST_MEMBERS;
+                break;
+            }
+            const uint64_t tr = bits_at(bytes, q * 8);
+            if (lane == 0) {
+                cd.m_off[n_members] = op;
+                cd.m_crc[n_members] = (uint32_t)tr;
+                cd.m_isize[n_members] = (uint32_t)(tr >> 32);
+            }
+            n_members++;
+            q += 8;
+            bool member = false, trunc = false;
+            if (q == valid_bytes && at_eof) {
+                member = false;
+            } else if (q + 10 > valid_bytes) {
+                const uint64_t hv = bits_at(bytes, q * 8);
+                if (at_eof && !(q + 2 <= valid_bytes && (hv & 0xFFFF) == 0x8B1F)) member = false;
+                else trunc = true;
+            } else {
+                const uint64_t hv = bits_at(bytes, q * 8);
+                const uint32_t flg = (uint32_t)(hv >> 24) & 0xFFu;
+                if ((hv & 0xFFFFFF) != 0x088B1Fu || (flg & 0xE0u)) {
+                    member = false;  // bytes that are no gzip member: ignored like gzip does
+                } else {
+                    member = true;
+                    uint64_t p = q + 10;
+                    if (flg & 4u) {
+                        if (p + 2 > valid_bytes) trunc = true;
+                        else {
+                            const uint32_t xlen = (uint32_t)bits_at(bytes, p * 8) & 0xFFFFu;
+                            p += 2 + xlen;
+                            if (p > valid_bytes) trunc = true;
+                        }
+                    }
+                    for (uint32_t bit = 8; bit <= 16 && !trunc; bit <<= 1)
+                        if (flg & bit) {
+                            for (;;) {
+                                const uint64_t pp = p + (uint64_t)lane;
+                                const bool z = pp < valid_bytes && bytes[pp] == 0;
+                                const uint64_t zm = __ballot(z);
+                                if (zm) {
+                                    p += (uint64_t)__builtin_ctzll(zm) + 1;
+                                    break;
+                                }
+                                p += 64;
+                                if (p >= valid_bytes) {
+                                    trunc = true;
+                                    break;
+                                }
+                            }
+                        }
+                    if (!trunc && (flg & 2u)) {
+                        p += 2;
+                        if (p > valid_bytes) trunc = true;
+                    }
+                    q = p;
+                }
+            }
+            if (trunc) {
+                status = ST_GZHEAD;
+                break;
+            }
+            if (!member) {
+                flags |= 1u;  // the stream ends here
+                br.init(in, q * 8, lane);
+                break;
+            }
+            br.init(in, q * 8, lane);
+            fresh_member = true;
+            floor_op = op;
+        }
+    }
+    flush_to(op);
+    if (lane == 0) {
+        cd.status = status;
+        cd.blocks = blocks;
+        cd.bit_end = br.bitpos();
+        cd.out_len = op;
+        cd.n_members = n_members;
+        cd.flags = flags;
+    }
+}
+
+// ---- k_inflate3: the decode phase lane-parallel, the LDS and register diet for occupancy -------------------------------
+// Measured on version 2 and on the first cut of this kernel (NH_GZ_PROF, profiles/r04_inflate_summary.txt): a wave alone
+// on a chunk runs its uniform control flow at 10-20 cycles an instruction -- nothing in flight but its own dependent
+// chain --, 1300 cycles a match in an expansion loop with an integer modulo, 400 a token in the walk; 16 KB of LDS and
+// 111 registers let nine waves a CU hide that.  So: (1) the 64 lanes decode the tokens that WOULD start at the next 64
+// bit positions (16-bit root tables in LDS: two gathers for all of them), the real chain is walked with one v_readlane
+// a token; (2) every match of up to 64 symbols -- overlapping ones too, the run of a quality string -- is ONE read and
+// one write of the ring (lane % distance by a reciprocal held in a register); (3) ring of 2048 symbols, 16-bit tables,
+// build scratch shared with the input ring: 7.9 KB of LDS a wave, twenty waves a CU.
+constexpr uint32_t NEAR3 = 2048, M3 = NEAR3 - 1;
+constexpr uint32_t SPAN3 = 232, AHEAD3 = SPAN3 + 257, FLUSH3 = 256;
+constexpr uint32_t RING_DMAX3 = NEAR3 - AHEAD3 - 64;
+static_assert(RING_DMAX3 >= 2 * AHEAD3 + FLUSH3 + 258, "a source older than the ring must already be flushed");
+constexpr int ROOT3 = 9, DROOT3 = 8;
+
+struct Lds3 {
+    uint16_t ring[NEAR3];
+    // root tables, 16 bits an entry.  literals / lengths: bits 0-3 code length (0: longer than the root), 4-5 kind (0 literal,
+    // 1 length, 2 end of block), 6-13 the literal, or length symbol - 257 (5 bits) and its extra bits (3); distances: bits
+    // 0-3 code length, 4-8 distance symbol, 9-12 its extra bits
+    uint16_t lit[1 << ROOT3];
+    uint16_t dist[1 << DROOT3];
+    uint16_t clt[128];  // the code-length code: bits 0-3 length, 8-12 symbol
+    uint32_t lb[32], db[32];  // base | extra bits << 16 of the length / distance symbols
+    uint16_t lsym[288], dsym[32];
+    uint16_t lcount[16], dcount[16];
+    uint8_t lens[320];
+    uint16_t tmp[40];
+    union {
+        uint32_t inbuf[128];  // 512 bytes of the input as a ring of dwords (dword d of the buffer at d & 127): live inside a block
+        uint16_t code[320];   // build(): the symbols' codes, live between the blocks
+    };
+};
+
+__device__ __forceinline__ uint32_t lit_entry3(uint32_t s, uint32_t l) {
+    if (s < 256u) return l | (s << 6);
+    if (s == 256u) return l | (2u << 4);
+    if (s >= 286u) return 0u;  // (the two length symbols a fixed block has codes for but no meaning: the canonical walk reports them)
+    const uint32_t i = s - 257u;
+    return l | (1u << 4) | ((i | ((uint32_t)LEXT[i] << 5)) << 6);
+}
+__device__ __forceinline__ uint32_t dist_entry3(uint32_t s, uint32_t l) { return s >= 30u ? 0u : (l | (s << 4) | ((uint32_t)DEXT[s] << 9)); }
+
+// build() for Lds3: counts, canonical symbol list, codes, 16-bit root table; mode 0 the code-length code, 1 literals /
+// lengths, 2 distances.  False: over-subscribed.
+__device__ __forceinline__ bool build3(Lds3 &S, const uint8_t *lens, int n, uint16_t *count, uint16_t *symlist, uint16_t *root, int rootbits,
+                                       int mode, int lane) {
+    LDS_ORDER();
+    uint32_t over = 0;
+    if (lane == 0) {
+        uint16_t *offs = S.tmp, *next = S.tmp + 16;
+        for (int l = 0; l < 16; l++) count[l] = 0;
+        for (int s = 0; s < n; s++) count[lens[s]]++;
+        count[0] = 0;
+        uint32_t o = 0, c = 0;
+        int left = 1;
+        for (int l = 1; l < 16; l++) {
+            left = (left << 1) - (int)count[l];
+            if (left < 0) over = 1;
+            offs[l] = (uint16_t)o;
+            o += count[l];
+            c = (c + count[l - 1]) << 1;
+            next[l] = (uint16_t)c;
+        }
+        if (!over)
+            for (int s = 0; s < n; s++) {
+                const int l = lens[s];
+                if (l) {
+                    symlist[offs[l]++] = (uint16_t)s;
+                    S.code[s] = next[l]++;
+                }
+            }
+    }
+    if (uni(over)) return false;
+    for (int k = lane; k < (1 << rootbits); k += 64) root[k] = 0;
+    LDS_ORDER();
+    for (int s = lane; s < n; s += 64) {
+        const uint32_t l = lens[s];
+        if (l && l <= (uint32_t)rootbits) {
+            const uint32_t r = __builtin_bitreverse32((uint32_t)S.code[s]) >> (32 - l);
+            const uint32_t e = mode == 0 ? (l | ((uint32_t)s << 8)) : mode == 1 ? lit_entry3((uint32_t)s, l) : dist_entry3((uint32_t)s, l);
+            for (uint32_t k = r; k < (1u << rootbits); k += 1u << l) root[k] = (uint16_t)e;
+        }
+    }
+    LDS_ORDER();
+    return true;
+}
+
+__device__ __forceinline__ uint32_t parse_dynamic3(Lds3 &S, BitRd &br, int lane, int &nlit, int &ndist) {
+    br.ensure32(lane);
+    nlit = (int)br.take(5) + 257;
+    ndist = (int)br.take(5) + 1;
+    const int ncl = (int)br.take(4) + 4;
+    if (nlit > 286 || ndist > 30) return ST_HEADER;
+    LDS_ORDER();
+    if (lane < 19) S.lens[lane] = 0;
+    LDS_ORDER();
+    for (int i = 0; i < ncl; i++) {
+        br.ensure32(lane);
+        const uint32_t v = br.take(3);
+        if (lane == 0) S.lens[CLORDER[i]] = (uint8_t)v;
+    }
+    if (!build3(S, S.lens, 19, S.lcount, S.lsym, S.clt, 7, 0, lane)) return ST_HEADER;
+    const uint32_t c0 = S.clt[lane], c1 = S.clt[64 + lane];  // the 7-bit table of the code-length code: two registers
+    int i = 0;
+    uint32_t prev = 0;
+    while (i < nlit + ndist) {
+        br.ensure32(lane);
+        const uint32_t ix = br.peek(7);
+        const uint32_t e = ix < 64u ? rl(c0, ix) : rl(c1, ix - 64u);
+        const uint32_t l = e & 15u, sym = e >> 8;
+        if (l == 0) return ST_HEADER;
+        br.drop(l);
+        uint32_t rep = 1, val = sym;
+        if (sym == 16) {
+            if (i == 0) return ST_HEADER;
+            rep = 3 + br.take(2);
+            val = prev;
+        } else if (sym == 17) {
+            rep = 3 + br.take(3);
+            val = 0;
+        } else if (sym == 18) {
+            rep = 11 + br.take(7);
+            val = 0;
+        }
+        if (i + (int)rep > nlit + ndist) return ST_HEADER;
+        for (uint32_t k = (uint32_t)lane; k < rep; k += 64) S.lens[i + k] = (uint8_t)val;
+        i += (int)rep;
+        prev = val;
+    }
+    LDS_ORDER();
+    if (S.lens[256] == 0) return ST_HEADER;  // no end-of-block code
+    return 0;
+}
+
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(5, 8))) void k_inflate3(const uint32_t *in, uint64_t valid_bits,
+                                                                                              uint32_t at_eof, ChunkDesc *desc, uint16_t *sym,
+                                                                                              uint32_t slot_syms, uint32_t only) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    Lds3 &S = *(Lds3 *)smem;
+    const int lane = (int)threadIdx.x;
+    const uint32_t c = only != NOIDX ? only : blockIdx.x;
+    ChunkDesc &cd = desc[c];
+    if (cd.bit_start == NONE) {
+        if (lane == 0) {
+            cd.bit_end = 0;
+            cd.out_len = 0;
+            cd.status = 0;
+            cd.n_members = 0;
+            cd.flags = 0;
+            cd.blocks = 0;
+        }
+        return;
+    }
+    // the unknown 32 KiB before the chunk as markers: the newest NEAR3 of them in the ring (position q of the stream,
+    // counted from the chunk's first symbol, lives at q & M3; position -k holds marker 0x8000 | (32768 - k))
+    for (uint32_t i = (uint32_t)lane; i < NEAR3; i += 64) S.ring[i] = (uint16_t)(0x8000u | (WSIZE - NEAR3 + i));
+    if (lane < 29) S.lb[lane] = (uint32_t)LBASE[lane] | ((uint32_t)LEXT[lane] << 16);
+    if (lane < 30) S.db[lane] = (uint32_t)DBASE[lane] | ((uint32_t)DEXT[lane] << 16);
+    const uint32_t inv = lane ? (65536u + (uint32_t)lane - 1u) / (uint32_t)lane : 0u;  // lane d: ceil(65536 / d): x % d for x < 64 without a divide
+    LDS_ORDER();
+    const uint64_t stop_bit = cd.stop_bit;
+    uint16_t *o = sym + (uint64_t)c * slot_syms;
+    uint32_t op = 0, flushed = 0;  // symbols decoded; symbols in HBM
+    const uint32_t cap = cd.cap;
+    const uint8_t *bytes = (const uint8_t *)in;
+    BitRd br;
+    br.init(in, cd.bit_start, lane);
+    uint32_t status = 0, blocks = 0, n_members = 0, flags = 0;
+    uint32_t floor_op = 0;
+    bool fresh_member = false;
+    uint32_t tok = 0, tpos = 0;  // this lane's token of the window: literal 0x80000000 | byte, match distance | symbols << 16; offset in the window's output
+#ifdef NH_GZ_PROF
+    uint64_t pf[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    uint64_t tprev = __builtin_amdgcn_s_memtime();
+    const uint64_t tstart = tprev;
+#define GZ_STAMP(i)                                          \
+    do {                                                     \
+        const uint64_t t_ = __builtin_amdgcn_s_memtime();    \
+        pf[i] += t_ - tprev;                                 \
+        tprev = t_;                                          \
+    } while (0)
+#define GZ_COUNT(i, n) pf[i] += (n)
+#else
+#define GZ_STAMP(i)
+#define GZ_COUNT(i, n)
+#endif
+    auto flush_to = [&](uint32_t target) {  // ring -> HBM, 64 symbols an instruction
+        for (uint32_t p = flushed + (uint32_t)lane; p < target; p += 64) o[p] = S.ring[p & M3];
+        flushed = target;
+    };
+    // the fields of the token whose literal / length code has entry e (this lane's 64 bits of the stream in w):
+    // false when its distance code is longer than the root (de == 0)
+    auto fields = [&](uint32_t e, uint32_t de_in, bool have_de, uint64_t w, uint32_t &tok_o, uint32_t &info_o) -> bool {
+        const uint32_t l = e & 15u, kind = (e >> 4) & 3u, pay = (e >> 6) & 0xFFu;
+        const bool ism = kind == 1u;
+        const uint32_t lext = ism ? pay >> 5 : 0u;
+        const uint32_t w1 = (uint32_t)(w >> l);
+        const uint32_t de = have_de ? de_in : S.dist[(w1 >> lext) & ((1u << DROOT3) - 1u)];
+        const uint32_t lbv = S.lb[ism ? (pay & 31u) : 0u];
+        const uint32_t dl = de & 15u, dsy = (de >> 4) & 31u, dext = (de >> 9) & 15u;
+        const uint32_t dbv = S.db[dsy < 30u ? dsy : 0u];
+        const uint32_t len = (lbv & 0xFFFFu) + (w1 & ((1u << lext) - 1u));
+        const uint32_t dist = (dbv & 0xFFFFu) + ((uint32_t)(w >> (l + lext + dl)) & ((1u << dext) - 1u));
+        tok_o = ism ? (dist | (len << 16)) : (0x80000000u | pay);
+        info_o = (l + (ism ? lext + dl + dext : 0u)) | (kind << 6) | ((kind == 2u ? 0u : (ism ? len : 1u)) << 9);
+        return !(ism && de == 0u);
+    };
+    while (status == 0) {
+        uint64_t bitpos = br.bitpos();
+        if (bitpos >= stop_bit) break;  // a block boundary at or behind the stop position
+        if (bitpos + 3 > valid_bits) {
+            status = ST_INPUT;
+            break;
+        }
+        br.ensure32(lane);
+        const uint32_t bfinal = br.take(1), btype = br.take(2);
+        blocks++;
+        if (btype == 0) {  // stored: the bytes go straight from the input to the output (and the ring)
+            br.align8();
+            br.ensure32(lane);
+            bitpos = br.bitpos();
+            if (bitpos + 32 > valid_bits) {
+                status = ST_INPUT;
+                break;
+            }
+            const uint32_t len = br.take(16);
+            br.ensure32(lane);
+            const uint32_t nlen = br.take(16);
+            if ((len ^ nlen) != 0xFFFFu) {
+                status = ST_STORED;
+                break;
+            }
+            bitpos += 32;
+            if (bitpos + 8ull * len > valid_bits) {
+                status = ST_INPUT;
+                break;
+            }
+            if ((uint64_t)op + len > cap) {
+                status = ST_ROOM;
+                break;
+            }
+            flush_to(op);
+            const uint8_t *src = bytes + (bitpos >> 3);
+            asm volatile("" ::: "memory");
+            for (uint32_t i = (uint32_t)lane; i < len; i += 64) {
+                const uint16_t v = src[i];
+                S.ring[(op + i) & M3] = v;
+                o[op + i] = v;
+            }
+            LDS_ORDER();
+            op += len;
+            flushed = op;
+            if (len) br.init(in, bitpos + 8ull * len, lane);
+        } else if (btype == 3) {
+            status = ST_BTYPE;
+            break;
+        } else {
+            int nlit, ndist;
+            if (btype == 1) {  // fixed codes
+                LDS_ORDER();
+                for (int s = lane; s < 288; s += 64) S.lens[s] = s < 144 ? 8 : s < 256 ? 9 : s < 280 ? 7 : 8;
+                if (lane < 32) S.lens[288 + lane] = 5;
+                nlit = 288;
+                ndist = 30;
+            } else {
+                status = parse_dynamic3(S, br, lane, nlit, ndist);
+                if (status) break;
+            }
+            if (!build3(S, S.lens, nlit, S.lcount, S.lsym, S.lit, ROOT3, 1, lane) ||
+                !build3(S, S.lens + nlit, ndist, S.dcount, S.dsym, S.dist, DROOT3, 2, lane)) {
+                status = ST_HEADER;
+                break;
+            }
+            GZ_STAMP(0);
+            GZ_COUNT(11, 1);
+            // ---- the symbols of the block, a window of 64 bit positions at a time
+            bool eob = false;
+            uint64_t P = br.bitpos();                      // bit position of the next token
+            uint32_t in_upto = (uint32_t)(P >> 5) & ~63u;  // dwords of the input below this index are in the LDS ring (the newest 128)
+            LDS_ORDER();
+            while (!eob && status == 0) {
+                {
+                    const uint32_t need = (uint32_t)(P >> 5) + 6u;
+                    while (in_upto < need) {
+                        const uint32_t v = in[in_upto + (uint32_t)lane];
+                        S.inbuf[(in_upto + (uint32_t)lane) & 127u] = v;
+                        in_upto += 64u;
+                    }
+                    LDS_ORDER();
+                }
+                // phase 1: the token that would start at bit P + lane
+                const uint32_t bp = ((uint32_t)P & 31u) + (uint32_t)lane;
+                const uint32_t dwi = (uint32_t)(P >> 5) + (bp >> 5);
+                const uint32_t d0 = S.inbuf[dwi & 127u], d1 = S.inbuf[(dwi + 1u) & 127u], d2 = S.inbuf[(dwi + 2u) & 127u];
+                const uint32_t wlo = __builtin_amdgcn_alignbit(d1, d0, bp & 31u), whi = __builtin_amdgcn_alignbit(d2, d1, bp & 31u);
+                const uint64_t w = ((uint64_t)whi << 32) | wlo;  // 64 bits of the stream from bit P + lane
+                uint32_t info;  // bits 0-5 the token's bits, 6-7 kind (0 literal, 1 match, 2 end of block), 8 "not decoded yet", 9-17 symbols
+                {
+                    const uint32_t e = S.lit[wlo & ((1u << ROOT3) - 1u)];
+                    const bool okd = fields(e, 0u, false, w, tok, info);
+                    if (e == 0u || !okd) info |= 0x100u;
+                }
+                uint32_t pos = 0, span = 0;
+                uint64_t real = 0;
+                GZ_STAMP(1);
+                GZ_COUNT(6, 1);
+                // the walk along the real chain: one v_readlane a token
+                while (pos < 64u && span < SPAN3) {
+                    uint32_t inf = (uint32_t)__builtin_amdgcn_readlane((int)info, (int)pos);
+                    if (inf & 0x100u) {  // a code longer than a root table: the canonical walk, in the token's own lane
+                        GZ_COUNT(10, 1);
+                        if ((uint32_t)lane == pos) {
+                            uint32_t e = S.lit[wlo & ((1u << ROOT3) - 1u)];
+                            if (e == 0u) {
+                                uint32_t l2;
+                                const uint32_t sy = slow_symbol(w, S.lcount, S.lsym, l2);
+                                if (l2 != 0u && sy < 286u) e = lit_entry3(sy, l2);
+                            }
+                            if (e != 0u) {
+                                uint32_t t2, i2;
+                                bool ok = fields(e, 0u, false, w, t2, i2);
+                                if (!ok) {  // the distance code is a long one
+                                    const uint32_t l = e & 15u, lext = (e >> 11) & 7u;
+                                    uint32_t dl2;
+                                    const uint32_t dsy = slow_symbol(w >> (l + lext), S.dcount, S.dsym, dl2);
+                                    if (dl2 != 0u && dsy < 30u) ok = fields(e, dist_entry3(dsy, dl2), true, w, t2, i2);
+                                }
+                                if (ok) {
+                                    tok = t2;
+                                    info = i2;
+                                }
+                            }
+                        }
+                        inf = (uint32_t)__builtin_amdgcn_readlane((int)info, (int)pos);
+                        if (inf & 0x100u) {
+                            status = ST_LITLEN;
+                            break;
+                        }
+                    }
+                    if (((inf >> 6) & 3u) == 2u) {
+                        eob = true;
+                        pos += inf & 63u;
+                        break;
+                    }
+                    tpos = wlane(tpos, span, pos);
+                    real |= 1ull << pos;
+                    span += (inf >> 9) & 0x1FFu;
+                    pos += inf & 63u;
+                }
+                GZ_STAMP(2);
+                GZ_COUNT(7, (uint64_t)__popcll(real));
+                if (status) break;
+                P += pos;
+                if (P > valid_bits) {
+                    status = ST_INPUT;
+                    break;
+                }
+                if ((uint64_t)op + span > cap) {
+                    status = ST_ROOM;
+                    break;
+                }
+                // phase 2: expand.  LDS operations of one wave execute in order: a read issued behind a write sees it.
+                asm volatile("" ::: "memory");
+                const bool act = (real >> lane) & 1u;
+                const bool isl = act && (tok & 0x80000000u);
+                {   // a distance beyond the window (or beyond the start of a member that began in this chunk)
+                    const uint32_t at = op + tpos, dd = tok & 0xFFFFu;
+                    const bool far = act && !isl && (fresh_member ? dd > at - floor_op : dd > at + WSIZE);
+                    if (__ballot(far)) {
+                        status = ST_FAR;
+                        break;
+                    }
+                }
+                if (isl) S.ring[(op + tpos) & M3] = (uint16_t)(tok & 0xFFu);
+                const uint64_t mall = __ballot(act && !isl);
+                GZ_COUNT(8, (uint64_t)__popcll(mall));
+                // Far sources first.  A distance beyond the ring is longer than any match, so the source neither overlaps its
+                // own output nor anything this window writes: it lies in HBM (flushed a window ago at the latest) or before
+                // the chunk (markers).  All of the window's far matches of up to 64 symbols are loaded NOW -- one coalesced
+                // load each, past the L1 (sc1: the lines were written by this wave) -- and waited for once.
+                uint64_t mfar = __ballot(act && !isl && (tok & 0xFFFFu) > RING_DMAX3 && (tok >> 16) <= 64u);
+                uint16_t fv[4] = {0, 0, 0, 0};
+                uint64_t mf_done = 0;
+                if (mfar) {
+                    __builtin_amdgcn_s_waitcnt(0x0F70);  // what was flushed is in HBM
+                    uint64_t m2 = mfar;
+#pragma unroll
+                    for (int g = 0; g < 4; g++) {
+                        if (!m2) break;
+                        const uint32_t j = (uint32_t)__builtin_ctzll(m2);
+                        m2 &= m2 - 1;
+                        mf_done |= 1ull << j;
+                        const uint32_t t = (uint32_t)__builtin_amdgcn_readlane((int)tok, (int)j);
+                        const uint32_t Pj = op + (uint32_t)__builtin_amdgcn_readlane((int)tpos, (int)j);
+                        const uint32_t L = t >> 16, D = t & 0xFFFFu;
+                        const int32_t sp = (int32_t)(Pj - D) + lane;  // this lane's source position (negative: before the chunk)
+                        uint16_t v = (uint16_t)(0x8000u | (uint32_t)(sp + (int32_t)WSIZE));
+                        if ((uint32_t)lane < L && sp >= 0) v = __hip_atomic_load(&o[sp], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        fv[g] = v;
+                    }
+                }
+                // then the matches in order: the ring's own (one read, one write; with D < L the pattern repeats: lane % D),
+                // the far ones from their registers, long ones 64 symbols at a time
+                uint64_t mm = mall;
+                int fg = 0;
+                while (mm) {
+                    const uint32_t j = (uint32_t)__builtin_ctzll(mm);
+                    mm &= mm - 1;
+                    const uint32_t t = (uint32_t)__builtin_amdgcn_readlane((int)tok, (int)j);
+                    const uint32_t Pj = op + (uint32_t)__builtin_amdgcn_readlane((int)tpos, (int)j);
+                    const uint32_t L = t >> 16, D = t & 0xFFFFu;
+                    if ((mf_done >> j) & 1ull) {
+                        const uint16_t v = fg == 0 ? fv[0] : fg == 1 ? fv[1] : fg == 2 ? fv[2] : fv[3];
+                        fg++;
+                        if ((uint32_t)lane < L) S.ring[(Pj + (uint32_t)lane) & M3] = v;
+                    } else if (L <= 64u && D <= RING_DMAX3) {
+                        uint32_t from = (uint32_t)lane;
+                        if (D < 64u) {
+                            const uint32_t iv = (uint32_t)__builtin_amdgcn_readlane((int)inv, (int)D);
+                            from -= D * (((uint32_t)lane * iv) >> 16);
+                        }
+                        const uint16_t v = S.ring[(Pj - D + from) & M3];
+                        if ((uint32_t)lane < L) S.ring[(Pj + (uint32_t)lane) & M3] = v;
+                    } else {  // long (or the fifth far one of a window): every lane a symbol, 64 at a time
+                        GZ_COUNT(9, 1);
+                        if (D > RING_DMAX3) __builtin_amdgcn_s_waitcnt(0x0F70);
+                        for (uint32_t i = (uint32_t)lane; i < L; i += 64) {
+                            const uint32_t from = D >= L ? i : i % D;
+                            uint16_t v;
+                            if (D <= RING_DMAX3) {
+                                v = S.ring[(Pj - D + from) & M3];
+                            } else if (Pj + from >= D) {  // older than the ring, inside the chunk: from the output
+                                v = __hip_atomic_load(&o[Pj + from - D], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            } else {  // older than the ring, before the chunk: the marker itself
+                                v = (uint16_t)(0x8000u | (Pj + WSIZE - D + from));
+                            }
+                            S.ring[(Pj + i) & M3] = v;
+                        }
+                    }
+                }
+                asm volatile("" ::: "memory");
+                op += span;
+                GZ_STAMP(3);
+                if (op - flushed >= FLUSH3) flush_to(op);
+                GZ_STAMP(4);
+            }
+            if (status) break;
+            br.init(in, P, lane);  // the scalar reader goes on behind the block
+        }
+        if (bfinal) {
+            // ---- the member ends: trailer (CRC-32, ISIZE), then another member's header, or the end of the stream
+            br.align8();
+            bitpos = br.bitpos();
+            uint64_t q = bitpos >> 3;
+            const uint64_t valid_bytes = valid_bits >> 3;
+            if (q + 8 > valid_bytes) {
+                status = ST_INPUT;
+                break;
+            }
+            if (n_members == MAX_MEMBERS) {
+                status = ST_MEMBERS;
+                break;
+            }
+            const uint64_t tr = bits_at(bytes, q * 8);
+            if (lane == 0) {
+                cd.m_off[n_members] = op;
+                cd.m_crc[n_members] = (uint32_t)tr;
+                cd.m_isize[n_members] = (uint32_t)(tr >> 32);
+            }
+            n_members++;
+            q += 8;
+            bool member = false, trunc = false;
+            if (q == valid_bytes && at_eof) {
+                member = false;
+            } else if (q + 10 > valid_bytes) {
+                const uint64_t hv = bits_at(bytes, q * 8);
+                if (at_eof && !(q + 2 <= valid_bytes && (hv & 0xFFFF) == 0x8B1F)) member = false;
+                else trunc = true;
+            } else {
+                const uint64_t hv = bits_at(bytes, q * 8);
+                const uint32_t flg = (uint32_t)(hv >> 24) & 0xFFu;
+                if ((hv & 0xFFFFFF) != 0x088B1Fu || (flg & 0xE0u)) {
+                    member = false;  // bytes that are no gzip member: ignored like gzip does
+                } else {
+                    member = true;
+                    uint64_t p = q + 10;
+                    if (flg & 4u) {
+                        if (p + 2 > valid_bytes) trunc = true;
+                        else {
+                            const uint32_t xlen = (uint32_t)bits_at(bytes, p * 8) & 0xFFFFu;
+                            p += 2 + xlen;
+                            if (p > valid_bytes) trunc = true;
+                        }
+                    }
+                    for (uint32_t bit = 8; bit <= 16 && !trunc; bit <<= 1)
+                        if (flg & bit) {
+                            for (;;) {
+                                const uint64_t pp = p + (uint64_t)lane;
+                                const bool z = pp < valid_bytes && bytes[pp] == 0;
+                                const uint64_t zm = __ballot(z);
+                                if (zm) {
+                                    p += (uint64_t)__builtin_ctzll(zm) + 1;
+                                    break;
+                                }
+                                p += 64;
+                                if (p >= valid_bytes) {
+                                    trunc = true;
+                                    break;
+                                }
+                            }
+                        }
+                    if (!trunc && (flg & 2u)) {
+                        p += 2;
+                        if (p > valid_bytes) trunc = true;
+                    }
+                    q = p;
+                }
+            }
+            if (trunc) {
+                status = ST_GZHEAD;
+                break;
+            }
+            if (!member) {
+                flags |= 1u;  // the stream ends here
+                br.init(in, q * 8, lane);
+                break;
+            }
+            br.init(in, q * 8, lane);
+            fresh_member = true;
+            floor_op = op;
+        }
+    }
+    flush_to(op);
+#ifdef NH_GZ_PROF
+    pf[5] = __builtin_amdgcn_s_memtime() - tstart;
+    if (lane == 0)
+        for (int i = 0; i < 12; i++) cd.prof[i] = pf[i];
+#endif
+    if (lane == 0) {
+        cd.status = status;
+        cd.blocks = blocks;
+        cd.bit_end = br.bitpos();
+        cd.out_len = op;
+        cd.n_members = n_members;
+        cd.flags = flags;
+    }
+}
+
+// ---- k_search2 ------------------------------------------------------------------------------------------------------
+constexpr uint32_t CLROW = 129;  // bytes per lane of the code-length code's table (odd: the lanes' rows start in different banks)
+// One lane, one candidate: does a dynamic block header at bit `cand` decode into two complete codes with an end-of-block
+// symbol?  (Code lengths are not kept: Kraft sums as they come.)  tbl = this lane's 128 entries (length << 5 | symbol).
+// (the table is addressed as an offset into the workgroup's LDS: a pointer parameter would be a flat pointer here)
+__device__ __forceinline__ bool lane_header_ok(const uint8_t *bytes, uint64_t cand, uint64_t valid_bits, uint32_t tbl_off) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t lds_bytes[];
+    uint8_t *const tbl = lds_bytes + tbl_off;
+    uint64_t b = cand + 3;
+    uint64_t w = bits_at(bytes, b);
+    const uint32_t nlit = (uint32_t)(w & 31) + 257, ndist = (uint32_t)((w >> 5) & 31) + 1, ncl = (uint32_t)((w >> 10) & 15) + 4;
+    if (nlit > 286 || ndist > 30) return false;
+    b += 14;
+    uint8_t cl[19];
+#pragma unroll
+    for (int i = 0; i < 19; i++) cl[i] = 0;
+    w = bits_at(bytes, b);
+    uint64_t w2 = bits_at(bytes + 7, b);
+#pragma unroll
+    for (uint32_t i = 0; i < 19; i++) {
+        const uint32_t at = 3 * i;
+        const uint32_t v = i < ncl ? (at + 3 <= 56 ? (uint32_t)(w >> at) & 7 : (uint32_t)(w2 >> (at - 56)) & 7) : 0u;
+        // (CLORDER as a switch over the unrolled index: the array stays in registers)
+        constexpr uint8_t ORD[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15};
+        cl[ORD[i]] = (uint8_t)v;
+    }
+    b += 3 * ncl;
+    // canonical codes of the code-length code, its 7-bit table (complete by the cheap test that made this a candidate)
+    uint32_t cnt[8] = {0, 0, 0, 0, 0, 0, 0, 0}, next[8];
+#pragma unroll
+    for (int i = 0; i < 19; i++) cnt[cl[i]]++;
+    cnt[0] = 0;
+    uint32_t code = 0;
+#pragma unroll
+    for (int l = 1; l < 8; l++) {
+        code = (code + cnt[l - 1]) << 1;
+        next[l] = code;
+    }
+    for (uint32_t k = 0; k < 128; k++) tbl[k] = 0;
+#pragma unroll
+    for (uint32_t s = 0; s < 19; s++) {
+        const uint32_t l = cl[s];
+        if (l) {
+            const uint32_t cdw = next[l]++;
+            if (cdw >> l) return false;  // over-subscribed
+            const uint32_t r = __builtin_bitreverse32(cdw) >> (32 - l);
+            for (uint32_t k = r; k < 128; k += 1u << l) tbl[k] = (uint8_t)(l << 5 | s);
+        }
+    }
+    const uint32_t total = nlit + ndist;
+    uint32_t i = 0, prev = 0, kl = 0, kd = 0, cdist = 0, eob = 0;
+    while (i < total) {
+        if (b + 64 > valid_bits) return false;
+        w = bits_at(bytes, b);
+        const uint32_t e = tbl[w & 127];
+        const uint32_t l = e >> 5, sy = e & 31;
+        if (l == 0) return false;
+        b += l;
+        w >>= l;
+        uint32_t rep = 1, val = sy;
+        if (sy == 16) {
+            if (i == 0) return false;
+            rep = 3 + ((uint32_t)w & 3);
+            b += 2;
+            val = prev;
+        } else if (sy == 17) {
+            rep = 3 + ((uint32_t)w & 7);
+            b += 3;
+            val = 0;
+        } else if (sy == 18) {
+            rep = 11 + ((uint32_t)w & 127);
+            b += 7;
+            val = 0;
+        }
+        if (i + rep > total) return false;
+        if (val) {
+            const uint32_t wgt = 32768u >> val;
+            const uint32_t n1 = i >= nlit ? 0u : (i + rep <= nlit ? rep : nlit - i);
+            kl += n1 * wgt;
+            kd += (rep - n1) * wgt;
+            cdist += rep - n1;
+            if (i <= 256u && 256u < i + rep) eob = 1;
+        }
+        i += rep;
+        prev = val;
+    }
+    return eob && kl == 32768u && (kd == 32768u || cdist <= 1u);
+}
+
+__global__ __launch_bounds__(64) void k_search2(const uint32_t *in, uint64_t valid_bits, uint64_t stretch_bits, uint64_t first_bit,
+                                                uint64_t *start) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    Lds &S = *(Lds *)smem;
+    // the per-lane tables and the candidate list live where k_inflate keeps its ring (the wave-wide parse does not use it)
+    static_assert(offsetof(Lds, dist) >= 64 * CLROW && offsetof(Lds, window) == 0, "ring + literal root table hold the lanes' tables");
+    __shared__ uint64_t cand_list[128];
+    const uint32_t tbl = (uint32_t)threadIdx.x * CLROW;  // (offset into the LDS; dead whenever the wave-wide parse builds its tables there)
+    const int lane = (int)threadIdx.x;
+    const uint32_t c = blockIdx.x;
+    if (c == 0) {
+        if (lane == 0) start[0] = first_bit;
+        return;
+    }
+    load_bases(S, lane);
+    uint64_t from = (uint64_t)c * stretch_bits, to = from + stretch_bits;
+    if (from <= first_bit) from = first_bit + 1;
+    if (to + 160 > valid_bits) to = valid_bits > 160 ? valid_bits - 160 : 0;
+    const uint8_t *bytes = (const uint8_t *)in;
+    uint64_t found = NONE;
+    uint32_t nc = 0;
+    auto evaluate = [&](uint32_t count) {  // the first `count` candidates of the list, in order
+        LDS_ORDER();
+        const uint64_t mine = (uint32_t)lane < count ? cand_list[lane] : NONE;
+        const bool ok = mine != NONE && lane_header_ok(bytes, mine, valid_bits, tbl);
+        uint64_t m = __ballot(ok);
+        while (m && found == NONE) {
+            const uint32_t j = (uint32_t)__builtin_ctzll(m);
+            const uint64_t cb = cand_list[j];
+            if (plausible_block(S, in, cb, valid_bits, lane)) found = cb;
+            m &= m - 1;
+        }
+        LDS_ORDER();
+    };
+    for (uint64_t b0 = from; b0 < to && found == NONE; b0 += 64) {
+        const uint64_t b = b0 + (uint64_t)lane;
+        const uint64_t w = bits_at(bytes, b), w2 = bits_at(bytes + 7, b);  // w2: bits 56.. of the window
+        bool pre = b < to && (w & 7) == 4 && ((w >> 3) & 31) <= 29 && ((w >> 8) & 31) <= 29;
+        if (__ballot(pre)) {  // (seven of eight positions fail the first three bits)
+            const int ncl = (int)((w >> 13) & 15) + 4;
+            int left = 128, any = 0;
+            for (int i = 0; i < 19; i++) {
+                const unsigned at = 17 + 3 * (unsigned)i;
+                const unsigned l = i < ncl ? (at + 3 <= 56 ? (unsigned)(w >> at) & 7 : (unsigned)(w2 >> (at - 56)) & 7) : 0u;
+                if (l) {
+                    left -= 128 >> l;
+                    any = 1;
+                }
+            }
+            pre = pre && any && left == 0;
+            const uint64_t m = __ballot(pre);
+            if (m) {
+                if (pre) cand_list[nc + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u))] = b;
+                nc += (uint32_t)__popcll(m);
+                if (nc >= 64u) {
+                    evaluate(64u);
+                    LDS_ORDER();
+                    const uint64_t keep = (uint32_t)lane + 64u < nc ? cand_list[64 + lane] : NONE;
+                    LDS_ORDER();
+                    cand_list[lane] = keep;
+                    nc -= 64u;
+                }
+            }
+        }
+    }
+    if (found == NONE && nc) evaluate(nc);
+    if (lane == 0) start[c] = found;
+}
+
 // After the decode: which chunks count, do they chain, where does the text of each begin
 __global__ __launch_bounds__(1024) void k_finish(ChunkDesc *desc, uint32_t n, uint64_t *toff, SegResult *res) {
     __shared__ uint32_t s_end, s_broken, s_bad, s_members;
@@ -873,7 +2053,7 @@ __device__ __forceinline__ uint32_t multmodp(uint32_t a, uint32_t b) {  // a * b
     }
     return p;
 }
-__device__ uint32_t x8n_modp(uint64_t n) {  // x^(8n) mod P
+__device__ __forceinline__ uint32_t x8n_modp(uint64_t n) {  // x^(8n) mod P
     uint32_t p = 1u << 31, sq = 0x00800000u;  // x^0 ; x^8
     while (n) {
         if (n & 1) p = multmodp(sq, p);
@@ -1003,6 +2183,8 @@ public:
         look_ = std::max<size_t>((size_t)2u << 20, stretch_);
         slot_syms_ = (uint32_t)(16 * stretch_ + 65536);  // symbols a stretch's slot holds: text up to 16 : 1
         trace_ = getenv("NOHUMAN_TRACE") != nullptr;
+        v1_ = getenv("NOHUMAN_GZDEV_V1") != nullptr;  // the first versions of the search and decode kernels (A / B on one box)
+        v2_ = getenv("NOHUMAN_GZDEV_V2") != nullptr;  // the scalar-decode version of k_inflate
         if (hipSetDevice(device_) != hipSuccess) {
             err = "hipSetDevice failed";
             close();
@@ -1024,7 +2206,10 @@ public:
         if (ok) ok = hipMemset(d_win_[0], 0, WSIZE) == hipSuccess && hipMemset(d_in_, 0, in_bytes) == hipSuccess;
         if (ok)
             ok = hipFuncSetAttribute((const void *)k_search, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(Lds)) == hipSuccess &&
-                 hipFuncSetAttribute((const void *)k_inflate, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(Lds)) == hipSuccess;
+                 hipFuncSetAttribute((const void *)k_inflate, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(Lds)) == hipSuccess &&
+                 hipFuncSetAttribute((const void *)k_search2, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(Lds)) == hipSuccess &&
+                 hipFuncSetAttribute((const void *)k_inflate2, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(Lds)) == hipSuccess &&
+                 hipFuncSetAttribute((const void *)k_inflate3, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(Lds3)) == hipSuccess;
         for (auto &e : ev_)
             if (ok) ok = hipEventCreate(&e) == hipSuccess;
         if (!ok) {
@@ -1045,6 +2230,15 @@ public:
                     device_, path_.c_str(), (unsigned long long)st_.segments, (unsigned long long)st_.chunks, (unsigned long long)st_.redecoded,
                     (unsigned long long)st_.fallback_segments, (unsigned long long)st_.members, st_.gzip_bytes / 1e9, st_.text_bytes / 1e9, st_.ms_search,
                     st_.ms_decode, st_.ms_scan, st_.ms_resolve, st_.ms_crc, st_.s_host_copy, st_.s_wait);
+#ifdef NH_GZ_PROF
+        if (st_.chunks)
+            fprintf(stderr,
+                    "[gz prof] per chunk (x 10 ns): header+tables %.0f, lanes' decode %.0f, walk %.0f, expansion %.0f, flush %.0f, all %.0f; per chunk: "
+                    "windows %.0f tokens %.0f matches %.0f generic copies %.0f slow tokens %.0f blocks %.2f\n",
+                    (double)prof_[0] / st_.chunks, (double)prof_[1] / st_.chunks, (double)prof_[2] / st_.chunks, (double)prof_[3] / st_.chunks,
+                    (double)prof_[4] / st_.chunks, (double)prof_[5] / st_.chunks, (double)prof_[6] / st_.chunks, (double)prof_[7] / st_.chunks,
+                    (double)prof_[8] / st_.chunks, (double)prof_[9] / st_.chunks, (double)prof_[10] / st_.chunks, (double)prof_[11] / st_.chunks);
+#endif
         if (device_ >= 0) (void)hipSetDevice(device_);
         for (void *p : {(void *)d_in_, (void *)d_start_, (void *)d_desc_, (void *)d_toff_, (void *)d_sym_, (void *)d_maps_[0], (void *)d_maps_[1],
                         (void *)d_windows_, (void *)d_win_[0], (void *)d_win_[1], (void *)d_res_})
@@ -1081,6 +2275,9 @@ public:
 
 private:
     static constexpr size_t ALIGN = 4096;
+    typedef void (*InflateFn)(const uint32_t *, uint64_t, uint32_t, ChunkDesc *, uint16_t *, uint32_t, uint32_t);
+    InflateFn inflate_kernel() const { return v1_ ? k_inflate : v2_ ? k_inflate2 : k_inflate3; }
+    size_t inflate_lds() const { return v1_ || v2_ ? sizeof(Lds) : sizeof(Lds3); }
 
     long fail(const std::string &m) {
         if (error_.empty()) error_ = "gzip: " + m + " (" + path_ + ")";
@@ -1136,8 +2333,12 @@ private:
             GZ_TRY(hipMemcpyAsync(d_in_, h_in_, avail + 1024, hipMemcpyHostToDevice, stream));
             const uint64_t end_bit = std::min<uint64_t>((uint64_t)n_str * stretch_ * 8, valid_bits);
             if (trace_) (void)hipEventRecord(ev_[0], stream);
-            hipLaunchKernelGGL(k_search, dim3(n_str), dim3(64), sizeof(Lds), stream, (const uint32_t *)d_in_, valid_bits, (uint64_t)stretch_ * 8,
-                               first_bit, d_start_);
+            if (v1_)
+                hipLaunchKernelGGL(k_search, dim3(n_str), dim3(64), sizeof(Lds), stream, (const uint32_t *)d_in_, valid_bits, (uint64_t)stretch_ * 8,
+                                   first_bit, d_start_);
+            else
+                hipLaunchKernelGGL(k_search2, dim3(n_str), dim3(64), sizeof(Lds), stream, (const uint32_t *)d_in_, valid_bits,
+                                   (uint64_t)stretch_ * 8, first_bit, d_start_);
             if (fake_start_ > 0 && (uint32_t)fake_start_ < n_str) {  // test knob: pretend the search found a start that is none
                 const uint64_t bogus = (uint64_t)fake_start_ * stretch_ * 8 + 13;
                 GZ_TRY(hipMemcpyAsync(d_start_ + fake_start_, &bogus, 8, hipMemcpyHostToDevice, stream));
@@ -1146,8 +2347,8 @@ private:
             }
             hipLaunchKernelGGL(k_plan, dim3(1), dim3(1024), 0, stream, (const uint64_t *)d_start_, n_str, end_bit, slot_syms_, d_desc_);
             if (trace_) (void)hipEventRecord(ev_[1], stream);
-            hipLaunchKernelGGL(k_inflate, dim3(n_str), dim3(64), sizeof(Lds), stream, (const uint32_t *)d_in_, valid_bits, at_eof ? 1u : 0u, d_desc_,
-                               d_sym_, slot_syms_, NOIDX);
+            hipLaunchKernelGGL(inflate_kernel(), dim3(n_str), dim3(64), inflate_lds(), stream, (const uint32_t *)d_in_, valid_bits,
+                               at_eof ? 1u : 0u, d_desc_, d_sym_, slot_syms_, NOIDX);
             if (trace_) (void)hipEventRecord(ev_[2], stream);
             uint32_t redo = 0;
             for (;;) {
@@ -1169,8 +2370,8 @@ private:
                 uint32_t prev = bad;
                 while (prev > 0 && h_desc_[--prev].bit_start == NONE) {
                 }
-                hipLaunchKernelGGL(k_inflate, dim3(1), dim3(64), sizeof(Lds), stream, (const uint32_t *)d_in_, valid_bits, at_eof ? 1u : 0u, d_desc_,
-                                   d_sym_, slot_syms_, prev);
+                hipLaunchKernelGGL(inflate_kernel(), dim3(1), dim3(64), inflate_lds(), stream, (const uint32_t *)d_in_, valid_bits,
+                                   at_eof ? 1u : 0u, d_desc_, d_sym_, slot_syms_, prev);
                 redo++;
                 st_.redecoded++;
                 if (redo > n_str) return fail("the chunks of a piece do not chain");
@@ -1227,6 +2428,9 @@ private:
             for (uint32_t c = 0; c <= r.end_chunk; c++) {
                 const ChunkDesc &d = h_desc_[c];
                 if (d.bit_start == NONE) continue;
+#ifdef NH_GZ_PROF
+                for (int i = 0; i < 12; i++) prof_[i] += d.prof[i];
+#endif
                 uint32_t a = 0;
                 for (uint32_t p = 0; p <= d.n_members; p++) {
                     const uint32_t b = p < d.n_members ? d.m_off[p] : d.out_len;
@@ -1330,9 +2534,10 @@ private:
     hipEvent_t ev_[7] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     uint32_t run_crc_ = 0;
     uint64_t run_len_ = 0;
-    bool trace_ = false, warned_ = false, host_mode_ = false;
+    bool trace_ = false, warned_ = false, host_mode_ = false, v1_ = false, v2_ = false;
     uint32_t failed_in_a_row_ = 0, last_bad_ = 0;
     long fake_start_ = -1;
+    uint64_t prof_[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 };
 
 DevGunzip::DevGunzip() : impl_(new DevGunzipImpl()) {}
@@ -1366,7 +2571,8 @@ extern "C" int nh_gunzip_device_file(const char *in, const char *out, int32_t de
     nh::DevGunzip gz;
     std::string err;
     if (gz.open(in, device, (size_t)seg_bytes, (size_t)stretch_bytes, err) != 0) return nh::set_error(NH_EIO, "%s", err.c_str());
-    const size_t room = (size_t)256u << 20;
+    size_t room = (size_t)256u << 20;
+    if (const char *e = getenv("NOHUMAN_GZDEV_ROOM")) room = std::max<size_t>((size_t)atoll(e), (size_t)1u << 20);  // tool knob: text per piece
     uint8_t *d_text = nullptr;
     hipStream_t stream = nullptr;
     if (hipSetDevice(device) != hipSuccess || hipMalloc((void **)&d_text, room + 64) != hipSuccess ||
