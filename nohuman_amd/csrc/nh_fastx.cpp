@@ -7,6 +7,7 @@
 #include <dlfcn.h>
 #include <errno.h>
 #include <fcntl.h>
+#include <sys/stat.h>
 #include <unistd.h>
 #include <string.h>
 #include <zlib.h>
@@ -213,14 +214,23 @@ private:
 };
 
 // gzip decoded on a GPU: DevGunzip (nh_gunzip.hip) leaves a piece of text in device memory, read() fetches it from
-// there into the caller's buffer (the page-locked text buffer of a batch: one copy over PCIe, no inflate on the host)
+// there into the caller's buffer (the page-locked text buffer of a batch: one copy over PCIe, no inflate on the host).
+// Two text buffers: a helper thread has the GPU decode the next piece while this one is being fetched.
 class DevGzSource {
 public:
     ~DevGzSource() {
+        {
+            std::lock_guard<std::mutex> lk(mu_);
+            stop_ = true;
+        }
+        cv_.notify_all();
+        if (th_.joinable()) th_.join();
         gz_.close();
         if (device_ >= 0) (void)hipSetDevice(device_);
-        if (d_text_) (void)hipFree(d_text_);
+        for (Buf &b : buf_)
+            if (b.d) (void)hipFree(b.d);
         if (stream_) (void)hipStreamDestroy(stream_);
+        if (copy_stream_) (void)hipStreamDestroy(copy_stream_);
     }
     int open(const char *path, int device, std::string &err) {
         device_ = device;
@@ -229,14 +239,32 @@ public:
             return -1;
         }
         if (gz_.open(path, device, 0, 0, err) != 0) return -1;
-        // text of a piece: 64 MiB of gzip at up to 8 : 1 (a piece that would not fit is cut down by the reader)
-        room_ = (size_t)512u << 20;
-        if (const char *e = getenv("NOHUMAN_GZDEV_ROOM")) room_ = std::max<size_t>((size_t)atol(e), (size_t)1u << 20);
-        if (hipMalloc((void **)&d_text_, room_ + 64) != hipSuccess || hipStreamCreateWithFlags(&stream_, hipStreamNonBlocking) != hipSuccess) {
+        // text of a piece: 256 MiB of gzip at up to 10 : 1 (a piece that would not fit is cut down by the reader); small
+        // files get small buffers
+        room_ = (size_t)2560u << 20;
+        struct stat st;
+        if (stat(path, &st) == 0 && (uint64_t)st.st_size * 16 + ((size_t)64u << 20) < room_) room_ = (size_t)st.st_size * 16 + ((size_t)64u << 20);
+        if (const char *e = getenv("NOHUMAN_GZDEV_ROOM")) room_ = std::max<size_t>((size_t)atoll(e), (size_t)1u << 20);
+        for (;;) {
+            const bool ok = hipMalloc((void **)&buf_[0].d, room_ + 64) == hipSuccess && hipMalloc((void **)&buf_[1].d, room_ + 64) == hipSuccess;
+            if (ok) break;
             (void)hipGetLastError();
-            err = "the gzip reader's text buffer cannot be had";
+            for (Buf &b : buf_) {
+                if (b.d) (void)hipFree(b.d);
+                b.d = nullptr;
+            }
+            if (room_ <= ((size_t)128u << 20)) {
+                err = "the gzip reader's text buffers cannot be had";
+                return -1;
+            }
+            room_ /= 2;
+        }
+        if (hipStreamCreateWithFlags(&stream_, hipStreamNonBlocking) != hipSuccess ||
+            hipStreamCreateWithFlags(&copy_stream_, hipStreamNonBlocking) != hipSuccess) {
+            err = "cannot create streams";
             return -1;
         }
+        th_ = std::thread([this] { produce(); });
         return 0;
     }
     long read(uint8_t *buf, size_t cap, std::string &err) {
@@ -246,35 +274,79 @@ public:
         }
         size_t got = 0;
         while (got < cap) {
-            if (off_ == len_) {
-                if (gz_.ended()) break;
-                const long n = gz_.next(d_text_, room_, stream_);
-                if (n < 0) {
-                    err = gz_.error();
-                    return -1;
+            Buf &b = buf_[take_];
+            {
+                std::unique_lock<std::mutex> lk(mu_);
+                cv_.wait(lk, [&] { return b.full || done_; });
+                if (!b.full) {  // the stream has ended (or failed)
+                    if (!perr_.empty()) {
+                        err = perr_;
+                        return -1;
+                    }
+                    break;
                 }
-                off_ = 0;
-                len_ = (size_t)n;
-                if (n == 0) break;
             }
-            const size_t k = std::min(cap - got, len_ - off_);
-            if (hipMemcpyAsync(buf + got, d_text_ + off_, k, hipMemcpyDeviceToHost, stream_) != hipSuccess ||
-                hipStreamSynchronize(stream_) != hipSuccess) {
+            const size_t k = std::min(cap - got, b.len - b.off);
+            if (hipMemcpyAsync(buf + got, b.d + b.off, k, hipMemcpyDeviceToHost, copy_stream_) != hipSuccess ||
+                hipStreamSynchronize(copy_stream_) != hipSuccess) {
                 err = "gzip reader: fetching the text from the device failed";
                 return -1;
             }
-            off_ += k;
+            b.off += k;
             got += k;
+            if (b.off == b.len) {
+                {
+                    std::lock_guard<std::mutex> lk(mu_);
+                    b.full = false;
+                }
+                cv_.notify_all();
+                take_ ^= 1;
+            }
         }
         return (long)got;
     }
 
 private:
+    struct Buf {
+        uint8_t *d = nullptr;
+        size_t len = 0, off = 0;
+        bool full = false;
+    };
+    void produce() {
+        int fill = 0;
+        for (;;) {
+            Buf &b = buf_[fill];
+            {
+                std::unique_lock<std::mutex> lk(mu_);
+                cv_.wait(lk, [&] { return !b.full || stop_; });
+                if (stop_) return;
+            }
+            const long n = gz_.next(b.d, room_, stream_);
+            std::lock_guard<std::mutex> lk(mu_);
+            if (n <= 0) {
+                if (n < 0) perr_ = gz_.error();
+                done_ = true;
+                cv_.notify_all();
+                return;
+            }
+            b.len = (size_t)n;
+            b.off = 0;
+            b.full = true;
+            cv_.notify_all();
+            fill ^= 1;
+        }
+    }
     DevGunzip gz_;
     int device_ = -1;
-    uint8_t *d_text_ = nullptr;
-    size_t room_ = 0, off_ = 0, len_ = 0;
-    hipStream_t stream_ = nullptr;
+    Buf buf_[2];
+    size_t room_ = 0;
+    int take_ = 0;
+    hipStream_t stream_ = nullptr, copy_stream_ = nullptr;
+    std::thread th_;
+    std::mutex mu_;
+    std::condition_variable cv_;
+    bool stop_ = false, done_ = false;
+    std::string perr_;
 };
 
 ByteSource::~ByteSource() { close(); }

@@ -2174,13 +2174,17 @@ public:
         stretch_ = stretch_bytes ? stretch_bytes : (size_t)(32u << 10);
         if (stretch_ < 1024) stretch_ = 1024;
         stretch_ = (stretch_ + 63) & ~(size_t)63;
-        seg_ = seg_bytes ? seg_bytes : (size_t)(64u << 20);
+        // A piece is what the chip decodes at once, a wavefront a chunk: 256 MiB of gzip are ~8000 chunks, one and a half
+        // rounds of the 5120 wave slots (smaller pieces leave them empty: profiles/r04_inflate_summary.txt, 32 MiB pieces
+        // take four times as long).  No larger than the file; halved below while the buffers do not fit the HBM.
+        seg_ = seg_bytes ? seg_bytes : (size_t)(256u << 20);
         if (seg_ < stretch_) seg_ = stretch_;
-        seg_ = seg_ / stretch_ * stretch_;
-        n_slots_ = (uint32_t)(seg_ / stretch_);
+        if (seg_ > size_ + stretch_) seg_ = size_ + stretch_;
+        seg_ = (seg_ + stretch_ - 1) / stretch_ * stretch_;
         // a chunk's block may run past the piece: that much more of the file is on the device.  zlib's blocks hold at
         // most 64 KiB (stored) or some 16 K symbols; 2 MiB covers encoders with far larger ones
         look_ = std::max<size_t>((size_t)2u << 20, stretch_);
+        if (look_ > size_) look_ = (size_ + 4095) & ~(size_t)4095;
         slot_syms_ = (uint32_t)(16 * stretch_ + 65536);  // symbols a stretch's slot holds: text up to 16 : 1
         trace_ = getenv("NOHUMAN_TRACE") != nullptr;
         v1_ = getenv("NOHUMAN_GZDEV_V1") != nullptr;  // the first versions of the search and decode kernels (A / B on one box)
@@ -2190,20 +2194,28 @@ public:
             close();
             return -1;
         }
-        const size_t in_bytes = seg_ + look_ + ALIGN + 4096;
-        bool ok = hipMalloc((void **)&d_in_, in_bytes) == hipSuccess && hipHostMalloc((void **)&h_in_, in_bytes, hipHostMallocDefault) == hipSuccess &&
-                  hipMalloc((void **)&d_start_, (size_t)n_slots_ * 8) == hipSuccess &&
-                  hipMalloc((void **)&d_desc_, (size_t)n_slots_ * sizeof(ChunkDesc)) == hipSuccess &&
-                  hipHostMalloc((void **)&h_desc_, (size_t)n_slots_ * sizeof(ChunkDesc), hipHostMallocDefault) == hipSuccess &&
-                  hipMalloc((void **)&d_toff_, (size_t)n_slots_ * 8) == hipSuccess &&
-                  hipMalloc((void **)&d_sym_, ((size_t)n_slots_ * slot_syms_ + 1024) * 2) == hipSuccess &&
-                  hipMalloc((void **)&d_maps_[0], (size_t)n_slots_ * WSIZE * 2) == hipSuccess &&
-                  hipMalloc((void **)&d_maps_[1], (size_t)n_slots_ * WSIZE * 2) == hipSuccess &&
-                  hipMalloc((void **)&d_windows_, (size_t)n_slots_ * WSIZE) == hipSuccess &&
-                  hipMalloc((void **)&d_win_[0], WSIZE) == hipSuccess && hipMalloc((void **)&d_win_[1], WSIZE) == hipSuccess &&
-                  hipMalloc((void **)&d_res_, sizeof(SegResult)) == hipSuccess &&
-                  hipHostMalloc((void **)&h_res_, sizeof(SegResult), hipHostMallocDefault) == hipSuccess;
-        if (ok) ok = hipMemset(d_win_[0], 0, WSIZE) == hipSuccess && hipMemset(d_in_, 0, in_bytes) == hipSuccess;
+        bool ok = false;
+        for (;;) {
+            n_slots_ = (uint32_t)(seg_ / stretch_);
+            const size_t in_bytes = seg_ + look_ + ALIGN + 4096;
+            ok = hipMalloc((void **)&d_in_, in_bytes) == hipSuccess && hipHostMalloc((void **)&h_in_, in_bytes, hipHostMallocDefault) == hipSuccess &&
+                 hipMalloc((void **)&d_start_, (size_t)n_slots_ * 8) == hipSuccess &&
+                 hipMalloc((void **)&d_desc_, (size_t)n_slots_ * sizeof(ChunkDesc)) == hipSuccess &&
+                 hipHostMalloc((void **)&h_desc_, (size_t)n_slots_ * sizeof(ChunkDesc), hipHostMallocDefault) == hipSuccess &&
+                 hipMalloc((void **)&d_toff_, (size_t)n_slots_ * 8) == hipSuccess &&
+                 hipMalloc((void **)&d_sym_, ((size_t)n_slots_ * slot_syms_ + 1024) * 2) == hipSuccess &&
+                 hipMalloc((void **)&d_maps_[0], (size_t)n_slots_ * WSIZE * 2) == hipSuccess &&
+                 hipMalloc((void **)&d_maps_[1], (size_t)n_slots_ * WSIZE * 2) == hipSuccess &&
+                 hipMalloc((void **)&d_windows_, (size_t)n_slots_ * WSIZE) == hipSuccess &&
+                 hipMalloc((void **)&d_win_[0], WSIZE) == hipSuccess && hipMalloc((void **)&d_win_[1], WSIZE) == hipSuccess &&
+                 hipMalloc((void **)&d_res_, sizeof(SegResult)) == hipSuccess &&
+                 hipHostMalloc((void **)&h_res_, sizeof(SegResult), hipHostMallocDefault) == hipSuccess;
+            if (ok) ok = hipMemset(d_win_[0], 0, WSIZE) == hipSuccess && hipMemset(d_in_, 0, in_bytes) == hipSuccess;
+            if (ok || seg_ <= ((size_t)16u << 20)) break;
+            (void)hipGetLastError();
+            free_buffers();
+            seg_ = (seg_ / 2 + stretch_ - 1) / stretch_ * stretch_;
+        }
         if (ok)
             ok = hipFuncSetAttribute((const void *)k_search, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(Lds)) == hipSuccess &&
                  hipFuncSetAttribute((const void *)k_inflate, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(Lds)) == hipSuccess &&
@@ -2220,6 +2232,16 @@ public:
         }
         if (const char *e = getenv("NOHUMAN_GZDEV_FAKE_START")) fake_start_ = atol(e);  // test knob: a false positive of the search
         return 0;
+    }
+
+    void free_buffers() {
+        for (void *p : {(void *)d_in_, (void *)d_start_, (void *)d_desc_, (void *)d_toff_, (void *)d_sym_, (void *)d_maps_[0], (void *)d_maps_[1],
+                        (void *)d_windows_, (void *)d_win_[0], (void *)d_win_[1], (void *)d_res_})
+            if (p) (void)hipFree(p);
+        for (void *p : {(void *)h_in_, (void *)h_desc_, (void *)h_res_})
+            if (p) (void)hipHostFree(p);
+        d_in_ = nullptr, d_start_ = nullptr, d_desc_ = nullptr, d_toff_ = nullptr, d_sym_ = nullptr, d_maps_[0] = d_maps_[1] = nullptr;
+        d_windows_ = nullptr, d_win_[0] = d_win_[1] = nullptr, d_res_ = nullptr, h_in_ = nullptr, h_desc_ = nullptr, h_res_ = nullptr;
     }
 
     void close() {
@@ -2240,13 +2262,7 @@ public:
                     (double)prof_[8] / st_.chunks, (double)prof_[9] / st_.chunks, (double)prof_[10] / st_.chunks, (double)prof_[11] / st_.chunks);
 #endif
         if (device_ >= 0) (void)hipSetDevice(device_);
-        for (void *p : {(void *)d_in_, (void *)d_start_, (void *)d_desc_, (void *)d_toff_, (void *)d_sym_, (void *)d_maps_[0], (void *)d_maps_[1],
-                        (void *)d_windows_, (void *)d_win_[0], (void *)d_win_[1], (void *)d_res_})
-            if (p) (void)hipFree(p);
-        for (void *p : {(void *)h_in_, (void *)h_desc_, (void *)h_res_})
-            if (p) (void)hipHostFree(p);
-        d_in_ = nullptr, d_start_ = nullptr, d_desc_ = nullptr, d_toff_ = nullptr, d_sym_ = nullptr, d_maps_[0] = d_maps_[1] = nullptr;
-        d_windows_ = nullptr, d_win_[0] = d_win_[1] = nullptr, d_res_ = nullptr, h_in_ = nullptr, h_desc_ = nullptr, h_res_ = nullptr;
+        free_buffers();
         for (auto &e : ev_)
             if (e) {
                 (void)hipEventDestroy(e);

@@ -101,6 +101,54 @@ def test_paired_end_run_gzip_inputs(tmp_path):
         assert hl == recs[i]["hitlist"]
 
 
+@pytest.mark.parametrize("reader", ["device", "host"])
+def test_gzip_pairs_through_the_reader_on_the_gpu_and_on_the_host(tmp_path, monkeypatch, capfd, reader):
+    """gzip inputs through nh_run with the device reader on (NOHUMAN_GZ_READER=device: no silent
+    change of reader) and off (=host): the same kept FASTQ bytes, kraken lines and counts, and they are the goldens'.
+    Both mates gzip, several members in one of them, small pieces so that the chunks' windows are chained by the scan."""
+    from nohuman_amd import Engine
+    conf = 0.0
+    _, ext, recs, calls = _expected("expected_pe.json", conf)
+    raw1 = open(os.path.join(GOLD, "reads_pe_1.fq"), "rb").read()
+    raw2 = open(os.path.join(GOLD, "reads_pe_2.fq"), "rb").read()
+    cut = raw1.index(b"\n@", len(raw1) // 2) + 1
+    in1, in2 = tmp_path / "r_1.fq.gz", tmp_path / "r_2.fq.gz"
+    in1.write_bytes(gzip.compress(raw1[:cut], 6) + gzip.compress(raw1[cut:], 9))
+    in2.write_bytes(gzip.compress(raw2, 1))
+    monkeypatch.setenv("NOHUMAN_GZ_READER", reader)
+    monkeypatch.setenv("NOHUMAN_GZDEV_SEG", "16384")
+    monkeypatch.setenv("NOHUMAN_GZDEV_STRETCH", "2048")
+    monkeypatch.setenv("NOHUMAN_TRACE", "1")
+    r1 = read_fastq(os.path.join(GOLD, "reads_pe_1.fq"))
+    r2 = read_fastq(os.path.join(GOLD, "reads_pe_2.fq"))
+    o1, o2, k = tmp_path / "o_1.fq", tmp_path / "o_2.fq", tmp_path / "k.txt"
+    with Engine.open(DB) as eng:
+        st = eng.run(str(in1), str(o1), in2=str(in2), out2=str(o2), kraken_output=str(k), confidence=conf, threads=4)
+    err = capfd.readouterr().err
+    assert ("gzip reader on GPU" in err) == (reader == "device"), err[-2000:]  # the reader that was asked for did the work
+    keep = [i for i, c in enumerate(calls) if not c]
+    assert (st.total_sequences, st.classified) == (len(r1), len(r1) - len(keep))
+    assert o1.read_bytes() == _fastq_bytes([r1[i] for i in keep])
+    assert o2.read_bytes() == _fastq_bytes([r2[i] for i in keep])
+    lines = k.read_text().split("\n")[:-1]
+    assert [ln.split("\t")[4] for ln in lines] == [r["hitlist"] for r in recs]
+
+
+def test_damaged_gzip_input_fails_the_run_with_either_reader(tmp_path, monkeypatch):
+    from nohuman_amd import Engine, EngineError
+    raw = open(os.path.join(GOLD, "reads_se.fq"), "rb").read() * 20
+    good = gzip.compress(raw, 6)
+    bad = bytearray(good)
+    bad[len(bad) // 2] ^= 0x5A
+    p = tmp_path / "bad.fq.gz"
+    p.write_bytes(bytes(bad))
+    for reader in ("device", "host"):
+        monkeypatch.setenv("NOHUMAN_GZ_READER", reader)
+        with Engine.open(DB) as eng:
+            with pytest.raises(EngineError):
+                eng.run(str(p), str(tmp_path / "o.fq"), threads=4)
+
+
 def test_run_errors_are_reported(tmp_path):
     from nohuman_amd import CommandRunner, Engine, EngineError
     with pytest.raises(EngineError) as ei:

@@ -58,6 +58,8 @@ try:
             (0, 0, 0, 256 << 20), (64 << 20, 32768, 0, 1 << 30), (256 << 20, 16384, 0, 3 << 30))
     if os.environ.get("GZDEV_BENCH_QUICK"):
         runs = ((256 << 20, 32768, 0, 3 << 30), (32 << 20, 32768, 0, 3 << 30))
+    if os.environ.get("GZDEV_BENCH_QUICK") == "2":
+        runs = ((0, 0, 0, 3 << 30),)
     for seg, stretch, v1, room in runs:
         env = dict(os.environ, NOHUMAN_TRACE="1", NOHUMAN_GZDEV_ROOM=str(room))
         if v1:
@@ -72,7 +74,7 @@ try:
         cap = 134_217_689
         eng = Engine.synthetic(cap, int(cap * 0.7), depth=30, seed=7)
         outs = {}
-        for mode in ("device", "host", "device"):
+        for mode in ("device", "host"):
             for codec, cname in ((0, "plain"), (2, "gzip")):
                 o1, o2 = os.path.join(tmp, "o1_%s" % mode), os.path.join(tmp, "o2_%s" % mode)
                 os.environ["NOHUMAN_GZ_READER"] = mode
