@@ -1880,6 +1880,128 @@ __global__ __launch_bounds__(64) void k_search2(const uint32_t *in, uint64_t val
     if (lane == 0) start[c] = found;
 }
 
+// ---- k_search3: k_search2 on the compact tables of k_inflate3 (9.3 KB of LDS instead of 17.4: seventeen waves a CU; a
+// stretch's wave is latency-bound, 3 ms alone) -------------------------------------------------------------------------
+__device__ __forceinline__ bool plausible_block3(Lds3 &S, const uint32_t *in, uint64_t cand, uint64_t valid_bits, int lane) {
+    BitRd br;
+    br.init(in, cand + 3, lane);
+    int nlit, ndist;
+    if (parse_dynamic3(S, br, lane, nlit, ndist)) return false;
+    uint32_t sl = 0, sd = 0, cd = 0;
+    for (int k = lane; k < nlit; k += 64) sl += S.lens[k] ? 32768u >> S.lens[k] : 0u;
+    for (int k = lane; k < ndist; k += 64) {
+        const uint32_t l = S.lens[nlit + k];
+        sd += l ? 32768u >> l : 0u;
+        cd += l != 0;
+    }
+    sl = wsum(sl);
+    sd = wsum(sd);
+    cd = wsum(cd);
+    if (!(sl == 32768u && (sd == 32768u || cd <= 1u))) return false;
+    if (!build3(S, S.lens, nlit, S.lcount, S.lsym, S.lit, ROOT3, 1, lane)) return false;
+    if (!build3(S, S.lens + nlit, ndist, S.dcount, S.dsym, S.dist, DROOT3, 2, lane)) return false;
+    uint32_t produced = 0;
+    for (int tok = 0; tok < 256; tok++) {  // the block's first tokens must walk
+        if (br.bitpos() + 64 > valid_bits) return true;  // (the look-ahead ends here: what was walked was fine)
+        br.ensure32(lane);
+        uint32_t e = uni(S.lit[br.peek(ROOT3)]);
+        if (e == 0) {
+            uint32_t l;
+            const uint32_t sy = slow_symbol(br.bb, S.lcount, S.lsym, l);
+            if (l == 0 || sy >= 286u) return false;
+            e = uni(lit_entry3(uni(sy), uni(l)));
+        }
+        br.drop(e & 15u);
+        const uint32_t kind = (e >> 4) & 3u;
+        if (kind == 2u) break;
+        if (kind == 0u) {
+            produced++;
+            continue;
+        }
+        const uint32_t pay = (e >> 6) & 0xFFu;
+        const uint32_t len = (uint32_t)LBASE[pay & 31u] + br.take(pay >> 5);
+        br.ensure32(lane);
+        uint32_t de = uni(S.dist[br.peek(DROOT3)]);
+        if (de == 0) {
+            uint32_t dl;
+            const uint32_t dsy = slow_symbol(br.bb, S.dcount, S.dsym, dl);
+            if (dl == 0 || dsy >= 30u) return false;
+            de = uni(dist_entry3(uni(dsy), uni(dl)));
+        }
+        br.drop(de & 15u);
+        const uint32_t dist = (uint32_t)DBASE[(de >> 4) & 31u] + br.take((de >> 9) & 15u);
+        if (dist > produced + WSIZE) return false;
+        produced += len;
+    }
+    return true;
+}
+
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(5, 8))) void k_search3(const uint32_t *in, uint64_t valid_bits, uint64_t stretch_bits, uint64_t first_bit,
+                                                uint64_t *start) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    Lds3 &S = *(Lds3 *)smem;  // the wave-wide parse's tables and the lanes' own (64 x CLROW bytes) share the space: never live together
+    __shared__ uint64_t cand_list[128];
+    const uint32_t tbl = (uint32_t)threadIdx.x * CLROW;
+    const int lane = (int)threadIdx.x;
+    const uint32_t c = blockIdx.x;
+    if (c == 0) {
+        if (lane == 0) start[0] = first_bit;
+        return;
+    }
+    uint64_t from = (uint64_t)c * stretch_bits, to = from + stretch_bits;
+    if (from <= first_bit) from = first_bit + 1;
+    if (to + 160 > valid_bits) to = valid_bits > 160 ? valid_bits - 160 : 0;
+    const uint8_t *bytes = (const uint8_t *)in;
+    uint64_t found = NONE;
+    uint32_t nc = 0;
+    auto evaluate = [&](uint32_t count) {  // the first `count` candidates of the list, in order
+        LDS_ORDER();
+        const uint64_t mine = (uint32_t)lane < count ? cand_list[lane] : NONE;
+        const bool ok = mine != NONE && lane_header_ok(bytes, mine, valid_bits, tbl);
+        uint64_t m = __ballot(ok);
+        while (m && found == NONE) {
+            const uint32_t j = (uint32_t)__builtin_ctzll(m);
+            const uint64_t cb = cand_list[j];
+            if (plausible_block3(S, in, cb, valid_bits, lane)) found = cb;
+            m &= m - 1;
+        }
+        LDS_ORDER();
+    };
+    for (uint64_t b0 = from; b0 < to && found == NONE; b0 += 64) {
+        const uint64_t b = b0 + (uint64_t)lane;
+        const uint64_t w = bits_at(bytes, b), w2 = bits_at(bytes + 7, b);  // w2: bits 56.. of the window
+        bool pre = b < to && (w & 7) == 4 && ((w >> 3) & 31) <= 29 && ((w >> 8) & 31) <= 29;
+        if (__ballot(pre)) {  // (seven of eight positions fail the first three bits)
+            const int ncl = (int)((w >> 13) & 15) + 4;
+            int left = 128, any = 0;
+            for (int i = 0; i < 19; i++) {
+                const unsigned at = 17 + 3 * (unsigned)i;
+                const unsigned l = i < ncl ? (at + 3 <= 56 ? (unsigned)(w >> at) & 7 : (unsigned)(w2 >> (at - 56)) & 7) : 0u;
+                if (l) {
+                    left -= 128 >> l;
+                    any = 1;
+                }
+            }
+            pre = pre && any && left == 0;
+            const uint64_t m = __ballot(pre);
+            if (m) {
+                if (pre) cand_list[nc + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u))] = b;
+                nc += (uint32_t)__popcll(m);
+                if (nc >= 64u) {
+                    evaluate(64u);
+                    LDS_ORDER();
+                    const uint64_t keep = (uint32_t)lane + 64u < nc ? cand_list[64 + lane] : NONE;
+                    LDS_ORDER();
+                    cand_list[lane] = keep;
+                    nc -= 64u;
+                }
+            }
+        }
+    }
+    if (found == NONE && nc) evaluate(nc);
+    if (lane == 0) start[c] = found;
+}
+
 // After the decode: which chunks count, do they chain, where does the text of each begin
 __global__ __launch_bounds__(1024) void k_finish(ChunkDesc *desc, uint32_t n, uint64_t *toff, SegResult *res) {
     __shared__ uint32_t s_end, s_broken, s_bad, s_members;
@@ -2008,6 +2130,89 @@ __global__ __launch_bounds__(256) void k_windows(const uint16_t *scanned, const 
             v = x & 0x8000u ? w0[x & 0x7FFFu] : (uint8_t)x;
         }
         w[j] = v;
+    }
+}
+
+// ---- the same windows in three passes instead of log2(n) rounds over all maps (round 4: 13 rounds x 3 x 0.5 GB a piece of
+// 7560 chunks were 19 GB of traffic, 7 ms; this is 1.7 GB).  Groups of SCAN_GROUP consecutive chunks:
+//   k_scan_local   a workgroup a group walks its chunks in order, the running composition R in LDS (32 Ki x 16 bit, double
+//                  buffered): local[c] = map[c] o ... o map[first of the group]  (the maps straight from the symbols)
+//   k_scan_groups  one workgroup walks the groups' totals: pre[g] = total[g - 1] o ... o total[0]  (a few hundred steps)
+//   k_scan_windows windows[c + 1] = local[c] o pre[group of c] applied to the window before the piece
+constexpr uint32_t SCAN_GROUP = 32;
+__device__ __forceinline__ uint16_t map_entry(const uint16_t *src, uint32_t nsym, uint32_t j) {
+    if (nsym >= WSIZE) return src[nsym - WSIZE + j];
+    if (j < WSIZE - nsym) return (uint16_t)(0x8000u | (j + nsym));  // the old window moves up
+    return src[j - (WSIZE - nsym)];
+}
+__global__ __launch_bounds__(1024) void k_scan_local(const ChunkDesc *d, const uint16_t *sym, uint32_t slot_syms, uint32_t n, uint16_t *local) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    uint16_t *R = (uint16_t *)smem;  // WSIZE entries: the running composition (a thread's 32 entries pass through registers)
+    const uint32_t g = blockIdx.x, t = threadIdx.x;
+    const uint32_t c0 = g * SCAN_GROUP, c1 = c0 + SCAN_GROUP < n ? c0 + SCAN_GROUP : n;
+    for (uint32_t c = c0; c < c1; c++) {
+        const uint32_t nsym = d[c].bit_start == NONE ? 0u : d[c].out_len;
+        const uint16_t *src = sym + (uint64_t)c * slot_syms;
+        uint16_t *out = local + (size_t)c * WSIZE;
+        uint16_t v[WSIZE / 1024];
+#pragma unroll
+        for (uint32_t k = 0; k < WSIZE / 1024; k++) {
+            uint16_t x = map_entry(src, nsym, t + 1024 * k);
+            if (c != c0 && (x & 0x8000u)) x = R[x & 0x7FFFu];
+            v[k] = x;
+        }
+        __syncthreads();  // every read of R is done
+#pragma unroll
+        for (uint32_t k = 0; k < WSIZE / 1024; k++) {
+            R[t + 1024 * k] = v[k];
+            out[t + 1024 * k] = v[k];
+        }
+        __syncthreads();
+    }
+}
+__global__ __launch_bounds__(1024) void k_scan_groups(const uint16_t *local, uint32_t n, uint16_t *pre) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    uint16_t *R = (uint16_t *)smem;
+    const uint32_t t = threadIdx.x;
+    const uint32_t ng = (n + SCAN_GROUP - 1) / SCAN_GROUP;
+    for (uint32_t j = t; j < WSIZE; j += 1024) {
+        R[j] = (uint16_t)(0x8000u | j);  // pre[0]: the identity
+        pre[j] = (uint16_t)(0x8000u | j);
+    }
+    __syncthreads();
+    for (uint32_t g = 1; g < ng; g++) {  // pre[g] = total[g - 1] o pre[g - 1]
+        const uint32_t last = g * SCAN_GROUP - 1;  // the last chunk of group g - 1
+        const uint16_t *tot = local + (size_t)last * WSIZE;
+        uint16_t *out = pre + (size_t)g * WSIZE;
+        uint16_t v[WSIZE / 1024];
+#pragma unroll
+        for (uint32_t k = 0; k < WSIZE / 1024; k++) {
+            uint16_t x = tot[t + 1024 * k];
+            if (x & 0x8000u) x = R[x & 0x7FFFu];
+            v[k] = x;
+        }
+        __syncthreads();
+#pragma unroll
+        for (uint32_t k = 0; k < WSIZE / 1024; k++) {
+            R[t + 1024 * k] = v[k];
+            out[t + 1024 * k] = v[k];
+        }
+        __syncthreads();
+    }
+}
+__global__ __launch_bounds__(256) void k_scan_windows(const uint16_t *local, const uint16_t *pre, const uint8_t *w0, uint8_t *windows) {
+    const uint32_t c = blockIdx.x;  // the window of chunk c
+    uint8_t *w = windows + (size_t)c * WSIZE;
+    if (c == 0) {
+        for (uint32_t j = blockIdx.y * 256 + threadIdx.x; j < WSIZE; j += gridDim.y * 256) w[j] = w0[j];
+        return;
+    }
+    const uint16_t *m = local + (size_t)(c - 1) * WSIZE;
+    const uint16_t *p = pre + (size_t)((c - 1) / SCAN_GROUP) * WSIZE;
+    for (uint32_t j = blockIdx.y * 256 + threadIdx.x; j < WSIZE; j += gridDim.y * 256) {
+        uint16_t x = m[j];
+        if (x & 0x8000u) x = p[x & 0x7FFFu];
+        w[j] = x & 0x8000u ? w0[x & 0x7FFFu] : (uint8_t)x;
     }
 }
 
@@ -2189,6 +2394,7 @@ public:
         trace_ = getenv("NOHUMAN_TRACE") != nullptr;
         v1_ = getenv("NOHUMAN_GZDEV_V1") != nullptr;  // the first versions of the search and decode kernels (A / B on one box)
         v2_ = getenv("NOHUMAN_GZDEV_V2") != nullptr;  // the scalar-decode version of k_inflate
+        if (const char *e = getenv("NOHUMAN_GZDEV_SCAN")) scan_rounds_ = !strcmp(e, "rounds");  // the log2(n) rounds of the first version
         if (hipSetDevice(device_) != hipSuccess) {
             err = "hipSetDevice failed";
             close();
@@ -2221,7 +2427,9 @@ public:
                  hipFuncSetAttribute((const void *)k_inflate, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(Lds)) == hipSuccess &&
                  hipFuncSetAttribute((const void *)k_search2, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(Lds)) == hipSuccess &&
                  hipFuncSetAttribute((const void *)k_inflate2, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(Lds)) == hipSuccess &&
-                 hipFuncSetAttribute((const void *)k_inflate3, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(Lds3)) == hipSuccess;
+                 hipFuncSetAttribute((const void *)k_inflate3, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(Lds3)) == hipSuccess &&
+                 hipFuncSetAttribute((const void *)k_scan_local, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(2 * WSIZE)) == hipSuccess &&
+                 hipFuncSetAttribute((const void *)k_scan_groups, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(2 * WSIZE)) == hipSuccess;
         for (auto &e : ev_)
             if (ok) ok = hipEventCreate(&e) == hipSuccess;
         if (!ok) {
@@ -2291,6 +2499,7 @@ public:
 
 private:
     static constexpr size_t ALIGN = 4096;
+    static constexpr size_t SEARCH3_LDS = sizeof(Lds3) > 64 * CLROW ? sizeof(Lds3) : 64 * CLROW;
     typedef void (*InflateFn)(const uint32_t *, uint64_t, uint32_t, ChunkDesc *, uint16_t *, uint32_t, uint32_t);
     InflateFn inflate_kernel() const { return v1_ ? k_inflate : v2_ ? k_inflate2 : k_inflate3; }
     size_t inflate_lds() const { return v1_ || v2_ ? sizeof(Lds) : sizeof(Lds3); }
@@ -2352,8 +2561,11 @@ private:
             if (v1_)
                 hipLaunchKernelGGL(k_search, dim3(n_str), dim3(64), sizeof(Lds), stream, (const uint32_t *)d_in_, valid_bits, (uint64_t)stretch_ * 8,
                                    first_bit, d_start_);
-            else
+            else if (v2_)
                 hipLaunchKernelGGL(k_search2, dim3(n_str), dim3(64), sizeof(Lds), stream, (const uint32_t *)d_in_, valid_bits,
+                                   (uint64_t)stretch_ * 8, first_bit, d_start_);
+            else
+                hipLaunchKernelGGL(k_search3, dim3(n_str), dim3(64), SEARCH3_LDS, stream, (const uint32_t *)d_in_, valid_bits,
                                    (uint64_t)stretch_ * 8, first_bit, d_start_);
             if (fake_start_ > 0 && (uint32_t)fake_start_ < n_str) {  // test knob: pretend the search found a start that is none
                 const uint64_t bogus = (uint64_t)fake_start_ * stretch_ * 8 + 13;
@@ -2413,14 +2625,25 @@ private:
             // windows by the prefix scan, text, CRCs, the window behind the piece
             if (trace_) (void)hipEventRecord(ev_[3], stream);
             const uint32_t gy = 4;
-            hipLaunchKernelGGL(k_maps, dim3(n_str, gy), dim3(256), 0, stream, (const ChunkDesc *)d_desc_, (const uint16_t *)d_sym_, slot_syms_,
-                               d_maps_[0]);
-            int cur = 0;
-            for (uint32_t stride = 1; stride < n_str; stride <<= 1) {
-                hipLaunchKernelGGL(k_scan_round, dim3(n_str, gy), dim3(256), 0, stream, (const uint16_t *)d_maps_[cur], d_maps_[cur ^ 1], n_str, stride);
-                cur ^= 1;
+            if (scan_rounds_) {
+                hipLaunchKernelGGL(k_maps, dim3(n_str, gy), dim3(256), 0, stream, (const ChunkDesc *)d_desc_, (const uint16_t *)d_sym_, slot_syms_,
+                                   d_maps_[0]);
+                int cur = 0;
+                for (uint32_t stride = 1; stride < n_str; stride <<= 1) {
+                    hipLaunchKernelGGL(k_scan_round, dim3(n_str, gy), dim3(256), 0, stream, (const uint16_t *)d_maps_[cur], d_maps_[cur ^ 1], n_str,
+                                       stride);
+                    cur ^= 1;
+                }
+                hipLaunchKernelGGL(k_windows, dim3(n_str, gy), dim3(256), 0, stream, (const uint16_t *)d_maps_[cur], (const uint8_t *)d_win_[win_],
+                                   d_windows_);
+            } else {
+                const uint32_t ng = (n_str + SCAN_GROUP - 1) / SCAN_GROUP;
+                hipLaunchKernelGGL(k_scan_local, dim3(ng), dim3(1024), 2 * WSIZE, stream, (const ChunkDesc *)d_desc_, (const uint16_t *)d_sym_, slot_syms_,
+                                   n_str, d_maps_[0]);
+                hipLaunchKernelGGL(k_scan_groups, dim3(1), dim3(1024), 2 * WSIZE, stream, (const uint16_t *)d_maps_[0], n_str, d_maps_[1]);
+                hipLaunchKernelGGL(k_scan_windows, dim3(n_str, gy), dim3(256), 0, stream, (const uint16_t *)d_maps_[0], (const uint16_t *)d_maps_[1],
+                                   (const uint8_t *)d_win_[win_], d_windows_);
             }
-            hipLaunchKernelGGL(k_windows, dim3(n_str, gy), dim3(256), 0, stream, (const uint16_t *)d_maps_[cur], (const uint8_t *)d_win_[win_], d_windows_);
             if (trace_) (void)hipEventRecord(ev_[4], stream);
             hipLaunchKernelGGL(k_resolve, dim3(n_str, 8), dim3(256), 0, stream, (const ChunkDesc *)d_desc_, (const uint16_t *)d_sym_, slot_syms_,
                                (const uint8_t *)d_windows_, (const uint64_t *)d_toff_, d_dst);
@@ -2550,7 +2773,7 @@ private:
     hipEvent_t ev_[7] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     uint32_t run_crc_ = 0;
     uint64_t run_len_ = 0;
-    bool trace_ = false, warned_ = false, host_mode_ = false, v1_ = false, v2_ = false;
+    bool trace_ = false, warned_ = false, host_mode_ = false, v1_ = false, v2_ = false, scan_rounds_ = false;
     uint32_t failed_in_a_row_ = 0, last_bad_ = 0;
     long fake_start_ = -1;
     uint64_t prof_[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
