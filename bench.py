@@ -166,7 +166,7 @@ class Ctx:
 
 
 def measure(cx, args, *, steps, warmup, single_end=False, ont=False, hit_frac=0.0, n_rate=0.0, pairs=None,
-            keep=False, capacity=None):
+            keep=False, capacity=None, read_len=None):
     """Builds the synthetic table and batches in this GPU's HBM and times `steps` launches.  Returns a
     dict with the numbers of one bench line; with keep=True also the live objects (engine, batches)."""
     torch, dist, np = cx.torch, cx.dist, cx.np
@@ -175,7 +175,7 @@ def measure(cx, args, *, steps, warmup, single_end=False, ont=False, hit_frac=0.
     paired = not (single_end or ont)
     mates = 2 if paired else 1
     n_frag = pairs if pairs is not None else args.pairs
-    L = args.read_len
+    L = read_len or args.read_len
 
     # ---- database: synthetic HPRC.r2-like table built directly in this GPU's HBM -------------
     capacity = capacity or args.capacity
@@ -443,7 +443,10 @@ def main():
                          ("single_end_config1", dict(single_end=True, pairs=1_000_000)),
                          ("ont_config3_scaled", dict(ont=True, pairs=200_000)),
                          # a table of more than 2^32 cells (64-bit cell positions in the kernels): 17.6 GB, four copies
-                         ("wide_table_4.4G_cells_PE", dict(pairs=1_000_000, capacity=4_400_000_011))):
+                         ("wide_table_4.4G_cells_PE", dict(pairs=1_000_000, capacity=4_400_000_011)),
+                         # 2 x 250 bp Illumina pairs: longer than one tile (158 bases), so every chunk is left to the generic
+                         # kernel k_classify -- the shape MiSeq / NovaSeq SP 2 x 250 runs meet
+                         ("pe_2x250", dict(pairs=600_000, read_len=250))):
             vm, vlive = measure(cx, args, steps=12, warmup=3, keep=True, **kw)
             chk = cpu_baseline(cx, args, vlive, 1.5)
             vlive["eng"].close()
@@ -815,7 +818,8 @@ def e2e_leg(cx, args, eng):
                 os.environ.pop("NOHUMAN_TRACE", None)
             if best is None or dt < best[0]:
                 best = (dt, st.total_sequences, st.classified)
-                trace = " | ".join(x.strip() for x in open(tr_path).read().strip().splitlines() if "wall" in x or "gunzip consumer" in x)
+                trace = " | ".join(x.strip() for x in open(tr_path).read().strip().splitlines()
+                                   if "wall" in x or "gunzip consumer" in x or "gzip reader on GPU" in x)
         dt, nfr, ncl = best
         # every read was kept: the outputs are the generated text, member by member (byte-exact, by digest)
         ok = nfr == n * reps and ncl == 0
@@ -844,6 +848,33 @@ def e2e_leg(cx, args, eng):
         st_in = eng.run(files[0], os.path.join(tmp, "h_1.fq"), in2=files[1], out2=os.path.join(tmp, "h_2.fq"),
                         threads=threads, keep_human=True)
         dt_in = time.perf_counter() - t
+        # the other gzip reader on the same inputs (the default reads .gz on the GPU, nh_gunzip.hip; NOHUMAN_GZ_READER=host is
+        # round 3's reader on the host cores): nothing kept, and gzip outputs further down
+        default_reader = os.environ.get("NOHUMAN_GZ_READER", "device")
+        other_reader = "host" if default_reader != "host" else "device"
+        other = {}
+        try:
+            os.environ["NOHUMAN_GZ_READER"] = other_reader
+            t = time.perf_counter()
+            st_o = eng.run(files[0], os.path.join(tmp, "h_1.fq"), in2=files[1], out2=os.path.join(tmp, "h_2.fq"),
+                           threads=threads, keep_human=True)
+            dt_o = time.perf_counter() - t
+            t = time.perf_counter()
+            st_og = eng.run(files[0], os.path.join(tmp, "x_1.fq.gz"), in2=files[1], out2=os.path.join(tmp, "x_2.fq.gz"),
+                            threads=threads, out_codec=2, codec_threads=max(1, threads // 2))
+            dt_og = time.perf_counter() - t
+            for pth in ("x_1.fq.gz", "x_2.fq.gz"):
+                os.remove(os.path.join(tmp, pth))
+            other = {"reader": other_reader,
+                     "input_side_only": {"value": round(2 * st_o.total_sequences / dt_o / 1e6, 3), "wall_s": round(dt_o, 4)},
+                     "gzip_output": {"value": round(2 * st_og.total_sequences / dt_og / 1e6, 3), "wall_s": round(dt_og, 4)}}
+        except Exception as ex:
+            other = {"reader": other_reader, "error": str(ex)[:300]}
+        finally:
+            if default_reader == "device" and "NOHUMAN_GZ_READER" in os.environ and os.environ["NOHUMAN_GZ_READER"] == other_reader:
+                os.environ.pop("NOHUMAN_GZ_READER", None)
+            if default_reader == "host":
+                os.environ["NOHUMAN_GZ_READER"] = "host"
         # the same run with gzip outputs, the reference's default for gzip inputs (main.rs:238-245): the kept reads
         # are compressed on the GPU (nh_deflate.hip) as the writer hands them over; the files are inflated again
         # by the library's own reader and compared with the generated text like the plain outputs
@@ -919,6 +950,9 @@ def e2e_leg(cx, args, eng):
                                 "what": "same inputs, keep_human=1 (no read is kept: inflate + parse + H2D + "
                                         "classify + D2H, no output bytes)"},
             "gzip_output": gz,
+            "gzip_reader": default_reader + (" (nh_gunzip.hip: block search, decode, window scan, marker resolve, CRC-32 on the GPU)"
+                                             if default_reader != "host" else " (nh_inflate.cpp on the host cores)"),
+            "other_gzip_reader": other,
             "setup_seconds": round(t_setup, 1),
         }
     finally:

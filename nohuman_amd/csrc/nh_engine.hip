@@ -558,7 +558,9 @@ static uint32_t frag_chunk_for(const Engine *e, uint32_t flags, uint64_t n_frag)
     // small launch finer chunks lose more at their boundaries than they win at the tail: 1 M single reads 634
     // Mreads/s in chunks of 12 against 765 in chunks of 32); only a launch too small to give every wave two
     // chunks is cut finer.
-    uint32_t c = paired ? 24u : 32u;
+    // round 4 (tools/sweep_sched.py sechunk, three interleaved passes, 1 M single reads): 32 -> 1.087 ms, 40 / 48 / 56 ->
+    // 1.075, 60 -> 1.062 (+2.3 %): single-end chunks take the 60 reads whose 61 offsets the lanes can hold
+    uint32_t c = paired ? 24u : 60u;
     const uint64_t waves = (uint64_t)e->grid_blocks * 4;
     const uint64_t fair = n_frag / (2 * waves);
     if (fair < c) c = (uint32_t)fair;

@@ -72,9 +72,10 @@ settings = {
            ("24,8,100,100", {"NOHUMAN_SCHED": "24,8,100,100"}), ("16,8,100,200", {"NOHUMAN_SCHED": "16,8,100,200"})],
     "hit": [("flat (default)", {}), ("guided", {"NOHUMAN_SCHED": "guided"})],
     "ont": [("default", {})],
-    "sechunk": [("32", {}), ("28", {"NOHUMAN_FRAG_CHUNK": "28"}), ("24", {"NOHUMAN_FRAG_CHUNK": "24"}),
+    "sechunk": [("32", {}), ("40", {"NOHUMAN_FRAG_CHUNK": "40"}), ("48", {"NOHUMAN_FRAG_CHUNK": "48"}), ("56", {"NOHUMAN_FRAG_CHUNK": "56"}),
+                ("60", {"NOHUMAN_FRAG_CHUNK": "60"}), ("28", {"NOHUMAN_FRAG_CHUNK": "28"}), ("24", {"NOHUMAN_FRAG_CHUNK": "24"}),
                 ("20", {"NOHUMAN_FRAG_CHUNK": "20"}), ("16", {"NOHUMAN_FRAG_CHUNK": "16"}), ("12", {"NOHUMAN_FRAG_CHUNK": "12"})],
-    "pechunk": [("24", {}), ("20", {"NOHUMAN_FRAG_CHUNK": "20"}), ("16", {"NOHUMAN_FRAG_CHUNK": "16"}),
+    "pechunk": [("24", {}), ("28", {"NOHUMAN_FRAG_CHUNK": "28"}), ("20", {"NOHUMAN_FRAG_CHUNK": "20"}), ("16", {"NOHUMAN_FRAG_CHUNK": "16"}),
                 ("12", {"NOHUMAN_FRAG_CHUNK": "12"}), ("30", {"NOHUMAN_FRAG_CHUNK": "30"})],
 }
 for shape in shapes:
