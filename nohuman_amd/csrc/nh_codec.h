@@ -16,9 +16,12 @@ public:
     virtual int finish() = 0;
     // Optional: the host bytes [host, host + len) also lie at `dev` in the memory of GPU `device` until the next
     // settle() returns -- an encoder that works on that GPU may take spans of them from there.
-    virtual void map_device(const void *host, size_t len, const void *dev, int device) {
-        (void)host, (void)len, (void)dev, (void)device;
+    // host_valid false: the bytes exist ONLY at `dev` (a batch of the reader on the GPU); spans of such a range are never
+    // read from the host.  Only encoders that answer takes_device_spans() may be handed such ranges.
+    virtual void map_device(const void *host, size_t len, const void *dev, int device, bool host_valid = true) {
+        (void)host, (void)len, (void)dev, (void)device, (void)host_valid;
     }
+    virtual bool takes_device_spans() const { return false; }
     // every byte handed to write() so far has been taken over: the caller's memory (host and mapped) is free again
     virtual int settle() { return 0; }
 };

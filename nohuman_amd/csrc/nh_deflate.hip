@@ -917,11 +917,15 @@ public:
         if (!write_fd(fd_, header, sizeof header)) return rc_ = set_error(NH_EIO, "write error on %s", name_.c_str());
         return NH_OK;
     }
-    void map_device(const void *host, size_t len, const void *dev, int device) override {
+    void map_device(const void *host, size_t len, const void *dev, int device, bool host_valid) override {
         map_host_ = (const uint8_t *)host;
         map_len_ = device == dev_.device ? len : 0;
         map_dev_ = (const uint8_t *)dev;
+        map_host_valid_ = host_valid;
+        if (!host_valid && device != dev_.device && rc_ == NH_OK)
+            rc_ = set_error(NH_EDEVICE, "gzip encoder on GPU %d was handed text that lies only on GPU %d", dev_.device, device);
     }
+    bool takes_device_spans() const override { return true; }
     int settle() override {
         const uint64_t t0 = now_ns();
         if (rc_ == NH_OK && hipSetDevice(dev_.device) == hipSuccess) rc_ = dev_.settle();
@@ -943,7 +947,8 @@ public:
             const size_t take = n < room ? n : room;
             // a long span of text that is on this GPU already (the batch the classifier worked on) is copied
             // there; everything else is staged in page-locked memory and uploaded in one piece
-            if (take >= DEVICE_SPAN_MIN && c >= map_host_ && c + take <= map_host_ + map_len_) {
+            const bool mapped = c >= map_host_ && c + take <= map_host_ + map_len_;
+            if (mapped && (take >= DEVICE_SPAN_MIN || !map_host_valid_)) {
                 rc_ = dev_.append_device(cur_, map_dev_ + (c - map_host_), take);
             } else {
                 memcpy(b.h_in + b.fill, c, take);
@@ -1005,6 +1010,7 @@ private:
     DeflateDev dev_;
     const uint8_t *map_host_ = nullptr, *map_dev_ = nullptr;
     size_t map_len_ = 0;
+    bool map_host_valid_ = true;
     int cur_ = 0;
     uint32_t crc_ = 0;
     uint64_t total_ = 0, out_bytes_ = 0;

@@ -7,6 +7,7 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <functional>
 #include <string>
 #include <vector>
 
@@ -147,12 +148,29 @@ struct HalfBatch {  // the records one input file contributes to a batch
     SeqFormat format = FMT_AUTO;
     bool eof = false;
     std::string error;  // non-empty: malformed input
+    // A batch born on a GPU (DevFastqReader, nh_gunzip.h): its text lies at dev_text in the memory of device dev_device,
+    // `text` has its size but holds the bytes only once host_text_valid says so (fetched for outputs that need them);
+    // release() hands the device memory back to the reader when the batch is done.
+    const uint8_t *dev_text = nullptr;
+    int dev_device = -1;
+    bool host_text_valid = true;
+    std::function<void()> release;
     void reset() {
+        if (release) {
+            release();
+            release = nullptr;
+        }
+        dev_text = nullptr;
+        dev_device = -1;
+        host_text_valid = true;
         text.clear();
         recs.clear();
         format = FMT_AUTO;
         eof = false;
         error.clear();
+    }
+    ~HalfBatch() {
+        if (release) release();
     }
 };
 

@@ -60,6 +60,31 @@ private:
     DevGunzipImpl *impl_;
 };
 
+// The whole reader of a gzip FASTQ file on the GPU: DevGunzip's text stays in HBM, a newline scan and a record kernel
+// index it there (kraken2's record semantics, SURVEY.md A.6: header verbatim with trailing whitespace stripped, id up to
+// the first blank, '+' line dropped, a record the file ends inside is dropped, an empty header line ends the input), and
+// what the host gets is the record table -- the batch's text is copied from HBM to HBM where the classifier reads it,
+// and only kept records of outputs that are written by the host ever cross PCIe.
+struct HalfBatch;
+class DevFastqImpl;
+class DevFastqReader {
+public:
+    DevFastqReader();
+    ~DevFastqReader();
+    DevFastqReader(const DevFastqReader &) = delete;
+    DevFastqReader &operator=(const DevFastqReader &) = delete;
+    // 0 ok; -1 error (err); 1: not a file this reader takes (no regular gzip file, BGZF): use BlockReader
+    int open(const char *path, int device, std::string &err);
+    // The next batch of exactly max_recs records (fewer only at the end of the input: hb.eof), the same max_recs in every
+    // call.  0 ok (hb.error set on malformed input); 1: the text is no four-line FASTQ (FASTA, wrapped sequences) and
+    // nothing has been handed out yet: use BlockReader on the file instead.
+    int next_batch(HalfBatch &hb, size_t max_recs);
+    void close();  // waits until every batch handed out has been released
+
+private:
+    DevFastqImpl *impl_;
+};
+
 // Is the file one the device reader takes (a regular gzip file; not BGZF, whose members hold a single final block each
 // and give the block search nothing to find -- the host reader takes those)?
 bool dev_gunzip_wants(const char *path);

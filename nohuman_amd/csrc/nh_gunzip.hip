@@ -2344,6 +2344,7 @@ public:
 
     int open(const char *path, int device, size_t seg_bytes, size_t stretch_bytes, std::string &err) {
         close();
+        const auto t_open = std::chrono::steady_clock::now();
         path_ = path;
         device_ = device;
         fd_ = ::open(path, O_RDONLY | O_CLOEXEC);
@@ -2439,6 +2440,7 @@ public:
             return -1;
         }
         if (const char *e = getenv("NOHUMAN_GZDEV_FAKE_START")) fake_start_ = atol(e);  // test knob: a false positive of the search
+        open_s_ = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_open).count();
         return 0;
     }
 
@@ -2456,10 +2458,10 @@ public:
         if (trace_ && st_.segments)
             fprintf(stderr,
                     "[nohuman trace] gzip reader on GPU %d, %s: %llu pieces, %llu chunks (%llu decoded again), %llu pieces by the host decoder, "
-                    "%llu members, %.2f GB -> %.2f GB; kernels ms: search %.1f decode %.1f windows %.1f resolve %.1f crc %.1f; host: copy %.3f s, wait %.3f s\n",
+                    "%llu members, %.2f GB -> %.2f GB; kernels ms: search %.1f decode %.1f windows %.1f resolve %.1f crc %.1f; host: open %.3f s, copy %.3f s, wait %.3f s\n",
                     device_, path_.c_str(), (unsigned long long)st_.segments, (unsigned long long)st_.chunks, (unsigned long long)st_.redecoded,
                     (unsigned long long)st_.fallback_segments, (unsigned long long)st_.members, st_.gzip_bytes / 1e9, st_.text_bytes / 1e9, st_.ms_search,
-                    st_.ms_decode, st_.ms_scan, st_.ms_resolve, st_.ms_crc, st_.s_host_copy, st_.s_wait);
+                    st_.ms_decode, st_.ms_scan, st_.ms_resolve, st_.ms_crc, open_s_, st_.s_host_copy, st_.s_wait);
 #ifdef NH_GZ_PROF
         if (st_.chunks)
             fprintf(stderr,
@@ -2776,6 +2778,7 @@ private:
     bool trace_ = false, warned_ = false, host_mode_ = false, v1_ = false, v2_ = false, scan_rounds_ = false;
     uint32_t failed_in_a_row_ = 0, last_bad_ = 0;
     long fake_start_ = -1;
+    double open_s_ = 0;
     uint64_t prof_[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 };
 
@@ -2851,3 +2854,429 @@ extern "C" int nh_gunzip_device_file(const char *in, const char *out, int32_t de
     (void)hipFree(d_text);
     return rc;
 }
+
+// =====================================================================================================================
+// DevFastqReader: the record index on the device (nh_gunzip.h)
+// =====================================================================================================================
+#include <atomic>
+#include <condition_variable>
+#include <mutex>
+
+#include "nh_fastx.h"
+
+namespace nh {
+namespace fq {
+
+constexpr uint32_t TILE = 16384;  // bytes of text a workgroup counts / lists newlines of
+
+__global__ __launch_bounds__(256) void k_nl_count(const uint8_t *text, uint64_t n, uint32_t *tile_cnt) {
+    __shared__ uint32_t s_sum[4];
+    const uint64_t t0 = (uint64_t)blockIdx.x * TILE;
+    uint32_t c = 0;
+    for (uint32_t i = threadIdx.x * 16; i < TILE; i += 256 * 16) {
+        const uint64_t p = t0 + i;
+        if (p + 16 <= n) {
+            const uint4 v = *(const uint4 *)(text + p);  // (the text starts 16-byte aligned)
+            const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const uint32_t x = w[k] ^ 0x0A0A0A0Au;  // zero bytes where the text has '\n'
+                c += (uint32_t)__popc(~(((x & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | x | 0x7F7F7F7Fu));
+            }
+        } else {
+            for (uint64_t q = p; q < n && q < p + 16; q++) c += text[q] == '\n';
+        }
+    }
+    for (int o = 32; o > 0; o >>= 1) c += (uint32_t)__shfl_xor((int)c, o);
+    if ((threadIdx.x & 63) == 0) s_sum[threadIdx.x >> 6] = c;
+    __syncthreads();
+    if (threadIdx.x == 0) tile_cnt[blockIdx.x] = s_sum[0] + s_sum[1] + s_sum[2] + s_sum[3];
+}
+
+// exclusive prefix sum of the tiles' counts (one workgroup), total behind the last entry
+__global__ __launch_bounds__(1024) void k_nl_scan(uint32_t *tile_cnt, uint32_t n_tiles) {
+    __shared__ unsigned long long s[1024];
+    const uint32_t t = threadIdx.x, per = (n_tiles + 1023) / 1024;
+    unsigned long long sum = 0;
+    for (uint32_t i = 0; i < per; i++) {
+        const uint32_t k = t * per + i;
+        if (k < n_tiles) sum += tile_cnt[k];
+    }
+    s[t] = sum;
+    __syncthreads();
+    for (uint32_t o = 1; o < 1024; o <<= 1) {
+        const unsigned long long v = t >= o ? s[t - o] : 0;
+        __syncthreads();
+        s[t] += v;
+        __syncthreads();
+    }
+    unsigned long long run = s[t] - sum;
+    for (uint32_t i = 0; i < per; i++) {
+        const uint32_t k = t * per + i;
+        if (k < n_tiles) {
+            const uint32_t c = tile_cnt[k];
+            tile_cnt[k] = (uint32_t)run;
+            run += c;
+        }
+    }
+    if (t == 1023) tile_cnt[n_tiles] = (uint32_t)s[1023];
+}
+
+// positions of the newlines, in order
+__global__ __launch_bounds__(256) void k_nl_list(const uint8_t *text, uint64_t n, const uint32_t *tile_off, uint32_t *nl) {
+    __shared__ uint32_t s_cnt[256];
+    const uint64_t t0 = (uint64_t)blockIdx.x * TILE;
+    const uint32_t per = TILE / 256;  // 64 consecutive bytes a thread
+    const uint64_t p0 = t0 + (uint64_t)threadIdx.x * per;
+    uint64_t m = 0;  // bit i: byte p0 + i is a newline
+    for (uint32_t i = 0; i < per; i++)
+        if (p0 + i < n && text[p0 + i] == '\n') m |= 1ull << i;
+    s_cnt[threadIdx.x] = (uint32_t)__popcll(m);
+    __syncthreads();
+    for (uint32_t o = 1; o < 256; o <<= 1) {
+        const uint32_t v = threadIdx.x >= o ? s_cnt[threadIdx.x - o] : 0;
+        __syncthreads();
+        s_cnt[threadIdx.x] += v;
+        __syncthreads();
+    }
+    uint32_t at = tile_off[blockIdx.x] + s_cnt[threadIdx.x] - (uint32_t)__popcll(m);
+    while (m) {
+        nl[at++] = (uint32_t)(p0 + (uint64_t)__builtin_ctzll(m));
+        m &= m - 1;
+    }
+}
+
+__device__ __forceinline__ bool is_space(uint8_t c) { return c == ' ' || (c >= 9 && c <= 13); }
+
+// One record a thread: lines 4r .. 4r+3.  Offsets are relative to the first record of the record's batch (batches of
+// `bf` records from record 0 on); bstart[b] = absolute offset of batch b's first record, bstart[nb] = end of the last record.
+// bad: the smallest (record << 2 | kind) of a record that is none -- kind 1: empty header line or "@" alone (kraken2 ends
+// the input there), 2: no '@' (malformed).
+__global__ __launch_bounds__(256) void k_records(const uint8_t *text, const uint32_t *nl, uint32_t n_rec, uint32_t bf, RecRef *recs,
+                                                 uint32_t *bstart, unsigned long long *bad) {
+    const uint32_t r = blockIdx.x * 256 + threadIdx.x;
+    if (r >= n_rec) return;
+    const uint32_t l0 = 4 * r;
+    const uint32_t b0 = l0 ? nl[l0 - 1] + 1 : 0, e0 = nl[l0];
+    const uint32_t b1 = e0 + 1, e1 = nl[l0 + 1], b2 = e1 + 1, e2 = nl[l0 + 2], b3 = e2 + 1, e3 = nl[l0 + 3];
+    uint32_t he = e0, se = e1, qe = e3;
+    while (he > b0 && is_space(text[he - 1])) he--;
+    while (se > b1 && is_space(text[se - 1])) se--;
+    while (qe > b3 && is_space(text[qe - 1])) qe--;
+    if (he - b0 <= 1) atomicMin(bad, ((unsigned long long)r << 2) | 1ull);
+    else if (text[b0] != '@') atomicMin(bad, ((unsigned long long)r << 2) | 2ull);
+    uint32_t ie = b0 + 1;
+    while (ie < he && text[ie] != ' ' && text[ie] != '\t' && text[ie] != '\r') ie++;
+    const uint32_t rb = r / bf * bf;  // first record of the batch
+    const uint32_t base = rb ? nl[4 * rb - 1] + 1 : 0;
+    const bool canon = he == e0 && se == e1 && qe == e3 && e2 - b2 == 1 && text[b2] == '+';
+    RecRef x;
+    x.h = b0 - base;
+    x.hlen = he - b0;
+    x.idlen = ie > b0 ? ie - b0 - 1 : 0;
+    x.s = b1 - base;
+    x.slen = se - b1;
+    x.q = b3 - base;
+    x.qlen = qe - b3;
+    x.raw_end = canon ? e3 + 1 - base : 0;
+    recs[r] = x;
+    if (r == rb) bstart[r / bf] = b0;
+    if (r == n_rec - 1) bstart[(n_rec + bf - 1) / bf] = e3 + 1;
+}
+
+}  // namespace fq
+
+class DevFastqImpl {
+public:
+    ~DevFastqImpl() { close(); }
+    int open(const char *path, int device, std::string &err) {
+        if (!dev_gunzip_wants(path)) return 1;
+        device_ = device;
+        path_ = path;
+        if (hipSetDevice(device) != hipSuccess) {
+            err = "hipSetDevice failed";
+            return -1;
+        }
+        if (gz_.open(path, device, 0, 0, err) != 0) return -1;
+        room_ = (size_t)2560u << 20;
+        struct stat st;
+        if (stat(path, &st) == 0 && (uint64_t)st.st_size * 16 + ((size_t)64u << 20) < room_) room_ = (size_t)st.st_size * 16 + ((size_t)64u << 20);
+        if (const char *e = getenv("NOHUMAN_GZDEV_ROOM")) room_ = std::max<size_t>((size_t)atoll(e), (size_t)1u << 20);
+        if (hipStreamCreateWithFlags(&stream_, hipStreamNonBlocking) != hipSuccess) {
+            err = "cannot create a stream";
+            return -1;
+        }
+        for (;;) {
+            const bool ok = hipMalloc((void **)&buf_[0].d_text, room_ + 4096) == hipSuccess && hipMalloc((void **)&buf_[1].d_text, room_ + 4096) == hipSuccess;
+            if (ok) break;
+            (void)hipGetLastError();
+            for (Piece &b : buf_) {
+                if (b.d_text) (void)hipFree(b.d_text);
+                b.d_text = nullptr;
+            }
+            if (room_ <= ((size_t)128u << 20)) {
+                err = "the gzip reader's text buffers cannot be had";
+                return -1;
+            }
+            room_ /= 2;
+        }
+        if (hipMalloc((void **)&d_bad_, 8) != hipSuccess || hipHostMalloc((void **)&h_bad_, 8, hipHostMallocDefault) != hipSuccess) {
+            err = "the gzip reader's buffers cannot be had";
+            return -1;
+        }
+        trace_ = getenv("NOHUMAN_TRACE") != nullptr;
+        return 0;
+    }
+
+    int next_batch(HalfBatch &hb, size_t max_recs) {
+        hb.reset();
+        hb.format = FMT_FASTQ;
+        if (!error_.empty()) {
+            hb.error = error_;
+            return 0;
+        }
+        if (bf_ == 0) bf_ = max_recs ? max_recs : 1;
+        if (max_recs != bf_) {
+            hb.error = error_ = "DevFastqReader: the batch size changed";
+            return 0;
+        }
+        if (hipSetDevice(device_) != hipSuccess) {
+            hb.error = error_ = "hipSetDevice failed";
+            return 0;
+        }
+        for (;;) {
+            Piece &p = buf_[cur_];
+            if (p.loaded) {
+                const size_t left = p.n_rec - p.next_rec;
+                if (left >= bf_ || (p.last && left > 0)) return emit(hb, p);
+                if (p.last) {  // nothing left at all
+                    hb.eof = true;
+                    return 0;
+                }
+            }
+            const int rc = load_next();
+            if (rc == 1) return 1;
+            if (rc < 0) {
+                hb.error = error_;
+                return 0;
+            }
+        }
+    }
+
+    void close() {
+        // every batch handed out points into the text buffers: wait until the pipeline has let go of them
+        {
+            std::unique_lock<std::mutex> lk(mu_);
+            cv_.wait(lk, [&] { return buf_[0].outstanding == 0 && buf_[1].outstanding == 0; });
+        }
+        if (trace_ && pieces_)
+            fprintf(stderr, "[nohuman trace] record index on GPU %d, %s: %llu pieces, %llu records, index kernels + table D2H %.3f s, carried %.2f GB\n",
+                    device_, path_.c_str(), (unsigned long long)pieces_, (unsigned long long)records_, index_s_, carried_ / 1e9);
+        pieces_ = 0;
+        gz_.close();
+        if (device_ >= 0) (void)hipSetDevice(device_);
+        for (Piece &b : buf_) {
+            for (void *q : {(void *)b.d_text, (void *)b.d_nl, (void *)b.d_tiles, (void *)b.d_recs, (void *)b.d_bstart})
+                if (q) (void)hipFree(q);
+            for (void *q : {(void *)b.h_recs, (void *)b.h_bstart})
+                if (q) (void)hipHostFree(q);
+            b = Piece();
+        }
+        if (d_bad_) (void)hipFree(d_bad_);
+        if (h_bad_) (void)hipHostFree(h_bad_);
+        d_bad_ = nullptr, h_bad_ = nullptr;
+        if (stream_) (void)hipStreamDestroy(stream_);
+        stream_ = nullptr;
+    }
+
+private:
+    struct Piece {
+        uint8_t *d_text = nullptr;
+        uint32_t *d_nl = nullptr, *d_tiles = nullptr, *d_bstart = nullptr, *h_bstart = nullptr;
+        RecRef *d_recs = nullptr, *h_recs = nullptr;
+        size_t nl_cap = 0, tile_cap = 0, rec_cap = 0, bs_cap = 0;
+        size_t text_len = 0, used_len = 0;  // bytes of text; bytes up to the end of the last complete record
+        size_t n_rec = 0, next_rec = 0;
+        bool loaded = false, last = false;
+        int outstanding = 0;  // batches handed out and not yet released
+    };
+
+    int fail(const std::string &m) {
+        if (error_.empty()) error_ = m;
+        return -1;
+    }
+    template <class T>
+    bool grow_dev(T *&p, size_t &cap, size_t need) {
+        if (need <= cap) return true;
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        cap = need + need / 4 + 1024;
+        return hipMalloc((void **)&p, cap * sizeof(T)) == hipSuccess;
+    }
+
+    int emit(HalfBatch &hb, Piece &p) {
+        const size_t r0 = p.next_rec, r1 = std::min(p.n_rec, r0 + bf_);
+        const size_t b = r0 / bf_;
+        const size_t t0 = p.h_bstart[b], t1 = p.h_bstart[b + 1];
+        hb.recs.assign(p.h_recs + r0, p.h_recs + r1);
+        const size_t len = t1 - t0;
+        if (!hb.text.reserve(len + 64)) {
+            hb.error = error_ = "out of memory";
+            return 0;
+        }
+        hb.text.set_size(len);
+        hb.dev_text = p.d_text + t0;
+        hb.dev_device = device_;
+        hb.host_text_valid = false;
+        p.next_rec = r1;
+        hb.eof = p.last && r1 == p.n_rec;
+        {
+            std::lock_guard<std::mutex> lk(mu_);
+            p.outstanding++;
+        }
+        Piece *pp = &p;
+        hb.release = [this, pp] {
+            {
+                std::lock_guard<std::mutex> lk(mu_);
+                pp->outstanding--;
+            }
+            cv_.notify_all();
+        };
+        return 0;
+    }
+
+    // the next piece of the stream into the other buffer, behind what the current one could not hand out
+    int load_next() {
+        using namespace fq;
+        Piece &old = buf_[cur_];
+        Piece &p = buf_[cur_ ^ 1];
+        {
+            std::unique_lock<std::mutex> lk(mu_);
+            cv_.wait(lk, [&] { return p.outstanding == 0; });
+        }
+        size_t carry = 0;
+        if (old.loaded) {
+            // records not handed out (fewer than a batch) and the incomplete record behind them
+            const size_t from = old.next_rec < old.n_rec ? old.h_bstart[old.next_rec / bf_] : old.used_len;
+            carry = old.text_len - from;
+            if (carry >= room_) return fail("a FASTQ record larger than the gzip reader's text buffer");
+            if (carry && hipMemcpyAsync(p.d_text, old.d_text + from, carry, hipMemcpyDeviceToDevice, stream_) != hipSuccess) return fail("D2D of the carried text failed");
+            carried_ += carry;
+        }
+        const long n = gz_.next(p.d_text + carry, room_ - carry, stream_);
+        if (n < 0) return fail(gz_.error());
+        p.text_len = carry + (size_t)n;
+        p.last = gz_.ended();
+        p.loaded = true;
+        p.n_rec = p.next_rec = 0;
+        p.used_len = 0;
+        old.loaded = false;
+        cur_ ^= 1;
+        pieces_++;
+        if (p.text_len == 0) return 0;
+        const auto t0 = std::chrono::steady_clock::now();
+        if (p.last) {  // the input's last line may lack its newline
+            uint8_t lastc = 0;
+            if (hipMemcpyAsync(&lastc, p.d_text + p.text_len - 1, 1, hipMemcpyDeviceToHost, stream_) != hipSuccess || hipStreamSynchronize(stream_) != hipSuccess)
+                return fail("reading the text's last byte failed");
+            if (lastc != '\n') {
+                if (hipMemsetAsync(p.d_text + p.text_len, '\n', 1, stream_) != hipSuccess) return fail("hipMemsetAsync failed");
+                p.text_len++;
+            }
+        }
+        // newlines -> lines -> records
+        const uint32_t n_tiles = (uint32_t)((p.text_len + TILE - 1) / TILE);
+        if (!grow_dev(p.d_tiles, p.tile_cap, (size_t)n_tiles + 1)) return fail("the record index's buffers cannot be had");
+        hipLaunchKernelGGL(k_nl_count, dim3(n_tiles), dim3(256), 0, stream_, (const uint8_t *)p.d_text, (uint64_t)p.text_len, p.d_tiles);
+        hipLaunchKernelGGL(k_nl_scan, dim3(1), dim3(1024), 0, stream_, p.d_tiles, n_tiles);
+        uint32_t n_lines = 0;
+        if (hipMemcpyAsync(&n_lines, p.d_tiles + n_tiles, 4, hipMemcpyDeviceToHost, stream_) != hipSuccess || hipStreamSynchronize(stream_) != hipSuccess)
+            return fail("the newline count could not be read");
+        if (!grow_dev(p.d_nl, p.nl_cap, (size_t)n_lines + 4)) return fail("the record index's buffers cannot be had");
+        if (n_lines) hipLaunchKernelGGL(k_nl_list, dim3(n_tiles), dim3(256), 0, stream_, (const uint8_t *)p.d_text, (uint64_t)p.text_len, (const uint32_t *)p.d_tiles, p.d_nl);
+        size_t n_rec = n_lines / 4;
+        if (n_rec) {
+            const size_t nb = (n_rec + bf_ - 1) / bf_;
+            if (n_rec > p.rec_cap) {
+                if (p.h_recs) (void)hipHostFree(p.h_recs);
+                p.h_recs = nullptr;
+                if (!grow_dev(p.d_recs, p.rec_cap, n_rec) || hipHostMalloc((void **)&p.h_recs, p.rec_cap * sizeof(RecRef), hipHostMallocDefault) != hipSuccess)
+                    return fail("the record table's buffers cannot be had");
+            }
+            if (nb + 1 > p.bs_cap) {
+                if (p.h_bstart) (void)hipHostFree(p.h_bstart);
+                p.h_bstart = nullptr;
+                if (!grow_dev(p.d_bstart, p.bs_cap, nb + 1) || hipHostMalloc((void **)&p.h_bstart, p.bs_cap * 4, hipHostMallocDefault) != hipSuccess)
+                    return fail("the record table's buffers cannot be had");
+            }
+            *h_bad_ = ~0ull;
+            if (hipMemcpyAsync(d_bad_, h_bad_, 8, hipMemcpyHostToDevice, stream_) != hipSuccess) return fail("H2D failed");
+            hipLaunchKernelGGL(k_records, dim3((unsigned)((n_rec + 255) / 256)), dim3(256), 0, stream_, (const uint8_t *)p.d_text, (const uint32_t *)p.d_nl,
+                               (uint32_t)n_rec, (uint32_t)bf_, p.d_recs, p.d_bstart, d_bad_);
+            if (hipMemcpyAsync(h_bad_, d_bad_, 8, hipMemcpyDeviceToHost, stream_) != hipSuccess ||
+                hipMemcpyAsync(p.h_recs, p.d_recs, n_rec * sizeof(RecRef), hipMemcpyDeviceToHost, stream_) != hipSuccess ||
+                hipMemcpyAsync(p.h_bstart, p.d_bstart, (nb + 1) * 4, hipMemcpyDeviceToHost, stream_) != hipSuccess ||
+                hipStreamSynchronize(stream_) != hipSuccess)
+                return fail("the record table could not be read");
+            if (*h_bad_ != ~0ull) {
+                const size_t br = (size_t)(*h_bad_ >> 2);
+                const unsigned kind = (unsigned)(*h_bad_ & 3);
+                if (kind == 2) {
+                    if (!handed_out_ && pieces_ == 1 && br == 0) return 1;  // no FASTQ at all (FASTA, ...): the host reader's business
+                    // kraken2's message, with the line it saw
+                    const size_t b = br / bf_;
+                    const size_t at = (size_t)p.h_bstart[b] + p.h_recs[br].h;
+                    std::vector<char> line(std::min<size_t>(p.h_recs[br].hlen, 200));
+                    (void)hipMemcpy(line.data(), p.d_text + at, line.size(), hipMemcpyDeviceToHost);
+                    return fail("malformed FASTQ file (exp. '@', saw \"" + std::string(line.begin(), line.end()) + "\"), aborting");
+                }
+                // an empty header line (or "@" alone): kraken2 stops reading there
+                n_rec = br;
+                p.last = true;
+                if (n_rec) {
+                    const size_t nb2 = (n_rec + bf_ - 1) / bf_;
+                    const RecRef &lr = p.h_recs[n_rec - 1];
+                    const size_t lb = (n_rec - 1) / bf_;
+                    // the end of the last record that counts: its quality line's end (+ newline)
+                    uint32_t endq = p.h_bstart[lb] + lr.q + lr.qlen;
+                    p.h_bstart[nb2] = lr.raw_end ? p.h_bstart[lb] + lr.raw_end : endq + 1;
+                }
+            }
+        }
+        p.n_rec = n_rec;
+        p.used_len = n_rec ? p.h_bstart[(n_rec + bf_ - 1) / bf_] : 0;
+        if (p.last && p.used_len > p.text_len) p.used_len = p.text_len;
+        records_ += n_rec;
+        if (n_rec) handed_out_ = true;
+        // FASTA, or nothing recognisable, in the very first piece: not ours
+        if (!handed_out_ && pieces_ == 1 && p.text_len) {
+            uint8_t c0 = 0;
+            (void)hipMemcpy(&c0, p.d_text, 1, hipMemcpyDeviceToHost);
+            if (c0 != '@') return 1;
+        }
+        index_s_ += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+        return 0;
+    }
+
+    DevGunzip gz_;
+    std::string path_, error_;
+    int device_ = -1;
+    hipStream_t stream_ = nullptr;
+    Piece buf_[2];
+    int cur_ = 0;
+    size_t room_ = 0, bf_ = 0;
+    unsigned long long *d_bad_ = nullptr, *h_bad_ = nullptr;
+    bool handed_out_ = false, trace_ = false;
+    uint64_t pieces_ = 0, records_ = 0, carried_ = 0;
+    double index_s_ = 0;
+    std::mutex mu_;
+    std::condition_variable cv_;
+};
+
+DevFastqReader::DevFastqReader() : impl_(new DevFastqImpl()) {}
+DevFastqReader::~DevFastqReader() { delete impl_; }
+int DevFastqReader::open(const char *path, int device, std::string &err) { return impl_->open(path, device, err); }
+int DevFastqReader::next_batch(HalfBatch &hb, size_t max_recs) { return impl_->next_batch(hb, max_recs); }
+void DevFastqReader::close() { impl_->close(); }
+
+}  // namespace nh

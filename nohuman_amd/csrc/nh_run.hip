@@ -29,6 +29,7 @@
 
 #include "nh_codec.h"
 #include "nh_fastx.h"
+#include "nh_gunzip.h"
 #include "nh_internal.h"
 #include "nohuman_engine.h"
 
@@ -435,6 +436,10 @@ public:
     }
     void put(std::unique_ptr<HalfBatch> hb) {
         if (!hb) return;
+        if (hb->release) {  // a batch born on the GPU: its text buffer goes back to the device reader
+            hb->release();
+            hb->release = nullptr;
+        }
         std::lock_guard<std::mutex> lk(mu_);
         free_.push_back(std::move(hb));
     }
@@ -477,6 +482,53 @@ enum { ST_READ1 = 0, ST_READ2, ST_RPUSH1, ST_RPUSH2, ST_MPOP, ST_MSLOT, ST_MGATH
 static void reader_main(const char *path, BoundedQueue<std::unique_ptr<HalfBatch>> *out, RunState *rs,
                         BatchPool *pool, StageClock *clk, int which, size_t batch_frags, size_t batch_text,
                         unsigned gz_threads, int gz_device) {
+    // gzip FASTQ: the whole reader on the GPU (inflate, record index; the text stays in HBM) unless NOHUMAN_GZ_READER says
+    // otherwise -- "host": the host decoders; "device-text": inflate on the GPU, records parsed on the host (BlockReader)
+    {
+        const char *how = getenv("NOHUMAN_GZ_READER");
+        const bool want = gz_device >= 0 && !(how && (!strcmp(how, "host") || !strcmp(how, "device-text")));
+        if (want) {
+            DevFastqReader dr;
+            std::string derr;
+            const int orc = dr.open(path, gz_device, derr);
+            if (orc < 0) {
+                if (how && !strcmp(how, "device")) {  // asked for by name: no silent change of reader
+                    rs->fail(NH_EIO, derr);
+                    out->close();
+                    return;
+                }
+                fprintf(stderr, "nohuman: WARN %s: the gzip reader on GPU %d could not be set up (%s); reading on the host\n", path, gz_device,
+                        derr.c_str());
+            }
+            bool fell_back = orc != 0;
+            while (!fell_back) {
+                std::unique_ptr<HalfBatch> hb = pool->get();
+                uint64_t t0 = StageClock::now();
+                const int rc = dr.next_batch(*hb, batch_frags);
+                uint64_t t1 = StageClock::now();
+                clk->ns[ST_READ1 + which] += t1 - t0;
+                if (rc == 1) {  // no four-line FASTQ: the host parser reads the file (FASTA, wrapped lines, its error messages)
+                    pool->put(std::move(hb));
+                    fell_back = true;
+                    break;
+                }
+                if (!hb->error.empty()) {
+                    rs->fail(NH_EIO, hb->error);
+                    break;
+                }
+                const bool eof = hb->eof;
+                out->push(std::move(hb));
+                clk->ns[ST_RPUSH1 + which] += StageClock::now() - t1;
+                if (eof || rs->failed()) break;
+            }
+            if (!fell_back) {
+                out->close();
+                dr.close();  // (waits for the batches still in the pipeline: they point into its buffers)
+                return;
+            }
+            dr.close();
+        }
+    }
     BlockReader r;
     std::string err;
     if (r.open(path, err, gz_threads, gz_device) != 0) {
@@ -650,6 +702,12 @@ int run_engines(const std::vector<Engine *> &engines, const nh_run_args *a, nh_s
     const size_t BATCH_TEXT = rs.paired ? (size_t)0x7F000000u : (size_t)(512u << 20);
     const int G = (int)engines.size();
     const int mates = rs.paired ? 2 : 1;
+    // Batches of the reader on the GPU keep their text in HBM.  The host needs the bytes for plain outputs and the host's
+    // codecs, for the ids of --output lines and for the suffix of classified-out headers; gzip outputs encoded on the GPU
+    // take the kept records from HBM (a record that needs reformatting -- CRLF, "+id" -- makes the writer fetch its batch).
+    const bool host_text_wanted = !(a->out_codec == NH_CODEC_GZIP && o1.enc && o1.enc->takes_device_spans() &&
+                                    (!rs.paired || (o2.enc && o2.enc->takes_device_spans()))) ||
+                                  rs.want_k || a->keep_human != 0 || G > 1;  // (G > 1: a batch's slot and its file's encoder may sit on different GPUs)
     const uint32_t flags = rs.paired ? NH_FLAG_PAIRED : 0;
     auto t0 = std::chrono::steady_clock::now();
 
@@ -758,13 +816,29 @@ int run_engines(const std::vector<Engine *> &engines, const nh_run_args *a, nh_s
                 if (he != hipSuccess) wrc = set_error(NH_EDEVICE, "classify: %s", hipGetErrorString(he));
                 if (!wrc) wrc = check_error_flag(s.e);
                 if (!wrc) {
+                    const size_t base2w = (b.h1->text.size() + 8 + 255) & ~(size_t)255;
+                    // a batch whose text is only in HBM, and a kept record that must be rewritten (CRLF, "+id" line): fetch it
+                    auto need_fetch = [&](const HalfBatch &hb) {
+                        if (hb.host_text_valid) return false;
+                        for (size_t i = 0; i < b.n; i++)
+                            if (!hb.recs[i].raw_end && (s.h_res[i].call != 0) == (a->keep_human != 0)) return true;
+                        return false;
+                    };
+                    for (int m = 0; m < (rs.paired ? 2 : 1) && !wrc; m++) {
+                        HalfBatch &hb = m ? *b.h2 : *b.h1;
+                        if (need_fetch(hb)) {
+                            if (hipMemcpy(hb.text.data(), (const char *)s.d_text + (m ? base2w : 0), hb.text.size(), hipMemcpyDeviceToHost) != hipSuccess)
+                                wrc = set_error(NH_EDEVICE, "fetching a batch's text from the device failed");
+                            hb.host_text_valid = true;
+                        }
+                    }
                     // the batch's raw text is still in the slot's device buffer: an encoder on that GPU takes
                     // the kept records from there instead of a second trip over PCIe
-                    if (o1.enc) o1.enc->map_device(b.h1->text.data(), b.h1->text.size(), s.d_text, s.e->device);
-                    if (rs.paired && o2.enc) {
-                        const size_t base2 = (b.h1->text.size() + 8 + 255) & ~(size_t)255;
-                        o2.enc->map_device(b.h2->text.data(), b.h2->text.size(), (const char *)s.d_text + base2, s.e->device);
-                    }
+                    if (o1.enc) o1.enc->map_device(b.h1->text.data(), b.h1->text.size(), s.d_text, s.e->device, b.h1->host_text_valid);
+                    if (rs.paired && o2.enc)
+                        o2.enc->map_device(b.h2->text.data(), b.h2->text.size(), (const char *)s.d_text + base2w, s.e->device, b.h2->host_text_valid);
+                }
+                if (!wrc) {
                     format_batch(&rs, b, s, o1, o2, ok);
                     uint64_t c3 = StageClock::now();
                     clk.ns[ST_WFORMAT] += c3 - c2;
@@ -886,10 +960,22 @@ int run_engines(const std::vector<Engine *> &engines, const nh_run_args *a, nh_s
             uint64_t m3 = StageClock::now();
             clk.ns[ST_MGATHER] += m3 - m2;
             hipError_t he = hipSetDevice(s.e->device);
-            if (he == hipSuccess && len1)
-                he = hipMemcpyAsync(s.d_text, b.h1->text.data(), len1, hipMemcpyHostToDevice, s.stream);
-            if (he == hipSuccess && len2)
-                he = hipMemcpyAsync((char *)s.d_text + base2, b.h2->text.data(), len2, hipMemcpyHostToDevice, s.stream);
+            // the batch's text: from the host as it was read, or -- a batch of the reader on the GPU -- from HBM to HBM (from
+            // another device's memory: over xGMI); the bytes then go to the host only if an output written there needs them
+            auto stage_text = [&](HalfBatch &hb, size_t at, size_t len) -> hipError_t {
+                if (!len) return hipSuccess;
+                if (!hb.dev_text) return hipMemcpyAsync((char *)s.d_text + at, hb.text.data(), len, hipMemcpyHostToDevice, s.stream);
+                hipError_t e2 = hb.dev_device == s.e->device
+                                    ? hipMemcpyAsync((char *)s.d_text + at, hb.dev_text, len, hipMemcpyDeviceToDevice, s.stream)
+                                    : hipMemcpyPeerAsync((char *)s.d_text + at, s.e->device, hb.dev_text, hb.dev_device, len, s.stream);
+                if (e2 == hipSuccess && host_text_wanted) {
+                    e2 = hipMemcpyAsync(hb.text.data(), (char *)s.d_text + at, len, hipMemcpyDeviceToHost, s.stream);
+                    hb.host_text_valid = true;  // (once the stream has been synchronised: the writer does that first)
+                }
+                return e2;
+            };
+            if (he == hipSuccess) he = stage_text(*b.h1, 0, len1);
+            if (he == hipSuccess && rs.paired) he = stage_text(*b.h2, base2, len2);
             if (he == hipSuccess)
                 he = hipMemcpyAsync(s.d_off, s.h_off, b.n * mates * 8, hipMemcpyHostToDevice, s.stream);
             if (he == hipSuccess)
@@ -923,6 +1009,11 @@ int run_engines(const std::vector<Engine *> &engines, const nh_run_args *a, nh_s
     q1.close();
     q2.close();
     wq.close();
+    {   // what the readers had queued is dropped (a batch born on the GPU gives its text buffer back: its reader waits for that)
+        std::unique_ptr<HalfBatch> drop;
+        while (q1.pop(drop)) drop.reset();
+        while (q2.pop(drop)) drop.reset();
+    }
     t1.join();
     if (t2.joinable()) t2.join();
     tw.join();

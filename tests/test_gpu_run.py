@@ -134,6 +134,107 @@ def test_gzip_pairs_through_the_reader_on_the_gpu_and_on_the_host(tmp_path, monk
     assert [ln.split("\t")[4] for ln in lines] == [r["hitlist"] for r in recs]
 
 
+def _run_both_readers(tmp_path, monkeypatch, name, data1, data2=None, out_codec=0, batch=None, **kw):
+    """nh_run on gzip inputs with the reader on the GPU (record index there, text resident in HBM), with the GPU inflating for
+    the host parser ("device-text") and with the host reader: the three must write the same bytes and count the same"""
+    from nohuman_amd import Engine
+    outs = {}
+    p1 = tmp_path / (name + "_1.fq.gz")
+    p1.write_bytes(gzip.compress(data1, 6))
+    p2 = None
+    if data2 is not None:
+        p2 = tmp_path / (name + "_2.fq.gz")
+        p2.write_bytes(gzip.compress(data2, 6))
+    if batch:
+        monkeypatch.setenv("NOHUMAN_BATCH_FRAGS", str(batch))
+    for reader in ("device", "device-text", "host"):
+        monkeypatch.setenv("NOHUMAN_GZ_READER", reader)
+        o1, o2, k = tmp_path / ("o1_" + reader), tmp_path / ("o2_" + reader), tmp_path / ("k_" + reader)
+        with Engine.open(DB) as eng:
+            st = eng.run(str(p1), str(o1), in2=str(p2) if p2 else None, out2=str(o2) if p2 else None,
+                         kraken_output=str(k) if kw.pop("kraken", False) or kw.get("_k") else None, out_codec=out_codec, threads=4,
+                         **{a: b for a, b in kw.items() if not a.startswith("_")})
+        rd = (lambda p: gzip.decompress(p.read_bytes())) if out_codec == 2 else (lambda p: p.read_bytes())
+        outs[reader] = (rd(o1), rd(o2) if p2 else b"", k.read_bytes() if k.exists() else b"",
+                        (st.total_sequences, st.classified, st.total_bases))
+    monkeypatch.delenv("NOHUMAN_BATCH_FRAGS", raising=False)
+    assert outs["device"] == outs["host"], name
+    assert outs["device-text"] == outs["host"], name
+    return outs["host"]
+
+
+@pytest.mark.parametrize("out_codec", [0, 2])
+def test_record_index_on_the_gpu_keeps_kraken2s_record_semantics(tmp_path, monkeypatch, out_codec):
+    """The FASTQ shapes the host parser is tested with (tests/test_reader.py), through the device record index: CRLF, "+id" lines,
+    descriptions and trailing blanks on header lines, empty sequences, no newline at the end, a truncated last record
+    (dropped), an empty line that ends the input, lower case and N; small batches, so that records are carried from one
+    piece and batch to the next; plain and GPU-gzip outputs (the latter take kept records straight from HBM)."""
+    rs = read_fastq(os.path.join(GOLD, "reads_se.fq"))
+    def rec(i, h=None, seq=None, plus=b"+", nl=b"\n", q=None):
+        h0, _id, s0, q0 = rs[i]
+        s1 = s0 if seq is None else seq
+        return (h if h is not None else h0) + nl + s1 + nl + plus + nl + (q if q is not None else q0[:len(s1)] + b"I" * max(0, len(s1) - len(q0))) + nl
+    parts = []
+    for i in range(len(rs)):
+        kind = i % 9
+        if kind == 0: parts.append(rec(i, nl=b"\r\n"))
+        elif kind == 1: parts.append(rec(i, plus=b"+" + rs[i][0][1:]))
+        elif kind == 2: parts.append(rec(i, h=rs[i][0] + b" some description\t x  "))
+        elif kind == 3: parts.append(rec(i, seq=b"", q=b""))
+        elif kind == 4: parts.append(rec(i, seq=rs[i][2].lower()))
+        else: parts.append(rec(i))
+    body = b"".join(parts)
+    cases = {
+        "plain": body,
+        "no_final_newline": body[:-1],
+        "truncated_last_record": body + b"@cut\nACGTACGT\n+\n",
+        "empty_line_ends_input": body + b"\n" + rec(0) + rec(1),
+        "only_three_lines": b"@x\nACGT\n+\n",
+        "empty_file": b"",
+    }
+    for name, data in cases.items():
+        for batch in (7, 64):
+            got = _run_both_readers(tmp_path, monkeypatch, "%s_%d_%d" % (name, batch, out_codec), data, out_codec=out_codec, batch=batch, _k=True)
+            if name == "empty_line_ends_input":
+                assert got[3][0] == len(rs)  # what follows the empty line was never read
+            if name == "truncated_last_record":
+                assert got[3][0] == len(rs)
+
+
+def test_record_index_on_the_gpu_pairs_and_classified_out(tmp_path, monkeypatch):
+    raw1 = open(os.path.join(GOLD, "reads_pe_1.fq"), "rb").read()
+    raw2 = open(os.path.join(GOLD, "reads_pe_2.fq"), "rb").read()
+    for keep_human in (False, True):
+        for codec in (0, 2):
+            _run_both_readers(tmp_path, monkeypatch, "pe_%d_%d" % (keep_human, codec), raw1 * 3, raw2 * 3, out_codec=codec, batch=50,
+                              keep_human=keep_human, _k=True)
+
+
+def test_fasta_and_garbage_fall_back_to_the_host_parser(tmp_path, monkeypatch):
+    from nohuman_amd import Engine, EngineError
+    rs = read_fastq(os.path.join(GOLD, "reads_se.fq"))
+    fa = b"".join(b">" + r[1] + b"\n" + b"".join(r[2][j:j + 60] + b"\n" for j in range(0, len(r[2]), 60)) for r in rs)
+    _run_both_readers(tmp_path, monkeypatch, "fasta", fa, _k=True)
+    bad = tmp_path / "bad.fq.gz"
+    bad.write_bytes(gzip.compress(b"this is not fastq\n" * 50))
+    for reader in ("device", "host"):
+        monkeypatch.setenv("NOHUMAN_GZ_READER", reader)
+        with Engine.open(DB) as eng:
+            with pytest.raises(EngineError) as ei:
+                eng.run(str(bad), str(tmp_path / "o.fq"))
+            assert "unrecognized file format" in str(ei.value)
+    mid = tmp_path / "mid.fq.gz"  # a record in the middle that does not start with '@'
+    raw = open(os.path.join(GOLD, "reads_se.fq"), "rb").read()
+    cut = raw.index(b"\n@", len(raw) // 2) + 1
+    mid.write_bytes(gzip.compress(raw[:cut] + b"Xbroken\nACGT\n+\nIIII\n" + raw[cut:]))
+    for reader in ("device", "host"):
+        monkeypatch.setenv("NOHUMAN_GZ_READER", reader)
+        with Engine.open(DB) as eng:
+            with pytest.raises(EngineError) as ei:
+                eng.run(str(mid), str(tmp_path / "o.fq"))
+            assert "malformed FASTQ file (exp. '@', saw \"Xbroken\")" in str(ei.value), str(ei.value)
+
+
 def test_damaged_gzip_input_fails_the_run_with_either_reader(tmp_path, monkeypatch):
     from nohuman_amd import Engine, EngineError
     raw = open(os.path.join(GOLD, "reads_se.fq"), "rb").read() * 20
