@@ -2338,6 +2338,73 @@ using namespace gz;
         if (e_ != hipSuccess) return fail(std::string(#x) + ": " + hipGetErrorString(e_)); \
     } while (0)
 
+// The reader's large buffers (symbol slots, maps, text: a dozen gigabytes of HBM, a quarter of one page-locked) are kept
+// for the next run of the process instead of being freed: allocating and freeing them cost 0.5-0.9 s of a 2 s run
+// (profiles/r04_e2e.txt).  NOHUMAN_GZDEV_CACHE=0 turns that off; dev_cache_trim() empties it.
+namespace {
+struct CacheEntry {
+    int device;
+    size_t bytes;
+    void *p;
+    bool host;
+};
+std::mutex g_cache_mu;
+std::vector<CacheEntry> g_cache;
+bool cache_on() {
+    static const bool on = !(getenv("NOHUMAN_GZDEV_CACHE") && getenv("NOHUMAN_GZDEV_CACHE")[0] == '0');
+    return on;
+}
+}  // namespace
+void dev_cache_trim() {
+    std::lock_guard<std::mutex> lk(g_cache_mu);
+    for (CacheEntry &e : g_cache) {
+        if (e.host) (void)hipHostFree(e.p);
+        else {
+            (void)hipSetDevice(e.device);
+            (void)hipFree(e.p);
+        }
+    }
+    g_cache.clear();
+}
+static void *cache_alloc(int device, size_t bytes, bool host) {
+    if (cache_on() && bytes >= ((size_t)16u << 20)) {
+        std::lock_guard<std::mutex> lk(g_cache_mu);
+        for (size_t i = 0; i < g_cache.size(); i++) {
+            CacheEntry &e = g_cache[i];
+            if (e.host == host && (host || e.device == device) && e.bytes >= bytes && e.bytes <= bytes + bytes / 2) {
+                void *p = e.p;
+                g_cache.erase(g_cache.begin() + (long)i);
+                return p;
+            }
+        }
+    }
+    void *p = nullptr;
+    hipError_t e = host ? hipHostMalloc(&p, bytes, hipHostMallocDefault) : hipMalloc(&p, bytes);
+    if (e != hipSuccess) {  // make room: what the cache holds goes first
+        (void)hipGetLastError();
+        dev_cache_trim();
+        (void)hipSetDevice(device);
+        e = host ? hipHostMalloc(&p, bytes, hipHostMallocDefault) : hipMalloc(&p, bytes);
+        if (e != hipSuccess) {
+            (void)hipGetLastError();
+            return nullptr;
+        }
+    }
+    return p;
+}
+static void cache_free(int device, size_t bytes, void *p, bool host) {
+    if (!p) return;
+    if (cache_on() && bytes >= ((size_t)16u << 20)) {
+        std::lock_guard<std::mutex> lk(g_cache_mu);
+        if (g_cache.size() < 32) {
+            g_cache.push_back({device, bytes, p, host});
+            return;
+        }
+    }
+    if (host) (void)hipHostFree(p);
+    else (void)hipFree(p);
+}
+
 class DevGunzipImpl {
 public:
     ~DevGunzipImpl() { close(); }
@@ -2405,19 +2472,24 @@ public:
         for (;;) {
             n_slots_ = (uint32_t)(seg_ / stretch_);
             const size_t in_bytes = seg_ + look_ + ALIGN + 4096;
-            ok = hipMalloc((void **)&d_in_, in_bytes) == hipSuccess && hipHostMalloc((void **)&h_in_, in_bytes, hipHostMallocDefault) == hipSuccess &&
+            in_bytes_ = in_bytes;
+            sym_bytes_ = ((size_t)n_slots_ * slot_syms_ + 1024) * 2;
+            maps_bytes_ = (size_t)n_slots_ * WSIZE * 2;
+            d_in_ = (uint8_t *)cache_alloc(device_, in_bytes_, false);
+            h_in_ = (uint8_t *)cache_alloc(device_, in_bytes_, true);
+            d_sym_ = (uint16_t *)cache_alloc(device_, sym_bytes_, false);
+            d_maps_[0] = (uint16_t *)cache_alloc(device_, maps_bytes_, false);
+            d_maps_[1] = (uint16_t *)cache_alloc(device_, maps_bytes_, false);
+            d_windows_ = (uint8_t *)cache_alloc(device_, maps_bytes_ / 2, false);
+            ok = d_in_ && h_in_ && d_sym_ && d_maps_[0] && d_maps_[1] && d_windows_ &&
                  hipMalloc((void **)&d_start_, (size_t)n_slots_ * 8) == hipSuccess &&
                  hipMalloc((void **)&d_desc_, (size_t)n_slots_ * sizeof(ChunkDesc)) == hipSuccess &&
                  hipHostMalloc((void **)&h_desc_, (size_t)n_slots_ * sizeof(ChunkDesc), hipHostMallocDefault) == hipSuccess &&
                  hipMalloc((void **)&d_toff_, (size_t)n_slots_ * 8) == hipSuccess &&
-                 hipMalloc((void **)&d_sym_, ((size_t)n_slots_ * slot_syms_ + 1024) * 2) == hipSuccess &&
-                 hipMalloc((void **)&d_maps_[0], (size_t)n_slots_ * WSIZE * 2) == hipSuccess &&
-                 hipMalloc((void **)&d_maps_[1], (size_t)n_slots_ * WSIZE * 2) == hipSuccess &&
-                 hipMalloc((void **)&d_windows_, (size_t)n_slots_ * WSIZE) == hipSuccess &&
                  hipMalloc((void **)&d_win_[0], WSIZE) == hipSuccess && hipMalloc((void **)&d_win_[1], WSIZE) == hipSuccess &&
                  hipMalloc((void **)&d_res_, sizeof(SegResult)) == hipSuccess &&
                  hipHostMalloc((void **)&h_res_, sizeof(SegResult), hipHostMallocDefault) == hipSuccess;
-            if (ok) ok = hipMemset(d_win_[0], 0, WSIZE) == hipSuccess && hipMemset(d_in_, 0, in_bytes) == hipSuccess;
+            if (ok) ok = hipMemset(d_win_[0], 0, WSIZE) == hipSuccess;  // (the input buffer's tail is zeroed with every piece's upload)
             if (ok || seg_ <= ((size_t)16u << 20)) break;
             (void)hipGetLastError();
             free_buffers();
@@ -2445,10 +2517,15 @@ public:
     }
 
     void free_buffers() {
-        for (void *p : {(void *)d_in_, (void *)d_start_, (void *)d_desc_, (void *)d_toff_, (void *)d_sym_, (void *)d_maps_[0], (void *)d_maps_[1],
-                        (void *)d_windows_, (void *)d_win_[0], (void *)d_win_[1], (void *)d_res_})
+        cache_free(device_, in_bytes_, d_in_, false);
+        cache_free(device_, in_bytes_, h_in_, true);
+        cache_free(device_, sym_bytes_, d_sym_, false);
+        cache_free(device_, maps_bytes_, d_maps_[0], false);
+        cache_free(device_, maps_bytes_, d_maps_[1], false);
+        cache_free(device_, maps_bytes_ / 2, d_windows_, false);
+        for (void *p : {(void *)d_start_, (void *)d_desc_, (void *)d_toff_, (void *)d_win_[0], (void *)d_win_[1], (void *)d_res_})
             if (p) (void)hipFree(p);
-        for (void *p : {(void *)h_in_, (void *)h_desc_, (void *)h_res_})
+        for (void *p : {(void *)h_desc_, (void *)h_res_})
             if (p) (void)hipHostFree(p);
         d_in_ = nullptr, d_start_ = nullptr, d_desc_ = nullptr, d_toff_ = nullptr, d_sym_ = nullptr, d_maps_[0] = d_maps_[1] = nullptr;
         d_windows_ = nullptr, d_win_[0] = d_win_[1] = nullptr, d_res_ = nullptr, h_in_ = nullptr, h_desc_ = nullptr, h_res_ = nullptr;
@@ -2779,6 +2856,7 @@ private:
     uint32_t failed_in_a_row_ = 0, last_bad_ = 0;
     long fake_start_ = -1;
     double open_s_ = 0;
+    size_t in_bytes_ = 0, sym_bytes_ = 0, maps_bytes_ = 0;
     uint64_t prof_[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 };
 
@@ -2861,6 +2939,7 @@ extern "C" int nh_gunzip_device_file(const char *in, const char *out, int32_t de
 #include <atomic>
 #include <condition_variable>
 #include <mutex>
+#include <thread>
 
 #include "nh_fastx.h"
 
@@ -3007,11 +3086,11 @@ public:
             return -1;
         }
         for (;;) {
-            const bool ok = hipMalloc((void **)&buf_[0].d_text, room_ + 4096) == hipSuccess && hipMalloc((void **)&buf_[1].d_text, room_ + 4096) == hipSuccess;
-            if (ok) break;
-            (void)hipGetLastError();
+            buf_[0].d_text = (uint8_t *)cache_alloc(device_, room_ + 4096, false);
+            buf_[1].d_text = (uint8_t *)cache_alloc(device_, room_ + 4096, false);
+            if (buf_[0].d_text && buf_[1].d_text) break;
             for (Piece &b : buf_) {
-                if (b.d_text) (void)hipFree(b.d_text);
+                cache_free(device_, room_ + 4096, b.d_text, false);
                 b.d_text = nullptr;
             }
             if (room_ <= ((size_t)128u << 20)) {
@@ -3031,39 +3110,49 @@ public:
     int next_batch(HalfBatch &hb, size_t max_recs) {
         hb.reset();
         hb.format = FMT_FASTQ;
-        if (!error_.empty()) {
-            hb.error = error_;
-            return 0;
+        if (bf_ == 0) {
+            bf_ = max_recs ? max_recs : 1;
+            th_ = std::thread([this] { produce(); });  // pieces are decoded and indexed ahead of the batches handed out
         }
-        if (bf_ == 0) bf_ = max_recs ? max_recs : 1;
         if (max_recs != bf_) {
-            hb.error = error_ = "DevFastqReader: the batch size changed";
-            return 0;
-        }
-        if (hipSetDevice(device_) != hipSuccess) {
-            hb.error = error_ = "hipSetDevice failed";
+            hb.error = "DevFastqReader: the batch size changed";
             return 0;
         }
         for (;;) {
-            Piece &p = buf_[cur_];
-            if (p.loaded) {
-                const size_t left = p.n_rec - p.next_rec;
-                if (left >= bf_ || (p.last && left > 0)) return emit(hb, p);
-                if (p.last) {  // nothing left at all
+            Piece &p = buf_[take_];
+            {
+                std::unique_lock<std::mutex> lk(mu_);
+                cv_.wait(lk, [&] { return p.loaded || done_; });
+                if (!p.loaded) {  // the producer has ended: the end of the input, an error, or "not ours"
+                    if (fallback_) return 1;
+                    if (!error_.empty()) hb.error = error_;
                     hb.eof = true;
                     return 0;
                 }
             }
-            const int rc = load_next();
-            if (rc == 1) return 1;
-            if (rc < 0) {
-                hb.error = error_;
+            // whole batches, and at the end of the input what is left
+            const size_t full = p.last ? p.n_rec : p.n_rec / bf_ * bf_;
+            if (p.next_rec < full) return emit(hb, p, full);
+            {   // this piece has handed out what it had: on to the other buffer
+                std::lock_guard<std::mutex> lk(mu_);
+                p.loaded = false;
+            }
+            cv_.notify_all();
+            take_ ^= 1;
+            if (p.last) {
+                hb.eof = true;
                 return 0;
             }
         }
     }
 
     void close() {
+        {
+            std::lock_guard<std::mutex> lk(mu_);
+            stop_ = true;
+        }
+        cv_.notify_all();
+        if (th_.joinable()) th_.join();
         // every batch handed out points into the text buffers: wait until the pipeline has let go of them
         {
             std::unique_lock<std::mutex> lk(mu_);
@@ -3076,7 +3165,8 @@ public:
         gz_.close();
         if (device_ >= 0) (void)hipSetDevice(device_);
         for (Piece &b : buf_) {
-            for (void *q : {(void *)b.d_text, (void *)b.d_nl, (void *)b.d_tiles, (void *)b.d_recs, (void *)b.d_bstart})
+            cache_free(device_, room_ + 4096, b.d_text, false);
+            for (void *q : {(void *)b.d_nl, (void *)b.d_tiles, (void *)b.d_recs, (void *)b.d_bstart})
                 if (q) (void)hipFree(q);
             for (void *q : {(void *)b.h_recs, (void *)b.h_bstart})
                 if (q) (void)hipHostFree(q);
@@ -3097,7 +3187,7 @@ private:
         size_t nl_cap = 0, tile_cap = 0, rec_cap = 0, bs_cap = 0;
         size_t text_len = 0, used_len = 0;  // bytes of text; bytes up to the end of the last complete record
         size_t n_rec = 0, next_rec = 0;
-        bool loaded = false, last = false;
+        bool loaded = false, last = false, indexed = false;  // loaded: handed to the consumer; indexed: its record table is valid
         int outstanding = 0;  // batches handed out and not yet released
     };
 
@@ -3114,14 +3204,17 @@ private:
         return hipMalloc((void **)&p, cap * sizeof(T)) == hipSuccess;
     }
 
-    int emit(HalfBatch &hb, Piece &p) {
-        const size_t r0 = p.next_rec, r1 = std::min(p.n_rec, r0 + bf_);
+    int emit(HalfBatch &hb, Piece &p, size_t full) {
+        const size_t r0 = p.next_rec, r1 = std::min(full, r0 + bf_);
         const size_t b = r0 / bf_;
         const size_t t0 = p.h_bstart[b], t1 = p.h_bstart[b + 1];
         hb.recs.assign(p.h_recs + r0, p.h_recs + r1);
         const size_t len = t1 - t0;
-        if (!hb.text.reserve(len + 64)) {
-            hb.error = error_ = "out of memory";
+        // the host text buffer stays a token (its address is the batch's handle in the writer's span lists); whoever needs the
+        // bytes on the host reserves the real thing (nh_run: stage_text, the writer's fetch)
+        hb.text.clear();
+        if (!hb.text.reserve(64)) {
+            hb.error = "out of memory";
             return 0;
         }
         hb.text.set_size(len);
@@ -3129,7 +3222,7 @@ private:
         hb.dev_device = device_;
         hb.host_text_valid = false;
         p.next_rec = r1;
-        hb.eof = p.last && r1 == p.n_rec;
+        hb.eof = p.last && r1 == full;
         {
             std::lock_guard<std::mutex> lk(mu_);
             p.outstanding++;
@@ -3145,19 +3238,35 @@ private:
         return 0;
     }
 
-    // the next piece of the stream into the other buffer, behind what the current one could not hand out
+    // pieces into the two buffers in turn, each behind what the one before could not hand out as whole batches
+    void produce() {
+        (void)hipSetDevice(device_);
+        for (;;) {
+            const int rc = load_next();
+            std::lock_guard<std::mutex> lk(mu_);
+            if (rc != 0 || buf_[fill_ ^ 1].last || stop_) {  // (fill_ was flipped by load_next: the piece just loaded is the other one)
+                if (rc == 1) fallback_ = true;
+                done_ = true;
+                cv_.notify_all();
+                return;
+            }
+        }
+    }
+
     int load_next() {
         using namespace fq;
-        Piece &old = buf_[cur_];
-        Piece &p = buf_[cur_ ^ 1];
+        Piece &old = buf_[fill_ ^ 1];  // the piece loaded before this one (its record table stays valid while its batches go out)
+        Piece &p = buf_[fill_];
         {
             std::unique_lock<std::mutex> lk(mu_);
-            cv_.wait(lk, [&] { return p.outstanding == 0; });
+            cv_.wait(lk, [&] { return (!p.loaded && p.outstanding == 0) || stop_; });
+            if (stop_) return -2;
         }
         size_t carry = 0;
-        if (old.loaded) {
-            // records not handed out (fewer than a batch) and the incomplete record behind them
-            const size_t from = old.next_rec < old.n_rec ? old.h_bstart[old.next_rec / bf_] : old.used_len;
+        if (old.indexed) {
+            // the records behind the last whole batch and the incomplete record behind them
+            const size_t full = old.n_rec / bf_ * bf_;
+            const size_t from = full < old.n_rec ? old.h_bstart[full / bf_] : old.used_len;
             carry = old.text_len - from;
             if (carry >= room_) return fail("a FASTQ record larger than the gzip reader's text buffer");
             if (carry && hipMemcpyAsync(p.d_text, old.d_text + from, carry, hipMemcpyDeviceToDevice, stream_) != hipSuccess) return fail("D2D of the carried text failed");
@@ -3167,13 +3276,24 @@ private:
         if (n < 0) return fail(gz_.error());
         p.text_len = carry + (size_t)n;
         p.last = gz_.ended();
-        p.loaded = true;
         p.n_rec = p.next_rec = 0;
         p.used_len = 0;
-        old.loaded = false;
-        cur_ ^= 1;
         pieces_++;
-        if (p.text_len == 0) return 0;
+        const int irc = p.text_len ? index(p) : 0;
+        if (irc != 0) return irc;
+        p.indexed = true;
+        {
+            std::lock_guard<std::mutex> lk(mu_);
+            p.loaded = true;
+        }
+        cv_.notify_all();
+        fill_ ^= 1;
+        return 0;
+    }
+
+    // newlines -> lines -> records of the piece's text
+    int index(Piece &p) {
+        using namespace fq;
         const auto t0 = std::chrono::steady_clock::now();
         if (p.last) {  // the input's last line may lack its newline
             uint8_t lastc = 0;
@@ -3263,8 +3383,10 @@ private:
     int device_ = -1;
     hipStream_t stream_ = nullptr;
     Piece buf_[2];
-    int cur_ = 0;
+    int fill_ = 0, take_ = 0;
     size_t room_ = 0, bf_ = 0;
+    std::thread th_;
+    bool stop_ = false, done_ = false, fallback_ = false;
     unsigned long long *d_bad_ = nullptr, *h_bad_ = nullptr;
     bool handed_out_ = false, trace_ = false;
     uint64_t pieces_ = 0, records_ = 0, carried_ = 0;

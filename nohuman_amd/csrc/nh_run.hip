@@ -295,7 +295,8 @@ private:
 struct Batch {
     std::unique_ptr<HalfBatch> h1, h2;
     size_t n = 0;
-    int slot = -1;  // device * 2 + stream slot that carries its results
+    int slot = -1;  // stream slot that carries its results
+    int dev_index = 0;  // index of the slot's device among the run's engines
 };
 
 struct Slot {  // pinned host + device buffers of one in-flight batch
@@ -630,7 +631,7 @@ static void format_batch(RunState *rs, const Batch &b, const Slot &s, OutFile &o
     rs->total += b.n;
     rs->classified += classified;
     rs->total_bases += bases;
-    uint64_t *dc = &rs->dev_counts[4 * (size_t)(b.slot / 2)];
+    uint64_t *dc = &rs->dev_counts[4 * (size_t)b.dev_index];
     dc[0] += b.n;
     dc[1] += classified;
     dc[2] += bases;
@@ -728,10 +729,14 @@ int run_engines(const std::vector<Engine *> &engines, const nh_run_args *a, nh_s
             return set_error(NH_EDEVICE, "cannot allocate the run's counters on device %d", engines[g]->device);
         }
     }
-    std::vector<Slot> slots(2 * G);
-    for (int i = 0; i < 2 * G; i++) {
-        slots[i].e = engines[i / 2];
-        slots[i].work_slot = i & 1;
+    // stream slots a device: two keep the classifier busy; a third lets the copy of a batch's text back to the host (batches
+    // born on the GPU, outputs written by the host) run while the writer is still busy with the batch before
+    int NS = 3;
+    if (const char *env = getenv("NOHUMAN_SLOTS")) NS = std::max(1, std::min(8, atoi(env)));
+    std::vector<Slot> slots((size_t)NS * G);
+    for (int i = 0; i < NS * G; i++) {
+        slots[i].e = engines[i / NS];
+        slots[i].work_slot = i % NS;
         if (hipSetDevice(slots[i].e->device) != hipSuccess ||
             hipStreamCreateWithFlags(&slots[i].stream, hipStreamNonBlocking) != hipSuccess) {
             for (auto &s : slots) slot_free(s);
@@ -759,8 +764,15 @@ int run_engines(const std::vector<Engine *> &engines, const nh_run_args *a, nh_s
             fprintf(stderr, "[nohuman trace] batch: %zu fragments, text buffers of %zu bytes reserved at once, %d prefilled per file\n",
                     BATCH_FRAGS, pool1.first_reserve, prefill);
     }
-    pool1.start_prefill(prefill);
-    if (rs.paired) pool2.start_prefill(prefill);
+    int prefill1 = prefill, prefill2 = prefill;
+    {   // batches of the reader on the GPU carry no host text unless an output needs it: no page-locked buffers made ahead for them
+        const char *how = getenv("NOHUMAN_GZ_READER");
+        const bool dev_reader = !(how && (!strcmp(how, "host") || !strcmp(how, "device-text")));
+        if (dev_reader && !host_text_wanted && dev_gunzip_wants(a->in1)) pool1.first_reserve = 0, prefill1 = 0;
+        if (dev_reader && !host_text_wanted && rs.paired && dev_gunzip_wants(a->in2)) pool2.first_reserve = 0, prefill2 = 0;
+    }
+    if (prefill1) pool1.start_prefill(prefill1);
+    if (rs.paired && prefill2) pool2.start_prefill(prefill2);
     StageClock clk;
     // gzip inputs are inflated by `threads` workers in all, shared between the files
     unsigned gz_threads = (a->threads ? a->threads : 1) / (unsigned)mates;
@@ -775,7 +787,7 @@ int run_engines(const std::vector<Engine *> &engines, const nh_run_args *a, nh_s
 
     // writer: consumes batches in order; each arrives after its stream was synchronised.  The second
     // mate file is written by a helper so that both files are written at the same time.
-    BoundedQueue<Batch> wq((size_t)(2 * G));
+    BoundedQueue<Batch> wq((size_t)(NS * G));
     std::mutex slot_mu;
     std::condition_variable slot_cv;
     std::mutex w2_mu;
@@ -827,9 +839,13 @@ int run_engines(const std::vector<Engine *> &engines, const nh_run_args *a, nh_s
                     for (int m = 0; m < (rs.paired ? 2 : 1) && !wrc; m++) {
                         HalfBatch &hb = m ? *b.h2 : *b.h1;
                         if (need_fetch(hb)) {
-                            if (hipMemcpy(hb.text.data(), (const char *)s.d_text + (m ? base2w : 0), hb.text.size(), hipMemcpyDeviceToHost) != hipSuccess)
+                            const size_t L = hb.text.size();
+                            hb.text.clear();
+                            if (!hb.text.reserve(L + 64)) wrc = set_error(NH_EOOM, "out of memory");
+                            hb.text.set_size(L);
+                            if (!wrc && hipMemcpy(hb.text.data(), (const char *)s.d_text + (m ? base2w : 0), hb.text.size(), hipMemcpyDeviceToHost) != hipSuccess)
                                 wrc = set_error(NH_EDEVICE, "fetching a batch's text from the device failed");
-                            hb.host_text_valid = true;
+                            hb.host_text_valid = wrc == NH_OK;
                         }
                     }
                     // the batch's raw text is still in the slot's device buffer: an encoder on that GPU takes
@@ -896,7 +912,7 @@ int run_engines(const std::vector<Engine *> &engines, const nh_run_args *a, nh_s
             break;
         }
         if (b.n > 0) {
-            const int si = (int)(batch_no % (uint64_t)(2 * G));
+            const int si = (int)(batch_no % (uint64_t)(NS * G));
             Slot &s = slots[si];
             uint64_t m1 = StageClock::now();
             clk.ns[ST_MPOP] += m1 - m0;
@@ -908,6 +924,7 @@ int run_engines(const std::vector<Engine *> &engines, const nh_run_args *a, nh_s
             uint64_t m2 = StageClock::now();
             clk.ns[ST_MSLOT] += m2 - m1;
             b.slot = si;
+            b.dev_index = si / NS;
             // (start, length) of every sequence inside the raw text: text of file 1 at byte 0 of the device
             // buffer, text of file 2 behind it
             const size_t len1 = b.h1->text.size(), len2 = rs.paired ? b.h2->text.size() : 0;
@@ -969,6 +986,9 @@ int run_engines(const std::vector<Engine *> &engines, const nh_run_args *a, nh_s
                                     ? hipMemcpyAsync((char *)s.d_text + at, hb.dev_text, len, hipMemcpyDeviceToDevice, s.stream)
                                     : hipMemcpyPeerAsync((char *)s.d_text + at, s.e->device, hb.dev_text, hb.dev_device, len, s.stream);
                 if (e2 == hipSuccess && host_text_wanted) {
+                    hb.text.clear();  // (a batch born on the GPU comes with a token buffer: the real one only where it is needed)
+                    if (!hb.text.reserve(len + 64)) return hipErrorOutOfMemory;
+                    hb.text.set_size(len);
                     e2 = hipMemcpyAsync(hb.text.data(), (char *)s.d_text + at, len, hipMemcpyDeviceToHost, s.stream);
                     hb.host_text_valid = true;  // (once the stream has been synchronised: the writer does that first)
                 }
@@ -988,7 +1008,7 @@ int run_engines(const std::vector<Engine *> &engines, const nh_run_args *a, nh_s
                 rc = classify_device(s.e, s.d_text, s.d_off, b.n,
                                      flags | (nbases / b.n > 2000 ? NH_FLAG_LONG : 0u), a->confidence, s.d_res,
                                      rs.want_k ? s.d_taxa : nullptr, rs.want_k ? s.d_taxa_off : nullptr,
-                                     rs.d_run_counters[(size_t)(si / 2)], s.stream, s.d_len, ntext);
+                                     rs.d_run_counters[(size_t)(si / NS)], s.stream, s.d_len, ntext);
                 if (rc) rs.fail(rc, g_last_error);
             }
             if (!rs.failed()) {
