@@ -799,6 +799,8 @@ int nh_open_synthetic(uint64_t capacity, uint64_t n_keys, uint32_t depth, uint64
 }
 int nh_close(nh_engine *e) {
     nh::destroy((Engine *)e);
+    nh::run_cache_trim();  // (what the runs kept for one another goes with the engine)
+    nh::dev_cache_trim();
     return NH_OK;
 }
 

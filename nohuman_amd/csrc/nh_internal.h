@@ -90,6 +90,10 @@ int classify_host(Engine *e, const uint8_t *bases, const uint64_t *seq_offsets, 
                   uint32_t flags, double confidence, nh_result *results, uint32_t *kmer_taxa,
                   uint64_t *kmer_taxa_offsets, uint64_t kmer_taxa_cap);
 int check_error_flag(Engine *e);
+// buffers kept between the runs of a process (nh_run.hip: page-locked batch text; nh_gunzip.hip: the gzip reader's HBM and
+// staging): emptied when an engine is closed
+void run_cache_trim();
+void dev_cache_trim();
 // the path's only collective: rows[g] = counters of device ids[g] -> every row = the sum (RCCL, nh_collective.hip)
 // (d_src[g] != NULL: the four counters lie in device ids[g]'s memory and are reduced from there)
 int allreduce_counters(const int *ids, int n_dev, uint64_t *rows, std::string &backend,

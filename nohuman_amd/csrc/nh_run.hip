@@ -310,6 +310,7 @@ struct Slot {  // pinned host + device buffers of one in-flight batch
     nh_result *h_res = nullptr;
     uint32_t *h_taxa = nullptr;
     uint64_t *h_taxa_off = nullptr;
+    int *h_flag = nullptr;  // the engine's sticky error bits as of the end of this slot's batch (copied on its stream)
     void *d_text = nullptr, *d_off = nullptr, *d_len = nullptr, *d_res = nullptr, *d_taxa = nullptr, *d_taxa_off = nullptr;
     size_t cap_text = 0, cap_frag = 0, cap_taxa = 0;
     uint64_t n_taxa = 0;
@@ -319,6 +320,10 @@ struct Slot {  // pinned host + device buffers of one in-flight batch
 static int slot_reserve(Slot &s, size_t ntext, size_t nfrag, size_t ntaxa) {
     if (hipSetDevice(s.e->device) != hipSuccess) return set_error(NH_EDEVICE, "hipSetDevice failed");
     auto grow = [](size_t need) { return need + need / 4 + 4096; };
+    if (!s.h_flag) {
+        if (hipHostMalloc((void **)&s.h_flag, 64, hipHostMallocDefault) != hipSuccess) return set_error(NH_EOOM, "cannot allocate batch buffers");
+        *s.h_flag = 0;
+    }
     if (ntext + 64 > s.cap_text) {
         if (s.d_text) (void)hipFree(s.d_text);
         s.cap_text = grow(ntext + 64);
@@ -355,7 +360,7 @@ static int slot_reserve(Slot &s, size_t ntext, size_t nfrag, size_t ntaxa) {
 static void slot_free(Slot &s) {
     if (!s.e) return;
     (void)hipSetDevice(s.e->device);
-    for (void *p : {(void *)s.h_off, (void *)s.h_len, (void *)s.h_res, (void *)s.h_taxa, (void *)s.h_taxa_off})
+    for (void *p : {(void *)s.h_off, (void *)s.h_len, (void *)s.h_res, (void *)s.h_taxa, (void *)s.h_taxa_off, (void *)s.h_flag})
         if (p) (void)hipHostFree(p);
     for (void *p : {s.d_text, s.d_off, s.d_len, s.d_res, s.d_taxa, s.d_taxa_off})
         if (p) (void)hipFree(p);
@@ -367,23 +372,61 @@ static void slot_free(Slot &s) {
 // A host that cannot page-lock that much (memlock / cgroup limits) gets pageable memory instead -- the
 // asynchronous copy accepts it and merely stages it itself; a 64-byte header says which kind a block is.
 static std::atomic<int> g_pageable_batches{0};
+// Page-locking a batch buffer costs ~40 ms and releasing it as much again: a run of a few seconds spent 0.4-0.7 s of its wall
+// time on its dozen buffers.  Released buffers are kept for the process's next run (at most PINNED_KEEP of them; nh_close
+// of an engine empties the store, NOHUMAN_PINNED_CACHE=0 turns it off).
+static constexpr size_t PINNED_KEEP = 16;
+static std::mutex g_pinned_mu;
+static std::vector<void *> g_pinned_store;  // block starts (header: [0] kind, [1] usable bytes)
+static bool pinned_cache_on() {
+    static const bool on = !(getenv("NOHUMAN_PINNED_CACHE") && getenv("NOHUMAN_PINNED_CACHE")[0] == '0');
+    return on;
+}
 static void *pinned_alloc(size_t n) {
     void *p = nullptr;
     static const bool no_pin = getenv("NOHUMAN_NO_PINNED") != nullptr;  // test knob: exercise the fallback
+    if (!no_pin && pinned_cache_on() && n >= ((size_t)8u << 20)) {
+        std::lock_guard<std::mutex> lk(g_pinned_mu);
+        for (size_t i = 0; i < g_pinned_store.size(); i++) {
+            const uint64_t cap = ((uint64_t *)g_pinned_store[i])[1];
+            if (cap >= n && cap <= n + n / 2) {
+                p = g_pinned_store[i];
+                g_pinned_store.erase(g_pinned_store.begin() + (long)i);
+                return (char *)p + 64;
+            }
+        }
+    }
     if (!no_pin && hipHostMalloc(&p, n + 64, hipHostMallocPortable) == hipSuccess) {
-        *(uint64_t *)p = 1;
+        ((uint64_t *)p)[0] = 1;
+        ((uint64_t *)p)[1] = n;
         return (char *)p + 64;
     }
     (void)hipGetLastError();
     if (posix_memalign(&p, 64, n + 64) != 0) return nullptr;
-    *(uint64_t *)p = 2;
+    ((uint64_t *)p)[0] = 2;
+    ((uint64_t *)p)[1] = n;
     g_pageable_batches++;
     return (char *)p + 64;
 }
 static void pinned_free(void *q) {
     void *p = (char *)q - 64;
-    if (*(uint64_t *)p == 1) (void)hipHostFree(p);
-    else free(p);
+    if (*(uint64_t *)p == 1) {
+        if (pinned_cache_on() && ((uint64_t *)p)[1] >= ((size_t)8u << 20)) {
+            std::lock_guard<std::mutex> lk(g_pinned_mu);
+            if (g_pinned_store.size() < PINNED_KEEP) {
+                g_pinned_store.push_back(p);
+                return;
+            }
+        }
+        (void)hipHostFree(p);
+    } else {
+        free(p);
+    }
+}
+void run_cache_trim() {
+    std::lock_guard<std::mutex> lk(g_pinned_mu);
+    for (void *p : g_pinned_store) (void)hipHostFree(p);
+    g_pinned_store.clear();
 }
 
 // folds the counters of one run into the engine's running totals (nh_stats_get)
@@ -826,7 +869,9 @@ int run_engines(const std::vector<Engine *> &engines, const nh_run_args *a, nh_s
                 clk.ns[ST_WSYNC] += c2 - c1;
                 int wrc = NH_OK;
                 if (he != hipSuccess) wrc = set_error(NH_EDEVICE, "classify: %s", hipGetErrorString(he));
-                if (!wrc) wrc = check_error_flag(s.e);
+                // (the error bits came with the results on the slot's stream: a copy of their own here would queue behind
+                // whatever else the device is running -- the gzip reader's kernels -- once a batch)
+                if (!wrc && *s.h_flag) wrc = check_error_flag(s.e);
                 if (!wrc) {
                     const size_t base2w = (b.h1->text.size() + 8 + 255) & ~(size_t)255;
                     // a batch whose text is only in HBM, and a kept record that must be rewritten (CRLF, "+id" line): fetch it
@@ -1013,6 +1058,8 @@ int run_engines(const std::vector<Engine *> &engines, const nh_run_args *a, nh_s
             }
             if (!rs.failed()) {
                 he = hipMemcpyAsync(s.h_res, s.d_res, b.n * sizeof(nh_result), hipMemcpyDeviceToHost, s.stream);
+                if (he == hipSuccess)
+                    he = hipMemcpyAsync(s.h_flag, s.e->d_error + LAUNCH_SLOTS, sizeof(int), hipMemcpyDeviceToHost, s.stream);
                 if (he == hipSuccess && rs.want_k && toff)
                     he = hipMemcpyAsync(s.h_taxa, s.d_taxa, toff * 4, hipMemcpyDeviceToHost, s.stream);
                 if (he != hipSuccess) rs.fail(NH_EDEVICE, std::string("D2H: ") + hipGetErrorString(he));

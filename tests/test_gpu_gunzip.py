@@ -145,6 +145,16 @@ def test_a_false_block_start_is_decoded_again_from_the_true_end(tmp_path, monkey
     assert st["redecoded"] >= 1 and st["host_pieces"] == 0
 
 
+def test_a_false_start_whose_garbage_ends_the_stream_loses_no_text(tmp_path, monkeypatch):
+    """The planted false start also claims the end of the stream (NOHUMAN_GZDEV_FAKE_END): the chunks behind it are struck
+    for a moment, the seam check strikes the false start itself, and the chunks behind must come back WITH what they
+    decoded (a 7.4 GB bench input lost 115 MB of one piece this way: crc error; tools/gz_debug.py found it)."""
+    monkeypatch.setenv("NOHUMAN_GZDEV_FAKE_START", "5")
+    monkeypatch.setenv("NOHUMAN_GZDEV_FAKE_END", "1")
+    st = check(tmp_path, gzip.compress(FASTQ, 6), FASTQ, 1 << 20, 16384)
+    assert st["redecoded"] >= 1 and st["host_pieces"] == 0
+
+
 def test_damage_is_reported(tmp_path):
     good = gzip.compress(FASTQ[:3_000_000], 6)
     src, dst = tmp_path / "bad.gz", tmp_path / "bad.out"

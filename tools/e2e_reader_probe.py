@@ -9,7 +9,7 @@ eng = Engine.synthetic(cap, int(cap * 0.7), depth=30, seed=7)
 os.environ["NOHUMAN_TRACE"] = "1"
 d = os.path.dirname(f1)
 for rep in range(2):
-    for reader in ("device", "device-text", "host"):
+    for reader in ("device", "host"):
         for what, kw in (("nothing kept", dict(keep_human=True)), ("gzip out", dict(out_codec=2, codec_threads=8)), ("plain out", dict())):
             os.environ["NOHUMAN_GZ_READER"] = reader
             t = time.perf_counter()
