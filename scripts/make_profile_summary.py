@@ -26,7 +26,8 @@ def source_id():
 GIT_HEAD, KERNEL_HASH = source_id()
 wl = sys.argv[3] if len(sys.argv) > 3 else "pe"
 # the kernel the workload's fragments are classified in (the other one, launched with it, returns at once)
-KERNEL = 'k_classify<' if wl == "ont" else 'k_classify_short'
+GENERIC = wl in ("ont", "pe250")  # reads longer than one tile: every chunk is left to the generic kernel
+KERNEL = 'k_classify<' if GENERIC else 'k_classify_short'
 WARMUP = 3  # launches of the trace pass before bench.py's timed region
 
 
@@ -36,12 +37,12 @@ def mean_counter(pattern, kernel_sub, counter):
         for row in csv.DictReader(open(f)):
             if kernel_sub in row['Kernel_Name'] and row['Counter_Name'] == counter:
                 v = float(row['Counter_Value'])
-                if wl == "ont" and counter == 'SQ_WAVES' and v < 100:
+                if GENERIC and counter == 'SQ_WAVES' and v < 100:
                     continue
                 vals.append(v)
     # (the generic kernel is also launched as the BIG second pass and, for short reads, as the deferred pass:
     #  those dispatches do nothing; keep the ones that did the work = the larger half by value)
-    if wl == "ont" and vals:
+    if GENERIC and vals:
         big = max(vals)
         vals = [v for v in vals if v > 0.2 * big]
     return (sum(vals) / len(vals), len(vals)) if vals else (None, 0)
@@ -72,7 +73,7 @@ for f in glob.glob(os.path.join(src, 'trace/*kernel_trace.csv')):
     rows = [r for r in csv.DictReader(open(f)) if KERNEL in r['Kernel_Name']]
     rows.sort(key=lambda r: int(r['Start_Timestamp']))
     d = [(int(r['End_Timestamp']) - int(r['Start_Timestamp'])) for r in rows]
-    if wl == "ont" and d:
+    if GENERIC and d:
         d = [x for x in d if x > 0.2 * max(d)]
     durs = d[WARMUP:]
 steady = None
