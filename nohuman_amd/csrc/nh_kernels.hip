@@ -1335,6 +1335,20 @@ __device__ __forceinline__ void post_group(KArgsP ap, WL &S, const TaxList &TLI,
     }
 
 constexpr uint32_t PREF_LANES = 42;  // dwords a tile can need: (3 + 128 + 30 + 3) / 4 <= 41
+constexpr uint32_t SHORT_MAX = 158;  // TQ + K - 1 bases: at most one tile of 124 k-mers (k_classify_short)
+
+// 64 sequences spread evenly over the launch (lane i: sequence i * n / 64): is every one of them longer than a tile of the
+// short-read kernel?  Then that kernel has nothing to do but mark every chunk for the generic one -- 25 000 claims on one
+// counter, 0.35-0.41 ms of a 2.8 ms launch of 2 x 250 bp pairs (profiles/r04_pe250_summary.txt) -- so it returns at once,
+// and the generic kernel, which takes the same sample, classifies every chunk instead of the marked ones.  Only a
+// scheduling decision: the generic kernel classifies sequences of any length, whatever the sample missed.
+__device__ __forceinline__ bool sample_all_long(KArgsP ap, const int lane) {
+    KArgsP a = launder(ap);
+    const uint64_t ns = a->n_frag * (uint64_t)a->mates;
+    const uint64_t i = ns * (uint64_t)lane / 64u;
+    const uint32_t len = a->seq_len != nullptr ? a->seq_len[i] : (uint32_t)(a->seq_off[i + 1] - a->seq_off[i]);
+    return __ballot(len <= SHORT_MAX) == 0;
+}
 
 template <bool LINEAR, bool STD, bool CAP32, bool PROF, bool BIG>
 __global__ __launch_bounds__(WAVE * WAVES_PER_BLOCK, BIG ? 1 : (STD ? NH_MIN_WAVES : 3)) void k_classify(const KArgs args_by_kernarg_pointer) {
@@ -1342,8 +1356,12 @@ __global__ __launch_bounds__(WAVE * WAVES_PER_BLOCK, BIG ? 1 : (STD ? NH_MIN_WAV
     // BIG variant: only runs when some fragment overflowed the 64-entry list of the hot variant
     if (BIG && ap->pending[0] == 0) return;
     // after the short-read kernel: only the chunks it left behind (none: nothing to do)
-    const bool only_deferred = ap->only_deferred != 0;
-    if (only_deferred && ap->pending_long[0] == 0) return;
+    bool only_deferred = ap->only_deferred != 0;
+    if (only_deferred && ap->pending_long[0] == 0) {
+        // nothing marked: nothing to do -- unless the short-read kernel left EVERYTHING to this one (sample_all_long)
+        if (BIG || !sample_all_long(ap, (int)(threadIdx.x & 63))) return;
+        only_deferred = false;
+    }
     typedef WaveLdsT<STD, 1, QCAP_GENERIC> WL;
     __shared__ WL lds_all[WAVES_PER_BLOCK];
     __shared__ uint32_t big_lists[BIG ? WAVES_PER_BLOCK * 3 * BIG_LIST_CAP : 1];
@@ -1680,8 +1698,6 @@ __global__ __launch_bounds__(WAVE * WAVES_PER_BLOCK, BIG ? 1 : (STD ? NH_MIN_WAV
 //   * one call site of the probe / post code (the drain of the pipeline runs through it as well).
 // A chunk that holds a longer sequence is not touched: its bit is set in defer_bits and the generic
 // kernel, launched right behind, classifies exactly those chunks (none: it returns at once).
-constexpr uint32_t SHORT_MAX = 158;  // TQ + K - 1 bases: at most one tile of 124 k-mers
-
 // TLINE: the variant tools/timeline.py runs (per-wave timestamps, KArgs::timeline); compiled out of the others
 template <bool PROF, bool WIDE, bool TLINE>
 __global__ __launch_bounds__(WAVE * WAVES_PER_BLOCK, PROF ? 4 : NH_MIN_WAVES) void k_classify_short(const KArgs args_by_kernarg_pointer) {
@@ -1693,6 +1709,7 @@ __global__ __launch_bounds__(WAVE * WAVES_PER_BLOCK, PROF ? 4 : NH_MIN_WAVES) vo
     const int wib = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     WL &S = lds_all[wib];
     const TaxList TLI = {nullptr, nullptr, nullptr, 0};
+    if (sample_all_long(ap, lane)) return;  // reads longer than a tile throughout: all of it is the generic kernel's
     init_wave_lds<STD>(S, lane);
 
     constexpr uint32_t K = 35, L = 31;
@@ -1806,7 +1823,10 @@ __global__ __launch_bounds__(WAVE * WAVES_PER_BLOCK, PROF ? 4 : NH_MIN_WAVES) vo
                 if (__ballot(len_v > SHORT_MAX)) {  // a longer sequence: the whole chunk goes to the generic kernel
                     if (lane == 0) {
                         atomicOr(&launder(ap)->defer_bits[claim >> 5], 1u << (claim & 31));
-                        atomicMax(launder(ap)->pending_long, 1);
+                        // (one word for the whole launch: when every chunk is deferred -- 2 x 250 bp -- 25 000 atomics on it
+                        //  were half of this kernel's 0.41 ms; it only ever goes from 0 to 1)
+                        if (__hip_atomic_load(launder(ap)->pending_long, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0)
+                            atomicMax(launder(ap)->pending_long, 1);
                     }
                     nseq = 0;
                     t = 0;

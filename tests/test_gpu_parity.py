@@ -516,3 +516,38 @@ def test_default_geometry_length_mixtures_around_the_tile_boundary(toy, toy_orac
     _assert_same(got, exp, "seed %d paired %s conf %s chunk %s" % (seed, paired, conf, chunk))
     assert np.array_equal(taxa, etaxa)
     assert st.table_lookups == int(lookups.sum()) and st.total_bases == sum(lens)
+
+
+@pytest.mark.parametrize("paired", [False, True])
+@pytest.mark.parametrize("hidden_short", [False, True])
+def test_reads_longer_than_a_tile_throughout_skip_the_short_read_kernel(toy, toy_oracle, paired, hidden_short):
+    """2 x 250 bp: every one of the 64 sequences both kernels sample is longer than a tile (158 bases), so
+    k_classify_short returns at once and the generic kernel classifies every chunk (sample_all_long, nh_kernels.hip).
+    hidden_short: short reads (and reads without a k-mer) at places the sample does not look at -- the shortcut is a
+    scheduling decision, the results must not depend on what the sample saw."""
+    from nohuman_amd import Engine
+    ob, tb, hb, genomes, _ = toy
+    rng = np.random.default_rng(77 + 2 * paired + hidden_short)
+    n = 1300
+    ns = n * (2 if paired else 1)
+    lens = [int(rng.integers(200, 320)) for _ in range(ns)]
+    if hidden_short:
+        sampled = {ns * i // 64 for i in range(64)}
+        for j in rng.choice(ns, 200, replace=False):
+            if int(j) not in sampled:
+                lens[int(j)] = int(rng.choice([0, 20, 35, 100, 150, 158]))
+    g = sorted(genomes)
+    seqs = []
+    for ln in lens:
+        src = genomes[g[int(rng.integers(0, len(g)))]]
+        st = int(rng.integers(0, len(src) - ln))
+        seqs.append(synth.mutate(rng, src[st:st + ln], 0.01, 0.003, 0.0) if ln else b"")
+    reads = list(zip(seqs[0::2], seqs[1::2])) if paired else seqs
+    bases, offs = orc.pack_reads(reads, paired)
+    exp, lookups, etaxa, _ = toy_oracle.classify(bases, offs, paired, 0.05, want_taxa=True)
+    with Engine.from_images(ob, tb, hb) as eng:
+        got, taxa, _ = eng.classify(bases, offs, paired, 0.05, want_taxa=True)
+        st = eng.stats()
+    _assert_same(got, exp, "paired %s hidden_short %s" % (paired, hidden_short))
+    assert np.array_equal(taxa, etaxa)
+    assert st.table_lookups == int(lookups.sum()) and st.total_bases == sum(lens) and st.total_sequences == n
