@@ -51,6 +51,12 @@ public:
     // waits for it: the number of text bytes (0: the stream has ended), or -1 with error() set.  A piece that would
     // not fit `room` is cut down; `room` must hold at least 64 MiB.
     long next(void *d_dst, size_t room, hipStream_t stream);
+    // Pieces spread over several devices: add_device() gives the reader a buffer set on one more device (the index of the
+    // set, the first device being 0; -1 with err set); next_on(set, ...) decodes the next piece THERE (d_dst and stream on
+    // that device) -- the stream's state goes from piece to piece, the 32 KiB window by a device-to-device copy.
+    int add_device(int device, std::string &err);
+    long next_on(int set, void *d_dst, size_t room, hipStream_t stream);
+    uint64_t pieces_of(int set) const;
     bool ended() const;
     const std::string &error() const;
     const DevGunzipStats &stats() const;
@@ -73,8 +79,11 @@ public:
     ~DevFastqReader();
     DevFastqReader(const DevFastqReader &) = delete;
     DevFastqReader &operator=(const DevFastqReader &) = delete;
-    // 0 ok; -1 error (err); 1: not a file this reader takes (no regular gzip file, BGZF): use BlockReader
-    int open(const char *path, int device, std::string &err);
+    // 0 ok; -1 error (err); 1: not a file this reader takes (no regular gzip file, BGZF): use BlockReader.
+    // devices: the GPUs of the run, this file's first one first -- piece i of the stream is inflated and indexed on
+    // devices[i mod n], and its batches say so (HalfBatch::dev_device: nh_run classifies them where they were born).
+    int open(const char *path, const int *devices, int n_devices, std::string &err);
+    int open(const char *path, int device, std::string &err) { return open(path, &device, 1, err); }
     // The next batch of exactly max_recs records (fewer only at the end of the input: hb.eof), the same max_recs in every
     // call.  0 ok (hb.error set on malformed input); 1: the text is no four-line FASTQ (FASTA, wrapped sequences) and
     // nothing has been handed out yet: use BlockReader on the file instead.

@@ -19,6 +19,7 @@
 
 #include <algorithm>
 #include <chrono>
+#include <memory>
 
 #include "nh_inflate.h"
 #include "nh_internal.h"
@@ -2407,6 +2408,24 @@ static void cache_free(int device, size_t bytes, void *p, bool host) {
 }
 
 class DevGunzipImpl {
+    // The buffers of one device.  A reader that spreads its pieces over several devices (DevFastqReader with the devices
+    // of a run: piece i on device i mod G) has one set per device; the stream's state -- position, CRC, the window behind
+    // the last piece -- goes from piece to piece, the window by a 32 KiB copy from the set that decoded the piece before.
+    struct DevSet {
+        int device_ = -1;
+        uint8_t *d_in_ = nullptr, *h_in_ = nullptr;
+        uint64_t *d_start_ = nullptr, *d_toff_ = nullptr;
+        ChunkDesc *d_desc_ = nullptr, *h_desc_ = nullptr;
+        uint16_t *d_sym_ = nullptr, *d_maps_[2] = {nullptr, nullptr};
+        uint8_t *d_windows_ = nullptr, *d_win_[2] = {nullptr, nullptr};
+        int win_ = 0;
+        SegResult *d_res_ = nullptr, *h_res_ = nullptr;
+        hipEvent_t ev_[7] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+        uint64_t pieces = 0;
+    };
+    std::vector<std::unique_ptr<DevSet>> sets_;
+    DevSet *s_ = nullptr;  // the set the current piece is decoded with
+
 public:
     ~DevGunzipImpl() { close(); }
 
@@ -2414,7 +2433,9 @@ public:
         close();
         const auto t_open = std::chrono::steady_clock::now();
         path_ = path;
-        device_ = device;
+        sets_.emplace_back(new DevSet());
+        s_ = sets_[0].get();
+        s_->device_ = device;
         fd_ = ::open(path, O_RDONLY | O_CLOEXEC);
         if (fd_ < 0) {
             err = std::string("cannot open ") + path;
@@ -2464,7 +2485,7 @@ public:
         v1_ = getenv("NOHUMAN_GZDEV_V1") != nullptr;  // the first versions of the search and decode kernels (A / B on one box)
         v2_ = getenv("NOHUMAN_GZDEV_V2") != nullptr;  // the scalar-decode version of k_inflate
         if (const char *e = getenv("NOHUMAN_GZDEV_SCAN")) scan_rounds_ = !strcmp(e, "rounds");  // the log2(n) rounds of the first version
-        if (hipSetDevice(device_) != hipSuccess) {
+        if (hipSetDevice(s_->device_) != hipSuccess) {
             err = "hipSetDevice failed";
             close();
             return -1;
@@ -2472,40 +2493,15 @@ public:
         bool ok = false;
         for (;;) {
             n_slots_ = (uint32_t)(seg_ / stretch_);
-            const size_t in_bytes = seg_ + look_ + ALIGN + 4096;
-            in_bytes_ = in_bytes;
+            in_bytes_ = seg_ + look_ + ALIGN + 4096;
             sym_bytes_ = ((size_t)n_slots_ * slot_syms_ + 1024) * 2;
             maps_bytes_ = (size_t)n_slots_ * WSIZE * 2;
-            d_in_ = (uint8_t *)cache_alloc(device_, in_bytes_, false);
-            h_in_ = (uint8_t *)cache_alloc(device_, in_bytes_, true);
-            d_sym_ = (uint16_t *)cache_alloc(device_, sym_bytes_, false);
-            d_maps_[0] = (uint16_t *)cache_alloc(device_, maps_bytes_, false);
-            d_maps_[1] = (uint16_t *)cache_alloc(device_, maps_bytes_, false);
-            d_windows_ = (uint8_t *)cache_alloc(device_, maps_bytes_ / 2, false);
-            ok = d_in_ && h_in_ && d_sym_ && d_maps_[0] && d_maps_[1] && d_windows_ &&
-                 hipMalloc((void **)&d_start_, (size_t)n_slots_ * 8) == hipSuccess &&
-                 hipMalloc((void **)&d_desc_, (size_t)n_slots_ * sizeof(ChunkDesc)) == hipSuccess &&
-                 hipHostMalloc((void **)&h_desc_, (size_t)n_slots_ * sizeof(ChunkDesc), hipHostMallocDefault) == hipSuccess &&
-                 hipMalloc((void **)&d_toff_, (size_t)n_slots_ * 8) == hipSuccess &&
-                 hipMalloc((void **)&d_win_[0], WSIZE) == hipSuccess && hipMalloc((void **)&d_win_[1], WSIZE) == hipSuccess &&
-                 hipMalloc((void **)&d_res_, sizeof(SegResult)) == hipSuccess &&
-                 hipHostMalloc((void **)&h_res_, sizeof(SegResult), hipHostMallocDefault) == hipSuccess;
-            if (ok) ok = hipMemset(d_win_[0], 0, WSIZE) == hipSuccess;  // (the input buffer's tail is zeroed with every piece's upload)
+            ok = alloc_set(*s_);
             if (ok || seg_ <= ((size_t)16u << 20)) break;
             (void)hipGetLastError();
-            free_buffers();
+            free_set(*s_);
             seg_ = (seg_ / 2 + stretch_ - 1) / stretch_ * stretch_;
         }
-        if (ok)
-            ok = hipFuncSetAttribute((const void *)k_search, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(Lds)) == hipSuccess &&
-                 hipFuncSetAttribute((const void *)k_inflate, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(Lds)) == hipSuccess &&
-                 hipFuncSetAttribute((const void *)k_search2, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(Lds)) == hipSuccess &&
-                 hipFuncSetAttribute((const void *)k_inflate2, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(Lds)) == hipSuccess &&
-                 hipFuncSetAttribute((const void *)k_inflate3, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(Lds3)) == hipSuccess &&
-                 hipFuncSetAttribute((const void *)k_scan_local, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(2 * WSIZE)) == hipSuccess &&
-                 hipFuncSetAttribute((const void *)k_scan_groups, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(2 * WSIZE)) == hipSuccess;
-        for (auto &e : ev_)
-            if (ok) ok = hipEventCreate(&e) == hipSuccess;
         if (!ok) {
             (void)hipGetLastError();
             err = "the gzip reader's device buffers cannot be had";
@@ -2517,19 +2513,81 @@ public:
         return 0;
     }
 
-    void free_buffers() {
-        cache_free(device_, in_bytes_, d_in_, false);
-        cache_free(device_, in_bytes_, h_in_, true);
-        cache_free(device_, sym_bytes_, d_sym_, false);
-        cache_free(device_, maps_bytes_, d_maps_[0], false);
-        cache_free(device_, maps_bytes_, d_maps_[1], false);
-        cache_free(device_, maps_bytes_ / 2, d_windows_, false);
-        for (void *p : {(void *)d_start_, (void *)d_desc_, (void *)d_toff_, (void *)d_win_[0], (void *)d_win_[1], (void *)d_res_})
+    // the buffers of one device (sizes as open() settled them), its events, the kernels' LDS limits there
+    bool alloc_set(DevSet &d) {
+        if (hipSetDevice(d.device_) != hipSuccess) return false;
+        d.d_in_ = (uint8_t *)cache_alloc(d.device_, in_bytes_, false);
+        d.h_in_ = (uint8_t *)cache_alloc(d.device_, in_bytes_, true);
+        d.d_sym_ = (uint16_t *)cache_alloc(d.device_, sym_bytes_, false);
+        d.d_maps_[0] = (uint16_t *)cache_alloc(d.device_, maps_bytes_, false);
+        d.d_maps_[1] = (uint16_t *)cache_alloc(d.device_, maps_bytes_, false);
+        d.d_windows_ = (uint8_t *)cache_alloc(d.device_, maps_bytes_ / 2, false);
+        bool ok = d.d_in_ && d.h_in_ && d.d_sym_ && d.d_maps_[0] && d.d_maps_[1] && d.d_windows_ &&
+                  hipMalloc((void **)&d.d_start_, (size_t)n_slots_ * 8) == hipSuccess &&
+                  hipMalloc((void **)&d.d_desc_, (size_t)n_slots_ * sizeof(ChunkDesc)) == hipSuccess &&
+                  hipHostMalloc((void **)&d.h_desc_, (size_t)n_slots_ * sizeof(ChunkDesc), hipHostMallocDefault) == hipSuccess &&
+                  hipMalloc((void **)&d.d_toff_, (size_t)n_slots_ * 8) == hipSuccess &&
+                  hipMalloc((void **)&d.d_win_[0], WSIZE) == hipSuccess && hipMalloc((void **)&d.d_win_[1], WSIZE) == hipSuccess &&
+                  hipMalloc((void **)&d.d_res_, sizeof(SegResult)) == hipSuccess &&
+                  hipHostMalloc((void **)&d.h_res_, sizeof(SegResult), hipHostMallocDefault) == hipSuccess;
+        if (ok) ok = hipMemset(d.d_win_[0], 0, WSIZE) == hipSuccess;  // (the input buffer's tail is zeroed with every piece's upload)
+        if (ok)
+            ok = hipFuncSetAttribute((const void *)k_search, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(Lds)) == hipSuccess &&
+                 hipFuncSetAttribute((const void *)k_inflate, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(Lds)) == hipSuccess &&
+                 hipFuncSetAttribute((const void *)k_search2, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(Lds)) == hipSuccess &&
+                 hipFuncSetAttribute((const void *)k_inflate2, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(Lds)) == hipSuccess &&
+                 hipFuncSetAttribute((const void *)k_inflate3, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(Lds3)) == hipSuccess &&
+                 hipFuncSetAttribute((const void *)k_scan_local, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(2 * WSIZE)) == hipSuccess &&
+                 hipFuncSetAttribute((const void *)k_scan_groups, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(2 * WSIZE)) == hipSuccess;
+        for (auto &e : d.ev_)
+            if (ok && !e) ok = hipEventCreate(&e) == hipSuccess;
+        return ok;
+    }
+    void free_set(DevSet &d) {
+        if (d.device_ >= 0) (void)hipSetDevice(d.device_);
+        cache_free(d.device_, in_bytes_, d.d_in_, false);
+        cache_free(d.device_, in_bytes_, d.h_in_, true);
+        cache_free(d.device_, sym_bytes_, d.d_sym_, false);
+        cache_free(d.device_, maps_bytes_, d.d_maps_[0], false);
+        cache_free(d.device_, maps_bytes_, d.d_maps_[1], false);
+        cache_free(d.device_, maps_bytes_ / 2, d.d_windows_, false);
+        for (void *p : {(void *)d.d_start_, (void *)d.d_desc_, (void *)d.d_toff_, (void *)d.d_win_[0], (void *)d.d_win_[1], (void *)d.d_res_})
             if (p) (void)hipFree(p);
-        for (void *p : {(void *)h_desc_, (void *)h_res_})
+        for (void *p : {(void *)d.h_desc_, (void *)d.h_res_})
             if (p) (void)hipHostFree(p);
-        d_in_ = nullptr, d_start_ = nullptr, d_desc_ = nullptr, d_toff_ = nullptr, d_sym_ = nullptr, d_maps_[0] = d_maps_[1] = nullptr;
-        d_windows_ = nullptr, d_win_[0] = d_win_[1] = nullptr, d_res_ = nullptr, h_in_ = nullptr, h_desc_ = nullptr, h_res_ = nullptr;
+        for (auto &e : d.ev_)
+            if (e) {
+                (void)hipEventDestroy(e);
+                e = nullptr;
+            }
+        const int dev = d.device_;
+        d = DevSet();
+        d.device_ = dev;
+    }
+    // one more device (the same one again is allowed: a set of its own) for next_on(); its index, or -1
+    int add_device(int device, std::string &err) {
+        std::unique_ptr<DevSet> d(new DevSet());
+        d->device_ = device;
+        if (!alloc_set(*d)) {
+            (void)hipGetLastError();
+            free_set(*d);
+            err = "the gzip reader's device buffers cannot be had on device " + std::to_string(device);
+            return -1;
+        }
+        sets_.push_back(std::move(d));
+        return (int)sets_.size() - 1;
+    }
+    // The next piece is decoded with set k: the window behind the stream so far moves to it
+    bool select_set(int k, hipStream_t stream) {
+        DevSet *to = sets_[(size_t)k].get();
+        if (to == s_) return true;
+        if (hipSetDevice(to->device_) != hipSuccess) return false;
+        const hipError_t e = to->device_ == s_->device_
+                                 ? hipMemcpyAsync(to->d_win_[to->win_], s_->d_win_[s_->win_], WSIZE, hipMemcpyDeviceToDevice, stream)
+                                 : hipMemcpyPeerAsync(to->d_win_[to->win_], to->device_, s_->d_win_[s_->win_], s_->device_, WSIZE, stream);
+        if (e != hipSuccess || hipStreamSynchronize(stream) != hipSuccess) return false;
+        s_ = to;
+        return true;
     }
 
     void close() {
@@ -2537,7 +2595,7 @@ public:
             fprintf(stderr,
                     "[nohuman trace] gzip reader on GPU %d, %s: %llu pieces, %llu chunks (%llu decoded again), %llu pieces by the host decoder, "
                     "%llu members, %.2f GB -> %.2f GB; kernels ms: search %.1f decode %.1f windows %.1f resolve %.1f crc %.1f; host: open %.3f s, copy %.3f s, wait %.3f s\n",
-                    device_, path_.c_str(), (unsigned long long)st_.segments, (unsigned long long)st_.chunks, (unsigned long long)st_.redecoded,
+                    sets_.empty() ? -1 : sets_[0]->device_, path_.c_str(), (unsigned long long)st_.segments, (unsigned long long)st_.chunks, (unsigned long long)st_.redecoded,
                     (unsigned long long)st_.fallback_segments, (unsigned long long)st_.members, st_.gzip_bytes / 1e9, st_.text_bytes / 1e9, st_.ms_search,
                     st_.ms_decode, st_.ms_scan, st_.ms_resolve, st_.ms_crc, open_s_, st_.s_host_copy, st_.s_wait);
 #ifdef NH_GZ_PROF
@@ -2549,19 +2607,29 @@ public:
                     (double)prof_[4] / st_.chunks, (double)prof_[5] / st_.chunks, (double)prof_[6] / st_.chunks, (double)prof_[7] / st_.chunks,
                     (double)prof_[8] / st_.chunks, (double)prof_[9] / st_.chunks, (double)prof_[10] / st_.chunks, (double)prof_[11] / st_.chunks);
 #endif
-        if (device_ >= 0) (void)hipSetDevice(device_);
-        free_buffers();
-        for (auto &e : ev_)
-            if (e) {
-                (void)hipEventDestroy(e);
-                e = nullptr;
-            }
+        if (trace_ && sets_.size() > 1) {
+            std::string per;
+            for (auto &d : sets_) per += " " + std::to_string(d->device_) + ":" + std::to_string((unsigned long long)d->pieces);
+            fprintf(stderr, "[nohuman trace] gzip reader, %s: pieces by device (device:pieces)%s\n", path_.c_str(), per.c_str());
+        }
+        for (auto &d : sets_) free_set(*d);
+        sets_.clear();
+        s_ = nullptr;
         if (base_) munmap((void *)base_, size_);
         base_ = nullptr;
         if (fd_ >= 0) ::close(fd_);
         fd_ = -1;
         st_ = DevGunzipStats();
         ended_ = false;
+    }
+
+    int n_sets() const { return (int)sets_.size(); }
+    uint64_t pieces_of(int k) const { return sets_[(size_t)k]->pieces; }
+    long next_on(int k, void *d_dst, size_t room, hipStream_t stream) {
+        if (!error_.empty()) return -1;
+        if (k < 0 || k >= (int)sets_.size()) return fail("no such device set");
+        if (!select_set(k, stream)) return fail("moving the window between devices failed");
+        return next(d_dst, room, stream);
     }
 
     long next(void *d_dst, size_t room, hipStream_t stream) {
@@ -2614,7 +2682,7 @@ private:
 
     // one piece of the stream: up to n_slots_ stretches from the position the stream goes on at
     long piece(uint8_t *d_dst, size_t room, hipStream_t stream) {
-        if (hipSetDevice(device_) != hipSuccess) return fail("hipSetDevice failed");
+        if (hipSetDevice(s_->device_) != hipSuccess) return fail("hipSetDevice failed");
         const uint64_t a_byte = (pos_bit_ >> 3) / ALIGN * ALIGN;  // the piece's buffer starts here in the file
         const uint64_t first_bit = pos_bit_ - 8 * a_byte;
         if (a_byte >= size_) return fail("unexpected end of file");
@@ -2638,66 +2706,66 @@ private:
             const uint64_t valid_bits = 8ull * avail;
             // the bytes: page cache -> page-locked staging -> device
             const auto c0 = std::chrono::steady_clock::now();
-            memcpy(h_in_, base_ + a_byte, avail);
-            memset(h_in_ + avail, 0, 1024);
+            memcpy(s_->h_in_, base_ + a_byte, avail);
+            memset(s_->h_in_ + avail, 0, 1024);
             st_.s_host_copy += std::chrono::duration<double>(std::chrono::steady_clock::now() - c0).count();
-            GZ_TRY(hipMemcpyAsync(d_in_, h_in_, avail + 1024, hipMemcpyHostToDevice, stream));
+            GZ_TRY(hipMemcpyAsync(s_->d_in_, s_->h_in_, avail + 1024, hipMemcpyHostToDevice, stream));
             const uint64_t end_bit = std::min<uint64_t>((uint64_t)n_str * stretch_ * 8, valid_bits);
-            if (trace_) (void)hipEventRecord(ev_[0], stream);
+            if (trace_) (void)hipEventRecord(s_->ev_[0], stream);
             if (v1_)
-                hipLaunchKernelGGL(k_search, dim3(n_str), dim3(64), sizeof(Lds), stream, (const uint32_t *)d_in_, valid_bits, (uint64_t)stretch_ * 8,
-                                   first_bit, d_start_);
+                hipLaunchKernelGGL(k_search, dim3(n_str), dim3(64), sizeof(Lds), stream, (const uint32_t *)s_->d_in_, valid_bits, (uint64_t)stretch_ * 8,
+                                   first_bit, s_->d_start_);
             else if (v2_)
-                hipLaunchKernelGGL(k_search2, dim3(n_str), dim3(64), sizeof(Lds), stream, (const uint32_t *)d_in_, valid_bits,
-                                   (uint64_t)stretch_ * 8, first_bit, d_start_);
+                hipLaunchKernelGGL(k_search2, dim3(n_str), dim3(64), sizeof(Lds), stream, (const uint32_t *)s_->d_in_, valid_bits,
+                                   (uint64_t)stretch_ * 8, first_bit, s_->d_start_);
             else
-                hipLaunchKernelGGL(k_search3, dim3(n_str), dim3(64), SEARCH3_LDS, stream, (const uint32_t *)d_in_, valid_bits,
-                                   (uint64_t)stretch_ * 8, first_bit, d_start_);
+                hipLaunchKernelGGL(k_search3, dim3(n_str), dim3(64), SEARCH3_LDS, stream, (const uint32_t *)s_->d_in_, valid_bits,
+                                   (uint64_t)stretch_ * 8, first_bit, s_->d_start_);
             long fake_end = -1;
             if (fake_start_ > 0 && (uint32_t)fake_start_ < n_str) {  // test knob: pretend the search found a start that is none
                 const uint64_t bogus = (uint64_t)fake_start_ * stretch_ * 8 + 13;
-                GZ_TRY(hipMemcpyAsync(d_start_ + fake_start_, &bogus, 8, hipMemcpyHostToDevice, stream));
+                GZ_TRY(hipMemcpyAsync(s_->d_start_ + fake_start_, &bogus, 8, hipMemcpyHostToDevice, stream));
                 GZ_TRY(hipStreamSynchronize(stream));
                 if (getenv("NOHUMAN_GZDEV_FAKE_END")) fake_end = fake_start_;  // ... whose garbage even looks like the end of the stream
                 fake_start_ = -1;
             }
-            hipLaunchKernelGGL(k_plan, dim3(1), dim3(1024), 0, stream, (const uint64_t *)d_start_, n_str, end_bit, slot_syms_, d_desc_);
-            if (trace_) (void)hipEventRecord(ev_[1], stream);
-            hipLaunchKernelGGL(inflate_kernel(), dim3(n_str), dim3(64), inflate_lds(), stream, (const uint32_t *)d_in_, valid_bits,
-                               at_eof ? 1u : 0u, d_desc_, d_sym_, slot_syms_, NOIDX);
-            if (fake_end >= 0) hipLaunchKernelGGL(k_test_mark_end, dim3(1), dim3(1), 0, stream, d_desc_, (uint32_t)fake_end);
-            if (trace_) (void)hipEventRecord(ev_[2], stream);
+            hipLaunchKernelGGL(k_plan, dim3(1), dim3(1024), 0, stream, (const uint64_t *)s_->d_start_, n_str, end_bit, slot_syms_, s_->d_desc_);
+            if (trace_) (void)hipEventRecord(s_->ev_[1], stream);
+            hipLaunchKernelGGL(inflate_kernel(), dim3(n_str), dim3(64), inflate_lds(), stream, (const uint32_t *)s_->d_in_, valid_bits,
+                               at_eof ? 1u : 0u, s_->d_desc_, s_->d_sym_, slot_syms_, NOIDX);
+            if (fake_end >= 0) hipLaunchKernelGGL(k_test_mark_end, dim3(1), dim3(1), 0, stream, s_->d_desc_, (uint32_t)fake_end);
+            if (trace_) (void)hipEventRecord(s_->ev_[2], stream);
             uint32_t redo = 0;
             for (;;) {
-                hipLaunchKernelGGL(k_finish, dim3(1), dim3(1024), 0, stream, d_desc_, n_str, d_toff_, d_res_);
-                GZ_TRY(hipMemcpyAsync(h_res_, d_res_, sizeof(SegResult), hipMemcpyDeviceToHost, stream));
+                hipLaunchKernelGGL(k_finish, dim3(1), dim3(1024), 0, stream, s_->d_desc_, n_str, s_->d_toff_, s_->d_res_);
+                GZ_TRY(hipMemcpyAsync(s_->h_res_, s_->d_res_, sizeof(SegResult), hipMemcpyDeviceToHost, stream));
                 const auto w0 = std::chrono::steady_clock::now();
                 GZ_TRY(hipStreamSynchronize(stream));
                 st_.s_wait += std::chrono::duration<double>(std::chrono::steady_clock::now() - w0).count();
-                if (h_res_->bad_chunk != NOIDX && (h_res_->broken == NOIDX || h_res_->bad_chunk < h_res_->broken)) break;
-                if (h_res_->broken == NOIDX) break;
+                if (s_->h_res_->bad_chunk != NOIDX && (s_->h_res_->broken == NOIDX || s_->h_res_->bad_chunk < s_->h_res_->broken)) break;
+                if (s_->h_res_->broken == NOIDX) break;
                 // A chunk does not start where its predecessor ended: what the search found there was no block start.
                 // It is struck from the plan and its predecessor decoded again, now to the start after it (the host
                 // reader's "searching on"; costs time, never correctness).
-                const uint32_t bad = h_res_->broken;
-                GZ_TRY(hipMemcpyAsync(d_start_ + bad, &NONE, 8, hipMemcpyHostToDevice, stream));
-                hipLaunchKernelGGL(k_plan, dim3(1), dim3(1024), 0, stream, (const uint64_t *)d_start_, n_str, end_bit, slot_syms_, d_desc_);
-                GZ_TRY(hipMemcpyAsync(h_desc_, d_desc_, (size_t)n_str * sizeof(ChunkDesc), hipMemcpyDeviceToHost, stream));
+                const uint32_t bad = s_->h_res_->broken;
+                GZ_TRY(hipMemcpyAsync(s_->d_start_ + bad, &NONE, 8, hipMemcpyHostToDevice, stream));
+                hipLaunchKernelGGL(k_plan, dim3(1), dim3(1024), 0, stream, (const uint64_t *)s_->d_start_, n_str, end_bit, slot_syms_, s_->d_desc_);
+                GZ_TRY(hipMemcpyAsync(s_->h_desc_, s_->d_desc_, (size_t)n_str * sizeof(ChunkDesc), hipMemcpyDeviceToHost, stream));
                 GZ_TRY(hipStreamSynchronize(stream));
                 uint32_t prev = bad;
-                while (prev > 0 && h_desc_[--prev].bit_start == NONE) {
+                while (prev > 0 && s_->h_desc_[--prev].bit_start == NONE) {
                 }
-                hipLaunchKernelGGL(inflate_kernel(), dim3(1), dim3(64), inflate_lds(), stream, (const uint32_t *)d_in_, valid_bits,
-                                   at_eof ? 1u : 0u, d_desc_, d_sym_, slot_syms_, prev);
+                hipLaunchKernelGGL(inflate_kernel(), dim3(1), dim3(64), inflate_lds(), stream, (const uint32_t *)s_->d_in_, valid_bits,
+                                   at_eof ? 1u : 0u, s_->d_desc_, s_->d_sym_, slot_syms_, prev);
                 redo++;
                 st_.redecoded++;
                 if (redo > n_str) return fail("the chunks of a piece do not chain");
             }
-            const SegResult r = *h_res_;
+            const SegResult r = *s_->h_res_;
             if (trace_) {
                 float ms = 0;
-                if (hipEventElapsedTime(&ms, ev_[0], ev_[1]) == hipSuccess) st_.ms_search += ms;
-                if (hipEventElapsedTime(&ms, ev_[1], ev_[2]) == hipSuccess) st_.ms_decode += ms;
+                if (hipEventElapsedTime(&ms, s_->ev_[0], s_->ev_[1]) == hipSuccess) st_.ms_search += ms;
+                if (hipEventElapsedTime(&ms, s_->ev_[1], s_->ev_[2]) == hipSuccess) st_.ms_decode += ms;
             }
             if (r.bad_chunk != NOIDX || r.end_chunk == NOIDX) {
                 last_bad_ = r.bad_status;
@@ -2712,49 +2780,49 @@ private:
                 continue;
             }
             // windows by the prefix scan, text, CRCs, the window behind the piece
-            if (trace_) (void)hipEventRecord(ev_[3], stream);
+            if (trace_) (void)hipEventRecord(s_->ev_[3], stream);
             const uint32_t gy = 4;
             if (scan_rounds_) {
-                hipLaunchKernelGGL(k_maps, dim3(n_str, gy), dim3(256), 0, stream, (const ChunkDesc *)d_desc_, (const uint16_t *)d_sym_, slot_syms_,
-                                   d_maps_[0]);
+                hipLaunchKernelGGL(k_maps, dim3(n_str, gy), dim3(256), 0, stream, (const ChunkDesc *)s_->d_desc_, (const uint16_t *)s_->d_sym_, slot_syms_,
+                                   s_->d_maps_[0]);
                 int cur = 0;
                 for (uint32_t stride = 1; stride < n_str; stride <<= 1) {
-                    hipLaunchKernelGGL(k_scan_round, dim3(n_str, gy), dim3(256), 0, stream, (const uint16_t *)d_maps_[cur], d_maps_[cur ^ 1], n_str,
+                    hipLaunchKernelGGL(k_scan_round, dim3(n_str, gy), dim3(256), 0, stream, (const uint16_t *)s_->d_maps_[cur], s_->d_maps_[cur ^ 1], n_str,
                                        stride);
                     cur ^= 1;
                 }
-                hipLaunchKernelGGL(k_windows, dim3(n_str, gy), dim3(256), 0, stream, (const uint16_t *)d_maps_[cur], (const uint8_t *)d_win_[win_],
-                                   d_windows_);
+                hipLaunchKernelGGL(k_windows, dim3(n_str, gy), dim3(256), 0, stream, (const uint16_t *)s_->d_maps_[cur], (const uint8_t *)s_->d_win_[s_->win_],
+                                   s_->d_windows_);
             } else {
                 const uint32_t ng = (n_str + SCAN_GROUP - 1) / SCAN_GROUP;
-                hipLaunchKernelGGL(k_scan_local, dim3(ng), dim3(1024), 2 * WSIZE, stream, (const ChunkDesc *)d_desc_, (const uint16_t *)d_sym_, slot_syms_,
-                                   n_str, d_maps_[0]);
-                hipLaunchKernelGGL(k_scan_groups, dim3(1), dim3(1024), 2 * WSIZE, stream, (const uint16_t *)d_maps_[0], n_str, d_maps_[1]);
-                hipLaunchKernelGGL(k_scan_windows, dim3(n_str, gy), dim3(256), 0, stream, (const uint16_t *)d_maps_[0], (const uint16_t *)d_maps_[1],
-                                   (const uint8_t *)d_win_[win_], d_windows_);
+                hipLaunchKernelGGL(k_scan_local, dim3(ng), dim3(1024), 2 * WSIZE, stream, (const ChunkDesc *)s_->d_desc_, (const uint16_t *)s_->d_sym_, slot_syms_,
+                                   n_str, s_->d_maps_[0]);
+                hipLaunchKernelGGL(k_scan_groups, dim3(1), dim3(1024), 2 * WSIZE, stream, (const uint16_t *)s_->d_maps_[0], n_str, s_->d_maps_[1]);
+                hipLaunchKernelGGL(k_scan_windows, dim3(n_str, gy), dim3(256), 0, stream, (const uint16_t *)s_->d_maps_[0], (const uint16_t *)s_->d_maps_[1],
+                                   (const uint8_t *)s_->d_win_[s_->win_], s_->d_windows_);
             }
-            if (trace_) (void)hipEventRecord(ev_[4], stream);
-            hipLaunchKernelGGL(k_resolve, dim3(n_str, 8), dim3(256), 0, stream, (const ChunkDesc *)d_desc_, (const uint16_t *)d_sym_, slot_syms_,
-                               (const uint8_t *)d_windows_, (const uint64_t *)d_toff_, d_dst);
-            if (trace_) (void)hipEventRecord(ev_[5], stream);
-            hipLaunchKernelGGL(k_crc, dim3(n_str), dim3(256), 0, stream, d_desc_, (const uint64_t *)d_toff_, (const uint8_t *)d_dst);
-            hipLaunchKernelGGL(k_carry_window, dim3(1), dim3(1024), 0, stream, (const uint8_t *)d_dst, (uint64_t)room, (const SegResult *)d_res_,
-                               (const uint8_t *)d_win_[win_], d_win_[win_ ^ 1]);
-            if (trace_) (void)hipEventRecord(ev_[6], stream);
-            GZ_TRY(hipMemcpyAsync(h_desc_, d_desc_, (size_t)n_str * sizeof(ChunkDesc), hipMemcpyDeviceToHost, stream));
+            if (trace_) (void)hipEventRecord(s_->ev_[4], stream);
+            hipLaunchKernelGGL(k_resolve, dim3(n_str, 8), dim3(256), 0, stream, (const ChunkDesc *)s_->d_desc_, (const uint16_t *)s_->d_sym_, slot_syms_,
+                               (const uint8_t *)s_->d_windows_, (const uint64_t *)s_->d_toff_, d_dst);
+            if (trace_) (void)hipEventRecord(s_->ev_[5], stream);
+            hipLaunchKernelGGL(k_crc, dim3(n_str), dim3(256), 0, stream, s_->d_desc_, (const uint64_t *)s_->d_toff_, (const uint8_t *)d_dst);
+            hipLaunchKernelGGL(k_carry_window, dim3(1), dim3(1024), 0, stream, (const uint8_t *)d_dst, (uint64_t)room, (const SegResult *)s_->d_res_,
+                               (const uint8_t *)s_->d_win_[s_->win_], s_->d_win_[s_->win_ ^ 1]);
+            if (trace_) (void)hipEventRecord(s_->ev_[6], stream);
+            GZ_TRY(hipMemcpyAsync(s_->h_desc_, s_->d_desc_, (size_t)n_str * sizeof(ChunkDesc), hipMemcpyDeviceToHost, stream));
             const auto w0 = std::chrono::steady_clock::now();
             GZ_TRY(hipStreamSynchronize(stream));
             st_.s_wait += std::chrono::duration<double>(std::chrono::steady_clock::now() - w0).count();
             if (trace_) {
                 float ms = 0;
-                if (hipEventElapsedTime(&ms, ev_[3], ev_[4]) == hipSuccess) st_.ms_scan += ms;
-                if (hipEventElapsedTime(&ms, ev_[4], ev_[5]) == hipSuccess) st_.ms_resolve += ms;
-                if (hipEventElapsedTime(&ms, ev_[5], ev_[6]) == hipSuccess) st_.ms_crc += ms;
+                if (hipEventElapsedTime(&ms, s_->ev_[3], s_->ev_[4]) == hipSuccess) st_.ms_scan += ms;
+                if (hipEventElapsedTime(&ms, s_->ev_[4], s_->ev_[5]) == hipSuccess) st_.ms_resolve += ms;
+                if (hipEventElapsedTime(&ms, s_->ev_[5], s_->ev_[6]) == hipSuccess) st_.ms_crc += ms;
             }
-            win_ ^= 1;
+            s_->win_ ^= 1;
             // members: CRC-32 and ISIZE like gzip checks them
             for (uint32_t c = 0; c <= r.end_chunk; c++) {
-                const ChunkDesc &d = h_desc_[c];
+                const ChunkDesc &d = s_->h_desc_[c];
                 if (d.bit_start == NONE) continue;
 #ifdef NH_GZ_PROF
                 for (int i = 0; i < 12; i++) prof_[i] += d.prof[i];
@@ -2772,6 +2840,7 @@ private:
                         (unsigned long long)st_.segments, (unsigned long long)a_byte, (unsigned long long)first_bit, n_str, r.n_chunks, r.end_chunk, redo,
                         (unsigned long long)r.total, (unsigned long long)st_.text_bytes, (unsigned long long)r.end_bit, r.stream_end ? " (end of stream)" : "");
             st_.segments++;
+            s_->pieces++;
             st_.chunks += r.n_chunks;
             st_.text_bytes += r.total;
             st_.gzip_bytes += (a_byte * 8 + r.end_bit - pos_bit_) / 8;
@@ -2801,7 +2870,7 @@ private:
             warned_ = true;
         }
         std::vector<uint8_t> window(WSIZE);
-        GZ_TRY(hipMemcpyAsync(window.data(), d_win_[win_], WSIZE, hipMemcpyDeviceToHost, stream));
+        GZ_TRY(hipMemcpyAsync(window.data(), s_->d_win_[s_->win_], WSIZE, hipMemcpyDeviceToHost, stream));
         GZ_TRY(hipStreamSynchronize(stream));
         // to the first block boundary behind a megabyte of input (in host mode: sixteen), or with half the room full
         std::vector<uint8_t> out;
@@ -2826,9 +2895,9 @@ private:
             memcpy(nw.data(), window.data() + out.size(), WSIZE - out.size());
             memcpy(nw.data() + WSIZE - out.size(), out.data(), out.size());
         }
-        GZ_TRY(hipMemcpyAsync(d_win_[win_ ^ 1], nw.data(), WSIZE, hipMemcpyHostToDevice, stream));
+        GZ_TRY(hipMemcpyAsync(s_->d_win_[s_->win_ ^ 1], nw.data(), WSIZE, hipMemcpyHostToDevice, stream));
         GZ_TRY(hipStreamSynchronize(stream));
-        win_ ^= 1;
+        s_->win_ ^= 1;
         uint64_t a = 0;
         for (const GzMemberEnd &m : members) {
             account(crc32_fast(0, out.data() + a, (size_t)(m.out_pos - a)), m.out_pos - a);
@@ -2837,6 +2906,7 @@ private:
         }
         account(crc32_fast(0, out.data() + a, out.size() - (size_t)a), out.size() - a);
         st_.segments++;
+        s_->pieces++;
         st_.fallback_segments++;
         st_.text_bytes += out.size();
         st_.gzip_bytes += (eb - pos_bit_) / 8;
@@ -2849,21 +2919,13 @@ private:
     }
 
     std::string path_;
-    int device_ = -1, fd_ = -1;
+    int fd_ = -1;
     size_t size_ = 0;
     const uint8_t *base_ = nullptr;
     uint64_t pos_bit_ = 0;  // where the stream goes on (a block boundary), bits from the start of the file
     size_t stretch_ = 0, seg_ = 0, look_ = 0;
     uint32_t n_slots_ = 0, slot_syms_ = 0;
     double ratio_ = 6.0;  // text per compressed byte seen lately
-    uint8_t *d_in_ = nullptr, *h_in_ = nullptr;
-    uint64_t *d_start_ = nullptr, *d_toff_ = nullptr;
-    ChunkDesc *d_desc_ = nullptr, *h_desc_ = nullptr;
-    uint16_t *d_sym_ = nullptr, *d_maps_[2] = {nullptr, nullptr};
-    uint8_t *d_windows_ = nullptr, *d_win_[2] = {nullptr, nullptr};
-    int win_ = 0;
-    SegResult *d_res_ = nullptr, *h_res_ = nullptr;
-    hipEvent_t ev_[7] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     uint32_t run_crc_ = 0;
     uint64_t run_len_ = 0;
     bool trace_ = false, warned_ = false, host_mode_ = false, v1_ = false, v2_ = false, scan_rounds_ = false;
@@ -2881,6 +2943,9 @@ int DevGunzip::open(const char *path, int device, size_t seg_bytes, size_t stret
     return impl_->open(path, device, seg_bytes, stretch_bytes, err);
 }
 long DevGunzip::next(void *d_dst, size_t room, hipStream_t stream) { return impl_->next(d_dst, room, stream); }
+int DevGunzip::add_device(int device, std::string &err) { return impl_->add_device(device, err); }
+long DevGunzip::next_on(int set, void *d_dst, size_t room, hipStream_t stream) { return impl_->next_on(set, d_dst, room, stream); }
+uint64_t DevGunzip::pieces_of(int set) const { return impl_->pieces_of(set); }
 bool DevGunzip::ended() const { return impl_->ended_; }
 const std::string &DevGunzip::error() const { return impl_->error_; }
 const DevGunzipStats &DevGunzip::stats() const { return impl_->st_; }
@@ -3083,29 +3148,37 @@ __global__ __launch_bounds__(256) void k_records(const uint8_t *text, const uint
 class DevFastqImpl {
 public:
     ~DevFastqImpl() { close(); }
-    int open(const char *path, int device, std::string &err) {
+    int open(const char *path, const int *devices, int n_devices, std::string &err) {
         if (!dev_gunzip_wants(path)) return 1;
-        device_ = device;
+        if (n_devices < 1) return 1;
         path_ = path;
-        if (hipSetDevice(device) != hipSuccess) {
+        // piece i of the stream is decoded and indexed on lane i mod G (a lane: a device, a stream, a buffer set of the
+        // decoder); every lane has two text buffers, so a piece is decoded while the one before it on the lane goes out
+        lanes_.resize((size_t)n_devices);
+        for (int g = 0; g < n_devices; g++) lanes_[(size_t)g].device = devices[g];
+        if (hipSetDevice(devices[0]) != hipSuccess) {
             err = "hipSetDevice failed";
             return -1;
         }
-        if (gz_.open(path, device, 0, 0, err) != 0) return -1;
+        if (gz_.open(path, devices[0], 0, 0, err) != 0) return -1;
+        for (int g = 1; g < n_devices; g++)
+            if (gz_.add_device(devices[g], err) != g) return -1;
         room_ = (size_t)2560u << 20;
         struct stat st;
         if (stat(path, &st) == 0 && (uint64_t)st.st_size * 16 + ((size_t)64u << 20) < room_) room_ = (size_t)st.st_size * 16 + ((size_t)64u << 20);
         if (const char *e = getenv("NOHUMAN_GZDEV_ROOM")) room_ = std::max<size_t>((size_t)atoll(e), (size_t)1u << 20);
-        if (hipStreamCreateWithFlags(&stream_, hipStreamNonBlocking) != hipSuccess) {
-            err = "cannot create a stream";
-            return -1;
-        }
+        buf_.resize(2 * lanes_.size());
+        for (size_t i = 0; i < buf_.size(); i++) buf_[i].lane = (int)(i % lanes_.size());
         for (;;) {
-            buf_[0].d_text = (uint8_t *)cache_alloc(device_, room_ + 4096, false);
-            buf_[1].d_text = (uint8_t *)cache_alloc(device_, room_ + 4096, false);
-            if (buf_[0].d_text && buf_[1].d_text) break;
+            bool ok = true;
             for (Piece &b : buf_) {
-                cache_free(device_, room_ + 4096, b.d_text, false);
+                (void)hipSetDevice(lanes_[(size_t)b.lane].device);
+                b.d_text = (uint8_t *)cache_alloc(lanes_[(size_t)b.lane].device, room_ + 4096, false);
+                ok = ok && b.d_text;
+            }
+            if (ok) break;
+            for (Piece &b : buf_) {
+                cache_free(lanes_[(size_t)b.lane].device, room_ + 4096, b.d_text, false);
                 b.d_text = nullptr;
             }
             if (room_ <= ((size_t)128u << 20)) {
@@ -3114,9 +3187,12 @@ public:
             }
             room_ /= 2;
         }
-        if (hipMalloc((void **)&d_bad_, 8) != hipSuccess || hipHostMalloc((void **)&h_bad_, 8, hipHostMallocDefault) != hipSuccess) {
-            err = "the gzip reader's buffers cannot be had";
-            return -1;
+        for (Lane &l : lanes_) {
+            if (hipSetDevice(l.device) != hipSuccess || hipStreamCreateWithFlags(&l.stream, hipStreamNonBlocking) != hipSuccess ||
+                hipMalloc((void **)&l.d_bad, 8) != hipSuccess || hipHostMalloc((void **)&l.h_bad, 8, hipHostMallocDefault) != hipSuccess) {
+                err = "the gzip reader's buffers cannot be had";
+                return -1;
+            }
         }
         trace_ = getenv("NOHUMAN_TRACE") != nullptr;
         return 0;
@@ -3153,7 +3229,7 @@ public:
                 p.loaded = false;
             }
             cv_.notify_all();
-            take_ ^= 1;
+            take_ = (take_ + 1) % buf_.size();
             if (p.last) {
                 hb.eof = true;
                 return 0;
@@ -3171,27 +3247,35 @@ public:
         // every batch handed out points into the text buffers: wait until the pipeline has let go of them
         {
             std::unique_lock<std::mutex> lk(mu_);
-            cv_.wait(lk, [&] { return buf_[0].outstanding == 0 && buf_[1].outstanding == 0; });
+            cv_.wait(lk, [&] {
+                for (const Piece &b : buf_)
+                    if (b.outstanding) return false;
+                return true;
+            });
         }
         if (trace_ && pieces_)
-            fprintf(stderr, "[nohuman trace] record index on GPU %d, %s: %llu pieces, %llu records, index kernels + table D2H %.3f s, carried %.2f GB\n",
-                    device_, path_.c_str(), (unsigned long long)pieces_, (unsigned long long)records_, index_s_, carried_ / 1e9);
+            fprintf(stderr, "[nohuman trace] record index on GPU %d (%zu lane%s), %s: %llu pieces, %llu records, index kernels + table D2H %.3f s, carried %.2f GB\n",
+                    lanes_.empty() ? -1 : lanes_[0].device, lanes_.size(), lanes_.size() == 1 ? "" : "s", path_.c_str(), (unsigned long long)pieces_,
+                    (unsigned long long)records_, index_s_, carried_ / 1e9);
         pieces_ = 0;
         gz_.close();
-        if (device_ >= 0) (void)hipSetDevice(device_);
         for (Piece &b : buf_) {
-            cache_free(device_, room_ + 4096, b.d_text, false);
+            const int dev = lanes_[(size_t)b.lane].device;
+            (void)hipSetDevice(dev);
+            cache_free(dev, room_ + 4096, b.d_text, false);
             for (void *q : {(void *)b.d_nl, (void *)b.d_tiles, (void *)b.d_recs, (void *)b.d_bstart})
                 if (q) (void)hipFree(q);
             for (void *q : {(void *)b.h_recs, (void *)b.h_bstart})
                 if (q) (void)hipHostFree(q);
-            b = Piece();
         }
-        if (d_bad_) (void)hipFree(d_bad_);
-        if (h_bad_) (void)hipHostFree(h_bad_);
-        d_bad_ = nullptr, h_bad_ = nullptr;
-        if (stream_) (void)hipStreamDestroy(stream_);
-        stream_ = nullptr;
+        buf_.clear();
+        for (Lane &l : lanes_) {
+            (void)hipSetDevice(l.device);
+            if (l.d_bad) (void)hipFree(l.d_bad);
+            if (l.h_bad) (void)hipHostFree(l.h_bad);
+            if (l.stream) (void)hipStreamDestroy(l.stream);
+        }
+        lanes_.clear();
     }
 
 private:
@@ -3204,6 +3288,12 @@ private:
         size_t n_rec = 0, next_rec = 0;
         bool loaded = false, last = false, indexed = false;  // loaded: handed to the consumer; indexed: its record table is valid
         int outstanding = 0;  // batches handed out and not yet released
+        int lane = 0;
+    };
+    struct Lane {
+        int device = -1;
+        hipStream_t stream = nullptr;
+        unsigned long long *d_bad = nullptr, *h_bad = nullptr;
     };
 
     int fail(const std::string &m) {
@@ -3234,7 +3324,7 @@ private:
         }
         hb.text.set_size(len);
         hb.dev_text = p.d_text + t0;
-        hb.dev_device = device_;
+        hb.dev_device = lanes_[(size_t)p.lane].device;
         hb.host_text_valid = false;
         p.next_rec = r1;
         hb.eof = p.last && r1 == full;
@@ -3253,13 +3343,14 @@ private:
         return 0;
     }
 
-    // pieces into the two buffers in turn, each behind what the one before could not hand out as whole batches
+    // pieces into the buffers in turn (buffer i on lane i mod G), each behind what the one before could not hand out as
+    // whole batches
     void produce() {
-        (void)hipSetDevice(device_);
         for (;;) {
+            const size_t filled = fill_;
             const int rc = load_next();
             std::lock_guard<std::mutex> lk(mu_);
-            if (rc != 0 || buf_[fill_ ^ 1].last || stop_) {  // (fill_ was flipped by load_next: the piece just loaded is the other one)
+            if (rc != 0 || buf_[filled].last || stop_) {
                 if (rc == 1) fallback_ = true;
                 done_ = true;
                 cv_.notify_all();
@@ -3270,29 +3361,35 @@ private:
 
     int load_next() {
         using namespace fq;
-        Piece &old = buf_[fill_ ^ 1];  // the piece loaded before this one (its record table stays valid while its batches go out)
+        Piece &old = buf_[(fill_ + buf_.size() - 1) % buf_.size()];  // the piece loaded before this one (its record table stays valid while its batches go out)
         Piece &p = buf_[fill_];
+        Lane &ln = lanes_[(size_t)p.lane];
         {
             std::unique_lock<std::mutex> lk(mu_);
             cv_.wait(lk, [&] { return (!p.loaded && p.outstanding == 0) || stop_; });
             if (stop_) return -2;
         }
+        if (hipSetDevice(ln.device) != hipSuccess) return fail("hipSetDevice failed");
         size_t carry = 0;
         if (old.indexed) {
-            // the records behind the last whole batch and the incomplete record behind them
+            // the records behind the last whole batch and the incomplete record behind them (from the lane before: over xGMI)
             const size_t full = old.n_rec / bf_ * bf_;
             const size_t from = full < old.n_rec ? old.h_bstart[full / bf_] : old.used_len;
             carry = old.text_len - from;
             if (carry >= room_) return fail("a FASTQ record larger than the gzip reader's text buffer");
-            if (carry && hipMemcpyAsync(p.d_text, old.d_text + from, carry, hipMemcpyDeviceToDevice, stream_) != hipSuccess) return fail("D2D of the carried text failed");
+            const int odev = lanes_[(size_t)old.lane].device;
+            if (carry && (odev == ln.device ? hipMemcpyAsync(p.d_text, old.d_text + from, carry, hipMemcpyDeviceToDevice, ln.stream)
+                                            : hipMemcpyPeerAsync(p.d_text, ln.device, old.d_text + from, odev, carry, ln.stream)) != hipSuccess)
+                return fail("D2D of the carried text failed");
             carried_ += carry;
         }
-        const long n = gz_.next(p.d_text + carry, room_ - carry, stream_);
+        const long n = gz_.next_on(p.lane, p.d_text + carry, room_ - carry, ln.stream);
         if (n < 0) return fail(gz_.error());
         p.text_len = carry + (size_t)n;
         p.last = gz_.ended();
         p.n_rec = p.next_rec = 0;
         p.used_len = 0;
+        p.indexed = false;
         pieces_++;
         const int irc = p.text_len ? index(p) : 0;
         if (irc != 0) return irc;
@@ -3302,13 +3399,16 @@ private:
             p.loaded = true;
         }
         cv_.notify_all();
-        fill_ ^= 1;
+        fill_ = (fill_ + 1) % buf_.size();
         return 0;
     }
 
     // newlines -> lines -> records of the piece's text
     int index(Piece &p) {
         using namespace fq;
+        Lane &ln = lanes_[(size_t)p.lane];
+        hipStream_t const stream_ = ln.stream;
+        unsigned long long *const d_bad_ = ln.d_bad, *const h_bad_ = ln.h_bad;
         const auto t0 = std::chrono::steady_clock::now();
         if (p.last) {  // the input's last line may lack its newline
             uint8_t lastc = 0;
@@ -3395,14 +3495,12 @@ private:
 
     DevGunzip gz_;
     std::string path_, error_;
-    int device_ = -1;
-    hipStream_t stream_ = nullptr;
-    Piece buf_[2];
-    int fill_ = 0, take_ = 0;
+    std::vector<Lane> lanes_;
+    std::vector<Piece> buf_;
+    size_t fill_ = 0, take_ = 0;
     size_t room_ = 0, bf_ = 0;
     std::thread th_;
     bool stop_ = false, done_ = false, fallback_ = false;
-    unsigned long long *d_bad_ = nullptr, *h_bad_ = nullptr;
     bool handed_out_ = false, trace_ = false;
     uint64_t pieces_ = 0, records_ = 0, carried_ = 0;
     double index_s_ = 0;
@@ -3412,7 +3510,7 @@ private:
 
 DevFastqReader::DevFastqReader() : impl_(new DevFastqImpl()) {}
 DevFastqReader::~DevFastqReader() { delete impl_; }
-int DevFastqReader::open(const char *path, int device, std::string &err) { return impl_->open(path, device, err); }
+int DevFastqReader::open(const char *path, const int *devices, int n_devices, std::string &err) { return impl_->open(path, devices, n_devices, err); }
 int DevFastqReader::next_batch(HalfBatch &hb, size_t max_recs) { return impl_->next_batch(hb, max_recs); }
 void DevFastqReader::close() { impl_->close(); }
 

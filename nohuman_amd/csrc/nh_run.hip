@@ -525,7 +525,8 @@ enum { ST_READ1 = 0, ST_READ2, ST_RPUSH1, ST_RPUSH2, ST_MPOP, ST_MSLOT, ST_MGATH
 
 static void reader_main(const char *path, BoundedQueue<std::unique_ptr<HalfBatch>> *out, RunState *rs,
                         BatchPool *pool, StageClock *clk, int which, size_t batch_frags, size_t batch_text,
-                        unsigned gz_threads, int gz_device) {
+                        unsigned gz_threads, std::vector<int> gz_devices) {
+    const int gz_device = gz_devices.empty() ? -1 : gz_devices[0];
     // gzip FASTQ: the whole reader on the GPU (inflate, record index; the text stays in HBM) unless NOHUMAN_GZ_READER says
     // otherwise -- "host": the host decoders; "device-text": inflate on the GPU, records parsed on the host (BlockReader)
     {
@@ -534,7 +535,8 @@ static void reader_main(const char *path, BoundedQueue<std::unique_ptr<HalfBatch
         if (want) {
             DevFastqReader dr;
             std::string derr;
-            const int orc = dr.open(path, gz_device, derr);
+            // (the run's devices, this file's first: piece i of the stream is inflated, indexed and classified on device i mod G)
+            const int orc = dr.open(path, gz_devices.data(), (int)gz_devices.size(), derr);
             if (orc < 0) {
                 if (how && !strcmp(how, "device")) {  // asked for by name: no silent change of reader
                     rs->fail(NH_EIO, derr);
@@ -822,11 +824,17 @@ int run_engines(const std::vector<Engine *> &engines, const nh_run_args *a, nh_s
     if (gz_threads < 1) gz_threads = 1;
     if (gz_threads > 16) gz_threads = 16;  // beyond that the record parser of the file is the limit
     // gzip inputs are read on the GPU (nh_gunzip.hip): file 1 on the first device, file 2 on the second where there is one
-    std::thread t1(reader_main, a->in1, &q1, &rs, &pool1, &clk, 0, BATCH_FRAGS, BATCH_TEXT, gz_threads, engines[0]->device);
+    // ... piece by piece over the run's devices (the compressed ranges are the shards): file 1 starts on the
+    // first device, file 2 on the second, so the two files' pieces of the same moment sit on different GPUs
+    std::vector<int> devs1, devs2;
+    for (int g = 0; g < G; g++) {
+        devs1.push_back(engines[(size_t)g]->device);
+        devs2.push_back(engines[(size_t)((g + 1) % G)]->device);
+    }
+    if (getenv("NOHUMAN_GZ_SHARD") && getenv("NOHUMAN_GZ_SHARD")[0] == '0') devs1.resize(1), devs2.resize(1);  // (A / B: a file's reader on one device)
+    std::thread t1(reader_main, a->in1, &q1, &rs, &pool1, &clk, 0, BATCH_FRAGS, BATCH_TEXT, gz_threads, devs1);
     std::thread t2;
-    if (rs.paired)
-        t2 = std::thread(reader_main, a->in2, &q2, &rs, &pool2, &clk, 1, BATCH_FRAGS, BATCH_TEXT, gz_threads,
-                         engines[G > 1 ? 1 : 0]->device);
+    if (rs.paired) t2 = std::thread(reader_main, a->in2, &q2, &rs, &pool2, &clk, 1, BATCH_FRAGS, BATCH_TEXT, gz_threads, devs2);
 
     // writer: consumes batches in order; each arrives after its stream was synchronised.  The second
     // mate file is written by a helper so that both files are written at the same time.
@@ -933,6 +941,7 @@ int run_engines(const std::vector<Engine *> &engines, const nh_run_args *a, nh_s
     // main: pair halves, stage, launch
     std::unique_ptr<HalfBatch> carry1, carry2;
     uint64_t batch_no = 0;
+    std::vector<uint64_t> home_turn((size_t)G, 0);
     bool end1 = false, end2 = false;
     for (;;) {
         if (rs.failed()) break;
@@ -957,15 +966,34 @@ int run_engines(const std::vector<Engine *> &engines, const nh_run_args *a, nh_s
             break;
         }
         if (b.n > 0) {
-            const int si = (int)(batch_no % (uint64_t)(NS * G));
-            Slot &s = slots[si];
+            // the slot: in turn over all devices' slots -- but a batch born on a GPU (the gzip reader there) is classified
+            // on THAT device, in that device's slots in turn, unless they are all busy and another device has a free one
+            // (then its text crosses xGMI once); the writer takes the batches in the order they are pushed, whatever the slot
+            int si = (int)(batch_no % (uint64_t)(NS * G));
             uint64_t m1 = StageClock::now();
             clk.ns[ST_MPOP] += m1 - m0;
             {
+                int home = -1;
+                if (G > 1 && b.h1->dev_text)
+                    for (int g = 0; g < G; g++)
+                        if (engines[(size_t)g]->device == b.h1->dev_device) {
+                            home = g;
+                            break;
+                        }
                 std::unique_lock<std::mutex> lk(slot_mu);
-                slot_cv.wait(lk, [&] { return !s.busy; });
-                s.busy = true;
+                if (home >= 0) {
+                    si = home * NS + (int)(home_turn[(size_t)home]++ % (uint64_t)NS);
+                    if (slots[(size_t)si].busy)
+                        for (int k = 0; k < NS * G; k++)
+                            if (!slots[(size_t)k].busy) {
+                                si = k;
+                                break;
+                            }
+                }
+                slot_cv.wait(lk, [&] { return !slots[(size_t)si].busy; });
+                slots[(size_t)si].busy = true;
             }
+            Slot &s = slots[si];
             uint64_t m2 = StageClock::now();
             clk.ns[ST_MSLOT] += m2 - m1;
             b.slot = si;

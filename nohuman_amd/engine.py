@@ -38,7 +38,8 @@ def probe() -> str:
 
 
 def run(db_dir, in1, out1, in2=None, out2=None, kraken_output=None, report=None, confidence: float = 0.0,
-        threads: int = 1, keep_human: bool = False, device_ids=None) -> "_lib.nh_stats":
+        threads: int = 1, keep_human: bool = False, device_ids=None, out_codec: int = 0,
+        codec_threads: int = 0) -> "_lib.nh_stats":
     """nh_run: whole run, database loaded into every listed device (default: all visible)."""
     a = _lib.nh_run_args()
     a.db_dir = os.fsencode(db_dir)
@@ -51,6 +52,8 @@ def run(db_dir, in1, out1, in2=None, out2=None, kraken_output=None, report=None,
     a.confidence = float(confidence)
     a.threads = int(threads)
     a.keep_human = int(bool(keep_human))
+    a.out_codec = int(out_codec)
+    a.codec_threads = int(codec_threads)
     ids = None
     if device_ids:
         ids = (C.c_int32 * len(device_ids))(*device_ids)

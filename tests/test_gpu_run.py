@@ -342,6 +342,47 @@ def test_many_small_batches_two_engines_keep_input_order(tmp_path, monkeypatch):
         assert (tmp_path / ("a" + n)).read_bytes() == (tmp_path / ("b" + n)).read_bytes()
 
 
+def test_two_engines_on_device_0_sharded(tmp_path, monkeypatch, capfd):
+    """one run over G devices -- the pieces of each gzip file's compressed stream go round the run's
+    devices (piece i is inflated, indexed and classified on device i mod G; the stream's window moves from device to device,
+    the partial batch behind a piece too), the ordered writer is unchanged.  Two engines, both on GPU 0 (the multi-device
+    path on one device: two decoder buffer sets, two lanes a file, four more stream slots): the same output bytes,
+    kraken lines and counters as one engine, for plain and gzip outputs, and as the host reader."""
+    from nohuman_amd import engine
+    _, ext, recs, calls = _expected("expected_pe.json", 0.0)
+    raw1 = open(os.path.join(GOLD, "reads_pe_1.fq"), "rb").read()
+    raw2 = open(os.path.join(GOLD, "reads_pe_2.fq"), "rb").read()
+    # forty copies, pieces of 4 KiB of gzip (a piece ends at a block boundary: some 35 KB each): a dozen pieces a file
+    in1, in2 = tmp_path / "r_1.fq.gz", tmp_path / "r_2.fq.gz"
+    in1.write_bytes(gzip.compress(raw1 * 40, 6))
+    in2.write_bytes(gzip.compress(raw2 * 25, 1) + gzip.compress(raw2 * 15, 9))
+    monkeypatch.setenv("NOHUMAN_GZDEV_SEG", "4096")
+    monkeypatch.setenv("NOHUMAN_GZDEV_STRETCH", "1024")
+    monkeypatch.setenv("NOHUMAN_BATCH_FRAGS", "96")
+    monkeypatch.setenv("NOHUMAN_TRACE", "1")
+    res = {}
+    for tag, ids, reader, codec in (("one", [0], "device", 0), ("two", [0, 0], "device", 0), ("two_gz", [0, 0], "device", 2),
+                                    ("two_host", [0, 0], "host", 0), ("three", [0, 0, 0], "device", 0)):
+        monkeypatch.setenv("NOHUMAN_GZ_READER", reader)
+        o1, o2, k = tmp_path / (tag + "_1"), tmp_path / (tag + "_2"), tmp_path / (tag + ".k")
+        st = engine.run(DB, str(in1), str(o1), in2=str(in2), out2=str(o2), kraken_output=str(k), device_ids=ids, out_codec=codec,
+                        threads=4)
+        err = capfd.readouterr().err
+        rd = (lambda p: gzip.decompress(p.read_bytes())) if codec == 2 else (lambda p: p.read_bytes())
+        res[tag] = (rd(o1), rd(o2), k.read_bytes(), (st.total_sequences, st.classified, st.total_bases))
+        if reader == "device" and len(ids) > 1:
+            # both lanes of each file decoded pieces: "pieces by device (device:pieces) 0:a 0:b" with a, b > 0
+            lines = [ln for ln in err.splitlines() if "pieces by device" in ln]
+            assert len(lines) == 2, err[-3000:]
+            for ln in lines:
+                counts = [int(x.split(":")[1]) for x in ln.split(")")[-1].split()]
+                assert len(counts) == len(ids) and min(counts) >= 2, ln
+    n = len(calls) * 40
+    assert res["one"][3][0] == n and res["one"][3][1] == 40 * sum(1 for c in calls if c)
+    for tag in ("two", "two_gz", "two_host", "three"):
+        assert res[tag] == res["one"], tag
+
+
 def test_fragments_with_many_taxa_in_concurrent_batches(tmp_path, monkeypatch):
     """Batches in flight on the two stream slots of an engine each carry fragments that hit more than
     64 distinct taxa (second kernel pass): every launch has its own 'left for the second pass' word,
