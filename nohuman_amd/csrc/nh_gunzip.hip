@@ -2466,13 +2466,18 @@ public:
         pos_bit_ = (uint64_t)(d - base_) * 8;
         if (const char *e = getenv("NOHUMAN_GZDEV_SEG")) seg_bytes = (size_t)atol(e);
         if (const char *e = getenv("NOHUMAN_GZDEV_STRETCH")) stretch_bytes = (size_t)atol(e);
-        stretch_ = stretch_bytes ? stretch_bytes : (size_t)(32u << 10);
+        // defaults (profiles/r04_inflate_summary.txt, sweep of piece and chunk sizes on 6.4 GB of text): pieces of 512 MiB of gzip in
+        // chunks of 64 KiB -- 8192 chunks a piece, the search's work halves with the chunk count -- take 251 ms of kernels
+        // where pieces of 256 MiB in chunks of 32 KiB took 314; a file too small for such a piece keeps the 32 KiB chunks
+        // (the chip's 5120 wave slots want thousands of chunks a piece)
+        const bool big = size_ >= ((size_t)512u << 20);
+        stretch_ = stretch_bytes ? stretch_bytes : (size_t)((big ? 64u : 32u) << 10);
         if (stretch_ < 1024) stretch_ = 1024;
         stretch_ = (stretch_ + 63) & ~(size_t)63;
-        // A piece is what the chip decodes at once, a wavefront a chunk: 256 MiB of gzip are ~8000 chunks, one and a half
-        // rounds of the 5120 wave slots (smaller pieces leave them empty: profiles/r04_inflate_summary.txt, 32 MiB pieces
-        // take four times as long).  No larger than the file; halved below while the buffers do not fit the HBM.
-        seg_ = seg_bytes ? seg_bytes : (size_t)(256u << 20);
+        // A piece is what the chip decodes at once, a wavefront a chunk: thousands of chunks, more than one round of the 5120
+        // wave slots (smaller pieces leave them empty: profiles/r04_inflate_summary.txt, 32 MiB pieces take four times as
+        // long).  No larger than the file; halved below while the buffers do not fit the HBM.
+        seg_ = seg_bytes ? seg_bytes : (size_t)(512u << 20);
         if (seg_ < stretch_) seg_ = stretch_;
         if (seg_ > size_ + stretch_) seg_ = size_ + stretch_;
         seg_ = (seg_ + stretch_ - 1) / stretch_ * stretch_;
@@ -2971,7 +2976,11 @@ extern "C" int nh_gunzip_device_file(const char *in, const char *out, int32_t de
     nh::DevGunzip gz;
     std::string err;
     if (gz.open(in, device, (size_t)seg_bytes, (size_t)stretch_bytes, err) != 0) return nh::set_error(NH_EIO, "%s", err.c_str());
-    size_t room = (size_t)256u << 20;
+    size_t room = (size_t)3584u << 20;
+    {
+        struct stat st;
+        if (stat(in, &st) == 0 && (uint64_t)st.st_size * 16 + ((size_t)64u << 20) < room) room = (size_t)st.st_size * 16 + ((size_t)64u << 20);
+    }
     if (const char *e = getenv("NOHUMAN_GZDEV_ROOM")) room = std::max<size_t>((size_t)atoll(e), (size_t)1u << 20);  // tool knob: text per piece
     uint8_t *d_text = nullptr;
     hipStream_t stream = nullptr;
@@ -3163,7 +3172,9 @@ public:
         if (gz_.open(path, devices[0], 0, 0, err) != 0) return -1;
         for (int g = 1; g < n_devices; g++)
             if (gz_.add_device(devices[g], err) != g) return -1;
-        room_ = (size_t)2560u << 20;
+        // text of a piece: 512 MiB of gzip at FASTQ's 4-5 : 1 and the partial batch carried in front of it (the record index
+        // addresses a piece's text with 32 bits: below 4 GiB)
+        room_ = (size_t)3584u << 20;
         struct stat st;
         if (stat(path, &st) == 0 && (uint64_t)st.st_size * 16 + ((size_t)64u << 20) < room_) room_ = (size_t)st.st_size * 16 + ((size_t)64u << 20);
         if (const char *e = getenv("NOHUMAN_GZDEV_ROOM")) room_ = std::max<size_t>((size_t)atoll(e), (size_t)1u << 20);

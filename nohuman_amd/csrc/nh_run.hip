@@ -38,12 +38,24 @@ namespace nh {
 // Output file written with writev(): a batch's output is a list of spans, either slices of the raw
 // input text (kept records that need no reformatting -- the common case, no copy) or pieces of a
 // scratch buffer (reformatted records, kraken output lines).
-struct OutFile {
-    int fd = -1;
-    std::string path;
+// What one batch puts into one output file: slices of the batch's raw text (the normal case: nothing is copied) and of
+// a scratch string (reformatted records), in output order
+struct Spans {
     std::vector<struct iovec> iov;
     std::vector<char> is_scratch;  // per span: iov_base is an offset into scratch
     std::string scratch;
+    void clear() {
+        iov.clear();
+        is_scratch.clear();
+        scratch.clear();
+    }
+};
+
+struct OutFile {
+    int fd = -1;
+    std::string path;
+    Spans sp;  // the batch being formatted (the writer moves it into the flusher's job and gets a cleared one back)
+    std::string &scratch = sp.scratch;
     std::unique_ptr<StreamEncoder> enc;  // set: the spans go through a streaming encoder
     int open(const char *p, int codec = NH_CODEC_NONE, unsigned codec_threads = 1, int device = -1) {
         path = p;
@@ -57,27 +69,31 @@ struct OutFile {
     }
     void add_raw(const char *p, size_t n) {
         if (!n) return;
-        if (!iov.empty() && !is_scratch.back() && (const char *)iov.back().iov_base + iov.back().iov_len == p) {
+        std::vector<struct iovec> &iov = sp.iov;
+        if (!iov.empty() && !sp.is_scratch.back() && (const char *)iov.back().iov_base + iov.back().iov_len == p) {
             iov.back().iov_len += n;
             return;
         }
         iov.push_back({(void *)p, n});
-        is_scratch.push_back(0);
+        sp.is_scratch.push_back(0);
     }
     // the caller appended [from, scratch.size()) to scratch
     void add_scratch(size_t from) {
-        const size_t n = scratch.size() - from;
+        const size_t n = sp.scratch.size() - from;
         if (!n) return;
-        if (!iov.empty() && is_scratch.back() && (size_t)iov.back().iov_base + iov.back().iov_len == from) {
+        std::vector<struct iovec> &iov = sp.iov;
+        if (!iov.empty() && sp.is_scratch.back() && (size_t)iov.back().iov_base + iov.back().iov_len == from) {
             iov.back().iov_len += n;
             return;
         }
         iov.push_back({(void *)from, n});
-        is_scratch.push_back(1);
+        sp.is_scratch.push_back(1);
     }
-    int flush() {  // write all spans, then forget them
+    int flush() { return flush(sp); }
+    int flush(Spans &x) {  // write all spans of x, then forget them
+        std::vector<struct iovec> &iov = x.iov;
         for (size_t i = 0; i < iov.size(); i++)
-            if (is_scratch[i]) iov[i].iov_base = (void *)(scratch.data() + (size_t)iov[i].iov_base);
+            if (x.is_scratch[i]) iov[i].iov_base = (void *)(x.scratch.data() + (size_t)iov[i].iov_base);
         size_t i = 0;
         int rc = NH_OK;
         if (enc) {
@@ -101,9 +117,7 @@ struct OutFile {
                 iov[i].iov_len -= left;
             }
         }
-        iov.clear();
-        is_scratch.clear();
-        scratch.clear();
+        x.clear();
         return rc;
     }
     int close() {
@@ -775,8 +789,9 @@ int run_engines(const std::vector<Engine *> &engines, const nh_run_args *a, nh_s
         }
     }
     // stream slots a device: two keep the classifier busy; a third lets the copy of a batch's text back to the host (batches
-    // born on the GPU, outputs written by the host) run while the writer is still busy with the batch before
-    int NS = 3;
+    // born on the GPU, outputs written by the host) run while the writer is still busy with the batch before; a fourth is
+    // held by the batch the flusher is writing
+    int NS = 4;
     if (const char *env = getenv("NOHUMAN_SLOTS")) NS = std::max(1, std::min(8, atoi(env)));
     std::vector<Slot> slots((size_t)NS * G);
     for (int i = 0; i < NS * G; i++) {
@@ -836,14 +851,25 @@ int run_engines(const std::vector<Engine *> &engines, const nh_run_args *a, nh_s
     std::thread t2;
     if (rs.paired) t2 = std::thread(reader_main, a->in2, &q2, &rs, &pool2, &clk, 1, BATCH_FRAGS, BATCH_TEXT, gz_threads, devs2);
 
-    // writer: consumes batches in order; each arrives after its stream was synchronised.  The second
-    // mate file is written by a helper so that both files are written at the same time.
+    // writer: consumes batches in order; each arrives after its stream was synchronised.  Two stages: the WRITER
+    // waits for the batch's stream, decides and formats (span lists, nothing is copied); the FLUSHER writes the spans
+    // of the batch before while the writer is on the next one -- a helper takes the second mate file, so that both files
+    // are written at the same time -- and only then gives the batch's buffers and its stream slot back.  (One thread did
+    // both in round 3: 35.5 GB of kept text leave through writev() at 12 GB/s, 2.9 s, and the 1.3 s of waiting and
+    // formatting came on top, profiles/r04_e2e.txt.)
+    struct FlushJob {
+        Batch b;
+        Spans s1, s2, sk;
+        bool valid = false;  // (false: the run had failed when the batch arrived -- only its buffers go back)
+    };
     BoundedQueue<Batch> wq((size_t)(NS * G));
+    BoundedQueue<std::unique_ptr<FlushJob>> fq(1);
     std::mutex slot_mu;
     std::condition_variable slot_cv;
     std::mutex w2_mu;
     std::condition_variable w2_cv;
     int w2_state = 0;  // 0 idle, 1 flush requested, 2 done, -1 quit
+    Spans *w2_spans = nullptr;
     int w2_rc = NH_OK;
     std::string w2_err;
     std::thread tw2;
@@ -853,8 +879,9 @@ int run_engines(const std::vector<Engine *> &engines, const nh_run_args *a, nh_s
                 std::unique_lock<std::mutex> lk(w2_mu);
                 w2_cv.wait(lk, [&] { return w2_state == 1 || w2_state == -1; });
                 if (w2_state == -1) return;
+                Spans *sp2 = w2_spans;
                 lk.unlock();
-                int frc = o2.flush();
+                int frc = o2.flush(*sp2);
                 lk.lock();
                 w2_rc = frc;
                 if (frc) w2_err = g_last_error;
@@ -862,6 +889,46 @@ int run_engines(const std::vector<Engine *> &engines, const nh_run_args *a, nh_s
                 w2_cv.notify_all();
             }
         });
+    std::thread tf([&] {
+        std::unique_ptr<FlushJob> j;
+        while (fq.pop(j)) {
+            Slot &s = slots[j->b.slot];
+            if (j->valid && !rs.failed()) {
+                uint64_t c3 = StageClock::now();
+                (void)hipSetDevice(s.e->device);
+                const Batch &b = j->b;
+                const size_t base2w = (b.h1->text.size() + 8 + 255) & ~(size_t)255;
+                // the batch's raw text is still in the slot's device buffer: an encoder on that GPU takes
+                // the kept records from there instead of a second trip over PCIe
+                if (o1.enc) o1.enc->map_device(b.h1->text.data(), b.h1->text.size(), s.d_text, s.e->device, b.h1->host_text_valid);
+                if (rs.paired && o2.enc)
+                    o2.enc->map_device(b.h2->text.data(), b.h2->text.size(), (const char *)s.d_text + base2w, s.e->device, b.h2->host_text_valid);
+                if (rs.paired) {
+                    std::lock_guard<std::mutex> lk(w2_mu);
+                    w2_spans = &j->s2;
+                    w2_state = 1;
+                    w2_cv.notify_all();
+                }
+                int wrc = o1.flush(j->s1);
+                if (!wrc && rs.want_k) wrc = ok.flush(j->sk);
+                if (rs.paired) {
+                    std::unique_lock<std::mutex> lk(w2_mu);
+                    w2_cv.wait(lk, [&] { return w2_state == 2; });
+                    w2_state = 0;
+                    if (!wrc && w2_rc) wrc = set_error(w2_rc, "%s", w2_err.c_str());
+                }
+                clk.ns[ST_WWRITE] += StageClock::now() - c3;
+                if (wrc) rs.fail(wrc, g_last_error);
+            }
+            pool1.put(std::move(j->b.h1));
+            pool2.put(std::move(j->b.h2));
+            {
+                std::lock_guard<std::mutex> lk(slot_mu);
+                s.busy = false;
+            }
+            slot_cv.notify_all();
+        }
+    });
     std::thread tw([&] {
         Batch b;
         for (;;) {
@@ -870,6 +937,7 @@ int run_engines(const std::vector<Engine *> &engines, const nh_run_args *a, nh_s
             uint64_t c1 = StageClock::now();
             clk.ns[ST_WPOP] += c1 - c0;
             Slot &s = slots[b.slot];
+            std::unique_ptr<FlushJob> j(new FlushJob());
             if (!rs.failed()) {
                 (void)hipSetDevice(s.e->device);
                 hipError_t he = hipStreamSynchronize(s.stream);
@@ -901,41 +969,24 @@ int run_engines(const std::vector<Engine *> &engines, const nh_run_args *a, nh_s
                             hb.host_text_valid = wrc == NH_OK;
                         }
                     }
-                    // the batch's raw text is still in the slot's device buffer: an encoder on that GPU takes
-                    // the kept records from there instead of a second trip over PCIe
-                    if (o1.enc) o1.enc->map_device(b.h1->text.data(), b.h1->text.size(), s.d_text, s.e->device, b.h1->host_text_valid);
-                    if (rs.paired && o2.enc)
-                        o2.enc->map_device(b.h2->text.data(), b.h2->text.size(), (const char *)s.d_text + base2w, s.e->device, b.h2->host_text_valid);
                 }
                 if (!wrc) {
                     format_batch(&rs, b, s, o1, o2, ok);
-                    uint64_t c3 = StageClock::now();
-                    clk.ns[ST_WFORMAT] += c3 - c2;
-                    if (rs.paired) {
-                        std::lock_guard<std::mutex> lk(w2_mu);
-                        w2_state = 1;
-                        w2_cv.notify_all();
-                    }
-                    wrc = o1.flush();
-                    if (!wrc && rs.want_k) wrc = ok.flush();
-                    if (rs.paired) {
-                        std::unique_lock<std::mutex> lk(w2_mu);
-                        w2_cv.wait(lk, [&] { return w2_state == 2; });
-                        w2_state = 0;
-                        if (!wrc && w2_rc) wrc = set_error(w2_rc, "%s", w2_err.c_str());
-                    }
-                    clk.ns[ST_WWRITE] += StageClock::now() - c3;
+                    clk.ns[ST_WFORMAT] += StageClock::now() - c2;
+                    j->s1 = std::move(o1.sp);
+                    j->s2 = std::move(o2.sp);
+                    j->sk = std::move(ok.sp);
+                    o1.sp.clear();
+                    o2.sp.clear();
+                    ok.sp.clear();
+                    j->valid = true;
                 }
                 if (wrc) rs.fail(wrc, g_last_error);
             }
-            pool1.put(std::move(b.h1));
-            pool2.put(std::move(b.h2));
-            {
-                std::lock_guard<std::mutex> lk(slot_mu);
-                s.busy = false;
-            }
-            slot_cv.notify_all();
+            j->b = std::move(b);
+            fq.push(std::move(j));
         }
+        fq.close();
     });
 
     // main: pair halves, stage, launch
@@ -1112,6 +1163,7 @@ int run_engines(const std::vector<Engine *> &engines, const nh_run_args *a, nh_s
     t1.join();
     if (t2.joinable()) t2.join();
     tw.join();
+    tf.join();
     if (tw2.joinable()) {
         {
             std::lock_guard<std::mutex> lk(w2_mu);

@@ -60,6 +60,9 @@ try:
         runs = ((256 << 20, 32768, 0, 3 << 30), (32 << 20, 32768, 0, 3 << 30))
     if os.environ.get("GZDEV_BENCH_QUICK") == "2":
         runs = ((0, 0, 0, 3 << 30),)
+    if os.environ.get("GZDEV_BENCH_QUICK") == "3":  # piece and chunk sizes
+        runs = ((256 << 20, 32768, 0, 6 << 30), (160 << 20, 32768, 0, 6 << 30), (320 << 20, 32768, 0, 6 << 30), (512 << 20, 32768, 0, 6 << 30),
+                (512 << 20, 65536, 0, 6 << 30), (640 << 20, 65536, 0, 6 << 30), (384 << 20, 49152, 0, 6 << 30))
     for seg, stretch, v1, room in runs:
         env = dict(os.environ, NOHUMAN_TRACE="1", NOHUMAN_GZDEV_ROOM=str(room))
         if v1:
