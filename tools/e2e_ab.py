@@ -1,0 +1,32 @@
+"""Same-box A / B of nh_run on a prepared gzip pair: every setting (a string of env assignments) is run `reps` times, interleaved.
+    python tools/e2e_ab.py r_1.fq.gz r_2.fq.gz plain|gzip|none reps "A=1 B=2" "A=0" ...   ("" = defaults)"""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from nohuman_amd import Engine
+f1, f2, what, reps = sys.argv[1], sys.argv[2], sys.argv[3], int(sys.argv[4])
+settings = sys.argv[5:] or [""]
+cap = 134_217_689
+eng = Engine.synthetic(cap, int(cap * 0.7), depth=30, seed=7)
+d = os.path.dirname(f1)
+kw = {"plain": {}, "gzip": dict(out_codec=2, codec_threads=8), "none": dict(keep_human=True)}[what]
+res = {s: [] for s in settings}
+for rep in range(reps + 1):
+    for s in settings:
+        keys = []
+        for kv in s.split():
+            k, v = kv.split("=", 1)
+            os.environ[k] = v
+            keys.append(k)
+        for o in ("o1", "o2"):
+            if os.path.exists(os.path.join(d, o)):
+                os.remove(os.path.join(d, o))
+        t = time.perf_counter()
+        st = eng.run(f1, os.path.join(d, "o1"), in2=f2, out2=os.path.join(d, "o2"), threads=16, **kw)
+        dt = time.perf_counter() - t
+        for k in keys:
+            os.environ.pop(k, None)
+        if rep:  # (the first round warms buffers and page cache)
+            res[s].append(dt)
+for s in settings:
+    v = sorted(res[s])
+    print("%-40s %s  median %.3f s = %.1f Mreads/s" % (s or "(defaults)", " ".join("%.3f" % x for x in res[s]), v[len(v) // 2], 2 * st.total_sequences / v[len(v) // 2] / 1e6), flush=True)
