@@ -2007,7 +2007,7 @@ __global__ void k_test_mark_end(ChunkDesc *desc, uint32_t c) { desc[c].flags |= 
 
 // After the decode: which chunks count, do they chain, where does the text of each begin
 __global__ __launch_bounds__(1024) void k_finish(ChunkDesc *desc, uint32_t n, uint64_t *toff, SegResult *res) {
-    __shared__ uint32_t s_end, s_broken, s_bad, s_members;
+    __shared__ uint32_t s_end, s_broken, s_bad, s_members, s_cnt;
     __shared__ unsigned long long s_scan[1024];
     const uint32_t t = threadIdx.x;
     if (t == 0) {
@@ -2015,6 +2015,7 @@ __global__ __launch_bounds__(1024) void k_finish(ChunkDesc *desc, uint32_t n, ui
         s_broken = NOIDX;
         s_bad = NOIDX;
         s_members = 0;
+        s_cnt = 0;
     }
     __syncthreads();
     // the chunk the stream ended in, or the last one
@@ -2051,10 +2052,15 @@ __global__ __launch_bounds__(1024) void k_finish(ChunkDesc *desc, uint32_t n, ui
     // exclusive prefix sum of the lengths: per thread a run of chunks, then a scan over the threads
     const uint32_t per = (n + 1023) / 1024;
     unsigned long long sum = 0;
+    uint32_t mine = 0;
     for (uint32_t i = 0; i < per; i++) {
         const uint32_t c = t * per + i;
-        if (c < n && desc[c].bit_start != NONE) sum += desc[c].out_len;
+        if (c < n && desc[c].bit_start != NONE) {
+            sum += desc[c].out_len;
+            mine++;
+        }
     }
+    if (mine) atomicAdd(&s_cnt, mine);
     s_scan[t] = sum;
     __syncthreads();
     for (uint32_t o = 1; o < 1024; o <<= 1) {
@@ -2073,9 +2079,7 @@ __global__ __launch_bounds__(1024) void k_finish(ChunkDesc *desc, uint32_t n, ui
     }
     if (t == 1023) res->total = s_scan[1023];
     if (t == 0) {
-        uint32_t cnt = 0;
-        for (uint32_t c = 0; c < n; c++) cnt += desc[c].bit_start != NONE;
-        res->n_chunks = cnt;
+        res->n_chunks = s_cnt;  // (counted by all threads above: one thread walking 8192 descriptors was a millisecond a piece)
         res->end_chunk = last;
         res->end_bit = last != NOIDX ? desc[last].bit_end : 0;
         res->broken = s_broken;
@@ -2271,6 +2275,7 @@ __device__ __forceinline__ uint32_t x8n_modp(uint64_t n) {  // x^(8n) mod P
 __global__ __launch_bounds__(256) void k_crc(ChunkDesc *d, const uint64_t *toff, const uint8_t *text) {
     __shared__ uint32_t T[4][256];
     __shared__ uint32_t part[256];
+    __shared__ uint32_t xl[9];  // x^(8 L 2^j) mod P: what a CRC moves by when 2^j slices follow it
     const uint32_t c = blockIdx.x, t = threadIdx.x;
     if (d[c].bit_start == NONE) return;
     {
@@ -2284,44 +2289,56 @@ __global__ __launch_bounds__(256) void k_crc(ChunkDesc *d, const uint64_t *toff,
         T[k][t] = (v >> 8) ^ T[0][v & 0xFF];
     }
     __syncthreads();
-    if (d[c].bit_start == NONE) return;
     const uint32_t nm = d[c].n_members, total = d[c].out_len;
     const uint8_t *base = text + toff[c];
     uint32_t a = 0;
     for (uint32_t p = 0; p <= nm; p++) {
         const uint32_t b = p < nm ? d[c].m_off[p] : total;
         const uint32_t len = b - a;
-        // slices of L bytes, a thread each (L a multiple of 4); standard CRC-32 per slice
+        // slices of L bytes, a thread each (L a multiple of 16); standard CRC-32 per slice, sixteen bytes a load (a lane's
+        // slice is a kilobyte away from its neighbour's: every load instruction is 64 separate requests, so make them few)
         uint32_t L = (len + 255) / 256;
-        L = (L + 3) & ~3u;
-        if (L == 0) L = 4;
+        L = (L + 15) & ~15u;
+        if (L == 0) L = 16;
         const uint32_t s0 = t * L < len ? t * L : len, s1 = (t + 1) * L < len ? (t + 1) * L : len;
         uint32_t crc = 0xFFFFFFFFu;
         const uint8_t *q = base + a + s0;
         uint32_t k = s1 - s0;
-        while (k >= 4) {
-            struct __attribute__((packed)) U4 {
-                uint32_t v;
+        while (k >= 16) {
+            struct __attribute__((packed)) U16 {
+                uint32_t v[4];
             };
-            const uint32_t x = crc ^ ((const U4 *)q)->v;
-            crc = T[3][x & 0xFF] ^ T[2][(x >> 8) & 0xFF] ^ T[1][(x >> 16) & 0xFF] ^ T[0][x >> 24];
-            q += 4;
-            k -= 4;
+            const U16 w = *(const U16 *)q;
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                const uint32_t x = crc ^ w.v[i];
+                crc = T[3][x & 0xFF] ^ T[2][(x >> 8) & 0xFF] ^ T[1][(x >> 16) & 0xFF] ^ T[0][x >> 24];
+            }
+            q += 16;
+            k -= 16;
         }
         while (k--) crc = (crc >> 8) ^ T[0][(crc ^ *q++) & 0xFF];
         part[t] = ~crc;
-        __syncthreads();
         if (t == 0) {
-            // crc(A || B) = crc(A) * x^(8|B|) + crc(B): the slices from left to right (all of length L but the last)
-            const uint32_t nsl = len ? (len + L - 1) / L : 0;
-            uint32_t acc = 0;
-            if (nsl) {
-                const uint32_t xl = x8n_modp(L), xlast = x8n_modp(len - (nsl - 1) * L);
-                acc = part[0];
-                for (uint32_t i = 1; i < nsl; i++) acc = multmodp(i + 1 == nsl ? xlast : xl, acc) ^ part[i];
+            uint32_t v = x8n_modp(L);
+            for (int j = 0; j < 9; j++) {
+                xl[j] = v;
+                v = multmodp(v, v);
             }
-            d[c].piece_crc[p] = acc;
         }
+        __syncthreads();
+        // crc(A || B) = crc(A) * x^(8|B|) + crc(B), as a tree over the slices: at level j thread i (a multiple of 2^(j+1)) takes
+        // in the 2^j slices to its right (all of length L but the ragged end of the piece, whose thread computes its own power)
+        for (int j = 0; j < 8; j++) {
+            const uint32_t w = 1u << j;
+            if ((t & (2 * w - 1)) == 0) {
+                const uint64_t r0 = (uint64_t)(t + w) * L, r1 = (uint64_t)(t + 2 * w) * L;
+                const uint32_t rb = (uint32_t)((r1 < len ? r1 : len) - (r0 < len ? r0 : len));  // bytes of the right block
+                if (rb) part[t] = multmodp(rb == w * L ? xl[j] : x8n_modp(rb), part[t]) ^ part[t + w];
+            }
+            __syncthreads();
+        }
+        if (t == 0) d[c].piece_crc[p] = part[0];
         __syncthreads();
         a = b;
     }
