@@ -57,6 +57,17 @@ public:
     int add_device(int device, std::string &err);
     long next_on(int set, void *d_dst, size_t room, hipStream_t stream);
     uint64_t pieces_of(int set) const;
+    // Pieces decoded AHEAD of the stream (what makes the reader scale with the devices): the file is a grid of cells of one
+    // piece's size; decode_ahead(set, cell) runs the first phase of a cell's piece -- search, decode to symbols, chain check:
+    // everything that needs neither the window nor the stream's state -- on that set, from any thread, while the stream is
+    // elsewhere.  take(set, use_ahead) is the stream's next piece on that set, in stream order: the decoded cell if it starts
+    // exactly where the stream stands (windows, text, CRCs are done now), else a piece decoded in order from the stream's
+    // position to the end of its cell.  ahead_ok(): the reader's shape allows it.
+    bool ahead_ok() const;
+    uint64_t cell_of_position() const;
+    uint64_t cells() const;
+    void decode_ahead(int set, uint64_t cell, hipStream_t stream);
+    long take(int set, bool use_ahead, void *d_dst, size_t room, hipStream_t stream);
     bool ended() const;
     const std::string &error() const;
     const DevGunzipStats &stats() const;

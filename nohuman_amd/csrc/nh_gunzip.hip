@@ -20,6 +20,7 @@
 #include <algorithm>
 #include <chrono>
 #include <memory>
+#include <mutex>
 
 #include "nh_inflate.h"
 #include "nh_internal.h"
@@ -91,6 +92,7 @@ struct SegResult {  // k_finish
     uint32_t bad_status;
     uint32_t stream_end;
     uint32_t members, pad;
+    uint64_t first_start;  // bit position of the first chunk (a speculative piece: the first block start the search found)
 };
 
 struct Lds {
@@ -423,7 +425,9 @@ __global__ __launch_bounds__(64) void k_search(const uint32_t *in, uint64_t vali
 __global__ __launch_bounds__(1024) void k_plan(const uint64_t *start, uint32_t n, uint64_t end_bit, uint32_t slot_syms, ChunkDesc *desc) {
     for (uint32_t c = threadIdx.x; c < n; c += 1024) {
         ChunkDesc &d = desc[c];
-        const uint64_t s = start[c];
+        // (a piece may end inside its last stretch -- one that is cut at a boundary of the piece grid: what the search found
+        //  behind the end belongs to the next piece)
+        const uint64_t s = c == 0 || start[c] < end_bit ? start[c] : NONE;
         d.bit_start = s;
         if (s == NONE) {
             d.stop_bit = 0;
@@ -431,7 +435,7 @@ __global__ __launch_bounds__(1024) void k_plan(const uint64_t *start, uint32_t n
             continue;
         }
         uint32_t nx = c + 1;
-        while (nx < n && start[nx] == NONE) nx++;
+        while (nx < n && (start[nx] == NONE || start[nx] >= end_bit)) nx++;
         d.stop_bit = nx < n ? start[nx] : end_bit;
         const uint64_t cap = (uint64_t)(nx - c) * slot_syms;
         d.cap = cap > 0xFFFFF000ull ? 0xFFFFF000u : (uint32_t)cap;
@@ -1384,7 +1388,11 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(5, 8))) void
     };
     while (status == 0) {
         uint64_t bitpos = br.bitpos();
-        if (bitpos >= stop_bit) break;  // a block boundary at or behind the stop position
+        // A block boundary at or behind the stop position -- and what follows is a block the SEARCH can find (not final, dynamic
+        // Huffman): the empty stored block of a flush point (pigz, gzp: one every 128-512 KiB of text), a fixed or a final
+        // block are decoded with this chunk.  So a piece ends exactly where the piece decoded ahead of the stream for the
+        // next cell of the grid begins (every eighth was refused on gzp's output before this).
+        if (bitpos >= stop_bit && (bitpos + 3 > valid_bits || (bits_at(bytes, bitpos) & 7u) == 4u)) break;
         if (bitpos + 3 > valid_bits) {
             status = ST_INPUT;
             break;
@@ -1945,12 +1953,13 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(5, 8))) void
     const uint32_t tbl = (uint32_t)threadIdx.x * CLROW;
     const int lane = (int)threadIdx.x;
     const uint32_t c = blockIdx.x;
-    if (c == 0) {
+    // (first_bit == NONE: a piece decoded ahead of the stream -- no known start, stretch 0 is searched like the others)
+    if (c == 0 && first_bit != NONE) {
         if (lane == 0) start[0] = first_bit;
         return;
     }
     uint64_t from = (uint64_t)c * stretch_bits, to = from + stretch_bits;
-    if (from <= first_bit) from = first_bit + 1;
+    if (first_bit != NONE && from <= first_bit) from = first_bit + 1;
     if (to + 160 > valid_bits) to = valid_bits > 160 ? valid_bits - 160 : 0;
     const uint8_t *bytes = (const uint8_t *)in;
     uint64_t found = NONE;
@@ -2087,6 +2096,9 @@ __global__ __launch_bounds__(1024) void k_finish(ChunkDesc *desc, uint32_t n, ui
         res->bad_status = s_bad != NOIDX ? desc[s_bad].status : 0;
         res->stream_end = stream_end ? 1u : 0u;
         res->members = s_members;
+        uint64_t fs = NONE;
+        for (uint32_t c = 0; c < n && fs == NONE; c++) fs = desc[c].bit_start;  // (the first stretches' chunks: a handful of reads)
+        res->first_start = fs;
     }
 }
 
@@ -2425,6 +2437,20 @@ static void cache_free(int device, size_t bytes, void *p, bool host) {
 }
 
 class DevGunzipImpl {
+    friend class DevGunzip;
+    // what one piece is decoded from, and what its first phase found (phase_a / phase_b below)
+    struct PieceJob {
+        uint64_t a_byte = 0;        // the piece's buffer starts here in the file
+        uint64_t first_bit = NONE;  // known start (bits from a_byte), or NONE
+        uint32_t n = 0;             // stretches
+        uint64_t limit_bits = 0;    // the piece ends at the first block boundary at or behind this bit (0: behind its last stretch)
+        // phase A's results
+        uint32_t n_str = 0, redo = 0;
+        uint64_t valid_bits = 0, end_bit = 0;
+        bool at_eof = false, valid = false;
+        SegResult r{};
+    };
+
     // The buffers of one device.  A reader that spreads its pieces over several devices (DevFastqReader with the devices
     // of a run: piece i on device i mod G) has one set per device; the stream's state -- position, CRC, the window behind
     // the last piece -- goes from piece to piece, the window by a 32 KiB copy from the set that decoded the piece before.
@@ -2439,6 +2465,8 @@ class DevGunzipImpl {
         SegResult *d_res_ = nullptr, *h_res_ = nullptr;
         hipEvent_t ev_[7] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
         uint64_t pieces = 0;
+        PieceJob spec;           // a cell of the piece grid decoded ahead of the stream on this set (phase A only)
+        uint64_t spec_cell = 0;
     };
     std::vector<std::unique_ptr<DevSet>> sets_;
     DevSet *s_ = nullptr;  // the set the current piece is decoded with
@@ -2481,6 +2509,7 @@ public:
             return -1;
         }
         pos_bit_ = (uint64_t)(d - base_) * 8;
+        grid0_ = (uint64_t)(d - base_) / ALIGN * ALIGN;
         if (const char *e = getenv("NOHUMAN_GZDEV_SEG")) seg_bytes = (size_t)atol(e);
         if (const char *e = getenv("NOHUMAN_GZDEV_STRETCH")) stretch_bytes = (size_t)atol(e);
         // defaults (profiles/r04_inflate_summary.txt, sweep of piece and chunk sizes on 6.4 GB of text): pieces of 512 MiB of gzip in
@@ -2531,6 +2560,7 @@ public:
             return -1;
         }
         if (const char *e = getenv("NOHUMAN_GZDEV_FAKE_START")) fake_start_ = atol(e);  // test knob: a false positive of the search
+        if (const char *e = getenv("NOHUMAN_GZDEV_FAKE_SPEC")) fake_spec_ = atol(e);
         open_s_ = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_open).count();
         return 0;
     }
@@ -2629,6 +2659,10 @@ public:
                     (double)prof_[4] / st_.chunks, (double)prof_[5] / st_.chunks, (double)prof_[6] / st_.chunks, (double)prof_[7] / st_.chunks,
                     (double)prof_[8] / st_.chunks, (double)prof_[9] / st_.chunks, (double)prof_[10] / st_.chunks, (double)prof_[11] / st_.chunks);
 #endif
+        if (trace_ && (spec_used_ || spec_refused_))
+            fprintf(stderr, "[nohuman trace] gzip reader, %s: %llu pieces decoded ahead of the stream taken, %llu refused (decoded again in order)\n",
+                    path_.c_str(), (unsigned long long)spec_used_, (unsigned long long)spec_refused_);
+        spec_used_ = spec_refused_ = 0;
         if (trace_ && sets_.size() > 1) {
             std::string per;
             for (auto &d : sets_) per += " " + std::to_string(d->device_) + ":" + std::to_string((unsigned long long)d->pieces);
@@ -2702,8 +2736,203 @@ private:
         return true;
     }
 
-    // one piece of the stream: up to n_slots_ stretches from the position the stream goes on at
-    long piece(uint8_t *d_dst, size_t room, hipStream_t stream) {
+    // ---- a piece in two phases.  A: upload, block search, decode to symbols, chain check (with the re-decodes it asks for) --
+    // everything that needs neither the window nor the stream's state, so a piece AHEAD of the stream can run it (first_bit
+    // NONE: no known start; the reader over several devices decodes the pieces of the grid concurrently this way).  B:
+    // windows, text, CRCs, the window behind the piece, the member bookkeeping -- in stream order.
+    long phase_a(DevSet &d, PieceJob &j, hipStream_t stream, bool spec) {
+        auto bad = [&](const std::string &m) -> long { return spec ? -1 : fail(m); };
+#define GZA_TRY(x)                                                                      \
+    do {                                                                                \
+        hipError_t e_ = (x);                                                            \
+        if (e_ != hipSuccess) return bad(std::string(#x) + ": " + hipGetErrorString(e_)); \
+    } while (0)
+        j.valid = false;
+        const size_t want = (size_t)j.n * stretch_ + look_;
+        const size_t avail = (size_t)std::min<uint64_t>(want, size_ - j.a_byte);
+        j.at_eof = j.a_byte + avail == size_;
+        const uint32_t n_str = (uint32_t)std::min<uint64_t>(j.n, (avail + stretch_ - 1) / stretch_);
+        j.n_str = n_str;
+        j.valid_bits = 8ull * avail;
+        const uint64_t valid_bits = j.valid_bits;
+        // the bytes: page cache -> page-locked staging -> device
+        const auto c0 = std::chrono::steady_clock::now();
+        memcpy(d.h_in_, base_ + j.a_byte, avail);
+        memset(d.h_in_ + avail, 0, 1024);
+        const double copy_s = std::chrono::duration<double>(std::chrono::steady_clock::now() - c0).count();
+        GZA_TRY(hipMemcpyAsync(d.d_in_, d.h_in_, avail + 1024, hipMemcpyHostToDevice, stream));
+        uint64_t end_bit = std::min<uint64_t>((uint64_t)n_str * stretch_ * 8, valid_bits);
+        if (j.limit_bits && j.limit_bits < end_bit) end_bit = j.limit_bits;
+        j.end_bit = end_bit;
+        if (trace_) (void)hipEventRecord(d.ev_[0], stream);
+        if (v1_)
+            hipLaunchKernelGGL(k_search, dim3(n_str), dim3(64), sizeof(Lds), stream, (const uint32_t *)d.d_in_, valid_bits, (uint64_t)stretch_ * 8,
+                               j.first_bit, d.d_start_);
+        else if (v2_)
+            hipLaunchKernelGGL(k_search2, dim3(n_str), dim3(64), sizeof(Lds), stream, (const uint32_t *)d.d_in_, valid_bits,
+                               (uint64_t)stretch_ * 8, j.first_bit, d.d_start_);
+        else
+            hipLaunchKernelGGL(k_search3, dim3(n_str), dim3(64), SEARCH3_LDS, stream, (const uint32_t *)d.d_in_, valid_bits,
+                               (uint64_t)stretch_ * 8, j.first_bit, d.d_start_);
+        long fake_end = -1;
+        if (!spec && fake_start_ > 0 && (uint32_t)fake_start_ < n_str) {  // test knob: pretend the search found a start that is none
+            const uint64_t bogus = (uint64_t)fake_start_ * stretch_ * 8 + 13;
+            GZA_TRY(hipMemcpyAsync(d.d_start_ + fake_start_, &bogus, 8, hipMemcpyHostToDevice, stream));
+            GZA_TRY(hipStreamSynchronize(stream));
+            if (getenv("NOHUMAN_GZDEV_FAKE_END")) fake_end = fake_start_;  // ... whose garbage even looks like the end of the stream
+            fake_start_ = -1;
+        }
+        if (spec && fake_spec_ > 0) {  // test knob: the first start of a piece decoded ahead is no block start (the piece is refused)
+            if (--fake_spec_ == 0) {
+                const uint64_t bogus = 13;
+                GZA_TRY(hipMemcpyAsync(d.d_start_, &bogus, 8, hipMemcpyHostToDevice, stream));
+                GZA_TRY(hipStreamSynchronize(stream));
+            }
+        }
+        hipLaunchKernelGGL(k_plan, dim3(1), dim3(1024), 0, stream, (const uint64_t *)d.d_start_, n_str, end_bit, slot_syms_, d.d_desc_);
+        if (trace_) (void)hipEventRecord(d.ev_[1], stream);
+        hipLaunchKernelGGL(inflate_kernel(), dim3(n_str), dim3(64), inflate_lds(), stream, (const uint32_t *)d.d_in_, valid_bits,
+                           j.at_eof ? 1u : 0u, d.d_desc_, d.d_sym_, slot_syms_, NOIDX);
+        if (fake_end >= 0) hipLaunchKernelGGL(k_test_mark_end, dim3(1), dim3(1), 0, stream, d.d_desc_, (uint32_t)fake_end);
+        if (trace_) (void)hipEventRecord(d.ev_[2], stream);
+        uint32_t redo = 0;
+        double wait_s = 0;
+        for (;;) {
+            hipLaunchKernelGGL(k_finish, dim3(1), dim3(1024), 0, stream, d.d_desc_, n_str, d.d_toff_, d.d_res_);
+            GZA_TRY(hipMemcpyAsync(d.h_res_, d.d_res_, sizeof(SegResult), hipMemcpyDeviceToHost, stream));
+            const auto w0 = std::chrono::steady_clock::now();
+            GZA_TRY(hipStreamSynchronize(stream));
+            wait_s += std::chrono::duration<double>(std::chrono::steady_clock::now() - w0).count();
+            if (d.h_res_->bad_chunk != NOIDX && (d.h_res_->broken == NOIDX || d.h_res_->bad_chunk < d.h_res_->broken)) break;
+            if (d.h_res_->broken == NOIDX) break;
+            // A chunk does not start where its predecessor ended: what the search found there was no block start.
+            // It is struck from the plan and its predecessor decoded again, now to the start after it (the host
+            // reader's "searching on"; costs time, never correctness).
+            const uint32_t badc = d.h_res_->broken;
+            GZA_TRY(hipMemcpyAsync(d.d_start_ + badc, &NONE, 8, hipMemcpyHostToDevice, stream));
+            hipLaunchKernelGGL(k_plan, dim3(1), dim3(1024), 0, stream, (const uint64_t *)d.d_start_, n_str, end_bit, slot_syms_, d.d_desc_);
+            GZA_TRY(hipMemcpyAsync(d.h_desc_, d.d_desc_, (size_t)n_str * sizeof(ChunkDesc), hipMemcpyDeviceToHost, stream));
+            GZA_TRY(hipStreamSynchronize(stream));
+            uint32_t prev = badc;
+            while (prev > 0 && d.h_desc_[--prev].bit_start == NONE) {
+            }
+            if (d.h_desc_[prev].bit_start == NONE) return bad("the chunks of a piece do not chain");  // (the struck one was the piece's first)
+            hipLaunchKernelGGL(inflate_kernel(), dim3(1), dim3(64), inflate_lds(), stream, (const uint32_t *)d.d_in_, valid_bits,
+                               j.at_eof ? 1u : 0u, d.d_desc_, d.d_sym_, slot_syms_, prev);
+            redo++;
+            if (redo > n_str) return bad("the chunks of a piece do not chain");
+        }
+        j.r = *d.h_res_;
+        j.redo = redo;
+        {
+            std::lock_guard<std::mutex> lk(st_mu_);
+            st_.s_host_copy += copy_s;
+            st_.s_wait += wait_s;
+            st_.redecoded += redo;
+            if (trace_) {
+                float ms = 0;
+                if (hipEventElapsedTime(&ms, d.ev_[0], d.ev_[1]) == hipSuccess) st_.ms_search += ms;
+                if (hipEventElapsedTime(&ms, d.ev_[1], d.ev_[2]) == hipSuccess) st_.ms_decode += ms;
+            }
+        }
+        j.valid = true;
+        return 0;
+#undef GZA_TRY
+    }
+
+    // phase B of a piece whose phase A went through (no bad chunk, the text fits the room)
+    long phase_b(DevSet &d, const PieceJob &j, uint8_t *d_dst, size_t room, hipStream_t stream) {
+        const SegResult &r = j.r;
+        const uint32_t n_str = j.n_str;
+        const uint64_t a_byte = j.a_byte;
+        // windows by the prefix scan, text, CRCs, the window behind the piece
+        if (trace_) (void)hipEventRecord(d.ev_[3], stream);
+        const uint32_t gy = 4;
+        if (scan_rounds_) {
+            hipLaunchKernelGGL(k_maps, dim3(n_str, gy), dim3(256), 0, stream, (const ChunkDesc *)d.d_desc_, (const uint16_t *)d.d_sym_, slot_syms_,
+                               d.d_maps_[0]);
+            int cur = 0;
+            for (uint32_t stride = 1; stride < n_str; stride <<= 1) {
+                hipLaunchKernelGGL(k_scan_round, dim3(n_str, gy), dim3(256), 0, stream, (const uint16_t *)d.d_maps_[cur], d.d_maps_[cur ^ 1], n_str,
+                                   stride);
+                cur ^= 1;
+            }
+            hipLaunchKernelGGL(k_windows, dim3(n_str, gy), dim3(256), 0, stream, (const uint16_t *)d.d_maps_[cur], (const uint8_t *)d.d_win_[d.win_],
+                               d.d_windows_);
+        } else {
+            const uint32_t ng = (n_str + SCAN_GROUP - 1) / SCAN_GROUP;
+            hipLaunchKernelGGL(k_scan_local, dim3(ng), dim3(1024), 2 * WSIZE, stream, (const ChunkDesc *)d.d_desc_, (const uint16_t *)d.d_sym_, slot_syms_,
+                               n_str, d.d_maps_[0]);
+            hipLaunchKernelGGL(k_scan_groups, dim3(1), dim3(1024), 2 * WSIZE, stream, (const uint16_t *)d.d_maps_[0], n_str, d.d_maps_[1]);
+            hipLaunchKernelGGL(k_scan_windows, dim3(n_str, gy), dim3(256), 0, stream, (const uint16_t *)d.d_maps_[0], (const uint16_t *)d.d_maps_[1],
+                               (const uint8_t *)d.d_win_[d.win_], d.d_windows_);
+        }
+        if (trace_) (void)hipEventRecord(d.ev_[4], stream);
+        hipLaunchKernelGGL(k_resolve, dim3(n_str, 8), dim3(256), 0, stream, (const ChunkDesc *)d.d_desc_, (const uint16_t *)d.d_sym_, slot_syms_,
+                           (const uint8_t *)d.d_windows_, (const uint64_t *)d.d_toff_, d_dst);
+        if (trace_) (void)hipEventRecord(d.ev_[5], stream);
+        hipLaunchKernelGGL(k_crc, dim3(n_str), dim3(256), 0, stream, d.d_desc_, (const uint64_t *)d.d_toff_, (const uint8_t *)d_dst);
+        hipLaunchKernelGGL(k_carry_window, dim3(1), dim3(1024), 0, stream, (const uint8_t *)d_dst, (uint64_t)room, (const SegResult *)d.d_res_,
+                           (const uint8_t *)d.d_win_[d.win_], d.d_win_[d.win_ ^ 1]);
+        if (trace_) (void)hipEventRecord(d.ev_[6], stream);
+        GZ_TRY(hipMemcpyAsync(d.h_desc_, d.d_desc_, (size_t)n_str * sizeof(ChunkDesc), hipMemcpyDeviceToHost, stream));
+        const auto w0 = std::chrono::steady_clock::now();
+        GZ_TRY(hipStreamSynchronize(stream));
+        {
+            std::lock_guard<std::mutex> lk(st_mu_);
+            st_.s_wait += std::chrono::duration<double>(std::chrono::steady_clock::now() - w0).count();
+            if (trace_) {
+                float ms = 0;
+                if (hipEventElapsedTime(&ms, d.ev_[3], d.ev_[4]) == hipSuccess) st_.ms_scan += ms;
+                if (hipEventElapsedTime(&ms, d.ev_[4], d.ev_[5]) == hipSuccess) st_.ms_resolve += ms;
+                if (hipEventElapsedTime(&ms, d.ev_[5], d.ev_[6]) == hipSuccess) st_.ms_crc += ms;
+            }
+        }
+        d.win_ ^= 1;
+        // members: CRC-32 and ISIZE like gzip checks them
+        for (uint32_t c = 0; c <= r.end_chunk; c++) {
+            const ChunkDesc &cd = d.h_desc_[c];
+            if (cd.bit_start == NONE) continue;
+#ifdef NH_GZ_PROF
+            for (int i = 0; i < 12; i++) prof_[i] += cd.prof[i];
+#endif
+            uint32_t a = 0;
+            for (uint32_t p = 0; p <= cd.n_members; p++) {
+                const uint32_t b = p < cd.n_members ? cd.m_off[p] : cd.out_len;
+                account(cd.piece_crc[p], b - a);
+                if (p < cd.n_members && !member_end(cd.m_crc[p], cd.m_isize[p])) return -1;
+                a = b;
+            }
+        }
+        const uint64_t first_bit = pos_bit_ - 8 * a_byte;
+        if (debug_)
+            fprintf(stderr, "[gzdev] piece %llu: file byte %llu + bit %llu, %u stretches, %u chunks (last %u), %u decoded again, text %llu at %llu, ends at bit %llu%s%s\n",
+                    (unsigned long long)st_.segments, (unsigned long long)a_byte, (unsigned long long)first_bit, n_str, r.n_chunks, r.end_chunk, j.redo,
+                    (unsigned long long)r.total, (unsigned long long)st_.text_bytes, (unsigned long long)r.end_bit, r.stream_end ? " (end of stream)" : "",
+                    j.first_bit == NONE ? " (decoded ahead)" : "");
+        {
+            std::lock_guard<std::mutex> lk(st_mu_);
+            st_.segments++;
+            d.pieces++;
+            st_.chunks += r.n_chunks;
+            st_.text_bytes += r.total;
+            st_.gzip_bytes += (a_byte * 8 + r.end_bit - pos_bit_) / 8;
+        }
+        if (r.total) ratio_ = std::max(ratio_ * 0.9, (double)r.total / std::max<double>(1.0, (double)(r.end_bit - first_bit) / 8));
+        pos_bit_ = a_byte * 8 + r.end_bit;
+        if (r.stream_end) {
+            if (run_len_) return fail("unexpected end of file");
+            ended_ = true;
+        } else if ((pos_bit_ >> 3) >= size_) {
+            return fail("unexpected end of file");
+        }
+        return (long)r.total;
+    }
+
+    // one piece of the stream, both phases on the current set: up to n_slots_ stretches from the position the stream goes on
+    // at (limit_byte: but no further than the first block boundary at or behind that byte of the file -- a boundary of the
+    // piece grid, see DevFastqReader over several devices)
+    long piece(uint8_t *d_dst, size_t room, hipStream_t stream, uint64_t limit_byte = 0) {
         if (hipSetDevice(s_->device_) != hipSuccess) return fail("hipSetDevice failed");
         const uint64_t a_byte = (pos_bit_ >> 3) / ALIGN * ALIGN;  // the piece's buffer starts here in the file
         const uint64_t first_bit = pos_bit_ - 8 * a_byte;
@@ -2723,160 +2952,83 @@ private:
             if (fit < n) n = fit < 1 ? 1u : (uint32_t)fit;
         }
         for (;;) {
-            const size_t want = (size_t)n * stretch_ + look_;
-            const size_t avail = (size_t)std::min<uint64_t>(want, size_ - a_byte);
-            const bool at_eof = a_byte + avail == size_;
-            const uint32_t n_str = (uint32_t)std::min<uint64_t>(n, (avail + stretch_ - 1) / stretch_);
-            const uint64_t valid_bits = 8ull * avail;
-            // the bytes: page cache -> page-locked staging -> device
-            const auto c0 = std::chrono::steady_clock::now();
-            memcpy(s_->h_in_, base_ + a_byte, avail);
-            memset(s_->h_in_ + avail, 0, 1024);
-            st_.s_host_copy += std::chrono::duration<double>(std::chrono::steady_clock::now() - c0).count();
-            GZ_TRY(hipMemcpyAsync(s_->d_in_, s_->h_in_, avail + 1024, hipMemcpyHostToDevice, stream));
-            const uint64_t end_bit = std::min<uint64_t>((uint64_t)n_str * stretch_ * 8, valid_bits);
-            if (trace_) (void)hipEventRecord(s_->ev_[0], stream);
-            if (v1_)
-                hipLaunchKernelGGL(k_search, dim3(n_str), dim3(64), sizeof(Lds), stream, (const uint32_t *)s_->d_in_, valid_bits, (uint64_t)stretch_ * 8,
-                                   first_bit, s_->d_start_);
-            else if (v2_)
-                hipLaunchKernelGGL(k_search2, dim3(n_str), dim3(64), sizeof(Lds), stream, (const uint32_t *)s_->d_in_, valid_bits,
-                                   (uint64_t)stretch_ * 8, first_bit, s_->d_start_);
-            else
-                hipLaunchKernelGGL(k_search3, dim3(n_str), dim3(64), SEARCH3_LDS, stream, (const uint32_t *)s_->d_in_, valid_bits,
-                                   (uint64_t)stretch_ * 8, first_bit, s_->d_start_);
-            long fake_end = -1;
-            if (fake_start_ > 0 && (uint32_t)fake_start_ < n_str) {  // test knob: pretend the search found a start that is none
-                const uint64_t bogus = (uint64_t)fake_start_ * stretch_ * 8 + 13;
-                GZ_TRY(hipMemcpyAsync(s_->d_start_ + fake_start_, &bogus, 8, hipMemcpyHostToDevice, stream));
-                GZ_TRY(hipStreamSynchronize(stream));
-                if (getenv("NOHUMAN_GZDEV_FAKE_END")) fake_end = fake_start_;  // ... whose garbage even looks like the end of the stream
-                fake_start_ = -1;
+            PieceJob j;
+            j.a_byte = a_byte;
+            j.first_bit = first_bit;
+            j.n = n;
+            if (limit_byte > a_byte) {
+                j.limit_bits = 8 * (limit_byte - a_byte);
+                if (j.limit_bits <= first_bit) j.limit_bits = 0;  // (cannot be: the limit is a boundary behind the position)
+                const uint64_t need = (limit_byte - a_byte + stretch_ - 1) / stretch_;
+                if (need < j.n) j.n = (uint32_t)need;
             }
-            hipLaunchKernelGGL(k_plan, dim3(1), dim3(1024), 0, stream, (const uint64_t *)s_->d_start_, n_str, end_bit, slot_syms_, s_->d_desc_);
-            if (trace_) (void)hipEventRecord(s_->ev_[1], stream);
-            hipLaunchKernelGGL(inflate_kernel(), dim3(n_str), dim3(64), inflate_lds(), stream, (const uint32_t *)s_->d_in_, valid_bits,
-                               at_eof ? 1u : 0u, s_->d_desc_, s_->d_sym_, slot_syms_, NOIDX);
-            if (fake_end >= 0) hipLaunchKernelGGL(k_test_mark_end, dim3(1), dim3(1), 0, stream, s_->d_desc_, (uint32_t)fake_end);
-            if (trace_) (void)hipEventRecord(s_->ev_[2], stream);
-            uint32_t redo = 0;
-            for (;;) {
-                hipLaunchKernelGGL(k_finish, dim3(1), dim3(1024), 0, stream, s_->d_desc_, n_str, s_->d_toff_, s_->d_res_);
-                GZ_TRY(hipMemcpyAsync(s_->h_res_, s_->d_res_, sizeof(SegResult), hipMemcpyDeviceToHost, stream));
-                const auto w0 = std::chrono::steady_clock::now();
-                GZ_TRY(hipStreamSynchronize(stream));
-                st_.s_wait += std::chrono::duration<double>(std::chrono::steady_clock::now() - w0).count();
-                if (s_->h_res_->bad_chunk != NOIDX && (s_->h_res_->broken == NOIDX || s_->h_res_->bad_chunk < s_->h_res_->broken)) break;
-                if (s_->h_res_->broken == NOIDX) break;
-                // A chunk does not start where its predecessor ended: what the search found there was no block start.
-                // It is struck from the plan and its predecessor decoded again, now to the start after it (the host
-                // reader's "searching on"; costs time, never correctness).
-                const uint32_t bad = s_->h_res_->broken;
-                GZ_TRY(hipMemcpyAsync(s_->d_start_ + bad, &NONE, 8, hipMemcpyHostToDevice, stream));
-                hipLaunchKernelGGL(k_plan, dim3(1), dim3(1024), 0, stream, (const uint64_t *)s_->d_start_, n_str, end_bit, slot_syms_, s_->d_desc_);
-                GZ_TRY(hipMemcpyAsync(s_->h_desc_, s_->d_desc_, (size_t)n_str * sizeof(ChunkDesc), hipMemcpyDeviceToHost, stream));
-                GZ_TRY(hipStreamSynchronize(stream));
-                uint32_t prev = bad;
-                while (prev > 0 && s_->h_desc_[--prev].bit_start == NONE) {
-                }
-                hipLaunchKernelGGL(inflate_kernel(), dim3(1), dim3(64), inflate_lds(), stream, (const uint32_t *)s_->d_in_, valid_bits,
-                                   at_eof ? 1u : 0u, s_->d_desc_, s_->d_sym_, slot_syms_, prev);
-                redo++;
-                st_.redecoded++;
-                if (redo > n_str) return fail("the chunks of a piece do not chain");
-            }
-            const SegResult r = *s_->h_res_;
-            if (trace_) {
-                float ms = 0;
-                if (hipEventElapsedTime(&ms, s_->ev_[0], s_->ev_[1]) == hipSuccess) st_.ms_search += ms;
-                if (hipEventElapsedTime(&ms, s_->ev_[1], s_->ev_[2]) == hipSuccess) st_.ms_decode += ms;
-            }
+            if (phase_a(*s_, j, stream, false) != 0) return -1;
+            const SegResult &r = j.r;
             if (r.bad_chunk != NOIDX || r.end_chunk == NOIDX) {
                 last_bad_ = r.bad_status;
                 if (++failed_in_a_row_ >= 2) host_mode_ = true;
-                return host_piece(d_dst, room, stream, a_byte, first_bit, end_bit, r);
+                return host_piece(d_dst, room, stream, a_byte, first_bit, j.end_bit, r);
             }
             failed_in_a_row_ = 0;
             if (r.total > room) {
-                if (n_str <= 1) return fail("a chunk's text does not fit the batch buffer");
-                n = std::max<uint32_t>(1u, n_str / 4);  // cut the piece down and decode again
-                ratio_ = std::max(ratio_, (double)r.total / ((double)n_str * stretch_));
+                if (j.n_str <= 1) return fail("a chunk's text does not fit the batch buffer");
+                n = std::max<uint32_t>(1u, j.n_str / 4);  // cut the piece down and decode again
+                ratio_ = std::max(ratio_, (double)r.total / ((double)j.n_str * stretch_));
                 continue;
             }
-            // windows by the prefix scan, text, CRCs, the window behind the piece
-            if (trace_) (void)hipEventRecord(s_->ev_[3], stream);
-            const uint32_t gy = 4;
-            if (scan_rounds_) {
-                hipLaunchKernelGGL(k_maps, dim3(n_str, gy), dim3(256), 0, stream, (const ChunkDesc *)s_->d_desc_, (const uint16_t *)s_->d_sym_, slot_syms_,
-                                   s_->d_maps_[0]);
-                int cur = 0;
-                for (uint32_t stride = 1; stride < n_str; stride <<= 1) {
-                    hipLaunchKernelGGL(k_scan_round, dim3(n_str, gy), dim3(256), 0, stream, (const uint16_t *)s_->d_maps_[cur], s_->d_maps_[cur ^ 1], n_str,
-                                       stride);
-                    cur ^= 1;
-                }
-                hipLaunchKernelGGL(k_windows, dim3(n_str, gy), dim3(256), 0, stream, (const uint16_t *)s_->d_maps_[cur], (const uint8_t *)s_->d_win_[s_->win_],
-                                   s_->d_windows_);
-            } else {
-                const uint32_t ng = (n_str + SCAN_GROUP - 1) / SCAN_GROUP;
-                hipLaunchKernelGGL(k_scan_local, dim3(ng), dim3(1024), 2 * WSIZE, stream, (const ChunkDesc *)s_->d_desc_, (const uint16_t *)s_->d_sym_, slot_syms_,
-                                   n_str, s_->d_maps_[0]);
-                hipLaunchKernelGGL(k_scan_groups, dim3(1), dim3(1024), 2 * WSIZE, stream, (const uint16_t *)s_->d_maps_[0], n_str, s_->d_maps_[1]);
-                hipLaunchKernelGGL(k_scan_windows, dim3(n_str, gy), dim3(256), 0, stream, (const uint16_t *)s_->d_maps_[0], (const uint16_t *)s_->d_maps_[1],
-                                   (const uint8_t *)s_->d_win_[s_->win_], s_->d_windows_);
-            }
-            if (trace_) (void)hipEventRecord(s_->ev_[4], stream);
-            hipLaunchKernelGGL(k_resolve, dim3(n_str, 8), dim3(256), 0, stream, (const ChunkDesc *)s_->d_desc_, (const uint16_t *)s_->d_sym_, slot_syms_,
-                               (const uint8_t *)s_->d_windows_, (const uint64_t *)s_->d_toff_, d_dst);
-            if (trace_) (void)hipEventRecord(s_->ev_[5], stream);
-            hipLaunchKernelGGL(k_crc, dim3(n_str), dim3(256), 0, stream, s_->d_desc_, (const uint64_t *)s_->d_toff_, (const uint8_t *)d_dst);
-            hipLaunchKernelGGL(k_carry_window, dim3(1), dim3(1024), 0, stream, (const uint8_t *)d_dst, (uint64_t)room, (const SegResult *)s_->d_res_,
-                               (const uint8_t *)s_->d_win_[s_->win_], s_->d_win_[s_->win_ ^ 1]);
-            if (trace_) (void)hipEventRecord(s_->ev_[6], stream);
-            GZ_TRY(hipMemcpyAsync(s_->h_desc_, s_->d_desc_, (size_t)n_str * sizeof(ChunkDesc), hipMemcpyDeviceToHost, stream));
-            const auto w0 = std::chrono::steady_clock::now();
-            GZ_TRY(hipStreamSynchronize(stream));
-            st_.s_wait += std::chrono::duration<double>(std::chrono::steady_clock::now() - w0).count();
-            if (trace_) {
-                float ms = 0;
-                if (hipEventElapsedTime(&ms, s_->ev_[3], s_->ev_[4]) == hipSuccess) st_.ms_scan += ms;
-                if (hipEventElapsedTime(&ms, s_->ev_[4], s_->ev_[5]) == hipSuccess) st_.ms_resolve += ms;
-                if (hipEventElapsedTime(&ms, s_->ev_[5], s_->ev_[6]) == hipSuccess) st_.ms_crc += ms;
-            }
-            s_->win_ ^= 1;
-            // members: CRC-32 and ISIZE like gzip checks them
-            for (uint32_t c = 0; c <= r.end_chunk; c++) {
-                const ChunkDesc &d = s_->h_desc_[c];
-                if (d.bit_start == NONE) continue;
-#ifdef NH_GZ_PROF
-                for (int i = 0; i < 12; i++) prof_[i] += d.prof[i];
-#endif
-                uint32_t a = 0;
-                for (uint32_t p = 0; p <= d.n_members; p++) {
-                    const uint32_t b = p < d.n_members ? d.m_off[p] : d.out_len;
-                    account(d.piece_crc[p], b - a);
-                    if (p < d.n_members && !member_end(d.m_crc[p], d.m_isize[p])) return -1;
-                    a = b;
-                }
-            }
+            return phase_b(*s_, j, d_dst, room, stream);
+        }
+    }
+
+    // ---- pieces decoded ahead of the stream (several devices).  The file is a grid of cells of n_slots_ stretches from the
+    // first member's first block; cell k's piece starts at the first block start the search finds in it and ends at the first
+    // block boundary behind it.  spec_decode() runs phase A of a cell on set k -- any thread, while the stream is elsewhere;
+    // take() is the stream's next piece ON set k, in stream order: the set's decoded cell if it starts exactly where the
+    // stream stands (the normal case), else a piece decoded now, from the stream's position to the end of ITS cell -- which
+    // puts the stream back on the grid.
+    uint64_t cell_bytes() const { return (uint64_t)n_slots_ * stretch_; }
+    uint64_t cell_of_pos() const { return ((pos_bit_ >> 3) - grid0_) / cell_bytes(); }
+    uint64_t cells() const { return (size_ - grid0_ + cell_bytes() - 1) / cell_bytes(); }
+    bool spec_ok() const { return !v1_ && !v2_ && stretch_ % ALIGN == 0 && !host_mode_; }
+    void spec_decode(int k, uint64_t cell, hipStream_t stream) {
+        DevSet &d = *sets_[(size_t)k];
+        d.spec = PieceJob();
+        d.spec_cell = cell;
+        if (hipSetDevice(d.device_) != hipSuccess) return;
+        d.spec.a_byte = grid0_ + cell * cell_bytes();
+        if (d.spec.a_byte >= size_) return;
+        d.spec.first_bit = NONE;
+        d.spec.n = n_slots_;
+        if (phase_a(d, d.spec, stream, true) != 0) d.spec.valid = false;
+    }
+    long take(int k, bool use_spec, void *d_dst, size_t room, hipStream_t stream) {
+        if (!error_.empty()) return -1;
+        if (ended_) return 0;
+        if (k < 0 || k >= (int)sets_.size()) return fail("no such device set");
+        if (!select_set(k, stream)) return fail("moving the window between devices failed");
+        DevSet &d = *s_;
+        const PieceJob &j = d.spec;
+        if (use_spec && j.valid && !host_mode_ && j.r.bad_chunk == NOIDX && j.r.end_chunk != NOIDX && j.r.first_start != NONE &&
+            j.a_byte * 8 + j.r.first_start == pos_bit_ && j.r.total <= room) {
+            failed_in_a_row_ = 0;
+            spec_used_++;
+            const long n = phase_b(d, j, (uint8_t *)d_dst, room, stream);
+            d.spec.valid = false;
+            if (n != 0) return n;
+            // (a piece without text -- an empty member --: the stream goes on below)
+        } else if (use_spec) {
+            spec_refused_++;
             if (debug_)
-                fprintf(stderr, "[gzdev] piece %llu: file byte %llu + bit %llu, %u stretches, %u chunks (last %u), %u decoded again, text %llu at %llu, ends at bit %llu%s\n",
-                        (unsigned long long)st_.segments, (unsigned long long)a_byte, (unsigned long long)first_bit, n_str, r.n_chunks, r.end_chunk, redo,
-                        (unsigned long long)r.total, (unsigned long long)st_.text_bytes, (unsigned long long)r.end_bit, r.stream_end ? " (end of stream)" : "");
-            st_.segments++;
-            s_->pieces++;
-            st_.chunks += r.n_chunks;
-            st_.text_bytes += r.total;
-            st_.gzip_bytes += (a_byte * 8 + r.end_bit - pos_bit_) / 8;
-            if (r.total) ratio_ = std::max(ratio_ * 0.9, (double)r.total / std::max<double>(1.0, (double)(r.end_bit - first_bit) / 8));
-            pos_bit_ = a_byte * 8 + r.end_bit;
-            if (r.stream_end) {
-                if (run_len_) return fail("unexpected end of file");
-                ended_ = true;
-            } else if ((pos_bit_ >> 3) >= size_) {
-                return fail("unexpected end of file");
-            }
-            return (long)r.total;
+                fprintf(stderr, "[gzdev] cell %llu decoded ahead is refused: valid %d, bad chunk %u (status %u), last chunk %u, first start bit %llu of the file, the stream stands at %llu, text %llu of %zu\n",
+                        (unsigned long long)d.spec_cell, (int)j.valid, j.r.bad_chunk, j.r.bad_status, j.r.end_chunk,
+                        (unsigned long long)(j.a_byte * 8 + j.r.first_start), (unsigned long long)pos_bit_, (unsigned long long)j.r.total, room);
+        }
+        d.spec.valid = false;
+        for (;;) {
+            if (ended_) return 0;
+            const uint64_t limit = grid0_ + (cell_of_pos() + 1) * cell_bytes();
+            const long n = piece((uint8_t *)d_dst, room, stream, limit < size_ ? limit : 0);
+            if (n != 0) return n;
         }
     }
 
@@ -2949,10 +3101,14 @@ private:
     uint64_t pos_bit_ = 0;  // where the stream goes on (a block boundary), bits from the start of the file
     size_t stretch_ = 0, seg_ = 0, look_ = 0;
     uint32_t n_slots_ = 0, slot_syms_ = 0;
-    double ratio_ = 6.0;  // text per compressed byte seen lately
+    double ratio_ = 5.0;  // text per compressed byte seen lately (before anything was seen: FASTQ's 4-5 : 1; a piece that does not fit is cut down)
     uint32_t run_crc_ = 0;
     uint64_t run_len_ = 0;
     bool trace_ = false, warned_ = false, host_mode_ = false, v1_ = false, v2_ = false, scan_rounds_ = false;
+    std::mutex st_mu_;           // the statistics: phase A of a piece decoded ahead runs on another thread
+    uint64_t grid0_ = 0;         // the piece grid starts at the first member's first block (aligned down)
+    uint64_t spec_used_ = 0, spec_refused_ = 0;
+    long fake_spec_ = 0;         // test knob NOHUMAN_GZDEV_FAKE_SPEC=k: the k-th piece decoded ahead gets a false first start
     bool debug_ = getenv("NOHUMAN_GZDEV_NOCRC") != nullptr;  // debugging aid: one line per piece, CRC failures reported and passed over
     uint32_t failed_in_a_row_ = 0, last_bad_ = 0;
     long fake_start_ = -1;
@@ -2970,6 +3126,11 @@ long DevGunzip::next(void *d_dst, size_t room, hipStream_t stream) { return impl
 int DevGunzip::add_device(int device, std::string &err) { return impl_->add_device(device, err); }
 long DevGunzip::next_on(int set, void *d_dst, size_t room, hipStream_t stream) { return impl_->next_on(set, d_dst, room, stream); }
 uint64_t DevGunzip::pieces_of(int set) const { return impl_->pieces_of(set); }
+bool DevGunzip::ahead_ok() const { return impl_->spec_ok(); }
+uint64_t DevGunzip::cell_of_position() const { return impl_->cell_of_pos(); }
+uint64_t DevGunzip::cells() const { return impl_->cells(); }
+void DevGunzip::decode_ahead(int set, uint64_t cell, hipStream_t stream) { impl_->spec_decode(set, cell, stream); }
+long DevGunzip::take(int set, bool use_ahead, void *d_dst, size_t room, hipStream_t stream) { return impl_->take(set, use_ahead, d_dst, room, stream); }
 bool DevGunzip::ended() const { return impl_->ended_; }
 const std::string &DevGunzip::error() const { return impl_->error_; }
 const DevGunzipStats &DevGunzip::stats() const { return impl_->st_; }
@@ -3046,6 +3207,7 @@ extern "C" int nh_gunzip_device_file(const char *in, const char *out, int32_t de
 // =====================================================================================================================
 #include <atomic>
 #include <condition_variable>
+#include <deque>
 #include <mutex>
 #include <thread>
 
@@ -3180,8 +3342,11 @@ public:
         if (!dev_gunzip_wants(path)) return 1;
         if (n_devices < 1) return 1;
         path_ = path;
-        // piece i of the stream is decoded and indexed on lane i mod G (a lane: a device, a stream, a buffer set of the
-        // decoder); every lane has two text buffers, so a piece is decoded while the one before it on the lane goes out
+        // A lane = a device of the run with a buffer set of the decoder, two streams and two text buffers.  One lane: piece
+        // after piece, each decoded while the batches of the one before go out.  Several lanes: the pieces of the stream are
+        // decoded AHEAD on all lanes at once (DevGunzip::decode_ahead: search and decode need neither the window nor the
+        // stream's state) and taken in stream order (windows, text, CRC, record index) -- piece i's batches are classified on
+        // the device it was decoded on.
         lanes_.resize((size_t)n_devices);
         for (int g = 0; g < n_devices; g++) lanes_[(size_t)g].device = devices[g];
         if (hipSetDevice(devices[0]) != hipSuccess) {
@@ -3198,7 +3363,7 @@ public:
         if (stat(path, &st) == 0 && (uint64_t)st.st_size * 16 + ((size_t)64u << 20) < room_) room_ = (size_t)st.st_size * 16 + ((size_t)64u << 20);
         if (const char *e = getenv("NOHUMAN_GZDEV_ROOM")) room_ = std::max<size_t>((size_t)atoll(e), (size_t)1u << 20);
         buf_.resize(2 * lanes_.size());
-        for (size_t i = 0; i < buf_.size(); i++) buf_[i].lane = (int)(i % lanes_.size());
+        for (size_t i = 0; i < buf_.size(); i++) buf_[i].lane = (int)(i / 2);
         for (;;) {
             bool ok = true;
             for (Piece &b : buf_) {
@@ -3219,11 +3384,13 @@ public:
         }
         for (Lane &l : lanes_) {
             if (hipSetDevice(l.device) != hipSuccess || hipStreamCreateWithFlags(&l.stream, hipStreamNonBlocking) != hipSuccess ||
-                hipMalloc((void **)&l.d_bad, 8) != hipSuccess || hipHostMalloc((void **)&l.h_bad, 8, hipHostMallocDefault) != hipSuccess) {
+                hipStreamCreateWithFlags(&l.stream_a, hipStreamNonBlocking) != hipSuccess || hipMalloc((void **)&l.d_bad, 8) != hipSuccess ||
+                hipHostMalloc((void **)&l.h_bad, 8, hipHostMallocDefault) != hipSuccess) {
                 err = "the gzip reader's buffers cannot be had";
                 return -1;
             }
         }
+        ahead_ = lanes_.size() > 1 && gz_.ahead_ok() && !(getenv("NOHUMAN_GZ_AHEAD") && getenv("NOHUMAN_GZ_AHEAD")[0] == '0');
         trace_ = getenv("NOHUMAN_TRACE") != nullptr;
         return 0;
     }
@@ -3240,27 +3407,30 @@ public:
             return 0;
         }
         for (;;) {
-            Piece &p = buf_[take_];
+            Piece *pp = nullptr;
             {
                 std::unique_lock<std::mutex> lk(mu_);
-                cv_.wait(lk, [&] { return p.loaded || done_; });
-                if (!p.loaded) {  // the producer has ended: the end of the input, an error, or "not ours"
+                cv_.wait(lk, [&] { return !order_.empty() || done_; });
+                if (order_.empty()) {  // the producer has ended: the end of the input, an error, or "not ours"
                     if (fallback_) return 1;
                     if (!error_.empty()) hb.error = error_;
                     hb.eof = true;
                     return 0;
                 }
+                pp = &buf_[order_.front()];
             }
+            Piece &p = *pp;
             // whole batches, and at the end of the input what is left
             const size_t full = p.last ? p.n_rec : p.n_rec / bf_ * bf_;
             if (p.next_rec < full) return emit(hb, p, full);
-            {   // this piece has handed out what it had: on to the other buffer
+            const bool last = p.last;
+            {   // this piece has handed out what it had: on to the next
                 std::lock_guard<std::mutex> lk(mu_);
                 p.loaded = false;
+                order_.pop_front();
             }
             cv_.notify_all();
-            take_ = (take_ + 1) % buf_.size();
-            if (p.last) {
+            if (last) {
                 hb.eof = true;
                 return 0;
             }
@@ -3274,6 +3444,8 @@ public:
         }
         cv_.notify_all();
         if (th_.joinable()) th_.join();
+        for (Lane &l : lanes_)
+            if (l.worker.joinable()) l.worker.join();
         // every batch handed out points into the text buffers: wait until the pipeline has let go of them
         {
             std::unique_lock<std::mutex> lk(mu_);
@@ -3284,9 +3456,9 @@ public:
             });
         }
         if (trace_ && pieces_)
-            fprintf(stderr, "[nohuman trace] record index on GPU %d (%zu lane%s), %s: %llu pieces, %llu records, index kernels + table D2H %.3f s, carried %.2f GB\n",
-                    lanes_.empty() ? -1 : lanes_[0].device, lanes_.size(), lanes_.size() == 1 ? "" : "s", path_.c_str(), (unsigned long long)pieces_,
-                    (unsigned long long)records_, index_s_, carried_ / 1e9);
+            fprintf(stderr, "[nohuman trace] record index on GPU %d (%zu lane%s%s), %s: %llu pieces, %llu records, index kernels + table D2H %.3f s, carried %.2f GB\n",
+                    lanes_.empty() ? -1 : lanes_[0].device, lanes_.size(), lanes_.size() == 1 ? "" : "s", ahead_ ? ", pieces decoded ahead" : "", path_.c_str(),
+                    (unsigned long long)pieces_, (unsigned long long)records_, index_s_, carried_ / 1e9);
         pieces_ = 0;
         gz_.close();
         for (Piece &b : buf_) {
@@ -3299,11 +3471,13 @@ public:
                 if (q) (void)hipHostFree(q);
         }
         buf_.clear();
+        order_.clear();
         for (Lane &l : lanes_) {
             (void)hipSetDevice(l.device);
             if (l.d_bad) (void)hipFree(l.d_bad);
             if (l.h_bad) (void)hipHostFree(l.h_bad);
             if (l.stream) (void)hipStreamDestroy(l.stream);
+            if (l.stream_a) (void)hipStreamDestroy(l.stream_a);
         }
         lanes_.clear();
     }
@@ -3322,8 +3496,11 @@ private:
     };
     struct Lane {
         int device = -1;
-        hipStream_t stream = nullptr;
+        hipStream_t stream = nullptr, stream_a = nullptr;  // the stream's own work; a piece decoded ahead
         unsigned long long *d_bad = nullptr, *h_bad = nullptr;
+        std::thread worker;
+        int state = 0;      // 0 idle, 1 a cell is being decoded ahead, 2 decoded
+        uint64_t cell = 0;  // which
     };
 
     int fail(const std::string &m) {
@@ -3373,14 +3550,49 @@ private:
         return 0;
     }
 
-    // pieces into the buffers in turn (buffer i on lane i mod G), each behind what the one before could not hand out as
-    // whole batches
-    void produce() {
+    // the lanes' workers: a cell of the piece grid decoded ahead of the stream
+    void work(size_t g) {
+        Lane &ln = lanes_[g];
         for (;;) {
-            const size_t filled = fill_;
-            const int rc = load_next();
+            uint64_t cell;
+            {
+                std::unique_lock<std::mutex> lk(mu_);
+                cv_.wait(lk, [&] { return ln.state == 1 || stop_ || done_; });
+                if (ln.state != 1) return;
+                cell = ln.cell;
+            }
+            gz_.decode_ahead((int)g, cell, ln.stream_a);
+            {
+                std::lock_guard<std::mutex> lk(mu_);
+                ln.state = 2;
+            }
+            cv_.notify_all();
+        }
+    }
+    // idle lanes get the next cells of the grid (never the cell the stream stands in, nor one behind it)
+    void assign_ahead() {
+        const uint64_t k = gz_.cell_of_position(), n = gz_.cells();
+        std::lock_guard<std::mutex> lk(mu_);
+        if (next_cell_ <= k) next_cell_ = k + 1;
+        for (Lane &l : lanes_)
+            if (l.state == 2 && l.cell < k) l.state = 0;  // (the stream is past it: a block longer than a cell -- tiny cells of the tests)
+        for (Lane &l : lanes_)
+            if (l.state == 0 && next_cell_ < n) {
+                l.cell = next_cell_++;
+                l.state = 1;
+            }
+        cv_.notify_all();
+    }
+
+    // the stream's pieces in order: each behind what the one before could not hand out as whole batches
+    void produce() {
+        if (ahead_)
+            for (size_t g = 0; g < lanes_.size(); g++) lanes_[g].worker = std::thread([this, g] { work(g); });
+        for (;;) {
+            bool last = false;
+            const int rc = load_next(last);
             std::lock_guard<std::mutex> lk(mu_);
-            if (rc != 0 || buf_[filled].last || stop_) {
+            if (rc != 0 || last || stop_) {
                 if (rc == 1) fallback_ = true;
                 done_ = true;
                 cv_.notify_all();
@@ -3389,20 +3601,58 @@ private:
         }
     }
 
-    int load_next() {
+    int load_next(bool &last) {
         using namespace fq;
-        Piece &old = buf_[(fill_ + buf_.size() - 1) % buf_.size()];  // the piece loaded before this one (its record table stays valid while its batches go out)
-        Piece &p = buf_[fill_];
-        Lane &ln = lanes_[(size_t)p.lane];
+        // ---- which lane takes the stream's next piece
+        size_t g = piece_no_ % lanes_.size();
+        bool use_ahead = false;
+        if (ahead_ && gz_.ahead_ok()) {
+            assign_ahead();
+            const uint64_t k = gz_.cell_of_position();
+            std::unique_lock<std::mutex> lk(mu_);
+            size_t pick = lanes_.size();
+            for (size_t i = 0; i < lanes_.size(); i++)
+                if (lanes_[i].state != 0 && lanes_[i].cell == k) pick = i;
+            if (pick < lanes_.size()) {
+                use_ahead = true;
+            } else {
+                // nobody decoded this cell ahead (the stream's first piece; a piece that was refused, or ended early): an idle
+                // lane decodes it in order -- or, all being busy with cells further on, the one furthest ahead gives its cell up
+                for (size_t i = 0; i < lanes_.size(); i++)
+                    if (lanes_[i].state == 0) pick = i;
+                if (pick == lanes_.size()) {
+                    pick = 0;
+                    for (size_t i = 1; i < lanes_.size(); i++)
+                        if (lanes_[i].cell > lanes_[pick].cell) pick = i;
+                    if (next_cell_ > lanes_[pick].cell) next_cell_ = lanes_[pick].cell;  // (it is dealt out again)
+                }
+            }
+            g = pick;
+            cv_.wait(lk, [&] { return lanes_[g].state != 1 || stop_; });
+            if (stop_) return -2;
+            lanes_[g].state = 3;  // the stream's own (not idle: no new cell until the piece is through)
+        }
+        Lane &ln = lanes_[g];
+        // ---- a free text buffer of that lane
+        Piece *pp = nullptr;
         {
             std::unique_lock<std::mutex> lk(mu_);
-            cv_.wait(lk, [&] { return (!p.loaded && p.outstanding == 0) || stop_; });
-            if (stop_) return -2;
+            cv_.wait(lk, [&] {
+                for (size_t i = 2 * g; i < 2 * g + 2; i++)
+                    if (!buf_[i].loaded && buf_[i].outstanding == 0 && &buf_[i] != last_) {
+                        pp = &buf_[i];
+                        return true;
+                    }
+                return stop_;
+            });
+            if (!pp) return -2;
         }
+        Piece &p = *pp;
         if (hipSetDevice(ln.device) != hipSuccess) return fail("hipSetDevice failed");
         size_t carry = 0;
-        if (old.indexed) {
+        if (last_ && last_->indexed) {
             // the records behind the last whole batch and the incomplete record behind them (from the lane before: over xGMI)
+            Piece &old = *last_;
             const size_t full = old.n_rec / bf_ * bf_;
             const size_t from = full < old.n_rec ? old.h_bstart[full / bf_] : old.used_len;
             carry = old.text_len - from;
@@ -3413,23 +3663,32 @@ private:
                 return fail("D2D of the carried text failed");
             carried_ += carry;
         }
-        const long n = gz_.next_on(p.lane, p.d_text + carry, room_ - carry, ln.stream);
+        const long n = ahead_ ? gz_.take((int)g, use_ahead, p.d_text + carry, room_ - carry, ln.stream)
+                              : gz_.next_on((int)g, p.d_text + carry, room_ - carry, ln.stream);
+        if (ahead_) {
+            std::lock_guard<std::mutex> lk(mu_);
+            ln.state = 0;
+        }
         if (n < 0) return fail(gz_.error());
+        if (ahead_ && gz_.ahead_ok() && !gz_.ended()) assign_ahead();  // (this lane's next cell is decoded while its piece is indexed)
         p.text_len = carry + (size_t)n;
         p.last = gz_.ended();
         p.n_rec = p.next_rec = 0;
         p.used_len = 0;
         p.indexed = false;
         pieces_++;
+        piece_no_++;
         const int irc = p.text_len ? index(p) : 0;
         if (irc != 0) return irc;
         p.indexed = true;
+        last = p.last;
+        last_ = &p;
         {
             std::lock_guard<std::mutex> lk(mu_);
             p.loaded = true;
+            order_.push_back((size_t)(pp - &buf_[0]));
         }
         cv_.notify_all();
-        fill_ = (fill_ + 1) % buf_.size();
         return 0;
     }
 
@@ -3527,7 +3786,10 @@ private:
     std::string path_, error_;
     std::vector<Lane> lanes_;
     std::vector<Piece> buf_;
-    size_t fill_ = 0, take_ = 0;
+    std::deque<size_t> order_;   // the pieces handed to the consumer, in stream order (indices into buf_)
+    Piece *last_ = nullptr;      // the piece produced last: what it could not hand out as whole batches goes in front of the next
+    uint64_t piece_no_ = 0, next_cell_ = 0;
+    bool ahead_ = false;
     size_t room_ = 0, bf_ = 0;
     std::thread th_;
     bool stop_ = false, done_ = false, fallback_ = false;

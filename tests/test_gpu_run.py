@@ -383,6 +383,50 @@ def test_two_engines_on_device_0_sharded(tmp_path, monkeypatch, capfd):
         assert res[tag] == res["one"], tag
 
 
+def test_pieces_decoded_ahead_on_several_lanes(tmp_path, monkeypatch, capfd):
+    """The reader over several devices decodes the pieces of the grid AHEAD of the stream, a lane each at the same time
+    (search + decode need neither the window nor the stream's state), and takes them in stream order.  Three engines on
+    GPU 0; cells of 256 KiB of gzip (most pieces decoded ahead are taken), of 16 KiB (a deflate block spans cells: most are
+    refused or stale, and the stream decodes in order to the next cell boundary), and a planted false first start
+    (NOHUMAN_GZDEV_FAKE_SPEC): always the bytes and counters of one engine."""
+    from nohuman_amd import engine
+    _, ext, recs, calls = _expected("expected_pe.json", 0.0)
+    raw1 = open(os.path.join(GOLD, "reads_pe_1.fq"), "rb").read()
+    raw2 = open(os.path.join(GOLD, "reads_pe_2.fq"), "rb").read()
+    in1, in2 = tmp_path / "r_1.fq.gz", tmp_path / "r_2.fq.gz"
+    in1.write_bytes(gzip.compress(raw1 * 160, 6))
+    in2.write_bytes(gzip.compress(raw2 * 100, 1) + gzip.compress(raw2 * 60, 9))
+    monkeypatch.setenv("NOHUMAN_BATCH_FRAGS", "2048")
+    monkeypatch.setenv("NOHUMAN_TRACE", "1")
+    monkeypatch.setenv("NOHUMAN_GZ_READER", "device")
+    res = {}
+    for tag, ids, seg, fake in (("one", [0], 262144, None), ("three", [0, 0, 0], 262144, None), ("three_fake", [0, 0, 0], 262144, "2"),
+                                ("two_tiny", [0, 0], 16384, None), ("three_off", [0, 0, 0], 262144, "off")):
+        monkeypatch.setenv("NOHUMAN_GZDEV_SEG", str(seg))
+        monkeypatch.setenv("NOHUMAN_GZDEV_STRETCH", "4096")
+        monkeypatch.delenv("NOHUMAN_GZDEV_FAKE_SPEC", raising=False)
+        monkeypatch.delenv("NOHUMAN_GZ_AHEAD", raising=False)
+        if fake == "off":
+            monkeypatch.setenv("NOHUMAN_GZ_AHEAD", "0")
+        elif fake:
+            monkeypatch.setenv("NOHUMAN_GZDEV_FAKE_SPEC", fake)
+        o1, o2, k = tmp_path / (tag + "_1"), tmp_path / (tag + "_2"), tmp_path / (tag + ".k")
+        st = engine.run(DB, str(in1), str(o1), in2=str(in2), out2=str(o2), kraken_output=str(k), device_ids=ids, threads=4)
+        err = capfd.readouterr().err
+        res[tag] = (o1.read_bytes(), o2.read_bytes(), k.read_bytes(), (st.total_sequences, st.classified, st.total_bases))
+        took = [ln for ln in err.splitlines() if "decoded ahead of the stream taken" in ln]
+        if tag in ("three", "three_fake"):
+            assert len(took) == 2, err[-3000:]
+            for ln in took:
+                a, b = int(ln.split(":")[-1].split()[0]), int(ln.split("taken,")[1].split()[0])
+                assert a >= 3 and (b >= 1 if fake else True), ln  # pieces were taken (and with the planted start: one refused)
+        if tag in ("one", "three_off"):
+            assert not took, err[-2000:]
+    assert res["one"][3][0] == len(calls) * 160
+    for tag in ("three", "three_fake", "two_tiny", "three_off"):
+        assert res[tag] == res["one"], tag
+
+
 def test_fragments_with_many_taxa_in_concurrent_batches(tmp_path, monkeypatch):
     """Batches in flight on the two stream slots of an engine each carry fragments that hit more than
     64 distinct taxa (second kernel pass): every launch has its own 'left for the second pass' word,
