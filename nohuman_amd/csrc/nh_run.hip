@@ -847,6 +847,10 @@ int run_engines(const std::vector<Engine *> &engines, const nh_run_args *a, nh_s
         devs2.push_back(engines[(size_t)((g + 1) % G)]->device);
     }
     if (getenv("NOHUMAN_GZ_SHARD") && getenv("NOHUMAN_GZ_SHARD")[0] == '0') devs1.resize(1), devs2.resize(1);  // (A / B: a file's reader on one device)
+    if (const char *e = getenv("NOHUMAN_GZ_LANES")) {  // tuning knob: several lanes of the reader on ONE device (pieces decoded ahead there)
+        const int n = atoi(e);
+        while (G == 1 && (int)devs1.size() < n && n <= 4) devs1.push_back(devs1[0]), devs2.push_back(devs2[0]);
+    }
     std::thread t1(reader_main, a->in1, &q1, &rs, &pool1, &clk, 0, BATCH_FRAGS, BATCH_TEXT, gz_threads, devs1);
     std::thread t2;
     if (rs.paired) t2 = std::thread(reader_main, a->in2, &q2, &rs, &pool2, &clk, 1, BATCH_FRAGS, BATCH_TEXT, gz_threads, devs2);

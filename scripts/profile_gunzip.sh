@@ -24,9 +24,10 @@ m = re.search(r"pieces (\d+) chunks (\d+) text (\d+)", tr)
 pieces, chunks, text = (int(x) for x in m.groups()) if m else (0, 0, 0)
 inp = open(out + "/input.txt").read().strip() if os.path.exists(out + "/input.txt") else ""
 print("# profiles/%s_inflate_summary.txt -- rocprofv3 over ONE pass of the gzip reader on the GPU (nh_gunzip.hip) on 1 x MI355X" % tag)
-print("# command: bash scripts/profile_gunzip.sh %s   (tools/gz_prof_run.py: nh_gunzip_device_file, pieces of 256 MiB of gzip, chunks of 32 KiB," % tag)
-print("#          text to a 3 GiB device buffer, written to /dev/null; input: tools/gz_make_input.py, bench.py's e2e FASTQ text, level 6)")
+print("# command: bash scripts/profile_gunzip.sh %s   (tools/gz_prof_run.py: nh_gunzip_device_file with the reader's defaults -- pieces of 512 MiB" % tag)
+print("#          of gzip in chunks of 64 KiB --, text to a device buffer, written to /dev/null; input: tools/gz_make_input.py, bench.py's e2e FASTQ text, level 6)")
 print("# source: git HEAD %s" % head)
+print("# builder's notes (versions of the kernels, size sweeps, what was tried and dropped): profiles/r04_inflate_notes.txt")
 print("# input: %s ; pass: %d pieces, %d chunks, %d bytes of text" % (inp, pieces, chunks, text))
 print()
 print("== rocprofv3 --kernel-trace --stats, the reader's kernels (ms per pass, GB/s of TEXT = text bytes / kernel time)")

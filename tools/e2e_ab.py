@@ -1,5 +1,5 @@
 """Same-box A / B of nh_run on a prepared gzip pair: every setting (a string of env assignments) is run `reps` times, interleaved.
-    python tools/e2e_ab.py r_1.fq.gz r_2.fq.gz plain|gzip|none reps "A=1 B=2" "A=0" ...   ("" = defaults)"""
+    python tools/e2e_ab.py r_1.fq.gz r_2.fq.gz plain|gzip|none|se-plain|se-gzip|se-none reps "A=1 B=2" "A=0" ...   ("" = defaults)"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from nohuman_amd import Engine
@@ -8,6 +8,8 @@ settings = sys.argv[5:] or [""]
 cap = 134_217_689
 eng = Engine.synthetic(cap, int(cap * 0.7), depth=30, seed=7)
 d = os.path.dirname(f1)
+se = what.startswith("se-")  # single-end: the first file only
+what = what[3:] if se else what
 kw = {"plain": {}, "gzip": dict(out_codec=2, codec_threads=8), "none": dict(keep_human=True)}[what]
 res = {s: [] for s in settings}
 for rep in range(reps + 1):
@@ -21,7 +23,7 @@ for rep in range(reps + 1):
             if os.path.exists(os.path.join(d, o)):
                 os.remove(os.path.join(d, o))
         t = time.perf_counter()
-        st = eng.run(f1, os.path.join(d, "o1"), in2=f2, out2=os.path.join(d, "o2"), threads=16, **kw)
+        st = eng.run(f1, os.path.join(d, "o1"), in2=None if se else f2, out2=None if se else os.path.join(d, "o2"), threads=16, **kw)
         dt = time.perf_counter() - t
         for k in keys:
             os.environ.pop(k, None)
@@ -29,4 +31,4 @@ for rep in range(reps + 1):
             res[s].append(dt)
 for s in settings:
     v = sorted(res[s])
-    print("%-40s %s  median %.3f s = %.1f Mreads/s" % (s or "(defaults)", " ".join("%.3f" % x for x in res[s]), v[len(v) // 2], 2 * st.total_sequences / v[len(v) // 2] / 1e6), flush=True)
+    print("%-40s %s  median %.3f s = %.1f Mreads/s" % (s or "(defaults)", " ".join("%.3f" % x for x in res[s]), v[len(v) // 2], (1 if se else 2) * st.total_sequences / v[len(v) // 2] / 1e6), flush=True)
