@@ -22,7 +22,8 @@ head = os.environ.get("NOHUMAN_GIT_HEAD", "unknown (snapshot without .git)")
 tr = open(out + "/trace.out").read()
 m = re.search(r"pieces (\d+) chunks (\d+) text (\d+)", tr)
 pieces, chunks, text = (int(x) for x in m.groups()) if m else (0, 0, 0)
-inp = open(out + "/input.txt").read().strip() if os.path.exists(out + "/input.txt") else ""
+inp = open(out + "/input.txt").read().strip().splitlines()[-1] if os.path.exists(out + "/input.txt") else ""
+inp += " (5 members of 3 000 000 records of 150 bp, Illumina-style ids, binned qualities: 4.30 : 1)"
 print("# profiles/%s_inflate_summary.txt -- rocprofv3 over ONE pass of the gzip reader on the GPU (nh_gunzip.hip) on 1 x MI355X" % tag)
 print("# command: bash scripts/profile_gunzip.sh %s   (tools/gz_prof_run.py: nh_gunzip_device_file with the reader's defaults -- pieces of 512 MiB" % tag)
 print("#          of gzip in chunks of 64 KiB --, text to a device buffer, written to /dev/null; input: tools/gz_make_input.py, bench.py's e2e FASTQ text, level 6)")
