@@ -3465,10 +3465,12 @@ public:
             const int dev = lanes_[(size_t)b.lane].device;
             (void)hipSetDevice(dev);
             cache_free(dev, room_ + 4096, b.d_text, false);
-            for (void *q : {(void *)b.d_nl, (void *)b.d_tiles, (void *)b.d_recs, (void *)b.d_bstart})
-                if (q) (void)hipFree(q);
-            for (void *q : {(void *)b.h_recs, (void *)b.h_bstart})
-                if (q) (void)hipHostFree(q);
+            cache_free(dev, b.nl_cap * 4, b.d_nl, false);
+            cache_free(dev, b.tile_cap * 4, b.d_tiles, false);
+            cache_free(dev, b.rec_cap * sizeof(RecRef), b.d_recs, false);
+            cache_free(dev, b.bs_cap * 4, b.d_bstart, false);
+            cache_free(dev, b.rec_cap * sizeof(RecRef), b.h_recs, true);
+            cache_free(dev, b.bs_cap * 4, b.h_bstart, true);
         }
         buf_.clear();
         order_.clear();
@@ -3493,6 +3495,7 @@ private:
         bool loaded = false, last = false, indexed = false;  // loaded: handed to the consumer; indexed: its record table is valid
         int outstanding = 0;  // batches handed out and not yet released
         int lane = 0;
+        bool prepared = false;  // prealloc() is through with it
     };
     struct Lane {
         int device = -1;
@@ -3507,13 +3510,47 @@ private:
         if (error_.empty()) error_ = m;
         return -1;
     }
+    // the record index's buffers (a piece of 2.3 GB of text: 9 M newline positions, a 220 MB record table on the device and
+    // page-locked on the host) come from the process-wide store like the decoder's: page-locking the table took 0.1 s a buffer
     template <class T>
-    bool grow_dev(T *&p, size_t &cap, size_t need) {
+    bool grow_dev(int device, T *&p, size_t &cap, size_t need, bool host = false) {
         if (need <= cap) return true;
-        if (p) (void)hipFree(p);
+        cache_free(device, cap * sizeof(T), p, host);
         p = nullptr;
         cap = need + need / 4 + 1024;
-        return hipMalloc((void **)&p, cap * sizeof(T)) == hipSuccess;
+        p = (T *)cache_alloc(device, cap * sizeof(T), host);
+        if (!p) cap = 0;
+        return p != nullptr;
+    }
+    // Before the first piece is indexed: the buffers at the size this file's pieces will need (a guess: 4.5 : 1, records of
+    // 300 bytes), made by a helper while the first piece is still being decoded
+    void prealloc() {
+        struct stat st;
+        size_t text = room_;
+        if (stat(path_.c_str(), &st) == 0 && (uint64_t)st.st_size * 5 < text) text = (size_t)st.st_size * 5;
+        const size_t recs = text / 300 + 4096, lines = 4 * recs + 16, tiles = text / fq::TILE + 2, batches = recs / (bf_ ? bf_ : 1) + 8;
+        for (Piece &p : buf_) {
+            const int dev = lanes_[(size_t)p.lane].device;
+            if (hipSetDevice(dev) != hipSuccess) break;
+            (void)grow_dev(dev, p.d_tiles, p.tile_cap, tiles);
+            (void)grow_dev(dev, p.d_nl, p.nl_cap, lines);
+            if (grow_dev(dev, p.d_recs, p.rec_cap, recs)) {
+                size_t hc = 0;
+                if (!grow_dev(dev, p.h_recs, hc, p.rec_cap, true)) p.rec_cap = 0;  // (the two tables grow together)
+                else if (hc < p.rec_cap) p.rec_cap = hc;
+            }
+            if (grow_dev(dev, p.d_bstart, p.bs_cap, batches)) {
+                size_t hc = 0;
+                if (!grow_dev(dev, p.h_bstart, hc, p.bs_cap, true)) p.bs_cap = 0;
+                else if (hc < p.bs_cap) p.bs_cap = hc;
+            }
+            std::lock_guard<std::mutex> lk(mu_);
+            p.prepared = true;
+            cv_.notify_all();
+        }
+        std::lock_guard<std::mutex> lk(mu_);
+        for (Piece &p : buf_) p.prepared = true;
+        cv_.notify_all();
     }
 
     int emit(HalfBatch &hb, Piece &p, size_t full) {
@@ -3586,6 +3623,13 @@ private:
 
     // the stream's pieces in order: each behind what the one before could not hand out as whole batches
     void produce() {
+        std::thread pre([this] { prealloc(); });
+        struct Join {
+            std::thread &t;
+            ~Join() {
+                if (t.joinable()) t.join();
+            }
+        } join_pre{pre};
         if (ahead_)
             for (size_t g = 0; g < lanes_.size(); g++) lanes_[g].worker = std::thread([this, g] { work(g); });
         for (;;) {
@@ -3698,6 +3742,11 @@ private:
         Lane &ln = lanes_[(size_t)p.lane];
         hipStream_t const stream_ = ln.stream;
         unsigned long long *const d_bad_ = ln.d_bad, *const h_bad_ = ln.h_bad;
+        {
+            std::unique_lock<std::mutex> lk(mu_);
+            cv_.wait(lk, [&] { return p.prepared; });
+        }
+        const int dev = ln.device;
         const auto t0 = std::chrono::steady_clock::now();
         if (p.last) {  // the input's last line may lack its newline
             uint8_t lastc = 0;
@@ -3710,28 +3759,28 @@ private:
         }
         // newlines -> lines -> records
         const uint32_t n_tiles = (uint32_t)((p.text_len + TILE - 1) / TILE);
-        if (!grow_dev(p.d_tiles, p.tile_cap, (size_t)n_tiles + 1)) return fail("the record index's buffers cannot be had");
+        if (!grow_dev(dev, p.d_tiles, p.tile_cap, (size_t)n_tiles + 1)) return fail("the record index's buffers cannot be had");
         hipLaunchKernelGGL(k_nl_count, dim3(n_tiles), dim3(256), 0, stream_, (const uint8_t *)p.d_text, (uint64_t)p.text_len, p.d_tiles);
         hipLaunchKernelGGL(k_nl_scan, dim3(1), dim3(1024), 0, stream_, p.d_tiles, n_tiles);
         uint32_t n_lines = 0;
         if (hipMemcpyAsync(&n_lines, p.d_tiles + n_tiles, 4, hipMemcpyDeviceToHost, stream_) != hipSuccess || hipStreamSynchronize(stream_) != hipSuccess)
             return fail("the newline count could not be read");
-        if (!grow_dev(p.d_nl, p.nl_cap, (size_t)n_lines + 4)) return fail("the record index's buffers cannot be had");
+        if (!grow_dev(dev, p.d_nl, p.nl_cap, (size_t)n_lines + 4)) return fail("the record index's buffers cannot be had");
         if (n_lines) hipLaunchKernelGGL(k_nl_list, dim3(n_tiles), dim3(256), 0, stream_, (const uint8_t *)p.d_text, (uint64_t)p.text_len, (const uint32_t *)p.d_tiles, p.d_nl);
         size_t n_rec = n_lines / 4;
         if (n_rec) {
             const size_t nb = (n_rec + bf_ - 1) / bf_;
             if (n_rec > p.rec_cap) {
-                if (p.h_recs) (void)hipHostFree(p.h_recs);
-                p.h_recs = nullptr;
-                if (!grow_dev(p.d_recs, p.rec_cap, n_rec) || hipHostMalloc((void **)&p.h_recs, p.rec_cap * sizeof(RecRef), hipHostMallocDefault) != hipSuccess)
+                size_t hc = p.rec_cap;
+                if (!grow_dev(dev, p.d_recs, p.rec_cap, n_rec) || !grow_dev(dev, p.h_recs, hc, p.rec_cap, true))
                     return fail("the record table's buffers cannot be had");
+                p.rec_cap = std::min(p.rec_cap, hc);
             }
             if (nb + 1 > p.bs_cap) {
-                if (p.h_bstart) (void)hipHostFree(p.h_bstart);
-                p.h_bstart = nullptr;
-                if (!grow_dev(p.d_bstart, p.bs_cap, nb + 1) || hipHostMalloc((void **)&p.h_bstart, p.bs_cap * 4, hipHostMallocDefault) != hipSuccess)
+                size_t hc = p.bs_cap;
+                if (!grow_dev(dev, p.d_bstart, p.bs_cap, nb + 1) || !grow_dev(dev, p.h_bstart, hc, p.bs_cap, true))
                     return fail("the record table's buffers cannot be had");
+                p.bs_cap = std::min(p.bs_cap, hc);
             }
             *h_bad_ = ~0ull;
             if (hipMemcpyAsync(d_bad_, h_bad_, 8, hipMemcpyHostToDevice, stream_) != hipSuccess) return fail("H2D failed");
