@@ -221,7 +221,10 @@ constexpr uint32_t HASH_BYTES = 5;
 NH_HD inline uint32_t hash_at(uint64_t lo) {
     return (uint32_t)(((lo & ((1ull << (8u * HASH_BYTES)) - 1ull)) * 0x9E3779B97F4A7C15ull) >> 32);
 }
-constexpr uint32_t BUCKET_BITS = 10;
+#ifndef NH_BUCKET_BITS
+#define NH_BUCKET_BITS 10
+#endif
+constexpr uint32_t BUCKET_BITS = NH_BUCKET_BITS;
 // a bucket entry is a position of the region in 16 bits (regions are at most 64 KiB); 0xFFFF = empty: the last
 // position of a full region can never be a candidate (candidates lie before the position that asks)
 constexpr uint32_t EMPTY_ENTRY = 0xFFFFu;

@@ -427,6 +427,32 @@ def test_pieces_decoded_ahead_on_several_lanes(tmp_path, monkeypatch, capfd):
         assert res[tag] == res["one"], tag
 
 
+def test_lanes_with_pieces_the_host_decoder_takes_over(tmp_path, monkeypatch, capfd):
+    """Reads of a million identical bases (text beyond 16 : 1 in a chunk) between ordinary ones: those pieces are decoded by the
+    host decoder -- loudly --, the stream leaves the piece grid and finds back to it; with three lanes decoding ahead the
+    outputs are one engine's and the host reader's."""
+    from nohuman_amd import engine
+    raw1 = open(os.path.join(GOLD, "reads_pe_1.fq"), "rb").read()
+    big = b"@long.%d\n" + b"A" * 1_000_000 + b"\n+\n" + b"I" * 1_000_000 + b"\n"
+    data = raw1 * 30 + big % 1 + raw1 * 25 + big % 2 + big % 3 + raw1 * 40
+    in1 = tmp_path / "r.fq.gz"
+    in1.write_bytes(gzip.compress(data, 6))
+    monkeypatch.setenv("NOHUMAN_BATCH_FRAGS", "2048")
+    monkeypatch.setenv("NOHUMAN_GZDEV_SEG", "262144")
+    monkeypatch.setenv("NOHUMAN_GZDEV_STRETCH", "4096")
+    res = {}
+    for tag, ids, reader in (("one", [0], "device"), ("three", [0, 0, 0], "device"), ("host", [0], "host")):
+        monkeypatch.setenv("NOHUMAN_GZ_READER", reader)
+        o1, k = tmp_path / (tag + "_1"), tmp_path / (tag + ".k")
+        st = engine.run(DB, str(in1), str(o1), kraken_output=str(k), device_ids=ids, threads=4)
+        err = capfd.readouterr().err
+        res[tag] = (o1.read_bytes(), k.read_bytes(), (st.total_sequences, st.classified, st.total_bases))
+        if reader == "device":
+            assert "decoded on the host" in err, err[-1500:]
+    assert res["one"][2][0] == 95 * (len(raw1.split(b"\n")) // 4) + 3
+    assert res["three"] == res["one"] and res["host"] == res["one"]
+
+
 def test_fragments_with_many_taxa_in_concurrent_batches(tmp_path, monkeypatch):
     """Batches in flight on the two stream slots of an engine each carry fragments that hit more than
     64 distinct taxa (second kernel pass): every launch has its own 'left for the second pass' word,
