@@ -174,6 +174,10 @@ static int alloc_table(Engine *e, uint64_t capacity) {
 #endif
         if (capacity >= 0xFFFFFF00ull && !quad) want = 1;
     }
+    // (what earlier runs of the process keep for their next one -- the gzip reader's buffers in HBM, page-locked batch
+    //  buffers -- must not cost a database its table copies: the stores are emptied first)
+    run_cache_trim();
+    dev_cache_trim();
     for (;; want >>= 1) {
         const uint64_t sh = 32 / want;
         const uint64_t stride = ((e->table_cells_alloc + 32 + 31) & ~31ull) - (want > 1 ? sh : 0);

@@ -3362,6 +3362,7 @@ public:
         struct stat st;
         if (stat(path, &st) == 0 && (uint64_t)st.st_size * 16 + ((size_t)64u << 20) < room_) room_ = (size_t)st.st_size * 16 + ((size_t)64u << 20);
         if (const char *e = getenv("NOHUMAN_GZDEV_ROOM")) room_ = std::max<size_t>((size_t)atoll(e), (size_t)1u << 20);
+        if (room_ > ((size_t)4092u << 20)) room_ = (size_t)4092u << 20;  // (32-bit positions in a piece's text)
         buf_.resize(2 * lanes_.size());
         for (size_t i = 0; i < buf_.size(); i++) buf_[i].lane = (int)(i / 2);
         for (;;) {
