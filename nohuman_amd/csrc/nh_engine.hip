@@ -174,15 +174,23 @@ static int alloc_table(Engine *e, uint64_t capacity) {
 #endif
         if (capacity >= 0xFFFFFF00ull && !quad) want = 1;
     }
-    // (what earlier runs of the process keep for their next one -- the gzip reader's buffers in HBM, page-locked batch
-    //  buffers -- must not cost a database its table copies: the stores are emptied first)
-    run_cache_trim();
-    dev_cache_trim();
+    bool trimmed = false;
     for (;; want >>= 1) {
         const uint64_t sh = 32 / want;
         const uint64_t stride = ((e->table_cells_alloc + 32 + 31) & ~31ull) - (want > 1 ? sh : 0);
         const size_t bytes = (size_t)(stride * want + 64) * sizeof(uint32_t) + 256;
-        if (hipMalloc(&e->d_table_raw, bytes) == hipSuccess) {
+        hipError_t he = hipMalloc(&e->d_table_raw, bytes);
+        if (he != hipSuccess && !trimmed) {
+            // what earlier runs of the process keep for their next one (the gzip reader's buffers in HBM, page-locked batch
+            // buffers) must not cost a database its table copies: the stores are emptied and the allocation tried again
+            // (not up front: giving 100 GB back to the driver and taking them again costs a run seconds)
+            (void)hipGetLastError();
+            run_cache_trim();
+            dev_cache_trim();
+            trimmed = true;
+            he = hipMalloc(&e->d_table_raw, bytes);
+        }
+        if (he == hipSuccess) {
             e->d_table = (uint32_t *)(((uintptr_t)e->d_table_raw + 127) & ~(uintptr_t)127);
             e->n_copies = want;
             e->copy_stride = stride;

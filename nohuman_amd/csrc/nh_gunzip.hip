@@ -2427,7 +2427,7 @@ static void cache_free(int device, size_t bytes, void *p, bool host) {
     if (!p) return;
     if (cache_on() && bytes >= ((size_t)16u << 20)) {
         std::lock_guard<std::mutex> lk(g_cache_mu);
-        if (g_cache.size() < 32) {
+        if (g_cache.size() < 96) {
             g_cache.push_back({device, bytes, p, host});
             return;
         }
@@ -3225,8 +3225,11 @@ __global__ __launch_bounds__(256) void k_nl_count(const uint8_t *text, uint64_t 
     for (uint32_t i = threadIdx.x * 16; i < TILE; i += 256 * 16) {
         const uint64_t p = t0 + i;
         if (p + 16 <= n) {
-            const uint4 v = *(const uint4 *)(text + p);  // (the text starts 16-byte aligned)
-            const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+            struct __attribute__((packed)) U16 {
+                uint32_t v[4];
+            };
+            const U16 v = *(const U16 *)(text + p);  // (any alignment: a piece's text starts where the part carried over begins)
+            const uint32_t w[4] = {v.v[0], v.v[1], v.v[2], v.v[3]};
 #pragma unroll
             for (int k = 0; k < 4; k++) {
                 const uint32_t x = w[k] ^ 0x0A0A0A0Au;  // zero bytes where the text has '\n'
@@ -3342,6 +3345,7 @@ public:
         if (!dev_gunzip_wants(path)) return 1;
         if (n_devices < 1) return 1;
         path_ = path;
+        const auto t_open = std::chrono::steady_clock::now();
         // A lane = a device of the run with a buffer set of the decoder, two streams and two text buffers.  One lane: piece
         // after piece, each decoded while the batches of the one before go out.  Several lanes: the pieces of the stream are
         // decoded AHEAD on all lanes at once (DevGunzip::decode_ahead: search and decode need neither the window nor the
@@ -3354,8 +3358,10 @@ public:
             return -1;
         }
         if (gz_.open(path, devices[0], 0, 0, err) != 0) return -1;
+        const double t_a = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_open).count();
         for (int g = 1; g < n_devices; g++)
             if (gz_.add_device(devices[g], err) != g) return -1;
+        const double t_b = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_open).count();
         // text of a piece: 512 MiB of gzip at FASTQ's 4-5 : 1 and the partial batch carried in front of it (the record index
         // addresses a piece's text with 32 bits: below 4 GiB)
         room_ = (size_t)3584u << 20;
@@ -3363,6 +3369,10 @@ public:
         if (stat(path, &st) == 0 && (uint64_t)st.st_size * 16 + ((size_t)64u << 20) < room_) room_ = (size_t)st.st_size * 16 + ((size_t)64u << 20);
         if (const char *e = getenv("NOHUMAN_GZDEV_ROOM")) room_ = std::max<size_t>((size_t)atoll(e), (size_t)1u << 20);
         if (room_ > ((size_t)4092u << 20)) room_ = (size_t)4092u << 20;  // (32-bit positions in a piece's text)
+        // The decoder writes a piece's text at d_text + head_; what the piece before could not hand out as whole batches (less
+        // than a batch of records and an incomplete one) is copied in FRONT of it afterwards, by the index stage -- so the
+        // decode of piece i + 1 does not wait for the index of piece i.
+        head_ = room_ >= ((size_t)2u << 30) ? (size_t)768u << 20 : (room_ / 2 + 4095) & ~(size_t)4095;
         buf_.resize(2 * lanes_.size());
         for (size_t i = 0; i < buf_.size(); i++) buf_[i].lane = (int)(i / 2);
         for (;;) {
@@ -3383,9 +3393,11 @@ public:
             }
             room_ /= 2;
         }
+        const double t_c = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_open).count();
         for (Lane &l : lanes_) {
             if (hipSetDevice(l.device) != hipSuccess || hipStreamCreateWithFlags(&l.stream, hipStreamNonBlocking) != hipSuccess ||
-                hipStreamCreateWithFlags(&l.stream_a, hipStreamNonBlocking) != hipSuccess || hipMalloc((void **)&l.d_bad, 8) != hipSuccess ||
+                hipStreamCreateWithFlags(&l.stream_a, hipStreamNonBlocking) != hipSuccess ||
+                hipStreamCreateWithFlags(&l.stream_i, hipStreamNonBlocking) != hipSuccess || hipMalloc((void **)&l.d_bad, 8) != hipSuccess ||
                 hipHostMalloc((void **)&l.h_bad, 8, hipHostMallocDefault) != hipSuccess) {
                 err = "the gzip reader's buffers cannot be had";
                 return -1;
@@ -3393,6 +3405,9 @@ public:
         }
         ahead_ = lanes_.size() > 1 && gz_.ahead_ok() && !(getenv("NOHUMAN_GZ_AHEAD") && getenv("NOHUMAN_GZ_AHEAD")[0] == '0');
         trace_ = getenv("NOHUMAN_TRACE") != nullptr;
+        open_s_ = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_open).count();
+        if (trace_ && getenv("NOHUMAN_GZDEV_NOCRC"))
+            fprintf(stderr, "[gzdev] reader set-up: decoder %.3f s, further lanes %.3f, text buffers %.3f, streams %.3f\n", t_a, t_b - t_a, t_c - t_b, open_s_ - t_c);
         return 0;
     }
 
@@ -3457,9 +3472,9 @@ public:
             });
         }
         if (trace_ && pieces_)
-            fprintf(stderr, "[nohuman trace] record index on GPU %d (%zu lane%s%s), %s: %llu pieces, %llu records, index kernels + table D2H %.3f s, carried %.2f GB\n",
+            fprintf(stderr, "[nohuman trace] record index on GPU %d (%zu lane%s%s), %s: %llu pieces, %llu records, index kernels + table D2H %.3f s, carried %.2f GB, buffers set up in %.3f s\n",
                     lanes_.empty() ? -1 : lanes_[0].device, lanes_.size(), lanes_.size() == 1 ? "" : "s", ahead_ ? ", pieces decoded ahead" : "", path_.c_str(),
-                    (unsigned long long)pieces_, (unsigned long long)records_, index_s_, carried_ / 1e9);
+                    (unsigned long long)pieces_, (unsigned long long)records_, index_s_, carried_ / 1e9, open_s_);
         pieces_ = 0;
         gz_.close();
         for (Piece &b : buf_) {
@@ -3481,6 +3496,7 @@ public:
             if (l.h_bad) (void)hipHostFree(l.h_bad);
             if (l.stream) (void)hipStreamDestroy(l.stream);
             if (l.stream_a) (void)hipStreamDestroy(l.stream_a);
+            if (l.stream_i) (void)hipStreamDestroy(l.stream_i);
         }
         lanes_.clear();
     }
@@ -3497,10 +3513,14 @@ private:
         int outstanding = 0;  // batches handed out and not yet released
         int lane = 0;
         bool prepared = false;  // prealloc() is through with it
+        uint8_t *text0 = nullptr;  // where the piece's text begins: d_text + head_ - (what was carried over from the piece before)
+        size_t body_len = 0;       // bytes the decoder wrote at d_text + head_
+        bool in_pipe = false;      // between the decode stage and its publication
+        bool tail_needed = false;  // published, and the piece after it has not taken its tail yet
     };
     struct Lane {
         int device = -1;
-        hipStream_t stream = nullptr, stream_a = nullptr;  // the stream's own work; a piece decoded ahead
+        hipStream_t stream = nullptr, stream_a = nullptr, stream_i = nullptr;  // the stream's own work; a piece decoded ahead; the index stage
         unsigned long long *d_bad = nullptr, *h_bad = nullptr;
         std::thread worker;
         int state = 0;      // 0 idle, 1 a cell is being decoded ahead, 2 decoded
@@ -3527,10 +3547,21 @@ private:
     // 300 bytes), made by a helper while the first piece is still being decoded
     void prealloc() {
         struct stat st;
+        memset(&st, 0, sizeof st);
         size_t text = room_;
         if (stat(path_.c_str(), &st) == 0 && (uint64_t)st.st_size * 5 < text) text = (size_t)st.st_size * 5;
         const size_t recs = text / 300 + 4096, lines = 4 * recs + 16, tiles = text / fq::TILE + 2, batches = recs / (bf_ ? bf_ : 1) + 8;
-        for (Piece &p : buf_) {
+        // (no more buffers than the file has pieces: page-locking a record table is 0.1 s, and a run over three lanes has twelve)
+        size_t want = buf_.size();
+        if (st.st_size > 0) want = std::min<size_t>(want, (size_t)((uint64_t)st.st_size / ((uint64_t)512u << 20)) + 2);
+        // the decode stage takes lane 0's buffers first, then the other lanes' in turn
+        std::vector<size_t> turn;
+        for (size_t k = 0; k < 2; k++)
+            for (size_t g = 0; g < lanes_.size(); g++) turn.push_back(2 * g + k);
+        size_t made = 0;
+        for (size_t bi : turn) {
+            Piece &p = buf_[bi];
+            if (made++ >= want) break;
             const int dev = lanes_[(size_t)p.lane].device;
             if (hipSetDevice(dev) != hipSuccess) break;
             (void)grow_dev(dev, p.d_tiles, p.tile_cap, tiles);
@@ -3568,7 +3599,7 @@ private:
             return 0;
         }
         hb.text.set_size(len);
-        hb.dev_text = p.d_text + t0;
+        hb.dev_text = p.text0 + t0;
         hb.dev_device = lanes_[(size_t)p.lane].device;
         hb.host_text_valid = false;
         p.next_rec = r1;
@@ -3622,24 +3653,30 @@ private:
         cv_.notify_all();
     }
 
-    // the stream's pieces in order: each behind what the one before could not hand out as whole batches
+    // Two stages.  DECODE (this thread): the stream's pieces in order -- which lane, a free text buffer there, the decoder
+    // (DevGunzip::take / next_on) writes the text at d_text + head_.  INDEX (a thread of its own, in the same order): what
+    // the piece before could not hand out as whole batches goes in front of the text, newline scan, record table, and the
+    // piece is published to next_batch().  The decode of piece i + 1 runs while piece i is indexed.
     void produce() {
         std::thread pre([this] { prealloc(); });
+        std::thread ix([this] { index_stage(); });
         struct Join {
-            std::thread &t;
+            std::thread &a, &b;
             ~Join() {
-                if (t.joinable()) t.join();
+                if (a.joinable()) a.join();
+                if (b.joinable()) b.join();
             }
-        } join_pre{pre};
+        } join_them{pre, ix};
         if (ahead_)
             for (size_t g = 0; g < lanes_.size(); g++) lanes_[g].worker = std::thread([this, g] { work(g); });
         for (;;) {
             bool last = false;
             const int rc = load_next(last);
             std::lock_guard<std::mutex> lk(mu_);
-            if (rc != 0 || last || stop_) {
+            if (rc != 0 || last || stop_ || done_) {
                 if (rc == 1) fallback_ = true;
-                done_ = true;
+                if (rc != 0) done_ = true;  // (an error: nothing more comes; the end of the input: the index stage says so)
+                decode_done_ = true;
                 cv_.notify_all();
                 return;
             }
@@ -3647,7 +3684,6 @@ private:
     }
 
     int load_next(bool &last) {
-        using namespace fq;
         // ---- which lane takes the stream's next piece
         size_t g = piece_no_ % lanes_.size();
         bool use_ahead = false;
@@ -3673,8 +3709,8 @@ private:
                 }
             }
             g = pick;
-            cv_.wait(lk, [&] { return lanes_[g].state != 1 || stop_; });
-            if (stop_) return -2;
+            cv_.wait(lk, [&] { return lanes_[g].state != 1 || stop_ || done_; });
+            if (stop_ || done_) return -2;
             lanes_[g].state = 3;  // the stream's own (not idle: no new cell until the piece is through)
         }
         Lane &ln = lanes_[g];
@@ -3684,15 +3720,66 @@ private:
             std::unique_lock<std::mutex> lk(mu_);
             cv_.wait(lk, [&] {
                 for (size_t i = 2 * g; i < 2 * g + 2; i++)
-                    if (!buf_[i].loaded && buf_[i].outstanding == 0 && &buf_[i] != last_) {
+                    if (!buf_[i].loaded && buf_[i].outstanding == 0 && !buf_[i].in_pipe && !buf_[i].tail_needed) {
                         pp = &buf_[i];
                         return true;
                     }
-                return stop_;
+                return stop_ || done_;
             });
             if (!pp) return -2;
+            pp->in_pipe = true;
         }
         Piece &p = *pp;
+        if (hipSetDevice(ln.device) != hipSuccess) return fail("hipSetDevice failed");
+        const long n = ahead_ ? gz_.take((int)g, use_ahead, p.d_text + head_, room_ - head_, ln.stream)
+                              : gz_.next_on((int)g, p.d_text + head_, room_ - head_, ln.stream);
+        if (ahead_) {
+            std::lock_guard<std::mutex> lk(mu_);
+            ln.state = 0;
+        }
+        if (n < 0) return fail(gz_.error());
+        if (ahead_ && gz_.ahead_ok() && !gz_.ended()) assign_ahead();  // (this lane's next cell is decoded while its piece is indexed)
+        p.body_len = (size_t)n;
+        p.last = gz_.ended();
+        last = p.last;
+        piece_no_++;
+        {
+            std::lock_guard<std::mutex> lk(mu_);
+            indexq_.push_back((size_t)(pp - &buf_[0]));
+        }
+        cv_.notify_all();
+        return 0;
+    }
+
+    void index_stage() {
+        for (;;) {
+            Piece *pp = nullptr;
+            {
+                std::unique_lock<std::mutex> lk(mu_);
+                cv_.wait(lk, [&] { return !indexq_.empty() || decode_done_ || stop_ || done_; });
+                if (stop_ || done_ || indexq_.empty()) {
+                    if (!done_) {  // (the decode stage ended without an error and everything it made is published)
+                        done_ = true;
+                        cv_.notify_all();
+                    }
+                    return;
+                }
+                pp = &buf_[indexq_.front()];
+                indexq_.pop_front();
+            }
+            const int rc = index_piece(*pp);
+            std::lock_guard<std::mutex> lk(mu_);
+            if (rc != 0 || pp->last) {
+                if (rc == 1) fallback_ = true;
+                done_ = true;
+                cv_.notify_all();
+                return;
+            }
+        }
+    }
+
+    int index_piece(Piece &p) {
+        Lane &ln = lanes_[(size_t)p.lane];
         if (hipSetDevice(ln.device) != hipSuccess) return fail("hipSetDevice failed");
         size_t carry = 0;
         if (last_ && last_->indexed) {
@@ -3701,37 +3788,34 @@ private:
             const size_t full = old.n_rec / bf_ * bf_;
             const size_t from = full < old.n_rec ? old.h_bstart[full / bf_] : old.used_len;
             carry = old.text_len - from;
-            if (carry >= room_) return fail("a FASTQ record larger than the gzip reader's text buffer");
+            if (carry > head_) return fail("a batch of FASTQ records larger than the gzip reader's buffer holds in front of a piece");
             const int odev = lanes_[(size_t)old.lane].device;
-            if (carry && (odev == ln.device ? hipMemcpyAsync(p.d_text, old.d_text + from, carry, hipMemcpyDeviceToDevice, ln.stream)
-                                            : hipMemcpyPeerAsync(p.d_text, ln.device, old.d_text + from, odev, carry, ln.stream)) != hipSuccess)
+            uint8_t *const dst = p.d_text + head_ - carry;
+            if (carry && ((odev == ln.device ? hipMemcpyAsync(dst, old.text0 + from, carry, hipMemcpyDeviceToDevice, ln.stream_i)
+                                             : hipMemcpyPeerAsync(dst, ln.device, old.text0 + from, odev, carry, ln.stream_i)) != hipSuccess ||
+                          hipStreamSynchronize(ln.stream_i) != hipSuccess))
                 return fail("D2D of the carried text failed");
             carried_ += carry;
-        }
-        const long n = ahead_ ? gz_.take((int)g, use_ahead, p.d_text + carry, room_ - carry, ln.stream)
-                              : gz_.next_on((int)g, p.d_text + carry, room_ - carry, ln.stream);
-        if (ahead_) {
             std::lock_guard<std::mutex> lk(mu_);
-            ln.state = 0;
+            old.tail_needed = false;
+            cv_.notify_all();
         }
-        if (n < 0) return fail(gz_.error());
-        if (ahead_ && gz_.ahead_ok() && !gz_.ended()) assign_ahead();  // (this lane's next cell is decoded while its piece is indexed)
-        p.text_len = carry + (size_t)n;
-        p.last = gz_.ended();
+        p.text0 = p.d_text + head_ - carry;
+        p.text_len = carry + p.body_len;
         p.n_rec = p.next_rec = 0;
         p.used_len = 0;
         p.indexed = false;
         pieces_++;
-        piece_no_++;
         const int irc = p.text_len ? index(p) : 0;
         if (irc != 0) return irc;
         p.indexed = true;
-        last = p.last;
         last_ = &p;
         {
             std::lock_guard<std::mutex> lk(mu_);
             p.loaded = true;
-            order_.push_back((size_t)(pp - &buf_[0]));
+            p.in_pipe = false;
+            p.tail_needed = !p.last;
+            order_.push_back((size_t)(&p - &buf_[0]));
         }
         cv_.notify_all();
         return 0;
@@ -3741,7 +3825,7 @@ private:
     int index(Piece &p) {
         using namespace fq;
         Lane &ln = lanes_[(size_t)p.lane];
-        hipStream_t const stream_ = ln.stream;
+        hipStream_t const stream_ = ln.stream_i;
         unsigned long long *const d_bad_ = ln.d_bad, *const h_bad_ = ln.h_bad;
         {
             std::unique_lock<std::mutex> lk(mu_);
@@ -3751,23 +3835,23 @@ private:
         const auto t0 = std::chrono::steady_clock::now();
         if (p.last) {  // the input's last line may lack its newline
             uint8_t lastc = 0;
-            if (hipMemcpyAsync(&lastc, p.d_text + p.text_len - 1, 1, hipMemcpyDeviceToHost, stream_) != hipSuccess || hipStreamSynchronize(stream_) != hipSuccess)
+            if (hipMemcpyAsync(&lastc, p.text0 + p.text_len - 1, 1, hipMemcpyDeviceToHost, stream_) != hipSuccess || hipStreamSynchronize(stream_) != hipSuccess)
                 return fail("reading the text's last byte failed");
             if (lastc != '\n') {
-                if (hipMemsetAsync(p.d_text + p.text_len, '\n', 1, stream_) != hipSuccess) return fail("hipMemsetAsync failed");
+                if (hipMemsetAsync(p.text0 + p.text_len, '\n', 1, stream_) != hipSuccess) return fail("hipMemsetAsync failed");
                 p.text_len++;
             }
         }
         // newlines -> lines -> records
         const uint32_t n_tiles = (uint32_t)((p.text_len + TILE - 1) / TILE);
         if (!grow_dev(dev, p.d_tiles, p.tile_cap, (size_t)n_tiles + 1)) return fail("the record index's buffers cannot be had");
-        hipLaunchKernelGGL(k_nl_count, dim3(n_tiles), dim3(256), 0, stream_, (const uint8_t *)p.d_text, (uint64_t)p.text_len, p.d_tiles);
+        hipLaunchKernelGGL(k_nl_count, dim3(n_tiles), dim3(256), 0, stream_, (const uint8_t *)p.text0, (uint64_t)p.text_len, p.d_tiles);
         hipLaunchKernelGGL(k_nl_scan, dim3(1), dim3(1024), 0, stream_, p.d_tiles, n_tiles);
         uint32_t n_lines = 0;
         if (hipMemcpyAsync(&n_lines, p.d_tiles + n_tiles, 4, hipMemcpyDeviceToHost, stream_) != hipSuccess || hipStreamSynchronize(stream_) != hipSuccess)
             return fail("the newline count could not be read");
         if (!grow_dev(dev, p.d_nl, p.nl_cap, (size_t)n_lines + 4)) return fail("the record index's buffers cannot be had");
-        if (n_lines) hipLaunchKernelGGL(k_nl_list, dim3(n_tiles), dim3(256), 0, stream_, (const uint8_t *)p.d_text, (uint64_t)p.text_len, (const uint32_t *)p.d_tiles, p.d_nl);
+        if (n_lines) hipLaunchKernelGGL(k_nl_list, dim3(n_tiles), dim3(256), 0, stream_, (const uint8_t *)p.text0, (uint64_t)p.text_len, (const uint32_t *)p.d_tiles, p.d_nl);
         size_t n_rec = n_lines / 4;
         if (n_rec) {
             const size_t nb = (n_rec + bf_ - 1) / bf_;
@@ -3785,7 +3869,7 @@ private:
             }
             *h_bad_ = ~0ull;
             if (hipMemcpyAsync(d_bad_, h_bad_, 8, hipMemcpyHostToDevice, stream_) != hipSuccess) return fail("H2D failed");
-            hipLaunchKernelGGL(k_records, dim3((unsigned)((n_rec + 255) / 256)), dim3(256), 0, stream_, (const uint8_t *)p.d_text, (const uint32_t *)p.d_nl,
+            hipLaunchKernelGGL(k_records, dim3((unsigned)((n_rec + 255) / 256)), dim3(256), 0, stream_, (const uint8_t *)p.text0, (const uint32_t *)p.d_nl,
                                (uint32_t)n_rec, (uint32_t)bf_, p.d_recs, p.d_bstart, d_bad_);
             if (hipMemcpyAsync(h_bad_, d_bad_, 8, hipMemcpyDeviceToHost, stream_) != hipSuccess ||
                 hipMemcpyAsync(p.h_recs, p.d_recs, n_rec * sizeof(RecRef), hipMemcpyDeviceToHost, stream_) != hipSuccess ||
@@ -3801,7 +3885,7 @@ private:
                     const size_t b = br / bf_;
                     const size_t at = (size_t)p.h_bstart[b] + p.h_recs[br].h;
                     std::vector<char> line(std::min<size_t>(p.h_recs[br].hlen, 200));
-                    (void)hipMemcpy(line.data(), p.d_text + at, line.size(), hipMemcpyDeviceToHost);
+                    (void)hipMemcpy(line.data(), p.text0 + at, line.size(), hipMemcpyDeviceToHost);
                     return fail("malformed FASTQ file (exp. '@', saw \"" + std::string(line.begin(), line.end()) + "\"), aborting");
                 }
                 // an empty header line (or "@" alone): kraken2 stops reading there
@@ -3825,7 +3909,7 @@ private:
         // FASTA, or nothing recognisable, in the very first piece: not ours
         if (!handed_out_ && pieces_ == 1 && p.text_len) {
             uint8_t c0 = 0;
-            (void)hipMemcpy(&c0, p.d_text, 1, hipMemcpyDeviceToHost);
+            (void)hipMemcpy(&c0, p.text0, 1, hipMemcpyDeviceToHost);
             if (c0 != '@') return 1;
         }
         index_s_ += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
@@ -3837,6 +3921,9 @@ private:
     std::vector<Lane> lanes_;
     std::vector<Piece> buf_;
     std::deque<size_t> order_;   // the pieces handed to the consumer, in stream order (indices into buf_)
+    std::deque<size_t> indexq_;  // decoded, waiting for the index stage
+    size_t head_ = 0;            // room in front of a piece's text for what is carried over from the piece before
+    bool decode_done_ = false;
     Piece *last_ = nullptr;      // the piece produced last: what it could not hand out as whole batches goes in front of the next
     uint64_t piece_no_ = 0, next_cell_ = 0;
     bool ahead_ = false;
@@ -3845,7 +3932,7 @@ private:
     bool stop_ = false, done_ = false, fallback_ = false;
     bool handed_out_ = false, trace_ = false;
     uint64_t pieces_ = 0, records_ = 0, carried_ = 0;
-    double index_s_ = 0;
+    double index_s_ = 0, open_s_ = 0;
     std::mutex mu_;
     std::condition_variable cv_;
 };
