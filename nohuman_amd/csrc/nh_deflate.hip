@@ -559,7 +559,7 @@ int gzip_ways() {
     static const int w = [] {
         const char *e = getenv("NOHUMAN_GZIP_WAYS");
         const int v = e ? atoi(e) : 8;
-        return v == 4 ? 4 : 8;
+        return v == 4 ? 4 : v == 6 ? 6 : 8;
     }();
     return w;
 }
@@ -766,6 +766,8 @@ struct DeflateDev {  // device side of one encoder: buffers for chunks in flight
                 a.prof = nullptr;
                 if (gzip_ways() == 4)
                     hipLaunchKernelGGL(dfl::k_deflate<4>, dim3(nr), dim3(64), 0, stream, a);
+                else if (gzip_ways() == 6)
+                    hipLaunchKernelGGL(dfl::k_deflate<6>, dim3(nr), dim3(64), 0, stream, a);
                 else
                     hipLaunchKernelGGL(dfl::k_deflate<8>, dim3(nr), dim3(64), 0, stream, a);
             }
@@ -815,6 +817,8 @@ struct DeflateDev {  // device side of one encoder: buffers for chunks in flight
         (void)hipEventRecord(b.k0, stream);
         if (gzip_ways() == 4)
             hipLaunchKernelGGL(dfl::k_deflate<4>, dim3(b.n_regions), dim3(64), 0, stream, a);
+        else if (gzip_ways() == 6)
+            hipLaunchKernelGGL(dfl::k_deflate<6>, dim3(b.n_regions), dim3(64), 0, stream, a);
         else
             hipLaunchKernelGGL(dfl::k_deflate<8>, dim3(b.n_regions), dim3(64), 0, stream, a);
         hipLaunchKernelGGL(dfl::k_deflate_offsets, dim3(1), dim3(64), 0, stream, b.d_sizes, b.n_regions, b.d_offsets);
