@@ -1,7 +1,7 @@
 """Differential soak of nh_run's two gzip readers: random FASTQ files with every oddity of the record semantics (CRLF, "+id"
 lines, trailing blanks on any line, lower case, N, empty sequences, a missing final newline, a truncated last record, an empty
 header line in the middle -- kraken2 stops there --, mates of unequal record counts), gzip at random levels and member cuts,
-random batch / piece / chunk sizes, single-end and paired, plain and gzip outputs, classified-out and unclassified-out:
+random batch / piece / chunk sizes, one to three lanes of the reader (pieces decoded ahead), single-end and paired, plain and gzip outputs, classified-out and unclassified-out:
 the reader on the GPU (inflate + record index there) must write exactly what the host reader writes.
     python tools/run_soak.py [cases=200] [seed=1]"""
 import gzip, os, sys, tempfile, zlib
@@ -74,6 +74,12 @@ for k in range(cases):
     os.environ["NOHUMAN_BATCH_FRAGS"] = str(int(rng.choice([16, 64, 500, 4096])))
     os.environ["NOHUMAN_GZDEV_SEG"] = str(int(rng.choice([16384, 65536, 1 << 20])))
     os.environ["NOHUMAN_GZDEV_STRETCH"] = str(int(rng.choice([1024, 2048, 8192])))
+    lanes = int(rng.choice([1, 1, 2, 3]))  # several lanes of the reader on the one device: pieces decoded ahead of the stream
+    os.environ.pop("NOHUMAN_GZ_LANES", None)
+    if lanes > 1:
+        os.environ["NOHUMAN_GZ_LANES"] = str(lanes)
+        os.environ["NOHUMAN_GZDEV_STRETCH"] = str(int(rng.choice([4096, 8192])))
+        os.environ["NOHUMAN_GZDEV_SEG"] = str(int(rng.choice([16384, 65536, 262144])))
     res = {}
     for reader in ("device", "host"):
         os.environ["NOHUMAN_GZ_READER"] = reader
@@ -95,8 +101,8 @@ for k in range(cases):
         if paired:
             open(os.path.join(keep, "a_2.fq.gz"), "wb").write(open(f2, "rb").read())
         dv, hv = res["device"], res["host"]
-        print("CASE %d DIFFERS: paired %s odd %s n %d kw %s batch %s seg %s stretch %s" % (k, paired, odd, n, kw, os.environ["NOHUMAN_BATCH_FRAGS"],
-              os.environ["NOHUMAN_GZDEV_SEG"], os.environ["NOHUMAN_GZDEV_STRETCH"]))
+        print("CASE %d DIFFERS: paired %s odd %s n %d kw %s batch %s seg %s stretch %s lanes %d" % (k, paired, odd, n, kw, os.environ["NOHUMAN_BATCH_FRAGS"],
+              os.environ["NOHUMAN_GZDEV_SEG"], os.environ["NOHUMAN_GZDEV_STRETCH"], lanes))
         print("   device:", [x if not isinstance(x, bytes) else (len(x), zlib.crc32(x)) for x in dv])
         print("   host  :", [x if not isinstance(x, bytes) else (len(x), zlib.crc32(x)) for x in hv], flush=True)
         if bad >= 5:
