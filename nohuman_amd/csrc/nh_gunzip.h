@@ -90,7 +90,7 @@ public:
     ~DevFastqReader();
     DevFastqReader(const DevFastqReader &) = delete;
     DevFastqReader &operator=(const DevFastqReader &) = delete;
-    // 0 ok; -1 error (err); 1: not a file this reader takes (no regular gzip file, BGZF): use BlockReader.
+    // 0 ok; -1 error (err); 1: not a file this reader takes (no regular gzip file): use BlockReader.
     // devices: the GPUs of the run, this file's first one first -- piece i of the stream is inflated and indexed on
     // devices[i mod n], and its batches say so (HalfBatch::dev_device: nh_run classifies them where they were born).
     int open(const char *path, const int *devices, int n_devices, std::string &err);
@@ -105,8 +105,7 @@ private:
     DevFastqImpl *impl_;
 };
 
-// Is the file one the device reader takes (a regular gzip file; not BGZF, whose members hold a single final block each
-// and give the block search nothing to find -- the host reader takes those)?
+// Is the file one the device reader takes (a regular gzip file; BGZF as well: its chunks' starts come from the members' headers)?
 bool dev_gunzip_wants(const char *path);
 
 }  // namespace nh

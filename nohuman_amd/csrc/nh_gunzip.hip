@@ -1392,7 +1392,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(5, 8))) void
         // Huffman): the empty stored block of a flush point (pigz, gzp: one every 128-512 KiB of text), a fixed or a final
         // block are decoded with this chunk.  So a piece ends exactly where the piece decoded ahead of the stream for the
         // next cell of the grid begins (every eighth was refused on gzp's output before this).
-        if (bitpos >= stop_bit && (bitpos + 3 > valid_bits || (bits_at(bytes, bitpos) & 7u) == 4u)) break;
+        // (at_eof bit 1: BGZF -- every member is one final block and the chunks' starts are the members' own, so any boundary ends the chunk)
+        if (bitpos >= stop_bit && ((at_eof & 2u) || bitpos + 3 > valid_bits || (bits_at(bytes, bitpos) & 7u) == 4u)) break;
         if (bitpos + 3 > valid_bits) {
             status = ST_INPUT;
             break;
@@ -1655,11 +1656,11 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(5, 8))) void
             n_members++;
             q += 8;
             bool member = false, trunc = false;
-            if (q == valid_bytes && at_eof) {
+            if (q == valid_bytes && (at_eof & 1u)) {
                 member = false;
             } else if (q + 10 > valid_bytes) {
                 const uint64_t hv = bits_at(bytes, q * 8);
-                if (at_eof && !(q + 2 <= valid_bytes && (hv & 0xFFFF) == 0x8B1F)) member = false;
+                if ((at_eof & 1u) && !(q + 2 <= valid_bytes && (hv & 0xFFFF) == 0x8B1F)) member = false;
                 else trunc = true;
             } else {
                 const uint64_t hv = bits_at(bytes, q * 8);
@@ -2448,6 +2449,7 @@ class DevGunzipImpl {
         uint32_t n_str = 0, redo = 0;
         uint64_t valid_bits = 0, end_bit = 0;
         bool at_eof = false, valid = false;
+        bool by_headers = false;    // BGZF: the chunks start at members (no window, no markers: nothing to scan)
         SegResult r{};
     };
 
@@ -2465,6 +2467,7 @@ class DevGunzipImpl {
         SegResult *d_res_ = nullptr, *h_res_ = nullptr;
         hipEvent_t ev_[7] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
         uint64_t pieces = 0;
+        uint64_t *h_start_ = nullptr;  // BGZF: the chunks' starts, computed on the host from the members' headers
         PieceJob spec;           // a cell of the piece grid decoded ahead of the stream on this set (phase A only)
         uint64_t spec_cell = 0;
     };
@@ -2510,6 +2513,13 @@ public:
         }
         pos_bit_ = (uint64_t)(d - base_) * 8;
         grid0_ = (uint64_t)(d - base_) / ALIGN * ALIGN;
+        // BGZF (bgzip, htslib): every member is ONE final block of at most 64 KiB of text and says its own size in the 'B' 'C'
+        // subfield of its header.  Nothing for the block search to find -- and nothing to search for: the chunks' starts are
+        // read off the headers, a chunk never needs a window, and the members' CRCs are checked like any other's.
+        bgzf_ = bgzf_block_size(0) != 0 && !getenv("NOHUMAN_GZDEV_NO_BGZF");
+        bgzf_hdr_ = 0;
+        if (bgzf_ && !stretch_bytes) stretch_bytes = (size_t)16u << 10;  // (a member of FASTQ text is 15-20 KB: one or two a chunk, four at most)
+        if (bgzf_ && !seg_bytes) seg_bytes = (size_t)256u << 20;
         if (const char *e = getenv("NOHUMAN_GZDEV_SEG")) seg_bytes = (size_t)atol(e);
         if (const char *e = getenv("NOHUMAN_GZDEV_STRETCH")) stretch_bytes = (size_t)atol(e);
         // defaults (profiles/r04_inflate_summary.txt, sweep of piece and chunk sizes on 6.4 GB of text): pieces of 512 MiB of gzip in
@@ -2581,7 +2591,8 @@ public:
                   hipMalloc((void **)&d.d_toff_, (size_t)n_slots_ * 8) == hipSuccess &&
                   hipMalloc((void **)&d.d_win_[0], WSIZE) == hipSuccess && hipMalloc((void **)&d.d_win_[1], WSIZE) == hipSuccess &&
                   hipMalloc((void **)&d.d_res_, sizeof(SegResult)) == hipSuccess &&
-                  hipHostMalloc((void **)&d.h_res_, sizeof(SegResult), hipHostMallocDefault) == hipSuccess;
+                  hipHostMalloc((void **)&d.h_res_, sizeof(SegResult), hipHostMallocDefault) == hipSuccess &&
+                  (!bgzf_ || hipHostMalloc((void **)&d.h_start_, (size_t)n_slots_ * 8, hipHostMallocDefault) == hipSuccess);
         if (ok) ok = hipMemset(d.d_win_[0], 0, WSIZE) == hipSuccess;  // (the input buffer's tail is zeroed with every piece's upload)
         if (ok)
             ok = hipFuncSetAttribute((const void *)k_search, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(Lds)) == hipSuccess &&
@@ -2605,7 +2616,7 @@ public:
         cache_free(d.device_, maps_bytes_ / 2, d.d_windows_, false);
         for (void *p : {(void *)d.d_start_, (void *)d.d_desc_, (void *)d.d_toff_, (void *)d.d_win_[0], (void *)d.d_win_[1], (void *)d.d_res_})
             if (p) (void)hipFree(p);
-        for (void *p : {(void *)d.h_desc_, (void *)d.h_res_})
+        for (void *p : {(void *)d.h_desc_, (void *)d.h_res_, (void *)d.h_start_})
             if (p) (void)hipHostFree(p);
         for (auto &e : d.ev_)
             if (e) {
@@ -2740,6 +2751,54 @@ private:
     // everything that needs neither the window nor the stream's state, so a piece AHEAD of the stream can run it (first_bit
     // NONE: no known start; the reader over several devices decodes the pieces of the grid concurrently this way).  B:
     // windows, text, CRCs, the window behind the piece, the member bookkeeping -- in stream order.
+    // BGZF: the member whose header starts at byte h of the file: its whole size (0: no BGZF member there) and where its data begin
+    uint64_t bgzf_block_size(uint64_t h, uint64_t *data_at = nullptr) const {
+        if (h + 18 > size_) return 0;
+        const uint8_t *q = base_ + h;
+        if (q[0] != 0x1f || q[1] != 0x8b || q[2] != 8 || !(q[3] & 4) || (q[3] & 0xE0)) return 0;
+        const uint32_t xlen = q[10] | ((uint32_t)q[11] << 8);
+        if (h + 12 + xlen > size_) return 0;
+        uint64_t bsize = 0;
+        for (uint32_t o = 0; o + 4 <= xlen;) {  // the subfields: SI1 SI2 LEN(2) data
+            const uint8_t *f = q + 12 + o;
+            const uint32_t len = f[2] | ((uint32_t)f[3] << 8);
+            if (f[0] == 'B' && f[1] == 'C' && len == 2 && o + 6 <= xlen) bsize = (uint64_t)(f[4] | ((uint32_t)f[5] << 8)) + 1;
+            o += 4 + len;
+        }
+        if (q[3] & (8 | 16 | 2)) return 0;  // (a name, a comment or a header CRC: bgzip writes none; such a file takes the search's way)
+        if (bsize < 12 + xlen + 8 || h + bsize > size_) return 0;
+        if (data_at) *data_at = h + 12 + xlen;
+        return bsize;
+    }
+    // the chunks' starts of a piece from the members' headers: chunk c starts at the first member whose data begin in stretch c
+    bool bgzf_starts(DevSet &d, const PieceJob &j, uint32_t n_str) {
+        for (uint32_t c = 0; c < n_str; c++) d.h_start_[c] = NONE;
+        d.h_start_[0] = j.first_bit;
+        // the member the stream stands at: walk on from the last one known
+        uint64_t h = bgzf_hdr_;
+        const uint64_t pos_byte = j.a_byte + (j.first_bit >> 3);
+        for (;;) {
+            uint64_t at = 0;
+            const uint64_t bs = bgzf_block_size(h, &at);
+            if (!bs) return false;
+            if (at == pos_byte) break;
+            if (at > pos_byte) return false;
+            h += bs;
+        }
+        bgzf_hdr_ = h;
+        const uint64_t end_byte = j.a_byte + (uint64_t)n_str * stretch_;
+        for (;;) {
+            uint64_t at = 0;
+            const uint64_t bs = bgzf_block_size(h, &at);
+            if (!bs || at >= end_byte) break;
+            const uint64_t bit = 8 * (at - j.a_byte);
+            const uint32_t c = (uint32_t)(bit / (8 * (uint64_t)stretch_));
+            if (c > 0 && c < n_str && d.h_start_[c] == NONE && bit > j.first_bit) d.h_start_[c] = bit;
+            h += bs;
+        }
+        return true;
+    }
+
     long phase_a(DevSet &d, PieceJob &j, hipStream_t stream, bool spec) {
         auto bad = [&](const std::string &m) -> long { return spec ? -1 : fail(m); };
 #define GZA_TRY(x)                                                                      \
@@ -2765,7 +2824,15 @@ private:
         if (j.limit_bits && j.limit_bits < end_bit) end_bit = j.limit_bits;
         j.end_bit = end_bit;
         if (trace_) (void)hipEventRecord(d.ev_[0], stream);
-        if (v1_)
+        bool by_headers = false;
+        if (bgzf_ && !spec && d.h_start_ && j.first_bit != NONE) {
+            by_headers = bgzf_starts(d, j, n_str);
+            j.by_headers = by_headers;
+            if (by_headers) GZA_TRY(hipMemcpyAsync(d.d_start_, d.h_start_, (size_t)n_str * 8, hipMemcpyHostToDevice, stream));
+            else bgzf_ = false;  // (the headers do not go on as they began: an ordinary gzip stream from here on)
+        }
+        if (by_headers) {
+        } else if (v1_)
             hipLaunchKernelGGL(k_search, dim3(n_str), dim3(64), sizeof(Lds), stream, (const uint32_t *)d.d_in_, valid_bits, (uint64_t)stretch_ * 8,
                                j.first_bit, d.d_start_);
         else if (v2_)
@@ -2791,8 +2858,9 @@ private:
         }
         hipLaunchKernelGGL(k_plan, dim3(1), dim3(1024), 0, stream, (const uint64_t *)d.d_start_, n_str, end_bit, slot_syms_, d.d_desc_);
         if (trace_) (void)hipEventRecord(d.ev_[1], stream);
+        const uint32_t kflags = (j.at_eof ? 1u : 0u) | (by_headers && !v1_ && !v2_ ? 2u : 0u);
         hipLaunchKernelGGL(inflate_kernel(), dim3(n_str), dim3(64), inflate_lds(), stream, (const uint32_t *)d.d_in_, valid_bits,
-                           j.at_eof ? 1u : 0u, d.d_desc_, d.d_sym_, slot_syms_, NOIDX);
+                           kflags, d.d_desc_, d.d_sym_, slot_syms_, NOIDX);
         if (fake_end >= 0) hipLaunchKernelGGL(k_test_mark_end, dim3(1), dim3(1), 0, stream, d.d_desc_, (uint32_t)fake_end);
         if (trace_) (void)hipEventRecord(d.ev_[2], stream);
         uint32_t redo = 0;
@@ -2818,7 +2886,7 @@ private:
             }
             if (d.h_desc_[prev].bit_start == NONE) return bad("the chunks of a piece do not chain");  // (the struck one was the piece's first)
             hipLaunchKernelGGL(inflate_kernel(), dim3(1), dim3(64), inflate_lds(), stream, (const uint32_t *)d.d_in_, valid_bits,
-                               j.at_eof ? 1u : 0u, d.d_desc_, d.d_sym_, slot_syms_, prev);
+                               kflags, d.d_desc_, d.d_sym_, slot_syms_, prev);
             redo++;
             if (redo > n_str) return bad("the chunks of a piece do not chain");
         }
@@ -2848,7 +2916,9 @@ private:
         // windows by the prefix scan, text, CRCs, the window behind the piece
         if (trace_) (void)hipEventRecord(d.ev_[3], stream);
         const uint32_t gy = 4;
-        if (scan_rounds_) {
+        if (j.by_headers) {
+            // (every chunk starts at a member's first block: it has no window and leaves no markers)
+        } else if (scan_rounds_) {
             hipLaunchKernelGGL(k_maps, dim3(n_str, gy), dim3(256), 0, stream, (const ChunkDesc *)d.d_desc_, (const uint16_t *)d.d_sym_, slot_syms_,
                                d.d_maps_[0]);
             int cur = 0;
@@ -2989,7 +3059,7 @@ private:
     uint64_t cell_bytes() const { return (uint64_t)n_slots_ * stretch_; }
     uint64_t cell_of_pos() const { return ((pos_bit_ >> 3) - grid0_) / cell_bytes(); }
     uint64_t cells() const { return (size_ - grid0_ + cell_bytes() - 1) / cell_bytes(); }
-    bool spec_ok() const { return !v1_ && !v2_ && stretch_ % ALIGN == 0 && !host_mode_; }
+    bool spec_ok() const { return !v1_ && !v2_ && !bgzf_ && stretch_ % ALIGN == 0 && !host_mode_; }
     void spec_decode(int k, uint64_t cell, hipStream_t stream) {
         DevSet &d = *sets_[(size_t)k];
         d.spec = PieceJob();
@@ -3105,6 +3175,8 @@ private:
     uint32_t run_crc_ = 0;
     uint64_t run_len_ = 0;
     bool trace_ = false, warned_ = false, host_mode_ = false, v1_ = false, v2_ = false, scan_rounds_ = false;
+    bool bgzf_ = false;          // a BGZF file: members of one final block each, their sizes in the headers -- no search needed
+    uint64_t bgzf_hdr_ = 0;      // header of the member whose data the stream stands at (byte offset in the file)
     std::mutex st_mu_;           // the statistics: phase A of a piece decoded ahead runs on another thread
     uint64_t grid0_ = 0;         // the piece grid starts at the first member's first block (aligned down)
     uint64_t spec_used_ = 0, spec_refused_ = 0;
@@ -3142,8 +3214,7 @@ bool dev_gunzip_wants(const char *path) {
     struct stat st;
     uint8_t h[18];
     bool ok = fstat(fd, &st) == 0 && S_ISREG(st.st_mode) && st.st_size >= 18 && ::read(fd, h, 18) == 18 && h[0] == 0x1f && h[1] == 0x8b && h[2] == 8;
-    // BGZF: FEXTRA with the 'B' 'C' subfield first (every member a single final block: nothing for the block search)
-    if (ok && (h[3] & 4) && h[12] == 'B' && h[13] == 'C') ok = false;
+    // (BGZF -- FEXTRA with the 'B' 'C' subfield -- is taken as well: its chunks' starts come from the members' headers)
     ::close(fd);
     return ok;
 }

@@ -89,7 +89,7 @@ def test_flush_points_and_empty_stored_blocks(tmp_path, flush):
 
 
 def test_many_small_members_and_header_fields(tmp_path):
-    """Members of 60 kB with extra fields (not BGZF's 'BC' first: those files go to the host reader, dev_gunzip_wants),
+    """Members of 60 kB with extra fields (no BGZF: no 'BC' subfield; the real thing is test_bgzf_chunk_starts_... below),
     a member with name, comment and header CRC, an empty member at the end.  More member ends than a chunk records
     (four) send a piece to the host decoder; the bytes and the CRC checks are the same."""
     parts, want = [], []
@@ -110,6 +110,43 @@ def test_many_small_members_and_header_fields(tmp_path):
     for seg, stretch in ((0, 0), (200_000, 8192), (50_000, 2048)):
         st = check(tmp_path, raw, data, seg, stretch)
         assert st["members"] == 52
+
+
+def bgzf(data, block=65280, level=6, eof=True):
+    """bgzip's format (htslib): members of at most 64 KiB of text, each ONE final deflate block, its whole size - 1 in the 'B' 'C'
+    subfield of the header's extra field; an empty member marks the end"""
+    out = []
+    for i in list(range(0, len(data), block)) + ([None] if eof else []):
+        blk = b"" if i is None else data[i:i + block]
+        co = zlib.compressobj(level, zlib.DEFLATED, -15)
+        body = co.compress(blk) + co.flush()
+        bsize = 12 + 6 + len(body) + 8 - 1
+        out.append(b"\x1f\x8b\x08\x04" + bytes(4) + b"\x00\xff" + struct.pack("<H", 6) + b"BC" + struct.pack("<HH", 2, bsize) + body +
+                   struct.pack("<II", zlib.crc32(blk), len(blk)))
+    return b"".join(out)
+
+
+@pytest.mark.parametrize("level", [1, 6, 9])
+def test_bgzf_chunk_starts_come_from_the_member_headers(tmp_path, level):
+    """BGZF on the device: no block search -- every member is one FINAL block, which the search does not
+    look for -- the chunks' starts are read off the 'B' 'C' sizes, and no piece goes to the host decoder."""
+    raw = bgzf(FASTQ, level=level)
+    assert gzip.decompress(raw) == FASTQ
+    for seg, stretch in ((0, 0), (1 << 20, 16384), (200_000, 8192), (64_000, 32768)):
+        st = check(tmp_path, raw, FASTQ, seg, stretch, "bgzf")
+        assert st["host_pieces"] == 0 and st["members"] == len(FASTQ) // 65280 + 2 and st["redecoded"] == 0
+    # small members (many a chunk: the host decoder takes those pieces over, loudly), no end marker, damage
+    small = bgzf(FASTQ[:1_500_000], block=3000, eof=False)
+    check(tmp_path, small, FASTQ[:1_500_000], 0, 0, "bgzf_small")
+    bad = bytearray(raw)
+    bad[len(raw) // 2] ^= 0x10
+    src = tmp_path / "bgzf_bad.gz"
+    src.write_bytes(bytes(bad))
+    with pytest.raises(RuntimeError):
+        gunzip_dev(src, tmp_path / "bgzf_bad.out")
+    # a BGZF head on an ordinary gzip tail (cat of two tools' outputs): the headers stop saying sizes, the search takes over
+    mixed = bgzf(FASTQ[:1_000_000], eof=False) + gzip.compress(FASTQ[1_000_000:], 6)
+    check(tmp_path, mixed, FASTQ, 300_000, 8192, "bgzf_mixed")
 
 
 def test_members_of_whole_files_concatenated(tmp_path):

@@ -453,6 +453,32 @@ def test_lanes_with_pieces_the_host_decoder_takes_over(tmp_path, monkeypatch, ca
     assert res["three"] == res["one"] and res["host"] == res["one"]
 
 
+def test_bgzf_inputs_through_the_reader_on_the_gpu(tmp_path, monkeypatch, capfd):
+    """bgzip-compressed FASTQ pairs through nh_run: the device reader takes BGZF (chunk starts from the members' headers), the
+    outputs are the host reader's."""
+    from nohuman_amd import Engine
+    from tests.test_gpu_gunzip import bgzf
+    raw1 = open(os.path.join(GOLD, "reads_pe_1.fq"), "rb").read() * 12
+    raw2 = open(os.path.join(GOLD, "reads_pe_2.fq"), "rb").read() * 12
+    in1, in2 = tmp_path / "r_1.fq.gz", tmp_path / "r_2.fq.gz"
+    in1.write_bytes(bgzf(raw1))
+    in2.write_bytes(bgzf(raw2, block=20000, level=1))
+    monkeypatch.setenv("NOHUMAN_TRACE", "1")
+    monkeypatch.setenv("NOHUMAN_BATCH_FRAGS", "1000")
+    res = {}
+    for reader in ("device", "host"):
+        monkeypatch.setenv("NOHUMAN_GZ_READER", reader)
+        o1, o2, k = tmp_path / ("o1_" + reader), tmp_path / ("o2_" + reader), tmp_path / ("k_" + reader)
+        with Engine.open(DB) as eng:
+            st = eng.run(str(in1), str(o1), in2=str(in2), out2=str(o2), kraken_output=str(k), threads=4)
+        err = capfd.readouterr().err
+        assert ("gzip reader on GPU" in err) == (reader == "device"), err[-1500:]
+        if reader == "device":
+            assert "0 pieces by the host decoder" in err
+        res[reader] = (o1.read_bytes(), o2.read_bytes(), k.read_bytes(), (st.total_sequences, st.classified, st.total_bases))
+    assert res["device"] == res["host"] and res["host"][3][0] == 12 * (raw1.count(b"\n") // 48)
+
+
 def test_fragments_with_many_taxa_in_concurrent_batches(tmp_path, monkeypatch):
     """Batches in flight on the two stream slots of an engine each carry fragments that hit more than
     64 distinct taxa (second kernel pass): every launch has its own 'left for the second pass' word,
