@@ -52,7 +52,25 @@ def text_of(rng, n):
     return b"".join(out)[:n]
 
 
+def bgzf_of(rng, data):
+    import struct
+    out = []
+    block = int(rng.choice([65280, 65280, 20000, 3000, 500]))
+    for i in list(range(0, len(data), block)) + ([None] if rng.random() < 0.7 or not data else []):
+        blk = b"" if i is None else data[i:i + block]
+        co = zlib.compressobj(int(rng.choice([1, 6, 9])), zlib.DEFLATED, -15)
+        body = co.compress(blk) + co.flush()
+        out.append(b"\x1f\x8b\x08\x04" + bytes(4) + b"\x00\xff" + struct.pack("<H", 6) + b"BC" + struct.pack("<HH", 2, 12 + 6 + len(body) + 8 - 1) +
+                   body + struct.pack("<II", zlib.crc32(blk), len(blk)))
+    return b"".join(out)
+
+
 def gz_of(rng, data):
+    if rng.random() < 0.15 and len(data) < 12_000_000:
+        raw = bgzf_of(rng, data)
+        if rng.random() < 0.2:
+            raw += gzip_tail(rng)
+        return raw
     parts, pos = [], 0
     nmem = int(rng.choice([1, 1, 1, 2, 3, 9]))
     cuts = sorted(int(x) for x in rng.integers(0, len(data) + 1, nmem - 1)) + [len(data)]
@@ -73,6 +91,13 @@ def gz_of(rng, data):
         else:
             parts.append(co.compress(blk) + co.flush())
     return b"".join(parts)
+
+
+TAIL = b""
+
+
+def gzip_tail(rng):
+    return b""  # (a BGZF file followed by other members changes the text: the caller would have to know; kept simple)
 
 
 rng = np.random.default_rng(seed)
