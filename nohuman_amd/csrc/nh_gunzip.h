@@ -2,12 +2,12 @@
 // path, /root/reference/src/main.rs:267, where kraken2's wrapper pipes them through `gzip -dc`).
 //
 // The compressed bytes go to the device as they are read; there
-//   k_search    finds, per stretch of the file, the first bit position that parses as a non-final dynamic-Huffman block
+//   k_search3   finds, per stretch of the file, the first bit position that parses as a non-final dynamic-Huffman block
 //               header (the seam test of nh_inflate.cpp plus a trial walk of the block's first tokens),
-//   k_inflate   decodes from every start found to the next one, a wavefront per chunk, to 16-bit symbols -- what a match
+//   k_inflate3  decodes from every start found to the next one, a wavefront per chunk, to 16-bit symbols -- what a match
 //               copies out of the unknown 32 KiB before the chunk is a marker 0x8000 | index --, walking over member
 //               trailers and headers,
-//   k_maps / k_scan_round / k_windows   give every chunk its window by a prefix scan over the chunks' index maps,
+//   k_scan_local / k_scan_groups / k_scan_windows   give every chunk its window by a prefix scan over the chunks' index maps,
 //   k_resolve   turns the symbols into the text, at its place in the caller's device buffer,
 //   k_crc       computes the CRC-32 of every chunk's pieces (the host joins them per member and checks CRC and ISIZE
 //               like gzip does).

@@ -30,19 +30,7 @@ namespace nh {
 namespace gz {
 
 constexpr uint32_t WSIZE = 32768;
-#ifndef NH_GZ_NEAR
-#define NH_GZ_NEAR 4096  // symbols of the window kept in LDS (a power of two, 4096 .. 32768); older sources come back from the output in HBM
-#endif
-constexpr uint32_t NEARSZ = NH_GZ_NEAR;
-constexpr int ROOT = 10, DROOT = 8;
 constexpr uint32_t MAX_MEMBERS = 4;  // member ends one chunk can record
-// k_inflate decodes a BATCH of tokens (at most 64, a lane each) before any of them is expanded: a batch stops growing at
-// SPAN_LIMIT symbols and so writes at most AHEAD symbols beyond its start.  A source at most RING_DMAX symbols back is
-// in the LDS ring whatever the batch has written ahead; older ones were flushed to HBM long ago (static_assert below).
-constexpr uint32_t SPAN_LIMIT = 768, AHEAD = SPAN_LIMIT + 257, FLUSH_AT = 256;
-constexpr uint32_t RING_DMAX = NEARSZ - AHEAD - 64;
-static_assert(NEARSZ >= 4096 && (NEARSZ & (NEARSZ - 1)) == 0 && NEARSZ <= WSIZE, "ring size");
-static_assert(RING_DMAX >= 2 * AHEAD + FLUSH_AT + 258, "a source older than the ring must already be flushed");
 constexpr uint64_t NONE = ~0ull;
 constexpr uint32_t NOIDX = 0xFFFFFFFFu;
 
@@ -95,23 +83,6 @@ struct SegResult {  // k_finish
     uint64_t first_start;  // bit position of the first chunk (a speculative piece: the first block start the search found)
 };
 
-struct Lds {
-    uint16_t window[NEARSZ];
-    // root tables: 0 = code longer than the root; else code length (4 bits) | extra bits (4) | base or literal (16) |
-    // kind << 28 (0 literal, 1 length, 2 end of block; distances: always 1)
-    uint32_t lit[1 << ROOT];
-    uint32_t dist[1 << DROOT];
-    uint32_t clt[128];
-    uint16_t lbase[32], dbase[32];
-    uint8_t lext[32], dext[32];
-    uint16_t lsym[288], dsym[32];
-    uint16_t lcount[16], dcount[16];
-    uint16_t code[320];
-    uint8_t lens[320];
-    uint16_t tmp[40];
-    uint32_t inbuf[128];  // k_inflate3: 512 bytes of the input as a ring of dwords (dword d of the buffer at d & 127)
-};
-
 __constant__ uint16_t LBASE[29] = {3, 4, 5, 6, 7, 8, 9, 10, 11, 13, 15, 17, 19, 23, 27, 31, 35, 43, 51, 59, 67, 83, 99, 115, 131, 163, 195, 227, 258};
 __constant__ uint8_t LEXT[29] = {0, 0, 0, 0, 0, 0, 0, 0, 1, 1, 1, 1, 2, 2, 2, 2, 3, 3, 3, 3, 4, 4, 4, 4, 5, 5, 5, 5, 0};
 __constant__ uint16_t DBASE[30] = {1, 2, 3, 4, 5, 7, 9, 13, 17, 25, 33, 49, 65, 97, 129, 193, 257, 385, 513, 769, 1025, 1537, 2049, 3073, 4097, 6145, 8193, 12289, 16385, 24577};
@@ -139,96 +110,6 @@ __device__ __forceinline__ uint64_t bits_at(const uint8_t *bytes, uint64_t b) { 
     return ((const U *)(bytes + (b >> 3)))->v >> (b & 7);
 }
 
-struct BitIn {  // wave-uniform reader over dwords held in the lanes
-    const uint32_t *in;   // dwords of the piece's buffer
-    uint32_t wbase;       // dword index of winA's lane 0
-    uint32_t winA, winB;  // this lane's dwords: wbase + lane, wbase + 64 + lane
-    __device__ __forceinline__ void init(const uint32_t *p, uint64_t bitpos, int lane) {
-        in = p;
-        wbase = (uint32_t)(bitpos >> 5) & ~63u;
-        winA = in[wbase + lane];
-        winB = in[wbase + 64 + lane];
-        __builtin_amdgcn_s_waitcnt(0x0F70);
-    }
-    __device__ __forceinline__ uint32_t dw(uint32_t d) const { return d < 64u ? rl(winA, d) : rl(winB, d - 64u); }
-    // 64 bits of the stream at bit position bitpos (positions move forward only)
-    __device__ __forceinline__ uint64_t fetch(uint64_t bitpos, int lane) {
-        uint32_t d = (uint32_t)(bitpos >> 5) - wbase;
-        if (d >= 64u) {  // the first register is used up: the second takes its place and is loaded again
-            if (d >= 128u) {  // (a jump: stored blocks, member headers re-initialise; this is the safety net)
-                init(in, bitpos, lane);
-                d = (uint32_t)(bitpos >> 5) - wbase;
-            } else {
-                winA = winB;
-                wbase += 64u;
-                winB = in[wbase + 64 + lane];
-                // waited for HERE, once per 256 bytes of input: left to the compiler, every later use of the registers
-                // waits for vmcnt(0) -- that is, for all the global stores of the copies in between
-                __builtin_amdgcn_s_waitcnt(0x0F70);
-                d -= 64u;
-            }
-        }
-        const uint32_t lo = dw(d), mid = dw(d + 1), hi = dw(d + 2);
-        const uint32_t sh = (uint32_t)bitpos & 31u;
-        const uint64_t lm = ((uint64_t)mid << 32) | lo;
-        return sh ? (lm >> sh) | ((uint64_t)hi << (64u - sh)) : lm;
-    }
-};
-
-__device__ __forceinline__ uint32_t entry_of(const Lds &S, int mode, uint32_t s, uint32_t l) {
-    if (mode == 0) return l | (s << 8);
-    if (mode == 2) return l | ((uint32_t)S.dext[s] << 4) | ((uint32_t)S.dbase[s] << 8) | (1u << 28);
-    if (s < 256u) return l | (s << 8);
-    if (s == 256u) return l | (2u << 28);
-    return l | ((uint32_t)S.lext[s - 257u] << 4) | ((uint32_t)S.lbase[s - 257u] << 8) | (1u << 28);
-}
-// (Everything that takes pointers into the LDS is force-inlined: out of line they become flat pointers, and the
-//  LDS-to-flat cast of this compiler version does not survive the machine verifier.)
-// counts, canonical symbol list, codes and root table of one alphabet (lens[0..n) in LDS); mode 0: the code-length
-// code, 1: literals / lengths, 2: distances.  False: the lengths are over-subscribed (no prefix code).
-__device__ __forceinline__ bool build(Lds &S, const uint8_t *lens, int n, uint16_t *count, uint16_t *symlist, uint32_t *root, int rootbits, int mode,
-                      int lane) {
-    LDS_ORDER();
-    uint32_t over = 0;
-    if (lane == 0) {
-        uint16_t *offs = S.tmp, *next = S.tmp + 16;
-        for (int l = 0; l < 16; l++) count[l] = 0;
-        for (int s = 0; s < n; s++) count[lens[s]]++;
-        count[0] = 0;
-        uint32_t o = 0, c = 0;
-        int left = 1;
-        for (int l = 1; l < 16; l++) {
-            left = (left << 1) - (int)count[l];
-            if (left < 0) over = 1;
-            offs[l] = (uint16_t)o;
-            o += count[l];
-            c = (c + count[l - 1]) << 1;
-            next[l] = (uint16_t)c;
-        }
-        if (!over)
-            for (int s = 0; s < n; s++) {
-                const int l = lens[s];
-                if (l) {
-                    symlist[offs[l]++] = (uint16_t)s;
-                    S.code[s] = next[l]++;
-                }
-            }
-    }
-    if (uni(over)) return false;
-    for (int k = lane; k < (1 << rootbits); k += 64) root[k] = 0;
-    LDS_ORDER();
-    for (int s = lane; s < n; s += 64) {
-        const int l = lens[s];
-        if (l && l <= rootbits) {
-            const uint32_t r = __builtin_bitreverse32((uint32_t)S.code[s]) >> (32 - l);
-            const uint32_t e = entry_of(S, mode, (uint32_t)s, (uint32_t)l);
-            for (uint32_t k = r; k < (1u << rootbits); k += 1u << l) root[k] = e;
-        }
-    }
-    LDS_ORDER();
-    return true;
-}
-
 // a symbol whose code is longer than the root table: canonical walk, one bit at a time
 __device__ __forceinline__ uint32_t slow_symbol(uint64_t w, const uint16_t *count, const uint16_t *symlist, uint32_t &len_out) {
     uint32_t code = 0, first = 0, index = 0;
@@ -246,178 +127,6 @@ __device__ __forceinline__ uint32_t slow_symbol(uint64_t w, const uint16_t *coun
     }
     len_out = 0;
     return 0xFFFFu;
-}
-
-// the header of a dynamic block behind its three type bits: the code lengths of both alphabets into S.lens[0 .. nlit + ndist)
-__device__ __forceinline__ uint32_t parse_dynamic(Lds &S, BitIn &bi, uint64_t &bitpos, int lane, int &nlit, int &ndist) {
-    uint64_t w = bi.fetch(bitpos, lane);
-    nlit = (int)(w & 31) + 257;
-    ndist = (int)((w >> 5) & 31) + 1;
-    const int ncl = (int)((w >> 10) & 15) + 4;
-    if (nlit > 286 || ndist > 30) return ST_HEADER;
-    bitpos += 14;
-    LDS_ORDER();
-    if (lane < 19) S.lens[lane] = 0;
-    LDS_ORDER();
-    for (int i = 0; i < ncl; i++) {  // (uniform; 3 bits each)
-        if ((i & 15) == 0) w = bi.fetch(bitpos, lane);
-        if (lane == 0) S.lens[CLORDER[i]] = (uint8_t)(w & 7);
-        w >>= 3;
-        bitpos += 3;
-    }
-    // the code-length code: all codes fit the 7-bit root
-    if (!build(S, S.lens, 19, S.lcount, S.lsym, S.clt, 7, 0, lane)) return ST_HEADER;
-    int i = 0;
-    uint32_t prev = 0;
-    while (i < nlit + ndist) {
-        w = bi.fetch(bitpos, lane);
-        const uint32_t e = uni(S.clt[w & 127]);
-        const uint32_t l = e & 15u, sym = e >> 8;
-        if (l == 0) return ST_HEADER;
-        bitpos += l;
-        w >>= l;
-        uint32_t rep = 1, val = sym;
-        if (sym == 16) {
-            if (i == 0) return ST_HEADER;
-            rep = 3 + ((uint32_t)w & 3);
-            bitpos += 2;
-            val = prev;
-        } else if (sym == 17) {
-            rep = 3 + ((uint32_t)w & 7);
-            bitpos += 3;
-            val = 0;
-        } else if (sym == 18) {
-            rep = 11 + ((uint32_t)w & 127);
-            bitpos += 7;
-            val = 0;
-        }
-        if (i + (int)rep > nlit + ndist) return ST_HEADER;
-        for (uint32_t k = (uint32_t)lane; k < rep; k += 64) S.code[i + k] = (uint16_t)val;
-        i += (int)rep;
-        prev = val;
-    }
-    LDS_ORDER();
-    for (int s = lane; s < nlit + ndist; s += 64) S.lens[s] = (uint8_t)S.code[s];
-    LDS_ORDER();
-    if (S.lens[256] == 0) return ST_HEADER;  // no end-of-block code
-    return 0;
-}
-
-__device__ __forceinline__ void load_bases(Lds &S, int lane) {
-    if (lane < 29) {
-        S.lbase[lane] = LBASE[lane];
-        S.lext[lane] = LEXT[lane];
-    }
-    if (lane < 30) {
-        S.dbase[lane] = DBASE[lane];
-        S.dext[lane] = DEXT[lane];
-    }
-    LDS_ORDER();
-}
-
-// Does a non-final dynamic block header start at bit `cand`?  The seam test of the host reader: the code lengths must
-// decode, both codes must be complete (the distance code may have a single symbol), end-of-block must have a code --
-// and the first tokens of the block must walk (a header that passes by chance decodes into nonsense soon).
-__device__ __forceinline__ bool plausible_block(Lds &S, const uint32_t *in, uint64_t cand, uint64_t valid_bits, int lane) {
-    BitIn bi;
-    bi.init(in, cand, lane);
-    uint64_t bp = cand + 3;
-    int nlit, ndist;
-    if (parse_dynamic(S, bi, bp, lane, nlit, ndist)) return false;
-    uint32_t sl = 0, sd = 0, cd = 0;
-    for (int k = lane; k < nlit; k += 64) sl += S.lens[k] ? 32768u >> S.lens[k] : 0u;
-    for (int k = lane; k < ndist; k += 64) {
-        const uint32_t l = S.lens[nlit + k];
-        sd += l ? 32768u >> l : 0u;
-        cd += l != 0;
-    }
-    sl = wsum(sl);
-    sd = wsum(sd);
-    cd = wsum(cd);
-    if (!(sl == 32768u && (sd == 32768u || cd <= 1u))) return false;
-    if (!build(S, S.lens, nlit, S.lcount, S.lsym, S.lit, ROOT, 1, lane)) return false;
-    if (!build(S, S.lens + nlit, ndist, S.dcount, S.dsym, S.dist, DROOT, 2, lane)) return false;
-    uint32_t produced = 0;
-    for (int tok = 0; tok < 256; tok++) {
-        if (bp + 64 > valid_bits) return true;  // (the look-ahead ends here: what was walked was fine)
-        uint64_t w = bi.fetch(bp, lane);
-        uint32_t e = uni(S.lit[w & ((1u << ROOT) - 1u)]);
-        if (e == 0) {
-            uint32_t l;
-            const uint32_t sym = slow_symbol(w, S.lcount, S.lsym, l);
-            if (l == 0 || sym >= 286u) return false;
-            e = entry_of(S, 1, sym, l);
-        }
-        const uint32_t l = e & 15u;
-        bp += l;
-        w >>= l;
-        const uint32_t kind = e >> 28;
-        if (kind == 2) break;
-        if (kind == 0) {
-            produced++;
-            continue;
-        }
-        const uint32_t lext = (e >> 4) & 15u;
-        const uint32_t len = ((e >> 8) & 0xFFFFu) + ((uint32_t)w & ((1u << lext) - 1u));
-        bp += lext;
-        w >>= lext;
-        uint32_t de = uni(S.dist[w & ((1u << DROOT) - 1u)]);
-        if (de == 0) {
-            uint32_t dl;
-            const uint32_t dsymv = slow_symbol(w, S.dcount, S.dsym, dl);
-            if (dl == 0 || dsymv >= 30u) return false;
-            de = entry_of(S, 2, dsymv, dl);
-        }
-        const uint32_t dext = (de >> 4) & 15u;
-        const uint32_t dist = ((de >> 8) & 0xFFFFu) + ((uint32_t)(w >> (de & 15u)) & ((1u << dext) - 1u));
-        if (dist > produced + WSIZE) return false;
-        bp += (de & 15u) + dext;
-        produced += len;
-    }
-    return true;
-}
-
-// start[c] = the first bit position in stretch c of the piece that passes the seam test (NONE: none); stretch 0 starts
-// at the position the stream is known to go on at
-__global__ __launch_bounds__(64) void k_search(const uint32_t *in, uint64_t valid_bits, uint64_t stretch_bits, uint64_t first_bit,
-                                               uint64_t *start) {
-    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-    Lds &S = *(Lds *)smem;
-    const int lane = (int)threadIdx.x;
-    const uint32_t c = blockIdx.x;
-    if (c == 0) {
-        if (lane == 0) start[0] = first_bit;
-        return;
-    }
-    load_bases(S, lane);  // (the trial walk reads the base / extra-bit tables through entry_of)
-    uint64_t from = (uint64_t)c * stretch_bits, to = from + stretch_bits;
-    if (from <= first_bit) from = first_bit + 1;
-    if (to + 160 > valid_bits) to = valid_bits > 160 ? valid_bits - 160 : 0;
-    const uint8_t *bytes = (const uint8_t *)in;
-    uint64_t found = NONE;
-    for (uint64_t b0 = from; b0 < to && found == NONE; b0 += 64) {
-        const uint64_t b = b0 + (uint64_t)lane;
-        const uint64_t w = bits_at(bytes, b), w2 = bits_at(bytes + 7, b);  // w2: bits 56.. of the window
-        bool pre = b < to && (w & 7) == 4 && ((w >> 3) & 31) <= 29 && ((w >> 8) & 31) <= 29;
-        const int ncl = (int)((w >> 13) & 15) + 4;
-        int left = 128, any = 0;
-        for (int i = 0; i < 19; i++) {
-            const unsigned at = 17 + 3 * (unsigned)i;
-            const unsigned l = i < ncl ? (at + 3 <= 56 ? (unsigned)(w >> at) & 7 : (unsigned)(w2 >> (at - 56)) & 7) : 0u;
-            if (l) {
-                left -= 128 >> l;
-                any = 1;
-            }
-        }
-        pre = pre && any && left == 0;
-        uint64_t m = __ballot(pre);
-        while (m && found == NONE) {
-            const uint64_t cand = b0 + (uint64_t)__builtin_ctzll(m);
-            if (plausible_block(S, in, cand, valid_bits, lane)) found = cand;
-            m &= m - 1;
-        }
-    }
-    if (lane == 0) start[c] = found;
 }
 
 // plan of the piece: chunk c runs from its start to the next start found (the last one to the first block boundary at or
@@ -442,296 +151,15 @@ __global__ __launch_bounds__(1024) void k_plan(const uint64_t *start, uint32_t n
     }
 }
 
-// Decodes chunk c (block index, or `only`) from its start to the first block boundary at or behind its stop position.
-__global__ __launch_bounds__(64) void k_inflate(const uint32_t *in, uint64_t valid_bits, uint32_t at_eof, ChunkDesc *desc, uint16_t *sym,
-                                                uint32_t slot_syms, uint32_t only) {
-    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-    Lds &S = *(Lds *)smem;
-    const int lane = (int)threadIdx.x;
-    const uint32_t c = only != NOIDX ? only : blockIdx.x;
-    ChunkDesc &cd = desc[c];
-    if (cd.bit_start == NONE) {
-        if (lane == 0) {
-            cd.bit_end = 0;
-            cd.out_len = 0;
-            cd.status = 0;
-            cd.n_members = 0;
-            cd.flags = 0;
-            cd.blocks = 0;
-        }
-        return;
-    }
-    // the unknown 32 KiB before the chunk as markers: the newest NEARSZ of them in the LDS ring (position q of the
-    // stream, counted from 32768 before the chunk, lives at q & (NEARSZ - 1))
-    for (uint32_t i = (uint32_t)lane; i < NEARSZ; i += 64) S.window[(WSIZE - NEARSZ + i) & (NEARSZ - 1)] = (uint16_t)(0x8000u | (WSIZE - NEARSZ + i));
-    load_bases(S, lane);
-    uint64_t bitpos = cd.bit_start;
-    const uint64_t stop_bit = cd.stop_bit;
-    uint16_t *o = sym + (uint64_t)c * slot_syms;
-    uint32_t op = 0;  // symbols written
-    const uint32_t cap = cd.cap;
-    const uint8_t *bytes = (const uint8_t *)in;
-    BitIn bi;
-    bi.init(in, bitpos, lane);
-    uint32_t status = 0, blocks = 0, n_members = 0, flags = 0;
-    uint32_t floor_op = 0;       // sources may not reach before this output position ...
-    bool fresh_member = false;   // ... once a member has started inside the chunk (before: the unknown window)
-    while (status == 0) {
-        if (bitpos >= stop_bit) break;  // a block boundary at or behind the stop position
-        if (bitpos + 3 > valid_bits) {
-            status = ST_INPUT;
-            break;
-        }
-        uint64_t w = bi.fetch(bitpos, lane);
-        const uint32_t bfinal = (uint32_t)w & 1u, btype = (uint32_t)(w >> 1) & 3u;
-        bitpos += 3;
-        blocks++;
-        if (btype == 0) {  // stored
-            bitpos = (bitpos + 7) & ~7ull;
-            if (bitpos + 32 > valid_bits) {
-                status = ST_INPUT;
-                break;
-            }
-            w = bi.fetch(bitpos, lane);
-            const uint32_t len = (uint32_t)w & 0xFFFFu, nlen = (uint32_t)(w >> 16) & 0xFFFFu;
-            if ((len ^ nlen) != 0xFFFFu) {
-                status = ST_STORED;
-                break;
-            }
-            bitpos += 32;
-            if (bitpos + 8ull * len > valid_bits) {
-                status = ST_INPUT;
-                break;
-            }
-            if ((uint64_t)op + len > cap) {
-                status = ST_ROOM;
-                break;
-            }
-            const uint8_t *src = bytes + (bitpos >> 3);
-            asm volatile("" ::: "memory");
-            for (uint32_t i = (uint32_t)lane; i < len; i += 64) {
-                const uint16_t v = src[i];
-                S.window[(op + WSIZE + i) & (NEARSZ - 1)] = v;
-                o[op + i] = v;
-            }
-            LDS_ORDER();
-            op += len;
-            bitpos += 8ull * len;
-            bi.init(in, bitpos, lane);
-        } else if (btype == 3) {
-            status = ST_BTYPE;
-            break;
-        } else {
-            int nlit, ndist;
-            if (btype == 1) {  // fixed codes
-                LDS_ORDER();
-                for (int s = lane; s < 288; s += 64) S.lens[s] = s < 144 ? 8 : s < 256 ? 9 : s < 280 ? 7 : 8;
-                if (lane < 32) S.lens[288 + lane] = 5;
-                nlit = 288;
-                ndist = 30;
-            } else {
-                status = parse_dynamic(S, bi, bitpos, lane, nlit, ndist);
-                if (status) break;
-            }
-            if (!build(S, S.lens, nlit, S.lcount, S.lsym, S.lit, ROOT, 1, lane) ||
-                !build(S, S.lens + nlit, ndist, S.dcount, S.dsym, S.dist, DROOT, 2, lane)) {
-                status = ST_HEADER;
-                break;
-            }
-            // ---- the symbols of the block
-            for (;;) {
-                if (bitpos > valid_bits) {
-                    status = ST_INPUT;
-                    break;
-                }
-                w = bi.fetch(bitpos, lane);
-                uint32_t e = uni(S.lit[w & ((1u << ROOT) - 1u)]);
-                if (e == 0) {  // a code longer than the root
-                    uint32_t l;
-                    const uint32_t sy = slow_symbol(w, S.lcount, S.lsym, l);
-                    if (l == 0 || sy >= 286u) {
-                        status = ST_LITLEN;
-                        break;
-                    }
-                    e = entry_of(S, 1, sy, l);
-                }
-                const uint32_t l = e & 15u;
-                bitpos += l;
-                w >>= l;
-                const uint32_t kind = e >> 28;
-                if (kind == 0) {
-                    if (op >= cap) {
-                        status = ST_ROOM;
-                        break;
-                    }
-                    const uint16_t v = (uint16_t)(e >> 8);
-                    if (lane == 0) {
-                        S.window[(op + WSIZE) & (NEARSZ - 1)] = v;
-                        o[op] = v;
-                    }
-                    op++;
-                    continue;
-                }
-                if (kind == 2) break;
-                const uint32_t lext = (e >> 4) & 15u;
-                const uint32_t len = ((e >> 8) & 0xFFFFu) + ((uint32_t)w & ((1u << lext) - 1u));
-                bitpos += lext;
-                w >>= lext;
-                uint32_t de = uni(S.dist[w & ((1u << DROOT) - 1u)]);
-                if (de == 0) {
-                    uint32_t dl;
-                    const uint32_t dsymv = slow_symbol(w, S.dcount, S.dsym, dl);
-                    if (dl == 0 || dsymv >= 30u) {
-                        status = ST_DIST;
-                        break;
-                    }
-                    de = entry_of(S, 2, dsymv, dl);
-                }
-                const uint32_t dl = de & 15u;
-                bitpos += dl;
-                w >>= dl;
-                const uint32_t dext = (de >> 4) & 15u;
-                const uint32_t dist = ((de >> 8) & 0xFFFFu) + ((uint32_t)w & ((1u << dext) - 1u));
-                bitpos += dext;
-                if ((uint64_t)op + len > cap) {
-                    status = ST_ROOM;
-                    break;
-                }
-                if (fresh_member ? dist > op - floor_op : dist > op + WSIZE) {
-                    status = ST_FAR;
-                    break;
-                }
-                // the copy: every lane a symbol; with dist < len the pattern repeats.  (LDS operations of one wave execute
-                // in order: the literal lane 0 wrote, the symbols of the last copy are there for this one)
-                asm volatile("" ::: "memory");
-                for (uint32_t i = (uint32_t)lane; i < len; i += 64) {
-                    const uint32_t from = dist >= len ? i : i % dist;
-                    uint16_t v;
-                    // (a ring slot is overwritten by the position NEARSZ later: a source this copy could reach with its own
-                    //  writes -- up to 258 symbols ahead -- is not taken from the ring)
-                    if (dist - from + 320u <= NEARSZ) {
-                        v = S.window[(op + WSIZE - dist + from) & (NEARSZ - 1)];
-                    } else if (op + from >= dist) {  // older than the ring, inside the chunk: from the output (written long ago)
-                        v = __hip_atomic_load(&o[op + from - dist], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    } else {                         // older than the ring, before the chunk: the marker itself
-                        v = (uint16_t)(0x8000u | (op + WSIZE - dist + from));
-                    }
-                    o[op + i] = v;
-                    S.window[(op + WSIZE + i) & (NEARSZ - 1)] = v;
-                }
-                asm volatile("" ::: "memory");
-                op += len;
-            }
-            if (status) break;
-        }
-        if (bfinal) {
-            // ---- the member ends: trailer (CRC-32, ISIZE), then another member's header, or the end of the stream
-            bitpos = (bitpos + 7) & ~7ull;
-            uint64_t q = bitpos >> 3;
-            const uint64_t valid_bytes = valid_bits >> 3;
-            if (q + 8 > valid_bytes) {
-                status = ST_INPUT;
-                break;
-            }
-            if (n_members == MAX_MEMBERS) {
-                status = ST_MEMBERS;
-                break;
-            }
-            const uint64_t tr = bits_at(bytes, q * 8);
-            if (lane == 0) {
-                cd.m_off[n_members] = op;
-                cd.m_crc[n_members] = (uint32_t)tr;
-                cd.m_isize[n_members] = (uint32_t)(tr >> 32);
-            }
-            n_members++;
-            q += 8;
-            bitpos = q * 8;
-            // gzip header (RFC 1952): ID1 ID2 CM FLG MTIME(4) XFL OS [XLEN + extra] [name 0] [comment 0] [CRC16]
-            bool member = false, trunc = false;
-            if (q == valid_bytes && at_eof) {
-                member = false;
-            } else if (q + 10 > valid_bytes) {
-                // fewer than ten bytes: at the end of the file gzip ignores them unless they begin like a member
-                const uint64_t hv = bits_at(bytes, q * 8);
-                if (at_eof && !(q + 2 <= valid_bytes && (hv & 0xFFFF) == 0x8B1F)) member = false;
-                else trunc = true;
-            } else {
-                const uint64_t hv = bits_at(bytes, q * 8);
-                const uint32_t flg = (uint32_t)(hv >> 24) & 0xFFu;
-                if ((hv & 0xFFFFFF) != 0x088B1Fu || (flg & 0xE0u)) {
-                    member = false;  // bytes that are no gzip member: ignored like gzip does
-                } else {
-                    member = true;
-                    uint64_t p = q + 10;
-                    if (flg & 4u) {
-                        if (p + 2 > valid_bytes) trunc = true;
-                        else {
-                            const uint32_t xlen = (uint32_t)bits_at(bytes, p * 8) & 0xFFFFu;
-                            p += 2 + xlen;
-                            if (p > valid_bytes) trunc = true;
-                        }
-                    }
-                    for (uint32_t bit = 8; bit <= 16 && !trunc; bit <<= 1)
-                        if (flg & bit) {  // zero-terminated: all lanes look at 64 bytes at a time
-                            for (;;) {
-                                const uint64_t pp = p + (uint64_t)lane;
-                                const bool z = pp < valid_bytes && bytes[pp] == 0;
-                                const uint64_t m = __ballot(z);
-                                if (m) {
-                                    p += (uint64_t)__builtin_ctzll(m) + 1;
-                                    break;
-                                }
-                                p += 64;
-                                if (p >= valid_bytes) {
-                                    trunc = true;
-                                    break;
-                                }
-                            }
-                        }
-                    if (!trunc && (flg & 2u)) {
-                        p += 2;
-                        if (p > valid_bytes) trunc = true;
-                    }
-                    q = p;
-                }
-            }
-            if (trunc) {
-                status = ST_GZHEAD;
-                break;
-            }
-            if (!member) {
-                flags |= 1u;  // the stream ends here
-                break;
-            }
-            bitpos = q * 8;
-            bi.init(in, bitpos, lane);
-            fresh_member = true;
-            floor_op = op;
-        }
-    }
-    if (lane == 0) {
-        cd.status = status;
-        cd.blocks = blocks;
-        cd.bit_end = bitpos;
-        cd.out_len = op;
-        cd.n_members = n_members;
-        cd.flags = flags;
-    }
-}
-
 // =====================================================================================================================
-// Version 2 of the two heavy kernels (round 4, profiles/r04_inflate_summary.txt).  What version 1 above spends its time on:
-// k_inflate ~1000 cycles a token in a chain of dependent latencies (bit fetch by three v_readlane, root table in LDS,
-// distance table in LDS, the window read of the copy, a store instruction per literal, vmcnt(0) waits behind those
-// stores); k_search nine tenths of its time in the wave-serial header parse of candidates that fail it.
-//   k_inflate2  (1) the root tables live in REGISTERS (1024 + 256 entries = 20 VGPRs, a lookup is s_set_gpr_idx +
-//               v_readlane), the bit buffer in scalars: a token's decode touches neither LDS nor memory; (2) tokens are
-//               parked in lanes (length, distance / literal, position) and expanded a batch at a time: literals by
-//               one store of all their lanes, matches whose sources lie before the group's first output overlapped four
-//               at a time; (3) the ring goes to HBM 64 symbols an instruction, not a store per token.
-//   k_search2   candidates that pass the cheap test are collected 64 at a time and their headers decoded IN PARALLEL,
-//               a lane each (own bit reader, own 7-bit table of the code-length code in LDS); only what survives that
-//               -- block starts, and one chance hit in 10^8 -- goes to the wave-wide parse and trial walk.
+// The two heavy kernels (round 4; the two versions before them are in the history of this file, what each step bought in
+// profiles/r04_inflate_notes.txt).  The first cut spent ~1000 cycles a token in a chain of dependent latencies (bit fetch
+// by three v_readlane, root table in LDS, distance table in LDS, the window read of the copy, a store instruction per
+// literal, vmcnt(0) waits behind those stores), and the search nine tenths of its time in the wave-serial header parse of
+// candidates that fail it.  Now: the bit buffer lives in scalars, tokens are decoded 64 bit positions at a time and
+// expanded a window at a time, the ring goes to HBM 64 symbols an instruction; the search collects the candidates that
+// pass the cheap test 64 at a time and decodes their headers IN PARALLEL, a lane each (own bit reader, own 7-bit table of
+// the code-length code in LDS) -- only what survives that goes to the wave-wide parse and trial walk.
 // =====================================================================================================================
 struct BitRd {  // wave-uniform bit reader: 128 dwords of input in two registers a lane, 64 bits of them in scalars
     const uint32_t *in;
@@ -789,397 +217,8 @@ __device__ __forceinline__ uint32_t wlane(uint32_t old, uint32_t val, uint32_t l
     asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tv_writelane_b32 %0, %1, m0" : "+v"(old) : "s"(val), "s"(lane) : "m0");
     return old;
 }
-__device__ __forceinline__ uint32_t lookup16(const uint32_t (&t)[16], uint32_t idx) {  // idx uniform, < 1024
-    const uint32_t v = t[idx >> 6];
-    return (uint32_t)__builtin_amdgcn_readlane((int)v, (int)(idx & 63u));
-}
-__device__ __forceinline__ uint32_t lookup4(const uint32_t (&t)[4], uint32_t idx) {  // idx uniform, < 256
-    const uint32_t v = t[idx >> 6];
-    return (uint32_t)__builtin_amdgcn_readlane((int)v, (int)(idx & 63u));
-}
-
-// code lengths of a dynamic block through the BitRd (the twin of parse_dynamic above)
-__device__ __forceinline__ uint32_t parse_dynamic2(Lds &S, BitRd &br, int lane, int &nlit, int &ndist) {
-    br.ensure32(lane);
-    nlit = (int)br.take(5) + 257;
-    ndist = (int)br.take(5) + 1;
-    const int ncl = (int)br.take(4) + 4;
-    if (nlit > 286 || ndist > 30) return ST_HEADER;
-    LDS_ORDER();
-    if (lane < 19) S.lens[lane] = 0;
-    LDS_ORDER();
-    for (int i = 0; i < ncl; i++) {
-        br.ensure32(lane);
-        const uint32_t v = br.take(3);
-        if (lane == 0) S.lens[CLORDER[i]] = (uint8_t)v;
-    }
-    if (!build(S, S.lens, 19, S.lcount, S.lsym, S.clt, 7, 0, lane)) return ST_HEADER;
-    const uint32_t c0 = S.clt[lane], c1 = S.clt[64 + lane];  // the 7-bit table of the code-length code: two registers
-    int i = 0;
-    uint32_t prev = 0;
-    while (i < nlit + ndist) {
-        br.ensure32(lane);
-        const uint32_t ix = br.peek(7);
-        const uint32_t e = ix < 64u ? rl(c0, ix) : rl(c1, ix - 64u);
-        const uint32_t l = e & 15u, sym = e >> 8;
-        if (l == 0) return ST_HEADER;
-        br.drop(l);
-        uint32_t rep = 1, val = sym;
-        if (sym == 16) {
-            if (i == 0) return ST_HEADER;
-            rep = 3 + br.take(2);
-            val = prev;
-        } else if (sym == 17) {
-            rep = 3 + br.take(3);
-            val = 0;
-        } else if (sym == 18) {
-            rep = 11 + br.take(7);
-            val = 0;
-        }
-        if (i + (int)rep > nlit + ndist) return ST_HEADER;
-        for (uint32_t k = (uint32_t)lane; k < rep; k += 64) S.lens[i + k] = (uint8_t)val;  // (lens is not read while it is written: the cl code has its own copy in c0 / c1)
-        i += (int)rep;
-        prev = val;
-    }
-    LDS_ORDER();
-    if (S.lens[256] == 0) return ST_HEADER;  // no end-of-block code
-    return 0;
-}
-
-__global__ __launch_bounds__(64) void k_inflate2(const uint32_t *in, uint64_t valid_bits, uint32_t at_eof, ChunkDesc *desc, uint16_t *sym,
-                                                 uint32_t slot_syms, uint32_t only) {
-    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-    Lds &S = *(Lds *)smem;
-    const int lane = (int)threadIdx.x;
-    const uint32_t c = only != NOIDX ? only : blockIdx.x;
-    ChunkDesc &cd = desc[c];
-    if (cd.bit_start == NONE) {
-        if (lane == 0) {
-            cd.bit_end = 0;
-            cd.out_len = 0;
-            cd.status = 0;
-            cd.n_members = 0;
-            cd.flags = 0;
-            cd.blocks = 0;
-        }
-        return;
-    }
-    constexpr uint32_t M = NEARSZ - 1;
-    // the unknown 32 KiB before the chunk as markers: the newest NEARSZ of them in the ring (position q of the stream,
-    // counted from the chunk's first symbol, lives at q & M; position -k holds marker 0x8000 | (32768 - k))
-    for (uint32_t i = (uint32_t)lane; i < NEARSZ; i += 64) S.window[i] = (uint16_t)(0x8000u | (WSIZE - NEARSZ + i));
-    load_bases(S, lane);
-    const uint64_t stop_bit = cd.stop_bit;
-    uint16_t *o = sym + (uint64_t)c * slot_syms;
-    uint32_t op = 0, flushed = 0;  // symbols decoded; symbols in HBM
-    const uint32_t cap = cd.cap;
-    const uint8_t *bytes = (const uint8_t *)in;
-    BitRd br;
-    br.init(in, cd.bit_start, lane);
-    uint32_t status = 0, blocks = 0, n_members = 0, flags = 0;
-    uint32_t floor_op = 0;
-    bool fresh_member = false;
-    uint32_t TL[16], TD[4];                 // root tables of the block's two codes, in registers
-    uint32_t tlen = 0, tval = 0, tpos = 0;  // this lane's token of the batch: symbols, distance (bit 16: literal, low byte), offset in the batch
-    auto flush_to = [&](uint32_t target) {  // ring -> HBM, 64 symbols an instruction
-        for (uint32_t p = flushed + (uint32_t)lane; p < target; p += 64) o[p] = S.window[p & M];
-        flushed = target;
-    };
-    while (status == 0) {
-        uint64_t bitpos = br.bitpos();
-        if (bitpos >= stop_bit) break;  // a block boundary at or behind the stop position
-        if (bitpos + 3 > valid_bits) {
-            status = ST_INPUT;
-            break;
-        }
-        br.ensure32(lane);
-        const uint32_t bfinal = br.take(1), btype = br.take(2);
-        blocks++;
-        if (btype == 0) {  // stored: the bytes go straight from the input to the output (and the ring)
-            br.align8();
-            br.ensure32(lane);
-            bitpos = br.bitpos();
-            if (bitpos + 32 > valid_bits) {
-                status = ST_INPUT;
-                break;
-            }
-            const uint32_t len = br.take(16);
-            br.ensure32(lane);
-            const uint32_t nlen = br.take(16);
-            if ((len ^ nlen) != 0xFFFFu) {
-                status = ST_STORED;
-                break;
-            }
-            bitpos += 32;
-            if (bitpos + 8ull * len > valid_bits) {
-                status = ST_INPUT;
-                break;
-            }
-            if ((uint64_t)op + len > cap) {
-                status = ST_ROOM;
-                break;
-            }
-            flush_to(op);
-            const uint8_t *src = bytes + (bitpos >> 3);
-            asm volatile("" ::: "memory");
-            for (uint32_t i = (uint32_t)lane; i < len; i += 64) {
-                const uint16_t v = src[i];
-                S.window[(op + i) & M] = v;
-                o[op + i] = v;
-            }
-            LDS_ORDER();
-            op += len;
-            flushed = op;
-            if (len) br.init(in, bitpos + 8ull * len, lane);
-        } else if (btype == 3) {
-            status = ST_BTYPE;
-            break;
-        } else {
-            int nlit, ndist;
-            if (btype == 1) {  // fixed codes
-                LDS_ORDER();
-                for (int s = lane; s < 288; s += 64) S.lens[s] = s < 144 ? 8 : s < 256 ? 9 : s < 280 ? 7 : 8;
-                if (lane < 32) S.lens[288 + lane] = 5;
-                nlit = 288;
-                ndist = 30;
-            } else {
-                status = parse_dynamic2(S, br, lane, nlit, ndist);
-                if (status) break;
-            }
-            if (!build(S, S.lens, nlit, S.lcount, S.lsym, S.lit, ROOT, 1, lane) ||
-                !build(S, S.lens + nlit, ndist, S.dcount, S.dsym, S.dist, DROOT, 2, lane)) {
-                status = ST_HEADER;
-                break;
-            }
-#pragma unroll
-            for (int j = 0; j < 16; j++) TL[j] = S.lit[j * 64 + lane];
-#pragma unroll
-            for (int j = 0; j < 4; j++) TD[j] = S.dist[j * 64 + lane];
-            // ---- the symbols of the block, a batch of tokens at a time
-            bool eob = false;
-            while (!eob && status == 0) {
-                // phase 1: decode (scalar unit; no LDS, no memory)
-                uint32_t n = 0, span = 0;
-                while (n < 64u && span < SPAN_LIMIT) {
-                    br.ensure32(lane);
-                    uint32_t e = lookup16(TL, br.peek(ROOT));
-                    if (e == 0) {  // a code longer than the root
-                        uint32_t l;
-                        const uint32_t sy = slow_symbol(br.bb, S.lcount, S.lsym, l);
-                        if (l == 0 || sy >= 286u) {
-                            status = ST_LITLEN;
-                            break;
-                        }
-                        e = entry_of(S, 1, uni(sy), uni(l));
-                        e = uni(e);
-                    }
-                    br.drop(e & 15u);
-                    const uint32_t kind = e >> 28;
-                    if (kind == 0) {
-                        tlen = wlane(tlen, 1u, n);
-                        tval = wlane(tval, 0x10000u | ((e >> 8) & 0xFFu), n);
-                        tpos = wlane(tpos, span, n);
-                        n++;
-                        span++;
-                        continue;
-                    }
-                    if (kind == 2) {
-                        eob = true;
-                        break;
-                    }
-                    const uint32_t lext = (e >> 4) & 15u;
-                    const uint32_t len = ((e >> 8) & 0xFFFFu) + br.take(lext);  // code <= 15 bits + 5 extra: within the 32 ensured
-                    br.ensure32(lane);
-                    uint32_t de = lookup4(TD, br.peek(DROOT));
-                    if (de == 0) {
-                        uint32_t dl;
-                        const uint32_t dsymv = slow_symbol(br.bb, S.dcount, S.dsym, dl);
-                        if (dl == 0 || dsymv >= 30u) {
-                            status = ST_DIST;
-                            break;
-                        }
-                        de = uni(entry_of(S, 2, uni(dsymv), uni(dl)));
-                    }
-                    br.drop(de & 15u);
-                    const uint32_t dext = (de >> 4) & 15u;
-                    const uint32_t dist = ((de >> 8) & 0xFFFFu) + br.take(dext);
-                    const uint32_t at = op + span;
-                    if (fresh_member ? dist > at - floor_op : dist > at + WSIZE) {
-                        status = ST_FAR;
-                        break;
-                    }
-                    tlen = wlane(tlen, len, n);
-                    tval = wlane(tval, dist, n);
-                    tpos = wlane(tpos, span, n);
-                    n++;
-                    span += len;
-                }
-                if (status) break;
-                if (br.bitpos() > valid_bits) {  // (a batch reads at most 64 x 48 bits past the last valid one: the buffer is padded)
-                    status = ST_INPUT;
-                    break;
-                }
-                if ((uint64_t)op + span > cap) {
-                    status = ST_ROOM;
-                    break;
-                }
-                // phase 2: expand.  LDS operations of one wave execute in order: a read issued behind a write sees it.
-                asm volatile("" ::: "memory");
-                const bool act = (uint32_t)lane < n;
-                const bool isl = act && (tval & 0x10000u);
-                if (isl) S.window[(op + tpos) & M] = (uint16_t)(tval & 0xFFu);
-                uint64_t mm = __ballot(act && !isl);
-                while (mm) {
-                    uint32_t Lg[4], Pg[4];
-                    uint16_t vg[4];
-                    int cnt = 0;
-                    uint32_t pfirst = 0;
-                    bool generic = false;
-                    uint32_t gL = 0, gD = 0, gP = 0;
-#pragma unroll
-                    for (int g = 0; g < 4; g++) {
-                        if (!mm || generic) break;
-                        const uint32_t j = (uint32_t)__builtin_ctzll(mm);
-                        const uint32_t L = rl(tlen, j), D = rl(tval, j), P = op + rl(tpos, j);
-                        const bool fast = D <= RING_DMAX && L <= 64u && D >= L;
-                        if (g == 0) {
-                            if (!fast) {
-                                generic = true;
-                                gL = L, gD = D, gP = P;
-                                mm &= mm - 1;
-                                break;
-                            }
-                            pfirst = P;
-                        } else if (!(fast && P - D + L <= pfirst)) {  // its source may be what the group is about to write
-                            break;
-                        }
-                        vg[g] = S.window[(P - D + (uint32_t)lane) & M];
-                        Lg[g] = L;
-                        Pg[g] = P;
-                        cnt = g + 1;
-                        mm &= mm - 1;
-                    }
-#pragma unroll
-                    for (int g = 0; g < 4; g++)
-                        if (g < cnt && (uint32_t)lane < Lg[g]) S.window[(Pg[g] + (uint32_t)lane) & M] = vg[g];
-                    if (generic) {  // long, overlapping or far: every lane a symbol, 64 at a time; with D < L the pattern repeats
-                        if (gD > RING_DMAX) __builtin_amdgcn_s_waitcnt(0x0F70);  // what was flushed is in HBM
-                        for (uint32_t i = (uint32_t)lane; i < gL; i += 64) {
-                            const uint32_t from = gD >= gL ? i : i % gD;
-                            uint16_t v;
-                            if (gD <= RING_DMAX) {
-                                v = S.window[(gP - gD + from) & M];
-                            } else if (gP + from >= gD) {  // older than the ring, inside the chunk: from the output
-                                v = __hip_atomic_load(&o[gP + from - gD], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                            } else {  // older than the ring, before the chunk: the marker itself
-                                v = (uint16_t)(0x8000u | (gP + WSIZE - gD + from));
-                            }
-                            S.window[(gP + i) & M] = v;
-                        }
-                    }
-                }
-                asm volatile("" ::: "memory");
-                op += span;
-                if (op - flushed >= FLUSH_AT) flush_to(op);
-            }
-            if (status) break;
-        }
-        if (bfinal) {
-            // ---- the member ends: trailer (CRC-32, ISIZE), then another member's header, or the end of the stream
-            br.align8();
-            bitpos = br.bitpos();
-            uint64_t q = bitpos >> 3;
-            const uint64_t valid_bytes = valid_bits >> 3;
-            if (q + 8 > valid_bytes) {
-                status = ST_INPUT;
-                break;
-            }
-            if (n_members == MAX_MEMBERS) {
-                status = ST_MEMBERS;
-                break;
-            }
-            const uint64_t tr = bits_at(bytes, q * 8);
-            if (lane == 0) {
-                cd.m_off[n_members] = op;
-                cd.m_crc[n_members] = (uint32_t)tr;
-                cd.m_isize[n_members] = (uint32_t)(tr >> 32);
-            }
-            n_members++;
-            q += 8;
-            bool member = false, trunc = false;
-            if (q == valid_bytes && at_eof) {
-                member = false;
-            } else if (q + 10 > valid_bytes) {
-                const uint64_t hv = bits_at(bytes, q * 8);
-                if (at_eof && !(q + 2 <= valid_bytes && (hv & 0xFFFF) == 0x8B1F)) member = false;
-                else trunc = true;
-            } else {
-                const uint64_t hv = bits_at(bytes, q * 8);
-                const uint32_t flg = (uint32_t)(hv >> 24) & 0xFFu;
-                if ((hv & 0xFFFFFF) != 0x088B1Fu || (flg & 0xE0u)) {
-                    member = false;  // bytes that are no gzip member: ignored like gzip does
-                } else {
-                    member = true;
-                    uint64_t p = q + 10;
-                    if (flg & 4u) {
-                        if (p + 2 > valid_bytes) trunc = true;
-                        else {
-                            const uint32_t xlen = (uint32_t)bits_at(bytes, p * 8) & 0xFFFFu;
-                            p += 2 + xlen;
-                            if (p > valid_bytes) trunc = true;
-                        }
-                    }
-                    for (uint32_t bit = 8; bit <= 16 && !trunc; bit <<= 1)
-                        if (flg & bit) {
-                            for (;;) {
-                                const uint64_t pp = p + (uint64_t)lane;
-                                const bool z = pp < valid_bytes && bytes[pp] == 0;
-                                const uint64_t zm = __ballot(z);
-                                if (zm) {
-                                    p += (uint64_t)__builtin_ctzll(zm) + 1;
-                                    break;
-                                }
-                                p += 64;
-                                if (p >= valid_bytes) {
-                                    trunc = true;
-                                    break;
-                                }
-                            }
-                        }
-                    if (!trunc && (flg & 2u)) {
-                        p += 2;
-                        if (p > valid_bytes) trunc = true;
-                    }
-                    q = p;
-                }
-            }
-            if (trunc) {
-                status = ST_GZHEAD;
-                break;
-            }
-            if (!member) {
-                flags |= 1u;  // the stream ends here
-                br.init(in, q * 8, lane);
-                break;
-            }
-            br.init(in, q * 8, lane);
-            fresh_member = true;
-            floor_op = op;
-        }
-    }
-    flush_to(op);
-    if (lane == 0) {
-        cd.status = status;
-        cd.blocks = blocks;
-        cd.bit_end = br.bitpos();
-        cd.out_len = op;
-        cd.n_members = n_members;
-        cd.flags = flags;
-    }
-}
-
 // ---- k_inflate3: the decode phase lane-parallel, the LDS and register diet for occupancy -------------------------------
-// Measured on version 2 and on the first cut of this kernel (NH_GZ_PROF, profiles/r04_inflate_summary.txt): a wave alone
+// Measured on the version before and on the first cut of this kernel (NH_GZ_PROF, profiles/r04_inflate_notes.txt): a wave alone
 // on a chunk runs its uniform control flow at 10-20 cycles an instruction -- nothing in flight but its own dependent
 // chain --, 1300 cycles a match in an expansion loop with an integer modulo, 400 a token in the walk; 16 KB of LDS and
 // 111 registers let nine waves a CU hide that.  So: (1) the 64 lanes decode the tokens that WOULD start at the next 64
@@ -1732,7 +771,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(5, 8))) void
     }
 }
 
-// ---- k_search2 ------------------------------------------------------------------------------------------------------
+// ---- the search: a candidate's header, one lane each ---------------------------------------------------------------
 constexpr uint32_t CLROW = 129;  // bytes per lane of the code-length code's table (odd: the lanes' rows start in different banks)
 // One lane, one candidate: does a dynamic block header at bit `cand` decode into two complete codes with an end-of-block
 // symbol?  (Code lengths are not kept: Kraft sums as they come.)  tbl = this lane's 128 entries (length << 5 | symbol).
@@ -1821,77 +860,8 @@ __device__ __forceinline__ bool lane_header_ok(const uint8_t *bytes, uint64_t ca
     return eob && kl == 32768u && (kd == 32768u || cdist <= 1u);
 }
 
-__global__ __launch_bounds__(64) void k_search2(const uint32_t *in, uint64_t valid_bits, uint64_t stretch_bits, uint64_t first_bit,
-                                                uint64_t *start) {
-    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-    Lds &S = *(Lds *)smem;
-    // the per-lane tables and the candidate list live where k_inflate keeps its ring (the wave-wide parse does not use it)
-    static_assert(offsetof(Lds, dist) >= 64 * CLROW && offsetof(Lds, window) == 0, "ring + literal root table hold the lanes' tables");
-    __shared__ uint64_t cand_list[128];
-    const uint32_t tbl = (uint32_t)threadIdx.x * CLROW;  // (offset into the LDS; dead whenever the wave-wide parse builds its tables there)
-    const int lane = (int)threadIdx.x;
-    const uint32_t c = blockIdx.x;
-    if (c == 0) {
-        if (lane == 0) start[0] = first_bit;
-        return;
-    }
-    load_bases(S, lane);
-    uint64_t from = (uint64_t)c * stretch_bits, to = from + stretch_bits;
-    if (from <= first_bit) from = first_bit + 1;
-    if (to + 160 > valid_bits) to = valid_bits > 160 ? valid_bits - 160 : 0;
-    const uint8_t *bytes = (const uint8_t *)in;
-    uint64_t found = NONE;
-    uint32_t nc = 0;
-    auto evaluate = [&](uint32_t count) {  // the first `count` candidates of the list, in order
-        LDS_ORDER();
-        const uint64_t mine = (uint32_t)lane < count ? cand_list[lane] : NONE;
-        const bool ok = mine != NONE && lane_header_ok(bytes, mine, valid_bits, tbl);
-        uint64_t m = __ballot(ok);
-        while (m && found == NONE) {
-            const uint32_t j = (uint32_t)__builtin_ctzll(m);
-            const uint64_t cb = cand_list[j];
-            if (plausible_block(S, in, cb, valid_bits, lane)) found = cb;
-            m &= m - 1;
-        }
-        LDS_ORDER();
-    };
-    for (uint64_t b0 = from; b0 < to && found == NONE; b0 += 64) {
-        const uint64_t b = b0 + (uint64_t)lane;
-        const uint64_t w = bits_at(bytes, b), w2 = bits_at(bytes + 7, b);  // w2: bits 56.. of the window
-        bool pre = b < to && (w & 7) == 4 && ((w >> 3) & 31) <= 29 && ((w >> 8) & 31) <= 29;
-        if (__ballot(pre)) {  // (seven of eight positions fail the first three bits)
-            const int ncl = (int)((w >> 13) & 15) + 4;
-            int left = 128, any = 0;
-            for (int i = 0; i < 19; i++) {
-                const unsigned at = 17 + 3 * (unsigned)i;
-                const unsigned l = i < ncl ? (at + 3 <= 56 ? (unsigned)(w >> at) & 7 : (unsigned)(w2 >> (at - 56)) & 7) : 0u;
-                if (l) {
-                    left -= 128 >> l;
-                    any = 1;
-                }
-            }
-            pre = pre && any && left == 0;
-            const uint64_t m = __ballot(pre);
-            if (m) {
-                if (pre) cand_list[nc + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u))] = b;
-                nc += (uint32_t)__popcll(m);
-                if (nc >= 64u) {
-                    evaluate(64u);
-                    LDS_ORDER();
-                    const uint64_t keep = (uint32_t)lane + 64u < nc ? cand_list[64 + lane] : NONE;
-                    LDS_ORDER();
-                    cand_list[lane] = keep;
-                    nc -= 64u;
-                }
-            }
-        }
-    }
-    if (found == NONE && nc) evaluate(nc);
-    if (lane == 0) start[c] = found;
-}
-
-// ---- k_search3: k_search2 on the compact tables of k_inflate3 (9.3 KB of LDS instead of 17.4: seventeen waves a CU; a
-// stretch's wave is latency-bound, 3 ms alone) -------------------------------------------------------------------------
+// ---- k_search3: the block search on the compact tables of k_inflate3 (9.3 KB of LDS: seventeen waves a CU; a stretch's
+// wave is latency-bound, 3 ms alone) -----------------------------------------------------------------------------------
 __device__ __forceinline__ bool plausible_block3(Lds3 &S, const uint32_t *in, uint64_t cand, uint64_t valid_bits, int lane) {
     BitRd br;
     br.init(in, cand + 3, lane);
@@ -2100,54 +1070,6 @@ __global__ __launch_bounds__(1024) void k_finish(ChunkDesc *desc, uint32_t n, ui
         uint64_t fs = NONE;
         for (uint32_t c = 0; c < n && fs == NONE; c++) fs = desc[c].bit_start;  // (the first stretches' chunks: a handful of reads)
         res->first_start = fs;
-    }
-}
-
-// ---- the chunks' windows: a chunk's effect on the window is an index map (a byte of the next window is a literal, or
-// the byte at some index of this one: 0x8000 | index, the symbols' own form), maps compose associatively, and a
-// parallel prefix scan over the chunks' maps gives every chunk's window.
-__global__ __launch_bounds__(256) void k_maps(const ChunkDesc *d, const uint16_t *sym, uint32_t slot_syms, uint16_t *maps) {
-    const uint32_t c = blockIdx.x;
-    const uint32_t nsym = d[c].bit_start == NONE ? 0u : d[c].out_len;
-    const uint16_t *src = sym + (uint64_t)c * slot_syms;
-    uint16_t *m = maps + (size_t)c * WSIZE;
-    // a member that starts inside the chunk cuts the chain: nothing before it can be referred to (its symbols carry no
-    // markers), which the symbols themselves already say
-    for (uint32_t j = blockIdx.y * 256 + threadIdx.x; j < WSIZE; j += gridDim.y * 256) {
-        uint16_t v;
-        if (nsym >= WSIZE) v = src[nsym - WSIZE + j];
-        else if (j < WSIZE - nsym) v = (uint16_t)(0x8000u | (j + nsym));  // the old window moves up
-        else v = src[j - (WSIZE - nsym)];
-        m[j] = v;
-    }
-}
-// one round of the scan: dst[c] = src[c] o src[c - stride] (first through the earlier map, then through c's)
-__global__ __launch_bounds__(256) void k_scan_round(const uint16_t *src, uint16_t *dst, uint32_t n, uint32_t stride) {
-    const uint32_t c = blockIdx.x;
-    const uint16_t *b = src + (size_t)c * WSIZE;
-    uint16_t *o = dst + (size_t)c * WSIZE;
-    if (c < stride) {
-        for (uint32_t j = blockIdx.y * 256 + threadIdx.x; j < WSIZE; j += gridDim.y * 256) o[j] = b[j];
-        return;
-    }
-    const uint16_t *a = src + (size_t)(c - stride) * WSIZE;
-    for (uint32_t j = blockIdx.y * 256 + threadIdx.x; j < WSIZE; j += gridDim.y * 256) {
-        const uint16_t v = b[j];
-        o[j] = v & 0x8000u ? a[v & 0x7FFFu] : v;
-    }
-}
-// windows[c] = the scanned map of chunk c - 1 applied to the window before the piece (w0); windows[0] = w0
-__global__ __launch_bounds__(256) void k_windows(const uint16_t *scanned, const uint8_t *w0, uint8_t *windows) {
-    const uint32_t c = blockIdx.x;  // the window of chunk c
-    uint8_t *w = windows + (size_t)c * WSIZE;
-    for (uint32_t j = blockIdx.y * 256 + threadIdx.x; j < WSIZE; j += gridDim.y * 256) {
-        uint8_t v;
-        if (c == 0) v = w0[j];
-        else {
-            const uint16_t x = scanned[(size_t)(c - 1) * WSIZE + j];
-            v = x & 0x8000u ? w0[x & 0x7FFFu] : (uint8_t)x;
-        }
-        w[j] = v;
     }
 }
 
@@ -2543,9 +1465,6 @@ public:
         if (look_ > size_) look_ = (size_ + 4095) & ~(size_t)4095;
         slot_syms_ = (uint32_t)(16 * stretch_ + 65536);  // symbols a stretch's slot holds: text up to 16 : 1
         trace_ = getenv("NOHUMAN_TRACE") != nullptr;
-        v1_ = getenv("NOHUMAN_GZDEV_V1") != nullptr;  // the first versions of the search and decode kernels (A / B on one box)
-        v2_ = getenv("NOHUMAN_GZDEV_V2") != nullptr;  // the scalar-decode version of k_inflate
-        if (const char *e = getenv("NOHUMAN_GZDEV_SCAN")) scan_rounds_ = !strcmp(e, "rounds");  // the log2(n) rounds of the first version
         if (hipSetDevice(s_->device_) != hipSuccess) {
             err = "hipSetDevice failed";
             close();
@@ -2595,11 +1514,7 @@ public:
                   (!bgzf_ || hipHostMalloc((void **)&d.h_start_, (size_t)n_slots_ * 8, hipHostMallocDefault) == hipSuccess);
         if (ok) ok = hipMemset(d.d_win_[0], 0, WSIZE) == hipSuccess;  // (the input buffer's tail is zeroed with every piece's upload)
         if (ok)
-            ok = hipFuncSetAttribute((const void *)k_search, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(Lds)) == hipSuccess &&
-                 hipFuncSetAttribute((const void *)k_inflate, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(Lds)) == hipSuccess &&
-                 hipFuncSetAttribute((const void *)k_search2, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(Lds)) == hipSuccess &&
-                 hipFuncSetAttribute((const void *)k_inflate2, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(Lds)) == hipSuccess &&
-                 hipFuncSetAttribute((const void *)k_inflate3, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(Lds3)) == hipSuccess &&
+            ok = hipFuncSetAttribute((const void *)k_inflate3, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(Lds3)) == hipSuccess &&
                  hipFuncSetAttribute((const void *)k_scan_local, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(2 * WSIZE)) == hipSuccess &&
                  hipFuncSetAttribute((const void *)k_scan_groups, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(2 * WSIZE)) == hipSuccess;
         for (auto &e : d.ev_)
@@ -2716,8 +1631,8 @@ private:
     static constexpr size_t ALIGN = 4096;
     static constexpr size_t SEARCH3_LDS = sizeof(Lds3) > 64 * CLROW ? sizeof(Lds3) : 64 * CLROW;
     typedef void (*InflateFn)(const uint32_t *, uint64_t, uint32_t, ChunkDesc *, uint16_t *, uint32_t, uint32_t);
-    InflateFn inflate_kernel() const { return v1_ ? k_inflate : v2_ ? k_inflate2 : k_inflate3; }
-    size_t inflate_lds() const { return v1_ || v2_ ? sizeof(Lds) : sizeof(Lds3); }
+    InflateFn inflate_kernel() const { return k_inflate3; }
+    size_t inflate_lds() const { return sizeof(Lds3); }
 
     long fail(const std::string &m) {
         if (error_.empty()) error_ = "gzip: " + m + " (" + path_ + ")";
@@ -2831,14 +1746,7 @@ private:
             if (by_headers) GZA_TRY(hipMemcpyAsync(d.d_start_, d.h_start_, (size_t)n_str * 8, hipMemcpyHostToDevice, stream));
             else bgzf_ = false;  // (the headers do not go on as they began: an ordinary gzip stream from here on)
         }
-        if (by_headers) {
-        } else if (v1_)
-            hipLaunchKernelGGL(k_search, dim3(n_str), dim3(64), sizeof(Lds), stream, (const uint32_t *)d.d_in_, valid_bits, (uint64_t)stretch_ * 8,
-                               j.first_bit, d.d_start_);
-        else if (v2_)
-            hipLaunchKernelGGL(k_search2, dim3(n_str), dim3(64), sizeof(Lds), stream, (const uint32_t *)d.d_in_, valid_bits,
-                               (uint64_t)stretch_ * 8, j.first_bit, d.d_start_);
-        else
+        if (!by_headers)
             hipLaunchKernelGGL(k_search3, dim3(n_str), dim3(64), SEARCH3_LDS, stream, (const uint32_t *)d.d_in_, valid_bits,
                                (uint64_t)stretch_ * 8, j.first_bit, d.d_start_);
         long fake_end = -1;
@@ -2858,7 +1766,7 @@ private:
         }
         hipLaunchKernelGGL(k_plan, dim3(1), dim3(1024), 0, stream, (const uint64_t *)d.d_start_, n_str, end_bit, slot_syms_, d.d_desc_);
         if (trace_) (void)hipEventRecord(d.ev_[1], stream);
-        const uint32_t kflags = (j.at_eof ? 1u : 0u) | (by_headers && !v1_ && !v2_ ? 2u : 0u);
+        const uint32_t kflags = (j.at_eof ? 1u : 0u) | (by_headers ? 2u : 0u);
         hipLaunchKernelGGL(inflate_kernel(), dim3(n_str), dim3(64), inflate_lds(), stream, (const uint32_t *)d.d_in_, valid_bits,
                            kflags, d.d_desc_, d.d_sym_, slot_syms_, NOIDX);
         if (fake_end >= 0) hipLaunchKernelGGL(k_test_mark_end, dim3(1), dim3(1), 0, stream, d.d_desc_, (uint32_t)fake_end);
@@ -2918,17 +1826,6 @@ private:
         const uint32_t gy = 4;
         if (j.by_headers) {
             // (every chunk starts at a member's first block: it has no window and leaves no markers)
-        } else if (scan_rounds_) {
-            hipLaunchKernelGGL(k_maps, dim3(n_str, gy), dim3(256), 0, stream, (const ChunkDesc *)d.d_desc_, (const uint16_t *)d.d_sym_, slot_syms_,
-                               d.d_maps_[0]);
-            int cur = 0;
-            for (uint32_t stride = 1; stride < n_str; stride <<= 1) {
-                hipLaunchKernelGGL(k_scan_round, dim3(n_str, gy), dim3(256), 0, stream, (const uint16_t *)d.d_maps_[cur], d.d_maps_[cur ^ 1], n_str,
-                                   stride);
-                cur ^= 1;
-            }
-            hipLaunchKernelGGL(k_windows, dim3(n_str, gy), dim3(256), 0, stream, (const uint16_t *)d.d_maps_[cur], (const uint8_t *)d.d_win_[d.win_],
-                               d.d_windows_);
         } else {
             const uint32_t ng = (n_str + SCAN_GROUP - 1) / SCAN_GROUP;
             hipLaunchKernelGGL(k_scan_local, dim3(ng), dim3(1024), 2 * WSIZE, stream, (const ChunkDesc *)d.d_desc_, (const uint16_t *)d.d_sym_, slot_syms_,
@@ -3059,7 +1956,7 @@ private:
     uint64_t cell_bytes() const { return (uint64_t)n_slots_ * stretch_; }
     uint64_t cell_of_pos() const { return ((pos_bit_ >> 3) - grid0_) / cell_bytes(); }
     uint64_t cells() const { return (size_ - grid0_ + cell_bytes() - 1) / cell_bytes(); }
-    bool spec_ok() const { return !v1_ && !v2_ && !bgzf_ && stretch_ % ALIGN == 0 && !host_mode_; }
+    bool spec_ok() const { return !bgzf_ && stretch_ % ALIGN == 0 && !host_mode_; }
     void spec_decode(int k, uint64_t cell, hipStream_t stream) {
         DevSet &d = *sets_[(size_t)k];
         d.spec = PieceJob();
@@ -3174,7 +2071,7 @@ private:
     double ratio_ = 5.0;  // text per compressed byte seen lately (before anything was seen: FASTQ's 4-5 : 1; a piece that does not fit is cut down)
     uint32_t run_crc_ = 0;
     uint64_t run_len_ = 0;
-    bool trace_ = false, warned_ = false, host_mode_ = false, v1_ = false, v2_ = false, scan_rounds_ = false;
+    bool trace_ = false, warned_ = false, host_mode_ = false;
     bool bgzf_ = false;          // a BGZF file: members of one final block each, their sizes in the headers -- no search needed
     uint64_t bgzf_hdr_ = 0;      // header of the member whose data the stream stands at (byte offset in the file)
     std::mutex st_mu_;           // the statistics: phase A of a piece decoded ahead runs on another thread

@@ -18,7 +18,7 @@ code = ("import sys, ctypes as C; sys.path.insert(0, %r)\n"
 subprocess.run([sys.executable, "-c", code, src, ref, "host"], check=True)
 a = np.memmap(ref, np.uint8, "r")
 print("host text", a.size, flush=True)
-runs = [({}, 0, 0), ({"NOHUMAN_GZDEV_V2": "1"}, 0, 0), ({}, 0, 16384)]
+runs = [({}, 0, 0), ({}, 0, 16384), ({}, 64 << 20, 32768)]
 for env, seg, stretch in runs:
     out = src + ".dev"
     e = dict(os.environ, NOHUMAN_GZDEV_NOCRC="1", NOHUMAN_TRACE="1", **env)
