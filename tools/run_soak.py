@@ -47,7 +47,22 @@ def fastq(rng, n, odd):
     return data
 
 
+def bgzf(rng, data):
+    import struct
+    out = []
+    block = int(rng.choice([65280, 20000, 3000]))
+    for i in list(range(0, len(data), block)) + [None]:
+        blk = b"" if i is None else data[i:i + block]
+        co = zlib.compressobj(int(rng.choice([1, 6])), zlib.DEFLATED, -15)
+        body = co.compress(blk) + co.flush()
+        out.append(b"\x1f\x8b\x08\x04" + bytes(4) + b"\x00\xff" + struct.pack("<H", 6) + b"BC" + struct.pack("<HH", 2, 12 + 6 + len(body) + 8 - 1) +
+                   body + struct.pack("<II", zlib.crc32(blk), len(blk)))
+    return b"".join(out)
+
+
 def gz(rng, data):
+    if rng.random() < 0.2:
+        return bgzf(rng, data)  # bgzip's format: the reader on the GPU takes its chunk starts from the members' headers
     parts, pos = [], 0
     cuts = sorted(int(x) for x in rng.integers(0, len(data) + 1, int(rng.choice([0, 0, 1, 3])))) + [len(data)]
     for c in cuts:
