@@ -180,3 +180,21 @@ def test_many_taxa_in_one_segment_take_the_second_pass(monkeypatch):
     with Engine.from_images(minidb.opts_bytes(), tax.to_bytes(), hashb) as eng:
         exp = _check(eng, odb, reads, 0.0, "many taxa")
     assert (exp["call"] != 0).sum() > 60
+
+
+@pytest.mark.parametrize("seed", range(8))
+def test_segments_soak_many_reads_many_launches(toy, toy_oracle, toy_engine, seed):
+    """the partials of a split read travel by write-through stores, a counter and sc1 loads (no release /
+    acquire pair) -- a soak over seeds and repeated launches: reads of 20-200 kb (up to fifty segments each, finished by
+    whichever wave comes last), every launch compared with the oracle, which knows no segments."""
+    _, _, _, genomes, _ = toy
+    rng = np.random.default_rng(500 + seed)
+    reads = []
+    for _ in range(40):
+        ln = int(rng.integers(20_000, 200_000))
+        reads.append(synth.mutate(rng, _genome_walk(rng, genomes, ln), 0.0, 0.002, 0.0))
+    bases, offs = orc.pack_reads(reads, False)
+    exp = toy_oracle.classify(bases, offs, False, 0.0)[0]
+    for launch in range(4):
+        got = toy_engine.classify(bases, offs, False, 0.0, long_reads=True)
+        _same(got, exp, "seed %d launch %d" % (seed, launch))
