@@ -2756,7 +2756,7 @@ private:
             const size_t full = old.n_rec / bf_ * bf_;
             const size_t from = full < old.n_rec ? old.h_bstart[full / bf_] : old.used_len;
             carry = old.text_len - from;
-            if (carry > head_) return fail("a batch of FASTQ records larger than the gzip reader's buffer holds in front of a piece");
+            if (carry > head_) return fail("a batch of FASTQ records is larger than the room the gzip reader on the GPU keeps in front of a piece (768 MiB); lower NOHUMAN_BATCH_FRAGS or read with NOHUMAN_GZ_READER=host");
             const int odev = lanes_[(size_t)old.lane].device;
             uint8_t *const dst = p.d_text + head_ - carry;
             if (carry && ((odev == ln.device ? hipMemcpyAsync(dst, old.text0 + from, carry, hipMemcpyDeviceToDevice, ln.stream_i)
