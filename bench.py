@@ -665,8 +665,9 @@ def gzip_leg(cx, args):
             "ratio": round(len(data) / out_bytes, 3),
             "inflates_to_the_text": bool(same),
             "zlib6_one_core": {"MBps": round(len(sample) / dz / 1e6, 1), "ratio": round(len(sample) / len(z), 3)},
-            "what": "one wave per 64 KiB of text, dynamic Huffman blocks of 32 KiB, 8-way hash buckets in LDS; kernel time = HIP "
-                    "events around the encoder's kernels of every 128 MiB chunk; wall includes staging, CRC-32 and the file",
+            "what": "one wave per 64 KiB of text, dynamic Huffman blocks of 32 KiB, %s-way hash buckets in LDS (NOHUMAN_GZIP_WAYS); kernel time = HIP "
+                    "events around the encoder's kernels of every 128 MiB chunk; wall includes staging, CRC-32 and the file"
+                    % os.environ.get("NOHUMAN_GZIP_WAYS", "4"),
         }
     finally:
         shutil.rmtree(tmp, ignore_errors=True)

@@ -558,8 +558,11 @@ using dfl::crc32_join;
 int gzip_ways() {
     static const int w = [] {
         const char *e = getenv("NOHUMAN_GZIP_WAYS");
-        const int v = e ? atoi(e) : 8;
-        return v == 4 ? 4 : v == 6 ? 6 : 8;
+        // four ways since round 4: 12 KB of LDS a wave = three waves a SIMD, 27.2 GB/s against 20.3 with eight ways (two waves),
+        // the run of 50 M gzip pairs to gzip 15 % shorter, the files 1.4 % larger (4.054 : 1 against 4.112; zlib -6: 4.299);
+        // NOHUMAN_GZIP_WAYS=6 | 8 for the smaller files (profiles/r04_e2e.txt)
+        const int v = e ? atoi(e) : 4;
+        return v == 8 ? 8 : v == 6 ? 6 : 4;
     }();
     return w;
 }
