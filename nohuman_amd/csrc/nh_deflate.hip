@@ -31,6 +31,9 @@
 #include <zlib.h>
 
 #include <chrono>
+#include <condition_variable>
+#include <mutex>
+#include <thread>
 #include <string>
 #include <vector>
 
@@ -916,7 +919,10 @@ bool write_fd(int fd, const void *p, size_t n) {
 class GpuGzipEncoder : public StreamEncoder {
 public:
     GpuGzipEncoder(int fd, const char *name) : fd_(fd), name_(name) {}
-    ~GpuGzipEncoder() override { dev_.destroy(); }
+    ~GpuGzipEncoder() override {
+        stop_writer();
+        dev_.destroy();
+    }
     int init(int device) {
         const int rc = dev_.init(device);
         if (rc != NH_OK) return rc;
@@ -972,6 +978,8 @@ public:
         if (rc_ == NH_OK && dev_.buf[cur_].fill) rotate();
         for (int k = 0; k < DeflateDev::NBUF && rc_ == NH_OK; k++) retire((cur_ + k) % DeflateDev::NBUF);
         if (rc_ != NH_OK) return rc_;
+        wait_writer();
+        if (rc_ != NH_OK) return rc_;
         unsigned char tail[10] = {0x03, 0x00};  // final block: fixed codes, end-of-block only
         for (int i = 0; i < 4; i++) {
             tail[2 + i] = (unsigned char)(crc_ >> (8 * i));
@@ -996,17 +1004,66 @@ private:
         cur_ = (cur_ + 1) % DeflateDev::NBUF;
         retire(cur_);
     }
+    // A finished chunk's bytes go to the file on a thread of their own, one chunk behind: the caller (nh_run's flusher) waits
+    // for the GPU on the next chunk meanwhile instead of for the file (4.4 GB a mate file: 0.7 s of a 2.8 s run).  The chunk's
+    // page-locked output buffer is taken again only NBUF rotations later, long after its bytes are written.
     void retire(int i) {
         if (!dev_.buf[i].in_flight || rc_ != NH_OK) return;
         size_t len = 0;
         const uint64_t t0 = now_ns();
         if ((rc_ = dev_.collect(i, &len, &crc_)) != NH_OK) return;
         const uint64_t t1 = now_ns();
-        if (!write_fd(fd_, dev_.buf[i].h_out, len)) rc_ = set_error(NH_EIO, "write error on %s", name_.c_str());
+        wait_writer();
+        if (rc_ == NH_OK && len) post_write(dev_.buf[i].h_out, len);
         t_collect_ += t1 - t0;
         t_file_ += now_ns() - t1;
         out_bytes_ += len;
     }
+    void post_write(const void *p, size_t n) {
+        if (!wt_.joinable()) wt_ = std::thread([this] { writer_main(); });
+        std::lock_guard<std::mutex> lk(wmu_);
+        wjob_ = p;
+        wlen_ = n;
+        wbusy_ = true;
+        wcv_.notify_all();
+    }
+    void wait_writer() {
+        std::unique_lock<std::mutex> lk(wmu_);
+        wcv_.wait(lk, [&] { return !wbusy_; });
+        if (werr_ && rc_ == NH_OK) rc_ = set_error(NH_EIO, "write error on %s", name_.c_str());
+    }
+    void stop_writer() {
+        {
+            std::lock_guard<std::mutex> lk(wmu_);
+            wquit_ = true;
+            wcv_.notify_all();
+        }
+        if (wt_.joinable()) wt_.join();
+    }
+    void writer_main() {
+        for (;;) {
+            const void *p;
+            size_t n;
+            {
+                std::unique_lock<std::mutex> lk(wmu_);
+                wcv_.wait(lk, [&] { return wbusy_ || wquit_; });
+                if (!wbusy_) return;
+                p = wjob_;
+                n = wlen_;
+            }
+            const bool ok = write_fd(fd_, p, n);
+            std::lock_guard<std::mutex> lk(wmu_);
+            if (!ok) werr_ = true;
+            wbusy_ = false;
+            wcv_.notify_all();
+        }
+    }
+    std::thread wt_;
+    std::mutex wmu_;
+    std::condition_variable wcv_;
+    const void *wjob_ = nullptr;
+    size_t wlen_ = 0;
+    bool wbusy_ = false, wquit_ = false, werr_ = false;
     static uint64_t now_ns() {
         return (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now().time_since_epoch()).count();
     }
