@@ -261,7 +261,8 @@ int nh_gunzip_file(const char *in, const char *out, uint32_t threads, uint64_t c
 /* The gzip READER on the GPU (nohuman_amd/csrc/nh_gunzip.hip; what nh_run reads .gz inputs with: replaces the `gzip -dc`
  * pipe of kraken2's wrapper): decompress `in` to `out` on `device` -- block search, decode to
  * 16-bit symbols with markers, the chunks' windows by a prefix scan, marker replacement and the members' CRC-32 on the
- * device; seg_bytes / stretch_bytes = compressed bytes per piece / per chunk (0 = defaults).  stats8 (optional):
+ * device (BGZF files: the chunks' starts from the members' headers, no search); seg_bytes / stretch_bytes = compressed
+ * bytes per piece / per chunk (0 = defaults).  stats8 (optional):
  * {pieces, chunks, chunks decoded again after a false block start, pieces the host decoder took over, members, text
  * bytes, gzip bytes, kernel microseconds (NOHUMAN_TRACE only)}.  Test / tool support like nh_gunzip_file. */
 int nh_gunzip_device_file(const char *in, const char *out, int32_t device, uint64_t seg_bytes, uint64_t stretch_bytes,
