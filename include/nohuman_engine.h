@@ -267,6 +267,10 @@ int nh_gunzip_file(const char *in, const char *out, uint32_t threads, uint64_t c
  * bytes, gzip bytes, kernel microseconds (NOHUMAN_TRACE only)}.  Test / tool support like nh_gunzip_file. */
 int nh_gunzip_device_file(const char *in, const char *out, int32_t device, uint64_t seg_bytes, uint64_t stretch_bytes,
                           uint64_t *stats8);
+/* Bytes of idle buffers the process keeps between runs for the gzip reader on `device` (page_locked != 0: its
+ * page-locked staging, all devices): bounded by bytes, oldest evicted first, given back before any allocation of the
+ * run path fails, emptied by nh_close.  Diagnostic / test support. */
+uint64_t nh_cache_bytes(int32_t device, int32_t page_locked);
 /* The one collective of the path: `counters` holds n_devices rows of 4 uint64
  * {fragments, classified, bases, table_lookups}, row g being the totals of device_ids[g] (NULL =
  * 0..n_devices-1); on return every row is the sum over the devices -- one ncclAllReduce(4 x uint64, sum)

@@ -76,6 +76,7 @@ SYMBOLS = {
     "nh_compress_file_device": (C.c_int, [C.c_char_p, C.c_char_p, C.c_int, C.c_uint32, C.c_int32]),
     "nh_gzip_gpu_file": (C.c_int, [C.c_int32, _P, C.c_uint64, C.c_char_p, C.POINTER(C.c_uint64)]),
     "nh_gunzip_file": (C.c_int, [C.c_char_p, C.c_char_p, C.c_uint32, C.c_uint64, C.POINTER(C.c_uint64)]),
+    "nh_cache_bytes": (C.c_uint64, [C.c_int32, C.c_int32]),
     "nh_gunzip_device_file": (C.c_int, [C.c_char_p, C.c_char_p, C.c_int32, C.c_uint64, C.c_uint64, C.POINTER(C.c_uint64)]),
     "nh_fastx_scan": (C.c_int, [C.c_char_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64),
                                 C.POINTER(C.c_uint64)]),

@@ -123,7 +123,7 @@ int allreduce_counters(const int *ids, int n_dev, uint64_t *rows, std::string &b
     for (int g = 0; g < n_dev && he == hipSuccess; g++) {
         he = hipSetDevice(ids[g]);
         if (he == hipSuccess) he = hipStreamCreateWithFlags(&st[g], hipStreamNonBlocking);
-        if (he == hipSuccess) he = hipMalloc((void **)&d[g], 4 * sizeof(uint64_t));
+        if (he == hipSuccess) he = dev_malloc((void **)&d[g], 4 * sizeof(uint64_t));
         if (he == hipSuccess && !(d_src && d_src[g]))
             he = hipMemcpyAsync(d[g], rows + 4 * g, 4 * sizeof(uint64_t), hipMemcpyHostToDevice, st[g]);
     }

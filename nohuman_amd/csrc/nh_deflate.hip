@@ -575,7 +575,7 @@ int gzip_ways() {
 void *host_alloc(size_t n) {
     void *p = nullptr;
     static const bool no_pin = getenv("NOHUMAN_NO_PINNED") != nullptr;
-    if (!no_pin && hipHostMalloc(&p, n + 64, hipHostMallocDefault) == hipSuccess) {
+    if (!no_pin && host_malloc(&p, n + 64, hipHostMallocDefault) == hipSuccess) {
         *(uint64_t *)p = 1;
         return (char *)p + 64;
     }
@@ -648,14 +648,14 @@ struct DeflateDev {  // device side of one encoder: buffers for chunks in flight
         slot_stride = REGION + 256;
         for (Buf &b : buf) {
             if (!(b.h_in = (uint8_t *)host_alloc(CHUNK + 64))) return set_error(NH_EOOM, "gzip encoder: no memory for the staging buffers");
-            if ((e = hipMalloc((void **)&b.d_in, CHUNK + 256)) != hipSuccess) return fail(e, "device input");
+            if ((e = dev_malloc((void **)&b.d_in, CHUNK + 256)) != hipSuccess) return fail(e, "device input");
             if ((e = hipMemset(b.d_in, 0, CHUNK + 256)) != hipSuccess) return fail(e, "memset");
-            if ((e = hipMalloc((void **)&b.d_slots, (size_t)max_regions * slot_stride)) != hipSuccess) return fail(e, "slots");
-            if ((e = hipMalloc((void **)&b.d_sizes, max_regions * sizeof(uint32_t))) != hipSuccess) return fail(e, "sizes");
-            if ((e = hipMalloc((void **)&b.d_crcs, max_regions * sizeof(uint32_t))) != hipSuccess) return fail(e, "crcs");
+            if ((e = dev_malloc((void **)&b.d_slots, (size_t)max_regions * slot_stride)) != hipSuccess) return fail(e, "slots");
+            if ((e = dev_malloc((void **)&b.d_sizes, max_regions * sizeof(uint32_t))) != hipSuccess) return fail(e, "sizes");
+            if ((e = dev_malloc((void **)&b.d_crcs, max_regions * sizeof(uint32_t))) != hipSuccess) return fail(e, "crcs");
             if (!(b.h_crcs = (uint32_t *)host_alloc(max_regions * sizeof(uint32_t)))) return set_error(NH_EOOM, "gzip encoder: no memory for the staging buffers");
-            if ((e = hipMalloc((void **)&b.d_offsets, (max_regions + 1) * sizeof(uint64_t))) != hipSuccess) return fail(e, "offsets");
-            if ((e = hipMalloc((void **)&b.d_out, (size_t)max_regions * slot_stride)) != hipSuccess) return fail(e, "packed output");
+            if ((e = dev_malloc((void **)&b.d_offsets, (max_regions + 1) * sizeof(uint64_t))) != hipSuccess) return fail(e, "offsets");
+            if ((e = dev_malloc((void **)&b.d_out, (size_t)max_regions * slot_stride)) != hipSuccess) return fail(e, "packed output");
             if (!(b.h_out = (uint8_t *)host_alloc((size_t)max_regions * slot_stride)) || !(b.h_total = (uint64_t *)host_alloc(64)))
                 return set_error(NH_EOOM, "gzip encoder: no memory for the staging buffers");
             if ((e = hipEventCreate(&b.done)) != hipSuccess) return fail(e, "event");
@@ -663,9 +663,9 @@ struct DeflateDev {  // device side of one encoder: buffers for chunks in flight
             if ((e = hipEventCreate(&b.k1)) != hipSuccess) return fail(e, "event");
             if ((e = hipEventCreateWithFlags(&b.filled, hipEventDisableTiming)) != hipSuccess) return fail(e, "event");
         }
-        if ((e = hipMalloc((void **)&d_tok, (size_t)max_regions * dfl::TOK_CAP * sizeof(uint32_t))) != hipSuccess) return fail(e, "tokens");
+        if ((e = dev_malloc((void **)&d_tok, (size_t)max_regions * dfl::TOK_CAP * sizeof(uint32_t))) != hipSuccess) return fail(e, "tokens");
         // d_prior: two rows that alternate from chunk to chunk, then the two candidates for the first prices of a stream
-        if ((e = hipMalloc((void **)&d_prior, 4 * dfl::PRIOR_BYTES)) != hipSuccess) return fail(e, "prior");
+        if ((e = dev_malloc((void **)&d_prior, 4 * dfl::PRIOR_BYTES)) != hipSuccess) return fail(e, "prior");
         // The price feedback from block to block has two stable states on FASTQ text: bases matched wherever four of
         // them repeat and their literals dear (where zlib's rules lead), or bases literal and cheap with only long
         // repeats matched.  Which one is smaller depends on the qualities (few distinct values: the second, by 7 %;
@@ -681,7 +681,7 @@ struct DeflateDev {  // device side of one encoder: buffers for chunks in flight
         if ((e = hipMemcpy(d_prior + 2 * dfl::PRIOR_BYTES, prior, sizeof prior, hipMemcpyHostToDevice)) != hipSuccess) return fail(e, "prior copy");
         if ((e = hipMemcpy(d_prior, prior[1], dfl::PRIOR_BYTES, hipMemcpyHostToDevice)) != hipSuccess) return fail(e, "prior copy");
         if (getenv("NOHUMAN_GZIP_PROF")) {
-            if ((e = hipMalloc((void **)&d_prof, 64)) != hipSuccess) return fail(e, "prof");
+            if ((e = dev_malloc((void **)&d_prof, 64)) != hipSuccess) return fail(e, "prof");
             (void)hipMemset(d_prof, 0, 64);
         }
         return NH_OK;

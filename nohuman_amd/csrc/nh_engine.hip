@@ -23,6 +23,23 @@
 
 namespace nh {
 
+static hipError_t alloc_retry(void **p, size_t bytes, bool host, unsigned flags) {
+    hipError_t e = host ? hipHostMalloc(p, bytes, flags) : hipMalloc(p, bytes);
+    if (e == hipSuccess) return e;
+    (void)hipGetLastError();
+    int dev = -1;
+    (void)hipGetDevice(&dev);
+    run_cache_trim();
+    dev_cache_trim();  // (frees on every device it holds buffers of)
+    if (dev >= 0) (void)hipSetDevice(dev);
+    e = host ? hipHostMalloc(p, bytes, flags) : hipMalloc(p, bytes);
+    if (e != hipSuccess) (void)hipGetLastError();
+    return e;
+}
+hipError_t dev_malloc(void **p, size_t bytes) { return alloc_retry(p, bytes, false, 0); }
+hipError_t host_malloc(void **p, size_t bytes, unsigned flags) { return alloc_retry(p, bytes, true, flags); }
+
+
 thread_local std::string g_last_error;
 
 int set_error(int code, const char *fmt, ...) {
@@ -237,24 +254,24 @@ static int common_open(Engine *e, int device) {
     if (const char *v = getenv("NOHUMAN_OPT_RESET_PER_MATE")) e->options.reset_per_mate = atoi(v) != 0;
     if (const char *v = getenv("NOHUMAN_OPT_MIN_HIT_GROUPS")) e->options.minimum_hit_groups = (uint32_t)atoi(v);
     HIP_TRY(hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking));
-    HIP_TRY(hipMalloc((void **)&e->d_counters, (CNT_N + 12) * sizeof(uint64_t)));
+    HIP_TRY(dev_malloc((void **)&e->d_counters, (CNT_N + 12) * sizeof(uint64_t)));
     HIP_TRY(hipMemset(e->d_counters, 0, (CNT_N + 12) * sizeof(uint64_t)));
     // launch slots start CLEAN and every launch leaves its slot clean again (k_finish_launch)
-    HIP_TRY(hipMalloc((void **)&e->d_work, LAUNCH_SLOTS * WORK_PASSES * WORK_WORDS * WORK_STRIDE * sizeof(unsigned long long)));
+    HIP_TRY(dev_malloc((void **)&e->d_work, LAUNCH_SLOTS * WORK_PASSES * WORK_WORDS * WORK_STRIDE * sizeof(unsigned long long)));
     HIP_TRY(hipMemset(e->d_work, 0, LAUNCH_SLOTS * WORK_PASSES * WORK_WORDS * WORK_STRIDE * sizeof(unsigned long long)));
-    HIP_TRY(hipMalloc((void **)&e->d_cshard, LAUNCH_SLOTS * COUNTER_SHARDS * COUNTER_STRIDE * sizeof(unsigned long long)));
+    HIP_TRY(dev_malloc((void **)&e->d_cshard, LAUNCH_SLOTS * COUNTER_SHARDS * COUNTER_STRIDE * sizeof(unsigned long long)));
     HIP_TRY(hipMemset(e->d_cshard, 0, LAUNCH_SLOTS * COUNTER_SHARDS * COUNTER_STRIDE * sizeof(unsigned long long)));
     // [0, LAUNCH_SLOTS) "fragments left to the BIG variant" per launch slot, then the sticky error bits,
     // then [LAUNCH_SLOTS + 1, 2 LAUNCH_SLOTS + 1) "chunks left to the generic kernel" per launch slot
-    HIP_TRY(hipMalloc((void **)&e->d_error, (2 * LAUNCH_SLOTS + 1) * sizeof(int)));
+    HIP_TRY(dev_malloc((void **)&e->d_error, (2 * LAUNCH_SLOTS + 1) * sizeof(int)));
     HIP_TRY(hipMemset(e->d_error, 0, (2 * LAUNCH_SLOTS + 1) * sizeof(int)));
-    HIP_TRY(hipMalloc((void **)&e->d_defer, LAUNCH_SLOTS * DEFER_WORDS * sizeof(uint32_t)));
+    HIP_TRY(dev_malloc((void **)&e->d_defer, LAUNCH_SLOTS * DEFER_WORDS * sizeof(uint32_t)));
     HIP_TRY(hipMemset(e->d_defer, 0, LAUNCH_SLOTS * DEFER_WORDS * sizeof(uint32_t)));
     return NH_OK;
 }
 
 static int upload_taxonomy(Engine *e) {
-    HIP_TRY(hipMalloc((void **)&e->d_parent, e->parent.size() * sizeof(uint32_t)));
+    HIP_TRY(dev_malloc((void **)&e->d_parent, e->parent.size() * sizeof(uint32_t)));
     HIP_TRY(hipMemcpy(e->d_parent, e->parent.data(), e->parent.size() * sizeof(uint32_t),
                       hipMemcpyHostToDevice));
     return NH_OK;
@@ -401,7 +418,7 @@ int open_dir(const char *db_dir, int device, Engine **out) {
         hipEvent_t ev[2];
         hipError_t he = hipMemset(e->d_table, 0, e->table_cells_alloc * sizeof(uint32_t));
         for (int i = 0; i < 2 && he == hipSuccess; i++) {
-            he = hipHostMalloc(&pin[i], CH, hipHostMallocDefault);
+            he = host_malloc(&pin[i], CH, hipHostMallocDefault);
             if (he == hipSuccess) he = hipEventCreate(&ev[i]);
         }
         uint64_t left = 4 * e->info.capacity, off = 0;
@@ -528,7 +545,7 @@ static int ensure(void **p, size_t *cap, size_t need) {
     *p = nullptr;
     *cap = 0;
     size_t want = need + need / 4 + 256;
-    HIP_TRY(hipMalloc(p, want));
+    HIP_TRY(dev_malloc(p, want));
     *cap = want;
     return NH_OK;
 }
@@ -602,11 +619,11 @@ static int ensure_split(Engine *e, unsigned slot, uint64_t n_frag) {
     sb = SplitBufs{};
     e->split_single_cap[slot] = 0;
     const uint64_t nsingle = n_frag + n_frag / 4 + 1024;
-    if (hipMalloc((void **)&sb.hdr, sizeof(SplitHdr)) != hipSuccess ||
-        hipMalloc((void **)&sb.items_multi, want_seg * sizeof(SplitItem)) != hipSuccess ||
-        hipMalloc((void **)&sb.items_single, nsingle * sizeof(uint32_t)) != hipSuccess ||
-        hipMalloc((void **)&sb.part, want_seg * PART_DWORDS * sizeof(uint32_t)) != hipSuccess ||
-        hipMalloc((void **)&sb.part_done, want_seg * sizeof(uint32_t)) != hipSuccess) {
+    if (dev_malloc((void **)&sb.hdr, sizeof(SplitHdr)) != hipSuccess ||
+        dev_malloc((void **)&sb.items_multi, want_seg * sizeof(SplitItem)) != hipSuccess ||
+        dev_malloc((void **)&sb.items_single, nsingle * sizeof(uint32_t)) != hipSuccess ||
+        dev_malloc((void **)&sb.part, want_seg * PART_DWORDS * sizeof(uint32_t)) != hipSuccess ||
+        dev_malloc((void **)&sb.part_done, want_seg * sizeof(uint32_t)) != hipSuccess) {
         (void)hipGetLastError();
         for (void *p : {(void *)sb.hdr, (void *)sb.items_multi, (void *)sb.items_single, (void *)sb.part, (void *)sb.part_done})
             if (p) (void)hipFree(p);
@@ -911,7 +928,7 @@ int nh_synthetic_add_sequences(nh_engine *e_, const void *d_bases, const void *d
     HIP_TRY(hipSetDevice(e->device));
     finish_devdb_public(e);
     unsigned long long *d_ins = nullptr, ins = 0;
-    HIP_TRY(hipMalloc((void **)&d_ins, 8));
+    HIP_TRY(nh::dev_malloc((void **)&d_ins, 8));
     HIP_TRY(hipMemsetAsync(d_ins, 0, 8, (hipStream_t)stream));
     hipError_t he = nh::launch_insert_sequences(e->dev, d_bases, d_seq_offsets, n_seq, value, d_ins,
                                                 e->grid_blocks, (hipStream_t)stream);

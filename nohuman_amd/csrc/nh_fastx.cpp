@@ -213,6 +213,8 @@ private:
     unsigned streams_ = 0;  // complete streams decoded so far
 };
 
+hipError_t dev_malloc(void **p, size_t bytes);  // nh_internal.h (nh_engine.hip): what the process keeps between runs goes before an allocation fails
+
 // gzip decoded on a GPU: DevGunzip (nh_gunzip.hip) leaves a piece of text in device memory, read() fetches it from
 // there into the caller's buffer (the page-locked text buffer of a batch: one copy over PCIe, no inflate on the host).
 // Two text buffers: a helper thread has the GPU decode the next piece while this one is being fetched.
@@ -246,7 +248,7 @@ public:
         if (stat(path, &st) == 0 && (uint64_t)st.st_size * 16 + ((size_t)64u << 20) < room_) room_ = (size_t)st.st_size * 16 + ((size_t)64u << 20);
         if (const char *e = getenv("NOHUMAN_GZDEV_ROOM")) room_ = std::max<size_t>((size_t)atoll(e), (size_t)1u << 20);
         for (;;) {
-            const bool ok = hipMalloc((void **)&buf_[0].d, room_ + 64) == hipSuccess && hipMalloc((void **)&buf_[1].d, room_ + 64) == hipSuccess;
+            const bool ok = dev_malloc((void **)&buf_[0].d, room_ + 64) == hipSuccess && dev_malloc((void **)&buf_[1].d, room_ + 64) == hipSuccess;
             if (ok) break;
             (void)hipGetLastError();
             for (Buf &b : buf_) {

@@ -95,10 +95,19 @@ public:
     // devices[i mod n], and its batches say so (HalfBatch::dev_device: nh_run classifies them where they were born).
     int open(const char *path, const int *devices, int n_devices, std::string &err);
     int open(const char *path, int device, std::string &err) { return open(path, &device, 1, err); }
-    // The next batch of exactly max_recs records (fewer only at the end of the input: hb.eof), the same max_recs in every
-    // call.  0 ok (hb.error set on malformed input); 1: the text is no four-line FASTQ (FASTA, wrapped sequences) and
-    // nothing has been handed out yet: use BlockReader on the file instead.
-    int next_batch(HalfBatch &hb, size_t max_recs);
+    // The next batch.  max_text == 0 (paired inputs: both files' readers must cut at the same records): exactly max_recs
+    // records, fewer only at the end of the input (hb.eof).  max_text > 0 (single-end): up to max_recs records and cut after
+    // the record that reaches max_text bytes (BlockReader::next_batch's rule), and a piece hands out every complete record
+    // it holds -- so a file of short reads followed by long ones never has to carry more than one record from piece to
+    // piece.  The same max_recs / max_text in every call.
+    // 0 ok (hb.error set on malformed input -- kraken2's message).
+    // 1: this reader hands the file over to BlockReader: either the text is no four-line FASTQ (FASTA, wrapped sequences;
+    //    nothing handed out yet) or the device reader could not go on (a batch larger than the room it keeps in front of a
+    //    piece, buffers that cannot be had, a stream its decoder gives up on: handover_reason()).  records_handed() records
+    //    have been handed out -- whole batches in paired mode --; BlockReader skips that many and reads on (reader_main, nh_run.hip).
+    int next_batch(HalfBatch &hb, size_t max_recs, size_t max_text = 0);
+    uint64_t records_handed() const;
+    const std::string &handover_reason() const;  // empty: "not ours" (no FASTQ)
     void close();  // waits until every batch handed out has been released
 
 private:

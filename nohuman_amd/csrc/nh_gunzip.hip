@@ -1292,9 +1292,15 @@ using namespace gz;
         if (e_ != hipSuccess) return fail(std::string(#x) + ": " + hipGetErrorString(e_)); \
     } while (0)
 
-// The reader's large buffers (symbol slots, maps, text: a dozen gigabytes of HBM, a quarter of one page-locked) are kept
-// for the next run of the process instead of being freed: allocating and freeing them cost 0.5-0.9 s of a 2 s run
-// (profiles/r04_e2e.txt).  NOHUMAN_GZDEV_CACHE=0 turns that off; dev_cache_trim() empties it.
+// The reader's large buffers are kept for the next run of the process instead of being freed: allocating and freeing them
+// cost 0.5-0.9 s of a 2 s run (profiles/r04_e2e.txt).  What that is, per input file at the default piece and chunk sizes
+// (512 MiB of gzip in 8192 chunks of 64 KiB): symbol slots 8192 x (16 x 64 Ki + 64 Ki) x 2 B = 18.3 GB, index maps 1.1 GB,
+// windows 0.3 GB, input 0.5 GB (and as much page-locked), two text buffers of 3.5 GB, the record index 0.5 GB -- 28 GB of
+// HBM a file, 56 GB a paired run.  The store is bounded BY BYTES per device (64 GiB of HBM -- one paired run's buffers --
+// and 8 GiB page-locked; NOHUMAN_GZDEV_CACHE_GB / NOHUMAN_GZDEV_CACHE_HOST_GB) and evicts the oldest entries first, so runs
+// over inputs of other sizes replace what is kept instead of piling up; every allocation of the run path gives the
+// store back before it fails (dev_malloc / host_malloc, nh_internal.h).  NOHUMAN_GZDEV_CACHE=0 turns it off;
+// dev_cache_trim() empties it (nh_close).
 namespace {
 struct CacheEntry {
     int device;
@@ -1303,22 +1309,36 @@ struct CacheEntry {
     bool host;
 };
 std::mutex g_cache_mu;
-std::vector<CacheEntry> g_cache;
+std::vector<CacheEntry> g_cache;  // oldest first
 bool cache_on() {
     static const bool on = !(getenv("NOHUMAN_GZDEV_CACHE") && getenv("NOHUMAN_GZDEV_CACHE")[0] == '0');
     return on;
 }
+size_t cache_limit(bool host) {
+    static const size_t dev_lim = (size_t)(getenv("NOHUMAN_GZDEV_CACHE_GB") ? atof(getenv("NOHUMAN_GZDEV_CACHE_GB")) : 64.0) << 30;
+    static const size_t host_lim = (size_t)(getenv("NOHUMAN_GZDEV_CACHE_HOST_GB") ? atof(getenv("NOHUMAN_GZDEV_CACHE_HOST_GB")) : 8.0) << 30;
+    return host ? host_lim : dev_lim;
+}
+void cache_release(const CacheEntry &e) {
+    if (e.host) (void)hipHostFree(e.p);
+    else {
+        (void)hipSetDevice(e.device);
+        (void)hipFree(e.p);
+    }
+}
 }  // namespace
 void dev_cache_trim() {
     std::lock_guard<std::mutex> lk(g_cache_mu);
-    for (CacheEntry &e : g_cache) {
-        if (e.host) (void)hipHostFree(e.p);
-        else {
-            (void)hipSetDevice(e.device);
-            (void)hipFree(e.p);
-        }
-    }
+    for (CacheEntry &e : g_cache) cache_release(e);
     g_cache.clear();
+}
+// bytes the store holds (test hook: nh_gunzip_cache_bytes)
+static size_t cache_bytes(int device, bool host) {
+    std::lock_guard<std::mutex> lk(g_cache_mu);
+    size_t sum = 0;
+    for (const CacheEntry &e : g_cache)
+        if (e.host == host && (host || device < 0 || e.device == device)) sum += e.bytes;
+    return sum;
 }
 static void *cache_alloc(int device, size_t bytes, bool host) {
     if (cache_on() && bytes >= ((size_t)16u << 20)) {
@@ -1333,27 +1353,43 @@ static void *cache_alloc(int device, size_t bytes, bool host) {
         }
     }
     void *p = nullptr;
-    hipError_t e = host ? hipHostMalloc(&p, bytes, hipHostMallocDefault) : hipMalloc(&p, bytes);
-    if (e != hipSuccess) {  // make room: what the cache holds goes first
-        (void)hipGetLastError();
-        dev_cache_trim();
-        (void)hipSetDevice(device);
-        e = host ? hipHostMalloc(&p, bytes, hipHostMallocDefault) : hipMalloc(&p, bytes);
-        if (e != hipSuccess) {
-            (void)hipGetLastError();
-            return nullptr;
-        }
-    }
+    // (on failure: everything the process keeps between runs goes first, then one more try)
+    const hipError_t e = host ? host_malloc(&p, bytes) : dev_malloc(&p, bytes);
+    if (e != hipSuccess) return nullptr;
+    (void)hipSetDevice(device);
     return p;
 }
 static void cache_free(int device, size_t bytes, void *p, bool host) {
     if (!p) return;
-    if (cache_on() && bytes >= ((size_t)16u << 20)) {
-        std::lock_guard<std::mutex> lk(g_cache_mu);
-        if (g_cache.size() < 96) {
+    if (cache_on() && bytes >= ((size_t)16u << 20) && bytes <= cache_limit(host)) {
+        std::vector<CacheEntry> out;
+        {
+            std::lock_guard<std::mutex> lk(g_cache_mu);
             g_cache.push_back({device, bytes, p, host});
-            return;
+            // the bound: by bytes per device (page-locked memory: one pool), by entries overall; the oldest go first
+            size_t sum = 0;
+            for (const CacheEntry &e : g_cache)
+                if (e.host == host && (host || e.device == device)) sum += e.bytes;
+            for (size_t i = 0; i + 1 < g_cache.size() && sum > cache_limit(host);) {  // (the newest, this one, stays)
+                const CacheEntry e = g_cache[i];
+                if (e.host == host && (host || e.device == device)) {
+                    sum -= e.bytes;
+                    out.push_back(e);
+                    g_cache.erase(g_cache.begin() + (long)i);
+                } else {
+                    i++;
+                }
+            }
+            while (g_cache.size() > 96) {
+                out.push_back(g_cache.front());
+                g_cache.erase(g_cache.begin());
+            }
         }
+        int dev = -1;
+        (void)hipGetDevice(&dev);
+        for (const CacheEntry &e : out) cache_release(e);
+        if (!out.empty() && dev >= 0) (void)hipSetDevice(dev);
+        return;
     }
     if (host) (void)hipHostFree(p);
     else (void)hipFree(p);
@@ -1504,14 +1540,14 @@ public:
         d.d_maps_[1] = (uint16_t *)cache_alloc(d.device_, maps_bytes_, false);
         d.d_windows_ = (uint8_t *)cache_alloc(d.device_, maps_bytes_ / 2, false);
         bool ok = d.d_in_ && d.h_in_ && d.d_sym_ && d.d_maps_[0] && d.d_maps_[1] && d.d_windows_ &&
-                  hipMalloc((void **)&d.d_start_, (size_t)n_slots_ * 8) == hipSuccess &&
-                  hipMalloc((void **)&d.d_desc_, (size_t)n_slots_ * sizeof(ChunkDesc)) == hipSuccess &&
-                  hipHostMalloc((void **)&d.h_desc_, (size_t)n_slots_ * sizeof(ChunkDesc), hipHostMallocDefault) == hipSuccess &&
-                  hipMalloc((void **)&d.d_toff_, (size_t)n_slots_ * 8) == hipSuccess &&
-                  hipMalloc((void **)&d.d_win_[0], WSIZE) == hipSuccess && hipMalloc((void **)&d.d_win_[1], WSIZE) == hipSuccess &&
-                  hipMalloc((void **)&d.d_res_, sizeof(SegResult)) == hipSuccess &&
-                  hipHostMalloc((void **)&d.h_res_, sizeof(SegResult), hipHostMallocDefault) == hipSuccess &&
-                  (!bgzf_ || hipHostMalloc((void **)&d.h_start_, (size_t)n_slots_ * 8, hipHostMallocDefault) == hipSuccess);
+                  dev_malloc((void **)&d.d_start_, (size_t)n_slots_ * 8) == hipSuccess &&
+                  dev_malloc((void **)&d.d_desc_, (size_t)n_slots_ * sizeof(ChunkDesc)) == hipSuccess &&
+                  host_malloc((void **)&d.h_desc_, (size_t)n_slots_ * sizeof(ChunkDesc), hipHostMallocDefault) == hipSuccess &&
+                  dev_malloc((void **)&d.d_toff_, (size_t)n_slots_ * 8) == hipSuccess &&
+                  dev_malloc((void **)&d.d_win_[0], WSIZE) == hipSuccess && dev_malloc((void **)&d.d_win_[1], WSIZE) == hipSuccess &&
+                  dev_malloc((void **)&d.d_res_, sizeof(SegResult)) == hipSuccess &&
+                  host_malloc((void **)&d.h_res_, sizeof(SegResult), hipHostMallocDefault) == hipSuccess &&
+                  (!bgzf_ || host_malloc((void **)&d.h_start_, (size_t)n_slots_ * 8, hipHostMallocDefault) == hipSuccess);
         if (ok) ok = hipMemset(d.d_win_[0], 0, WSIZE) == hipSuccess;  // (the input buffer's tail is zeroed with every piece's upload)
         if (ok)
             ok = hipFuncSetAttribute((const void *)k_inflate3, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(Lds3)) == hipSuccess &&
@@ -1646,7 +1682,10 @@ private:
         return true;
     }
     bool member_end(uint32_t crc, uint32_t isize) {
-        st_.members++;
+        {
+            std::lock_guard<std::mutex> lk(st_mu_);
+            st_.members++;
+        }
         if (crc != run_crc_ || isize != (uint32_t)run_len_) {
             static const bool go_on = getenv("NOHUMAN_GZDEV_NOCRC") != nullptr;  // debugging aid: write the text anyway, say where
             if (go_on) {
@@ -1904,10 +1943,19 @@ private:
         const uint64_t a_byte = (pos_bit_ >> 3) / ALIGN * ALIGN;  // the piece's buffer starts here in the file
         const uint64_t first_bit = pos_bit_ - 8 * a_byte;
         if (a_byte >= size_) return fail("unexpected end of file");
-        if (host_mode_) {  // the device gave up on this file twice in a row (text beyond 16 : 1, giant blocks): the host decoder reads on
+        if (host_mode_) {
+            // the device gave up on this file twice in a row (text beyond 16 : 1, many small members, giant blocks): the host
+            // decoder reads on -- for a stint of 16 MiB steps, then the device is tried again (one more refusal doubles the
+            // next stint, up to 64 steps = 1 GiB of gzip): a stretch of odd data does not put the rest of the file on one core
             SegResult r{};
             r.bad_status = last_bad_;
-            return host_piece(d_dst, room, stream, a_byte, first_bit, 8ull * (size_ - a_byte), r);
+            if (host_left_ == 0) {
+                host_mode_ = false;
+                failed_in_a_row_ = 1;  // (one refusal is enough to come back here)
+            } else {
+                host_left_--;
+                return host_piece(d_dst, room, stream, a_byte, first_bit, 8ull * (size_ - a_byte), r);
+            }
         }
         // stretches this piece decodes: what the room holds at the ratio seen so far (a piece that does not fit is cut down).
         // (Smaller first pieces, to give the pipeline its first batches sooner, were measured and dropped: an eighth and a
@@ -1933,9 +1981,14 @@ private:
             const SegResult &r = j.r;
             if (r.bad_chunk != NOIDX || r.end_chunk == NOIDX) {
                 last_bad_ = r.bad_status;
-                if (++failed_in_a_row_ >= 2) host_mode_ = true;
+                if (++failed_in_a_row_ >= 2) {
+                    host_mode_ = true;
+                    host_left_ = host_stint_;
+                    host_stint_ = std::min<uint32_t>(64, host_stint_ * 2);
+                }
                 return host_piece(d_dst, room, stream, a_byte, first_bit, j.end_bit, r);
             }
+            if (failed_in_a_row_ == 0) host_stint_ = 8;  // (two clean pieces in a row: the odd stretch is behind)
             failed_in_a_row_ = 0;
             if (r.total > room) {
                 if (j.n_str <= 1) return fail("a chunk's text does not fit the batch buffer");
@@ -2048,11 +2101,14 @@ private:
             a = m.out_pos;
         }
         account(crc32_fast(0, out.data() + a, out.size() - (size_t)a), out.size() - a);
-        st_.segments++;
-        s_->pieces++;
-        st_.fallback_segments++;
-        st_.text_bytes += out.size();
-        st_.gzip_bytes += (eb - pos_bit_) / 8;
+        {
+            std::lock_guard<std::mutex> lk(st_mu_);  // (phase A of a piece decoded ahead updates the statistics on another thread)
+            st_.segments++;
+            s_->pieces++;
+            st_.fallback_segments++;
+            st_.text_bytes += out.size();
+            st_.gzip_bytes += (eb - pos_bit_) / 8;
+        }
         pos_bit_ = eb;
         if (stream_end) {
             if (run_len_) return fail("unexpected end of file");
@@ -2080,6 +2136,7 @@ private:
     long fake_spec_ = 0;         // test knob NOHUMAN_GZDEV_FAKE_SPEC=k: the k-th piece decoded ahead gets a false first start
     bool debug_ = getenv("NOHUMAN_GZDEV_NOCRC") != nullptr;  // debugging aid: one line per piece, CRC failures reported and passed over
     uint32_t failed_in_a_row_ = 0, last_bad_ = 0;
+    uint32_t host_left_ = 0, host_stint_ = 8;  // host mode: steps left of this stint; the next stint's length
     long fake_start_ = -1;
     double open_s_ = 0;
     size_t in_bytes_ = 0, sym_bytes_ = 0, maps_bytes_ = 0;
@@ -2118,6 +2175,8 @@ bool dev_gunzip_wants(const char *path) {
 
 }  // namespace nh
 
+extern "C" uint64_t nh_cache_bytes(int32_t device, int32_t page_locked) { return (uint64_t)nh::cache_bytes(device, page_locked != 0); }
+
 extern "C" int nh_gunzip_device_file(const char *in, const char *out, int32_t device, uint64_t seg_bytes, uint64_t stretch_bytes,
                                      uint64_t *stats8) {
     if (!in || !out) return nh::set_error(NH_EINVAL, "null argument");
@@ -2132,7 +2191,7 @@ extern "C" int nh_gunzip_device_file(const char *in, const char *out, int32_t de
     if (const char *e = getenv("NOHUMAN_GZDEV_ROOM")) room = std::max<size_t>((size_t)atoll(e), (size_t)1u << 20);  // tool knob: text per piece
     uint8_t *d_text = nullptr;
     hipStream_t stream = nullptr;
-    if (hipSetDevice(device) != hipSuccess || hipMalloc((void **)&d_text, room + 64) != hipSuccess ||
+    if (hipSetDevice(device) != hipSuccess || nh::dev_malloc((void **)&d_text, room + 64) != hipSuccess ||
         hipStreamCreateWithFlags(&stream, hipStreamNonBlocking) != hipSuccess) {
         if (d_text) (void)hipFree(d_text);
         return nh::set_error(NH_EOOM, "cannot allocate the text buffer on device %d", device);
@@ -2283,7 +2342,9 @@ __global__ __launch_bounds__(256) void k_records(const uint8_t *text, const uint
     while (he > b0 && is_space(text[he - 1])) he--;
     while (se > b1 && is_space(text[se - 1])) se--;
     while (qe > b3 && is_space(text[qe - 1])) qe--;
-    if (he - b0 <= 1) atomicMin(bad, ((unsigned long long)r << 2) | 1ull);
+    // (the host parser, nh_fastx.cpp parse_one: an empty line ends the input, anything else without '@' is malformed --
+    //  a one-character line "X" too --, "@" alone ends the input)
+    if (he == b0 || (he - b0 == 1 && text[b0] == '@')) atomicMin(bad, ((unsigned long long)r << 2) | 1ull);
     else if (text[b0] != '@') atomicMin(bad, ((unsigned long long)r << 2) | 2ull);
     uint32_t ie = b0 + 1;
     while (ie < he && text[ie] != ' ' && text[ie] != '\t' && text[ie] != '\r') ie++;
@@ -2365,25 +2426,27 @@ public:
         for (Lane &l : lanes_) {
             if (hipSetDevice(l.device) != hipSuccess || hipStreamCreateWithFlags(&l.stream, hipStreamNonBlocking) != hipSuccess ||
                 hipStreamCreateWithFlags(&l.stream_a, hipStreamNonBlocking) != hipSuccess ||
-                hipStreamCreateWithFlags(&l.stream_i, hipStreamNonBlocking) != hipSuccess || hipMalloc((void **)&l.d_bad, 8) != hipSuccess ||
-                hipHostMalloc((void **)&l.h_bad, 8, hipHostMallocDefault) != hipSuccess) {
+                hipStreamCreateWithFlags(&l.stream_i, hipStreamNonBlocking) != hipSuccess || dev_malloc((void **)&l.d_bad, 8) != hipSuccess ||
+                host_malloc((void **)&l.h_bad, 8, hipHostMallocDefault) != hipSuccess) {
                 err = "the gzip reader's buffers cannot be had";
                 return -1;
             }
         }
         ahead_ = lanes_.size() > 1 && gz_.ahead_ok() && !(getenv("NOHUMAN_GZ_AHEAD") && getenv("NOHUMAN_GZ_AHEAD")[0] == '0');
         trace_ = getenv("NOHUMAN_TRACE") != nullptr;
+        if (const char *e = getenv("NOHUMAN_GZDEV_FAIL_AT")) fail_at_ = atol(e);
         open_s_ = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_open).count();
         if (trace_ && getenv("NOHUMAN_GZDEV_NOCRC"))
             fprintf(stderr, "[gzdev] reader set-up: decoder %.3f s, further lanes %.3f, text buffers %.3f, streams %.3f\n", t_a, t_b - t_a, t_c - t_b, open_s_ - t_c);
         return 0;
     }
 
-    int next_batch(HalfBatch &hb, size_t max_recs) {
+    int next_batch(HalfBatch &hb, size_t max_recs, size_t max_text) {
         hb.reset();
         hb.format = FMT_FASTQ;
         if (bf_ == 0) {
             bf_ = max_recs ? max_recs : 1;
+            max_text_ = std::min<size_t>(max_text, (size_t)3u << 30);  // (0: batches of exactly bf_ records -- paired inputs)
             th_ = std::thread([this] { produce(); });  // pieces are decoded and indexed ahead of the batches handed out
         }
         if (max_recs != bf_) {
@@ -2397,7 +2460,10 @@ public:
                 cv_.wait(lk, [&] { return !order_.empty() || done_; });
                 if (order_.empty()) {  // the producer has ended: the end of the input, an error, or "not ours"
                     if (fallback_) return 1;
-                    if (!error_.empty()) hb.error = error_;
+                    if (!error_.empty()) {
+                        if (!hard_) return 1;  // the host reader goes on from records_handed() (handover_reason())
+                        hb.error = error_;
+                    }
                     hb.eof = true;
                     return 0;
                 }
@@ -2405,7 +2471,7 @@ public:
             }
             Piece &p = *pp;
             // whole batches, and at the end of the input what is left
-            const size_t full = p.last ? p.n_rec : p.n_rec / bf_ * bf_;
+            const size_t full = p.last || max_text_ ? p.n_rec : p.n_rec / bf_ * bf_;
             if (p.next_rec < full) return emit(hb, p, full);
             const bool last = p.last;
             {   // this piece has handed out what it had: on to the next
@@ -2420,6 +2486,9 @@ public:
             }
         }
     }
+
+    uint64_t records_handed() const { return handed_recs_; }
+    const std::string &handover_reason() const { return error_; }
 
     void close() {
         {
@@ -2495,8 +2564,14 @@ private:
         uint64_t cell = 0;  // which
     };
 
-    int fail(const std::string &m) {
-        if (error_.empty()) error_ = m;
+    // What stops this reader does not stop the run: the host reader takes the file over from the records handed out so far
+    // (next_batch() == 1) and says what it finds -- a damaged stream fails there with gzip's messages.  Malformed FASTQ in
+    // text whose CRC-32 was right is the input's fault on any reader: hard.
+    int fail(const std::string &m, bool hard = false) {
+        if (error_.empty()) {
+            error_ = m;
+            hard_ = hard;
+        }
         return -1;
     }
     // the record index's buffers (a piece of 2.3 GB of text: 9 M newline positions, a 220 MB record table on the device and
@@ -2554,10 +2629,31 @@ private:
     }
 
     int emit(HalfBatch &hb, Piece &p, size_t full) {
-        const size_t r0 = p.next_rec, r1 = std::min(full, r0 + bf_);
-        const size_t b = r0 / bf_;
-        const size_t t0 = p.h_bstart[b], t1 = p.h_bstart[b + 1];
+        // the record table is laid out in batches of bf_ records from the piece's first (k_records: offsets relative to the
+        // batch's first record).  A batch whose text exceeds max_text_ goes out in parts: cut behind the record that reaches
+        // the budget (BlockReader::next_batch's rule), the part's offsets moved to its own first record
+        const size_t r0 = p.next_rec, b = r0 / bf_, g0 = b * bf_, gend = std::min(full, g0 + bf_);
+        const size_t base = p.h_bstart[b];
+        const size_t t0 = r0 == g0 ? base : base + p.h_recs[r0].h;
+        size_t r1 = gend, t1 = p.h_bstart[b + 1];
+        if (max_text_ && t1 - t0 > max_text_) {
+            r1 = r0;
+            size_t pos = 0;
+            while (r1 < gend && pos < max_text_) {
+                r1++;
+                pos = (r1 < gend ? base + p.h_recs[r1].h : (size_t)p.h_bstart[b + 1]) - t0;
+            }
+            t1 = t0 + pos;
+        }
         hb.recs.assign(p.h_recs + r0, p.h_recs + r1);
+        if (const uint32_t delta = (uint32_t)(t0 - base))
+            for (RecRef &x : hb.recs) {
+                x.h -= delta;
+                x.s -= delta;
+                x.q -= delta;
+                if (x.raw_end) x.raw_end -= delta;
+            }
+        handed_recs_ += r1 - r0;
         const size_t len = t1 - t0;
         // the host text buffer stays a token (its address is the batch's handle in the writer's span lists); whoever needs the
         // bytes on the host reserves the real thing (nh_run: stage_text, the writer's fetch)
@@ -2682,6 +2778,7 @@ private:
             lanes_[g].state = 3;  // the stream's own (not idle: no new cell until the piece is through)
         }
         Lane &ln = lanes_[g];
+        if (fail_at_ > 0 && piece_no_ == (uint64_t)fail_at_) return fail("test knob NOHUMAN_GZDEV_FAIL_AT");  // (the handover, provoked)
         // ---- a free text buffer of that lane
         Piece *pp = nullptr;
         {
@@ -2753,10 +2850,12 @@ private:
         if (last_ && last_->indexed) {
             // the records behind the last whole batch and the incomplete record behind them (from the lane before: over xGMI)
             Piece &old = *last_;
-            const size_t full = old.n_rec / bf_ * bf_;
+            const size_t full = max_text_ ? old.n_rec : old.n_rec / bf_ * bf_;  // (single-end: every complete record went out)
             const size_t from = full < old.n_rec ? old.h_bstart[full / bf_] : old.used_len;
             carry = old.text_len - from;
-            if (carry > head_) return fail("a batch of FASTQ records is larger than the room the gzip reader on the GPU keeps in front of a piece (768 MiB); lower NOHUMAN_BATCH_FRAGS or read with NOHUMAN_GZ_READER=host");
+            if (carry > head_)  // (paired batches of very long records, or one record of hundreds of megabytes: the host reader's)
+                return fail("a batch of " + std::to_string(bf_) + " records holds more text than the " + std::to_string(head_ >> 20) +
+                            " MiB the reader keeps in front of a piece");
             const int odev = lanes_[(size_t)old.lane].device;
             uint8_t *const dst = p.d_text + head_ - carry;
             if (carry && ((odev == ln.device ? hipMemcpyAsync(dst, old.text0 + from, carry, hipMemcpyDeviceToDevice, ln.stream_i)
@@ -2854,7 +2953,7 @@ private:
                     const size_t at = (size_t)p.h_bstart[b] + p.h_recs[br].h;
                     std::vector<char> line(std::min<size_t>(p.h_recs[br].hlen, 200));
                     (void)hipMemcpy(line.data(), p.text0 + at, line.size(), hipMemcpyDeviceToHost);
-                    return fail("malformed FASTQ file (exp. '@', saw \"" + std::string(line.begin(), line.end()) + "\"), aborting");
+                    return fail("malformed FASTQ file (exp. '@', saw \"" + std::string(line.begin(), line.end()) + "\"), aborting", true);
                 }
                 // an empty header line (or "@" alone): kraken2 stops reading there
                 n_rec = br;
@@ -2886,6 +2985,10 @@ private:
 
     DevGunzip gz_;
     std::string path_, error_;
+    bool hard_ = false;            // error_ is the input's fault (malformed FASTQ): no handover to the host reader
+    size_t max_text_ = 0;          // single-end: a batch is cut behind the record that reaches this many bytes (0: by records only)
+    uint64_t handed_recs_ = 0;     // records in the batches handed out
+    long fail_at_ = 0;             // test knob NOHUMAN_GZDEV_FAIL_AT=k: the reader gives up before the stream's k-th piece (k >= 1)
     std::vector<Lane> lanes_;
     std::vector<Piece> buf_;
     std::deque<size_t> order_;   // the pieces handed to the consumer, in stream order (indices into buf_)
@@ -2908,7 +3011,9 @@ private:
 DevFastqReader::DevFastqReader() : impl_(new DevFastqImpl()) {}
 DevFastqReader::~DevFastqReader() { delete impl_; }
 int DevFastqReader::open(const char *path, const int *devices, int n_devices, std::string &err) { return impl_->open(path, devices, n_devices, err); }
-int DevFastqReader::next_batch(HalfBatch &hb, size_t max_recs) { return impl_->next_batch(hb, max_recs); }
+int DevFastqReader::next_batch(HalfBatch &hb, size_t max_recs, size_t max_text) { return impl_->next_batch(hb, max_recs, max_text); }
+uint64_t DevFastqReader::records_handed() const { return impl_->records_handed(); }
+const std::string &DevFastqReader::handover_reason() const { return impl_->handover_reason(); }
 void DevFastqReader::close() { impl_->close(); }
 
 }  // namespace nh

@@ -94,6 +94,18 @@ int check_error_flag(Engine *e);
 // staging): emptied when an engine is closed
 void run_cache_trim();
 void dev_cache_trim();
+// Every allocation of the run path goes through these two: when the device (or the page-locked pool) is full, what the
+// process keeps between runs is given back first and the allocation tried once more -- idle buffers never fail a run.
+hipError_t dev_malloc(void **p, size_t bytes);
+hipError_t host_malloc(void **p, size_t bytes, unsigned flags = hipHostMallocDefault);
+template <class T>
+inline hipError_t dev_malloc(T **p, size_t bytes) {
+    return dev_malloc((void **)p, bytes);
+}
+template <class T>
+inline hipError_t host_malloc(T **p, size_t bytes, unsigned flags = hipHostMallocDefault) {
+    return host_malloc((void **)p, bytes, flags);
+}
 // the path's only collective: rows[g] = counters of device ids[g] -> every row = the sum (RCCL, nh_collective.hip)
 // (d_src[g] != NULL: the four counters lie in device ids[g]'s memory and are reduced from there)
 int allreduce_counters(const int *ids, int n_dev, uint64_t *rows, std::string &backend,

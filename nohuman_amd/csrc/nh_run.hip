@@ -335,13 +335,13 @@ static int slot_reserve(Slot &s, size_t ntext, size_t nfrag, size_t ntaxa) {
     if (hipSetDevice(s.e->device) != hipSuccess) return set_error(NH_EDEVICE, "hipSetDevice failed");
     auto grow = [](size_t need) { return need + need / 4 + 4096; };
     if (!s.h_flag) {
-        if (hipHostMalloc((void **)&s.h_flag, 64, hipHostMallocDefault) != hipSuccess) return set_error(NH_EOOM, "cannot allocate batch buffers");
+        if (host_malloc((void **)&s.h_flag, 64, hipHostMallocDefault) != hipSuccess) return set_error(NH_EOOM, "cannot allocate batch buffers");
         *s.h_flag = 0;
     }
     if (ntext + 64 > s.cap_text) {
         if (s.d_text) (void)hipFree(s.d_text);
         s.cap_text = grow(ntext + 64);
-        if (hipMalloc(&s.d_text, s.cap_text) != hipSuccess)
+        if (dev_malloc(&s.d_text, s.cap_text) != hipSuccess)
             return set_error(NH_EOOM, "cannot allocate batch buffers (%zu bytes)", s.cap_text);
     }
     if (nfrag > s.cap_frag) {
@@ -351,21 +351,21 @@ static int slot_reserve(Slot &s, size_t ntext, size_t nfrag, size_t ntaxa) {
             if (p) (void)hipFree(p);
         s.cap_frag = grow(nfrag);
         const size_t ns = 2 * s.cap_frag + 2;
-        if (hipHostMalloc((void **)&s.h_off, ns * 8, hipHostMallocDefault) != hipSuccess ||
-            hipHostMalloc((void **)&s.h_len, ns * 4, hipHostMallocDefault) != hipSuccess ||
-            hipHostMalloc((void **)&s.h_res, s.cap_frag * sizeof(nh_result), hipHostMallocDefault) != hipSuccess ||
-            hipHostMalloc((void **)&s.h_taxa_off, (s.cap_frag + 1) * 8, hipHostMallocDefault) != hipSuccess ||
-            hipMalloc(&s.d_off, ns * 8) != hipSuccess || hipMalloc(&s.d_len, ns * 4) != hipSuccess ||
-            hipMalloc(&s.d_res, s.cap_frag * sizeof(nh_result)) != hipSuccess ||
-            hipMalloc(&s.d_taxa_off, (s.cap_frag + 1) * 8) != hipSuccess)
+        if (host_malloc((void **)&s.h_off, ns * 8, hipHostMallocDefault) != hipSuccess ||
+            host_malloc((void **)&s.h_len, ns * 4, hipHostMallocDefault) != hipSuccess ||
+            host_malloc((void **)&s.h_res, s.cap_frag * sizeof(nh_result), hipHostMallocDefault) != hipSuccess ||
+            host_malloc((void **)&s.h_taxa_off, (s.cap_frag + 1) * 8, hipHostMallocDefault) != hipSuccess ||
+            dev_malloc(&s.d_off, ns * 8) != hipSuccess || dev_malloc(&s.d_len, ns * 4) != hipSuccess ||
+            dev_malloc(&s.d_res, s.cap_frag * sizeof(nh_result)) != hipSuccess ||
+            dev_malloc(&s.d_taxa_off, (s.cap_frag + 1) * 8) != hipSuccess)
             return set_error(NH_EOOM, "cannot allocate batch buffers (%zu fragments)", s.cap_frag);
     }
     if (ntaxa > s.cap_taxa) {
         if (s.h_taxa) (void)hipHostFree(s.h_taxa);
         if (s.d_taxa) (void)hipFree(s.d_taxa);
         s.cap_taxa = grow(ntaxa);
-        if (hipHostMalloc((void **)&s.h_taxa, s.cap_taxa * 4, hipHostMallocDefault) != hipSuccess ||
-            hipMalloc(&s.d_taxa, s.cap_taxa * 4) != hipSuccess)
+        if (host_malloc((void **)&s.h_taxa, s.cap_taxa * 4, hipHostMallocDefault) != hipSuccess ||
+            dev_malloc(&s.d_taxa, s.cap_taxa * 4) != hipSuccess)
             return set_error(NH_EOOM, "cannot allocate k-mer taxa buffers");
     }
     return NH_OK;
@@ -410,7 +410,7 @@ static void *pinned_alloc(size_t n) {
             }
         }
     }
-    if (!no_pin && hipHostMalloc(&p, n + 64, hipHostMallocPortable) == hipSuccess) {
+    if (!no_pin && host_malloc(&p, n + 64, hipHostMallocPortable) == hipSuccess) {
         ((uint64_t *)p)[0] = 1;
         ((uint64_t *)p)[1] = n;
         return (char *)p + 64;
@@ -537,64 +537,25 @@ struct StageClock {  // NOHUMAN_TRACE=1: where the wall time of a run goes, per 
 };
 enum { ST_READ1 = 0, ST_READ2, ST_RPUSH1, ST_RPUSH2, ST_MPOP, ST_MSLOT, ST_MGATHER, ST_MLAUNCH, ST_WPOP, ST_WSYNC, ST_WFORMAT, ST_WWRITE };
 
-static void reader_main(const char *path, BoundedQueue<std::unique_ptr<HalfBatch>> *out, RunState *rs,
-                        BatchPool *pool, StageClock *clk, int which, size_t batch_frags, size_t batch_text,
-                        unsigned gz_threads, std::vector<int> gz_devices) {
-    const int gz_device = gz_devices.empty() ? -1 : gz_devices[0];
-    // gzip FASTQ: the whole reader on the GPU (inflate, record index; the text stays in HBM) unless NOHUMAN_GZ_READER says
-    // otherwise -- "host": the host decoders; "device-text": inflate on the GPU, records parsed on the host (BlockReader)
-    {
-        const char *how = getenv("NOHUMAN_GZ_READER");
-        const bool want = gz_device >= 0 && !(how && (!strcmp(how, "host") || !strcmp(how, "device-text")));
-        if (want) {
-            DevFastqReader dr;
-            std::string derr;
-            // (the run's devices, this file's first: piece i of the stream is inflated, indexed and classified on device i mod G)
-            const int orc = dr.open(path, gz_devices.data(), (int)gz_devices.size(), derr);
-            if (orc < 0) {
-                if (how && !strcmp(how, "device")) {  // asked for by name: no silent change of reader
-                    rs->fail(NH_EIO, derr);
-                    out->close();
-                    return;
-                }
-                fprintf(stderr, "nohuman: WARN %s: the gzip reader on GPU %d could not be set up (%s); reading on the host\n", path, gz_device,
-                        derr.c_str());
-            }
-            bool fell_back = orc != 0;
-            while (!fell_back) {
-                std::unique_ptr<HalfBatch> hb = pool->get();
-                uint64_t t0 = StageClock::now();
-                const int rc = dr.next_batch(*hb, batch_frags);
-                uint64_t t1 = StageClock::now();
-                clk->ns[ST_READ1 + which] += t1 - t0;
-                if (rc == 1) {  // no four-line FASTQ: the host parser reads the file (FASTA, wrapped lines, its error messages)
-                    pool->put(std::move(hb));
-                    fell_back = true;
-                    break;
-                }
-                if (!hb->error.empty()) {
-                    rs->fail(NH_EIO, hb->error);
-                    break;
-                }
-                const bool eof = hb->eof;
-                out->push(std::move(hb));
-                clk->ns[ST_RPUSH1 + which] += StageClock::now() - t1;
-                if (eof || rs->failed()) break;
-            }
-            if (!fell_back) {
-                out->close();
-                dr.close();  // (waits for the batches still in the pipeline: they point into its buffers)
-                return;
-            }
-            dr.close();
+// the host reader's loop: batches of an opened BlockReader into the queue, behind `skip` records that are read and dropped
+// (the reader on the GPU handed them out before it handed the file over)
+static void host_read(BlockReader &r, BoundedQueue<std::unique_ptr<HalfBatch>> *out, RunState *rs, BatchPool *pool, StageClock *clk, int which,
+                      size_t batch_frags, size_t batch_text, uint64_t skip) {
+    while (skip) {
+        std::unique_ptr<HalfBatch> hb = pool->get();
+        r.next_batch(*hb, (size_t)std::min<uint64_t>(skip, batch_frags), batch_text);
+        if (!hb->error.empty()) {
+            rs->fail(NH_EIO, hb->error);
+            return;
         }
-    }
-    BlockReader r;
-    std::string err;
-    if (r.open(path, err, gz_threads, gz_device) != 0) {
-        rs->fail(NH_EIO, err);
-        out->close();
-        return;
+        const size_t n = hb->recs.size();
+        const bool eof = hb->eof;
+        pool->put(std::move(hb));
+        skip -= std::min<uint64_t>(skip, n);
+        if (eof || rs->failed()) {  // (the file ends inside what the device reader read: it cannot be the same file)
+            if (skip) rs->fail(NH_EIO, "the input changed while it was read");
+            return;
+        }
     }
     for (;;) {
         std::unique_ptr<HalfBatch> hb = pool->get();
@@ -612,6 +573,118 @@ static void reader_main(const char *path, BoundedQueue<std::unique_ptr<HalfBatch
         clk->ns[ST_RPUSH1 + which] += StageClock::now() - t1;
         if (eof || rs->failed()) break;
     }
+}
+
+// Which reader a gzip input starts on when NOHUMAN_GZ_READER does not say.  Measured (tools/reader_choice.py,
+// profiles/r05_reader_choice.txt; run time with the reader on the GPU / with the host reader on 16 cores):
+//   outputs gzip-encoded on the GPU (the text never leaves HBM): 0.45-0.94 at every size from 50 MB to 1 GB a file, paired
+//     and single-end, and 0.79-0.92 on long reads                                                      -> the GPU
+//   short reads, only classified reads kept / --output wanted (the text is fetched, little is written): 0.33-0.78 -> the GPU
+//   outputs written by the host (plain, bzip2, xz, zstd: every kept byte crosses PCIe and goes through
+//     writev): 0.78-0.98 below 128 MiB a file, 1.09-1.21 above                                         -> the host above
+//   long reads (batches few and large: nothing flows before the first 512 MiB piece is through) with outputs written by the
+//     host or nothing kept: 1.14-1.26                                                                  -> the host
+static bool device_reader_pays(const char *path, size_t mean_record_bytes, bool host_text_wanted, bool outputs_by_host) {
+    struct stat st;
+    if (stat(path, &st) != 0 || !S_ISREG(st.st_mode)) return false;
+    if (const char *e = getenv("NOHUMAN_GZDEV_MIN_BYTES")) return (uint64_t)st.st_size >= (uint64_t)atoll(e);  // tuning / test knob
+    if (!host_text_wanted) return true;
+    if (mean_record_bytes > 4096) return false;
+    return !(outputs_by_host && (uint64_t)st.st_size >= ((uint64_t)128u << 20));
+}
+
+static void reader_main(const char *path, BoundedQueue<std::unique_ptr<HalfBatch>> *out, RunState *rs,
+                        BatchPool *pool, StageClock *clk, int which, size_t batch_frags, size_t batch_text,
+                        unsigned gz_threads, std::vector<int> gz_devices, bool device_reader) {
+    const int gz_device = gz_devices.empty() ? -1 : gz_devices[0];
+    // gzip FASTQ: the whole reader on the GPU (inflate, record index; the text stays in HBM) where that pays (the caller
+    // decides: device_reader) or NOHUMAN_GZ_READER says "device"; "host": the host decoders; "device-text": inflate on the
+    // GPU, records parsed on the host (BlockReader)
+    uint64_t skip = 0;  // records the reader on the GPU handed out before it handed the file over
+    {
+        const char *how = getenv("NOHUMAN_GZ_READER");
+        const bool named = how && !strcmp(how, "device");
+        if (gz_device >= 0 && device_reader) {
+            DevFastqReader dr;
+            std::string derr;
+            // (the run's devices, this file's first: piece i of the stream is inflated, indexed and classified on device i mod G)
+            const int orc = dr.open(path, gz_devices.data(), (int)gz_devices.size(), derr);
+            if (orc < 0) {
+                if (named) {  // asked for by name: no silent change of reader
+                    rs->fail(NH_EIO, derr);
+                    out->close();
+                    return;
+                }
+                fprintf(stderr, "nohuman: WARN %s: the gzip reader on GPU %d could not be set up (%s); reading on the host\n", path, gz_device,
+                        derr.c_str());
+            }
+            bool fell_back = orc != 0;
+            while (!fell_back) {
+                std::unique_ptr<HalfBatch> hb = pool->get();
+                uint64_t t0 = StageClock::now();
+                // (paired inputs: both files' readers cut at the same record counts; single-end batches are cut by text as well)
+                const int rc = dr.next_batch(*hb, batch_frags, rs->paired ? 0 : batch_text);
+                uint64_t t1 = StageClock::now();
+                clk->ns[ST_READ1 + which] += t1 - t0;
+                if (rc == 1) {
+                    // no four-line FASTQ: the host parser reads the file (FASTA, wrapped lines, its error messages) -- or the
+                    // reader on the GPU could not go on: the host reader does, behind the records already handed out
+                    pool->put(std::move(hb));
+                    if (!dr.handover_reason().empty()) {
+                        if (named) {
+                            rs->fail(NH_EIO, dr.handover_reason());
+                            break;
+                        }
+                        skip = dr.records_handed();
+                        fprintf(stderr, "nohuman: WARN %s: the gzip reader on GPU %d stopped (%s); the host reader goes on from record %llu\n", path,
+                                gz_device, dr.handover_reason().c_str(), (unsigned long long)skip);
+                    }
+                    fell_back = true;
+                    break;
+                }
+                if (!hb->error.empty()) {
+                    rs->fail(NH_EIO, hb->error);
+                    break;
+                }
+                const bool eof = hb->eof;
+                out->push(std::move(hb));
+                clk->ns[ST_RPUSH1 + which] += StageClock::now() - t1;
+                if (eof || rs->failed()) break;
+            }
+            if (!fell_back) {
+                out->close();
+                dr.close();  // (waits for the batches still in the pipeline: they point into its buffers)
+                return;
+            }
+            if (skip == 0) dr.close();
+            else {
+                // the batches it handed out are still in the pipeline and point into its buffers: the host reader starts now, the
+                // device reader's buffers go when they are through (close() waits for them)
+                BlockReader r;
+                std::string err;
+                if (r.open(path, err, gz_threads, -1) != 0) {
+                    rs->fail(NH_EIO, err);
+                    out->close();
+                    dr.close();
+                    return;
+                }
+                host_read(r, out, rs, pool, clk, which, batch_frags, batch_text, skip);
+                out->close();
+                dr.close();
+                return;
+            }
+        }
+    }
+    BlockReader r;
+    std::string err;
+    // (the GPU inflates for the host parser only when asked for by name: "device-text", or "device" and the text is no FASTQ)
+    const char *how = getenv("NOHUMAN_GZ_READER");
+    if (r.open(path, err, gz_threads, how && (!strcmp(how, "device-text") || !strcmp(how, "device")) ? gz_device : -1) != 0) {
+        rs->fail(NH_EIO, err);
+        out->close();
+        return;
+    }
+    host_read(r, out, rs, pool, clk, which, batch_frags, batch_text, 0);
     out->close();
 }
 
@@ -759,7 +832,11 @@ int run_engines(const std::vector<Engine *> &engines, const nh_run_args *a, nh_s
     // byte budget of one reader's batch: single-end batches are cut by it; paired batches are cut by record
     // count (both readers at the same count), and their budget only keeps the text of the two halves together
     // below the 4 GB a batch's 32-bit sequence positions can address
-    const size_t BATCH_TEXT = rs.paired ? (size_t)0x7F000000u : (size_t)(512u << 20);
+    size_t BATCH_TEXT = rs.paired ? (size_t)0x7F000000u : (size_t)(512u << 20);
+    if (const char *env = getenv("NOHUMAN_BATCH_TEXT")) {  // test knob (single-end): batches cut by text at small scale
+        const long v = atol(env);
+        if (v > 0 && !rs.paired) BATCH_TEXT = (size_t)v;
+    }
     const int G = (int)engines.size();
     const int mates = rs.paired ? 2 : 1;
     // Batches of the reader on the GPU keep their text in HBM.  The host needs the bytes for plain outputs and the host's
@@ -782,7 +859,7 @@ int run_engines(const std::vector<Engine *> &engines, const nh_run_args *a, nh_s
     };
     for (int g = 0; g < G; g++) {
         const size_t nb = (CNT_N + 12) * sizeof(uint64_t);  // (+12: the words of the instrumented kernel variant)
-        if (hipSetDevice(engines[g]->device) != hipSuccess || hipMalloc((void **)&rs.d_run_counters[g], nb) != hipSuccess ||
+        if (hipSetDevice(engines[g]->device) != hipSuccess || dev_malloc((void **)&rs.d_run_counters[g], nb) != hipSuccess ||
             hipMemset(rs.d_run_counters[g], 0, nb) != hipSuccess) {
             free_run_counters();
             return set_error(NH_EDEVICE, "cannot allocate the run's counters on device %d", engines[g]->device);
@@ -825,11 +902,24 @@ int run_engines(const std::vector<Engine *> &engines, const nh_run_args *a, nh_s
                     BATCH_FRAGS, pool1.first_reserve, prefill);
     }
     int prefill1 = prefill, prefill2 = prefill;
-    {   // batches of the reader on the GPU carry no host text unless an output needs it: no page-locked buffers made ahead for them
+    // which reader takes a gzip input: NOHUMAN_GZ_READER by name ("device", "host", "device-text"), else by the input
+    // (device_reader_pays); paired files go the same way (the smaller file decides)
+    bool dev_reader1 = false, dev_reader2 = false;
+    {
         const char *how = getenv("NOHUMAN_GZ_READER");
-        const bool dev_reader = !(how && (!strcmp(how, "host") || !strcmp(how, "device-text")));
-        if (dev_reader && !host_text_wanted && dev_gunzip_wants(a->in1)) pool1.first_reserve = 0, prefill1 = 0;
-        if (dev_reader && !host_text_wanted && rs.paired && dev_gunzip_wants(a->in2)) pool2.first_reserve = 0, prefill2 = 0;
+        const bool off = how && (!strcmp(how, "host") || !strcmp(how, "device-text"));
+        const bool named = how && !strcmp(how, "device");
+        const bool by_host = !(a->out_codec == NH_CODEC_GZIP && o1.enc && o1.enc->takes_device_spans() &&
+                               (!rs.paired || (o2.enc && o2.enc->takes_device_spans())));
+        dev_reader1 = !off && dev_gunzip_wants(a->in1) && (named || device_reader_pays(a->in1, mean_rec, host_text_wanted, by_host));
+        dev_reader2 = rs.paired && !off && dev_gunzip_wants(a->in2) && (named || device_reader_pays(a->in2, mean_rec, host_text_wanted, by_host));
+        if (rs.paired && !named && dev_reader1 != dev_reader2 && dev_gunzip_wants(a->in1) && dev_gunzip_wants(a->in2)) dev_reader1 = dev_reader2 = false;
+        if (getenv("NOHUMAN_TRACE"))
+            fprintf(stderr, "[nohuman trace] gzip reader: %s%s%s\n", dev_reader1 ? "GPU" : "host", rs.paired ? (dev_reader2 ? " / GPU" : " / host") : "",
+                    how ? " (NOHUMAN_GZ_READER)" : "");
+        // batches of the reader on the GPU carry no host text unless an output needs it: no page-locked buffers made ahead for them
+        if (dev_reader1 && !host_text_wanted) pool1.first_reserve = 0, prefill1 = 0;
+        if (dev_reader2 && !host_text_wanted) pool2.first_reserve = 0, prefill2 = 0;
     }
     if (prefill1) pool1.start_prefill(prefill1);
     if (rs.paired && prefill2) pool2.start_prefill(prefill2);
@@ -851,9 +941,9 @@ int run_engines(const std::vector<Engine *> &engines, const nh_run_args *a, nh_s
         const int n = atoi(e);
         while (G == 1 && (int)devs1.size() < n && n <= 4) devs1.push_back(devs1[0]), devs2.push_back(devs2[0]);
     }
-    std::thread t1(reader_main, a->in1, &q1, &rs, &pool1, &clk, 0, BATCH_FRAGS, BATCH_TEXT, gz_threads, devs1);
+    std::thread t1(reader_main, a->in1, &q1, &rs, &pool1, &clk, 0, BATCH_FRAGS, BATCH_TEXT, gz_threads, devs1, dev_reader1);
     std::thread t2;
-    if (rs.paired) t2 = std::thread(reader_main, a->in2, &q2, &rs, &pool2, &clk, 1, BATCH_FRAGS, BATCH_TEXT, gz_threads, devs2);
+    if (rs.paired) t2 = std::thread(reader_main, a->in2, &q2, &rs, &pool2, &clk, 1, BATCH_FRAGS, BATCH_TEXT, gz_threads, devs2, dev_reader2);
 
     // writer: consumes batches in order; each arrives after its stream was synchronised.  Two stages: the WRITER
     // waits for the batch's stream, decides and formats (span lists, nothing is copied); the FLUSHER writes the spans

@@ -18,11 +18,14 @@ import json
 genomes = None
 
 
-def fastq(rng, n, odd):
+def fastq(rng, n, odd, long_tail=False):
     out = []
     acgt = np.frombuffer(b"ACGT", np.uint8)
-    for i in range(n):
+    n_long = int(rng.integers(3, 12)) if long_tail and n else 0  # short reads first, then very long ones
+    for i in range(n + n_long):
         ln = int(rng.choice([0, 20, 35, 60, 100, 150, 151, 300, 2000])) if rng.random() < 0.3 else 150
+        if i >= n:
+            ln = int(rng.integers(20000, 120000))
         seq = bytes(acgt[rng.integers(0, 4, ln)])
         if odd and rng.random() < 0.1:
             seq = seq.lower()
@@ -44,6 +47,10 @@ def fastq(rng, n, odd):
         k = int(rng.integers(1, n - 1))
         cut = sum(len(x) for x in out[:k])
         data = data[:cut] + (b"\n" if rng.random() < 0.5 else b"@\n") + data[cut:]  # an empty header line: the input ends there
+    elif odd and n > 10 and rng.random() < 0.04:
+        k = int(rng.integers(1, n - 1))
+        cut = sum(len(x) for x in out[:k])
+        data = data[:cut] + bytes(rng.choice(list(b"X+>#"), 1).astype(np.uint8)) + b"\n" + data[cut:]  # a one-character line that is no '@': malformed on any reader
     return data
 
 
@@ -78,8 +85,9 @@ for k in range(cases):
     paired = bool(rng.random() < 0.5)
     odd = bool(rng.random() < 0.7)
     n = int(rng.choice([0, 1, 7, 300, 2000, 9000]))
-    d1 = fastq(rng, n, odd)
-    d2 = fastq(rng, n if rng.random() < 0.8 else max(0, n - int(rng.integers(0, 5))), odd) if paired else None
+    long_tail = bool(rng.random() < 0.25)
+    d1 = fastq(rng, n, odd, long_tail)
+    d2 = fastq(rng, n if rng.random() < 0.8 else max(0, n - int(rng.integers(0, 5))), odd, long_tail) if paired else None
     f1, f2 = os.path.join(tmp, "a_1.fq.gz"), os.path.join(tmp, "a_2.fq.gz")
     open(f1, "wb").write(gz(rng, d1))
     if paired:
@@ -95,9 +103,20 @@ for k in range(cases):
         os.environ["NOHUMAN_GZ_LANES"] = str(lanes)
         os.environ["NOHUMAN_GZDEV_STRETCH"] = str(int(rng.choice([4096, 8192])))
         os.environ["NOHUMAN_GZDEV_SEG"] = str(int(rng.choice([16384, 65536, 262144])))
+    # the product's default (no reader named: it may hand the file over to the host reader mid-stream, and single-end batches
+    # are cut by text) in the cases with the long tail and in a third of the others; the reader named in the rest
+    auto = long_tail or bool(rng.random() < 0.33)
+    os.environ["NOHUMAN_GZDEV_MIN_BYTES"] = "0"
+    os.environ.pop("NOHUMAN_GZDEV_ROOM", None)
+    os.environ.pop("NOHUMAN_BATCH_TEXT", None)
+    if long_tail:
+        os.environ["NOHUMAN_GZDEV_ROOM"] = str(int(rng.choice([1 << 20, 2 << 20, 8 << 20])))
+        os.environ["NOHUMAN_BATCH_TEXT"] = str(int(rng.choice([100000, 1 << 20, 512 << 20])))
     res = {}
     for reader in ("device", "host"):
         os.environ["NOHUMAN_GZ_READER"] = reader
+        if auto and reader == "device":
+            os.environ.pop("NOHUMAN_GZ_READER")
         o1, o2, ko = (os.path.join(tmp, "%s_%s" % (reader, x)) for x in ("o1", "o2", "k"))
         for o in (o1, o2, ko):
             if os.path.exists(o):
@@ -116,8 +135,8 @@ for k in range(cases):
         if paired:
             open(os.path.join(keep, "a_2.fq.gz"), "wb").write(open(f2, "rb").read())
         dv, hv = res["device"], res["host"]
-        print("CASE %d DIFFERS: paired %s odd %s n %d kw %s batch %s seg %s stretch %s lanes %d" % (k, paired, odd, n, kw, os.environ["NOHUMAN_BATCH_FRAGS"],
-              os.environ["NOHUMAN_GZDEV_SEG"], os.environ["NOHUMAN_GZDEV_STRETCH"], lanes))
+        print("CASE %d DIFFERS: paired %s odd %s n %d long tail %s default reader %s kw %s batch %s seg %s stretch %s lanes %d room %s" % (k, paired, odd, n, long_tail, auto, kw,
+              os.environ["NOHUMAN_BATCH_FRAGS"], os.environ["NOHUMAN_GZDEV_SEG"], os.environ["NOHUMAN_GZDEV_STRETCH"], lanes, os.environ.get("NOHUMAN_GZDEV_ROOM")))
         print("   device:", [x if not isinstance(x, bytes) else (len(x), zlib.crc32(x)) for x in dv])
         print("   host  :", [x if not isinstance(x, bytes) else (len(x), zlib.crc32(x)) for x in hv], flush=True)
         if bad >= 5:
