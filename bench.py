@@ -12,16 +12,21 @@ WORLD_SIZE in the environment) this process IS one rank; started directly with N
 the N rank processes (before anything here touches the GPU), relays rank 0's line and exits with
 their status.
 
-Prints ONE JSON line on rank 0 (contract in the round brief), including
-  "roofline":     algorithmic bytes (sum len + 64*D + 16 per fragment) per
-                  launch / average kernel duration measured with HIP events on the launch stream,
-  "cpu_baseline": the CPU oracle (oracle/k2_oracle.c, kind "port": kraken2 itself is not on the
-                  box) timed on the host cores on a bounded sample of the same workload,
-  "variants":     N=1 only, reduced step counts: the hit path (half of the fragments "human"), the
-                  single-end shape of BASELINE.json configs[1] and ONT-like long reads (configs[3] shape,
-                  200 k reads per launch), each checked against the oracle on a sample,
-  "e2e":          N=1 only: nh_run() files-in -> files-out on gzip pairs (configs[2] shape at a stated
-                  scale), wall clock and per-stage times; never mixed into `value`.
+Prints ONE JSON line on rank 0 (contract in the round brief).  Everything the driver keeps is inside the objects it
+preserves whole:
+  "config":       the workload, and config.e2e (N=1 only): nh_run() files-in -> files-out on gzip pairs (configs[2] shape
+                  at a stated scale) and on one gzip file of ONT-like reads (configs[3] shape, scaled) -- Mreads/s and wall
+                  seconds only, never mixed into `value`;
+  "roofline":     algorithmic bytes (sum len + 64*D + 16 per fragment) per launch / average kernel
+                  duration measured with HIP events on the launch stream; value_two_streams: the same launches issued on two
+                  alternating streams (what nh_run's stream slots do); roofline.variants (N=1 only, reduced step counts):
+                  single-end configs[1], hit path, ONT-like long reads, a table of > 2^32 cells, 2 x 250 bp pairs -- frac,
+                  kernel_ms, both values, checked against the oracle on a sample;
+  "cpu_baseline": kraken2 itself with the reference's argv (src/main.rs:215-267) when a `kraken2` binary is on PATH
+                  (kind "kraken2"), else the CPU oracle (oracle/k2_oracle.c, kind "port") timed on the host cores on a
+                  bounded sample of the same workload.
+The long descriptions (workload strings, per-stage traces, what each leg did) go to stderr and to bench_details.json
+(directory NOHUMAN_BENCH_LOGDIR, default the current one), not into the line.
 """
 import argparse
 import json
@@ -257,12 +262,36 @@ def measure(cx, args, *, steps, warmup, single_end=False, ont=False, hit_frac=0.
     elapsed = time.perf_counter() - t_start
     kernel_ms = ev0.elapsed_time(ev1) / max(steps, 1)
 
+    # ---- the same launches on TWO alternating streams: what nh_run's stream slots do in production (a launch's tail
+    # overlaps the next one's ramp).  Reported beside the single-stream value, never instead of it.
+    s2 = [torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)]
+    res2 = [results, torch.empty_like(results)]
+    counters2 = torch.zeros(4, dtype=torch.int64, device=dev)
+
+    def step2(i):
+        eng.classify_device(pool[i % len(pool)].data_ptr(), offsets.data_ptr(), n_frag, paired, args.confidence,
+                            res2[i % 2].data_ptr(), counters2.data_ptr(), s2[i % 2].cuda_stream, long_reads=ont)
+
+    for i in range(min(warmup, 2)):
+        step2(i)
+    torch.cuda.synchronize()
+    barrier()
+    t2 = time.perf_counter()
+    for i in range(steps):
+        step2(warmup + i)
+    torch.cuda.synchronize()
+    barrier()
+    elapsed2 = time.perf_counter() - t2
+    del res2, counters2
+
     # ---- totals: the one collective of the path (classified-count all-reduce) ------------------
     from nohuman_amd.dist import gather_floats, reduce_counters
     (frags, classified, nbases, lookups), elapsed_max = reduce_counters(counters, elapsed)
     rank_kernel_ms = gather_floats(kernel_ms, dev)
+    elapsed2_max = max(gather_floats(elapsed2, dev))
     reads_total = frags * mates
     value = reads_total / elapsed_max / 1e6
+    value2 = reads_total / elapsed2_max / 1e6
 
     # per-launch algorithmic bytes on this rank
     c = [int(x) for x in counters.tolist()]
@@ -322,6 +351,9 @@ def measure(cx, args, *, steps, warmup, single_end=False, ont=False, hit_frac=0.
             "kernel_ms": round(kernel_ms, 4),
             "kernel_ms_per_rank": [round(x, 4) for x in rank_kernel_ms],
             "algorithmic_bytes_per_launch": int(alg_bytes_launch),
+            # the same launches on two alternating streams (nh_run's slots): whole-job Mreads/s and its roofline fraction
+            "value_two_streams": round(value2, 3),
+            "frac_two_streams": round(alg_bytes_launch * steps / elapsed2_max / 1e9 / HBM_PEAK_GBS, 4) if elapsed2_max > 0 else None,
         },
     }
     live = dict(eng=eng, pool=pool, offsets=offsets, results=results, step=step, mates=mates, paired=paired,
@@ -420,55 +452,93 @@ def main():
         "roofline": m["roofline"],
     }
     solo = cx.rank == 0 and cx.world == 1
-    # ---- CPU baseline: the oracle on the host cores, bounded sample (rank 0, N=1 only) --------
+    details = {"headline_workload": m["workload"]}
+    out["config"]["workload"] = short_workload(m)
+    # ---- CPU baseline: kraken2 itself when the box has it, else the oracle on the host cores; bounded sample (rank 0, N=1 only)
     if solo and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(cx, args, live, args.cpu_seconds)
     # ---- e2e: files in -> files out through nh_run on the same engine (N=1 only) --------------------
-    if solo and not args.no_e2e and not (args.ont or args.single_end):
+    plain_pe = not (args.ont or args.single_end)
+    if solo and not args.no_e2e and plain_pe:
         try:
-            out["e2e"] = e2e_leg(cx, args, live["eng"])
+            out["config"]["e2e"], details["e2e"] = e2e_leg(cx, args, live["eng"])
         except Exception as ex:  # the e2e leg must never cost the headline line
-            out["e2e"] = {"error": repr(ex)}
+            out["config"]["e2e"] = {"error": repr(ex)[:300]}
+        try:
+            ont_nums, details["e2e_ont"] = e2e_ont_leg(cx, args, live["eng"])
+            out["config"].setdefault("e2e", {}).update(ont_nums)
+        except Exception as ex:
+            out["config"].setdefault("e2e", {})["ont_error"] = repr(ex)[:300]
     live["eng"].close()
     del live
     torch.cuda.empty_cache()
     # ---- the output stage on its own: the GPU gzip encoder on FASTQ text (N=1 only) ------------------------------
-    if solo and not args.no_e2e and not (args.ont or args.single_end):
+    if solo and not args.no_e2e and plain_pe:
         try:
-            out["gzip_encoder"] = gzip_leg(cx, args)
+            gzl = gzip_leg(cx, args)
+            details["gzip_encoder"] = gzl
+            out["config"].setdefault("e2e", {})["gzip_encoder"] = {
+                "kernel_GBps": gzl["kernel_GBps"], "wall_GBps": gzl["wall_GBps"], "ratio": gzl["ratio"],
+                "inflates_to_the_text": gzl["inflates_to_the_text"], "zlib6_one_core_MBps": gzl["zlib6_one_core"]["MBps"],
+                "zlib6_ratio": gzl["zlib6_one_core"]["ratio"]}
         except Exception as ex:
-            out["gzip_encoder"] = {"error": repr(ex)}
-    # ---- variants at reduced step counts: hit path, single-end (N=1 only) --------------------------
+            out["config"].setdefault("e2e", {})["gzip_encoder"] = {"error": repr(ex)[:300]}
+    # ---- variants at reduced step counts (N=1 only): inside `roofline`, numbers only ------------------------
     if solo and not args.no_variants and not (args.ont or args.single_end or args.hit_frac):
-        out["variants"] = {}
-        for name, kw in (("hit_frac_0.5_PE", dict(hit_frac=0.5, pairs=1_000_000)),
-                         ("single_end_config1", dict(single_end=True, pairs=1_000_000)),
-                         ("ont_config3_scaled", dict(ont=True, pairs=200_000)),
+        variants = {}
+        details["variants"] = {}
+        for name, kw in (("se", dict(single_end=True, pairs=1_000_000)),            # configs[1]
+                         ("hit", dict(hit_frac=0.5, pairs=1_000_000)),              # half of the fragments "human"
+                         ("ont", dict(ont=True, pairs=200_000)),                    # configs[3] shape, 200 k reads a launch
                          # a table of more than 2^32 cells (64-bit cell positions in the kernels): 17.6 GB, four copies
-                         ("wide_table_4.4G_cells_PE", dict(pairs=1_000_000, capacity=4_400_000_011)),
+                         ("wide", dict(pairs=1_000_000, capacity=4_400_000_011)),
                          # 2 x 250 bp Illumina pairs: longer than one tile (158 bases), so every chunk is left to the generic
-                         # kernel k_classify -- the shape MiSeq / NovaSeq SP 2 x 250 runs meet (VERDICT r3 item 4)
-                         ("pe_2x250", dict(pairs=600_000, read_len=250))):
+                         # kernel k_classify -- the shape MiSeq / NovaSeq SP 2 x 250 runs meet
+                         ("pe250", dict(pairs=600_000, read_len=250))):
             vm, vlive = measure(cx, args, steps=12, warmup=3, keep=True, **kw)
-            chk = cpu_baseline(cx, args, vlive, 1.5)
+            chk = cpu_baseline(cx, args, vlive, 1.5, oracle_only=True)
             vlive["eng"].close()
             del vlive
             torch.cuda.empty_cache()
-            out["variants"][name] = {
-                "value": vm["value"], "unit": "Mreads/s", "steps": 12, "warmup": 3,
-                "fragments_per_step": vm["fragments_per_step"], "paired": vm["paired"],
-                "classified_fraction": vm["classified_fraction"], "lookups_per_read": vm["lookups_per_read"],
-                "roofline_frac": vm["roofline"]["frac"], "kernel_ms": vm["roofline"]["kernel_ms"],
-                "traffic": vm["roofline"]["traffic"], "traffic_stale": vm["roofline"]["traffic_stale"],
-                "hbm_achievable_frac": vm["roofline"]["hbm_achievable_frac"],
-                "algorithmic_bytes_per_launch": vm["roofline"]["algorithmic_bytes_per_launch"],
-                "gpu_equals_oracle_on_sample": chk["gpu_equals_oracle"], "oracle_sample_fragments": chk["fragments"],
-                "workload": vm["workload"],
+            r = vm["roofline"]
+            variants[name] = {
+                "frac": r["frac"], "kernel_ms": r["kernel_ms"], "value": vm["value"], "value_two_streams": r["value_two_streams"],
+                "frac_two_streams": r["frac_two_streams"], "hbm_achievable_frac": r["hbm_achievable_frac"],
+                "traffic": r["traffic"], "traffic_stale": r["traffic_stale"],
+                "algorithmic_bytes_per_launch": r["algorithmic_bytes_per_launch"], "fragments_per_step": vm["fragments_per_step"],
+                "classified_fraction": round(vm["classified_fraction"], 4), "lookups_per_read": round(vm["lookups_per_read"], 3),
+                "gpu_equals_oracle": chk["gpu_equals_oracle"], "oracle_sample_fragments": chk["fragments"],
             }
+            details["variants"][name] = {"workload": vm["workload"], "steps": 12, "warmup": 3, "kernel": r["kernel"]}
+        out["roofline"]["variants"] = variants
+    if cx.rank == 0:
+        write_details(details)
     if cx.rank == 0:
         print(json.dumps(out), flush=True)
     if cx.world > 1:
         dist.destroy_process_group()
+
+
+def short_workload(m):
+    """config.workload: one short phrase (the full description goes to bench_details.json)"""
+    return "%d x %s per step per GPU, iid ACGT resident in HBM; hash table %.2f GB (%s), load %.2f" % (
+        m["fragments_per_step"], "read pairs" if m["paired"] else "single-end reads", m["database"]["capacity"] * 4 / 1e9,
+        "REAL database" if not str(m["database"]["source"]).startswith("synthetic") else "synthetic HPRC.r2-like",
+        m["database"]["size"] / max(m["database"]["capacity"], 1))
+
+
+def write_details(details):
+    """What the line no longer carries: stderr (one line) and bench_details.json"""
+    try:
+        txt = json.dumps(details)
+        sys.stderr.write("bench-details: " + txt + "\n")
+        sys.stderr.flush()
+        logdir = os.environ.get("NOHUMAN_BENCH_LOGDIR", ".")
+        os.makedirs(logdir, exist_ok=True)
+        with open(os.path.join(logdir, "bench_details.json"), "w") as fo:
+            fo.write(txt + "\n")
+    except OSError:
+        pass
 
 
 def rank_table(cx, kernel_ms):
@@ -542,9 +612,130 @@ def hbm_frac(key, n_frag, kernel_ms):
     return round(w["traffic_bytes_per_launch"] / (kernel_ms * 1e-3) / 1e9 / t.get("hbm_achievable_gbs", 6290.0), 4)
 
 
-def cpu_baseline(cx, args, live, budget_s):
+def write_k2_db(db_dir, opts_image, taxo_image, header, cells):
+    """A kraken2 database directory from the engine's images (nh_opts_image, nh_taxonomy_image, nh_table_download): the
+    three files of /root/reference/src/lib.rs:120, in the layout of SURVEY.md A.1."""
+    import struct
+    os.makedirs(db_dir, exist_ok=True)
+    with open(os.path.join(db_dir, "opts.k2d"), "wb") as fo:
+        fo.write(opts_image)
+    with open(os.path.join(db_dir, "taxo.k2d"), "wb") as fo:
+        fo.write(taxo_image)
+    with open(os.path.join(db_dir, "hash.k2d"), "wb") as fo:
+        fo.write(struct.pack("<4Q", *[int(x) for x in header]))
+        cells.tofile(fo)
+
+
+def kraken2_argv(threads, db_dir, out_pattern, inputs, confidence=0.0, kraken_output="/dev/null"):
+    """The argv nohuman builds for its subprocess (/root/reference/src/main.rs:210-267), token for token: --threads T --db DB
+    --output /dev/null --confidence C [--paired] --unclassified-out <tmp>/kraken_out[#].fq inputs.  (Rust prints 0.0f32 as "0".)"""
+    conf = ("%g" % confidence)
+    argv = ["--threads", str(int(threads)), "--db", db_dir, "--output", kraken_output, "--confidence", conf]
+    if len(inputs) == 2:
+        argv.append("--paired")
+    argv += ["--unclassified-out", out_pattern]
+    return argv + list(inputs)
+
+
+def time_kraken2(exe, threads, db_dir, inputs, tmp, confidence=0.0):
+    """Runs the stock binary with the reference's argv; wall seconds, and what its own stderr summary says (the three
+    integers of /root/reference/src/lib.rs:61-97 and the `processed in Ts` timer, which excludes the database load)."""
+    import re
+    out = os.path.join(tmp, "kraken_out#.fq" if len(inputs) == 2 else "kraken_out.fq")
+    argv = [exe] + kraken2_argv(threads, db_dir, out, inputs, confidence)
+    t = time.perf_counter()
+    p = subprocess.run(argv, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, text=True)
+    wall = time.perf_counter() - t
+    for q in (out.replace("#", "_1"), out.replace("#", "_2"), out):
+        if os.path.exists(q):
+            os.remove(q)
+    if p.returncode != 0:
+        raise RuntimeError("kraken2 failed with stderr %s" % p.stderr[-500:])
+    err = p.stderr.replace(",", "")
+    m = re.search(r"(\d+) sequences \(([0-9.]+) Mbp\) processed in ([0-9.]+)s", err)
+    c = re.search(r"(\d+) sequences classified", err)
+    u = re.search(r"(\d+) sequences unclassified", err)
+    return {"argv": argv, "wall_s": wall, "sequences": int(m.group(1)) if m else None, "own_seconds": float(m.group(3)) if m else None,
+            "classified": int(c.group(1)) if c else None, "unclassified": int(u.group(1)) if u else None}
+
+
+def sample_fastq(cx, live, n_frag, paths):
+    """The first n_frag fragments of batch 0 as FASTQ (ids syn.<idx>[/1|/2], qualities 'I': SURVEY.md section 8d)"""
+    torch = cx.torch
+    mates = live["mates"]
+    offs = live["offsets"][:n_frag * mates + 1].cpu().numpy()
+    bases = live["pool"][0][:int(offs[-1])].cpu().numpy()
+    for mate, path in enumerate(paths):
+        with open(path, "wb") as fo:
+            rows = []
+            for i in range(n_frag):
+                a, b = int(offs[i * mates + mate]), int(offs[i * mates + mate + 1])
+                rows.append(b"@syn.%d%s\n" % (i, (b"/%d" % (mate + 1)) if mates == 2 else b""))
+                rows.append(bases[a:b].tobytes())
+                rows.append(b"\n+\n" + b"I" * (b - a) + b"\n")
+                if len(rows) >= 300000:
+                    fo.write(b"".join(rows))
+                    rows = []
+            fo.write(b"".join(rows))
+
+
+def kraken2_baseline(cx, args, live, exe, cores):
+    """SURVEY.md section 8d case 1: the stock kraken2 binary on the headline's first batch with exactly the argv nohuman builds,
+    at `cores` threads and at 1 thread, against the SAME table (written to a tmpfs database directory from the engine's images).
+    The same directory is what scripts/parity_vs_kraken2.sh takes at bench size."""
+    import shutil
+    import tempfile
+    np, torch = cx.np, cx.torch
+    eng, mates = live["eng"], live["mates"]
+    base = "/dev/shm" if os.path.isdir("/dev/shm") and os.access("/dev/shm", os.W_OK) else None
+    tmp = tempfile.mkdtemp(prefix="nh_bench_k2_", dir=base)
+    try:
+        info = eng.info
+        db = os.path.join(tmp, "db")
+        write_k2_db(db, eng.opts_image(), eng.taxonomy_image(), (info.capacity, info.size, info.key_bits, info.value_bits), eng.download_table())
+        n_all = min(live["n_frag"], int(os.environ.get("NOHUMAN_BENCH_K2_FRAGMENTS", "2500000")))
+        n_one = max(1, n_all // 10)
+        paths = [os.path.join(tmp, "r_%d.fq" % (m + 1)) for m in range(mates)]
+        sample_fastq(cx, live, n_all, paths)
+        full = time_kraken2(exe, cores, db, paths, tmp, args.confidence)
+        one_paths = [p + ".one" for p in paths]
+        for p, q in zip(paths, one_paths):  # the first tenth for the one-thread figure
+            with open(p, "rb") as fi, open(q, "wb") as fo:
+                lines = 4 * n_one
+                for k, ln in enumerate(fi):
+                    if k >= lines:
+                        break
+                    fo.write(ln)
+        one = time_kraken2(exe, 1, db, one_paths, tmp, args.confidence)
+        # the GPU on the same sample: classified counts must agree (the per-read diff is scripts/parity_vs_kraken2.sh's job)
+        live["step"](0)
+        torch.cuda.synchronize()
+        gpu_classified = int((live["results"][:n_all, 0] != 0).sum().item())
+        keep = os.environ.get("NOHUMAN_BENCH_K2_KEEP")  # a directory: the database and the sample stay for the parity script
+        if keep:
+            shutil.copytree(tmp, keep, dirs_exist_ok=True)
+        secs = full["own_seconds"] or full["wall_s"]
+        return {
+            "value": round(n_all * mates / secs / 1e6, 4), "unit": "Mreads/s", "cores": cores, "kind": "kraken2",
+            "wall_value": round(n_all * mates / full["wall_s"] / 1e6, 4),
+            "one_thread": {"value": round(n_one * mates / (one["own_seconds"] or one["wall_s"]) / 1e6, 4), "fragments": n_one},
+            "fragments": n_all,
+            "classified": full["classified"], "gpu_classified": gpu_classified,
+            "classified_equal_gpu": full["classified"] == gpu_classified,
+            "argv": " ".join(full["argv"]),
+            "sample": "first %d fragments (%d reads) of batch 0 as FASTQ in tmpfs, the engine's own table written as a kraken2 database; "
+                      "stock kraken2 with nohuman's argv (src/main.rs:215-267) at %d threads; value from its own 'processed in' timer "
+                      "(database load excluded), wall_value from the wall clock" % (n_all, n_all * mates, cores),
+        }
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+
+
+def cpu_baseline(cx, args, live, budget_s, oracle_only=False):
     """Times oracle/k2_oracle.c (pthreads, all host cores) on the first fragments of batch 0 with
-    the very same table (downloaded from HBM), and checks the GPU results on that sample."""
+    the very same table (downloaded from HBM), and checks the GPU results on that sample.  When a `kraken2` binary is on
+    PATH (pin day) the stock binary is the baseline (kind "kraken2") and the port stays beside it."""
+    import shutil
     np, torch = cx.np, cx.torch
     from oracle import oracle as orc
     from nohuman_amd.dist import usable_cpu_count
@@ -580,7 +771,9 @@ def cpu_baseline(cx, args, live, budget_s):
     exp = np.concatenate(outs)
     ok = (np.array_equal(got[:, 0], exp["call"]) and np.array_equal(got[:, 1], exp["total_kmers"])
           and np.array_equal(got[:, 2], exp["clade_hits"]) and np.array_equal(got[:, 3], exp["hit_groups"]))
-    return {
+    del odb
+    exe = None if oracle_only else shutil.which("kraken2")
+    port = {
         "value": round(done * mates / spent / 1e6, 4),
         "unit": "Mreads/s",
         "cores": cores,
@@ -588,9 +781,19 @@ def cpu_baseline(cx, args, live, budget_s):
         "gpu_equals_oracle": bool(ok),
         "fragments": done,
         "sample": "first %d fragments (%d reads) of batch 0, same table; oracle/k2_oracle.c on %d "
-                  "pthreads (kraken2 binary not on the box); GPU==oracle on sample: %s"
-                  % (done, done * mates, cores, ok),
+                  "pthreads (%s); GPU==oracle on sample: %s"
+                  % (done, done * mates, cores, "kraken2 timed beside it" if exe else "kraken2 binary not on the box", ok),
     }
+    if not exe:
+        return port
+    try:
+        k2 = kraken2_baseline(cx, args, live, exe, cores)
+    except Exception as ex:  # a binary that does not run must not cost the line: the port stands, the failure is named
+        port["kraken2_error"] = repr(ex)[:300]
+        return port
+    k2["gpu_equals_oracle"] = bool(ok)
+    k2["port"] = {k: port[k] for k in ("value", "cores", "fragments", "gpu_equals_oracle")}
+    return k2
 
 
 def _hash_file_ranges(path, ranges):
@@ -822,7 +1025,7 @@ def e2e_leg(cx, args, eng):
             if best is None or dt < best[0]:
                 best = (dt, st.total_sequences, st.classified)
                 trace = " | ".join(x.strip() for x in open(tr_path).read().strip().splitlines()
-                                   if "wall" in x or "gunzip consumer" in x or "gzip reader on GPU" in x)
+                                   if "wall" in x or "gunzip consumer" in x or "gzip reader" in x)
         dt, nfr, ncl = best
         # every read was kept: the outputs are the generated text, member by member (byte-exact, by digest)
         ok = nfr == n * reps and ncl == 0
@@ -846,60 +1049,40 @@ def e2e_leg(cx, args, eng):
         ok = ok and checked.get(1) is True and checked.get(2) is True
         for p in (o1, o2):
             os.remove(p)
-        # the input side alone: same run with --classified-out semantics (nothing is kept, nothing written)
-        t = time.perf_counter()
-        st_in = eng.run(files[0], os.path.join(tmp, "h_1.fq"), in2=files[1], out2=os.path.join(tmp, "h_2.fq"),
-                        threads=threads, keep_human=True)
-        dt_in = time.perf_counter() - t
-        # the other gzip reader on the same inputs (the default reads .gz on the GPU, nh_gunzip.hip; NOHUMAN_GZ_READER=host is
-        # round 3's reader on the host cores): nothing kept, and gzip outputs further down
-        default_reader = os.environ.get("NOHUMAN_GZ_READER", "device")
-        other_reader = "host" if default_reader != "host" else "device"
-        other = {}
-        try:
-            os.environ["NOHUMAN_GZ_READER"] = other_reader
-            t = time.perf_counter()
-            st_o = eng.run(files[0], os.path.join(tmp, "h_1.fq"), in2=files[1], out2=os.path.join(tmp, "h_2.fq"),
-                           threads=threads, keep_human=True)
-            dt_o = time.perf_counter() - t
-            t = time.perf_counter()
-            st_og = eng.run(files[0], os.path.join(tmp, "x_1.fq.gz"), in2=files[1], out2=os.path.join(tmp, "x_2.fq.gz"),
-                            threads=threads, out_codec=2, codec_threads=max(1, threads // 2))
-            dt_og = time.perf_counter() - t
-            for pth in ("x_1.fq.gz", "x_2.fq.gz"):
-                os.remove(os.path.join(tmp, pth))
-            other = {"reader": other_reader,
-                     "input_side_only": {"value": round(2 * st_o.total_sequences / dt_o / 1e6, 3), "wall_s": round(dt_o, 4)},
-                     "gzip_output": {"value": round(2 * st_og.total_sequences / dt_og / 1e6, 3), "wall_s": round(dt_og, 4)}}
-        except Exception as ex:
-            other = {"reader": other_reader, "error": str(ex)[:300]}
-        finally:
-            if default_reader == "device" and "NOHUMAN_GZ_READER" in os.environ and os.environ["NOHUMAN_GZ_READER"] == other_reader:
-                os.environ.pop("NOHUMAN_GZ_READER", None)
-            if default_reader == "host":
-                os.environ["NOHUMAN_GZ_READER"] = "host"
-        # the same run with gzip outputs, the reference's default for gzip inputs (main.rs:238-245): the kept reads
-        # are compressed on the GPU (nh_deflate.hip) as the writer hands them over; the files are inflated again
-        # by the library's own reader and compared with the generated text like the plain outputs
-        gz = {}
-        try:
-            g1, g2 = os.path.join(tmp, "o_1.fq.gz"), os.path.join(tmp, "o_2.fq.gz")
-            tr_path = os.path.join(tmp, "trace_gz.txt")
+        def which_reader(tr):  # "[nohuman trace] gzip reader: GPU / GPU" -> what nh_run chose (device_reader_pays, nh_run.hip)
+            for ln in tr.splitlines():
+                if "gzip reader:" in ln:
+                    return ln.split("gzip reader:")[1].strip()
+            return "?"
+
+        def traced_run(label, **kw):
+            tr_path = os.path.join(tmp, "trace_%s.txt" % label)
             saved = os.dup(2)
             fd = os.open(tr_path, os.O_WRONLY | os.O_CREAT | os.O_TRUNC, 0o600)
             os.environ["NOHUMAN_TRACE"] = "1"
             try:
                 os.dup2(fd, 2)
                 t = time.perf_counter()
-                st_gz = eng.run(files[0], g1, in2=files[1], out2=g2, threads=threads, out_codec=2,
-                                codec_threads=max(1, threads // 2))
-                dt_gz = time.perf_counter() - t
+                st = eng.run(files[0], kw.pop("o1"), in2=files[1], out2=kw.pop("o2"), threads=threads, **kw)
+                dt = time.perf_counter() - t
             finally:
                 os.dup2(saved, 2)
                 os.close(saved)
                 os.close(fd)
                 os.environ.pop("NOHUMAN_TRACE", None)
-            trace_gz = " | ".join(x.strip() for x in open(tr_path).read().strip().splitlines() if "wall" in x or "gzip encoder" in x)
+            return st, dt, open(tr_path).read()
+
+        reader_plain = which_reader(open(os.path.join(tmp, "trace.txt")).read())
+        # the input side alone: same run with --classified-out semantics (nothing is kept, nothing written)
+        st_in, dt_in, tr_in = traced_run("none", o1=os.path.join(tmp, "h_1.fq"), o2=os.path.join(tmp, "h_2.fq"), keep_human=True)
+        # the same run with gzip outputs, the reference's default for gzip inputs (main.rs:238-245): the kept reads
+        # are compressed on the GPU (nh_deflate.hip) as the writer hands them over; the files are inflated again
+        # by the library's own reader and compared with the generated text like the plain outputs
+        gz = {}
+        gz_detail = {}
+        try:
+            g1, g2 = os.path.join(tmp, "o_1.fq.gz"), os.path.join(tmp, "o_2.fq.gz")
+            st_gz, dt_gz, tr_gz = traced_run("gz", o1=g1, o2=g2, out_codec=2, codec_threads=max(1, threads // 2))
             out_gz = os.path.getsize(g1) + os.path.getsize(g2)
             gz_ok = {}
 
@@ -920,44 +1103,182 @@ def e2e_leg(cx, args, eng):
             for th in vt:
                 th.join()
             host_rate = sum(b for b, _ in host_gz) / max(1e-9, sum(sec for _, sec in host_gz)) if host_gz else 0.0
-            gz = {"value": round(2 * st_gz.total_sequences / dt_gz / 1e6, 3), "unit": "Mreads/s", "wall_s": round(dt_gz, 4),
-                  "what": "same inputs, outputs written as gzip (out_codec 2): one ordinary member per file, encoded on the "
-                          "GPU, 64 KiB of text per wave",
+            gz = {"value": round(2 * st_gz.total_sequences / dt_gz / 1e6, 3), "wall_s": round(dt_gz, 4), "reader": which_reader(tr_gz),
                   "output_ratio": round(text_bytes / max(out_gz, 1), 3),
-                  "stages": trace_gz,
                   "outputs_equal_inputs": bool(gz_ok.get(1) is True and gz_ok.get(2) is True and st_gz.total_sequences == n * reps),
-                  "outputs_check": "both files inflated by nh_gunzip_file, xxh3-64 per member range == the generated text",
-                  "host_encoder_GBps": round(host_rate / 1e9, 3),
-                  "host_encoder_what": "nh_compress_file (zlib -6 blocks on %d workers, what gzp does in the reference) on this "
-                                       "leg's own input members, two files at a time" % max(1, threads // 2)}
+                  "host_encoder_GBps": round(host_rate / 1e9, 3)}
+            gz_detail = {"what": "same inputs, outputs written as gzip (out_codec 2): one ordinary member per file, encoded on the GPU, "
+                                 "64 KiB of text per wave; both files inflated by nh_gunzip_file, xxh3-64 per member range == the generated text",
+                         "stages": " | ".join(x.strip() for x in tr_gz.splitlines() if "wall" in x or "gzip encoder" in x or "gzip reader" in x),
+                         "host_encoder_what": "nh_compress_file (zlib -6 blocks on %d workers, what gzp does in the reference) on this "
+                                              "leg's own input members, two files at a time" % max(1, threads // 2)}
         except Exception as ex:  # reported, not fatal for the line
             gz = {"error": str(ex)[:300]}
-        return {
-            "workload": "%d pairs of %d bp = 2 gzip FASTQ files of %d members x %d pairs (%d distinct members in rotation; "
-                        "level 6; Illumina-style ids, binned qualities; %.2f GB compressed, %.2f GB of text: %.2f:1), every read "
-                        "kept and written back uncompressed; configs[2] shape at %.0f %% scale"
-                        % (nfr, L, reps, n, distinct, gz_bytes / 1e9, text_bytes / 1e9, text_bytes / max(gz_bytes, 1),
-                           100.0 * nfr / 50e6),
-            "value": round(2 * nfr / dt / 1e6, 3),
+        # each reader by NAME on the same inputs (NOHUMAN_GZ_READER=device: nh_gunzip.hip on the GPU; =host: nh_inflate.cpp on
+        # the host cores): what the choice above was made from
+        named = {}
+        keep_env = os.environ.get("NOHUMAN_GZ_READER")
+        try:
+            for reader in ("device", "host"):
+                os.environ["NOHUMAN_GZ_READER"] = reader
+                t = time.perf_counter()
+                st_o = eng.run(files[0], os.path.join(tmp, "h_1.fq"), in2=files[1], out2=os.path.join(tmp, "h_2.fq"),
+                               threads=threads, keep_human=True)
+                dt_o = time.perf_counter() - t
+                t = time.perf_counter()
+                st_og = eng.run(files[0], os.path.join(tmp, "x_1.fq.gz"), in2=files[1], out2=os.path.join(tmp, "x_2.fq.gz"),
+                                threads=threads, out_codec=2, codec_threads=max(1, threads // 2))
+                dt_og = time.perf_counter() - t
+                for pth in ("x_1.fq.gz", "x_2.fq.gz"):
+                    os.remove(os.path.join(tmp, pth))
+                for p in (o1, o2):
+                    if os.path.exists(p):
+                        os.remove(p)
+                t = time.perf_counter()
+                st_op = eng.run(files[0], o1, in2=files[1], out2=o2, threads=threads)
+                dt_op = time.perf_counter() - t
+                named[reader] = {"input_side_only": round(2 * st_o.total_sequences / dt_o / 1e6, 3),
+                                 "gzip_to_gzip": round(2 * st_og.total_sequences / dt_og / 1e6, 3),
+                                 "gzip_to_plain": round(2 * st_op.total_sequences / dt_op / 1e6, 3)}
+        except Exception as ex:
+            named["error"] = str(ex)[:300]
+        finally:
+            if keep_env is None:
+                os.environ.pop("NOHUMAN_GZ_READER", None)
+            else:
+                os.environ["NOHUMAN_GZ_READER"] = keep_env
+        nums = {
             "unit": "Mreads/s",
-            "wall_s": round(dt, 4),
+            "pairs": int(nfr),
+            "scale_of_configs2": round(nfr / 50e6, 3),
             "host_threads": threads,
-            "fragments": int(nfr),
-            "classified": int(ncl),
-            "outputs_equal_inputs": bool(ok),
-            "outputs_check": "xxh3-64 of every member's byte range of both outputs == xxh3-64 of the generated text (%.1f s)" % t_verify,
             "gzip_ratio": round(text_bytes / max(gz_bytes, 1), 2),
-            "stages": trace,
-            "input_side_only": {"value": round(2 * st_in.total_sequences / dt_in / 1e6, 3), "unit": "Mreads/s",
-                                "wall_s": round(dt_in, 4),
-                                "what": "same inputs, keep_human=1 (no read is kept: inflate + parse + H2D + "
-                                        "classify + D2H, no output bytes)"},
-            "gzip_output": gz,
-            "gzip_reader": default_reader + (" (nh_gunzip.hip: block search, decode, window scan, marker resolve, CRC-32 on the GPU)"
-                                             if default_reader != "host" else " (nh_inflate.cpp on the host cores)"),
-            "other_gzip_reader": other,
+            "gzip_to_plain": {"value": round(2 * nfr / dt / 1e6, 3), "wall_s": round(dt, 4), "reader": reader_plain,
+                              "outputs_equal_inputs": bool(ok)},
+            "gzip_to_gzip": gz,
+            "input_side_only": {"value": round(2 * st_in.total_sequences / dt_in / 1e6, 3), "wall_s": round(dt_in, 4),
+                                "reader": which_reader(tr_in)},
+            "outputs_equal_inputs": bool(ok and gz.get("outputs_equal_inputs") is True),
+            "readers_by_name": named,
             "setup_seconds": round(t_setup, 1),
         }
+        details = {
+            "workload": "%d pairs of %d bp = 2 gzip FASTQ files of %d members x %d pairs (%d distinct members in rotation; "
+                        "level 6; Illumina-style ids, binned qualities; %.2f GB compressed, %.2f GB of text: %.2f:1), every read "
+                        "kept; configs[2] shape at %.0f %% scale"
+                        % (nfr, L, reps, n, distinct, gz_bytes / 1e9, text_bytes / 1e9, text_bytes / max(gz_bytes, 1), 100.0 * nfr / 50e6),
+            "outputs_check": "xxh3-64 of every member's byte range of both outputs == xxh3-64 of the generated text (%.1f s)" % t_verify,
+            "gzip_to_plain_stages": trace,
+            "input_side_only": "same inputs, keep_human=1 (no read is kept: inflate + parse + H2D + classify + D2H, no output bytes)",
+            "gzip_to_gzip": gz_detail,
+            "reader": "chosen by nh_run (device_reader_pays, nh_run.hip) unless named; 'GPU' = nh_gunzip.hip (block search, decode, window "
+                      "scan, marker resolve, CRC-32 and the record index on the GPU), 'host' = nh_inflate.cpp + nh_fastx.cpp on the host cores",
+        }
+        return nums, details
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+
+
+def e2e_ont_leg(cx, args, eng):
+    """configs[3] end to end, scaled: ONE gzip FASTQ file of ONT-like reads (length lognormal(8.8, 0.85) in [200, 200000],
+    N50 ~ 10 kb) through nh_run, gzip in -> gzip out (the reference's default for a gzip input, main.rs:238-245) and the input
+    side alone; the output is inflated again and compared with the generated text by xxh3-64 per member."""
+    import ctypes
+    import shutil
+    import tempfile
+    np, torch = cx.np, cx.torch
+    from nohuman_amd import _lib
+    from nohuman_amd.dist import usable_cpu_count
+    threads = usable_cpu_count()
+    n_member = int(os.environ.get("NOHUMAN_BENCH_ONT_READS", "100000"))
+    members = int(os.environ.get("NOHUMAN_BENCH_ONT_MEMBERS", "5"))
+    base = "/dev/shm" if os.path.isdir("/dev/shm") and os.access("/dev/shm", os.W_OK) else None
+    tmp = tempfile.mkdtemp(prefix="nh_bench_ont_", dir=base)
+    try:
+        t0 = time.time()
+        dev = cx.dev
+        g = torch.Generator(device=dev)
+        g.manual_seed(4)
+        lens = torch.exp(torch.randn(n_member, generator=g, device=dev, dtype=torch.float64) * 0.85 + 8.8).clamp(200, 200000).to(torch.int64)
+        total = int(lens.sum().item())
+        acgt = torch.tensor([65, 67, 71, 84], dtype=torch.uint8, device=dev)
+        seq = acgt[torch.randint(0, 4, (total,), generator=g, device=dev)].cpu().numpy()
+        lens_h = lens.cpu().numpy()
+        srt = np.sort(lens_h)[::-1]
+        n50 = int(srt[np.searchsorted(np.cumsum(srt), total / 2)])
+        plain = os.path.join(tmp, "ont.fq")
+        with open(plain, "wb") as fo:
+            off = 0
+            rows = []
+            for i in range(n_member):
+                ln = int(lens_h[i])
+                rows.append(b"@ont.%d runid=nh ch=%d\n" % (i, i % 512))
+                rows.append(seq[off:off + ln].tobytes())
+                rows.append(b"\n+\n" + b"5" * ln + b"\n")
+                off += ln
+                if len(rows) >= 3000:
+                    fo.write(b"".join(rows))
+                    rows = []
+            fo.write(b"".join(rows))
+        del seq
+        text_len = os.path.getsize(plain)
+        member_hash = _hash_file_ranges(plain, [(0, text_len)])[0]
+        if _lib.lib().nh_compress_file(os.fsencode(plain), os.fsencode(plain + ".gz"), 2, threads) != 0:
+            raise RuntimeError("nh_compress_file failed")
+        os.remove(plain)
+        fin = os.path.join(tmp, "ont_all.fq.gz")
+        with open(fin, "wb") as out:
+            for _ in range(members):
+                with open(plain + ".gz", "rb") as src:
+                    shutil.copyfileobj(src, out, 16 << 20)
+        os.remove(plain + ".gz")
+        t_setup = time.time() - t0
+        gout = os.path.join(tmp, "o.fq.gz")
+        best = None
+        for _ in range(2):
+            if os.path.exists(gout):
+                os.remove(gout)
+            t = time.perf_counter()
+            st = eng.run(fin, gout, threads=threads, out_codec=2, codec_threads=max(1, threads // 2))
+            dt = time.perf_counter() - t
+            if best is None or dt < best[0]:
+                best = (dt, st.total_sequences, st.classified, st.total_bases)
+        dt, nfr, ncl, nb = best
+        back = os.path.join(tmp, "back.fq")
+        st3 = (ctypes.c_uint64 * 3)()
+        rc = _lib.lib().nh_gunzip_file(os.fsencode(gout), os.fsencode(back), threads, 0, st3)
+        same = rc == 0 and os.path.getsize(back) == text_len * members and \
+            _hash_file_ranges(back, [(k * text_len, text_len) for k in range(members)]) == [member_hash] * members
+        out_ratio = text_len * members / max(os.path.getsize(gout), 1)
+        os.remove(back)
+        os.remove(gout)
+        t = time.perf_counter()
+        st_in = eng.run(fin, os.path.join(tmp, "h.fq"), threads=threads, keep_human=True)
+        dt_in = time.perf_counter() - t
+        named = {}
+        keep_env = os.environ.get("NOHUMAN_GZ_READER")
+        try:
+            for reader in ("device", "host"):
+                os.environ["NOHUMAN_GZ_READER"] = reader
+                t = time.perf_counter()
+                eng.run(fin, gout, threads=threads, out_codec=2, codec_threads=max(1, threads // 2))
+                named[reader] = round(nfr / (time.perf_counter() - t) / 1e6, 4)
+                os.remove(gout)
+        finally:
+            if keep_env is None:
+                os.environ.pop("NOHUMAN_GZ_READER", None)
+            else:
+                os.environ["NOHUMAN_GZ_READER"] = keep_env
+        nums = {"ont_gzip_to_gzip": {"value": round(nfr / dt / 1e6, 4), "wall_s": round(dt, 4), "Gbases_per_s": round(nb / dt / 1e9, 3),
+                                     "reads": int(nfr), "N50": n50, "outputs_equal_inputs": bool(same and nfr == n_member * members and ncl == 0),
+                                     "output_ratio": round(out_ratio, 3), "readers_by_name": named},
+                "ont_input_side_only": {"value": round(st_in.total_sequences / dt_in / 1e6, 4), "wall_s": round(dt_in, 4)}}
+        details = {"workload": "%d ONT-like reads = ONE gzip FASTQ file of %d members x %d reads (the same member %d times; level 6; %.2f GB "
+                               "compressed, %.2f GB of text), %.2f Gbases, N50 %d; configs[3] shape at %.1f %% scale; every read kept, gzip out; "
+                               "output inflated by nh_gunzip_file, xxh3-64 per member == the generated text"
+                               % (nfr, members, n_member, members, os.path.getsize(fin) / 1e9, text_len * members / 1e9, nb / 1e9, n50, 100.0 * nfr / 10e6),
+                   "setup_seconds": round(t_setup, 1)}
+        return nums, details
     finally:
         shutil.rmtree(tmp, ignore_errors=True)
 

@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define NH_ABI_VERSION 3
+#define NH_ABI_VERSION 4
 
 typedef enum {
     NH_OK = 0,
@@ -82,20 +82,23 @@ typedef struct {
     uint32_t minimum_hit_groups; /* default 2 */
     int32_t linear_probing;      /* default 1 (kraken2 builds with -DLINEAR_PROBING) */
     int32_t reset_per_mate;      /* default 1 (last minimizer/taxon reset for each mate) */
-    /* ABI 3 (was `reserved`, 0): which k-mers next to an ambiguous base count as ambiguous ("A:n" in the hit list,
-     * no look-up) -- the two recollections of kraken2's scanner, switchable until a binary has been diffed
-     * (BASELINE.md section 2):
-     *   NH_AMBIGUITY_LAST_LMER (0)  the bool* flag of MinimizerScanner::NextMinimizer: an ambiguous byte among the
+    /* ABI 4 (ABI 2: `reserved`, 0; ABI 3: 0 / 1): which k-mers next to an ambiguous base count as ambiguous ("A:n" in the
+     * hit list, no look-up) -- the two recollections of kraken2's scanner, switchable until a binary has been diffed
+     * (BASELINE.md section 2).  ZERO MEANS "THE ENGINE'S DEFAULT": a caller that fills the struct
+     * from scratch and leaves the former `reserved` word 0 keeps the pinned default instead of silently selecting a rule:
+     *   NH_AMBIGUITY_ENGINE_DEFAULT (0)  whatever NH_AMBIGUITY_DEFAULT names (nh_options_get reports the rule in force);
+     *   NH_AMBIGUITY_LAST_LMER (1)  the bool* flag of MinimizerScanner::NextMinimizer: an ambiguous byte among the
      *                               k-mer's last l bases; an isolated N costs l = 31 k-mers, the next three are
      *                               looked up with windows of 1, 2, 3 l-mers;
-     *   NH_AMBIGUITY_QUEUE (1)      mmscanner.h is_ambiguous() = (queue_pos_ < k_ - l_) || !!last_ambig_, what
+     *   NH_AMBIGUITY_QUEUE (2)      mmscanner.h is_ambiguous() = (queue_pos_ < k_ - l_) || !!last_ambig_, what
      *                               classify.cc / build_db.cc ask: also ambiguous until k - l l-mers have been queued
      *                               behind the base, i.e. an ambiguous byte among the last k - 1 bases; an isolated N
-     *                               costs k - 1 = 34 k-mers.  Default. */
+     *                               costs k - 1 = 34 k-mers.  The default. */
     int32_t ambiguity_rule;
 } nh_options;
-#define NH_AMBIGUITY_LAST_LMER 0
-#define NH_AMBIGUITY_QUEUE 1
+#define NH_AMBIGUITY_ENGINE_DEFAULT 0
+#define NH_AMBIGUITY_LAST_LMER 1
+#define NH_AMBIGUITY_QUEUE 2
 #define NH_AMBIGUITY_DEFAULT NH_AMBIGUITY_QUEUE
 
 /* flags of nh_classify_* */

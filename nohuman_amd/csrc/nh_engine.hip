@@ -160,7 +160,7 @@ static void finish_devdb(Engine *e) {
     d.linear_probing = e->options.linear_probing;
     d.reset_per_mate = e->options.reset_per_mate;
     d.min_hit_groups = e->options.minimum_hit_groups;
-    d.ambig_rule = e->options.ambiguity_rule;
+    d.ambig_rule = e->options.ambiguity_rule == NH_AMBIGUITY_LAST_LMER ? 0 : 1;  // (the kernels' numbering: 0 last l-mer, 1 queue)
     // bound of the probe loop: every round advances by at least one cell
     d.max_chunks = i.capacity + 1 > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)(i.capacity + 1);
 }
@@ -249,10 +249,21 @@ static int common_open(Engine *e, int device) {
     e->options.reset_per_mate = 1;
     e->options.ambiguity_rule = NH_AMBIGUITY_DEFAULT;
     // per-process overrides of the "verify first" switches (parity_vs_kraken2.sh walks their lattice through the CLI)
-    if (const char *v = getenv("NOHUMAN_OPT_AMBIGUITY_RULE")) e->options.ambiguity_rule = atoi(v) != 0;
-    if (const char *v = getenv("NOHUMAN_OPT_LINEAR_PROBING")) e->options.linear_probing = atoi(v) != 0;
-    if (const char *v = getenv("NOHUMAN_OPT_RESET_PER_MATE")) e->options.reset_per_mate = atoi(v) != 0;
-    if (const char *v = getenv("NOHUMAN_OPT_MIN_HIT_GROUPS")) e->options.minimum_hit_groups = (uint32_t)atoi(v);
+    // (NOHUMAN_OPT_AMBIGUITY_RULE: 0 = last l-mer, 1 = queue -- a plain index, as the lattice walker passes it).
+    // They change what every engine of the process classifies: each one applied is said once on stderr.
+    bool overridden = false;
+    if (const char *v = getenv("NOHUMAN_OPT_AMBIGUITY_RULE")) e->options.ambiguity_rule = atoi(v) != 0 ? NH_AMBIGUITY_QUEUE : NH_AMBIGUITY_LAST_LMER, overridden = true;
+    if (const char *v = getenv("NOHUMAN_OPT_LINEAR_PROBING")) e->options.linear_probing = atoi(v) != 0, overridden = true;
+    if (const char *v = getenv("NOHUMAN_OPT_RESET_PER_MATE")) e->options.reset_per_mate = atoi(v) != 0, overridden = true;
+    if (const char *v = getenv("NOHUMAN_OPT_MIN_HIT_GROUPS")) e->options.minimum_hit_groups = (uint32_t)atoi(v), overridden = true;
+    if (overridden) {
+        static std::atomic<bool> said{false};
+        if (!said.exchange(true))
+            fprintf(stderr, "nohuman: WARN NOHUMAN_OPT_* overrides the classification switches of every engine of this process: ambiguity rule %s, "
+                            "linear probing %d, per-mate reset %d, minimum hit groups %u\n",
+                    e->options.ambiguity_rule == NH_AMBIGUITY_QUEUE ? "queue" : "last l-mer", e->options.linear_probing, e->options.reset_per_mate,
+                    e->options.minimum_hit_groups);
+    }
     HIP_TRY(hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking));
     HIP_TRY(dev_malloc((void **)&e->d_counters, (CNT_N + 12) * sizeof(uint64_t)));
     HIP_TRY(hipMemset(e->d_counters, 0, (CNT_N + 12) * sizeof(uint64_t)));
@@ -845,10 +856,11 @@ int nh_options_get(const nh_engine *e, nh_options *o) {
 }
 int nh_options_set(nh_engine *e, const nh_options *o) {
     if (!e || !o) return set_error(NH_EINVAL, "null argument");
-    if (o->ambiguity_rule != NH_AMBIGUITY_LAST_LMER && o->ambiguity_rule != NH_AMBIGUITY_QUEUE)
-        return set_error(NH_EINVAL, "nh_options.ambiguity_rule must be 0 or 1");
+    if (o->ambiguity_rule < NH_AMBIGUITY_ENGINE_DEFAULT || o->ambiguity_rule > NH_AMBIGUITY_QUEUE)
+        return set_error(NH_EINVAL, "nh_options.ambiguity_rule must be 0 (the engine's default), 1 (last l-mer) or 2 (queue)");
     std::lock_guard<std::mutex> lock(((Engine *)e)->db_mu);
     ((Engine *)e)->options = *o;
+    if (o->ambiguity_rule == NH_AMBIGUITY_ENGINE_DEFAULT) ((Engine *)e)->options.ambiguity_rule = NH_AMBIGUITY_DEFAULT;
     return NH_OK;
 }
 int nh_taxon_external(const nh_engine *e_, uint32_t internal, uint64_t *external) {

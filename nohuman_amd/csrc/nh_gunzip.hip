@@ -1315,8 +1315,8 @@ bool cache_on() {
     return on;
 }
 size_t cache_limit(bool host) {
-    static const size_t dev_lim = (size_t)(getenv("NOHUMAN_GZDEV_CACHE_GB") ? atof(getenv("NOHUMAN_GZDEV_CACHE_GB")) : 64.0) << 30;
-    static const size_t host_lim = (size_t)(getenv("NOHUMAN_GZDEV_CACHE_HOST_GB") ? atof(getenv("NOHUMAN_GZDEV_CACHE_HOST_GB")) : 8.0) << 30;
+    static const size_t dev_lim = (size_t)((getenv("NOHUMAN_GZDEV_CACHE_GB") ? atof(getenv("NOHUMAN_GZDEV_CACHE_GB")) : 64.0) * 1073741824.0);
+    static const size_t host_lim = (size_t)((getenv("NOHUMAN_GZDEV_CACHE_HOST_GB") ? atof(getenv("NOHUMAN_GZDEV_CACHE_HOST_GB")) : 8.0) * 1073741824.0);
     return host ? host_lim : dev_lim;
 }
 void cache_release(const CacheEntry &e) {

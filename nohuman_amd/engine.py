@@ -143,7 +143,11 @@ class Engine:
                     ambiguity_rule=None):
         o = self.options()
         if ambiguity_rule is not None:
-            o.ambiguity_rule = int(ambiguity_rule)
+            # the rule as a plain index (0 = last l-mer, 1 = mmscanner.h is_ambiguous()); the C ABI keeps 0 for
+            # "the engine's default" (include/nohuman_engine.h: NH_AMBIGUITY_LAST_LMER 1, NH_AMBIGUITY_QUEUE 2)
+            if int(ambiguity_rule) not in (0, 1):
+                raise EngineError(-1, "ambiguity_rule must be 0 (last l-mer) or 1 (queue)")
+            o.ambiguity_rule = int(ambiguity_rule) + 1
         if minimum_hit_groups is not None:
             o.minimum_hit_groups = int(minimum_hit_groups)
         if linear_probing is not None:
@@ -151,6 +155,10 @@ class Engine:
         if reset_per_mate is not None:
             o.reset_per_mate = int(reset_per_mate)
         _check(self._L.nh_options_set(self._h, C.byref(o)))
+
+    def ambiguity_rule(self) -> int:
+        """The rule in force as a plain index (0 = last l-mer, 1 = queue)"""
+        return int(self.options().ambiguity_rule) - 1
 
     def external_id(self, internal: int) -> int:
         v = C.c_uint64(0)

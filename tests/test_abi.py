@@ -28,7 +28,7 @@ def test_library_exports_every_declared_symbol():
     L = _lib.lib()  # raises if the .so is missing or lacks a symbol
     for name in _declared_symbols():
         assert getattr(L, name) is not None
-    assert L.nh_abi_version() == 3
+    assert L.nh_abi_version() == 4
 
 
 def test_struct_layouts_match_header():

@@ -1,0 +1,98 @@
+"""Pin-day kit: when a `kraken2` binary is on PATH, bench.py's cpu_baseline leg times exactly the argv
+nohuman builds for its subprocess (/root/reference/src/main.rs:210-267) against the engine's own table written as a kraken2
+database directory, and reports kind "kraken2" with the port beside it.  No kraken2 exists on either box: a fake binary
+records what it was called with and answers in kraken2's stderr grammar (/root/reference/src/lib.rs:61-97)."""
+import json
+import os
+import stat
+import struct
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+FAKE = r'''#!/usr/bin/python3
+import json, os, sys, time
+a = sys.argv[1:]
+with open(os.environ["FAKE_K2_LOG"], "a") as f:
+    f.write(json.dumps(a) + "\n")
+paired = "--paired" in a
+out = a[a.index("--unclassified-out") + 1]
+inputs = a[-2:] if paired else a[-1:]
+n = sum(1 for _ in open(inputs[0], "rb")) // 4
+for p in ([out.replace("#", "_1"), out.replace("#", "_2")] if paired else [out]):
+    open(p, "wb").close()
+for f in ("hash.k2d", "opts.k2d", "taxo.k2d"):
+    assert os.path.getsize(os.path.join(a[a.index("--db") + 1], f)) > 0
+time.sleep(0.05)
+sys.stderr.write("Loading database information... done.\n")
+sys.stderr.write("%d sequences (%.2f Mbp) processed in 0.500s (%.1f Kseq/m, %.2f Mbp/m).\n" % (n, n * 300 / 1e6, n / 0.5 * 60 / 1e3, 1.0))
+sys.stderr.write("  0 sequences classified (0.00%%)\n  %d sequences unclassified (100.00%%)\n" % n)
+'''
+
+
+def _fake_kraken2(tmp_path):
+    d = tmp_path / "bin"
+    d.mkdir()
+    exe = d / "kraken2"
+    exe.write_text(FAKE)
+    exe.chmod(exe.stat().st_mode | stat.S_IXUSR | stat.S_IXGRP | stat.S_IXOTH)
+    return str(d), str(exe)
+
+
+def test_the_argv_is_the_references_token_for_token():
+    import bench
+    # src/main.rs:215-224 (threads, db, output, confidence), :231 (--paired), :262 (--unclassified-out), :266 (inputs)
+    assert bench.kraken2_argv(16, "/db", "/t/kraken_out#.fq", ["a_1.fq", "a_2.fq"]) == [
+        "--threads", "16", "--db", "/db", "--output", "/dev/null", "--confidence", "0", "--paired",
+        "--unclassified-out", "/t/kraken_out#.fq", "a_1.fq", "a_2.fq"]
+    assert bench.kraken2_argv(1, "/db", "/t/kraken_out.fq", ["a.fq"], confidence=0.1) == [
+        "--threads", "1", "--db", "/db", "--output", "/dev/null", "--confidence", "0.1", "--unclassified-out", "/t/kraken_out.fq", "a.fq"]
+
+
+def test_the_stock_binary_is_timed_with_that_argv_and_its_summary_parsed(tmp_path, monkeypatch):
+    import bench
+    from oracle import minidb
+    from tests import synth
+    bindir, exe = _fake_kraken2(tmp_path)
+    log = tmp_path / "argv.log"
+    monkeypatch.setenv("FAKE_K2_LOG", str(log))
+    ob, tb, hb, _, _ = synth.toy_db()
+    cap, size, kb, vb = struct.unpack("<4Q", hb[:32])
+    cells = np.frombuffer(hb[32:], dtype=np.uint32)
+    db = tmp_path / "db"
+    bench.write_k2_db(str(db), ob, tb, (cap, size, kb, vb), cells)
+    assert (db / "hash.k2d").read_bytes() == hb and (db / "opts.k2d").read_bytes() == ob and (db / "taxo.k2d").read_bytes() == tb
+    r1, r2 = tmp_path / "r_1.fq", tmp_path / "r_2.fq"
+    for p, t in ((r1, 1), (r2, 2)):
+        p.write_bytes(b"".join(b"@syn.%d/%d\nACGT\n+\nIIII\n" % (i, t) for i in range(37)))
+    res = bench.time_kraken2(exe, 8, str(db), [str(r1), str(r2)], str(tmp_path))
+    assert (res["sequences"], res["classified"], res["unclassified"], res["own_seconds"]) == (37, 0, 37, 0.5)
+    argv = json.loads(log.read_text().splitlines()[0])
+    assert argv == bench.kraken2_argv(8, str(db), str(tmp_path / "kraken_out#.fq"), [str(r1), str(r2)])
+    assert not (tmp_path / "kraken_out_1.fq").exists()  # the outputs of the timed run are removed
+
+
+@pytest.mark.gpu
+def test_bench_reports_kind_kraken2_when_the_binary_is_on_path(tmp_path):
+    bindir, _ = _fake_kraken2(tmp_path)
+    log = tmp_path / "argv.log"
+    env = dict(os.environ, PATH=bindir + os.pathsep + os.environ.get("PATH", ""), FAKE_K2_LOG=str(log),
+               NOHUMAN_BENCH_LOGDIR=str(tmp_path))
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1", "--pairs", "20000",
+                          "--capacity", "4000037", "--no-e2e", "--no-variants", "--cpu-seconds", "1"],
+                         env=env, capture_output=True, text=True, timeout=600, cwd=str(tmp_path))
+    assert out.returncode == 0, out.stderr[-2000:]
+    line = json.loads(out.stdout.strip().splitlines()[-1])
+    cb = line["cpu_baseline"]
+    assert cb["kind"] == "kraken2" and cb["port"]["gpu_equals_oracle"] is True and cb["fragments"] == 20000
+    assert cb["classified_equal_gpu"] is True and cb["one_thread"]["fragments"] == 2000
+    calls = [json.loads(x) for x in log.read_text().splitlines()]
+    assert [c[1] for c in calls] == [str(cb["cores"]), "1"]  # nproc threads, then one
+    for c in calls:
+        assert c[0] == "--threads" and c[2] == "--db" and c[4:9] == ["--output", "/dev/null", "--confidence", "0", "--paired"]
+        assert c[9] == "--unclassified-out" and c[10].endswith("kraken_out#.fq") and len(c) == 13

@@ -47,7 +47,7 @@ def test_toy_db_parity(toy, toy_oracle, toy_engine, paired, confidence):
 @pytest.fixture(params=[1, 0], ids=["ambig_queue", "ambig_last_lmer"])
 def both_rules(request, toy_oracle, toy_engine):
     """nh_options.ambiguity_rule on the shared engine and oracle: 1 = mmscanner.h is_ambiguous() (default), 0 = last l bases"""
-    keep = toy_engine.options().ambiguity_rule
+    keep = toy_engine.ambiguity_rule()
     toy_oracle.set(ambiguity_rule=request.param)
     toy_engine.set_options(ambiguity_rule=request.param)
     yield request.param
@@ -69,7 +69,7 @@ def test_isolated_n_costs_k_minus_1_or_l_kmers(toy, toy_engine, both_rules):
 def test_ambiguity_rule_is_validated(toy_engine):
     with pytest.raises(Exception):
         toy_engine.set_options(ambiguity_rule=2)
-    assert toy_engine.options().ambiguity_rule in (0, 1)
+    assert toy_engine.ambiguity_rule() in (0, 1) and toy_engine.options().ambiguity_rule in (1, 2)
 
 
 def test_edge_cases(toy, toy_oracle, toy_engine, both_rules):
