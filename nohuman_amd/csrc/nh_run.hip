@@ -581,16 +581,20 @@ static void host_read(BlockReader &r, BoundedQueue<std::unique_ptr<HalfBatch>> *
 //     and single-end, and 0.79-0.92 on long reads                                                      -> the GPU
 //   short reads, only classified reads kept / --output wanted (the text is fetched, little is written): 0.33-0.78 -> the GPU
 //   outputs written by the host (plain, bzip2, xz, zstd: every kept byte crosses PCIe and goes through
-//     writev): 0.78-0.98 below 128 MiB a file, 1.09-1.21 above                                         -> the host above
+//     writev): 0.78-0.98 below 128 MiB a file, 1.09-1.21 from there to 1 GiB, 0.88 at 4 GiB             -> the host in between
 //   long reads (batches few and large: nothing flows before the first 512 MiB piece is through) with outputs written by the
 //     host or nothing kept: 1.14-1.26                                                                  -> the host
-static bool device_reader_pays(const char *path, size_t mean_record_bytes, bool host_text_wanted, bool outputs_by_host) {
+static bool device_reader_pays(const char *path, size_t mean_record_bytes, bool host_text_wanted, bool bulk_by_host) {
     struct stat st;
     if (stat(path, &st) != 0 || !S_ISREG(st.st_mode)) return false;
     if (const char *e = getenv("NOHUMAN_GZDEV_MIN_BYTES")) return (uint64_t)st.st_size >= (uint64_t)atoll(e);  // tuning / test knob
     if (!host_text_wanted) return true;
     if (mean_record_bytes > 4096) return false;
-    return !(outputs_by_host && (uint64_t)st.st_size >= ((uint64_t)128u << 20));
+    // bulk_by_host: most of the input is expected to leave through the host (the default mode keeps the non-human reads; a
+    // --keep-human-reads run keeps few).  Between 128 MiB and 2 GiB a file -- one to four pieces, little to pipeline -- the
+    // host reader is the faster one then; above, the GPU reader's pieces overlap the writes (50 M pairs: 25.5 against 22.3)
+    const uint64_t sz = (uint64_t)st.st_size;
+    return !(bulk_by_host && sz >= ((uint64_t)128u << 20) && sz < ((uint64_t)2u << 30));
 }
 
 static void reader_main(const char *path, BoundedQueue<std::unique_ptr<HalfBatch>> *out, RunState *rs,
@@ -909,8 +913,8 @@ int run_engines(const std::vector<Engine *> &engines, const nh_run_args *a, nh_s
         const char *how = getenv("NOHUMAN_GZ_READER");
         const bool off = how && (!strcmp(how, "host") || !strcmp(how, "device-text"));
         const bool named = how && !strcmp(how, "device");
-        const bool by_host = !(a->out_codec == NH_CODEC_GZIP && o1.enc && o1.enc->takes_device_spans() &&
-                               (!rs.paired || (o2.enc && o2.enc->takes_device_spans())));
+        const bool by_host = a->keep_human == 0 && !(a->out_codec == NH_CODEC_GZIP && o1.enc && o1.enc->takes_device_spans() &&
+                                                     (!rs.paired || (o2.enc && o2.enc->takes_device_spans())));
         dev_reader1 = !off && dev_gunzip_wants(a->in1) && (named || device_reader_pays(a->in1, mean_rec, host_text_wanted, by_host));
         dev_reader2 = rs.paired && !off && dev_gunzip_wants(a->in2) && (named || device_reader_pays(a->in2, mean_rec, host_text_wanted, by_host));
         if (rs.paired && !named && dev_reader1 != dev_reader2 && dev_gunzip_wants(a->in1) && dev_gunzip_wants(a->in2)) dev_reader1 = dev_reader2 = false;

@@ -55,7 +55,7 @@ try:
 except Exception as e:
     out.append("# (bench line of the trace pass not available: %s)" % e)
 out.append("# profiles/%s_%s_summary.txt -- rocprofv3 summaries of bench.py on 1 x MI355X, workload '%s'" % (rnd, wl, wl))
-out.append("# command: bash scripts/profile.sh %s %s   (trace pass: bench.py with its reported step count + %d warm-up launches;" % (rnd, wl, WARMUP))
+out.append("# command: bash scripts/profile.sh %s %s   (trace pass: bench.py with its reported step count behind the wake launches and %d warm-up launches;" % (rnd, wl, WARMUP))
 out.append("#          PMC passes: the same with --steps 5 --warmup 2, one rocprofv3 run per counter group)")
 out.append("# source: git HEAD %s, sha256(nh_kernels.hip + nh_device.h)[:16] = %s" % (GIT_HEAD, KERNEL_HASH))
 if bj:
@@ -63,7 +63,7 @@ if bj:
         bj['value'], bj['unit'], bj['ms_per_step'], bj['roofline']['kernel_ms'], bj['roofline']['frac']))
     out.append("# workload: " + bj['config']['workload'])
 out.append("")
-out.append("== rocprofv3 --kernel-trace --stats (trace_kernel_stats.csv), our kernels (ALL dispatches incl. %d warm-ups)" % WARMUP)
+out.append("== rocprofv3 --kernel-trace --stats (trace_kernel_stats.csv), our kernels (ALL dispatches: wake launches, %d warm-ups, the timed steps, the two-stream repetition)" % WARMUP)
 for row in csv.reader(open(os.path.join(src, 'trace/trace_kernel_stats.csv'))):
     if row and (row[0] == 'Name' or 'nh::' in row[0]):
         out.append("  " + ", ".join(c[:70] for c in row))
@@ -75,12 +75,15 @@ for f in glob.glob(os.path.join(src, 'trace/*kernel_trace.csv')):
     d = [(int(r['End_Timestamp']) - int(r['Start_Timestamp'])) for r in rows]
     if GENERIC and d:
         d = [x for x in d if x > 0.2 * max(d)]
-    durs = d[WARMUP:]
+    # the trace holds: bench.py's untimed wake launches (roofline.wake_launches), the warm-up steps, the K timed steps, then the
+    # two-stream repetition (2 + K launches): the timed region is what counts
+    wake = int(bj['roofline'].get('wake_launches', 0)) if bj else 0
+    durs = d[wake + WARMUP:wake + WARMUP + int(bj['steps'])] if bj else d[WARMUP:]
 steady = None
 if durs:
     steady = sum(durs) / len(durs)
     out.append("")
-    out.append("== %s, the %d dispatches of the timed region (warm-ups dropped): mean %.1f us, min %.1f, max %.1f" % (
+    out.append("== %s, the %d dispatches of the timed region (wake launches and warm-ups dropped): mean %.1f us, min %.1f, max %.1f" % (
         KERNEL.rstrip('<'), len(durs), steady / 1e3, min(durs) / 1e3, max(durs) / 1e3))
     if bj:
         ab = bj['roofline']['algorithmic_bytes_per_launch']

@@ -27,7 +27,7 @@ for W in $WORKLOADS; do
   OUT=$REPO/gpurun_out/prof_${TAG}_$W
   mkdir -p "$OUT"
   COMMON="--no-cpu-baseline --no-e2e --no-variants $WARGS"
-  BENCH="python3 $REPO/bench.py --steps 5 --warmup 2 $COMMON"
+  BENCH="python3 $REPO/bench.py --steps 5 --warmup 2 --wake-ms 0 $COMMON"
   cd /tmp
   # the trace pass runs the step count bench.py reports on (3 warm-up launches), so that the
   # average duration of the classify kernel is the steady-state one

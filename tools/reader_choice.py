@@ -76,14 +76,21 @@ try:
         print("%-44s device %.3f s   host %.3f s   device/host %.2f   (%d fragments)" % (label, d, h, d / h, n), flush=True)
 
     outs = (("gzip out", dict(out_codec=2, codec_threads=8)), ("plain out", dict()), ("nothing kept", dict(keep_human=True)))
-    for k in (1, 2, 4, 8, 14, 20):
+    big = len(sys.argv) > 3 and sys.argv[3] == "big"  # the larger files, outputs written by the host only
+    for k in ((30, 40, 60, 80) if big else (1, 2, 4, 8, 14, 20)):
         p1, p2 = os.path.join(tmp, "r_1.fq.gz"), os.path.join(tmp, "r_2.fq.gz")
-        open(p1, "wb").write(g1 * k)
-        open(p2, "wb").write(g2 * k)
-        for what, kw in outs:
+        with open(p1, "wb") as fo:
+            for _ in range(k):
+                fo.write(g1)
+        with open(p2, "wb") as fo:
+            for _ in range(k):
+                fo.write(g2)
+        for what, kw in (outs[1:2] if big else outs):
             bench("PE %4.0f MB a file, %s" % (len(g1) * k / 1e6, what), p1, p2, kw)
-        for what, kw in outs[:1] + outs[2:]:
+        for what, kw in (outs[1:2] if big else outs[:1] + outs[2:]):
             bench("SE %4.0f MB, %s" % (len(g1) * k / 1e6, what), p1, None, kw)
+    if big:
+        raise SystemExit(0)
     for n in (100_000, 300_000):
         p = ont(n)
         for what, kw in outs:

@@ -53,7 +53,7 @@ def run(w, env):
     def step(i):
         w["eng"].classify_device(w["pool"][i % 2].data_ptr(), w["offs"].data_ptr(), w["n"], w["paired"], 0.0,
                                  w["res"].data_ptr(), w["cnt"].data_ptr(), st, long_reads=w["ont"])
-    for i in range(2): step(i)
+    for i in range(5): step(i)
     torch.cuda.synchronize()
     e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
     e0.record()
@@ -66,11 +66,14 @@ settings = {
            ("12,4,150,150", {"NOHUMAN_SCHED": "12,4,150,150"}), ("12,2,100,100", {"NOHUMAN_SCHED": "12,2,100,100"}),
            ("12,6,100,100", {"NOHUMAN_SCHED": "12,6,100,100"}), ("8,4,100,100", {"NOHUMAN_SCHED": "8,4,100,100"}),
            ("16,8,100,100", {"NOHUMAN_SCHED": "16,8,100,100"})],
-    "se": [("flat (default)", {}), ("guided", {"NOHUMAN_SCHED": "guided"}), ("16,8,50,50", {"NOHUMAN_SCHED": "16,8,50,50"}),
-           ("16,8,150,150", {"NOHUMAN_SCHED": "16,8,150,150"}), ("16,4,100,100", {"NOHUMAN_SCHED": "16,4,100,100"}),
-           ("16,12,100,100", {"NOHUMAN_SCHED": "16,12,100,100"}), ("24,12,100,100", {"NOHUMAN_SCHED": "24,12,100,100"}),
-           ("24,8,100,100", {"NOHUMAN_SCHED": "24,8,100,100"}), ("16,8,100,200", {"NOHUMAN_SCHED": "16,8,100,200"})],
-    "hit": [("flat (default)", {}), ("guided", {"NOHUMAN_SCHED": "guided"})],
+    "se": [("default 28,12,100,100", {}), ("off (flat)", {"NOHUMAN_SCHED": "off"}), ("28,12,50,50", {"NOHUMAN_SCHED": "28,12,50,50"}),
+           ("28,12,150,150", {"NOHUMAN_SCHED": "28,12,150,150"}), ("28,12,200,200", {"NOHUMAN_SCHED": "28,12,200,200"}),
+           ("28,12,100,200", {"NOHUMAN_SCHED": "28,12,100,200"}), ("28,12,200,100", {"NOHUMAN_SCHED": "28,12,200,100"}),
+           ("28,4,100,100", {"NOHUMAN_SCHED": "28,4,100,100"}), ("28,8,100,100", {"NOHUMAN_SCHED": "28,8,100,100"}),
+           ("28,20,100,100", {"NOHUMAN_SCHED": "28,20,100,100"}), ("16,8,100,100", {"NOHUMAN_SCHED": "16,8,100,100"}),
+           ("40,12,100,100", {"NOHUMAN_SCHED": "40,12,100,100"}), ("20,4,150,150", {"NOHUMAN_SCHED": "20,4,150,150"})],
+    "hit": [("default 12,6,100,100", {}), ("off (flat)", {"NOHUMAN_SCHED": "off"}), ("12,6,50,50", {"NOHUMAN_SCHED": "12,6,50,50"}),
+            ("12,6,200,200", {"NOHUMAN_SCHED": "12,6,200,200"}), ("12,2,100,100", {"NOHUMAN_SCHED": "12,2,100,100"}), ("8,4,150,150", {"NOHUMAN_SCHED": "8,4,150,150"})],
     "ont": [("default", {})],
     "sechunk": [("32", {}), ("40", {"NOHUMAN_FRAG_CHUNK": "40"}), ("48", {"NOHUMAN_FRAG_CHUNK": "48"}), ("56", {"NOHUMAN_FRAG_CHUNK": "56"}),
                 ("60", {"NOHUMAN_FRAG_CHUNK": "60"}), ("28", {"NOHUMAN_FRAG_CHUNK": "28"}), ("24", {"NOHUMAN_FRAG_CHUNK": "24"}),
@@ -81,6 +84,11 @@ settings = {
 for shape in shapes:
     w = make(shape)
     reads = w["n"] * w["mates"]
+    # the chip's first ~40 ms under load are a power-management transient (profiles/r05_launch_series.txt): launches are 10-30 %
+    # slower there.  Every sweep starts behind it, and the passes keep the GPU busy back to back.
+    t_wake = time.perf_counter()
+    while time.perf_counter() - t_wake < 0.25:
+        run(w, {})
     rows = {name: [] for name, _ in settings[shape]}
     for p in range(passes):
         for name, env in settings[shape]:
