@@ -115,13 +115,15 @@ int allreduce_counters(const int *ids, int n_dev, uint64_t *rows, std::string &b
     int version = 0;
     (void)r.GetVersion(&version);
     std::vector<ncclComm_t> comms((size_t)n_dev, nullptr);
-    int rc = r.CommInitAll(comms.data(), n_dev, ids);
+    std::vector<int> hip_ids((size_t)n_dev);  // (RCCL takes HIP ordinals; `ids` are this library's logical devices)
+    for (int g = 0; g < n_dev; g++) hip_ids[(size_t)g] = dev_phys(ids[g]);
+    int rc = r.CommInitAll(comms.data(), n_dev, hip_ids.data());
     if (rc != 0) return set_error(NH_EDEVICE, "ncclCommInitAll over %d device(s): %s", n_dev, r.GetErrorString(rc));
     std::vector<uint64_t *> d((size_t)n_dev, nullptr);
     std::vector<hipStream_t> st((size_t)n_dev, nullptr);
     hipError_t he = hipSuccess;
     for (int g = 0; g < n_dev && he == hipSuccess; g++) {
-        he = hipSetDevice(ids[g]);
+        he = dev_set(ids[g]);
         if (he == hipSuccess) he = hipStreamCreateWithFlags(&st[g], hipStreamNonBlocking);
         if (he == hipSuccess) he = dev_malloc((void **)&d[g], 4 * sizeof(uint64_t));
         if (he == hipSuccess && !(d_src && d_src[g]))
@@ -131,7 +133,7 @@ int allreduce_counters(const int *ids, int n_dev, uint64_t *rows, std::string &b
     if (he == hipSuccess) {
         nrc = r.GroupStart();
         for (int g = 0; g < n_dev && nrc == 0; g++) {
-            he = hipSetDevice(ids[g]);
+            he = dev_set(ids[g]);
             if (he != hipSuccess) break;
             const void *send = (d_src && d_src[g]) ? (const void *)d_src[g] : (const void *)d[g];
             nrc = r.AllReduce(send, d[g], 4, kNcclUint64, kNcclSum, comms[g], st[g]);
@@ -140,12 +142,12 @@ int allreduce_counters(const int *ids, int n_dev, uint64_t *rows, std::string &b
         if (nrc == 0) nrc = erc;
     }
     for (int g = 0; g < n_dev && he == hipSuccess && nrc == 0; g++) {
-        he = hipSetDevice(ids[g]);
+        he = dev_set(ids[g]);
         if (he == hipSuccess) he = hipMemcpyAsync(rows + 4 * g, d[g], 4 * sizeof(uint64_t), hipMemcpyDeviceToHost, st[g]);
         if (he == hipSuccess) he = hipStreamSynchronize(st[g]);
     }
     for (int g = 0; g < n_dev; g++) {
-        (void)hipSetDevice(ids[g]);
+        (void)dev_set(ids[g]);
         if (d[g]) (void)hipFree(d[g]);
         if (st[g]) (void)hipStreamDestroy(st[g]);
         if (comms[g]) (void)r.CommDestroy(comms[g]);

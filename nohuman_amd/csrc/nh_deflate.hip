@@ -639,7 +639,7 @@ struct DeflateDev {  // device side of one encoder: buffers for chunks in flight
 
     int init(int dev) {
         device = dev;
-        hipError_t e = hipSetDevice(device);
+        hipError_t e = dev_set(device);
         if (e != hipSuccess) return fail(e, "hipSetDevice");
         if ((e = hipStreamCreateWithFlags(&stream, hipStreamNonBlocking)) != hipSuccess) return fail(e, "stream");
         if ((e = hipStreamCreateWithFlags(&copy_stream, hipStreamNonBlocking)) != hipSuccess) return fail(e, "stream");
@@ -688,7 +688,7 @@ struct DeflateDev {  // device side of one encoder: buffers for chunks in flight
     }
     void destroy() {
         if (device < 0) return;
-        (void)hipSetDevice(device);
+        (void)dev_set(device);
         if (copy_stream) (void)hipStreamSynchronize(copy_stream);
         if (stream) (void)hipStreamSynchronize(stream);
         for (Buf &b : buf) {
@@ -796,12 +796,14 @@ struct DeflateDev {  // device side of one encoder: buffers for chunks in flight
     // queues the compression of buf[i]
     int submit(int i) {
         Buf &b = buf[i];
-        hipError_t e = hipSetDevice(device);
+        hipError_t e = dev_set(device);
         if (e != hipSuccess) return fail(e, "hipSetDevice");
         b.n_regions = (uint32_t)((b.fill + REGION - 1) / REGION);
         const int urc = upload_staged(i);
         if (urc != NH_OK) return urc;
         if ((e = hipEventRecord(b.filled, copy_stream)) != hipSuccess) return fail(e, "event");
+        dev_check(device, "gzip encoder, a chunk's kernels");
+        dev_check_ptr(b.d_in, device, "gzip encoder (input chunk)");
         if ((e = hipStreamWaitEvent(stream, b.filled, 0)) != hipSuccess) return fail(e, "wait");
         if (chunks == 0) {
             const int prc = pilot(b);
@@ -845,7 +847,7 @@ struct DeflateDev {  // device side of one encoder: buffers for chunks in flight
     // waits for buf[i] and brings its stream to h_out; *len = its bytes
     int collect(int i, size_t *len, uint32_t *crc) {
         Buf &b = buf[i];
-        hipError_t e = hipSetDevice(device);
+        hipError_t e = dev_set(device);
         if (e != hipSuccess) return fail(e, "hipSetDevice");
         if ((e = hipEventSynchronize(b.done)) != hipSuccess) return fail(e, "kernel");
         float ms = 0;
@@ -932,6 +934,7 @@ public:
     }
     void map_device(const void *host, size_t len, const void *dev, int device, bool host_valid) override {
         map_host_ = (const uint8_t *)host;
+        dev_check_ptr(dev, device, "gzip encoder, a batch's text in HBM");
         map_len_ = device == dev_.device ? len : 0;
         map_dev_ = (const uint8_t *)dev;
         map_host_valid_ = host_valid;
@@ -941,7 +944,7 @@ public:
     bool takes_device_spans() const override { return true; }
     int settle() override {
         const uint64_t t0 = now_ns();
-        if (rc_ == NH_OK && hipSetDevice(dev_.device) == hipSuccess) rc_ = dev_.settle();
+        if (rc_ == NH_OK && dev_set(dev_.device) == hipSuccess) rc_ = dev_.settle();
         map_len_ = 0;
         t_settle_ += now_ns() - t0;
         return rc_;
@@ -953,7 +956,7 @@ public:
             ~Acc() { t += now_ns() - t0; }
         } acc{t_write_, tw0};
         const uint8_t *c = (const uint8_t *)p;
-        if (n && hipSetDevice(dev_.device) != hipSuccess) rc_ = set_error(NH_EDEVICE, "gzip encoder: hipSetDevice failed");
+        if (n && dev_set(dev_.device) != hipSuccess) rc_ = set_error(NH_EDEVICE, "gzip encoder: hipSetDevice failed");
         while (n && rc_ == NH_OK) {
             DeflateDev::Buf &b = dev_.buf[cur_];
             const size_t room = DeflateDev::CHUNK - b.fill;

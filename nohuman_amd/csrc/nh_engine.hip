@@ -18,22 +18,168 @@
 #include <vector>
 
 #include "nh_device.h"
+#include <map>
+
 #include "nh_internal.h"
 #include "nohuman_engine.h"
 
 namespace nh {
 
+// ---- logical devices (nh_internal.h) ----------------------------------------------------------------------------------
+namespace {
+int fake_devices() {
+    static const int n = getenv("NOHUMAN_FAKE_DEVICES") ? std::max(0, atoi(getenv("NOHUMAN_FAKE_DEVICES"))) : 0;
+    return n;
+}
+thread_local int tl_ldev = -1;
+std::mutex g_dev_mu;
+std::string g_dev_violation;
+struct DevAlloc {
+    size_t bytes;
+    int ldev;
+};
+std::map<uintptr_t, DevAlloc> g_dev_allocs;  // debug mode: device allocations of this library, by start address
+void dev_register(const void *p, size_t bytes, int ldev) {
+    std::lock_guard<std::mutex> lk(g_dev_mu);
+    const uintptr_t a = (uintptr_t)p;
+    // (what overlaps a fresh allocation was freed in the meantime)
+    auto it = g_dev_allocs.lower_bound(a);
+    if (it != g_dev_allocs.begin()) {
+        auto pr = std::prev(it);
+        if (pr->first + pr->second.bytes > a) it = pr;
+    }
+    while (it != g_dev_allocs.end() && it->first < a + bytes) it = g_dev_allocs.erase(it);
+    g_dev_allocs[a] = {bytes, ldev};
+}
+}  // namespace
+bool dev_debug() {
+    static const bool on = getenv("NOHUMAN_DEBUG_DEVICE") && getenv("NOHUMAN_DEBUG_DEVICE")[0] != '0';
+    return on;
+}
+int dev_count() {
+    if (fake_devices() > 0) return fake_devices();
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) {
+        (void)hipGetLastError();
+        return 0;
+    }
+    return n;
+}
+int dev_phys(int ldev) { return fake_devices() > 0 ? 0 : ldev; }
+hipError_t dev_set(int ldev) {
+    if (ldev < 0 || (fake_devices() > 0 && ldev >= fake_devices())) return hipErrorInvalidDevice;
+    const hipError_t e = hipSetDevice(dev_phys(ldev));
+    if (e == hipSuccess) tl_ldev = ldev;
+    return e;
+}
+int dev_current() { return tl_ldev; }
+static void dev_violate(const std::string &m) {
+    std::lock_guard<std::mutex> lk(g_dev_mu);
+    if (g_dev_violation.empty()) {
+        g_dev_violation = m;
+        fprintf(stderr, "nohuman: DEVICE DISCIPLINE: %s\n", m.c_str());
+    }
+}
+std::string dev_violation(bool clear) {
+    std::lock_guard<std::mutex> lk(g_dev_mu);
+    std::string m = g_dev_violation;
+    if (clear) g_dev_violation.clear();
+    return m;
+}
+void dev_check(int owner, const char *where) {
+    if (!dev_debug()) return;
+    int hip_dev = -1;
+    (void)hipGetDevice(&hip_dev);
+    if (tl_ldev != owner || hip_dev != dev_phys(owner))
+        dev_violate(std::string(where) + ": the thread's device is " + std::to_string(tl_ldev) + " (HIP " + std::to_string(hip_dev) +
+                    "), the work belongs to device " + std::to_string(owner));
+}
+void dev_check_ptr(const void *p, int owner, const char *where) {
+    if (!dev_debug() || !p) return;
+    {
+        std::lock_guard<std::mutex> lk(g_dev_mu);
+        const uintptr_t a = (uintptr_t)p;
+        auto it = g_dev_allocs.upper_bound(a);
+        if (it != g_dev_allocs.begin()) {
+            --it;
+            if (a < it->first + it->second.bytes && it->second.ldev != owner) {
+                const int have = it->second.ldev;
+                g_dev_mu.unlock();
+                dev_violate(std::string(where) + ": a buffer of device " + std::to_string(have) + " is used as one of device " + std::to_string(owner));
+                g_dev_mu.lock();
+                return;
+            }
+        }
+    }
+    hipPointerAttribute_t at;
+    if (hipPointerGetAttributes(&at, p) != hipSuccess) {
+        (void)hipGetLastError();
+        return;  // (not known to the runtime: pageable host memory)
+    }
+    if (at.type == hipMemoryTypeDevice && at.device != dev_phys(owner))
+        dev_violate(std::string(where) + ": the buffer lies on HIP device " + std::to_string(at.device) + ", its owner is device " +
+                    std::to_string(owner) + " (HIP " + std::to_string(dev_phys(owner)) + ")");
+}
+hipError_t dev_copy_between(void *dst, int dst_ldev, const void *src, int src_ldev, size_t n, hipStream_t stream) {
+    if (!n) return hipSuccess;
+    dev_check(dst_ldev, "dev_copy_between");
+    dev_check_ptr(dst, dst_ldev, "dev_copy_between (destination)");
+    dev_check_ptr(src, src_ldev, "dev_copy_between (source)");
+    if (dst_ldev == src_ldev) return hipMemcpyAsync(dst, src, n, hipMemcpyDeviceToDevice, stream);
+    static const bool no_peer = getenv("NOHUMAN_NO_PEER") && getenv("NOHUMAN_NO_PEER")[0] != '0';
+    const int pd = dev_phys(dst_ldev), ps = dev_phys(src_ldev);
+    if (no_peer) {
+        // over the host: D2H on the source's device, H2D on the destination's (page-locked staging, one piece at a time)
+        const size_t piece = std::min<size_t>(n, (size_t)64u << 20);
+        void *h = nullptr;
+        hipError_t e = host_malloc(&h, piece);
+        if (e != hipSuccess) return e;
+        e = hipStreamSynchronize(stream);  // (what the stream had queued before this copy comes first)
+        for (size_t off = 0; off < n && e == hipSuccess; off += piece) {
+            const size_t m = std::min(piece, n - off);
+            e = dev_set(src_ldev);
+            if (e == hipSuccess) e = hipMemcpy(h, (const char *)src + off, m, hipMemcpyDeviceToHost);
+            const hipError_t e2 = dev_set(dst_ldev);
+            if (e == hipSuccess) e = e2;
+            if (e == hipSuccess) e = hipMemcpy((char *)dst + off, h, m, hipMemcpyHostToDevice);
+        }
+        (void)dev_set(dst_ldev);
+        (void)hipHostFree(h);
+        return e;
+    }
+    if (pd != ps) {
+        static std::mutex mu;
+        static std::vector<std::pair<int, int>> tried;
+        std::lock_guard<std::mutex> lk(mu);
+        if (std::find(tried.begin(), tried.end(), std::make_pair(pd, ps)) == tried.end()) {
+            tried.push_back({pd, ps});
+            int can = 0;
+            if (hipDeviceCanAccessPeer(&can, pd, ps) == hipSuccess && can) {
+                const hipError_t pe = hipDeviceEnablePeerAccess(ps, 0);  // (the current device is pd: dev_check above)
+                if (pe != hipSuccess && pe != hipErrorPeerAccessAlreadyEnabled)
+                    fprintf(stderr, "nohuman: WARN peer access from GPU %d to GPU %d could not be enabled (%s); copies between them are staged by the runtime\n",
+                            pd, ps, hipGetErrorString(pe));
+            } else if (getenv("NOHUMAN_TRACE")) {
+                fprintf(stderr, "[nohuman trace] no peer access from GPU %d to GPU %d: copies between them are staged by the runtime\n", pd, ps);
+            }
+            (void)hipGetLastError();
+        }
+    }
+    return hipMemcpyPeerAsync(dst, pd, src, ps, n, stream);
+}
+
 static hipError_t alloc_retry(void **p, size_t bytes, bool host, unsigned flags) {
     hipError_t e = host ? hipHostMalloc(p, bytes, flags) : hipMalloc(p, bytes);
-    if (e == hipSuccess) return e;
-    (void)hipGetLastError();
-    int dev = -1;
-    (void)hipGetDevice(&dev);
-    run_cache_trim();
-    dev_cache_trim();  // (frees on every device it holds buffers of)
-    if (dev >= 0) (void)hipSetDevice(dev);
-    e = host ? hipHostMalloc(p, bytes, flags) : hipMalloc(p, bytes);
-    if (e != hipSuccess) (void)hipGetLastError();
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        const int dev = dev_current();
+        run_cache_trim();
+        dev_cache_trim();  // (frees on every device it holds buffers of)
+        if (dev >= 0) (void)dev_set(dev);
+        e = host ? hipHostMalloc(p, bytes, flags) : hipMalloc(p, bytes);
+        if (e != hipSuccess) (void)hipGetLastError();
+    }
+    if (e == hipSuccess && !host && dev_debug()) dev_register(*p, bytes, dev_current());
     return e;
 }
 hipError_t dev_malloc(void **p, size_t bytes) { return alloc_retry(p, bytes, false, 0); }
@@ -72,10 +218,11 @@ static int check_device(int device) {
     if (e != hipSuccess || n <= 0)
         return set_error(NH_EDEVICE, "no HIP device available (%s)",
                          e == hipSuccess ? "count 0" : hipGetErrorString(e));
+    n = dev_count();  // (logical devices: nh_internal.h)
     if (device < 0 || device >= n)
         return set_error(NH_EDEVICE, "device %d out of range (have %d)", device, n);
     hipDeviceProp_t prop;
-    HIP_TRY(hipGetDeviceProperties(&prop, device));
+    HIP_TRY(hipGetDeviceProperties(&prop, dev_phys(device)));
     if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
         return set_error(NH_EDEVICE, "device %d is %s; this library is built for gfx950 only",
                          device, prop.gcnArchName);
@@ -225,7 +372,7 @@ static int alloc_table(Engine *e, uint64_t capacity) {
 // that time, after a device-wide sync, never lazily in the launch path: launches come in on several
 // streams and host threads at once.
 int refresh_table_copies(Engine *e) {
-    HIP_TRY(hipSetDevice(e->device));
+    HIP_TRY(dev_set(e->device));
     HIP_TRY(hipDeviceSynchronize());
     for (uint32_t j = 1; j < e->n_copies; j++)
         HIP_TRY(hipMemcpyAsync(e->d_table + j * e->copy_stride, e->d_table, e->table_cells_alloc * sizeof(uint32_t),
@@ -239,9 +386,9 @@ static int common_open(Engine *e, int device) {
     if (rc) return rc;
     e->device = device;
     e->info.device = device;
-    HIP_TRY(hipSetDevice(device));
+    HIP_TRY(dev_set(device));
     hipDeviceProp_t prop;
-    HIP_TRY(hipGetDeviceProperties(&prop, device));
+    HIP_TRY(hipGetDeviceProperties(&prop, dev_phys(device)));
     e->n_cu = prop.multiProcessorCount;
     e->grid_blocks = e->n_cu * classify_blocks_per_cu();  // every resident wave slot, persistent
     e->options.minimum_hit_groups = 2;
@@ -290,7 +437,7 @@ static int upload_taxonomy(Engine *e) {
 
 void destroy(Engine *e) {
     if (!e) return;
-    if (e->device >= 0) (void)hipSetDevice(e->device);
+    if (e->device >= 0) (void)dev_set(e->device);
     if (e->d_table_raw) (void)hipFree(e->d_table_raw);
     if (e->d_parent) (void)hipFree(e->d_parent);
     if (e->d_counters) (void)hipFree(e->d_counters);
@@ -655,6 +802,9 @@ int classify_device(Engine *e, const void *d_bases, const void *d_seq_off, uint6
                          const void *d_kmer_taxa_off, void *d_counters, hipStream_t stream,
                          const void *d_seq_len, uint64_t bases_end) {
     const unsigned slot = e->launch_seq.fetch_add(1) % LAUNCH_SLOTS;
+    dev_check(e->device, "classify_device");  // (NOHUMAN_DEBUG_DEVICE: the launch belongs to the engine's device, and so do its buffers)
+    dev_check_ptr(d_bases, e->device, "classify_device (sequence text)");
+    dev_check_ptr(d_results, e->device, "classify_device (results)");
     if (!(confidence >= 0.0 && confidence <= 1.0))
         return set_error(NH_EINVAL, "Confidence score must be in the closed interval [0, 1]");
     if ((d_kmer_taxa != nullptr) != (d_kmer_taxa_off != nullptr))
@@ -703,6 +853,7 @@ int classify_device(Engine *e, const void *d_bases, const void *d_seq_off, uint6
 
 int check_error_flag(Engine *e) {
     int flag = 0;
+    dev_check(e->device, "check_error_flag");
     HIP_TRY(hipMemcpy(&flag, e->d_error + LAUNCH_SLOTS, sizeof(int), hipMemcpyDeviceToHost));
     if (flag) {
         HIP_TRY(hipMemset(e->d_error + LAUNCH_SLOTS, 0, sizeof(int)));
@@ -721,7 +872,7 @@ int classify_host(Engine *e, const uint8_t *bases, const uint64_t *seq_offsets, 
     if ((kmer_taxa != nullptr) != (kmer_taxa_offsets != nullptr))
         return set_error(NH_EINVAL, "kmer_taxa and kmer_taxa_offsets go together");
     std::lock_guard<std::mutex> lock(e->mu);
-    HIP_TRY(hipSetDevice(e->device));
+    HIP_TRY(dev_set(e->device));
     const int mates = (flags & NH_FLAG_PAIRED) ? 2 : 1;
     const uint64_t n_seq = n_frag * (uint64_t)mates;
     if (n_frag == 0) return NH_OK;
@@ -793,7 +944,7 @@ int nh_device_count(int *count) {
         *count = 0;
         return set_error(NH_EDEVICE, "hipGetDeviceCount: %s", hipGetErrorString(e));
     }
-    *count = n;
+    *count = n > 0 ? nh::dev_count() : 0;  // (logical devices: NOHUMAN_FAKE_DEVICES on a test box)
     return NH_OK;
 }
 
@@ -874,7 +1025,7 @@ int nh_table_download(const nh_engine *e_, uint32_t *cells, uint64_t n_cells) {
     const Engine *e = (const Engine *)e_;
     if (!e || !cells) return set_error(NH_EINVAL, "null argument");
     if (n_cells != e->info.capacity) return set_error(NH_EINVAL, "n_cells != capacity");
-    HIP_TRY(hipSetDevice(e->device));
+    HIP_TRY(nh::dev_set(e->device));
     HIP_TRY(hipMemcpy(cells, e->d_table, n_cells * 4, hipMemcpyDeviceToHost));
     return NH_OK;
 }
@@ -917,6 +1068,7 @@ int nh_classify_batch_device(nh_engine *e_, const void *d_bases, const void *d_s
                              void *stream) {
     Engine *e = (Engine *)e_;
     if (!e || !d_bases || !d_seq_offsets || !d_results) return set_error(NH_EINVAL, "null argument");
+    HIP_TRY(nh::dev_set(e->device));  // (the launch goes to the engine's device whatever the calling thread had selected)
     return nh::classify_device(e, d_bases, d_seq_offsets, n_frag, flags, confidence, d_results,
                                d_kmer_taxa, d_kmer_taxa_offsets, d_counters, (hipStream_t)stream);
 }
@@ -927,6 +1079,7 @@ int nh_classify_records_device(nh_engine *e_, const void *d_text, uint64_t text_
                                void *d_counters, void *stream) {
     Engine *e = (Engine *)e_;
     if (!e || !d_text || !d_seq_starts || !d_seq_lens || !d_results) return set_error(NH_EINVAL, "null argument");
+    HIP_TRY(nh::dev_set(e->device));
     return nh::classify_device(e, d_text, d_seq_starts, n_frag, flags, confidence, d_results, d_kmer_taxa,
                                d_kmer_taxa_offsets, d_counters, (hipStream_t)stream, d_seq_lens, text_len);
 }
@@ -937,7 +1090,7 @@ int nh_synthetic_add_sequences(nh_engine *e_, const void *d_bases, const void *d
     if (!e || !d_bases || !d_seq_offsets) return set_error(NH_EINVAL, "null argument");
     if (value == 0 || value >= e->info.node_count) return set_error(NH_EINVAL, "value is not a taxon id");
     std::lock_guard<std::mutex> lock(e->mu);
-    HIP_TRY(hipSetDevice(e->device));
+    HIP_TRY(nh::dev_set(e->device));
     finish_devdb_public(e);
     unsigned long long *d_ins = nullptr, ins = 0;
     HIP_TRY(nh::dev_malloc((void **)&d_ins, 8));
@@ -966,7 +1119,7 @@ int nh_stats_get(nh_engine *e_, nh_stats *s) {
     Engine *e = (Engine *)e_;
     if (!e || !s) return set_error(NH_EINVAL, "null argument");
     std::lock_guard<std::mutex> lock(e->mu);
-    HIP_TRY(hipSetDevice(e->device));
+    HIP_TRY(nh::dev_set(e->device));
     uint64_t c[nh::CNT_N];
     HIP_TRY(hipMemcpy(c, e->d_counters, sizeof c, hipMemcpyDeviceToHost));
     s->total_sequences = c[nh::CNT_FRAGMENTS];
@@ -981,7 +1134,7 @@ int nh_stats_reset(nh_engine *e_) {
     Engine *e = (Engine *)e_;
     if (!e) return set_error(NH_EINVAL, "null argument");
     std::lock_guard<std::mutex> lock(e->mu);
-    HIP_TRY(hipSetDevice(e->device));
+    HIP_TRY(nh::dev_set(e->device));
     HIP_TRY(hipMemset(e->d_counters, 0, (nh::CNT_N + 12) * sizeof(uint64_t)));
     HIP_TRY(hipDeviceSynchronize());  // (launches run on non-blocking streams, which a legacy-stream memset does not order)
     e->seconds = 0;

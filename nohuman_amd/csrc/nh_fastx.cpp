@@ -213,7 +213,9 @@ private:
     unsigned streams_ = 0;  // complete streams decoded so far
 };
 
-hipError_t dev_malloc(void **p, size_t bytes);  // nh_internal.h (nh_engine.hip): what the process keeps between runs goes before an allocation fails
+// nh_internal.h (nh_engine.hip): allocations give back what the process keeps between runs before they fail; devices are logical
+hipError_t dev_malloc(void **p, size_t bytes);
+hipError_t dev_set(int ldev);
 
 // gzip decoded on a GPU: DevGunzip (nh_gunzip.hip) leaves a piece of text in device memory, read() fetches it from
 // there into the caller's buffer (the page-locked text buffer of a batch: one copy over PCIe, no inflate on the host).
@@ -228,7 +230,7 @@ public:
         cv_.notify_all();
         if (th_.joinable()) th_.join();
         gz_.close();
-        if (device_ >= 0) (void)hipSetDevice(device_);
+        if (device_ >= 0) (void)dev_set(device_);
         for (Buf &b : buf_)
             if (b.d) (void)hipFree(b.d);
         if (stream_) (void)hipStreamDestroy(stream_);
@@ -236,7 +238,7 @@ public:
     }
     int open(const char *path, int device, std::string &err) {
         device_ = device;
-        if (hipSetDevice(device) != hipSuccess) {
+        if (dev_set(device) != hipSuccess) {
             err = "hipSetDevice failed";
             return -1;
         }
@@ -270,7 +272,7 @@ public:
         return 0;
     }
     long read(uint8_t *buf, size_t cap, std::string &err) {
-        if (hipSetDevice(device_) != hipSuccess) {
+        if (dev_set(device_) != hipSuccess) {
             err = "hipSetDevice failed";
             return -1;
         }

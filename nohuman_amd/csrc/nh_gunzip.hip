@@ -1322,7 +1322,7 @@ size_t cache_limit(bool host) {
 void cache_release(const CacheEntry &e) {
     if (e.host) (void)hipHostFree(e.p);
     else {
-        (void)hipSetDevice(e.device);
+        (void)dev_set(e.device);
         (void)hipFree(e.p);
     }
 }
@@ -1341,6 +1341,7 @@ static size_t cache_bytes(int device, bool host) {
     return sum;
 }
 static void *cache_alloc(int device, size_t bytes, bool host) {
+    if (!host) dev_check(device, "gzip reader, buffer allocation");
     if (cache_on() && bytes >= ((size_t)16u << 20)) {
         std::lock_guard<std::mutex> lk(g_cache_mu);
         for (size_t i = 0; i < g_cache.size(); i++) {
@@ -1356,7 +1357,6 @@ static void *cache_alloc(int device, size_t bytes, bool host) {
     // (on failure: everything the process keeps between runs goes first, then one more try)
     const hipError_t e = host ? host_malloc(&p, bytes) : dev_malloc(&p, bytes);
     if (e != hipSuccess) return nullptr;
-    (void)hipSetDevice(device);
     return p;
 }
 static void cache_free(int device, size_t bytes, void *p, bool host) {
@@ -1388,7 +1388,7 @@ static void cache_free(int device, size_t bytes, void *p, bool host) {
         int dev = -1;
         (void)hipGetDevice(&dev);
         for (const CacheEntry &e : out) cache_release(e);
-        if (!out.empty() && dev >= 0) (void)hipSetDevice(dev);
+        if (!out.empty() && dev >= 0) (void)dev_set(dev);
         return;
     }
     if (host) (void)hipHostFree(p);
@@ -1501,7 +1501,7 @@ public:
         if (look_ > size_) look_ = (size_ + 4095) & ~(size_t)4095;
         slot_syms_ = (uint32_t)(16 * stretch_ + 65536);  // symbols a stretch's slot holds: text up to 16 : 1
         trace_ = getenv("NOHUMAN_TRACE") != nullptr;
-        if (hipSetDevice(s_->device_) != hipSuccess) {
+        if (dev_set(s_->device_) != hipSuccess) {
             err = "hipSetDevice failed";
             close();
             return -1;
@@ -1532,7 +1532,7 @@ public:
 
     // the buffers of one device (sizes as open() settled them), its events, the kernels' LDS limits there
     bool alloc_set(DevSet &d) {
-        if (hipSetDevice(d.device_) != hipSuccess) return false;
+        if (dev_set(d.device_) != hipSuccess) return false;
         d.d_in_ = (uint8_t *)cache_alloc(d.device_, in_bytes_, false);
         d.h_in_ = (uint8_t *)cache_alloc(d.device_, in_bytes_, true);
         d.d_sym_ = (uint16_t *)cache_alloc(d.device_, sym_bytes_, false);
@@ -1558,7 +1558,7 @@ public:
         return ok;
     }
     void free_set(DevSet &d) {
-        if (d.device_ >= 0) (void)hipSetDevice(d.device_);
+        if (d.device_ >= 0) (void)dev_set(d.device_);
         cache_free(d.device_, in_bytes_, d.d_in_, false);
         cache_free(d.device_, in_bytes_, d.h_in_, true);
         cache_free(d.device_, sym_bytes_, d.d_sym_, false);
@@ -1595,10 +1595,8 @@ public:
     bool select_set(int k, hipStream_t stream) {
         DevSet *to = sets_[(size_t)k].get();
         if (to == s_) return true;
-        if (hipSetDevice(to->device_) != hipSuccess) return false;
-        const hipError_t e = to->device_ == s_->device_
-                                 ? hipMemcpyAsync(to->d_win_[to->win_], s_->d_win_[s_->win_], WSIZE, hipMemcpyDeviceToDevice, stream)
-                                 : hipMemcpyPeerAsync(to->d_win_[to->win_], to->device_, s_->d_win_[s_->win_], s_->device_, WSIZE, stream);
+        if (dev_set(to->device_) != hipSuccess) return false;
+        const hipError_t e = dev_copy_between(to->d_win_[to->win_], to->device_, s_->d_win_[s_->win_], s_->device_, WSIZE, stream);
         if (e != hipSuccess || hipStreamSynchronize(stream) != hipSuccess) return false;
         s_ = to;
         return true;
@@ -1761,6 +1759,8 @@ private:
         if (e_ != hipSuccess) return bad(std::string(#x) + ": " + hipGetErrorString(e_)); \
     } while (0)
         j.valid = false;
+        dev_check(d.device_, "gzip reader, phase A of a piece");
+        dev_check_ptr(d.d_in_, d.device_, "gzip reader, phase A (input buffer)");
         const size_t want = (size_t)j.n * stretch_ + look_;
         const size_t avail = (size_t)std::min<uint64_t>(want, size_ - j.a_byte);
         j.at_eof = j.a_byte + avail == size_;
@@ -1860,6 +1860,9 @@ private:
         const SegResult &r = j.r;
         const uint32_t n_str = j.n_str;
         const uint64_t a_byte = j.a_byte;
+        dev_check(d.device_, "gzip reader, phase B of a piece");
+        dev_check_ptr(d_dst, d.device_, "gzip reader, phase B (text buffer)");
+        dev_check_ptr(d.d_sym_, d.device_, "gzip reader, phase B (symbols)");
         // windows by the prefix scan, text, CRCs, the window behind the piece
         if (trace_) (void)hipEventRecord(d.ev_[3], stream);
         const uint32_t gy = 4;
@@ -1939,7 +1942,7 @@ private:
     // at (limit_byte: but no further than the first block boundary at or behind that byte of the file -- a boundary of the
     // piece grid, see DevFastqReader over several devices)
     long piece(uint8_t *d_dst, size_t room, hipStream_t stream, uint64_t limit_byte = 0) {
-        if (hipSetDevice(s_->device_) != hipSuccess) return fail("hipSetDevice failed");
+        if (dev_set(s_->device_) != hipSuccess) return fail("hipSetDevice failed");
         const uint64_t a_byte = (pos_bit_ >> 3) / ALIGN * ALIGN;  // the piece's buffer starts here in the file
         const uint64_t first_bit = pos_bit_ - 8 * a_byte;
         if (a_byte >= size_) return fail("unexpected end of file");
@@ -2014,7 +2017,7 @@ private:
         DevSet &d = *sets_[(size_t)k];
         d.spec = PieceJob();
         d.spec_cell = cell;
-        if (hipSetDevice(d.device_) != hipSuccess) return;
+        if (dev_set(d.device_) != hipSuccess) return;
         d.spec.a_byte = grid0_ + cell * cell_bytes();
         if (d.spec.a_byte >= size_) return;
         d.spec.first_bit = NONE;
@@ -2066,6 +2069,7 @@ private:
             warned_ = true;
         }
         std::vector<uint8_t> window(WSIZE);
+        dev_check(s_->device_, "gzip reader, a piece by the host decoder");
         GZ_TRY(hipMemcpyAsync(window.data(), s_->d_win_[s_->win_], WSIZE, hipMemcpyDeviceToHost, stream));
         GZ_TRY(hipStreamSynchronize(stream));
         // to the first block boundary behind a megabyte of input (in host mode: sixteen), or with half the room full
@@ -2191,7 +2195,7 @@ extern "C" int nh_gunzip_device_file(const char *in, const char *out, int32_t de
     if (const char *e = getenv("NOHUMAN_GZDEV_ROOM")) room = std::max<size_t>((size_t)atoll(e), (size_t)1u << 20);  // tool knob: text per piece
     uint8_t *d_text = nullptr;
     hipStream_t stream = nullptr;
-    if (hipSetDevice(device) != hipSuccess || nh::dev_malloc((void **)&d_text, room + 64) != hipSuccess ||
+    if (nh::dev_set(device) != hipSuccess || nh::dev_malloc((void **)&d_text, room + 64) != hipSuccess ||
         hipStreamCreateWithFlags(&stream, hipStreamNonBlocking) != hipSuccess) {
         if (d_text) (void)hipFree(d_text);
         return nh::set_error(NH_EOOM, "cannot allocate the text buffer on device %d", device);
@@ -2382,7 +2386,7 @@ public:
         // the device it was decoded on.
         lanes_.resize((size_t)n_devices);
         for (int g = 0; g < n_devices; g++) lanes_[(size_t)g].device = devices[g];
-        if (hipSetDevice(devices[0]) != hipSuccess) {
+        if (nh::dev_set(devices[0]) != hipSuccess) {
             err = "hipSetDevice failed";
             return -1;
         }
@@ -2407,7 +2411,7 @@ public:
         for (;;) {
             bool ok = true;
             for (Piece &b : buf_) {
-                (void)hipSetDevice(lanes_[(size_t)b.lane].device);
+                (void)nh::dev_set(lanes_[(size_t)b.lane].device);
                 b.d_text = (uint8_t *)cache_alloc(lanes_[(size_t)b.lane].device, room_ + 4096, false);
                 ok = ok && b.d_text;
             }
@@ -2424,7 +2428,7 @@ public:
         }
         const double t_c = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_open).count();
         for (Lane &l : lanes_) {
-            if (hipSetDevice(l.device) != hipSuccess || hipStreamCreateWithFlags(&l.stream, hipStreamNonBlocking) != hipSuccess ||
+            if (nh::dev_set(l.device) != hipSuccess || hipStreamCreateWithFlags(&l.stream, hipStreamNonBlocking) != hipSuccess ||
                 hipStreamCreateWithFlags(&l.stream_a, hipStreamNonBlocking) != hipSuccess ||
                 hipStreamCreateWithFlags(&l.stream_i, hipStreamNonBlocking) != hipSuccess || dev_malloc((void **)&l.d_bad, 8) != hipSuccess ||
                 host_malloc((void **)&l.h_bad, 8, hipHostMallocDefault) != hipSuccess) {
@@ -2516,7 +2520,7 @@ public:
         gz_.close();
         for (Piece &b : buf_) {
             const int dev = lanes_[(size_t)b.lane].device;
-            (void)hipSetDevice(dev);
+            (void)nh::dev_set(dev);
             cache_free(dev, room_ + 4096, b.d_text, false);
             cache_free(dev, b.nl_cap * 4, b.d_nl, false);
             cache_free(dev, b.tile_cap * 4, b.d_tiles, false);
@@ -2528,7 +2532,7 @@ public:
         buf_.clear();
         order_.clear();
         for (Lane &l : lanes_) {
-            (void)hipSetDevice(l.device);
+            (void)nh::dev_set(l.device);
             if (l.d_bad) (void)hipFree(l.d_bad);
             if (l.h_bad) (void)hipHostFree(l.h_bad);
             if (l.stream) (void)hipStreamDestroy(l.stream);
@@ -2606,7 +2610,7 @@ private:
             Piece &p = buf_[bi];
             if (made++ >= want) break;
             const int dev = lanes_[(size_t)p.lane].device;
-            if (hipSetDevice(dev) != hipSuccess) break;
+            if (nh::dev_set(dev) != hipSuccess) break;
             (void)grow_dev(dev, p.d_tiles, p.tile_cap, tiles);
             (void)grow_dev(dev, p.d_nl, p.nl_cap, lines);
             if (grow_dev(dev, p.d_recs, p.rec_cap, recs)) {
@@ -2795,7 +2799,7 @@ private:
             pp->in_pipe = true;
         }
         Piece &p = *pp;
-        if (hipSetDevice(ln.device) != hipSuccess) return fail("hipSetDevice failed");
+        if (nh::dev_set(ln.device) != hipSuccess) return fail("hipSetDevice failed");
         const long n = ahead_ ? gz_.take((int)g, use_ahead, p.d_text + head_, room_ - head_, ln.stream)
                               : gz_.next_on((int)g, p.d_text + head_, room_ - head_, ln.stream);
         if (ahead_) {
@@ -2845,7 +2849,7 @@ private:
 
     int index_piece(Piece &p) {
         Lane &ln = lanes_[(size_t)p.lane];
-        if (hipSetDevice(ln.device) != hipSuccess) return fail("hipSetDevice failed");
+        if (nh::dev_set(ln.device) != hipSuccess) return fail("hipSetDevice failed");
         size_t carry = 0;
         if (last_ && last_->indexed) {
             // the records behind the last whole batch and the incomplete record behind them (from the lane before: over xGMI)
@@ -2858,8 +2862,7 @@ private:
                             " MiB the reader keeps in front of a piece");
             const int odev = lanes_[(size_t)old.lane].device;
             uint8_t *const dst = p.d_text + head_ - carry;
-            if (carry && ((odev == ln.device ? hipMemcpyAsync(dst, old.text0 + from, carry, hipMemcpyDeviceToDevice, ln.stream_i)
-                                             : hipMemcpyPeerAsync(dst, ln.device, old.text0 + from, odev, carry, ln.stream_i)) != hipSuccess ||
+            if (carry && (dev_copy_between(dst, ln.device, old.text0 + from, odev, carry, ln.stream_i) != hipSuccess ||
                           hipStreamSynchronize(ln.stream_i) != hipSuccess))
                 return fail("D2D of the carried text failed");
             carried_ += carry;
@@ -2899,6 +2902,8 @@ private:
             cv_.wait(lk, [&] { return p.prepared; });
         }
         const int dev = ln.device;
+        dev_check(dev, "record index of a piece");
+        dev_check_ptr(p.text0, dev, "record index (text)");
         const auto t0 = std::chrono::steady_clock::now();
         if (p.last) {  // the input's last line may lack its newline
             uint8_t lastc = 0;

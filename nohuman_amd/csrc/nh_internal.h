@@ -94,6 +94,27 @@ int check_error_flag(Engine *e);
 // staging): emptied when an engine is closed
 void run_cache_trim();
 void dev_cache_trim();
+// ---- devices.  Every device id in this library (nh_open's `device`, nh_run_args.device_ids, Engine::device, a batch's
+// dev_device ...) is a LOGICAL device; dev_set() is the only way a thread selects one.  By default logical == HIP ordinal.
+// NOHUMAN_FAKE_DEVICES=N (test mode for a box with one GPU): N logical devices, all on HIP device 0 -- the run's engines,
+// reader lanes, encoders, streams and buffers then have N distinct owners, copies between them take the peer route, and
+// NOHUMAN_DEBUG_DEVICE=1 checks the discipline a real multi-GPU node enforces by failing: dev_check() that the calling
+// thread's current logical device is the owner's at every launch / copy / allocation site, dev_check_ptr() that a buffer
+// was allocated under its owner (this library's allocations are registered; hipPointerGetAttributes has the last word on
+// the physical device).  The first violation is kept (dev_violation()) and fails the run that meets it.
+int dev_count();                 // logical devices (<= 0: none / HIP error)
+int dev_phys(int ldev);          // HIP ordinal behind a logical device
+hipError_t dev_set(int ldev);    // hipSetDevice(dev_phys(ldev)) and the thread's logical device
+int dev_current();               // the thread's logical device (-1: none selected yet)
+bool dev_debug();
+void dev_check(int owner, const char *where);
+void dev_check_ptr(const void *p, int owner, const char *where);
+std::string dev_violation(bool clear = false);
+// n bytes from device memory of src_ldev to device memory of dst_ldev on `stream` (a stream of dst_ldev, the calling
+// thread's current device): the same logical device: an ordinary device-to-device copy; otherwise hipMemcpyPeerAsync --
+// peer access between the two HIP devices is enabled the first time where hipDeviceCanAccessPeer allows it (without it the
+// runtime stages the copy itself) -- or, under NOHUMAN_NO_PEER=1, through a page-locked host buffer (D2H, H2D; synchronous).
+hipError_t dev_copy_between(void *dst, int dst_ldev, const void *src, int src_ldev, size_t n, hipStream_t stream);
 // Every allocation of the run path goes through these two: when the device (or the page-locked pool) is full, what the
 // process keeps between runs is given back first and the allocation tried once more -- idle buffers never fail a run.
 hipError_t dev_malloc(void **p, size_t bytes);

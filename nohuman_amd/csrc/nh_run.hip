@@ -332,7 +332,7 @@ struct Slot {  // pinned host + device buffers of one in-flight batch
 };
 
 static int slot_reserve(Slot &s, size_t ntext, size_t nfrag, size_t ntaxa) {
-    if (hipSetDevice(s.e->device) != hipSuccess) return set_error(NH_EDEVICE, "hipSetDevice failed");
+    if (dev_set(s.e->device) != hipSuccess) return set_error(NH_EDEVICE, "hipSetDevice failed");
     auto grow = [](size_t need) { return need + need / 4 + 4096; };
     if (!s.h_flag) {
         if (host_malloc((void **)&s.h_flag, 64, hipHostMallocDefault) != hipSuccess) return set_error(NH_EOOM, "cannot allocate batch buffers");
@@ -373,7 +373,7 @@ static int slot_reserve(Slot &s, size_t ntext, size_t nfrag, size_t ntaxa) {
 
 static void slot_free(Slot &s) {
     if (!s.e) return;
-    (void)hipSetDevice(s.e->device);
+    (void)dev_set(s.e->device);
     for (void *p : {(void *)s.h_off, (void *)s.h_len, (void *)s.h_res, (void *)s.h_taxa, (void *)s.h_taxa_off, (void *)s.h_flag})
         if (p) (void)hipHostFree(p);
     for (void *p : {s.d_text, s.d_off, s.d_len, s.d_res, s.d_taxa, s.d_taxa_off})
@@ -856,14 +856,14 @@ int run_engines(const std::vector<Engine *> &engines, const nh_run_args *a, nh_s
     auto free_run_counters = [&] {
         for (int g = 0; g < G; g++)
             if (rs.d_run_counters[g]) {
-                (void)hipSetDevice(engines[g]->device);
+                (void)dev_set(engines[g]->device);
                 (void)hipFree(rs.d_run_counters[g]);
                 rs.d_run_counters[g] = nullptr;
             }
     };
     for (int g = 0; g < G; g++) {
         const size_t nb = (CNT_N + 12) * sizeof(uint64_t);  // (+12: the words of the instrumented kernel variant)
-        if (hipSetDevice(engines[g]->device) != hipSuccess || dev_malloc((void **)&rs.d_run_counters[g], nb) != hipSuccess ||
+        if (dev_set(engines[g]->device) != hipSuccess || dev_malloc((void **)&rs.d_run_counters[g], nb) != hipSuccess ||
             hipMemset(rs.d_run_counters[g], 0, nb) != hipSuccess) {
             free_run_counters();
             return set_error(NH_EDEVICE, "cannot allocate the run's counters on device %d", engines[g]->device);
@@ -878,7 +878,7 @@ int run_engines(const std::vector<Engine *> &engines, const nh_run_args *a, nh_s
     for (int i = 0; i < NS * G; i++) {
         slots[i].e = engines[i / NS];
         slots[i].work_slot = i % NS;
-        if (hipSetDevice(slots[i].e->device) != hipSuccess ||
+        if (dev_set(slots[i].e->device) != hipSuccess ||
             hipStreamCreateWithFlags(&slots[i].stream, hipStreamNonBlocking) != hipSuccess) {
             for (auto &s : slots) slot_free(s);
             free_run_counters();
@@ -993,7 +993,7 @@ int run_engines(const std::vector<Engine *> &engines, const nh_run_args *a, nh_s
             Slot &s = slots[j->b.slot];
             if (j->valid && !rs.failed()) {
                 uint64_t c3 = StageClock::now();
-                (void)hipSetDevice(s.e->device);
+                (void)dev_set(s.e->device);
                 const Batch &b = j->b;
                 const size_t base2w = (b.h1->text.size() + 8 + 255) & ~(size_t)255;
                 // the batch's raw text is still in the slot's device buffer: an encoder on that GPU takes
@@ -1037,7 +1037,7 @@ int run_engines(const std::vector<Engine *> &engines, const nh_run_args *a, nh_s
             Slot &s = slots[b.slot];
             std::unique_ptr<FlushJob> j(new FlushJob());
             if (!rs.failed()) {
-                (void)hipSetDevice(s.e->device);
+                (void)dev_set(s.e->device);
                 hipError_t he = hipStreamSynchronize(s.stream);
                 uint64_t c2 = StageClock::now();
                 clk.ns[ST_WSYNC] += c2 - c1;
@@ -1175,6 +1175,7 @@ int run_engines(const std::vector<Engine *> &engines, const nh_run_args *a, nh_s
                 wq.push(std::move(b));
                 break;
             }
+            dev_check_ptr(s.d_text, s.e->device, "nh_run, a slot's text buffer");
             uint64_t nbases = 0, toff = 0;
             for (size_t i = 0; i < b.n; i++) {
                 const RecRef &r1 = b.h1->recs[i];
@@ -1198,15 +1199,17 @@ int run_engines(const std::vector<Engine *> &engines, const nh_run_args *a, nh_s
             // H2D, classify, D2H: all asynchronous on the slot's stream
             uint64_t m3 = StageClock::now();
             clk.ns[ST_MGATHER] += m3 - m2;
-            hipError_t he = hipSetDevice(s.e->device);
+            hipError_t he = dev_set(s.e->device);
+            {   // test knob of the checker itself: the launch goes out under the run's FIRST device whatever slot carries it
+                static const bool brk = getenv("NOHUMAN_DEBUG_DEVICE_BREAK") != nullptr;
+                if (brk) he = dev_set(engines[0]->device);
+            }
             // the batch's text: from the host as it was read, or -- a batch of the reader on the GPU -- from HBM to HBM (from
             // another device's memory: over xGMI); the bytes then go to the host only if an output written there needs them
             auto stage_text = [&](HalfBatch &hb, size_t at, size_t len) -> hipError_t {
                 if (!len) return hipSuccess;
                 if (!hb.dev_text) return hipMemcpyAsync((char *)s.d_text + at, hb.text.data(), len, hipMemcpyHostToDevice, s.stream);
-                hipError_t e2 = hb.dev_device == s.e->device
-                                    ? hipMemcpyAsync((char *)s.d_text + at, hb.dev_text, len, hipMemcpyDeviceToDevice, s.stream)
-                                    : hipMemcpyPeerAsync((char *)s.d_text + at, s.e->device, hb.dev_text, hb.dev_device, len, s.stream);
+                hipError_t e2 = dev_copy_between((char *)s.d_text + at, s.e->device, hb.dev_text, hb.dev_device, len, s.stream);
                 if (e2 == hipSuccess && host_text_wanted) {
                     hb.text.clear();  // (a batch born on the GPU comes with a token buffer: the real one only where it is needed)
                     if (!hb.text.reserve(len + 64)) return hipErrorOutOfMemory;
@@ -1288,6 +1291,13 @@ int run_engines(const std::vector<Engine *> &engines, const nh_run_args *a, nh_s
         free_run_counters();
         return set_error(rs.err_code, "%s", rs.err_msg.c_str());
     }
+    if (dev_debug()) {  // NOHUMAN_DEBUG_DEVICE: a launch, copy or allocation under the wrong device fails the run that met it
+        const std::string v = dev_violation(true);
+        if (!v.empty()) {
+            free_run_counters();
+            return set_error(NH_EDEVICE, "device discipline: %s", v.c_str());
+        }
+    }
 
     // The run's only exchange step: the counters the classify kernels kept in each
     // device's HBM are summed by ONE all-reduce over RCCL, reduced where they lie.  The sums the writer kept
@@ -1299,7 +1309,7 @@ int run_engines(const std::vector<Engine *> &engines, const nh_run_args *a, nh_s
         uint64_t dsum[4] = {0, 0, 0, 0};
         hipError_t he = hipSuccess;
         for (int g = 0; g < G && he == hipSuccess; g++) {
-            he = hipSetDevice(engines[g]->device);
+            he = dev_set(engines[g]->device);
             if (he == hipSuccess) he = hipMemcpy(&rows[4 * g], rs.d_run_counters[g], 32, hipMemcpyDeviceToHost);
             for (int i = 0; i < 4; i++) dsum[i] += rows[4 * g + i];
             if (he == hipSuccess) {  // the engine's running totals (nh_stats_get) include this run
@@ -1425,6 +1435,7 @@ int nh_run(const nh_run_args *args, nh_stats *stats) {
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
         return nh::set_error(NH_EDEVICE, "no HIP device available");
+    ndev = nh::dev_count();
     std::vector<int> devs;
     if (args->device_ids && args->n_devices > 0)
         devs.assign(args->device_ids, args->device_ids + args->n_devices);

@@ -136,6 +136,36 @@ def test_bench_self_launch_dry_run():
     assert rec["n_gpus"] == 2 and rec["ranks_counted"] == 2 and rec["world_size_seen"] == 2
 
 
+@pytest.mark.parametrize("how", ["self-launch", "torch.distributed.run"])
+def test_bench_eight_ranks_dry_run(tmp_path, how):
+    """configs[4] is 8 GPUs of one node and no such node has been available (SCALE skipped every round): the launch plumbing
+    of `bench.py --gpus 8` at its real width on CPU -- both ways it is started: directly (it spawns its ranks) and the
+    driver's way, `python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 ...`."""
+    import json
+    import socket
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, NOHUMAN_BENCH_DRYRUN="1", NOHUMAN_BENCH_LOGDIR=str(tmp_path), OMP_NUM_THREADS="1")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    if how == "self-launch":
+        cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "8", "--steps", "2", "--warmup", "1"]
+    else:
+        s = socket.socket()
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+        s.close()
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "8", "--master-addr", "127.0.0.1",
+               "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", "8", "--steps", "2", "--warmup", "1"]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout  # rank 0 alone prints
+    rec = json.loads(lines[0])
+    assert rec["n_gpus"] == 8 and rec["ranks_counted"] == 8 and rec["world_size_seen"] == 8
+
+
 def test_bench_launcher_names_a_dead_rank_and_returns_within_seconds(tmp_path):
     """a rank that dies before the rendezvous used to leave rank 0 in init_process_group until torch's
     timeout.  The launcher polls all ranks, names the first non-zero exit, terminates the others and returns."""
