@@ -46,6 +46,8 @@ def lib():
     if _LIB is None:
         so = build() if os.path.exists(os.path.join(_HERE, "k2_oracle.c")) and _have_cc() \
             else os.path.join(_HERE, "libk2oracle.so")
+        # K2ORACLE_LIB: another build of the same source (the sanitizer build of tests/test_sanitizers.py)
+        so = os.environ.get("K2ORACLE_LIB") or so
         L = C.CDLL(so)
         L.k2o_last_error.restype = C.c_char_p
         L.k2o_fmix64.restype = C.c_uint64
