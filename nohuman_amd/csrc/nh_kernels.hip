@@ -1534,7 +1534,6 @@ __global__ __launch_bounds__(WAVE * WAVES_PER_BLOCK, BIG ? 1 : (STD ? NH_MIN_WAV
             const int oi = (int)fc * mates;
             const uint32_t o0 = __builtin_amdgcn_readlane(off_v, oi);
             const uint32_t o1 = __builtin_amdgcn_readlane(off_v, oi + 1);
-            const uint32_t o2 = mates == 2 ? __builtin_amdgcn_readlane(off_v, oi + 2) : o1;  // prefetch only
             const uint32_t n0 = __builtin_amdgcn_readlane(len_v, oi);
             const uint32_t n1 = mates == 2 ? __builtin_amdgcn_readlane(len_v, oi + 1) : 0u;
             const uint32_t nk0 = n0 >= K ? n0 - K + 1 : 0;
@@ -1604,25 +1603,30 @@ __global__ __launch_bounds__(WAVE * WAVES_PER_BLOCK, BIG ? 1 : (STD ? NH_MIN_WAV
                     }
                     tag1 = tag2;
                     w1 = w2;
-                    // the tile to be scanned two scans from now (a full group away, so its load has
-                    // a whole probe phase to arrive): two tiles on in this sequence, else the first
-                    // tile of the sequence after the next one; only guessed inside the chunk
+                    // the tile to be scanned two scans from now (a full group away, so its load has a whole probe phase
+                    // to arrive): the scan order -- tiles of a sequence, then the next mate, then the next fragment of the
+                    // chunk -- stepped twice from here.  (Round 5: the guess used to assume ONE tile per sequence once a
+                    // sequence ended, so reads of two or three tiles -- 2 x 250 bp -- found every second tile's dword not
+                    // loaded and fetched it synchronously.)  Lengths of the sequences ahead come from the lanes of len_v; a
+                    // sequence without k-mers there makes the guess wrong, which costs a load, never a result: the tag decides.
                     const bool seq_end = q0 + TQ >= nk;
                     uint64_t ng0 = g0 + 2 * TQ;
                     bool pf_on = true;
                     if (q0 + 2 * TQ >= nk) {
-                        uint32_t o_next;
-                        if (!seq_end) {  // one more tile here, then the next sequence
-                            o_next = (m == 0 && mates == 2) ? o1 : o2;
-                            pf_on = (m == 0 && mates == 2) || fc + 1 < ncf;
-                        } else if (mates == 2) {  // same mate of the next fragment
-                            o_next = m == 0 ? o2 : __builtin_amdgcn_readlane(off_v, oi + 3);
-                            pf_on = fc + 1 < ncf;
-                        } else {  // single-end: the fragment after the next
-                            o_next = __builtin_amdgcn_readlane(off_v, oi + 2);
-                            pf_on = fc + 2 < ncf;
+                        uint32_t si = (uint32_t)oi + (uint32_t)m;  // sequence index within the chunk
+                        uint32_t q2 = q0, nk2 = nk;
+#pragma unroll
+                        for (int hop = 0; hop < 2; hop++) {
+                            q2 += TQ;
+                            if (q2 >= nk2) {
+                                q2 = 0;
+                                si++;
+                                const uint32_t ln = __builtin_amdgcn_readlane(len_v, (int)(si < 63u ? si : 63u));
+                                nk2 = ln >= K ? ln - K + 1 : 0u;
+                            }
                         }
-                        ng0 = cbase + o_next;
+                        pf_on = si < nseq;
+                        ng0 = cbase + __builtin_amdgcn_readlane(off_v, (int)(si < 63u ? si : 63u)) + q2;
                     }
                     const uint32_t *pf_ptr = tile_ptr(pf_on ? ng0 : g0);
                     tag2 = pf_on ? (uint32_t)(ng0 - cbase) + 1u : 0u;
