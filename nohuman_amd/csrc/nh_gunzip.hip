@@ -2464,9 +2464,14 @@ public:
                 cv_.wait(lk, [&] { return !order_.empty() || done_; });
                 if (order_.empty()) {  // the producer has ended: the end of the input, an error, or "not ours"
                     if (fallback_) return 1;
-                    if (!error_.empty()) {
-                        if (!hard_) return 1;  // the host reader goes on from records_handed() (handover_reason())
-                        hb.error = error_;
+                    bool hard = false;
+                    const std::string e = error_text(&hard);
+                    if (!e.empty()) {
+                        if (!hard) {  // the host reader goes on from records_handed() (handover_reason())
+                            reason_ = e;
+                            return 1;
+                        }
+                        hb.error = e;
                     }
                     hb.eof = true;
                     return 0;
@@ -2492,7 +2497,7 @@ public:
     }
 
     uint64_t records_handed() const { return handed_recs_; }
-    const std::string &handover_reason() const { return error_; }
+    const std::string &handover_reason() const { return reason_; }  // (set by the next_batch() call that returned 1)
 
     void close() {
         {
@@ -2572,11 +2577,17 @@ private:
     // (next_batch() == 1) and says what it finds -- a damaged stream fails there with gzip's messages.  Malformed FASTQ in
     // text whose CRC-32 was right is the input's fault on any reader: hard.
     int fail(const std::string &m, bool hard = false) {
+        std::lock_guard<std::mutex> lk(err_mu_);  // (the decode stage, the index stage and the lanes' workers may all end here)
         if (error_.empty()) {
             error_ = m;
             hard_ = hard;
         }
         return -1;
+    }
+    std::string error_text(bool *hard = nullptr) {
+        std::lock_guard<std::mutex> lk(err_mu_);
+        if (hard) *hard = hard_;
+        return error_;
     }
     // the record index's buffers (a piece of 2.3 GB of text: 9 M newline positions, a 220 MB record table on the device and
     // page-locked on the host) come from the process-wide store like the decoder's: page-locking the table took 0.1 s a buffer
@@ -2991,6 +3002,8 @@ private:
     DevGunzip gz_;
     std::string path_, error_;
     bool hard_ = false;            // error_ is the input's fault (malformed FASTQ): no handover to the host reader
+    std::mutex err_mu_;            // error_ / hard_
+    std::string reason_;           // why next_batch() handed the file over (a copy: the producers may still be ending)
     size_t max_text_ = 0;          // single-end: a batch is cut behind the record that reaches this many bytes (0: by records only)
     uint64_t handed_recs_ = 0;     // records in the batches handed out
     long fail_at_ = 0;             // test knob NOHUMAN_GZDEV_FAIL_AT=k: the reader gives up before the stream's k-th piece (k >= 1)
