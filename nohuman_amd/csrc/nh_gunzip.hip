@@ -1961,8 +1961,10 @@ private:
             }
         }
         // stretches this piece decodes: what the room holds at the ratio seen so far (a piece that does not fit is cut down).
-        // (Smaller first pieces, to give the pipeline its first batches sooner, were measured and dropped: an eighth and a
-        // quarter of a piece first cost 0.1 s of a 1.7 s run -- small pieces leave the chip's wave slots empty.)
+        // (Smaller first pieces, to give the pipeline its first batches sooner, were measured and dropped twice: round 4, an
+        // eighth and a quarter of a piece first cost 0.1 s of a 1.7 s run -- small pieces leave the chip's wave slots empty;
+        // round 5, an eighth / a quarter / a half first, 20 M pairs: gzip out 1.389 -> 1.409 s, plain out 1.753 -> 1.797,
+        // nothing kept 1.170 -> 1.264 -- the run is bound by the GPU's codec kernels, not by when its first batch flows.)
         uint32_t n = n_slots_;
         {
             const double per_stretch = ratio_ * 1.3 * (double)stretch_ + 4096;
