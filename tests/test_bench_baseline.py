@@ -96,3 +96,35 @@ def test_bench_reports_kind_kraken2_when_the_binary_is_on_path(tmp_path):
     for c in calls:
         assert c[0] == "--threads" and c[2] == "--db" and c[4:9] == ["--output", "/dev/null", "--confidence", "0", "--paired"]
         assert c[9] == "--unclassified-out" and c[10].endswith("kraken_out#.fq") and len(c) == 13
+
+
+@pytest.mark.gpu
+def test_the_bench_line_keeps_the_drivers_contract_and_carries_its_numbers_inside_config_and_roofline(tmp_path):
+    """One whole `python bench.py` at toy sizes: the contract's keys, e2e numbers inside `config`, variants inside `roofline`
+    (the objects the driver keeps whole), every leg checked against its oracle / its inputs, and a line short enough to survive."""
+    env = dict(os.environ, NOHUMAN_BENCH_LOGDIR=str(tmp_path), NOHUMAN_BENCH_ONT_READS="3000", NOHUMAN_BENCH_ONT_MEMBERS="2")
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "3", "--warmup", "1", "--pairs", "50000", "--capacity", "4000037",
+                          "--e2e-pairs", "20000", "--e2e-reps", "2", "--e2e-distinct", "2", "--cpu-seconds", "1", "--wake-ms", "20"],
+                         env=env, capture_output=True, text=True, timeout=900, cwd=str(tmp_path))
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1 and len(lines[0]) < 8000
+    d = json.loads(lines[0])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data",
+              "config", "roofline", "cpu_baseline"):
+        assert k in d, k
+    assert d["n_gpus"] == 1 and d["steps"] == 3 and d["warmup"] == 1 and d["vs_baseline"] is None and d["dtype"] == "u64"
+    r = d["roofline"]
+    assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3
+    assert r["value_two_streams"] > 0 and r["wake_launches"] >= 1
+    assert set(r["variants"]) == {"se", "hit", "ont", "wide", "pe250"}
+    for name, v in r["variants"].items():
+        assert v["gpu_equals_oracle"] is True and v["frac"] > 0 and v["kernel_ms"] > 0 and v["value_two_streams"] > 0, name
+    e = d["config"]["e2e"]
+    assert e["outputs_equal_inputs"] is True and e["gzip_to_plain"]["value"] > 0 and e["gzip_to_gzip"]["value"] > 0
+    assert e["ont_gzip_to_gzip"]["outputs_equal_inputs"] is True and e["ont_gzip_to_gzip"]["reads"] == 6000
+    assert set(e["readers_by_name"]) == {"device", "host"} and e["gzip_encoder"]["inflates_to_the_text"] is True
+    assert d["cpu_baseline"]["kind"] == "port" and d["cpu_baseline"]["gpu_equals_oracle"] is True
+    assert isinstance(d["config"]["workload"], str) and len(d["config"]["workload"]) < 200
+    details = json.load(open(tmp_path / "bench_details.json"))
+    assert "e2e" in details and "variants" in details and "headline_workload" in details
