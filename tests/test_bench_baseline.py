@@ -103,7 +103,7 @@ def test_the_bench_line_keeps_the_drivers_contract_and_carries_its_numbers_insid
     """One whole `python bench.py` at toy sizes: the contract's keys, e2e numbers inside `config`, variants inside `roofline`
     (the objects the driver keeps whole), every leg checked against its oracle / its inputs, and a line short enough to survive."""
     env = dict(os.environ, NOHUMAN_BENCH_LOGDIR=str(tmp_path), NOHUMAN_BENCH_ONT_READS="3000", NOHUMAN_BENCH_ONT_MEMBERS="2")
-    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "3", "--warmup", "1", "--pairs", "50000", "--capacity", "4000037",
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "3", "--warmup", "1", "--pairs", "50000", "--capacity", "400000009",
                           "--e2e-pairs", "20000", "--e2e-reps", "2", "--e2e-distinct", "2", "--cpu-seconds", "1", "--wake-ms", "20"],
                          env=env, capture_output=True, text=True, timeout=900, cwd=str(tmp_path))
     assert out.returncode == 0, out.stderr[-3000:]
