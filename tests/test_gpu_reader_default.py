@@ -165,3 +165,21 @@ print("AFTER", int(L.nh_cache_bytes(0, 0)), int(L.nh_cache_bytes(0, 1)))
     after = [int(x) for x in out.stdout.split("AFTER")[1].split()]
     assert all(0 < x <= (512 << 20) for x in seen), seen  # kept, and never beyond the bound (two text buffers of 400 MiB do not fit: the newest stays)
     assert after == [0, 0]  # nh_close empties the store
+
+
+def test_fasta_in_gzip_goes_to_the_host_parser_in_the_default_mode_too(tmp_path, monkeypatch, capfd):
+    """No reader named, the GPU reader chosen by size: a gzip file that holds FASTA (wrapped lines) is handed to the host parser
+    before a batch has gone out -- no warning, same bytes as the host reader."""
+    from tests.fastq_util import read_fastq
+    rs = read_fastq(os.path.join(ROOT, "tests", "golden", "reads_se.fq"))
+    fa = b"".join(b">" + r[1] + b" d\n" + b"".join(r[2][j:j + 60] + b"\n" for j in range(0, len(r[2]), 60)) for r in rs) * 3
+    p = tmp_path / "x.fa.gz"
+    p.write_bytes(gzip.compress(fa, 6))
+    _small_scale(monkeypatch, batch=100)
+    monkeypatch.delenv("NOHUMAN_GZ_READER", raising=False)
+    dev = _run(tmp_path, "dev", p)
+    err = capfd.readouterr().err
+    assert "gzip reader: GPU" in err and "WARN" not in err, err[-1500:]
+    monkeypatch.setenv("NOHUMAN_GZ_READER", "host")
+    host = _run(tmp_path, "host", p)
+    assert dev == host and host[3][0] == 3 * len(rs)
