@@ -306,8 +306,13 @@ private:
     bool closed_ = false;
 };
 
+// What the two input files contribute to one launch: records [off, off + n) of each half.  Normally a half is used whole
+// (both readers cut at the same record counts); where a reader had to cut by TEXT (a batch's record text is addressed with 32
+// bits), or the two files came from different readers after a handover, the halves differ in length and the longer one is used
+// in parts: the halves are shared, and go back to their pool (device-born ones: to their reader) when the last part is through.
 struct Batch {
-    std::unique_ptr<HalfBatch> h1, h2;
+    std::shared_ptr<HalfBatch> h1, h2;
+    size_t off1 = 0, off2 = 0;
     size_t n = 0;
     int slot = -1;  // stream slot that carries its results
     int dev_index = 0;  // index of the slot's device among the run's engines
@@ -714,13 +719,15 @@ static void format_batch(RunState *rs, const Batch &b, const Slot &s, OutFile &o
     const char *t2 = rs->paired ? b.h2->text.data() : nullptr;
     char tmp[128];
     uint64_t bases = 0, classified = 0;
+    const RecRef *const R1 = b.h1->recs.data() + b.off1;
+    const RecRef *const R2 = rs->paired ? b.h2->recs.data() + b.off2 : nullptr;
     for (size_t i = 0; i < b.n; i++) {
-        const RecRef &r1 = b.h1->recs[i];
+        const RecRef &r1 = R1[i];
         const uint32_t call = s.h_res[i].call;
         const bool is_class = call != 0;
         classified += is_class;
         rs->call_counts[call] += is_class;
-        bases += r1.slen + (rs->paired ? b.h2->recs[i].slen : 0);
+        bases += r1.slen + (rs->paired ? R2[i].slen : 0);
         if (is_class == keep_class) {
             if (!is_class && r1.raw_end) {
                 o1.add_raw(t1 + r1.h, r1.raw_end - r1.h);
@@ -735,7 +742,7 @@ static void format_batch(RunState *rs, const Batch &b, const Slot &s, OutFile &o
                 o1.add_scratch(from);
             }
             if (rs->paired) {
-                const RecRef &r2 = b.h2->recs[i];
+                const RecRef &r2 = R2[i];
                 if (!is_class && r2.raw_end) {
                     o2.add_raw(t2 + r2.h, r2.raw_end - r2.h);
                 } else {
@@ -755,7 +762,7 @@ static void format_batch(RunState *rs, const Batch &b, const Slot &s, OutFile &o
             snprintf(tmp, sizeof tmp, "\t%llu\t", (unsigned long long)ext);
             bufk += tmp;
             if (rs->paired)
-                snprintf(tmp, sizeof tmp, "%u|%u\t", r1.slen, b.h2->recs[i].slen);
+                snprintf(tmp, sizeof tmp, "%u|%u\t", r1.slen, R2[i].slen);
             else
                 snprintf(tmp, sizeof tmp, "%u\t", r1.slen);
             bufk += tmp;
@@ -837,9 +844,9 @@ int run_engines(const std::vector<Engine *> &engines, const nh_run_args *a, nh_s
     // count (both readers at the same count), and their budget only keeps the text of the two halves together
     // below the 4 GB a batch's 32-bit sequence positions can address
     size_t BATCH_TEXT = rs.paired ? (size_t)0x7F000000u : (size_t)(512u << 20);
-    if (const char *env = getenv("NOHUMAN_BATCH_TEXT")) {  // test knob (single-end): batches cut by text at small scale
+    if (const char *env = getenv("NOHUMAN_BATCH_TEXT")) {  // test knob: batches cut by text at small scale (paired: the halves then differ in length)
         const long v = atol(env);
-        if (v > 0 && !rs.paired) BATCH_TEXT = (size_t)v;
+        if (v > 0) BATCH_TEXT = (size_t)v;
     }
     const int G = (int)engines.size();
     const int mates = rs.paired ? 2 : 1;
@@ -1018,8 +1025,8 @@ int run_engines(const std::vector<Engine *> &engines, const nh_run_args *a, nh_s
                 clk.ns[ST_WWRITE] += StageClock::now() - c3;
                 if (wrc) rs.fail(wrc, g_last_error);
             }
-            pool1.put(std::move(j->b.h1));
-            pool2.put(std::move(j->b.h2));
+            j->b.h1.reset();  // (the last part of a half gives it back to its pool: the deleter of take())
+            j->b.h2.reset();
             {
                 std::lock_guard<std::mutex> lk(slot_mu);
                 s.busy = false;
@@ -1051,8 +1058,9 @@ int run_engines(const std::vector<Engine *> &engines, const nh_run_args *a, nh_s
                     // a batch whose text is only in HBM, and a kept record that must be rewritten (CRLF, "+id" line): fetch it
                     auto need_fetch = [&](const HalfBatch &hb) {
                         if (hb.host_text_valid) return false;
+                        const size_t off = &hb == b.h1.get() ? b.off1 : b.off2;
                         for (size_t i = 0; i < b.n; i++)
-                            if (!hb.recs[i].raw_end && (s.h_res[i].call != 0) == (a->keep_human != 0)) return true;
+                            if (!hb.recs[off + i].raw_end && (s.h_res[i].call != 0) == (a->keep_human != 0)) return true;
                         return false;
                     };
                     for (int m = 0; m < (rs.paired ? 2 : 1) && !wrc; m++) {
@@ -1088,32 +1096,38 @@ int run_engines(const std::vector<Engine *> &engines, const nh_run_args *a, nh_s
     });
 
     // main: pair halves, stage, launch
-    std::unique_ptr<HalfBatch> carry1, carry2;
     uint64_t batch_no = 0;
     std::vector<uint64_t> home_turn((size_t)G, 0);
-    bool end1 = false, end2 = false;
+    // the half of each file in hand and how many of its records have gone out (a half is normally used whole: Batch)
+    std::shared_ptr<HalfBatch> c1, c2;
+    size_t p1 = 0, p2 = 0;
+    auto take = [](BoundedQueue<std::unique_ptr<HalfBatch>> &q, BatchPool *pool, std::shared_ptr<HalfBatch> &c, size_t &pos) {
+        std::unique_ptr<HalfBatch> u;
+        if (!q.pop(u)) return false;
+        c = std::shared_ptr<HalfBatch>(u.release(), [pool](HalfBatch *h) { pool->put(std::unique_ptr<HalfBatch>(h)); });
+        pos = 0;
+        return true;
+    };
     for (;;) {
         if (rs.failed()) break;
         Batch b;
         uint64_t m0 = StageClock::now();
-        if (!q1.pop(b.h1)) break;
-        end1 = b.h1->eof;
+        if ((!c1 || (p1 == c1->recs.size() && !c1->eof)) && !take(q1, &pool1, c1, p1)) break;
+        if (rs.paired && (!c2 || (p2 == c2->recs.size() && !c2->eof)) && !take(q2, &pool2, c2, p2)) break;
+        // kraken2 reads the files in lockstep and stops at the shorter one.  Both readers cut batches at the same record
+        // counts, so the halves normally pair up whole; where they do not (see Batch) the shorter one decides and the rest of
+        // the longer one pairs with the other file's next half -- no read is dropped, no run stopped
+        b.h1 = c1;
+        b.off1 = p1;
+        b.n = c1->recs.size() - p1;
         if (rs.paired) {
-            if (!q2.pop(b.h2)) break;
-            end2 = b.h2->eof;
+            b.h2 = c2;
+            b.off2 = p2;
+            b.n = std::min(b.n, c2->recs.size() - p2);
+            p2 += b.n;
         }
-        // kraken2 reads the files in lockstep and stops at the shorter one; both readers cut
-        // batches at the same record count, so only the last batch can differ in length
-        b.n = b.h1->recs.size();
-        if (rs.paired && b.h2->recs.size() < b.n) b.n = b.h2->recs.size();
-        const bool last = end1 || (rs.paired && end2);
-        if (rs.paired && !last && b.h1->recs.size() != b.h2->recs.size()) {
-            // both readers cut at the same record count, so only a byte-limited cut (the 32-bit text
-            // offsets of a batch) can desynchronise them before the end: never drop reads silently
-            rs.fail(NH_EIO, "paired inputs lost step before the end of either file (a batch of one mate "
-                            "file exceeded its 2 GB text budget); lower NOHUMAN_BATCH_FRAGS");
-            break;
-        }
+        p1 += b.n;
+        const bool last = (c1->eof && p1 == c1->recs.size()) || (rs.paired && c2->eof && p2 == c2->recs.size());
         if (b.n > 0) {
             // the slot: in turn over all devices' slots -- but a batch born on a GPU (the gzip reader there) is classified
             // on THAT device, in that device's slots in turn, unless they are all busy and another device has a free one
@@ -1161,10 +1175,10 @@ int run_engines(const std::vector<Engine *> &engines, const nh_run_args *a, nh_s
             const uint64_t k = s.e->info.k;
             if (rs.want_k) {
                 for (size_t i = 0; i < b.n; i++) {
-                    const uint64_t l1 = b.h1->recs[i].slen;
+                    const uint64_t l1 = b.h1->recs[b.off1 + i].slen;
                     ntaxa += l1 >= k ? l1 - k + 1 : 0;
                     if (rs.paired) {
-                        const uint64_t l2 = b.h2->recs[i].slen;
+                        const uint64_t l2 = b.h2->recs[b.off2 + i].slen;
                         ntaxa += (l2 >= k ? l2 - k + 1 : 0) + 1;
                     }
                 }
@@ -1178,7 +1192,7 @@ int run_engines(const std::vector<Engine *> &engines, const nh_run_args *a, nh_s
             dev_check_ptr(s.d_text, s.e->device, "nh_run, a slot's text buffer");
             uint64_t nbases = 0, toff = 0;
             for (size_t i = 0; i < b.n; i++) {
-                const RecRef &r1 = b.h1->recs[i];
+                const RecRef &r1 = b.h1->recs[b.off1 + i];
                 s.h_off[i * mates] = r1.s;
                 s.h_len[i * mates] = r1.slen;
                 nbases += r1.slen;
@@ -1187,7 +1201,7 @@ int run_engines(const std::vector<Engine *> &engines, const nh_run_args *a, nh_s
                     toff += r1.slen >= k ? r1.slen - k + 1 : 0;
                 }
                 if (rs.paired) {
-                    const RecRef &r2 = b.h2->recs[i];
+                    const RecRef &r2 = b.h2->recs[b.off2 + i];
                     s.h_off[i * mates + 1] = base2 + r2.s;
                     s.h_len[i * mates + 1] = r2.slen;
                     nbases += r2.slen;
@@ -1210,7 +1224,7 @@ int run_engines(const std::vector<Engine *> &engines, const nh_run_args *a, nh_s
                 if (!len) return hipSuccess;
                 if (!hb.dev_text) return hipMemcpyAsync((char *)s.d_text + at, hb.text.data(), len, hipMemcpyHostToDevice, s.stream);
                 hipError_t e2 = dev_copy_between((char *)s.d_text + at, s.e->device, hb.dev_text, hb.dev_device, len, s.stream);
-                if (e2 == hipSuccess && host_text_wanted) {
+                if (e2 == hipSuccess && host_text_wanted && !hb.host_text_valid) {  // (a half used in parts is fetched by its first)
                     hb.text.clear();  // (a batch born on the GPU comes with a token buffer: the real one only where it is needed)
                     if (!hb.text.reserve(len + 64)) return hipErrorOutOfMemory;
                     hb.text.set_size(len);
@@ -1251,6 +1265,8 @@ int run_engines(const std::vector<Engine *> &engines, const nh_run_args *a, nh_s
         if (last) break;
     }
     // shut the pipeline down (also on errors): unblock readers, drain the writer
+    c1.reset();  // (a reader on the GPU waits in close() for every batch it handed out)
+    c2.reset();
     pool1.stop();
     pool2.stop();
     q1.close();

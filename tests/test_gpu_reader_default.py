@@ -183,3 +183,43 @@ def test_fasta_in_gzip_goes_to_the_host_parser_in_the_default_mode_too(tmp_path,
     monkeypatch.setenv("NOHUMAN_GZ_READER", "host")
     host = _run(tmp_path, "host", p)
     assert dev == host and host[3][0] == 3 * len(rs)
+
+
+@pytest.mark.parametrize("shape", ["both host", "plain + gzip on the GPU", "gzip on the GPU + plain"])
+@pytest.mark.parametrize("codec", [0, 2])
+def test_paired_halves_of_unequal_length_are_used_in_parts(tmp_path, monkeypatch, shape, codec):
+    """A reader that has to cut a batch by TEXT (32-bit text offsets; here a 30 KB budget), or two files on different readers,
+    hand the pairing halves of different record counts.  That used to stop the run ("paired inputs lost step ... lower
+    NOHUMAN_BATCH_FRAGS"); the shorter half decides now and the rest of the longer one pairs with the other file's next half.
+    Mates of different read lengths, so that the two files' text cuts never coincide."""
+    raw1 = open(os.path.join(ROOT, "tests", "golden", "reads_pe_1.fq"), "rb").read() * 5
+    recs2 = []
+    from tests.fastq_util import read_fastq
+    for k in range(5):
+        for i, (h, _id, seq, q) in enumerate(read_fastq(os.path.join(ROOT, "tests", "golden", "reads_pe_2.fq"))):
+            cut = 60 + (i * 7) % 90  # mate 2: 60-149 bases
+            recs2.append(h + b"\n" + seq[:cut] + b"\n+\n" + q[:cut] + b"\n")
+    raw2 = b"".join(recs2)
+    gz1, gz2 = tmp_path / "r_1.fq.gz", tmp_path / "r_2.fq.gz"
+    pl1, pl2 = tmp_path / "r_1.fq", tmp_path / "r_2.fq"
+    gz1.write_bytes(gzip.compress(raw1, 6)); gz2.write_bytes(gzip.compress(raw2, 6))
+    pl1.write_bytes(raw1); pl2.write_bytes(raw2)
+    _small_scale(monkeypatch, batch=64)
+    monkeypatch.setenv("NOHUMAN_GZDEV_SEG", "16384")
+    monkeypatch.setenv("NOHUMAN_GZDEV_STRETCH", "2048")
+    monkeypatch.setenv("NOHUMAN_GZ_READER", "host")
+    want = _run(tmp_path, "want", gz1, gz2, out_codec=0)  # whole halves, host reader, plain outputs: the reference bytes
+    monkeypatch.setenv("NOHUMAN_BATCH_TEXT", "30000")
+    if shape == "both host":
+        a, b = gz1, gz2
+    else:
+        monkeypatch.setenv("NOHUMAN_GZ_READER", "device")
+        a, b = (pl1, gz2) if shape.startswith("plain") else (gz1, pl2)
+    from nohuman_amd import Engine
+    o1, o2, k = tmp_path / "o1", tmp_path / "o2", tmp_path / "k"
+    with Engine.open(DB) as eng:
+        st = eng.run(str(a), str(o1), in2=str(b), out2=str(o2), kraken_output=str(k), threads=4, out_codec=codec, codec_threads=2)
+    rd = (lambda p: gzip.decompress(p.read_bytes())) if codec == 2 else (lambda p: p.read_bytes())
+    got = (rd(o1), rd(o2), k.read_bytes(), (st.total_sequences, st.classified, st.total_bases))
+    assert got == want
+    assert want[3][0] == raw1.count(b"\n") // 4
