@@ -1112,8 +1112,8 @@ int run_engines(const std::vector<Engine *> &engines, const nh_run_args *a, nh_s
         if (rs.failed()) break;
         Batch b;
         uint64_t m0 = StageClock::now();
-        if ((!c1 || (p1 == c1->recs.size() && !c1->eof)) && !take(q1, &pool1, c1, p1)) break;
-        if (rs.paired && (!c2 || (p2 == c2->recs.size() && !c2->eof)) && !take(q2, &pool2, c2, p2)) break;
+        if (!c1 && !take(q1, &pool1, c1, p1)) break;
+        if (rs.paired && !c2 && !take(q2, &pool2, c2, p2)) break;
         // kraken2 reads the files in lockstep and stops at the shorter one.  Both readers cut batches at the same record
         // counts, so the halves normally pair up whole; where they do not (see Batch) the shorter one decides and the rest of
         // the longer one pairs with the other file's next half -- no read is dropped, no run stopped
@@ -1127,7 +1127,12 @@ int run_engines(const std::vector<Engine *> &engines, const nh_run_args *a, nh_s
             p2 += b.n;
         }
         p1 += b.n;
-        const bool last = (c1->eof && p1 == c1->recs.size()) || (rs.paired && c2->eof && p2 == c2->recs.size());
+        // a half that is used up is let go of HERE, not when the next one arrives: a reader on the GPU may need its buffer to
+        // produce that next one (a piece smaller than a batch hands out nothing until the piece behind it is decoded)
+        const bool done1 = p1 == c1->recs.size(), done2 = rs.paired && p2 == c2->recs.size();
+        const bool last = (done1 && c1->eof) || (done2 && c2->eof);
+        if (done1) c1.reset();
+        if (done2) c2.reset();
         if (b.n > 0) {
             // the slot: in turn over all devices' slots -- but a batch born on a GPU (the gzip reader there) is classified
             // on THAT device, in that device's slots in turn, unless they are all busy and another device has a free one
