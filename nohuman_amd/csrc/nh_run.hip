@@ -1172,7 +1172,7 @@ int run_engines(const std::vector<Engine *> &engines, const nh_run_args *a, nh_s
             const size_t base2 = (len1 + 8 + 255) & ~(size_t)255;
             const size_t ntext = rs.paired ? base2 + len2 : len1;
             if (ntext >= (1ull << 32)) {
-                rs.fail(NH_EINVAL, "a batch of more than 4 GB of record text; lower NOHUMAN_BATCH_FRAGS");
+                rs.fail(NH_EINVAL, "a batch of more than 4 GB of record text (its offsets are 32-bit): paired records of several kilobases each are not supported");
                 wq.push(std::move(b));
                 break;
             }
