@@ -62,7 +62,7 @@ def run(w, env):
     return e0.elapsed_time(e1) / steps
 
 settings = {
-    "pe": [("flat (default)", {}), ("guided", {"NOHUMAN_SCHED": "guided"}), ("12,4,50,50", {"NOHUMAN_SCHED": "12,4,50,50"}),
+    "pe": [("default 12,6,100,100", {}), ("off (flat)", {"NOHUMAN_SCHED": "off"}), ("12,4,50,50", {"NOHUMAN_SCHED": "12,4,50,50"}),
            ("12,4,150,150", {"NOHUMAN_SCHED": "12,4,150,150"}), ("12,2,100,100", {"NOHUMAN_SCHED": "12,2,100,100"}),
            ("12,6,100,100", {"NOHUMAN_SCHED": "12,6,100,100"}), ("8,4,100,100", {"NOHUMAN_SCHED": "8,4,100,100"}),
            ("16,8,100,100", {"NOHUMAN_SCHED": "16,8,100,100"})],
@@ -75,10 +75,10 @@ settings = {
     "hit": [("default 12,6,100,100", {}), ("off (flat)", {"NOHUMAN_SCHED": "off"}), ("12,6,50,50", {"NOHUMAN_SCHED": "12,6,50,50"}),
             ("12,6,200,200", {"NOHUMAN_SCHED": "12,6,200,200"}), ("12,2,100,100", {"NOHUMAN_SCHED": "12,2,100,100"}), ("8,4,150,150", {"NOHUMAN_SCHED": "8,4,150,150"})],
     "ont": [("default", {})],
-    "sechunk": [("32", {}), ("40", {"NOHUMAN_FRAG_CHUNK": "40"}), ("48", {"NOHUMAN_FRAG_CHUNK": "48"}), ("56", {"NOHUMAN_FRAG_CHUNK": "56"}),
+    "sechunk": [("default (60)", {}), ("40", {"NOHUMAN_FRAG_CHUNK": "40"}), ("48", {"NOHUMAN_FRAG_CHUNK": "48"}), ("56", {"NOHUMAN_FRAG_CHUNK": "56"}),
                 ("60", {"NOHUMAN_FRAG_CHUNK": "60"}), ("28", {"NOHUMAN_FRAG_CHUNK": "28"}), ("24", {"NOHUMAN_FRAG_CHUNK": "24"}),
                 ("20", {"NOHUMAN_FRAG_CHUNK": "20"}), ("16", {"NOHUMAN_FRAG_CHUNK": "16"}), ("12", {"NOHUMAN_FRAG_CHUNK": "12"})],
-    "pechunk": [("24", {}), ("28", {"NOHUMAN_FRAG_CHUNK": "28"}), ("20", {"NOHUMAN_FRAG_CHUNK": "20"}), ("16", {"NOHUMAN_FRAG_CHUNK": "16"}),
+    "pechunk": [("default (24)", {}), ("28", {"NOHUMAN_FRAG_CHUNK": "28"}), ("20", {"NOHUMAN_FRAG_CHUNK": "20"}), ("16", {"NOHUMAN_FRAG_CHUNK": "16"}),
                 ("12", {"NOHUMAN_FRAG_CHUNK": "12"}), ("30", {"NOHUMAN_FRAG_CHUNK": "30"})],
 }
 for shape in shapes:
