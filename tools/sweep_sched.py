@@ -22,7 +22,7 @@ def make(shape):
     eng = Engine.synthetic(cap, int(cap * 0.7) - (80_000_000 if shape == "hit" else 0), depth=30, seed=20250101)
     paired = shape in ("pe", "hit", "pechunk")
     mates = 2 if paired else 1
-    n = {"pe": 2_500_000, "se": 1_000_000, "hit": 1_000_000, "ont": 200_000, "sechunk": 1_000_000, "pechunk": 2_500_000}[shape]
+    n = {"pe": 2_500_000, "se": 1_000_000, "hit": 1_000_000, "ont": 200_000, "sechunk": 1_000_000, "pechunk": 2_500_000, "setail": 1_000_000}[shape]
     g = torch.Generator(device=dev); g.manual_seed(11)
     if shape == "ont":
         lens = torch.exp(torch.randn(n, generator=g, device=dev, dtype=torch.float64) * 0.85 + 8.8).clamp(200, 200000).to(torch.int64)
@@ -72,6 +72,8 @@ settings = {
            ("28,4,100,100", {"NOHUMAN_SCHED": "28,4,100,100"}), ("28,8,100,100", {"NOHUMAN_SCHED": "28,8,100,100"}),
            ("28,20,100,100", {"NOHUMAN_SCHED": "28,20,100,100"}), ("16,8,100,100", {"NOHUMAN_SCHED": "16,8,100,100"}),
            ("40,12,100,100", {"NOHUMAN_SCHED": "40,12,100,100"}), ("20,4,150,150", {"NOHUMAN_SCHED": "20,4,150,150"})],
+    "setail": [("default 28,12,100,100", {})] + [(x, {"NOHUMAN_SCHED": x}) for x in ("12,4,100,100", "12,4,60,100", "16,4,100,100", "20,4,100,100", "28,4,100,30",
+                                                                                       "28,4,100,50", "28,8,100,50", "20,8,100,100", "24,8,100,100", "28,12,100,60")],
     "hit": [("default 12,6,100,100", {}), ("off (flat)", {"NOHUMAN_SCHED": "off"}), ("12,6,50,50", {"NOHUMAN_SCHED": "12,6,50,50"}),
             ("12,6,200,200", {"NOHUMAN_SCHED": "12,6,200,200"}), ("12,2,100,100", {"NOHUMAN_SCHED": "12,2,100,100"}), ("8,4,150,150", {"NOHUMAN_SCHED": "8,4,150,150"})],
     "ont": [("default", {})],
