@@ -292,6 +292,16 @@ def measure(cx, args, *, steps, warmup, single_end=False, ont=False, hit_frac=0.
         eng.classify_device(pool[i % len(pool)].data_ptr(), offsets.data_ptr(), n_frag, paired, args.confidence,
                             res2[i % 2].data_ptr(), counters2.data_ptr(), s2[i % 2].cuda_stream, long_reads=ont)
 
+    # (the few hundred microseconds of synchronising and allocating above are enough of an idle moment to bring part of the
+    #  transient back -- the profiler's per-dispatch times show it, profiles/r05_launch_series.txt --: the same wake phase here)
+    if args.wake_ms > 0:
+        tw = time.perf_counter()
+        k = 0
+        while (time.perf_counter() - tw) * 1e3 < args.wake_ms / 2:
+            step2(k)
+            k += 1
+            if k % 4 == 0:
+                torch.cuda.synchronize()
     for i in range(min(warmup, 2)):
         step2(i)
     torch.cuda.synchronize()
