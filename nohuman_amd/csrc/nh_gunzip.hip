@@ -1528,8 +1528,9 @@ public:
             return -1;
         }
         // (the second staging buffer: wanted for files of more than one piece; without it pieces are staged as they come)
-        if (size_ > seg_ && !(getenv("NOHUMAN_GZDEV_STAGE_AHEAD") && getenv("NOHUMAN_GZDEV_STAGE_AHEAD")[0] == '0'))
-            s_->h_in2_ = (uint8_t *)cache_alloc(s_->device_, stage_bytes_, true);
+        // (page-locking half a gigabyte takes 50-80 ms: the helper that stages the second piece's bytes makes the buffer, while
+        //  the first piece's kernels run, not open())
+        stage_ahead_ = size_ > seg_ && !(getenv("NOHUMAN_GZDEV_STAGE_AHEAD") && getenv("NOHUMAN_GZDEV_STAGE_AHEAD")[0] == '0');
         if (const char *e = getenv("NOHUMAN_GZDEV_FAKE_START")) fake_start_ = atol(e);  // test knob: a false positive of the search
         if (const char *e = getenv("NOHUMAN_GZDEV_FAKE_SPEC")) fake_spec_ = atol(e);
         open_s_ = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_open).count();
@@ -1788,13 +1789,13 @@ private:
         if (!spec && pf_.valid) {
             if (pf_.th.joinable()) pf_.th.join();
             pf_.valid = false;
-            if (j.a_byte >= pf_.start && j.a_byte + avail <= pf_.start + pf_.len) {
+            if (pf_.buf && j.a_byte >= pf_.start && j.a_byte + avail <= pf_.start + pf_.len) {
                 src = pf_.buf + (j.a_byte - pf_.start);
                 stage = pf_.buf;
                 pf_hits_++;
             } else {
                 pf_misses_++;  // (a piece cut down, the host decoder's turn, a block longer than the look-ahead: copied now)
-                stage = pf_.buf == d.h_in_ ? d.h_in2_ : d.h_in_;  // (not the one the piece before was uploaded from)
+                stage = (pf_.buf == d.h_in_ || !d.h_in2_) ? (d.h_in2_ ? d.h_in2_ : d.h_in_) : d.h_in_;  // (the other one where there are two)
             }
         }
         if (!src) {
@@ -1804,17 +1805,24 @@ private:
         const double copy_s = std::chrono::duration<double>(std::chrono::steady_clock::now() - c0).count();
         GZA_TRY(hipMemcpyAsync(d.d_in_, src, avail, hipMemcpyHostToDevice, stream));
         GZA_TRY(hipMemsetAsync(d.d_in_ + avail, 0, 1024, stream));  // (what a kernel reads beyond the valid bits is zeros)
-        if (!spec && sets_.size() == 1 && d.h_in2_ && !j.at_eof) {
+        if (!spec && sets_.size() == 1 && stage_ahead_ && !j.at_eof) {
             // where the next piece is expected: at the end of this one's last stretch (it starts at the first block boundary at
             // or behind it: up to a block further on, which the buffer's slack covers)
-            pf_.buf = stage == d.h_in_ ? d.h_in2_ : d.h_in_;
             pf_.start = (j.a_byte + (uint64_t)n_str * stretch_) / ALIGN * ALIGN;
             pf_.len = pf_.start < size_ ? (size_t)std::min<uint64_t>(stage_bytes_, size_ - pf_.start) : 0;
             if (pf_.len) {
                 const uint8_t *from = base_ + pf_.start;
-                uint8_t *to = pf_.buf;
                 const size_t len = pf_.len;
-                pf_.th = std::thread([from, to, len] { memcpy(to, from, len); });
+                const bool into_second = stage == d.h_in_;
+                DevSet *dp = &d;
+                const size_t bytes = stage_bytes_;
+                pf_.buf = nullptr;  // (the helper says: the second buffer is made by its first use)
+                pf_.th = std::thread([this, dp, from, len, into_second, bytes] {
+                    if (into_second && !dp->h_in2_) dp->h_in2_ = (uint8_t *)cache_alloc(dp->device_, bytes, true);
+                    uint8_t *to = into_second ? dp->h_in2_ : dp->h_in_;
+                    if (to) memcpy(to, from, len);
+                    pf_.buf = to;
+                });
                 pf_.valid = true;
             }
         }
@@ -2201,6 +2209,7 @@ private:
         bool valid = false;
     } pf_;
     uint64_t pf_hits_ = 0, pf_misses_ = 0;
+    bool stage_ahead_ = false;
     uint64_t prof_[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 };
 
