@@ -11,6 +11,10 @@
 #include <stdlib.h>
 #include <string.h>
 #include <sys/stat.h>
+#include <algorithm>
+#include <thread>
+#include <unistd.h>
+#include <fcntl.h>
 
 #include <chrono>
 #include <mutex>
@@ -568,47 +572,94 @@ int open_dir(const char *db_dir, int device, Engine **out) {
                 rc = set_error(NH_EDB, "hash.k2d: file size does not match capacity");
         }
     }
+    const bool trace = getenv("NOHUMAN_TRACE") != nullptr;
+    auto now_s = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    const double t_a = now_s();
     if (!rc) rc = check_queue_packing(e);
     if (!rc) rc = alloc_table(e, e->info.capacity);
+    const double t_b = now_s();
+    double t_c = t_b;
     if (!rc) {
+        // The cells go page cache -> page-locked bounce buffers -> HBM.  One thread's read() moves ~10 GB/s, a PCIe 5 x16 link
+        // five times that: several loaders (NOHUMAN_DB_LOADERS, default 4) take the file's 64 MiB chunks in turn, each with its
+        // own descriptor, two bounce buffers and a stream (round 5; one loader: 0.50 s for the 5.73 GB table, tools/db_load_bench.py).
         const size_t CH = 64u << 20;
-        void *pin[2] = {nullptr, nullptr};
-        hipEvent_t ev[2];
-        hipError_t he = hipMemset(e->d_table, 0, e->table_cells_alloc * sizeof(uint32_t));
-        for (int i = 0; i < 2 && he == hipSuccess; i++) {
-            he = host_malloc(&pin[i], CH, hipHostMallocDefault);
-            if (he == hipSuccess) he = hipEventCreate(&ev[i]);
-        }
-        uint64_t left = 4 * e->info.capacity, off = 0;
-        int slot = 0;
-        bool used[2] = {false, false};
-        while (he == hipSuccess && left > 0) {
-            size_t n = left < CH ? (size_t)left : CH;
-            if (used[slot]) he = hipEventSynchronize(ev[slot]);
-            if (he != hipSuccess) break;
-            if (fread(pin[slot], 1, n, f) != n) {
-                rc = set_error(NH_EIO, "short read on hash.k2d");
-                break;
+        const uint64_t bytes = 4 * e->info.capacity;
+        const uint64_t n_chunks = (bytes + CH - 1) / CH;
+        int T = 4;
+        if (const char *env = getenv("NOHUMAN_DB_LOADERS")) T = atoi(env);
+        T = std::max(1, std::min<int>(T, (int)std::min<uint64_t>(16, n_chunks)));
+        hipError_t he0 = hipMemset(e->d_table, 0, e->table_cells_alloc * sizeof(uint32_t));
+        if (he0 == hipSuccess) he0 = hipDeviceSynchronize();  // (the loaders' streams do not wait for the legacy stream's memset)
+        t_c = now_s();
+        if (he0 != hipSuccess) rc = set_error(NH_EDEVICE, "table upload: %s", hipGetErrorString(he0));
+        const std::string hp = dir + "/hash.k2d";
+        std::vector<int> trc((size_t)T, NH_OK);
+        std::vector<std::string> terr((size_t)T);
+        auto loader = [&](int t) {
+            auto failed = [&](int code, const std::string &m) {
+                trc[(size_t)t] = code;
+                terr[(size_t)t] = m;
+            };
+            const int fd = ::open(hp.c_str(), O_RDONLY | O_CLOEXEC);
+            if (fd < 0) return failed(NH_EIO, "cannot read " + hp);
+            void *pin[2] = {nullptr, nullptr};
+            hipEvent_t ev[2] = {nullptr, nullptr};
+            hipStream_t st = nullptr;
+            hipError_t he = dev_set(device);
+            if (he == hipSuccess) he = hipStreamCreateWithFlags(&st, hipStreamNonBlocking);
+            for (int i = 0; i < 2 && he == hipSuccess; i++) {
+                he = host_malloc(&pin[i], CH, hipHostMallocDefault);
+                if (he == hipSuccess) he = hipEventCreate(&ev[i]);
             }
-            he = hipMemcpyAsync((uint8_t *)e->d_table + off, pin[slot], n, hipMemcpyHostToDevice,
-                                e->stream);
-            if (he == hipSuccess) he = hipEventRecord(ev[slot], e->stream);
-            used[slot] = true;
-            slot ^= 1;
-            off += n;
-            left -= n;
-        }
-        if (he == hipSuccess) he = hipStreamSynchronize(e->stream);
-        for (int i = 0; i < 2; i++)
-            if (pin[i]) {
-                (void)hipHostFree(pin[i]);
-                (void)hipEventDestroy(ev[i]);
+            bool used[2] = {false, false};
+            int slot = 0;
+            for (uint64_t c = (uint64_t)t; c < n_chunks && he == hipSuccess && trc[(size_t)t] == NH_OK; c += (uint64_t)T) {
+                const uint64_t off = c * CH;
+                const size_t n = (size_t)std::min<uint64_t>(CH, bytes - off);
+                if (used[slot]) he = hipEventSynchronize(ev[slot]);
+                if (he != hipSuccess) break;
+                size_t got = 0;
+                while (got < n) {
+                    const ssize_t r = pread(fd, (char *)pin[slot] + got, n - got, (off_t)(32 + off + got));
+                    if (r <= 0) break;
+                    got += (size_t)r;
+                }
+                if (got != n) {
+                    failed(NH_EIO, "short read on hash.k2d");
+                    break;
+                }
+                he = hipMemcpyAsync((uint8_t *)e->d_table + off, pin[slot], n, hipMemcpyHostToDevice, st);
+                if (he == hipSuccess) he = hipEventRecord(ev[slot], st);
+                used[slot] = true;
+                slot ^= 1;
             }
-        if (he != hipSuccess && !rc) rc = set_error(NH_EDEVICE, "table upload: %s", hipGetErrorString(he));
+            if (he == hipSuccess && st) he = hipStreamSynchronize(st);
+            for (int i = 0; i < 2; i++) {
+                if (pin[i]) (void)hipHostFree(pin[i]);
+                if (ev[i]) (void)hipEventDestroy(ev[i]);
+            }
+            if (st) (void)hipStreamDestroy(st);
+            ::close(fd);
+            if (he != hipSuccess && trc[(size_t)t] == NH_OK) failed(NH_EDEVICE, std::string("table upload: ") + hipGetErrorString(he));
+        };
+        if (!rc) {
+            std::vector<std::thread> th;
+            for (int t = 1; t < T; t++) th.emplace_back(loader, t);
+            loader(0);
+            for (auto &x : th) x.join();
+            (void)dev_set(device);
+            for (int t = 0; t < T && !rc; t++)
+                if (trc[(size_t)t] != NH_OK) rc = set_error(trc[(size_t)t], "%s", terr[(size_t)t].c_str());
+        }
     }
     if (f) fclose(f);
+    const double t_d = now_s();
     if (!rc) rc = upload_taxonomy(e);
     if (!rc) rc = refresh_table_copies(e);
+    if (trace && !rc)
+        fprintf(stderr, "[nohuman trace] database: table allocated in %.3f s, cleared in %.3f s, %.2f GB uploaded in %.3f s, taxonomy + copies %.3f s\n", t_b - t_a,
+                t_c - t_b, 4.0 * e->info.capacity / 1e9, t_d - t_c, now_s() - t_d);
     if (rc) {
         destroy(e);
         return rc;

@@ -1464,6 +1464,9 @@ int nh_run(const nh_run_args *args, nh_stats *stats) {
         for (int i = 0; i < (args->n_devices > 0 ? args->n_devices : ndev); i++) devs.push_back(i);
     // one replica of the database per device, loaded at the same time (each device has its own PCIe
     // link; the file comes from the page cache after the first reader)
+    const bool trace = getenv("NOHUMAN_TRACE") != nullptr;
+    const auto t_begin = std::chrono::steady_clock::now();
+    auto since = [&](std::chrono::steady_clock::time_point t) { return std::chrono::duration<double>(std::chrono::steady_clock::now() - t).count(); };
     std::vector<nh::Engine *> opened(devs.size(), nullptr);
     std::vector<int> rcs(devs.size(), NH_OK);
     std::vector<std::string> errs(devs.size());
@@ -1482,9 +1485,16 @@ int nh_run(const nh_run_args *args, nh_stats *stats) {
         if (opened[i]) engines.push_back(opened[i]);
         if (rcs[i] && !rc) rc = nh::set_error(rcs[i], "%s", errs[i].c_str());
     }
+    const double t_load = since(t_begin);
+    const auto t_run = std::chrono::steady_clock::now();
     if (!rc) rc = nh::run_engines(engines, args, stats);
+    const double s_run = since(t_run);
     std::string keep = nh::g_last_error;
+    const auto t_close = std::chrono::steady_clock::now();
     for (nh::Engine *e : engines) nh::destroy(e);
+    if (trace)
+        fprintf(stderr, "[nohuman trace] nh_run: database into HBM %.3f s, the run %.3f s, closing (HBM and page-locked buffers given back) %.3f s\n", t_load,
+                s_run, since(t_close));
     if (rc) nh::g_last_error = keep;
     return rc;
 }

@@ -18,7 +18,7 @@ try:
         eng.download_table().tofile(f)
     eng.close()
     size = os.path.getsize(os.path.join(db, "hash.k2d"))
-    for rep in range(3):
+    for rep in range(int(os.environ.get("DB_LOAD_REPS", "3"))):
         t = time.perf_counter()
         e = Engine.open(db)
         dt = time.perf_counter() - t
