@@ -38,7 +38,7 @@ try:
             dt = time.perf_counter() - t
             print("== %s, process %d: rc %d, wall %.3f s = %.1f Mreads/s" % (what, rep, r.returncode, dt, 2 * n * members / dt / 1e6))
             for ln in r.stderr.splitlines():
-                if any(k in ln for k in ("wall", "nh_run:", "ERROR", "WARN")):
+                if os.environ.get("CLI_COLD_ALL") and rep == 0 and "piece " not in ln or any(k in ln for k in ("wall", "nh_run:", "ERROR", "WARN")):
                     print("   ", ln[:230])
 finally:
     shutil.rmtree(tmp, ignore_errors=True)
