@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define NH_ABI_VERSION 4
+#define NH_ABI_VERSION 5
 
 typedef enum {
     NH_OK = 0,
@@ -114,7 +114,11 @@ int nh_probe(char *msg, size_t msg_len);
 int nh_device_count(int *count);
 
 /* Load <db_dir>/{hash,opts,taxo}.k2d -- or <db_dir>/db/... (src/lib.rs:119-141) -- into the HBM
- * of `device`.  Replaces kraken2's "Loading database information..." phase. */
+ * of `device`.  Replaces kraken2's "Loading database information..." phase.
+ * The CONTENT is checked too (ABI 5), because the kernels index the taxonomy with the cells' values and nohuman can have
+ * several database versions installed side by side (src/download.rs:178-222): every cell is read once on the device
+ * (about a millisecond per 5 GB); a value >= taxo.k2d's node count, a count of non-empty cells that is not the header's
+ * `size`, or a taxonomy whose parent ids do not lie below their children fail with NH_EDB -- never with a GPU fault. */
 int nh_open(const char *db_dir, int device, nh_engine **out);
 /* Same from in-memory images of the three files (borrowed for the duration of the call). */
 int nh_open_images(const void *opts, size_t opts_len, const void *taxo, size_t taxo_len,
@@ -133,6 +137,14 @@ int nh_synthetic_add_sequences(nh_engine *e, const void *d_bases, const void *d_
 int nh_close(nh_engine *e);
 
 int nh_db_info_get(const nh_engine *e, nh_db_info *info);
+/* What the content check of nh_open* measured (ABI 5). */
+typedef struct {
+    uint64_t non_empty_cells; /* cells whose value field is not 0; == nh_db_info.size of a database that opened */
+    uint64_t max_value;       /* largest value field in the table; < nh_db_info.node_count */
+    double load_factor;       /* non_empty_cells / capacity */
+    double seconds;           /* what the pass cost */
+} nh_db_check;
+int nh_db_check_get(const nh_engine *e, nh_db_check *c);
 /* The defaults of a freshly opened engine can be overridden per process by NOHUMAN_OPT_AMBIGUITY_RULE,
  * NOHUMAN_OPT_LINEAR_PROBING, NOHUMAN_OPT_RESET_PER_MATE, NOHUMAN_OPT_MIN_HIT_GROUPS (integers): how
  * scripts/parity_vs_kraken2.sh walks the switch lattice through nh_run and the CLI host. */
@@ -169,7 +181,9 @@ uint64_t nh_kmer_taxa_entries(const nh_engine *e, const uint64_t *seq_offsets, u
  * 8 bytes past the last base.  d_kmer_taxa / d_kmer_taxa_offsets may be NULL.  d_counters (may be
  * NULL) points at 4 uint64 accumulators {fragments, classified, bases, table_lookups} that the
  * kernel adds to.  This is the entry the roofline number of bench.py is measured on.
- * Up to 16 launches of one engine may be in flight at once (on any streams).
+ * Thread-safe per engine: any number of host threads may call it on one engine, each on its own stream.  The engine has
+ * 16 launch slots; a launch that finds its slot still taken by the launch sixteen before it waits for that one ON THE
+ * DEVICE (an event wait queued on `stream`), so more than 16 launches in flight are ordered, never mixed.
  */
 int nh_classify_batch_device(nh_engine *e, const void *d_bases, const void *d_seq_offsets,
                              uint64_t n_frag, uint32_t flags, double confidence, void *d_results,

@@ -29,6 +29,11 @@ class nh_db_info(C.Structure):
                 ("node_count", C.c_uint64), ("device", C.c_int32), ("reserved", C.c_int32)]
 
 
+class nh_db_check(C.Structure):
+    _fields_ = [("non_empty_cells", C.c_uint64), ("max_value", C.c_uint64), ("load_factor", C.c_double),
+                ("seconds", C.c_double)]
+
+
 class nh_options(C.Structure):
     _fields_ = [("minimum_hit_groups", C.c_uint32), ("linear_probing", C.c_int32),
                 ("reset_per_mate", C.c_int32), ("ambiguity_rule", C.c_int32)]
@@ -57,6 +62,7 @@ SYMBOLS = {
     "nh_synthetic_add_sequences": (C.c_int, [_P, _P, _P, C.c_uint64, C.c_uint32, _P]),
     "nh_close": (C.c_int, [_P]),
     "nh_db_info_get": (C.c_int, [_P, C.POINTER(nh_db_info)]),
+    "nh_db_check_get": (C.c_int, [_P, C.POINTER(nh_db_check)]),
     "nh_options_get": (C.c_int, [_P, C.POINTER(nh_options)]),
     "nh_options_set": (C.c_int, [_P, C.POINTER(nh_options)]),
     "nh_taxon_external": (C.c_int, [_P, C.c_uint32, C.POINTER(C.c_uint64)]),

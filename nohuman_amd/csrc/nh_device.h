@@ -143,6 +143,12 @@ struct KArgs {
 };
 
 // ---- host side of a launch ----
+// NOHUMAN_SCHED, parsed once when the engine is opened (nh_internal.h LaunchKnobs): "off" = the flat claim map, or
+// c1,c2,p1,p2 = sizes of the guided tail's chunks and its two lengths in percent
+struct SchedKnobs {
+    bool set = false, off = false;
+    uint32_t c1 = 0, c2 = 0, p1 = 100, p2 = 100;
+};
 // what one classify launch reads and writes (device pointers)
 struct LaunchIO {
     const void *d_bases = nullptr;

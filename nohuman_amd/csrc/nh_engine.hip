@@ -270,8 +270,10 @@ static int parse_taxonomy(Engine *e, const void *taxo, size_t taxo_len) {
     for (uint64_t i = 0; i < nc; i++) {
         const uint8_t *n = tb + 32 + 56 * i;
         uint64_t p = rd64(n);
-        if (i >= 2 && p >= i) return set_error(NH_EDB, "taxo.k2d: parent id not below child id");
-        e->parent[i] = (uint32_t)p;
+        // (the kernels climb with `while (b > a) b = parent[b]`: every parent below its child, the root's parent 0 --
+        //  a root that names another node as its parent would be a loop on the GPU.  Node 0 is kraken2's unused dummy.)
+        if (i >= 1 && p >= i) return set_error(NH_EDB, "taxo.k2d: parent id %llu of node %llu is not below it", (unsigned long long)p, (unsigned long long)i);
+        e->parent[i] = i == 0 ? 0u : (uint32_t)p;
         e->external[i] = rd64(n + 40);
     }
     return NH_OK;
@@ -354,11 +356,13 @@ static int alloc_table(Engine *e, uint64_t capacity) {
             // (not up front: giving 100 GB back to the driver and taking them again costs a run seconds)
             (void)hipGetLastError();
             run_cache_trim();
-            dev_cache_trim();
+            dev_cache_trim();  // (frees on every device it holds buffers of, and leaves the last one selected)
+            (void)dev_set(e->device);
             trimmed = true;
             he = hipMalloc(&e->d_table_raw, bytes);
         }
         if (he == hipSuccess) {
+            if (dev_debug()) dev_register(e->d_table_raw, bytes, e->device);
             e->d_table = (uint32_t *)(((uintptr_t)e->d_table_raw + 127) & ~(uintptr_t)127);
             e->n_copies = want;
             e->copy_stride = stride;
@@ -382,6 +386,44 @@ int refresh_table_copies(Engine *e) {
         HIP_TRY(hipMemcpyAsync(e->d_table + j * e->copy_stride, e->d_table, e->table_cells_alloc * sizeof(uint32_t),
                                hipMemcpyDeviceToDevice, e->stream));
     HIP_TRY(hipStreamSynchronize(e->stream));
+    return NH_OK;
+}
+
+LaunchKnobs read_launch_knobs() {
+    LaunchKnobs kn;
+    if (const char *env = getenv("NOHUMAN_FRAG_CHUNK")) kn.frag_chunk = (uint32_t)std::max(1, atoi(env));
+    if (const char *env = getenv("NOHUMAN_SEG_CAP")) {
+        const long v = atol(env);
+        if (v >= 1) kn.seg_cap = (uint64_t)v;
+    }
+    kn.sched = parse_sched_knobs(getenv("NOHUMAN_SCHED"));
+    return kn;
+}
+
+// Reads every cell of copy 0 once (k_validate_table, ~1.3 ms per 5.7 GB) and refuses what the kernels could not survive
+// or what cannot be a table kraken2-build wrote (TableCheck, nh_internal.h).  Reference: the three files are only checked for
+// existence (src/lib.rs:119-141), and several database versions can be installed side by side (src/download.rs:178-222).
+static int validate_table(Engine *e, bool check_size) {
+    auto t0 = std::chrono::steady_clock::now();
+    unsigned long long *d_out = (unsigned long long *)e->d_counters + CNT_N;  // (two of the spare words behind the counters)
+    unsigned long long out[2] = {0, 0};
+    HIP_TRY(hipMemsetAsync(d_out, 0, sizeof out, e->stream));
+    HIP_TRY(launch_validate_table(e->d_table, e->table_cells_alloc & ~3ull, (uint32_t)((1ull << e->info.value_bits) - 1), d_out, e->stream));
+    HIP_TRY(hipMemcpyAsync(out, d_out, sizeof out, hipMemcpyDeviceToHost, e->stream));
+    HIP_TRY(hipMemsetAsync(d_out, 0, sizeof out, e->stream));
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    e->check.non_empty = out[0];
+    e->check.max_value = out[1];
+    e->check.seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    if (getenv("NOHUMAN_TRACE"))
+        fprintf(stderr, "[nohuman trace] hash table checked in %.4f s: %llu of %llu cells in use (load %.4f), largest value %llu, taxonomy nodes %llu\n",
+                e->check.seconds, out[0], (unsigned long long)e->info.capacity, (double)out[0] / (double)e->info.capacity, out[1],
+                (unsigned long long)e->info.node_count);
+    if (out[1] >= e->info.node_count)
+        return set_error(NH_EDB, "hash.k2d holds the taxon value %llu but taxo.k2d has only %llu nodes: the two files are not of one database",
+                         out[1], (unsigned long long)e->info.node_count);
+    if (check_size && out[0] != e->info.size)
+        return set_error(NH_EDB, "hash.k2d: %llu cells are in use but its header says size %llu", out[0], (unsigned long long)e->info.size);
     return NH_OK;
 }
 
@@ -415,7 +457,9 @@ static int common_open(Engine *e, int device) {
                     e->options.ambiguity_rule == NH_AMBIGUITY_QUEUE ? "queue" : "last l-mer", e->options.linear_probing, e->options.reset_per_mate,
                     e->options.minimum_hit_groups);
     }
+    e->knobs = read_launch_knobs();
     HIP_TRY(hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking));
+    for (unsigned i = 0; i < LAUNCH_SLOTS; i++) HIP_TRY(hipEventCreateWithFlags(&e->slot_ev[i], hipEventDisableTiming));
     HIP_TRY(dev_malloc((void **)&e->d_counters, (CNT_N + 12) * sizeof(uint64_t)));
     HIP_TRY(hipMemset(e->d_counters, 0, (CNT_N + 12) * sizeof(uint64_t)));
     // launch slots start CLEAN and every launch leaves its slot clean again (k_finish_launch)
@@ -454,6 +498,8 @@ void destroy(Engine *e) {
             if (p) (void)hipFree(p);
     for (void *p : {e->st.d_bases, e->st.d_offsets, e->st.d_results, e->st.d_taxa, e->st.d_taxa_off})
         if (p) (void)hipFree(p);
+    for (hipEvent_t ev : e->slot_ev)
+        if (ev) (void)hipEventDestroy(ev);
     if (e->stream) (void)hipStreamDestroy(e->stream);
     delete e;
 }
@@ -489,6 +535,7 @@ int open_images(const void *opts, size_t opts_len, const void *taxo, size_t taxo
             if (he != hipSuccess) rc = set_error(NH_EDEVICE, "table upload: %s", hipGetErrorString(he));
         }
     }
+    if (!rc) rc = validate_table(e, true);
     if (!rc) rc = upload_taxonomy(e);
     if (!rc) rc = refresh_table_copies(e);
     if (rc) {
@@ -655,6 +702,7 @@ int open_dir(const char *db_dir, int device, Engine **out) {
     }
     if (f) fclose(f);
     const double t_d = now_s();
+    if (!rc) rc = validate_table(e, true);
     if (!rc) rc = upload_taxonomy(e);
     if (!rc) rc = refresh_table_copies(e);
     if (trace && !rc)
@@ -738,6 +786,7 @@ int open_synthetic(uint64_t capacity, uint64_t n_keys, uint32_t depth, uint64_t 
         if (he != hipSuccess) rc = set_error(NH_EDEVICE, "synthetic table: %s", hipGetErrorString(he));
         e->info.size = sz;
     }
+    if (!rc) rc = validate_table(e, true);  // (the generator checked like a file: what it inserted is what the table holds)
     if (!rc) rc = refresh_table_copies(e);
     if (rc) {
         destroy(e);
@@ -778,19 +827,19 @@ uint64_t kmer_taxa_entries(const Engine *e, const uint64_t *seq_offsets, uint64_
 
 
 // Every launch takes the next of LAUNCH_SLOTS (scheduling counter, "BIG pass pending" word), so
-// launches in flight on different streams of one engine never share them (more than LAUNCH_SLOTS
-// launches in flight at once on one engine are not supported).
+// launches in flight on different streams of one engine never share them; the launch that takes a slot
+// again waits for the slot's previous launch (Engine::slot_ev): more than LAUNCH_SLOTS launches in flight
+// on one engine are serialised slot by slot, never mixed.
 // Fragments a wave claims at a time.  Their offsets (mates * n + 1) must fit the 64 lanes; larger
 // chunks amortise the claim and the offsets load (measured best: 24 paired, 32 single-end), but a
 // small batch is cut finer so that every resident wave still gets about two chunks.
 static uint32_t frag_chunk_for(const Engine *e, uint32_t flags, uint64_t n_frag) {
     if (flags & NH_FLAG_LONG) return 1;
-    const char *env = getenv("NOHUMAN_FRAG_CHUNK");  // tuning / test knob (read at every launch)
     const bool paired = (flags & NH_FLAG_PAIRED) != 0;
     const uint32_t cap = paired ? 31u : 63u;
-    if (env) {
-        const uint32_t c = (uint32_t)atoi(env);
-        return c < 1 ? 1 : c > cap ? cap : c;
+    if (e->knobs.frag_chunk) {  // NOHUMAN_FRAG_CHUNK (tuning / test knob, read when the engine was opened)
+        const uint32_t c = e->knobs.frag_chunk;
+        return c > cap ? cap : c;
     }
     // 24 pairs / 32 reads = whole batches of 4 tiles (measured best: 31 / 16 / 12 pairs are 1.5-2 % slower, and for a
     // small launch finer chunks lose more at their boundaries than they win at the tail: 1 M single reads 634
@@ -809,19 +858,16 @@ static uint32_t frag_chunk_for(const Engine *e, uint32_t flags, uint64_t n_frag)
 
 // Item buffers of a launch slot for a launch of n_frag long reads: one list entry per read, and items /
 // partial slots for the segments of the reads that get cut (8 per read on average, 2^16 .. 2^20; what does
-// not fit is classified whole).  NOHUMAN_SEG_CAP overrides the number of segments (test knob).
+// not fit is classified whole).  NOHUMAN_SEG_CAP (LaunchKnobs) overrides the number of segments (test knob).
 static int ensure_split(Engine *e, unsigned slot, uint64_t n_frag) {
     std::lock_guard<std::mutex> lock(e->split_mu);
     SplitBufs &sb = e->split[slot];
     uint64_t want_seg = n_frag * 8;
     if (want_seg < (1u << 16)) want_seg = 1u << 16;
     if (want_seg > (1u << 20)) want_seg = 1u << 20;
-    if (const char *env = getenv("NOHUMAN_SEG_CAP")) {
-        const long v = atol(env);
-        if (v >= 1) want_seg = (uint64_t)v;
-    }
+    if (e->knobs.seg_cap) want_seg = e->knobs.seg_cap;
     if (sb.hdr && sb.seg_cap >= want_seg && e->split_single_cap[slot] >= n_frag) return NH_OK;
-    if (sb.hdr && getenv("NOHUMAN_SEG_CAP") && e->split_single_cap[slot] >= n_frag) return NH_OK;
+    if (sb.hdr && e->knobs.seg_cap && e->split_single_cap[slot] >= n_frag) return NH_OK;
     // (re)allocate: the slot's previous launch, if any, has long finished when its turn comes again
     for (void *p : {(void *)sb.hdr, (void *)sb.items_multi, (void *)sb.items_single, (void *)sb.part, (void *)sb.part_done})
         if (p) (void)hipFree(p);
@@ -852,7 +898,6 @@ int classify_device(Engine *e, const void *d_bases, const void *d_seq_off, uint6
                          uint32_t flags, double confidence, void *d_results, void *d_kmer_taxa,
                          const void *d_kmer_taxa_off, void *d_counters, hipStream_t stream,
                          const void *d_seq_len, uint64_t bases_end) {
-    const unsigned slot = e->launch_seq.fetch_add(1) % LAUNCH_SLOTS;
     dev_check(e->device, "classify_device");  // (NOHUMAN_DEBUG_DEVICE: the launch belongs to the engine's device, and so do its buffers)
     dev_check_ptr(d_bases, e->device, "classify_device (sequence text)");
     dev_check_ptr(d_results, e->device, "classify_device (results)");
@@ -879,6 +924,16 @@ int classify_device(Engine *e, const void *d_bases, const void *d_seq_off, uint6
     io.d_kmer_taxa = d_kmer_taxa;
     io.d_kmer_taxa_off = d_kmer_taxa_off;
     io.d_counters = d_counters;
+    // The launch takes the next slot and holds its mutex until its event is recorded: the slot's next user -- this thread
+    // or another, sixteen launches on -- finds the event of the launch before it and makes ITS stream wait for it.
+    const unsigned slot = e->launch_seq.fetch_add(1) % LAUNCH_SLOTS;
+    std::lock_guard<std::mutex> slot_lock(e->slot_mu[slot]);
+#ifndef NH_NO_SLOT_WAIT  // (-DNH_NO_SLOT_WAIT: rounds 1-5's behaviour, to show that tests/test_gpu_threads.py sees the difference)
+    if (e->slot_used[slot] && e->slot_stream[slot] != stream) {  // (the same stream orders its launches by itself)
+        const hipError_t we = hipStreamWaitEvent(stream, e->slot_ev[slot], 0);
+        if (we != hipSuccess) return set_error(NH_EDEVICE, "classify launch (slot wait): %s", hipGetErrorString(we));
+    }
+#endif
     LaunchSlot sl;
     sl.d_error = e->d_error + LAUNCH_SLOTS;
     sl.d_pending = e->d_error + slot;
@@ -897,7 +952,12 @@ int classify_device(Engine *e, const void *d_bases, const void *d_seq_off, uint6
             e->split_fresh[slot] = false;
         }
     }
-    hipError_t he = launch_classify(db, io, confidence, sl, frag_chunk_for(e, flags, n_frag), e->grid_blocks, stream);
+    hipError_t he = launch_classify(db, io, confidence, sl, frag_chunk_for(e, flags, n_frag), e->grid_blocks, stream, e->knobs.sched);
+    if (he == hipSuccess && n_frag) {
+        he = hipEventRecord(e->slot_ev[slot], stream);
+        e->slot_used[slot] = true;
+        e->slot_stream[slot] = stream;
+    }
     if (he != hipSuccess) return set_error(NH_EDEVICE, "classify launch: %s", hipGetErrorString(he));
     return NH_OK;
 }
@@ -1161,9 +1221,25 @@ int nh_synthetic_add_sequences(nh_engine *e_, const void *d_bases, const void *d
 // test hook (not part of the ABI in include/nohuman_engine.h): the claim map a launch of n_frag fragments
 // would get -- out = {n0, n01, total, base1, base2, c0, c1, c2}
 void nh_debug_sched(uint64_t n_frag, uint32_t c0, int mates, uint64_t waves, uint64_t *out) {
-    const nh::Sched sc = nh::make_sched(n_frag, c0, mates, waves);
+    const nh::Sched sc = nh::make_sched(n_frag, c0, mates, waves, nh::parse_sched_knobs(getenv("NOHUMAN_SCHED")));
     const uint64_t v[8] = {sc.n0, sc.n01, sc.total, sc.base1, sc.base2, sc.c0, sc.c1, sc.c2};
     memcpy(out, v, sizeof v);
+}
+
+// test / tuning hook (not part of the ABI): read NOHUMAN_FRAG_CHUNK / NOHUMAN_SEG_CAP / NOHUMAN_SCHED again for an open
+// engine (tools/sweep_sched.py changes them between launches); no launch of the engine may be in flight
+void nh_debug_reload_knobs(nh_engine *e) {
+    if (e) ((Engine *)e)->knobs = nh::read_launch_knobs();
+}
+
+int nh_db_check_get(const nh_engine *e_, nh_db_check *c) {
+    const Engine *e = (const Engine *)e_;
+    if (!e || !c) return set_error(NH_EINVAL, "null argument");
+    c->non_empty_cells = e->check.non_empty;
+    c->max_value = e->check.max_value;
+    c->load_factor = e->info.capacity ? (double)e->check.non_empty / (double)e->info.capacity : 0.0;
+    c->seconds = e->check.seconds;
+    return NH_OK;
 }
 
 int nh_stats_get(nh_engine *e_, nh_stats *s) {

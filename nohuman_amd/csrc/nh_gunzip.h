@@ -70,6 +70,9 @@ public:
     long take(int set, bool use_ahead, void *d_dst, size_t room, hipStream_t stream);
     bool ended() const;
     const std::string &error() const;
+    // error() is a failed END-TO-END check of the decode (a member's CRC-32 or ISIZE, the stream's end), not a resource or a
+    // "cannot go on here" condition: text handed out before it may be wrong
+    bool integrity_failure() const;
     const DevGunzipStats &stats() const;
     void close();
 

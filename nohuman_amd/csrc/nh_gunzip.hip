@@ -1386,8 +1386,7 @@ static void cache_free(int device, size_t bytes, void *p, bool host) {
                 g_cache.erase(g_cache.begin());
             }
         }
-        int dev = -1;
-        (void)hipGetDevice(&dev);
+        const int dev = dev_current();  // (a LOGICAL device: hipGetDevice's ordinal is 0 for every one of NOHUMAN_FAKE_DEVICES)
         for (const CacheEntry &e : out) cache_release(e);
         if (!out.empty() && dev >= 0) (void)dev_set(dev);
         return;
@@ -1533,6 +1532,7 @@ public:
         stage_ahead_ = size_ > seg_ && !(getenv("NOHUMAN_GZDEV_STAGE_AHEAD") && getenv("NOHUMAN_GZDEV_STAGE_AHEAD")[0] == '0');
         if (const char *e = getenv("NOHUMAN_GZDEV_FAKE_START")) fake_start_ = atol(e);  // test knob: a false positive of the search
         if (const char *e = getenv("NOHUMAN_GZDEV_FAKE_SPEC")) fake_spec_ = atol(e);
+        if (const char *e = getenv("NOHUMAN_GZDEV_FAKE_CRC")) fake_crc_ = atol(e);  // test knob: from the k-th piece on the text's CRC-32 comes out wrong
         open_s_ = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_open).count();
         return 0;
     }
@@ -1682,13 +1682,17 @@ private:
     InflateFn inflate_kernel() const { return k_inflate3; }
     size_t inflate_lds() const { return sizeof(Lds3); }
 
-    long fail(const std::string &m) {
-        if (error_.empty()) error_ = "gzip: " + m + " (" + path_ + ")";
+    long fail(const std::string &m, bool integrity = false) {
+        if (error_.empty()) {
+            error_ = "gzip: " + m + " (" + path_ + ")";
+            integrity_ = integrity;
+        }
         return -1;
     }
 
     // per-member bookkeeping like gzip's: CRC-32 and length of what was decoded against the trailer
     bool account(uint32_t crc, uint64_t len) {
+        if (fake_crc_ > 0 && st_.segments + 1 >= (uint64_t)fake_crc_ && len) crc ^= 1u;  // test knob: a wrong decode only the CRC sees
         run_crc_ = crc32_join(run_crc_, crc, len);  // (crc of nothing is 0, and joining to it changes nothing)
         run_len_ += len;
         return true;
@@ -1704,7 +1708,7 @@ private:
                 fprintf(stderr, "[gzdev] member %llu: crc %08x / %08x, length %u / %u (text so far %llu)\n", (unsigned long long)st_.members, run_crc_, crc,
                         (uint32_t)run_len_, isize, (unsigned long long)st_.text_bytes);
             } else {
-                fail(crc != run_crc_ ? "crc error" : "length error");
+                fail(crc != run_crc_ ? "crc error" : "length error", true);
                 return false;
             }
         }
@@ -1982,10 +1986,10 @@ private:
         if (r.total) ratio_ = std::max(ratio_ * 0.9, (double)r.total / std::max<double>(1.0, (double)(r.end_bit - first_bit) / 8));
         pos_bit_ = a_byte * 8 + r.end_bit;
         if (r.stream_end) {
-            if (run_len_) return fail("unexpected end of file");
+            if (run_len_) return fail("unexpected end of file", true);
             ended_ = true;
         } else if ((pos_bit_ >> 3) >= size_) {
-            return fail("unexpected end of file");
+            return fail("unexpected end of file", true);
         }
         return (long)r.total;
     }
@@ -2169,7 +2173,7 @@ private:
         }
         pos_bit_ = eb;
         if (stream_end) {
-            if (run_len_) return fail("unexpected end of file");
+            if (run_len_) return fail("unexpected end of file", true);
             ended_ = true;
         }
         return (long)out.size();
@@ -2196,6 +2200,8 @@ private:
     uint32_t failed_in_a_row_ = 0, last_bad_ = 0;
     uint32_t host_left_ = 0, host_stint_ = 8;  // host mode: steps left of this stint; the next stint's length
     long fake_start_ = -1;
+    long fake_crc_ = 0;
+    bool integrity_ = false;  // the error is one of the END-TO-END checks on the decode: a member's CRC-32 / ISIZE, the stream's end
     double open_s_ = 0;
     size_t in_bytes_ = 0, sym_bytes_ = 0, maps_bytes_ = 0, stage_bytes_ = 0;
     // The bytes of the stream's NEXT piece on their way into the other staging buffer (a helper thread, while this piece's
@@ -2229,6 +2235,7 @@ void DevGunzip::decode_ahead(int set, uint64_t cell, hipStream_t stream) { impl_
 long DevGunzip::take(int set, bool use_ahead, void *d_dst, size_t room, hipStream_t stream) { return impl_->take(set, use_ahead, d_dst, room, stream); }
 bool DevGunzip::ended() const { return impl_->ended_; }
 const std::string &DevGunzip::error() const { return impl_->error_; }
+bool DevGunzip::integrity_failure() const { return impl_->integrity_; }
 const DevGunzipStats &DevGunzip::stats() const { return impl_->st_; }
 void DevGunzip::close() { impl_->close(); }
 
@@ -2640,8 +2647,9 @@ private:
     };
 
     // What stops this reader does not stop the run: the host reader takes the file over from the records handed out so far
-    // (next_batch() == 1) and says what it finds -- a damaged stream fails there with gzip's messages.  Malformed FASTQ in
-    // text whose CRC-32 was right is the input's fault on any reader: hard.
+    // (next_batch() == 1) and says what it finds.  Two things are final (hard): malformed FASTQ in text whose CRC-32 was right
+    // -- the input's fault on any reader --, and a failed CRC-32 / ISIZE / stream end once records have been handed out -- the
+    // check that fails may be about those very records (decode_stage).
     int fail(const std::string &m, bool hard = false) {
         std::lock_guard<std::mutex> lk(err_mu_);  // (the decode stage, the index stage and the lanes' workers may all end here)
         if (error_.empty()) {
@@ -2883,7 +2891,12 @@ private:
             std::lock_guard<std::mutex> lk(mu_);
             ln.state = 0;
         }
-        if (n < 0) return fail(gz_.error());
+        // The members' CRC-32 / ISIZE (and the stream's end) are the only end-to-end check on the device decode, and a member that
+        // spans pieces has had its earlier pieces handed out, classified and written by the time its trailer is read: once records
+        // are out, such a failure ends the RUN (the host reader would decode the file again, pass its own check and
+        // the run would return NH_OK with whatever the device had decoded wrongly already in the outputs).  Nothing handed out
+        // yet: the host reader starts from the top and says what it finds.
+        if (n < 0) return fail(gz_.error(), gz_.integrity_failure() && handed_recs_.load() > 0);
         if (ahead_ && gz_.ahead_ok() && !gz_.ended()) assign_ahead();  // (this lane's next cell is decoded while its piece is indexed)
         p.body_len = (size_t)n;
         p.last = gz_.ended();
@@ -3071,7 +3084,7 @@ private:
     std::mutex err_mu_;            // error_ / hard_
     std::string reason_;           // why next_batch() handed the file over (a copy: the producers may still be ending)
     size_t max_text_ = 0;          // single-end: a batch is cut behind the record that reaches this many bytes (0: by records only)
-    uint64_t handed_recs_ = 0;     // records in the batches handed out
+    std::atomic<uint64_t> handed_recs_{0};  // records in the batches handed out (read by the decode stage when it fails)
     long fail_at_ = 0;             // test knob NOHUMAN_GZDEV_FAIL_AT=k: the reader gives up before the stream's k-th piece (k >= 1)
     std::vector<Lane> lanes_;
     std::vector<Piece> buf_;

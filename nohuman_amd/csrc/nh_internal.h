@@ -24,6 +24,26 @@ struct Staging {  // grow-only device buffers behind nh_classify_batch (host-buf
     size_t cap_bases = 0, cap_offsets = 0, cap_results = 0, cap_taxa = 0, cap_taxa_off = 0;
 };
 
+// Tuning / test knobs of a launch, read from the environment ONCE, when the engine is opened (round 6; rounds 1-5 called
+// getenv at every launch): NOHUMAN_FRAG_CHUNK (fragments a wave claims at a time), NOHUMAN_SEG_CAP (segments a long-read
+// launch may cut), NOHUMAN_SCHED (claim map: "off" or c1,c2,p1,p2).  nh_debug_reload_knobs (a test hook like
+// nh_debug_sched, not part of the ABI) reads them again for the sweeps of tools/.
+struct LaunchKnobs {
+    uint32_t frag_chunk = 0;  // 0: the default for the launch's shape
+    uint64_t seg_cap = 0;     // 0: 8 segments per read, 2^16 .. 2^20
+    SchedKnobs sched;
+};
+LaunchKnobs read_launch_knobs();
+SchedKnobs parse_sched_knobs(const char *env);  // NOHUMAN_SCHED's grammar (nh_kernels.hip, beside make_sched)
+
+// What nh_open* found when it read every cell of the table once (k_validate_table): a cell's value indexes the taxonomy
+// in every kernel, so a value >= node_count (a hash.k2d beside another database's taxo.k2d) is refused with NH_EDB
+// instead of faulting on the GPU; so is a table whose non-empty cells are not the `size` its header states.
+struct TableCheck {
+    uint64_t non_empty = 0, max_value = 0;
+    double seconds = 0;
+};
+
 struct Engine {
     int device = -1;
     int n_cu = 0;
@@ -49,6 +69,16 @@ struct Engine {
     bool split_fresh[LAUNCH_SLOTS] = {};  // buffers allocated, header not yet cleared (the first launch does it)
     std::mutex split_mu;
     std::atomic<unsigned> launch_seq{0};
+    // A launch slot is used by one launch at a time: the launch that takes a slot waits (on the device, hipStreamWaitEvent)
+    // for the event the slot's previous launch recorded behind its k_finish_launch.  With at most LAUNCH_SLOTS launches
+    // in flight -- what every caller in this repo does -- the event has long fired; more than that are ORDERED, not
+    // undefined (rounds 1-5 documented "not supported" and nothing detected it).  slot_mu orders the hosts' enqueues.
+    hipEvent_t slot_ev[LAUNCH_SLOTS] = {};
+    hipStream_t slot_stream[LAUNCH_SLOTS] = {};
+    bool slot_used[LAUNCH_SLOTS] = {};
+    std::mutex slot_mu[LAUNCH_SLOTS];
+    LaunchKnobs knobs;
+    TableCheck check;
     hipStream_t stream = nullptr;
     std::vector<uint32_t> parent;
     std::vector<uint64_t> external;
@@ -63,8 +93,10 @@ extern thread_local std::string g_last_error;
 int set_error(int code, const char *fmt, ...) __attribute__((format(printf, 2, 3)));
 
 hipError_t launch_classify(const DevDB &db, const LaunchIO &io, double confidence, const LaunchSlot &sl,
-                           uint32_t frag_chunk, int grid_blocks, hipStream_t stream);
-Sched make_sched(uint64_t n_frag, uint32_t c0, int mates, uint64_t waves);
+                           uint32_t frag_chunk, int grid_blocks, hipStream_t stream, const SchedKnobs &sched_knobs);
+Sched make_sched(uint64_t n_frag, uint32_t c0, int mates, uint64_t waves, const SchedKnobs &kn);
+hipError_t launch_validate_table(const uint32_t *table, uint64_t n_cells, uint32_t vmask, unsigned long long *d_out2,
+                                 hipStream_t stream);
 int classify_blocks_per_cu();
 hipError_t launch_insert_sequences(const DevDB &db, const void *d_bases, const void *d_seq_off,
                                    uint64_t n_seq, uint32_t value, unsigned long long *d_inserted,

@@ -528,6 +528,22 @@ __device__ __forceinline__ uint32_t carry_entries(const uint64_t pack) {
            (((uint32_t)(pack >> 32) & 0xFFFFu) != 0) + ((uint32_t)(pack >> 48) != 0);
 }
 
+// The 16-byte load of a probe round.  -DNH_PROBE_NT=1 marks it non-temporal (`global_load_dwordx4 ... nt`): the gather
+// microbenchmark measured 50.75 against 47.20 G probes/s for it (profiles/r02_gather_bench.txt; sc1 / sc0 variants: no
+// difference from plain) -- whether the product kernels gain is the A/B of profiles/r06_cache_policy.txt.
+#ifndef NH_PROBE_NT
+#define NH_PROBE_NT 0
+#endif
+typedef uint32_t nh_u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ uint4 probe_load16(const uint32_t *p) {
+#if NH_PROBE_NT
+    const nh_u32x4 v = __builtin_nontemporal_load(reinterpret_cast<const nh_u32x4 *>(p));
+    return make_uint4(v.x, v.y, v.z, v.w);
+#else
+    return *reinterpret_cast<const uint4 *>(p);
+#endif
+}
+
 // stopping cell among 4 loaded cells: the lowest j >= lo that is empty or holds the key
 __device__ __forceinline__ void scan4(const uint4 &c, uint32_t ckey, uint32_t vmask, uint32_t lo, uint32_t &res,
                                       uint32_t &resj) {
@@ -679,7 +695,7 @@ __device__ __forceinline__ void probe_queue(KArgsP ap, WL &S, const int lane,
                 const bool wide = lim > 4u;
                 nvalid = nvalid < lim ? nvalid : lim;
                 lo = (!wide && in_line < 4u) ? 4u - in_line : 0u;
-                const uint4 c0 = *reinterpret_cast<const uint4 *>(src - lo);
+                const uint4 c0 = probe_load16(src - lo);
                 constexpr int WCH = NH_WIDE_CELLS / 4;  // 16-byte chunks of a wide round
                 uint4 cw[WCH];
                 if (wide) {  // only the chunks that hold eligible cells are loaded (every lane-load costs the L1 a cycle)
@@ -687,7 +703,7 @@ __device__ __forceinline__ void probe_queue(KArgsP ap, WL &S, const int lane,
 #pragma unroll
                     for (int q = 1; q < WCH; q++) {
                         cw[q] = make_uint4(0, 0, 0, 0);  // (a stop found in an unloaded chunk lies beyond nvalid: ignored)
-                        if ((uint32_t)q < nch) cw[q] = *reinterpret_cast<const uint4 *>(src + 4 * q);
+                        if ((uint32_t)q < nch) cw[q] = probe_load16(src + 4 * q);
                     }
                 }
                 if (wide) {
@@ -850,7 +866,7 @@ __device__ __forceinline__ void probe_queue_quad(KArgsP ap, WL &S, const int lan
             if (q4 < nvk[k]) {  // (a chunk without eligible cells is not loaded: every line-visit costs the L1)
                 const uint64_t cell = WIDE ? (((uint64_t)(m >> 11) << 32) | p) : (uint64_t)p;
                 const uint32_t copy = WIDE ? ((m >> 8) & 7u) : (m >> 8);
-                c[k] = *reinterpret_cast<const uint4 *>(table + (uint64_t)copy * copy_stride + cell + q4);
+                c[k] = probe_load16(table + (uint64_t)copy * copy_stride + cell + q4);
             }
         }
         bool found = false;
@@ -2184,6 +2200,58 @@ __global__ __launch_bounds__(WAVE * WAVES_PER_BLOCK) void k_insert_sequences(con
     if (lane == 0 && inserted) atomicAdd(&ap->counters[0], inserted);
 }
 
+// ---- database check at open (nh_engine.hip: validate_table) ------------------------------------------------
+// One streaming pass over the cells of copy 0: how many are non-empty (value field != 0: kraken2's CompactHashCell is
+// empty when its value is 0) and the largest value.  Every kernel above indexes parent[] with a cell's value
+// unchecked -- the check is made here, once, at HBM speed (16 bytes a lane a step, one atomic pair per workgroup).
+typedef nh_u32x4 u32x4;
+__global__ __launch_bounds__(256) void k_validate_table(const u32x4 *cells4, const uint64_t n4, const uint32_t vmask,
+                                                        unsigned long long *out2) {
+    unsigned long long cnt = 0;
+    uint32_t mx = 0;
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
+        const u32x4 c = __builtin_nontemporal_load(cells4 + i);  // (read once: no reason to keep the lines in the L2)
+        const uint32_t a = c.x & vmask, b = c.y & vmask, d = c.z & vmask, e = c.w & vmask;
+        cnt += (a != 0) + (b != 0) + (d != 0) + (e != 0);
+        const uint32_t m1 = a > b ? a : b, m2 = d > e ? d : e;
+        const uint32_t m = m1 > m2 ? m1 : m2;
+        mx = m > mx ? m : mx;
+    }
+    for (int d = 32; d >= 1; d >>= 1) {
+        cnt += __shfl_xor(cnt, d, 64);
+        const uint32_t o = (uint32_t)__shfl_xor((int)mx, d, 64);
+        mx = o > mx ? o : mx;
+    }
+    __shared__ unsigned long long s_cnt[4];
+    __shared__ uint32_t s_mx[4];
+    const int w = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) {
+        s_cnt[w] = cnt;
+        s_mx[w] = mx;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int i = 1; i < 4; i++) {
+            cnt += s_cnt[i];
+            mx = s_mx[i] > mx ? s_mx[i] : mx;
+        }
+        if (cnt) atomicAdd(&out2[0], cnt);
+        if (mx) atomicMax(&out2[1], (unsigned long long)mx);
+    }
+}
+
+// n_cells: a multiple of 4 (the allocation's zero padding counts as empty cells); table: 16-byte aligned
+hipError_t launch_validate_table(const uint32_t *table, uint64_t n_cells, uint32_t vmask, unsigned long long *d_out2,
+                                 hipStream_t stream) {
+    const uint64_t n4 = n_cells / 4;
+    if (n4 == 0) return hipSuccess;
+    const uint64_t want = (n4 + 255) / 256;
+    const unsigned grid = (unsigned)(want < 256u * 16u ? want : 256u * 16u);
+    hipLaunchKernelGGL(k_validate_table, dim3(grid), dim3(256), 0, stream, (const u32x4 *)table, n4, vmask, d_out2);
+    return hipGetLastError();
+}
+
 // ---- host-side launchers ---------------------------------------------------------------------
 static bool is_std(const DevDB &db) {
     return db.k == 35 && db.l == 31 && db.revcom_version != 0 && db.min_hash == 0;
@@ -2211,7 +2279,22 @@ static void launch_variant(const KArgs &ka, dim3 g, dim3 b, hipStream_t stream, 
 // end of a launch was an atomic storm that no claim map could see through -- and (b) the tail's claims come
 // from TAIL_SHARDS counters: four times the claim rate in the last moments is more than one word retires.
 // NOHUMAN_SCHED=off: flat; NOHUMAN_SCHED=c1,c2,p1,p2: sizes and tail lengths in percent (tuning knob).
-Sched make_sched(uint64_t n_frag, uint32_t c0, int mates, uint64_t waves) {
+// (the knob is parsed once, when the engine is opened: read_launch_knobs)
+SchedKnobs parse_sched_knobs(const char *env) {
+    SchedKnobs kn;
+    if (!env) return kn;
+    unsigned a = 0, b = 0, c = 0, d = 0;
+    if (strcmp(env, "off") == 0) kn.set = kn.off = true;
+    else if (sscanf(env, "%u,%u,%u,%u", &a, &b, &c, &d) == 4 && a >= 1 && b >= 1) {
+        kn.set = true;
+        kn.c1 = a;
+        kn.c2 = b;
+        kn.p1 = c;
+        kn.p2 = d;
+    }
+    return kn;
+}
+Sched make_sched(uint64_t n_frag, uint32_t c0, int mates, uint64_t waves, const SchedKnobs &kn) {
     Sched sc;
     memset(&sc, 0, sizeof sc);
     if (c0 == 0) c0 = 1;
@@ -2219,15 +2302,13 @@ Sched make_sched(uint64_t n_frag, uint32_t c0, int mates, uint64_t waves) {
     uint32_t c1 = c0 / 2 / step * step, c2 = 3 * step;
     uint64_t p1 = 100, p2 = 100;
     bool guided = c0 >= 4 * step;
-    if (const char *env = getenv("NOHUMAN_SCHED")) {
-        unsigned a = 0, b = 0, c = 0, d = 0;
-        if (strcmp(env, "off") == 0) guided = false;
-        else if (sscanf(env, "%u,%u,%u,%u", &a, &b, &c, &d) == 4 && a >= 1 && b >= 1) {
-            guided = true;
-            c1 = a;
-            c2 = b;
-            p1 = c;
-            p2 = d;
+    if (kn.set) {
+        guided = !kn.off;
+        if (guided) {
+            c1 = kn.c1;
+            c2 = kn.c2;
+            p1 = kn.p1;
+            p2 = kn.p2;
         }
     }
     if (c1 > c0) c1 = c0;
@@ -2253,12 +2334,12 @@ Sched make_sched(uint64_t n_frag, uint32_t c0, int mates, uint64_t waves) {
 }
 
 hipError_t launch_classify(const DevDB &db, const LaunchIO &io, double confidence, const LaunchSlot &sl,
-                           uint32_t frag_chunk, int grid_blocks, hipStream_t stream) {
+                           uint32_t frag_chunk, int grid_blocks, hipStream_t stream, const SchedKnobs &sched_knobs) {
     const uint64_t n_frag = io.n_frag;
     if (n_frag == 0) return hipSuccess;
     if (frag_chunk == 0) frag_chunk = 1;
     // (the launch slot is clean: its previous launch's k_finish_launch, or the engine's start, left it so)
-    const Sched sched = make_sched(n_frag, frag_chunk, io.mates, (uint64_t)grid_blocks * WAVES_PER_BLOCK);
+    const Sched sched = make_sched(n_frag, frag_chunk, io.mates, (uint64_t)grid_blocks * WAVES_PER_BLOCK, sched_knobs);
     uint64_t need = (sched.total + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK;
     int grid = (int)(need < (uint64_t)grid_blocks ? need : (uint64_t)grid_blocks);
     dim3 g(grid), b(WAVE * WAVES_PER_BLOCK);

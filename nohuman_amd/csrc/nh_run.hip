@@ -310,9 +310,15 @@ private:
 // (both readers cut at the same record counts); where a reader had to cut by TEXT (a batch's record text is addressed with 32
 // bits), or the two files came from different readers after a handover, the halves differ in length and the longer one is used
 // in parts: the halves are shared, and go back to their pool (device-born ones: to their reader) when the last part is through.
+// A shared half is READ-ONLY once its first part has been queued (the writer used to fetch a device-born half's
+// text into hb.text in place while the main thread read its size for the next part and the flusher of the part before still
+// held spans into the old buffer): the halves' text lengths are taken when the half arrives (len1 / len2), and a part that
+// must have the bytes on the host after all (a kept record that is rewritten: CRLF, "+id") fetches them into a buffer of its own.
 struct Batch {
     std::shared_ptr<HalfBatch> h1, h2;
     size_t off1 = 0, off2 = 0;
+    size_t len1 = 0, len2 = 0;  // bytes of text of the two halves (the whole half's, also for a part)
+    std::unique_ptr<char[]> fetch1, fetch2;  // this part's own host copy of a half's text (see above), else null
     size_t n = 0;
     int slot = -1;  // stream slot that carries its results
     int dev_index = 0;  // index of the slot's device among the run's engines
@@ -697,14 +703,14 @@ static void reader_main(const char *path, BoundedQueue<std::unique_ptr<HalfBatch
     out->close();
 }
 
-static inline void put_record(std::string &dst, const HalfBatch &hb, const RecRef &r, const char *suffix) {
-    dst.append(hb.text.data() + r.h, r.hlen);
+static inline void put_record(std::string &dst, const char *text, int format, const RecRef &r, const char *suffix) {
+    dst.append(text + r.h, r.hlen);
     if (suffix) dst += suffix;
     dst += '\n';
-    dst.append(hb.text.data() + r.s, r.slen);
-    if (hb.format == FMT_FASTQ) {
+    dst.append(text + r.s, r.slen);
+    if (format == FMT_FASTQ) {
         dst += "\n+\n";
-        dst.append(hb.text.data() + r.q, r.qlen);
+        dst.append(text + r.q, r.qlen);
     }
     dst += '\n';
 }
@@ -715,8 +721,8 @@ static void format_batch(RunState *rs, const Batch &b, const Slot &s, OutFile &o
     const nh_run_args *a = rs->a;
     const Engine *e = s.e;
     const bool keep_class = a->keep_human != 0;
-    const char *t1 = b.h1->text.data();
-    const char *t2 = rs->paired ? b.h2->text.data() : nullptr;
+    const char *t1 = b.fetch1 ? b.fetch1.get() : b.h1->text.data();
+    const char *t2 = !rs->paired ? nullptr : b.fetch2 ? b.fetch2.get() : b.h2->text.data();
     char tmp[128];
     uint64_t bases = 0, classified = 0;
     const RecRef *const R1 = b.h1->recs.data() + b.off1;
@@ -738,7 +744,7 @@ static void format_batch(RunState *rs, const Batch &b, const Slot &s, OutFile &o
                     suffix = tmp;
                 }
                 const size_t from = o1.scratch.size();
-                put_record(o1.scratch, *b.h1, r1, suffix);
+                put_record(o1.scratch, t1, b.h1->format, r1, suffix);
                 o1.add_scratch(from);
             }
             if (rs->paired) {
@@ -747,7 +753,7 @@ static void format_batch(RunState *rs, const Batch &b, const Slot &s, OutFile &o
                     o2.add_raw(t2 + r2.h, r2.raw_end - r2.h);
                 } else {
                     const size_t from = o2.scratch.size();
-                    put_record(o2.scratch, *b.h2, r2, is_class ? tmp : nullptr);
+                    put_record(o2.scratch, t2, b.h2->format, r2, is_class ? tmp : nullptr);
                     o2.add_scratch(from);
                 }
             }
@@ -1002,12 +1008,13 @@ int run_engines(const std::vector<Engine *> &engines, const nh_run_args *a, nh_s
                 uint64_t c3 = StageClock::now();
                 (void)dev_set(s.e->device);
                 const Batch &b = j->b;
-                const size_t base2w = (b.h1->text.size() + 8 + 255) & ~(size_t)255;
+                const size_t base2w = (b.len1 + 8 + 255) & ~(size_t)255;
                 // the batch's raw text is still in the slot's device buffer: an encoder on that GPU takes
                 // the kept records from there instead of a second trip over PCIe
-                if (o1.enc) o1.enc->map_device(b.h1->text.data(), b.h1->text.size(), s.d_text, s.e->device, b.h1->host_text_valid);
+                // (a part that fetched its own host copy has its spans there: they are staged like any host memory)
+                if (o1.enc) o1.enc->map_device(b.h1->text.data(), b.len1, s.d_text, s.e->device, b.h1->host_text_valid);
                 if (rs.paired && o2.enc)
-                    o2.enc->map_device(b.h2->text.data(), b.h2->text.size(), (const char *)s.d_text + base2w, s.e->device, b.h2->host_text_valid);
+                    o2.enc->map_device(b.h2->text.data(), b.len2, (const char *)s.d_text + base2w, s.e->device, b.h2->host_text_valid);
                 if (rs.paired) {
                     std::lock_guard<std::mutex> lk(w2_mu);
                     w2_spans = &j->s2;
@@ -1054,8 +1061,9 @@ int run_engines(const std::vector<Engine *> &engines, const nh_run_args *a, nh_s
                 // whatever else the device is running -- the gzip reader's kernels -- once a batch)
                 if (!wrc && *s.h_flag) wrc = check_error_flag(s.e);
                 if (!wrc) {
-                    const size_t base2w = (b.h1->text.size() + 8 + 255) & ~(size_t)255;
+                    const size_t base2w = (b.len1 + 8 + 255) & ~(size_t)255;
                     // a batch whose text is only in HBM, and a kept record that must be rewritten (CRLF, "+id" line): fetch it
+                    // (into a buffer of this part: the half itself may be in use by other parts -- Batch)
                     auto need_fetch = [&](const HalfBatch &hb) {
                         if (hb.host_text_valid) return false;
                         const size_t off = &hb == b.h1.get() ? b.off1 : b.off2;
@@ -1064,15 +1072,14 @@ int run_engines(const std::vector<Engine *> &engines, const nh_run_args *a, nh_s
                         return false;
                     };
                     for (int m = 0; m < (rs.paired ? 2 : 1) && !wrc; m++) {
-                        HalfBatch &hb = m ? *b.h2 : *b.h1;
+                        const HalfBatch &hb = m ? *b.h2 : *b.h1;
                         if (need_fetch(hb)) {
-                            const size_t L = hb.text.size();
-                            hb.text.clear();
-                            if (!hb.text.reserve(L + 64)) wrc = set_error(NH_EOOM, "out of memory");
-                            hb.text.set_size(L);
-                            if (!wrc && hipMemcpy(hb.text.data(), (const char *)s.d_text + (m ? base2w : 0), hb.text.size(), hipMemcpyDeviceToHost) != hipSuccess)
+                            const size_t L = m ? b.len2 : b.len1;
+                            std::unique_ptr<char[]> &dst = m ? b.fetch2 : b.fetch1;
+                            dst.reset(new (std::nothrow) char[L + 64]);
+                            if (!dst) wrc = set_error(NH_EOOM, "out of memory");
+                            if (!wrc && hipMemcpy(dst.get(), (const char *)s.d_text + (m ? base2w : 0), L, hipMemcpyDeviceToHost) != hipSuccess)
                                 wrc = set_error(NH_EDEVICE, "fetching a batch's text from the device failed");
-                            hb.host_text_valid = wrc == NH_OK;
                         }
                     }
                 }
@@ -1100,29 +1107,32 @@ int run_engines(const std::vector<Engine *> &engines, const nh_run_args *a, nh_s
     std::vector<uint64_t> home_turn((size_t)G, 0);
     // the half of each file in hand and how many of its records have gone out (a half is normally used whole: Batch)
     std::shared_ptr<HalfBatch> c1, c2;
-    size_t p1 = 0, p2 = 0;
-    auto take = [](BoundedQueue<std::unique_ptr<HalfBatch>> &q, BatchPool *pool, std::shared_ptr<HalfBatch> &c, size_t &pos) {
+    size_t p1 = 0, p2 = 0, cl1 = 0, cl2 = 0;  // (cl: the half's bytes of text, read once, when it arrives)
+    auto take = [](BoundedQueue<std::unique_ptr<HalfBatch>> &q, BatchPool *pool, std::shared_ptr<HalfBatch> &c, size_t &pos, size_t &len) {
         std::unique_ptr<HalfBatch> u;
         if (!q.pop(u)) return false;
         c = std::shared_ptr<HalfBatch>(u.release(), [pool](HalfBatch *h) { pool->put(std::unique_ptr<HalfBatch>(h)); });
         pos = 0;
+        len = c->text.size();
         return true;
     };
     for (;;) {
         if (rs.failed()) break;
         Batch b;
         uint64_t m0 = StageClock::now();
-        if (!c1 && !take(q1, &pool1, c1, p1)) break;
-        if (rs.paired && !c2 && !take(q2, &pool2, c2, p2)) break;
+        if (!c1 && !take(q1, &pool1, c1, p1, cl1)) break;
+        if (rs.paired && !c2 && !take(q2, &pool2, c2, p2, cl2)) break;
         // kraken2 reads the files in lockstep and stops at the shorter one.  Both readers cut batches at the same record
         // counts, so the halves normally pair up whole; where they do not (see Batch) the shorter one decides and the rest of
         // the longer one pairs with the other file's next half -- no read is dropped, no run stopped
         b.h1 = c1;
         b.off1 = p1;
+        b.len1 = cl1;
         b.n = c1->recs.size() - p1;
         if (rs.paired) {
             b.h2 = c2;
             b.off2 = p2;
+            b.len2 = cl2;
             b.n = std::min(b.n, c2->recs.size() - p2);
             p2 += b.n;
         }
@@ -1168,7 +1178,7 @@ int run_engines(const std::vector<Engine *> &engines, const nh_run_args *a, nh_s
             b.dev_index = si / NS;
             // (start, length) of every sequence inside the raw text: text of file 1 at byte 0 of the device
             // buffer, text of file 2 behind it
-            const size_t len1 = b.h1->text.size(), len2 = rs.paired ? b.h2->text.size() : 0;
+            const size_t len1 = b.len1, len2 = rs.paired ? b.len2 : 0;
             const size_t base2 = (len1 + 8 + 255) & ~(size_t)255;
             const size_t ntext = rs.paired ? base2 + len2 : len1;
             if (ntext >= (1ull << 32)) {

@@ -134,6 +134,20 @@ class Engine:
         _check(self._L.nh_db_info_get(self._h, C.byref(i)))
         return i
 
+    def db_check(self) -> _lib.nh_db_check:
+        """What the content check of nh_open* found: non-empty cells, largest value, load factor, seconds."""
+        c = _lib.nh_db_check()
+        _check(self._L.nh_db_check_get(self._h, C.byref(c)))
+        return c
+
+    def reload_launch_knobs(self):
+        """Tuning / test hook: NOHUMAN_FRAG_CHUNK / NOHUMAN_SEG_CAP / NOHUMAN_SCHED are read when an engine is opened;
+        this reads them again (no launch may be in flight)."""
+        fn = self._L.nh_debug_reload_knobs
+        fn.restype = None
+        fn.argtypes = [C.c_void_p]
+        fn(self._h)
+
     def options(self) -> _lib.nh_options:
         o = _lib.nh_options()
         _check(self._L.nh_options_get(self._h, C.byref(o)))

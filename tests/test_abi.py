@@ -28,7 +28,7 @@ def test_library_exports_every_declared_symbol():
     L = _lib.lib()  # raises if the .so is missing or lacks a symbol
     for name in _declared_symbols():
         assert getattr(L, name) is not None
-    assert L.nh_abi_version() == 4
+    assert L.nh_abi_version() == 5
 
 
 def test_struct_layouts_match_header():
@@ -38,6 +38,7 @@ def test_struct_layouts_match_header():
     assert C.sizeof(_lib.nh_stats) == 48
     assert C.sizeof(_lib.nh_options) == 16
     assert C.sizeof(_lib.nh_db_info) == 96
+    assert C.sizeof(_lib.nh_db_check) == 32
     assert C.sizeof(_lib.nh_run_args) == 7 * 8 + 8 + 4 * 3 + 4 + 8 + 8
 
 

@@ -108,7 +108,7 @@ def test_the_bench_line_keeps_the_drivers_contract_and_carries_its_numbers_insid
                          env=env, capture_output=True, text=True, timeout=900, cwd=str(tmp_path))
     assert out.returncode == 0, out.stderr[-3000:]
     lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
-    assert len(lines) == 1 and len(lines[0]) < 8000
+    assert len(lines) == 1 and len(lines[0]) < 12000
     d = json.loads(lines[0])
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data",
               "config", "roofline", "cpu_baseline"):
@@ -117,13 +117,24 @@ def test_the_bench_line_keeps_the_drivers_contract_and_carries_its_numbers_insid
     r = d["roofline"]
     assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3
     assert r["value_two_streams"] > 0 and r["wake_launches"] >= 1
-    assert set(r["variants"]) == {"se", "hit", "ont", "wide", "pe250"}
+    assert set(r["variants"]) == {"se", "hit", "ont", "wide", "pe250", "n"}
     for name, v in r["variants"].items():
         assert v["gpu_equals_oracle"] is True and v["frac"] > 0 and v["kernel_ms"] > 0 and v["value_two_streams"] > 0, name
+        # the driver's record keeps scalars only -- the same numbers as roofline.<variant>_<what>
+        assert r[name + "_frac"] == v["frac"] and r[name + "_kernel_ms"] == v["kernel_ms"] and r[name + "_equals_oracle"] is True, name
+        assert r[name + "_value"] == v["value"] and r[name + "_frac_two_streams"] == v["frac_two_streams"], name
+    assert 0 < r["n_frac"] and r["variants"]["n"]["lookups_per_read"] < r["variants"]["se"]["lookups_per_read"]  # (N kills look-ups)
+    assert r["kernel_ms_without_wake"] > 0 and r["value_without_wake"] > 0
     e = d["config"]["e2e"]
     assert e["outputs_equal_inputs"] is True and e["gzip_to_plain"]["value"] > 0 and e["gzip_to_gzip"]["value"] > 0
     assert e["ont_gzip_to_gzip"]["outputs_equal_inputs"] is True and e["ont_gzip_to_gzip"]["reads"] == 6000
     assert set(e["readers_by_name"]) == {"device", "host"} and e["gzip_encoder"]["inflates_to_the_text"] is True
+    c = d["config"]
+    assert c["e2e_gzip_to_plain"] == e["gzip_to_plain"]["value"] and c["e2e_gzip_to_gzip"] == e["gzip_to_gzip"]["value"]
+    assert c["e2e_input_side"] == e["input_side_only"]["value"] and c["e2e_ont_gzip_to_gzip"] == e["ont_gzip_to_gzip"]["value"]
+    assert c["e2e_outputs_equal_inputs"] is True and isinstance(c["e2e_reader"], str) and c["e2e_pairs"] == 40000
+    assert c["e2e_host_reader_gzip_to_gzip"] == e["readers_by_name"]["host"]["gzip_to_gzip"]
+    assert all(not isinstance(v, (dict, list)) for k, v in c.items() if k.startswith("e2e_"))
     assert d["cpu_baseline"]["kind"] == "port" and d["cpu_baseline"]["gpu_equals_oracle"] is True
     assert isinstance(d["config"]["workload"], str) and len(d["config"]["workload"]) < 200
     details = json.load(open(tmp_path / "bench_details.json"))

@@ -112,6 +112,40 @@ def test_the_reader_on_the_gpu_hands_over_mid_stream(tmp_path, monkeypatch, capf
     assert dev == host and host[3][0] == raw1.count(b"\n") // 4
 
 
+@pytest.mark.parametrize("paired", [False, True])
+def test_a_wrong_decode_seen_only_by_the_crc_fails_the_run_once_records_are_out(tmp_path, monkeypatch, capfd, paired):
+    """the member's CRC-32 is the only end-to-end check on the device inflate, and a one-member file of
+    many pieces has its early pieces handed out, classified and written before the trailer is read.  A wrong decode that only
+    the CRC sees (NOHUMAN_GZDEV_FAKE_CRC=k: from the k-th piece on the text's CRC comes out wrong; the file itself is fine,
+    so the host reader would pass ITS check) must fail the run -- round 5 handed the file to the host reader and returned
+    NH_OK with the suspect records already in the output.  With nothing handed out yet (the whole file in one piece: the
+    trailer is read before the first batch goes out) the handover stays: the host reader starts from the top."""
+    from nohuman_amd import EngineError
+    raw1, raw2 = _short_then_long(7, 6000, 0, tag=b"/1"), _short_then_long(8, 6000, 0, tag=b"/2")  # (some forty pieces a file)
+    p1, p2 = tmp_path / "r_1.fq.gz", tmp_path / "r_2.fq.gz"
+    p1.write_bytes(gzip.compress(raw1, 6))
+    p2.write_bytes(gzip.compress(raw2, 6))
+    _small_scale(monkeypatch, batch=100)
+    monkeypatch.setenv("NOHUMAN_GZDEV_SEG", "16384")
+    monkeypatch.setenv("NOHUMAN_GZDEV_STRETCH", "2048")
+    monkeypatch.delenv("NOHUMAN_GZ_READER", raising=False)
+    monkeypatch.setenv("NOHUMAN_GZDEV_FAKE_CRC", "9")
+    with pytest.raises(EngineError) as ei:
+        _run(tmp_path, "dev", p1, p2 if paired else None)
+    assert "crc error" in str(ei.value), str(ei.value)
+    assert "the host reader goes on from record" not in capfd.readouterr().err
+    # one piece holds the whole file: the check fails before a record has gone out, and the host reader reads the (good) file
+    monkeypatch.setenv("NOHUMAN_GZDEV_SEG", str(64 << 20))
+    monkeypatch.setenv("NOHUMAN_GZDEV_ROOM", str(64 << 20))
+    monkeypatch.setenv("NOHUMAN_GZDEV_FAKE_CRC", "1")
+    dev = _run(tmp_path, "dev1", p1, p2 if paired else None)
+    assert "the host reader goes on from record 0" in capfd.readouterr().err
+    monkeypatch.delenv("NOHUMAN_GZDEV_FAKE_CRC")
+    monkeypatch.setenv("NOHUMAN_GZ_READER", "host")
+    host = _run(tmp_path, "host", p1, p2 if paired else None)
+    assert dev == host and host[3][0] == raw1.count(b"\n") // 4
+
+
 def test_a_one_character_header_line_is_malformed_on_both_readers(tmp_path, monkeypatch):
     """the host parser (and kraken2) end the input at an empty line or a lone '@', anything else without '@' is
     malformed -- a one-character line too; the record kernel used to end the input there silently."""

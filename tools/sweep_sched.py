@@ -1,4 +1,5 @@
-"""Sweeps launch-scheduling settings (NOHUMAN_SCHED / NOHUMAN_FRAG_CHUNK are read at every launch) on the
+"""Sweeps launch-scheduling settings (NOHUMAN_SCHED / NOHUMAN_FRAG_CHUNK: read when an engine is opened, and again by
+Engine.reload_launch_knobs(), which every setting here calls) on the
 bench shapes in ONE process, interleaved passes (boxes and processes differ by a few percent; only numbers
 of one call compare).  usage: sweep_sched.py [--passes 3] [--steps 20] [shape ...]   shapes: pe se hit ont"""
 import os, sys, time
@@ -49,6 +50,8 @@ def run(w, env):
     for k in ("NOHUMAN_SCHED", "NOHUMAN_FRAG_CHUNK"):
         os.environ.pop(k, None)
     os.environ.update(env)
+    torch.cuda.synchronize()
+    w["eng"].reload_launch_knobs()
     st = torch.cuda.current_stream().cuda_stream
     def step(i):
         w["eng"].classify_device(w["pool"][i % 2].data_ptr(), w["offs"].data_ptr(), w["n"], w["paired"], 0.0,
