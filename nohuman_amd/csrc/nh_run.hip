@@ -921,7 +921,7 @@ int run_engines(const std::vector<Engine *> &engines, const nh_run_args *a, nh_s
     int prefill1 = prefill, prefill2 = prefill;
     // which reader takes a gzip input: NOHUMAN_GZ_READER by name ("device", "host", "device-text"), else by the input
     // (device_reader_pays); paired files go the same way (the smaller file decides)
-    bool dev_reader1 = false, dev_reader2 = false;
+    bool dev_reader1 = false, dev_reader2 = false, split_readers = false;
     {
         const char *how = getenv("NOHUMAN_GZ_READER");
         const bool off = how && (!strcmp(how, "host") || !strcmp(how, "device-text"));
@@ -931,6 +931,10 @@ int run_engines(const std::vector<Engine *> &engines, const nh_run_args *a, nh_s
         dev_reader1 = !off && dev_gunzip_wants(a->in1) && (named || device_reader_pays(a->in1, mean_rec, host_text_wanted, by_host));
         dev_reader2 = rs.paired && !off && dev_gunzip_wants(a->in2) && (named || device_reader_pays(a->in2, mean_rec, host_text_wanted, by_host));
         if (rs.paired && !named && dev_reader1 != dev_reader2 && dev_gunzip_wants(a->in1) && dev_gunzip_wants(a->in2)) dev_reader1 = dev_reader2 = false;
+        // "split": the two mate files on the two KINDS of reader at once -- file 1 inflated and indexed on the GPU, file 2 by all
+        // the host's inflate workers (round 6: the GPU's codec kernels and the host's cores idle in turn otherwise)
+        split_readers = rs.paired && how && !strcmp(how, "split") && dev_gunzip_wants(a->in1) && dev_gunzip_wants(a->in2);
+        if (split_readers) dev_reader1 = true, dev_reader2 = false;
         if (getenv("NOHUMAN_TRACE"))
             fprintf(stderr, "[nohuman trace] gzip reader: %s%s%s\n", dev_reader1 ? "GPU" : "host", rs.paired ? (dev_reader2 ? " / GPU" : " / host") : "",
                     how ? " (NOHUMAN_GZ_READER)" : "");
@@ -945,6 +949,8 @@ int run_engines(const std::vector<Engine *> &engines, const nh_run_args *a, nh_s
     unsigned gz_threads = (a->threads ? a->threads : 1) / (unsigned)mates;
     if (gz_threads < 1) gz_threads = 1;
     if (gz_threads > 16) gz_threads = 16;  // beyond that the record parser of the file is the limit
+    unsigned gz_threads2 = gz_threads;
+    if (split_readers) gz_threads2 = std::min(16u, std::max(1u, a->threads ? a->threads : 1u));  // (file 1's reader is on the GPU: every worker to file 2)
     // gzip inputs are read on the GPU (nh_gunzip.hip): file 1 on the first device, file 2 on the second where there is one
     // ... piece by piece over the run's devices (the compressed ranges are the shards): file 1 starts on the
     // first device, file 2 on the second, so the two files' pieces of the same moment sit on different GPUs
@@ -960,7 +966,7 @@ int run_engines(const std::vector<Engine *> &engines, const nh_run_args *a, nh_s
     }
     std::thread t1(reader_main, a->in1, &q1, &rs, &pool1, &clk, 0, BATCH_FRAGS, BATCH_TEXT, gz_threads, devs1, dev_reader1);
     std::thread t2;
-    if (rs.paired) t2 = std::thread(reader_main, a->in2, &q2, &rs, &pool2, &clk, 1, BATCH_FRAGS, BATCH_TEXT, gz_threads, devs2, dev_reader2);
+    if (rs.paired) t2 = std::thread(reader_main, a->in2, &q2, &rs, &pool2, &clk, 1, BATCH_FRAGS, BATCH_TEXT, gz_threads2, devs2, dev_reader2);
 
     // writer: consumes batches in order; each arrives after its stream was synchronised.  Two stages: the WRITER
     // waits for the batch's stream, decides and formats (span lists, nothing is copied); the FLUSHER writes the spans

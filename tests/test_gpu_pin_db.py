@@ -18,10 +18,28 @@ def test_real_database_loads_and_agrees_with_the_oracle():
     from nohuman_amd import Engine, validate_db_directory
     from oracle import oracle as orc
     from tests import synth
+    import struct
+    from nohuman_amd import EngineError
     d = validate_db_directory(PIN)
     sizes = {n: os.path.getsize(os.path.join(d, n)) for n in ("hash.k2d", "opts.k2d", "taxo.k2d")}
-    with Engine.open(d) as eng:
+    # the headers as the FILES state them, read here without the engine: if nh_open refuses the database (round 6: it checks
+    # every cell's value against the taxonomy and the number of cells in use against the header) the verdict still says why
+    with open(os.path.join(d, "hash.k2d"), "rb") as f:
+        h_cap, h_size, h_kb, h_vb = struct.unpack("<4Q", f.read(32))
+    with open(os.path.join(d, "taxo.k2d"), "rb") as f:
+        t_magic, t_nodes = f.read(8), struct.unpack("<Q", f.read(8))[0]
+    print("hash.k2d header: capacity %d, size %d, key_bits %d, value_bits %d; taxo.k2d: magic %r, %d nodes" % (h_cap, h_size, h_kb, h_vb, t_magic, t_nodes))
+    try:
+        eng_cm = Engine.open(d)
+    except EngineError as ex:
+        print("FORMAT VERDICT: nh_open REFUSED the database: %s  (PINDAY.md says what each refusal means)" % ex.message)
+        raise
+    with eng_cm as eng:
         i = eng.info
+        chk = eng.db_check()
+        print("FORMAT VERDICT (content check of nh_open, one pass over the table on the GPU in %.4f s): %d cells in use == header size %d, "
+              "load factor %.4f, largest value %d < %d taxonomy nodes" % (chk.seconds, chk.non_empty_cells, i.size, chk.load_factor, chk.max_value, i.node_count))
+        assert chk.non_empty_cells == i.size and chk.max_value < i.node_count
         print("real database %s: capacity %d, size %d (load %.3f), key_bits %d, value_bits %d, nodes %d, k %d, l %d, "
               "spaced 0x%x, toggle 0x%x, min_hash %d, revcom_version %d"
               % (d, i.capacity, i.size, i.size / i.capacity, i.key_bits, i.value_bits, i.node_count, i.k, i.l,

@@ -69,8 +69,10 @@ def _check(torch, launches, cnt, what):
         got = out.cpu().numpy().view(np.uint32)
         for j, f in enumerate(("call", "total_kmers", "clade_hits", "hit_groups")):
             bad = np.flatnonzero(got[:, j] != b["exp"][f])
-            assert bad.size == 0, "%s: launch %d (%s): %d of %d records differ in %s, first at %d" % (
-                what, i, b["kind"], bad.size, b["n"], f, bad[0])
+            assert bad.size == 0, "%s: launch %d (%s): %d of %d records differ in %s, first at %d: got %r, expected %r; %d records never written" % (
+                what, i, b["kind"], bad.size, b["n"], f, bad[0], got[bad[0]].tolist(), [int(b["exp"][g][bad[0]]) for g in
+                                                                                         ("call", "total_kmers", "clade_hits", "hit_groups")],
+                int((got == 0xFFFFFFFF).all(axis=1).sum()))
         tot += (b["n"], int((b["exp"]["call"] != 0).sum()), b["n_bases"], b["lookups"])
     assert cnt.cpu().numpy().tolist() == tot.tolist(), what
 
@@ -90,15 +92,17 @@ def test_forty_launches_in_flight_on_several_streams(toy_engine, work, n_streams
     dev = torch.device("cuda:0")
     streams = [torch.cuda.Stream(device=dev) for _ in range(n_streams)]
     cnt = torch.zeros(4, dtype=torch.int64, device=dev)
-    torch.cuda.synchronize()
-    _hold(torch, streams)
+    # (the outputs are made and filled BEFORE the streams are parked: torch fills on its default stream, which is not
+    #  ordered with the launches' streams -- a fill queued beside a parked launch can land after it)
     launches = []
     for i in range(40):
         b = work[(i * 5 + i // 7) % len(work)]
-        out = torch.full((b["n"], 4), -1, dtype=torch.int32, device=dev)
+        launches.append((b, torch.full((b["n"], 4), -1, dtype=torch.int32, device=dev)))
+    torch.cuda.synchronize()
+    _hold(torch, streams)
+    for i, (b, out) in enumerate(launches):
         toy_engine.classify_device(b["d_bases"].data_ptr(), b["d_offs"].data_ptr(), b["n"], b["paired"], b["conf"],
                                    out.data_ptr(), cnt.data_ptr(), streams[i % n_streams].cuda_stream, long_reads=b["long"])
-        launches.append((b, out))
     _check(torch, launches, cnt, "%d streams" % n_streams)
 
 
