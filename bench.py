@@ -71,6 +71,9 @@ def parse_args(argv=None):
     ap.add_argument("--e2e-distinct", type=int, default=5,
                     help="distinct members generated (they repeat in rotation: compressing 36 GB of text at level 6 takes "
                          "the host two minutes, and the default run has to stay within a few)")
+    ap.add_argument("--e2e-multi-pairs", type=int, default=20_000_000,
+                    help="--gpus N > 1: pairs PER DEVICE of the one-process nh_run(n_devices = N) leg (configs[4] shape, cyclic members)")
+    ap.add_argument("--multi-child", default=None, help=argparse.SUPPRESS)  # internal: the fresh process of that leg
     ap.add_argument("--confidence", type=float, default=0.0)
     ap.add_argument("--hit-frac", type=float, default=0.0,
                     help="fraction of the fragments of every batch made 'human': their minimizers are "
@@ -415,6 +418,8 @@ def measure(cx, args, *, steps, warmup, single_end=False, ont=False, hit_frac=0.
 
 def main():
     args = parse_args()
+    if args.multi_child:
+        raise SystemExit(e2e_multi_child(args.multi_child))
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         raise SystemExit(launch_ranks(args))
 
@@ -518,9 +523,15 @@ def main():
             out["config"].setdefault("e2e", {}).update(ont_nums)
         except Exception as ex:
             out["config"].setdefault("e2e", {})["ont_error"] = repr(ex)[:300]
-    live["eng"].close()
-    del live
-    torch.cuda.empty_cache()
+    # ---- --gpus N > 1: the PRODUCT's own multi-device path -- ONE process, nh_run(n_devices = N): lanes of the gzip reader
+    # over the devices, peer copies, ncclCommInitAll, one writer per file -- which N single-device rank processes never
+    # touch.  Rank 0 writes the inputs and the database directory now and runs the leg in a FRESH child
+    # process once every rank has closed its engine and left the process group (below).
+    multi = cx.rank == 0 and cx.world > 1 and not args.no_e2e and not (args.ont or args.single_end)
+    if not multi:  # (rank 0 keeps its engine until the leg's database directory is written, below)
+        live["eng"].close()
+        del live
+        torch.cuda.empty_cache()
     # ---- the output stage on its own: the GPU gzip encoder on FASTQ text (N=1 only) ------------------------------
     if solo and not args.no_e2e and plain_pe:
         try:
@@ -576,13 +587,28 @@ def main():
                     out["roofline"]["%s_%s" % (name, short)] = v[key]
             if "skipped" in v:
                 out["roofline"]["%s_skipped" % name] = v["skipped"][:120]
+    if cx.world > 1:
+        dist.barrier()  # (every other rank's engine is closed; they leave now, rank 0 goes on alone)
+        dist.destroy_process_group()
+    if multi:
+        multi_spec = None
+        try:
+            multi_spec = e2e_multi_prepare(cx, args, live["eng"])
+            live["eng"].close()
+            del live
+            torch.cuda.empty_cache()
+            out["config"].setdefault("e2e", {})["multi"], details["e2e_multi"] = e2e_multi_run(multi_spec)
+        except Exception as ex:
+            out["config"].setdefault("e2e", {})["multi"] = {"error": repr(ex)[:300]}
+        finally:
+            if multi_spec:
+                import shutil
+                shutil.rmtree(multi_spec["tmp"], ignore_errors=True)
     flatten_e2e(out["config"])
     if cx.rank == 0:
         write_details(details)
     if cx.rank == 0:
         print(json.dumps(out), flush=True)
-    if cx.world > 1:
-        dist.destroy_process_group()
 
 
 def flatten_e2e(config):
@@ -1028,6 +1054,199 @@ def e2e_member(cx, n, L, tag, member, path):
     return n * reclen
 
 
+def make_e2e_inputs(cx, args, tmp, n, L, reps, threads):
+    """The gzip FASTQ pair of the e2e legs in `tmp`: two files of `reps` gzip members of n synthetic pairs each, the distinct
+    members in rotation (A B C D E A B ...), level 6 by the library's block-parallel host encoder.  Returns the files and what
+    the output checks need: every member's text length and xxh3-64."""
+    import shutil
+    import threading
+    from nohuman_amd import _lib
+    t0 = time.time()
+    files = [os.path.join(tmp, "r_%d.fq.gz" % tag) for tag in (1, 2)]
+    distinct = max(1, min(reps, args.e2e_distinct))
+    dist_hash = {1: [None] * distinct, 2: [None] * distinct}
+    dist_len = {1: [0] * distinct, 2: [0] * distinct}
+    errors = []
+
+    host_gz = []  # (bytes of text, seconds) of the host encoder at work on the inputs
+
+    def compress_member(plain, tag, k):  # member k is compressed while member k+1 is generated
+        try:
+            dist_hash[tag][k] = _hash_file_ranges(plain, [(0, os.path.getsize(plain))])[0]
+            tc = time.perf_counter()
+            if _lib.lib().nh_compress_file(os.fsencode(plain), os.fsencode(plain + ".gz"), 2, max(1, threads // 2)) != 0:
+                raise RuntimeError("nh_compress_file failed")
+            host_gz.append((os.path.getsize(plain), time.perf_counter() - tc))
+            os.remove(plain)
+        except Exception as ex:  # surfaced after the join
+            errors.append(ex)
+
+    pending = []
+    for k in range(distinct):
+        for tag in (1, 2):
+            plain = os.path.join(tmp, "m_%d_%d.fq" % (k, tag))
+            dist_len[tag][k] = e2e_member(cx, n, L, tag, k, plain)
+            while len(pending) >= 2:
+                pending.pop(0).join()
+            th = threading.Thread(target=compress_member, args=(plain, tag, k))
+            th.start()
+            pending.append(th)
+    for th in pending:
+        th.join()
+    if errors:
+        raise errors[0]
+    # the input files: `reps` members, the distinct ones in rotation (A B C D E A B ...)
+    member_hash = {tag: [dist_hash[tag][i % distinct] for i in range(reps)] for tag in (1, 2)}
+    member_len = {tag: [dist_len[tag][i % distinct] for i in range(reps)] for tag in (1, 2)}
+    for tag in (1, 2):
+        with open(files[tag - 1], "wb") as out:
+            for i in range(reps):
+                with open(os.path.join(tmp, "m_%d_%d.fq.gz" % (i % distinct, tag)), "rb") as src:
+                    shutil.copyfileobj(src, out, 16 << 20)
+        for k in range(distinct):
+            os.remove(os.path.join(tmp, "m_%d_%d.fq.gz" % (k, tag)))
+    t_setup = time.time() - t0
+    text_bytes = sum(member_len[1]) + sum(member_len[2])
+    gz_bytes = sum(os.path.getsize(f) for f in files)
+    return dict(files=files, member_len=member_len, member_hash=member_hash, text_bytes=text_bytes, gz_bytes=gz_bytes,
+                t_setup=t_setup, host_gz=host_gz, distinct=distinct)
+
+
+def e2e_multi_prepare(cx, args, eng):
+    """Inputs and database directory (tmpfs) of the one-process multi-device leg: a cyclic configs[4]-shaped gzip pair of
+    `--e2e-multi-pairs` pairs per device (scaled down to what the host's memory holds, scale stated), and the engine's table
+    written out as hash.k2d / opts.k2d / taxo.k2d -- nh_run() loads the database into every device itself."""
+    import shutil
+    import tempfile
+    from nohuman_amd.dist import usable_cpu_count
+    N = cx.world
+    n, L = args.e2e_pairs, args.read_len
+    want = max(1, -(-N * args.e2e_multi_pairs // n))  # members per file
+    base = "/dev/shm" if os.path.isdir("/dev/shm") and os.access("/dev/shm", os.W_OK) else None
+    info = eng.info
+    db_bytes = 4 * info.capacity + (1 << 20)
+    try:
+        free = shutil.disk_usage(base or tempfile.gettempdir()).free
+        with open("/proc/meminfo") as f:
+            avail = [int(x.split()[1]) * 1024 for x in f if x.startswith("MemAvailable:")][0]
+        room = min(free, avail)
+    except (OSError, IndexError, ValueError):
+        room = 1 << 62
+    # per member pair: gzip in + gzip out (4.1 : 1 each) and, while ONE output is checked, its text
+    per_rep = n * 2 * (51 + 2 * L + 4) * (2 / 4.0) + n * (51 + 2 * L + 4)
+    reps = want
+    while reps > 1 and per_rep * reps + db_bytes + (16 << 30) > 0.6 * room:
+        reps -= 1
+    tmp = tempfile.mkdtemp(prefix="nh_bench_multi_", dir=base)
+    try:
+        threads = usable_cpu_count()
+        inp = make_e2e_inputs(cx, args, tmp, n, L, reps, threads)
+        db = os.path.join(tmp, "db")
+        write_k2_db(db, eng.opts_image(), eng.taxonomy_image(), (info.capacity, info.size, info.key_bits, info.value_bits), eng.download_table())
+    except Exception:
+        shutil.rmtree(tmp, ignore_errors=True)
+        raise
+    return dict(tmp=tmp, db=db, files=inp["files"], member_len={str(k): v for k, v in inp["member_len"].items()},
+                member_hash={str(k): v for k, v in inp["member_hash"].items()}, pairs=n * reps, wanted_pairs=n * want, devices=N,
+                threads=threads, text_bytes=inp["text_bytes"], gz_bytes=inp["gz_bytes"], setup_s=round(inp["t_setup"], 1),
+                fake_devices=bool(getattr(cx, "one_gpu", False)))
+
+
+def e2e_multi_child(spec_path):
+    """The fresh process of the multi-device leg (python bench.py --multi-child spec.json): nh_run(n_devices = N), gzip in ->
+    gzip out, twice (the second run finds the process's buffers warm, like the single-device legs); one JSON line."""
+    spec = json.load(open(spec_path))
+    import nohuman_amd
+    o1, o2 = os.path.join(spec["tmp"], "mo_1.fq.gz"), os.path.join(spec["tmp"], "mo_2.fq.gz")
+    runs = []
+    for k in range(2):
+        for pth in (o1, o2):
+            if os.path.exists(pth):
+                os.remove(pth)
+        tr_path = os.path.join(spec["tmp"], "multi_trace_%d.txt" % k)
+        saved = os.dup(2)
+        fd = os.open(tr_path, os.O_WRONLY | os.O_CREAT | os.O_TRUNC, 0o600)
+        os.environ["NOHUMAN_TRACE"] = "1"
+        try:
+            os.dup2(fd, 2)
+            t = time.perf_counter()
+            st = nohuman_amd.engine.run(spec["db"], spec["files"][0], o1, in2=spec["files"][1], out2=o2, threads=spec["threads"],
+                                        device_ids=list(range(spec["devices"])), out_codec=2, codec_threads=max(1, spec["threads"] // 2))
+            dt = time.perf_counter() - t
+        finally:
+            os.dup2(saved, 2)
+            os.close(saved)
+            os.close(fd)
+        tr = open(tr_path).read()
+        pick = lambda key: [ln.split("]", 1)[1].strip() for ln in tr.splitlines() if key in ln]  # noqa: E731
+        runs.append({"wall_s": round(dt, 4), "run_s": round(st.seconds, 4), "total": int(st.total_sequences), "classified": int(st.classified),
+                     "pieces_by_device": pick("pieces by device"), "counters": pick("counters reduced by"), "phases": pick("nh_run: database into HBM"),
+                     "warn": [ln for ln in tr.splitlines() if "WARN" in ln or "DEVICE DISCIPLINE" in ln][:4]})
+    print(json.dumps({"multi_child": runs}), flush=True)
+    return 0
+
+
+def e2e_multi_run(spec):
+    """Starts the child, checks its outputs (each inflated by the library's host decoder, xxh3-64 per member == the generated
+    text), and condenses what it printed: Mreads/s over the run's own seconds (database load excluded, as kraken2's timer),
+    which device decoded how many pieces of each input, what reduced the counters."""
+    import ctypes
+    import re
+    from nohuman_amd import _lib
+    sp = os.path.join(spec["tmp"], "spec.json")
+    with open(sp, "w") as fo:
+        json.dump(spec, fo)
+    env = dict(os.environ)
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "TORCHELASTIC_RUN_ID", "GROUP_RANK", "ROLE_RANK"):
+        env.pop(k, None)
+    if spec["fake_devices"]:  # NOHUMAN_BENCH_ONE_GPU: N logical devices on the one GPU (nh_internal.h)
+        env["NOHUMAN_FAKE_DEVICES"] = str(spec["devices"])
+    t = time.perf_counter()
+    p = subprocess.run([sys.executable, os.path.abspath(__file__), "--multi-child", sp], env=env, capture_output=True, text=True,
+                       timeout=3600)
+    t_child = time.perf_counter() - t
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith('{"multi_child"')]
+    if p.returncode != 0 or not lines:
+        raise RuntimeError("multi-device child failed (%d): %s" % (p.returncode, (p.stderr or p.stdout)[-400:]))
+    runs = json.loads(lines[-1])["multi_child"]
+    best = min(runs, key=lambda r: r["run_s"])
+    ok = {}
+    threads = spec["threads"]
+    for tag in ("1", "2"):  # one output at a time: its text is in tmpfs only while it is checked
+        gzp = os.path.join(spec["tmp"], "mo_%s.fq.gz" % tag)
+        plain = os.path.join(spec["tmp"], "mo_%s.fq" % tag)
+        st3 = (ctypes.c_uint64 * 3)()
+        rc = _lib.lib().nh_gunzip_file(os.fsencode(gzp), os.fsencode(plain), threads, 0, st3)
+        os.remove(gzp)
+        offs, pos = [], 0
+        for ln in spec["member_len"][tag]:
+            offs.append((pos, ln))
+            pos += ln
+        ok[tag] = rc == 0 and os.path.getsize(plain) == pos and _hash_file_ranges(plain, offs) == spec["member_hash"][tag]
+        os.remove(plain)
+    pieces = {}
+    for ln in best["pieces_by_device"]:  # "gzip reader, <path>: pieces by device (device:pieces) 0:3 1:2"
+        m = re.search(r"gzip reader, (\S+): pieces by device \(device:pieces\)(.*)", ln)
+        if m:
+            pieces[os.path.basename(m.group(1))] = m.group(2).strip()
+    load = re.search(r"database into HBM ([0-9.]+) s", " ".join(best["phases"]))
+    backend = (best["counters"] or ["host sums (no collective ran)"])[0].replace("counters reduced by ", "")
+    nums = {
+        "value": round(2 * best["total"] / best["run_s"] / 1e6, 3), "unit": "Mreads/s", "wall_s": best["run_s"], "call_wall_s": best["wall_s"],
+        "db_load_s": float(load.group(1)) if load else None, "devices": spec["devices"],
+        "logical_devices_on_one_gpu": bool(spec["fake_devices"]), "pairs": best["total"], "pairs_per_device": best["total"] // spec["devices"],
+        "scale_of_request": round(spec["pairs"] / max(spec["wanted_pairs"], 1), 3), "host_threads": threads,
+        "rccl_backend": backend[:120], "pieces_by_device": "; ".join("%s %s" % kv for kv in sorted(pieces.items()))[:200],
+        "outputs_equal_inputs": bool(ok["1"] and ok["2"] and best["total"] == spec["pairs"] and best["classified"] == 0),
+        "first_run_wall_s": runs[0]["run_s"], "warnings": len(best["warn"]),
+    }
+    details = {"what": "ONE process, nh_run(n_devices = %d), gzip in -> gzip out on a cyclic configs[4]-shaped pair (%d pairs, %.2f GB of gzip, "
+                       "%.2f GB of text), database loaded into every device by the run itself; second of two runs in the process; child wall %.1f s, "
+                       "inputs + database written in %.1f s" % (spec["devices"], spec["pairs"], spec["gz_bytes"] / 1e9, spec["text_bytes"] / 1e9, t_child, spec["setup_s"]),
+               "runs": runs}
+    return nums, details
+
+
 def e2e_leg(cx, args, eng):
     """nh_run_engine on gzip FASTQ pairs: first byte read -> last byte written, database load excluded
     (as kraken2's own timer).  Inputs: `e2e_reps` DISTINCT gzip members of `e2e_pairs` synthetic pairs each
@@ -1059,53 +1278,9 @@ def e2e_leg(cx, args, eng):
         return {"skipped": "not enough memory-backed space for the e2e inputs and outputs (%.1f GB usable)" % (room / 1e9)}
     tmp = tempfile.mkdtemp(prefix="nh_bench_e2e_", dir=base)
     try:
-        t0 = time.time()
-        files = [os.path.join(tmp, "r_%d.fq.gz" % tag) for tag in (1, 2)]
-        distinct = max(1, min(reps, args.e2e_distinct))
-        dist_hash = {1: [None] * distinct, 2: [None] * distinct}
-        dist_len = {1: [0] * distinct, 2: [0] * distinct}
-        errors = []
-
-        host_gz = []  # (bytes of text, seconds) of the host encoder at work on the inputs
-
-        def compress_member(plain, tag, k):  # member k is compressed while member k+1 is generated
-            try:
-                dist_hash[tag][k] = _hash_file_ranges(plain, [(0, os.path.getsize(plain))])[0]
-                tc = time.perf_counter()
-                if _lib.lib().nh_compress_file(os.fsencode(plain), os.fsencode(plain + ".gz"), 2, max(1, threads // 2)) != 0:
-                    raise RuntimeError("nh_compress_file failed")
-                host_gz.append((os.path.getsize(plain), time.perf_counter() - tc))
-                os.remove(plain)
-            except Exception as ex:  # surfaced after the join
-                errors.append(ex)
-
-        pending = []
-        for k in range(distinct):
-            for tag in (1, 2):
-                plain = os.path.join(tmp, "m_%d_%d.fq" % (k, tag))
-                dist_len[tag][k] = e2e_member(cx, n, L, tag, k, plain)
-                while len(pending) >= 2:
-                    pending.pop(0).join()
-                th = threading.Thread(target=compress_member, args=(plain, tag, k))
-                th.start()
-                pending.append(th)
-        for th in pending:
-            th.join()
-        if errors:
-            raise errors[0]
-        # the input files: `reps` members, the distinct ones in rotation (A B C D E A B ...)
-        member_hash = {tag: [dist_hash[tag][i % distinct] for i in range(reps)] for tag in (1, 2)}
-        member_len = {tag: [dist_len[tag][i % distinct] for i in range(reps)] for tag in (1, 2)}
-        for tag in (1, 2):
-            with open(files[tag - 1], "wb") as out:
-                for i in range(reps):
-                    with open(os.path.join(tmp, "m_%d_%d.fq.gz" % (i % distinct, tag)), "rb") as src:
-                        shutil.copyfileobj(src, out, 16 << 20)
-            for k in range(distinct):
-                os.remove(os.path.join(tmp, "m_%d_%d.fq.gz" % (k, tag)))
-        t_setup = time.time() - t0
-        text_bytes = sum(member_len[1]) + sum(member_len[2])
-        gz_bytes = sum(os.path.getsize(f) for f in files)
+        inp = make_e2e_inputs(cx, args, tmp, n, L, reps, threads)
+        files, member_len, member_hash, distinct = inp["files"], inp["member_len"], inp["member_hash"], inp["distinct"]
+        text_bytes, gz_bytes, t_setup, host_gz = inp["text_bytes"], inp["gz_bytes"], inp["t_setup"], inp["host_gz"]
         o1, o2 = os.path.join(tmp, "o_1.fq"), os.path.join(tmp, "o_2.fq")
         best = None
         trace = ""

@@ -219,3 +219,38 @@ def test_bench_two_ranks_on_one_gpu(tmp_path):
     assert 37 < line["config"]["lookups_per_read"] < 40
     per_rank_reads_per_s = 200000 * 2 * 4 / (line["ms_per_step"] * 4 / 1e3)
     assert abs(line["value"] * 1e6 - 2 * per_rank_reads_per_s) / (2 * per_rank_reads_per_s) < 0.02
+
+
+@pytest.mark.gpu
+def test_bench_gpus_n_measures_the_products_own_multi_device_run(tmp_path):
+    """`bench.py --gpus N` runs N single-device rank processes -- the product's own G > 1 path (ONE process,
+    nh_run(n_devices = N): reader lanes over the devices, peer copies, the count all-reduce inside the library, one writer per
+    file) had no bench leg, so an 8-GPU node would not have measured it.  Now rank 0, once every rank has closed its engine and
+    left the process group, starts ONE fresh child that runs it on a cyclic configs[4]-shaped gzip pair.  Here: two ranks on
+    the one GPU (NOHUMAN_BENCH_ONE_GPU), the child under NOHUMAN_FAKE_DEVICES=2 (two logical devices on the one GPU, the
+    device discipline checked), at toy sizes with the reader's pieces scaled down so that both devices decode some."""
+    import json
+    import subprocess
+    import sys
+    ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, NOHUMAN_BENCH_ONE_GPU="1", NOHUMAN_BENCH_LOGDIR=str(tmp_path), NOHUMAN_DEBUG_DEVICE="1",
+               NOHUMAN_GZDEV_SEG="65536", NOHUMAN_GZDEV_STRETCH="4096", NOHUMAN_GZDEV_ROOM=str(8 << 20), NOHUMAN_BATCH_FRAGS="4096",
+               NOHUMAN_GZDEV_MIN_BYTES="0")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--pairs", "100000",
+           "--capacity", "200000033", "--pool", "2", "--no-cpu-baseline", "--no-variants", "--e2e-pairs", "20000", "--e2e-distinct", "2",
+           "--e2e-multi-pairs", "40000", "--wake-ms", "10"]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    line = json.loads(r.stdout.strip().splitlines()[-1])
+    assert line["n_gpus"] == 2 and line["value"] > 0
+    m = line["config"]["e2e"]["multi"]
+    assert "error" not in m, m
+    assert m["devices"] == 2 and m["logical_devices_on_one_gpu"] is True and m["pairs"] == 80000 and m["pairs_per_device"] == 40000
+    assert m["outputs_equal_inputs"] is True and m["value"] > 0 and m["scale_of_request"] == 1.0
+    # both logical devices decoded pieces of both inputs ("r_1.fq.gz 0:k 1:m; r_2.fq.gz ...")
+    assert "r_1.fq.gz" in m["pieces_by_device"] and " 1:" in m["pieces_by_device"] and "0:" in m["pieces_by_device"], m["pieces_by_device"]
+    c = line["config"]
+    assert c["e2e_multi_value"] == m["value"] and c["e2e_multi_devices"] == 2 and c["e2e_multi_outputs_equal_inputs"] is True
+    assert isinstance(c["e2e_multi_rccl_backend"], str) and isinstance(c["e2e_multi_pieces_by_device"], str)
