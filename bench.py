@@ -349,6 +349,8 @@ def measure(cx, args, *, steps, warmup, single_end=False, ont=False, hit_frac=0.
     tkey = None
     if not n_rate and L == 250 and paired and not (ont or wide or hit_frac) and capacity == 1_431_655_765 and abs(args.load - 0.7) < 1e-9:
         tkey = "pe250"
+    if n_rate == 0.001 and L == 150 and paired and not (ont or wide or hit_frac) and capacity == 1_431_655_765 and abs(args.load - 0.7) < 1e-9:
+        tkey = "n"
     if not n_rate and L == 150 and abs(args.load - 0.7) < 1e-9:
         if ont:
             tkey = "ont"

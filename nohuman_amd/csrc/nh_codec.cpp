@@ -17,6 +17,8 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
 #include <unistd.h>
 #include <zlib.h>
 
@@ -606,6 +608,106 @@ extern "C" int nh_gunzip_file(const char *in, const char *out, uint32_t threads,
     }
     if (::close(fout) != 0 && rc == NH_OK) rc = nh::set_error(NH_EIO, "write error on %s", out);
     if (stats3) gz.stats(&stats3[0], &stats3[1], &stats3[2]);
+    return rc;
+}
+
+// Test hook (not part of the ABI in include/nohuman_engine.h, like nh_debug_sched): the file decoded as a CHAIN OF RANGES, the way
+// the hybrid reader of nh_gunzip.hip uses RangeGunzip -- cell k = the bytes [k, k + 1) * cell_bytes of the file, each by a fresh
+// RangeGunzip whose chunks are all decoded before the stream's position and window at the cell are handed to it; every
+// `host_every`-th cell that way, the cells between by the sequential decoder (standing in for the GPU's pieces, which end at the
+// first block boundary behind their cell too).  The members' CRC-32 / ISIZE are checked here from the stretches the ranges report.
+// stats4: {cells by RangeGunzip, chunks accepted, chunks rejected, bytes decoded in order}.  Needs no GPU.
+extern "C" int nh_debug_gunzip_ranges(const char *in, const char *out, uint32_t threads, uint64_t cell_bytes, uint64_t chunk_bytes,
+                                      uint32_t host_every, uint64_t *stats4) {
+    if (!in || !out || !cell_bytes) return nh::set_error(NH_EINVAL, "nh_debug_gunzip_ranges: bad argument");
+    int fd = ::open(in, O_RDONLY | O_CLOEXEC);
+    if (fd < 0) return nh::set_error(NH_EIO, "cannot open %s", in);
+    struct stat st;
+    if (fstat(fd, &st) != 0 || st.st_size < 18) {
+        ::close(fd);
+        return nh::set_error(NH_EIO, "not a regular gzip file: %s", in);
+    }
+    const size_t size = (size_t)st.st_size;
+    const uint8_t *base = (const uint8_t *)mmap(nullptr, size, PROT_READ, MAP_PRIVATE, fd, 0);
+    ::close(fd);
+    if (base == (const uint8_t *)MAP_FAILED) return nh::set_error(NH_EIO, "cannot map %s", in);
+    int rc = NH_OK;
+    int fout = ::open(out, O_WRONLY | O_CREAT | O_TRUNC | O_CLOEXEC, 0666);
+    if (fout < 0) rc = nh::set_error(NH_EIO, "cannot create %s", out);
+    bool trunc = false;
+    const uint8_t *body = rc ? nullptr : nh::gzip_member_body(base, base + size, &trunc);
+    if (!rc && !body) rc = nh::set_error(NH_EIO, "not in gzip format: %s", in);
+    uint64_t P = body ? (uint64_t)(body - base) * 8 : 0;
+    std::vector<uint8_t> window(32768, 0), wafter(32768);
+    uint32_t run_crc = 0;
+    uint64_t run_len = 0, n_host = 0, acc = 0, rej = 0, gap = 0;
+    bool ended = false;
+    if (!host_every) host_every = 1;
+    auto member = [&](uint32_t crc, uint64_t len, bool end, uint32_t want_crc, uint32_t want_isize) {
+        run_crc = nh::crc32_join(run_crc, crc, len);
+        run_len += len;
+        if (!end) return true;
+        const bool ok = run_crc == want_crc && (uint32_t)run_len == want_isize;
+        run_crc = 0;
+        run_len = 0;
+        return ok;
+    };
+    for (uint64_t turn = 0; !rc && !ended; turn++) {
+        const uint64_t cell = (P >> 3) / cell_bytes, lo = cell * cell_bytes, hi = lo + cell_bytes;
+        uint64_t end_bit = 0;
+        if (turn % host_every == 0) {
+            nh::RangeGunzip rg;
+            rg.start(base, size, lo, hi, threads, (size_t)chunk_bytes);
+            rg.wait_speculated();
+            // (deflate expands 1032 : 1 at most; the buffer is not touched beyond what is written)
+            const size_t cap = (size_t)std::min<uint64_t>((std::min<uint64_t>(hi, size) - lo + 65536) * 1040, (uint64_t)1 << 33);
+            std::unique_ptr<uint8_t[]> text(new uint8_t[cap]);
+            std::vector<nh::GzSeg> segs;
+            const long n = rg.finish(P, window.data(), text.get(), cap, &end_bit, &ended, wafter.data(), segs);
+            if (n < 0) {
+                rc = nh::set_error(NH_EIO, "%s", rg.error().c_str());
+                break;
+            }
+            uint64_t a = 0, r = 0, g = 0;
+            rg.stats(&a, &r, &g);
+            acc += a, rej += r, gap += g, n_host++;
+            uint64_t sum = 0;
+            for (const nh::GzSeg &sg : segs) {
+                if (!member(sg.crc, sg.len, sg.member_end, sg.want_crc, sg.want_isize)) rc = nh::set_error(NH_EIO, "gzip: crc error");
+                sum += sg.len;
+            }
+            if (!rc && sum != (uint64_t)n) rc = nh::set_error(NH_EIO, "the stretches do not add up to the text");
+            if (!rc && !nh::write_all(fout, text.get(), (size_t)n)) rc = nh::set_error(NH_EIO, "write error on %s", out);
+            window.swap(wafter);
+        } else {  // (a piece of the other kind: in order, to the first block boundary behind the cell)
+            std::vector<uint8_t> o;
+            std::vector<nh::GzMemberEnd> members;
+            std::string err;
+            if (nh::inflate_from(base, base + size, P, hi * 8, window.data(), window.size(), o, members, &end_bit, &ended, err) != 0) {
+                rc = nh::set_error(NH_EIO, "%s", err.c_str());
+                break;
+            }
+            uint64_t a = 0;
+            for (const nh::GzMemberEnd &m : members) {
+                if (!member(nh::crc32_fast(0, o.data() + a, (size_t)(m.out_pos - a)), m.out_pos - a, true, m.crc, m.isize))
+                    rc = nh::set_error(NH_EIO, "gzip: crc error");
+                a = m.out_pos;
+            }
+            member(nh::crc32_fast(0, o.data() + a, o.size() - (size_t)a), o.size() - a, false, 0, 0);
+            if (!rc && !nh::write_all(fout, o.data(), o.size())) rc = nh::set_error(NH_EIO, "write error on %s", out);
+            if (o.size() >= window.size()) memcpy(window.data(), o.data() + o.size() - window.size(), window.size());
+            else {
+                memmove(window.data(), window.data() + o.size(), window.size() - o.size());
+                memcpy(window.data() + window.size() - o.size(), o.data(), o.size());
+            }
+        }
+        if (!rc && !ended && end_bit <= P) rc = nh::set_error(NH_EIO, "the stream did not advance");
+        P = end_bit;
+    }
+    if (!rc && run_len) rc = nh::set_error(NH_EIO, "gzip: unexpected end of file");
+    if (fout >= 0 && ::close(fout) != 0 && rc == NH_OK) rc = nh::set_error(NH_EIO, "write error on %s", out);
+    munmap((void *)base, size);
+    if (stats4) stats4[0] = n_host, stats4[1] = acc, stats4[2] = rej, stats4[3] = gap;
     return rc;
 }
 

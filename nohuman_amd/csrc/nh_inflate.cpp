@@ -933,6 +933,7 @@ struct Chunk {
     std::vector<Seg> segs;
     size_t read_off = 0;  // consumer: bytes already handed out
     bool verified = false;
+    size_t out_off = 0;   // range mode: where the chunk's text goes in the caller's buffer
 };
 
 // the chunk's output bytes [from, to) as one or two contiguous ranges, applied to f(ptr, n); the
@@ -1066,10 +1067,88 @@ public:
         inflight_.clear();
         pieces_.clear();
         spare_.clear();
-        if (base_) munmap((void *)base_, size_);
+        if (base_ && !range_) munmap((void *)base_, size_);
         base_ = nullptr;
         if (fd_ >= 0) ::close(fd_);
         fd_ = -1;
+        range_ = false;
+        range_dst_ = nullptr;
+    }
+
+    // ---- range mode (RangeGunzip, nh_inflate.h): the bytes [lo, hi) of a gzip file image that somebody else has mapped are
+    // decoded by this object's workers -- every chunk speculatively, at once, without knowing where the stream stands --
+    // and stitched later, when the caller knows the stream's position and window at the range (finish_range).
+    int open_range(const uint8_t *base, size_t size, uint64_t lo_byte, uint64_t hi_byte, unsigned threads, size_t chunk_bytes) {
+        close();
+        range_ = true;
+        base_ = base;
+        size_ = size;
+        lo_ = lo_byte < size ? lo_byte : size;
+        hi_ = hi_byte < size ? hi_byte : size;
+        if (hi_ < lo_) hi_ = lo_;
+        threads_ = threads < 1 ? 1 : threads;
+        chunk_ = chunk_bytes ? chunk_bytes : (size_t)(4u << 20);
+        if (chunk_ < 64) chunk_ = 64;
+        n_chunks_ = (size_t)((hi_ - lo_ + chunk_ - 1) / chunk_);
+        max_ahead_ = n_chunks_ + 2;  // (every chunk of the range is decoded ahead)
+        force_chain_ = false;        // (the start of the range is not known: nothing to chain from)
+        first_block_bit_ = 0;
+        next_dispatch_ = next_stitch_ = 0;
+        ended_ = failed_ = quit_ = false;
+        error_.clear();
+        P_ = lo_ * 8;
+        memset(window_, 0, sizeof window_);
+        cur_crc_ = 0;
+        cur_len_ = 0;
+        accepted_ = rejected_ = gap_bytes_ = 0;
+        out_total_ = 0;
+        for (unsigned i = 0; i < threads_; i++) workers_.emplace_back([this] { worker(); });
+        dispatch();
+        return 0;
+    }
+    void wait_speculated() {
+        std::unique_lock<std::mutex> lk(mu_);
+        cv_done_.wait(lk, [&] {
+            for (auto &c : inflight_)
+                if (!c->spec_done) return false;
+            return true;
+        });
+    }
+    // The stream stands at from_bit (a block boundary at or behind the range's first byte) with `window` before it: the
+    // range's text goes to dst; returns its length (-1: error()), the bit the stream stands at afterwards -- the first block
+    // boundary at or behind the range's end that passes the seam test, or the end of the stream --, the window there and the
+    // stretches of text by gzip member with their CRC-32 (the caller keeps the members' books: a member may have begun
+    // long before the range).
+    long finish_range(uint64_t from_bit, const uint8_t *window, uint8_t *dst, size_t cap, uint64_t *end_bit, bool *stream_end,
+                      uint8_t *window_after, std::vector<GzSeg> &segs) {
+        if (!range_ || failed_) return -1;
+        P_ = from_bit;
+        memcpy(window_, window, WSIZE);
+        range_dst_ = dst;
+        range_cap_ = cap;
+        out_total_ = 0;
+        while (!failed_ && !ended_) {
+            if (inflight_.empty() && P_ >= hi_ * 8) break;
+            (void)stitch_next(true);
+        }
+        if (failed_) return -1;
+        segs.clear();
+        for (auto &c : pieces_) {
+            {
+                std::unique_lock<std::mutex> lk(mu_);
+                cv_done_.wait(lk, [&] { return c->resolved; });
+            }
+            for (const Seg &sg : c->segs) segs.push_back({(uint64_t)sg.len, sg.crc, sg.member_end, sg.want_crc, sg.want_isize});
+        }
+        while (!pieces_.empty()) {
+            spare_.push_back(std::move(pieces_.front()));
+            pieces_.pop_front();
+        }
+        if (failed_) return -1;
+        *end_bit = P_;
+        *stream_end = ended_;
+        memcpy(window_after, window_, WSIZE);
+        return (long)out_total_;
     }
 
     long read(uint8_t *dst, size_t cap) {
@@ -1149,8 +1228,10 @@ private:
             const auto j0 = std::chrono::steady_clock::now();
             if (j.kind == 0)
                 speculate(*j.c);
-            else
+            else {
                 resolve_chunk(*j.c);
+                if (range_dst_) copy_out(*j.c);
+            }
             (j.kind == 0 ? t_spec_ns_ : t_resolve_ns_) +=
                 (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - j0).count();
             std::shared_ptr<TailInfo> tail;
@@ -1178,7 +1259,16 @@ private:
     }
 
     uint64_t chunk_bit(size_t c) const {  // nominal first bit of chunk c; beyond the file: "never"
+        // (range mode: the chunks tile [lo, hi); the last one ends at the first seam at or behind hi, a chunk's length further at most)
+        if (range_) return c < n_chunks_ ? (lo_ + (uint64_t)c * chunk_) * 8 : (hi_ + (uint64_t)(c - n_chunks_) * chunk_) * 8;
         return c >= n_chunks_ ? (uint64_t)-1 : (uint64_t)c * chunk_ * 8;
+    }
+    void copy_out(Chunk &c) {  // range mode: the chunk's (resolved) text to its place in the caller's buffer
+        size_t at = c.out_off;
+        for_ranges(c, 0, c.dec.total(), [&](const uint8_t *p, size_t k) {
+            memcpy(range_dst_ + at, p, k);
+            at += k;
+        });
     }
 
     // last WSIZE bytes of the stream after a chunk whose start is certain (c.window_before holds the
@@ -1206,7 +1296,7 @@ private:
         c.dec.reset(base_, end);
         c.found = false;
         c.chained = false;
-        if (c.index == 0) {
+        if (c.index == 0 && !range_) {
             memset(c.window_before, 0, WSIZE);
             c.dec.start_bytes(nullptr, 0);
             c.dec.run(first_block_bit_, chunk_bit(1), chunk_bit(2), false);
@@ -1347,7 +1437,15 @@ private:
         memcpy(window_, nw, WSIZE);
     }
 
+    bool place(Chunk &c) {  // range mode: the chunk's text follows what has been accepted so far
+        if (!range_dst_) return true;
+        c.out_off = out_total_;
+        out_total_ += c.dec.total();
+        if (out_total_ > range_cap_) return fail("gzip: the range's text does not fit the buffer");
+        return true;
+    }
     void accept(std::unique_ptr<Chunk> c) {
+        if (!place(*c)) return;
         memcpy(c->window_before, window_, WSIZE);
         advance_window(*c);
         P_ = c->dec.end_bit;
@@ -1383,12 +1481,14 @@ private:
         if (soft > target) soft = target;
         g->dec.run(P_, soft, (uint64_t)-1, true);
         if (g->dec.stop == STOP_ERROR) return fail(g->dec.error);
+        if (!place(*g)) return false;
         gap_bytes_ += g->dec.total();
         memcpy(g->window_before, window_, WSIZE);
         advance_window(*g);
         P_ = g->dec.end_bit;
         if (g->dec.stop == STOP_STREAM_END) ended_ = true;
         resolve_chunk(*g);
+        if (range_dst_) copy_out(*g);
         g->resolved = true;
         pieces_.push_back(std::move(g));
         return true;
@@ -1401,6 +1501,7 @@ private:
         dispatch();
         if (inflight_.empty()) {
             // no chunk left but the stream goes on (no block start was found in the rest)
+            if (range_) return P_ < hi_ * 8 && block ? gap_decode(hi_ * 8) : false;
             return block ? gap_decode((uint64_t)-1) : false;
         }
         Chunk &c = *inflight_.front();
@@ -1411,7 +1512,7 @@ private:
                 cv_done_.wait(lk, [&] { return c.spec_done; });
             }
         }
-        if (c.index == 0) {
+        if (c.index == 0 && !range_) {
             if (c.dec.stop == STOP_ERROR) return fail(c.dec.error);
             std::unique_ptr<Chunk> own = std::move(inflight_.front());
             inflight_.pop_front();
@@ -1471,6 +1572,10 @@ private:
 
     int fd_ = -1;
     const uint8_t *base_ = nullptr;
+    bool range_ = false;  // range mode: [lo_, hi_) of a mapping that belongs to the caller
+    uint64_t lo_ = 0, hi_ = 0;
+    uint8_t *range_dst_ = nullptr;
+    size_t range_cap_ = 0, out_total_ = 0;
     size_t size_ = 0, chunk_ = 0, n_chunks_ = 0, max_ahead_ = 0;
     unsigned threads_ = 1;
     bool force_chain_ = false;
@@ -1496,6 +1601,20 @@ private:
     bool quit_ = false;
     std::vector<std::thread> workers_;
 };
+
+RangeGunzip::RangeGunzip() : impl_(new GunzipImpl()) {}
+RangeGunzip::~RangeGunzip() { delete impl_; }
+int RangeGunzip::start(const uint8_t *base, size_t size, uint64_t lo_byte, uint64_t hi_byte, unsigned threads, size_t chunk_bytes) {
+    return impl_->open_range(base, size, lo_byte, hi_byte, threads, chunk_bytes);
+}
+void RangeGunzip::wait_speculated() { impl_->wait_speculated(); }
+long RangeGunzip::finish(uint64_t from_bit, const uint8_t *window, uint8_t *dst, size_t cap, uint64_t *end_bit, bool *stream_end,
+                         uint8_t *window_after, std::vector<GzSeg> &segs) {
+    return impl_->finish_range(from_bit, window, dst, cap, end_bit, stream_end, window_after, segs);
+}
+const std::string &RangeGunzip::error() const { return impl_->error(); }
+void RangeGunzip::stats(uint64_t *a, uint64_t *r, uint64_t *g) const { impl_->stats(a, r, g); }
+void RangeGunzip::close() { impl_->close(); }
 
 ParallelGunzip::ParallelGunzip() : impl_(new GunzipImpl()) {}
 ParallelGunzip::~ParallelGunzip() { delete impl_; }

@@ -68,6 +68,37 @@ private:
     GunzipImpl *impl_;
 };
 
+// A RANGE of a gzip stream on the host's cores, for the reader on the GPU (nh_gunzip.hip, round 6: the hybrid reader -- while
+// the GPU's codec kernels are the run's bottleneck the host's cores inflate some of the stream's cells): start() sets `threads`
+// workers on the bytes [lo, hi) of a gzip file image, every chunk decoded speculatively at once (16-bit symbols, markers for the
+// unknown window); finish() -- called when the stream, decoded elsewhere up to here, has reached the range -- stitches the
+// chunks from the stream's position and window, replaces the markers and puts the text into the caller's buffer.  The range
+// ends where ParallelGunzip's chunks end: at the first block boundary at or behind `hi` that passes the block-header test.
+struct GzSeg {  // a stretch of the range's text that belongs to one gzip member
+    uint64_t len;
+    uint32_t crc;  // CRC-32 of the stretch
+    bool member_end;
+    uint32_t want_crc, want_isize;  // the member's trailer (member_end)
+};
+class RangeGunzip {
+public:
+    RangeGunzip();
+    ~RangeGunzip();
+    RangeGunzip(const RangeGunzip &) = delete;
+    RangeGunzip &operator=(const RangeGunzip &) = delete;
+    int start(const uint8_t *base, size_t size, uint64_t lo_byte, uint64_t hi_byte, unsigned threads, size_t chunk_bytes);
+    void wait_speculated();  // every chunk has been tried (needs neither the stream's position nor its window)
+    // -1: error(); else the bytes of text written to dst
+    long finish(uint64_t from_bit, const uint8_t *window, uint8_t *dst, size_t cap, uint64_t *end_bit, bool *stream_end,
+                uint8_t *window_after, std::vector<GzSeg> &segs);
+    const std::string &error() const;
+    void stats(uint64_t *accepted, uint64_t *rejected, uint64_t *gap_bytes) const;
+    void close();
+
+private:
+    GunzipImpl *impl_;
+};
+
 // CRC-32 (gzip polynomial), slicing-by-16; crc = 0 to start
 uint32_t crc32_fast(uint32_t crc, const uint8_t *p, size_t n);
 

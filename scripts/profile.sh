@@ -3,7 +3,7 @@
 # MI355X guide prescribes: no --pmc together with trace domains other than --kernel-trace).
 #   gpurun -- 'bash scripts/profile.sh r03 pe se hit ont'     (workloads: pe = the bench default, se = configs[1],
 #                                                              hit = hit fraction 0.5, ont = configs[3] shape, wide,
-#                                                              pe250 = 2 x 250 bp pairs)
+#                                                              pe250 = 2 x 250 bp pairs, n = pairs with 0.1 % N)
 set -u
 TAG=${1:-r03}
 shift
@@ -22,6 +22,7 @@ for W in $WORKLOADS; do
     ont)  WARGS="--ont --pairs 200000" ; STEPS=8 ;;
     wide) WARGS="--pairs 1000000 --capacity 4400000011" ; STEPS=10 ;;
     pe250) WARGS="--read-len 250 --pairs 600000" ; STEPS=12 ;;
+    n)    WARGS="--n-rate 0.001 --pairs 1000000" ; STEPS=20 ;;
     *) echo "unknown workload $W"; continue ;;
   esac
   OUT=$REPO/gpurun_out/prof_${TAG}_$W
