@@ -68,6 +68,15 @@ public:
     uint64_t cells() const;
     void decode_ahead(int set, uint64_t cell, hipStream_t stream);
     long take(int set, bool use_ahead, void *d_dst, size_t room, hipStream_t stream);
+    // The hybrid reader's host lane (round 6): cells of the grid inflated by the host's cores (set_host_threads(n > 0) enables it)
+    // while the GPU decodes others -- decode_ahead_host(cell) from any thread, take_host() in stream order like take(); the
+    // piece's text ends up in device memory like any other's.  host_ok(room): the reader's shape and the text a cell is
+    // expected to hold allow it.
+    void set_host_threads(unsigned n);
+    bool host_ok(size_t room) const;
+    void decode_ahead_host(uint64_t cell);
+    long take_host(bool use_ahead, void *d_dst, size_t room, hipStream_t stream);
+    uint64_t host_pieces() const;
     bool ended() const;
     const std::string &error() const;
     // error() is a failed END-TO-END check of the decode (a member's CRC-32 or ISIZE, the stream's end), not a resource or a
@@ -96,8 +105,11 @@ public:
     // 0 ok; -1 error (err); 1: not a file this reader takes (no regular gzip file): use BlockReader.
     // devices: the GPUs of the run, this file's first one first -- piece i of the stream is inflated and indexed on
     // devices[i mod n], and its batches say so (HalfBatch::dev_device: nh_run classifies them where they were born).
-    int open(const char *path, const int *devices, int n_devices, std::string &err);
-    int open(const char *path, int device, std::string &err) { return open(path, &device, 1, err); }
+    // host_threads > 0: the HYBRID reader -- one more lane whose cells of the stream are inflated by that many workers on the
+    // host's cores while the devices decode the others (nh_run asks for it where the GPU's codec kernels are the run's
+    // bottleneck: gzip outputs encoded on the GPU); the text of every piece ends up on a device either way.
+    int open(const char *path, const int *devices, int n_devices, std::string &err, unsigned host_threads = 0);
+    int open(const char *path, int device, std::string &err) { return open(path, &device, 1, err, 0); }
     // The next batch.  max_text == 0 (paired inputs: both files' readers must cut at the same records): exactly max_recs
     // records, fewer only at the end of the input (hb.eof).  max_text > 0 (single-end): up to max_recs records and cut after
     // the record that reaches max_text bytes (BlockReader::next_batch's rule), and a piece hands out every complete record

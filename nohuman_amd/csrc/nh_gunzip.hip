@@ -1636,6 +1636,17 @@ public:
             for (auto &d : sets_) per += " " + std::to_string(d->device_) + ":" + std::to_string((unsigned long long)d->pieces);
             fprintf(stderr, "[nohuman trace] gzip reader, %s: pieces by device (device:pieces)%s\n", path_.c_str(), per.c_str());
         }
+        if (trace_ && host_pieces_)
+            fprintf(stderr, "[nohuman trace] gzip reader, %s: %llu pieces inflated by the host's cores (%u workers; stitching, marker replacement and upload %.3f s)\n",
+                    path_.c_str(), (unsigned long long)host_pieces_, host_threads_, host_s_);
+        host_pieces_ = 0;
+        host_s_ = 0;
+        if (hc_) hc_->close();
+        hc_.reset();
+        hc_valid_ = false;
+        if (h_text_ && !sets_.empty()) cache_free(sets_[0]->device_, h_text_cap_, h_text_, true);
+        h_text_ = nullptr;
+        h_text_cap_ = 0;
         if (pf_.th.joinable()) pf_.th.join();
         pf_.valid = false;
         if (trace_ && (pf_hits_ || pf_misses_))
@@ -2113,6 +2124,90 @@ private:
         }
     }
 
+    // ---- the HYBRID reader's host lane (round 6).  With the text re-encoded on the GPU the chip's codec kernels are the run's
+    // bottleneck and the host's cores idle: some cells of the piece grid are inflated there.  host_decode_ahead(cell): every
+    // chunk of the cell decoded speculatively by `host_threads_` workers (RangeGunzip, nh_inflate.cpp: the host decoder's own
+    // chunk machinery on a byte range) -- any thread, needs neither the stream's position nor its window.  take_host(): the
+    // stream's next piece, in stream order: the chunks stitched from the stream's position with the window behind the piece
+    // before (fetched from the device), markers replaced and CRCs taken on the workers, the text uploaded to where the
+    // GPU's resolve kernel would have put it, the window behind it left on the device -- the piece ends at the first block
+    // boundary at or behind its cell that passes the host's block-header test, which is where the GPU's search starts the next
+    // cell (a cell decoded ahead on the GPU whose first start is elsewhere is refused and decoded in order: correctness
+    // never depends on the two searches agreeing).
+    bool host_ok(size_t room) const { return host_threads_ > 0 && spec_ok() && ratio_ * 1.1 * (double)cell_bytes() <= (double)room; }
+    void host_decode_ahead(uint64_t cell) {
+        hc_valid_ = false;
+        if (!hc_) hc_.reset(new RangeGunzip());
+        const uint64_t lo = grid0_ + cell * cell_bytes();
+        if (lo >= size_) return;
+        // (chunks of 4 MiB like the host reader's; the tests' tiny cells are cut into eight)
+        const size_t chunk = (size_t)std::min<uint64_t>((uint64_t)4u << 20, std::max<uint64_t>(cell_bytes() / 8, 4096));
+        if (hc_->start(base_, size_, lo, lo + cell_bytes(), host_threads_, chunk) != 0) return;
+        hc_->wait_speculated();
+        hc_cell_ = cell;
+        hc_valid_ = true;
+    }
+    long take_host(bool use_spec, void *d_dst, size_t room, hipStream_t stream) {
+        if (!error_.empty()) return -1;
+        if (sets_.empty() || !select_set(0, stream)) return fail("moving the window between devices failed");
+        dev_check(s_->device_, "gzip reader, a piece by the host's cores");
+        for (;;) {
+            if (ended_) return 0;
+            const uint64_t cell = cell_of_pos();
+            if (!(use_spec && hc_valid_ && hc_cell_ == cell)) host_decode_ahead(cell);  // (nobody decoded it ahead: now, in order)
+            use_spec = false;
+            if (!hc_valid_) return fail("the host decoder could not be started");
+            hc_valid_ = false;
+            if (!h_text_ || h_text_cap_ < room) {
+                if (h_text_) cache_free(s_->device_, h_text_cap_, h_text_, true);
+                h_text_cap_ = 0;
+                h_text_ = (uint8_t *)cache_alloc(s_->device_, room, true);
+                if (!h_text_) return fail("the host lane's page-locked text buffer cannot be had");
+                h_text_cap_ = room;
+            }
+            uint8_t window[WSIZE], wafter[WSIZE];
+            GZ_TRY(hipMemcpyAsync(window, s_->d_win_[s_->win_], WSIZE, hipMemcpyDeviceToHost, stream));
+            GZ_TRY(hipStreamSynchronize(stream));
+            uint64_t eb = 0;
+            bool stream_end = false;
+            std::vector<GzSeg> segs;
+            const auto t0 = std::chrono::steady_clock::now();
+            const long n = hc_->finish(pos_bit_, window, h_text_, room, &eb, &stream_end, wafter, segs);
+            if (n < 0) {
+                error_ = hc_->error() + " (" + path_ + ")";
+                hc_->close();
+                return -1;
+            }
+            hc_->close();
+            if (n > 0) GZ_TRY(hipMemcpyAsync(d_dst, h_text_, (size_t)n, hipMemcpyHostToDevice, stream));
+            GZ_TRY(hipMemcpyAsync(s_->d_win_[s_->win_ ^ 1], wafter, WSIZE, hipMemcpyHostToDevice, stream));
+            GZ_TRY(hipStreamSynchronize(stream));
+            s_->win_ ^= 1;
+            for (const GzSeg &sg : segs) {
+                account(sg.crc, sg.len);
+                if (sg.member_end && !member_end(sg.want_crc, sg.want_isize)) return -1;
+            }
+            {
+                std::lock_guard<std::mutex> lk(st_mu_);
+                st_.segments++;
+                host_pieces_++;
+                st_.text_bytes += (uint64_t)n;
+                st_.gzip_bytes += (eb - pos_bit_) / 8;
+                host_s_ += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+            }
+            if (n > 0) ratio_ = std::max(ratio_ * 0.9, (double)n / std::max<double>(1.0, (double)(eb - pos_bit_) / 8));
+            if (!stream_end && eb <= pos_bit_) return fail("the host lane did not advance");
+            pos_bit_ = eb;
+            if (stream_end) {
+                if (run_len_) return fail("unexpected end of file", true);
+                ended_ = true;
+            } else if ((pos_bit_ >> 3) >= size_) {
+                return fail("unexpected end of file", true);
+            }
+            if (n != 0) return n;
+        }
+    }
+
     // The host decoder takes the piece over: from the same bit position, with the same window, to the first block
     // boundary behind the piece's first stretch (it is one core: the pieces behind go back to the device).
     long host_piece(uint8_t *d_dst, size_t room, hipStream_t stream, uint64_t a_byte, uint64_t first_bit, uint64_t end_bit, const SegResult &r) {
@@ -2201,6 +2296,15 @@ private:
     uint32_t host_left_ = 0, host_stint_ = 8;  // host mode: steps left of this stint; the next stint's length
     long fake_start_ = -1;
     long fake_crc_ = 0;
+    // the host lane of the hybrid reader (take_host)
+    unsigned host_threads_ = 0;
+    std::unique_ptr<RangeGunzip> hc_;
+    uint64_t hc_cell_ = 0;
+    bool hc_valid_ = false;
+    uint8_t *h_text_ = nullptr;  // page-locked: a host cell's text on its way to the device
+    size_t h_text_cap_ = 0;
+    uint64_t host_pieces_ = 0;
+    double host_s_ = 0;
     bool integrity_ = false;  // the error is one of the END-TO-END checks on the decode: a member's CRC-32 / ISIZE, the stream's end
     double open_s_ = 0;
     size_t in_bytes_ = 0, sym_bytes_ = 0, maps_bytes_ = 0, stage_bytes_ = 0;
@@ -2236,6 +2340,11 @@ long DevGunzip::take(int set, bool use_ahead, void *d_dst, size_t room, hipStrea
 bool DevGunzip::ended() const { return impl_->ended_; }
 const std::string &DevGunzip::error() const { return impl_->error_; }
 bool DevGunzip::integrity_failure() const { return impl_->integrity_; }
+void DevGunzip::set_host_threads(unsigned n) { impl_->host_threads_ = n; }
+bool DevGunzip::host_ok(size_t room) const { return impl_->host_ok(room); }
+void DevGunzip::decode_ahead_host(uint64_t cell) { impl_->host_decode_ahead(cell); }
+long DevGunzip::take_host(bool use_ahead, void *d_dst, size_t room, hipStream_t stream) { return impl_->take_host(use_ahead, d_dst, room, stream); }
+uint64_t DevGunzip::host_pieces() const { return impl_->host_pieces_; }
 const DevGunzipStats &DevGunzip::stats() const { return impl_->st_; }
 void DevGunzip::close() { impl_->close(); }
 
@@ -2447,7 +2556,7 @@ __global__ __launch_bounds__(256) void k_records(const uint8_t *text, const uint
 class DevFastqImpl {
 public:
     ~DevFastqImpl() { close(); }
-    int open(const char *path, const int *devices, int n_devices, std::string &err) {
+    int open(const char *path, const int *devices, int n_devices, std::string &err, unsigned host_threads) {
         if (!dev_gunzip_wants(path)) return 1;
         if (n_devices < 1) return 1;
         path_ = path;
@@ -2467,6 +2576,18 @@ public:
         const double t_a = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_open).count();
         for (int g = 1; g < n_devices; g++)
             if (gz_.add_device(devices[g], err) != g) return -1;
+        n_dev_lanes_ = lanes_.size();
+        // The hybrid reader (round 6): one more lane whose cells are inflated by the HOST's cores (DevGunzip::decode_ahead_host /
+        // take_host) -- its pieces' text is uploaded to the first device and indexed and classified there like any other's.
+        // What it is for: with gzip outputs encoded on the GPU the chip's codec kernels are the run's bottleneck while the
+        // host's cores idle (profiles/r05_e2e_busy_gzip.txt).  Needs the piece grid (no BGZF, which has no search to share).
+        if (host_threads > 0 && gz_.ahead_ok() && !(getenv("NOHUMAN_GZ_AHEAD") && getenv("NOHUMAN_GZ_AHEAD")[0] == '0')) {
+            Lane h;
+            h.device = devices[0];
+            h.host = true;
+            lanes_.push_back(std::move(h));
+            gz_.set_host_threads(host_threads);
+        }
         const double t_b = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_open).count();
         // text of a piece: 512 MiB of gzip at FASTQ's 4-5 : 1 and the partial batch carried in front of it (the record index
         // addresses a piece's text with 32 bits: below 4 GiB)
@@ -2639,6 +2760,7 @@ private:
     };
     struct Lane {
         int device = -1;
+        bool host = false;  // the hybrid reader's host lane: cells inflated by the host's cores, text uploaded to `device`
         hipStream_t stream = nullptr, stream_a = nullptr, stream_i = nullptr;  // the stream's own work; a piece decoded ahead; the index stage
         unsigned long long *d_bad = nullptr, *h_bad = nullptr;
         std::thread worker;
@@ -2783,7 +2905,8 @@ private:
                 if (ln.state != 1) return;
                 cell = ln.cell;
             }
-            gz_.decode_ahead((int)g, cell, ln.stream_a);
+            if (ln.host) gz_.decode_ahead_host(cell);
+            else gz_.decode_ahead((int)g, cell, ln.stream_a);
             {
                 std::lock_guard<std::mutex> lk(mu_);
                 ln.state = 2;
@@ -2798,11 +2921,22 @@ private:
         if (next_cell_ <= k) next_cell_ = k + 1;
         for (Lane &l : lanes_)
             if (l.state == 2 && l.cell < k) l.state = 0;  // (the stream is past it: a block longer than a cell -- tiny cells of the tests)
-        for (Lane &l : lanes_)
-            if (l.state == 0 && next_cell_ < n) {
-                l.cell = next_cell_++;
-                l.state = 1;
+        // (hybrid: while nobody holds the cell the stream stands in, one idle DEVICE lane is kept back for it -- load_next takes
+        //  it in order at once --, and the host lane gets a cell only while a cell's expected text fits its buffer)
+        const bool hybrid = lanes_.size() > n_dev_lanes_;
+        bool owned = false, kept = false;
+        for (const Lane &l : lanes_)
+            if (l.state != 0 && l.cell == k) owned = true;
+        for (Lane &l : lanes_) {
+            if (l.state != 0 || next_cell_ >= n) continue;
+            if (l.host && !gz_.host_ok(room_ - head_)) continue;
+            if (hybrid && !owned && !l.host && !kept) {
+                kept = true;
+                continue;
             }
+            l.cell = next_cell_++;
+            l.state = 1;
+        }
         cv_.notify_all();
     }
 
@@ -2838,7 +2972,7 @@ private:
 
     int load_next(bool &last) {
         // ---- which lane takes the stream's next piece
-        size_t g = piece_no_ % lanes_.size();
+        size_t g = piece_no_ % n_dev_lanes_;  // (in turn over the DEVICE lanes where pieces are not decoded ahead)
         bool use_ahead = false;
         if (ahead_ && gz_.ahead_ok()) {
             assign_ahead();
@@ -2852,11 +2986,12 @@ private:
             } else {
                 // nobody decoded this cell ahead (the stream's first piece; a piece that was refused, or ended early): an idle
                 // lane decodes it in order -- or, all being busy with cells further on, the one furthest ahead gives its cell up
-                for (size_t i = 0; i < lanes_.size(); i++)
+                // (device lanes only: an in-order piece on the host's cores would be the slowest way to decode it)
+                for (size_t i = 0; i < n_dev_lanes_; i++)
                     if (lanes_[i].state == 0) pick = i;
                 if (pick == lanes_.size()) {
                     pick = 0;
-                    for (size_t i = 1; i < lanes_.size(); i++)
+                    for (size_t i = 1; i < n_dev_lanes_; i++)
                         if (lanes_[i].cell > lanes_[pick].cell) pick = i;
                     if (next_cell_ > lanes_[pick].cell) next_cell_ = lanes_[pick].cell;  // (it is dealt out again)
                 }
@@ -2885,8 +3020,9 @@ private:
         }
         Piece &p = *pp;
         if (nh::dev_set(ln.device) != hipSuccess) return fail("hipSetDevice failed");
-        const long n = ahead_ ? gz_.take((int)g, use_ahead, p.d_text + head_, room_ - head_, ln.stream)
-                              : gz_.next_on((int)g, p.d_text + head_, room_ - head_, ln.stream);
+        const long n = ln.host  ? gz_.take_host(use_ahead, p.d_text + head_, room_ - head_, ln.stream)
+                       : ahead_ ? gz_.take((int)g, use_ahead, p.d_text + head_, room_ - head_, ln.stream)
+                                : gz_.next_on((int)g, p.d_text + head_, room_ - head_, ln.stream);
         if (ahead_) {
             std::lock_guard<std::mutex> lk(mu_);
             ln.state = 0;
@@ -3094,6 +3230,7 @@ private:
     bool decode_done_ = false;
     Piece *last_ = nullptr;      // the piece produced last: what it could not hand out as whole batches goes in front of the next
     uint64_t piece_no_ = 0, next_cell_ = 0;
+    size_t n_dev_lanes_ = 1;  // lanes_[0, n_dev_lanes_) are devices; one more behind them: the host lane (hybrid reader)
     bool ahead_ = false;
     size_t room_ = 0, bf_ = 0;
     std::thread th_;
@@ -3107,7 +3244,9 @@ private:
 
 DevFastqReader::DevFastqReader() : impl_(new DevFastqImpl()) {}
 DevFastqReader::~DevFastqReader() { delete impl_; }
-int DevFastqReader::open(const char *path, const int *devices, int n_devices, std::string &err) { return impl_->open(path, devices, n_devices, err); }
+int DevFastqReader::open(const char *path, const int *devices, int n_devices, std::string &err, unsigned host_threads) {
+    return impl_->open(path, devices, n_devices, err, host_threads);
+}
 int DevFastqReader::next_batch(HalfBatch &hb, size_t max_recs, size_t max_text) { return impl_->next_batch(hb, max_recs, max_text); }
 uint64_t DevFastqReader::records_handed() const { return impl_->records_handed(); }
 const std::string &DevFastqReader::handover_reason() const { return impl_->handover_reason(); }

@@ -610,7 +610,7 @@ static bool device_reader_pays(const char *path, size_t mean_record_bytes, bool 
 
 static void reader_main(const char *path, BoundedQueue<std::unique_ptr<HalfBatch>> *out, RunState *rs,
                         BatchPool *pool, StageClock *clk, int which, size_t batch_frags, size_t batch_text,
-                        unsigned gz_threads, std::vector<int> gz_devices, bool device_reader) {
+                        unsigned gz_threads, std::vector<int> gz_devices, bool device_reader, unsigned hybrid_threads) {
     const int gz_device = gz_devices.empty() ? -1 : gz_devices[0];
     // gzip FASTQ: the whole reader on the GPU (inflate, record index; the text stays in HBM) where that pays (the caller
     // decides: device_reader) or NOHUMAN_GZ_READER says "device"; "host": the host decoders; "device-text": inflate on the
@@ -623,7 +623,7 @@ static void reader_main(const char *path, BoundedQueue<std::unique_ptr<HalfBatch
             DevFastqReader dr;
             std::string derr;
             // (the run's devices, this file's first: piece i of the stream is inflated, indexed and classified on device i mod G)
-            const int orc = dr.open(path, gz_devices.data(), (int)gz_devices.size(), derr);
+            const int orc = dr.open(path, gz_devices.data(), (int)gz_devices.size(), derr, hybrid_threads);
             if (orc < 0) {
                 if (named) {  // asked for by name: no silent change of reader
                     rs->fail(NH_EIO, derr);
@@ -964,9 +964,28 @@ int run_engines(const std::vector<Engine *> &engines, const nh_run_args *a, nh_s
         const int n = atoi(e);
         while (G == 1 && (int)devs1.size() < n && n <= 4) devs1.push_back(devs1[0]), devs2.push_back(devs2[0]);
     }
-    std::thread t1(reader_main, a->in1, &q1, &rs, &pool1, &clk, 0, BATCH_FRAGS, BATCH_TEXT, gz_threads, devs1, dev_reader1);
+    // The hybrid reader (round 6, nh_gunzip.hip): where the kept text is re-encoded on the GPU the chip's codec kernels --
+    // inflate and deflate in turn -- are what the run waits for while the host's cores idle; some cells of each input's piece
+    // grid are then inflated by host workers (the threads the run was given, less the few its own stages keep busy, shared
+    // between the files).  NOHUMAN_GZ_HYBRID=0 | 1 | n: never / also for outputs the host writes / n workers per file.
+    unsigned hybrid_threads = 0;
+    {
+        const bool gpu_gzip = a->out_codec == NH_CODEC_GZIP && o1.enc && o1.enc->takes_device_spans() && (!rs.paired || (o2.enc && o2.enc->takes_device_spans()));
+        const unsigned T = a->threads ? a->threads : 1;
+        // (one device: with several the GPUs are not what the run waits for, and the reader's lanes over them are untested with it)
+        unsigned want = gpu_gzip && T >= 6 && G == 1 ? std::max(2u, (T - 4) / (unsigned)mates) : 0u;
+        if (const char *e = getenv("NOHUMAN_GZ_HYBRID")) {
+            const int v = atoi(e);
+            want = v <= 0 ? 0u : v == 1 ? std::max(1u, (T > 4 ? T - 4 : 1u) / (unsigned)mates) : (unsigned)v;
+        }
+        hybrid_threads = std::min(16u, want);
+        if (getenv("NOHUMAN_TRACE") && (dev_reader1 || dev_reader2))
+            fprintf(stderr, "[nohuman trace] gzip reader: hybrid %s (%u host workers per file)\n", hybrid_threads ? "on" : "off", hybrid_threads);
+    }
+    std::thread t1(reader_main, a->in1, &q1, &rs, &pool1, &clk, 0, BATCH_FRAGS, BATCH_TEXT, gz_threads, devs1, dev_reader1, hybrid_threads);
     std::thread t2;
-    if (rs.paired) t2 = std::thread(reader_main, a->in2, &q2, &rs, &pool2, &clk, 1, BATCH_FRAGS, BATCH_TEXT, gz_threads2, devs2, dev_reader2);
+    if (rs.paired)
+        t2 = std::thread(reader_main, a->in2, &q2, &rs, &pool2, &clk, 1, BATCH_FRAGS, BATCH_TEXT, gz_threads2, devs2, dev_reader2, hybrid_threads);
 
     // writer: consumes batches in order; each arrives after its stream was synchronised.  Two stages: the WRITER
     // waits for the batch's stream, decides and formats (span lists, nothing is copied); the FLUSHER writes the spans

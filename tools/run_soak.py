@@ -1,7 +1,7 @@
 """Differential soak of nh_run's two gzip readers: random FASTQ files with every oddity of the record semantics (CRLF, "+id"
 lines, trailing blanks on any line, lower case, N, empty sequences, a missing final newline, a truncated last record, an empty
 header line in the middle -- kraken2 stops there --, mates of unequal record counts), gzip at random levels and member cuts,
-random batch / piece / chunk sizes, one to three lanes of the reader (pieces decoded ahead), single-end and paired, plain and gzip outputs, classified-out and unclassified-out:
+random batch / piece / chunk sizes, one to three lanes of the reader (pieces decoded ahead), the hybrid reader's host lane on and off, single-end and paired, plain and gzip outputs, classified-out and unclassified-out:
 the reader on the GPU (inflate + record index there) must write exactly what the host reader writes.
     python tools/run_soak.py [cases=200] [seed=1]"""
 import gzip, os, sys, tempfile, zlib
@@ -103,6 +103,11 @@ for k in range(cases):
         os.environ["NOHUMAN_GZ_LANES"] = str(lanes)
         os.environ["NOHUMAN_GZDEV_STRETCH"] = str(int(rng.choice([4096, 8192])))
         os.environ["NOHUMAN_GZDEV_SEG"] = str(int(rng.choice([16384, 65536, 262144])))
+    # the hybrid reader (round 6): some cells of the stream inflated by host workers beside the GPU's (NH_SOAK_HYBRID=n forces it)
+    hyb = int(os.environ.get("NH_SOAK_HYBRID", "-1"))
+    if hyb < 0:
+        hyb = int(rng.choice([0, 0, 2, 3]))
+    os.environ["NOHUMAN_GZ_HYBRID"] = str(hyb)
     # the product's default (no reader named: it may hand the file over to the host reader mid-stream, and single-end batches
     # are cut by text) in the cases with the long tail and in a third of the others; the reader named in the rest
     auto = long_tail or bool(rng.random() < 0.33)
@@ -135,8 +140,8 @@ for k in range(cases):
         if paired:
             open(os.path.join(keep, "a_2.fq.gz"), "wb").write(open(f2, "rb").read())
         dv, hv = res["device"], res["host"]
-        print("CASE %d DIFFERS: paired %s odd %s n %d long tail %s default reader %s kw %s batch %s seg %s stretch %s lanes %d room %s" % (k, paired, odd, n, long_tail, auto, kw,
-              os.environ["NOHUMAN_BATCH_FRAGS"], os.environ["NOHUMAN_GZDEV_SEG"], os.environ["NOHUMAN_GZDEV_STRETCH"], lanes, os.environ.get("NOHUMAN_GZDEV_ROOM")))
+        print("CASE %d DIFFERS: paired %s odd %s n %d long tail %s default reader %s kw %s batch %s seg %s stretch %s lanes %d room %s hybrid %d" % (k, paired, odd, n, long_tail, auto, kw,
+              os.environ["NOHUMAN_BATCH_FRAGS"], os.environ["NOHUMAN_GZDEV_SEG"], os.environ["NOHUMAN_GZDEV_STRETCH"], lanes, os.environ.get("NOHUMAN_GZDEV_ROOM"), hyb))
         print("   device:", [x if not isinstance(x, bytes) else (len(x), zlib.crc32(x)) for x in dv])
         print("   host  :", [x if not isinstance(x, bytes) else (len(x), zlib.crc32(x)) for x in hv], flush=True)
         if bad >= 5:
