@@ -964,21 +964,18 @@ int run_engines(const std::vector<Engine *> &engines, const nh_run_args *a, nh_s
         const int n = atoi(e);
         while (G == 1 && (int)devs1.size() < n && n <= 4) devs1.push_back(devs1[0]), devs2.push_back(devs2[0]);
     }
-    // The hybrid reader (round 6, nh_gunzip.hip): where the kept text is re-encoded on the GPU the chip's codec kernels --
-    // inflate and deflate in turn -- are what the run waits for while the host's cores idle; some cells of each input's piece
-    // grid are then inflated by host workers (the threads the run was given, less the few its own stages keep busy, shared
-    // between the files).  NOHUMAN_GZ_HYBRID=0 | 1 | n: never / also for outputs the host writes / n workers per file.
+    // The hybrid reader (round 6, nh_gunzip.hip): some cells of each input's piece grid inflated by host workers beside the GPU's.
+    // OFF unless asked for (NOHUMAN_GZ_HYBRID=n: n workers per file; 1: the run's threads less four, shared between the files):
+    // built for the runs whose kept text is re-encoded on the GPU -- there the chip's codec kernels, inflate and deflate in turn,
+    // are what the run waits for while the host's cores idle -- and measured there: 28.8 -> 13.0 Mreads/s (profiles/r06_hybrid.txt).
+    // A cell takes six host workers 0.85 s + 0.4 s against the GPU's 0.28 s, the stream's pieces are taken in order, and a GPU lane
+    // holds ONE cell decoded ahead: the chip waits for the host's cell instead of being relieved by it.
     unsigned hybrid_threads = 0;
-    {
-        const bool gpu_gzip = a->out_codec == NH_CODEC_GZIP && o1.enc && o1.enc->takes_device_spans() && (!rs.paired || (o2.enc && o2.enc->takes_device_spans()));
+    if (const char *e = getenv("NOHUMAN_GZ_HYBRID")) {
+        const int v = atoi(e);
         const unsigned T = a->threads ? a->threads : 1;
-        // (one device: with several the GPUs are not what the run waits for, and the reader's lanes over them are untested with it)
-        unsigned want = gpu_gzip && T >= 6 && G == 1 ? std::max(2u, (T - 4) / (unsigned)mates) : 0u;
-        if (const char *e = getenv("NOHUMAN_GZ_HYBRID")) {
-            const int v = atoi(e);
-            want = v <= 0 ? 0u : v == 1 ? std::max(1u, (T > 4 ? T - 4 : 1u) / (unsigned)mates) : (unsigned)v;
-        }
-        hybrid_threads = std::min(16u, want);
+        const unsigned want = v <= 0 ? 0u : v == 1 ? std::max(1u, (T > 4 ? T - 4 : 1u) / (unsigned)mates) : (unsigned)v;
+        hybrid_threads = G == 1 ? std::min(16u, want) : 0u;  // (one device: the reader's lanes over several are untested with it)
         if (getenv("NOHUMAN_TRACE") && (dev_reader1 || dev_reader2))
             fprintf(stderr, "[nohuman trace] gzip reader: hybrid %s (%u host workers per file)\n", hybrid_threads ? "on" : "off", hybrid_threads);
     }

@@ -1,7 +1,8 @@
 """The HYBRID gzip reader (round 6): with the kept text re-encoded on the GPU the chip's codec kernels are what
-nh_run waits for while the host's cores idle, so some cells of each input's piece grid are inflated by host workers
+nh_run waits for while the host's cores idle, so some cells of each input's piece grid can be inflated by host workers
 (RangeGunzip, tests/test_gunzip_ranges.py) beside the GPU's -- decoded ahead, taken in stream order, their text uploaded and
-indexed on the device like any other piece's.  Whatever the mix, the run writes what the host reader writes (the reference hands
+indexed on the device like any other piece's.  It is correct and it does not pay (profiles/r06_hybrid.txt: the chip ends up
+waiting for the host's cells), so it is an option (NOHUMAN_GZ_HYBRID=n), not the default.  Whatever the mix, the run writes what the host reader writes (the reference hands
 its inputs to the path as they are, /root/reference/src/main.rs:267), the members' CRCs are checked across pieces of both kinds,
 and damage fails the run."""
 import gzip
@@ -55,7 +56,7 @@ def _host_pieces(err):
 
 @pytest.mark.parametrize("paired", [False, True])
 @pytest.mark.parametrize("codec", [0, 2])
-@pytest.mark.parametrize("seg,stretch", [(65536, 4096), (16384, 2048), (262144, 8192)])
+@pytest.mark.parametrize("seg,stretch", [(65536, 4096), (16384, 4096), (262144, 8192)])
 def test_hybrid_reader_writes_what_the_host_reader_writes(tmp_path, monkeypatch, capfd, paired, codec, seg, stretch):
     d1, d2 = _fastq(1, 9000, b"/1"), _fastq(2, 9000, b"/2")
     p1, p2 = tmp_path / "r_1.fq.gz", tmp_path / "r_2.fq.gz"
@@ -103,7 +104,7 @@ def test_members_flush_points_and_stored_blocks_across_pieces_of_both_kinds(tmp_
     p = tmp_path / "m.fq.gz"
     p.write_bytes(b"".join(parts))
     want = data + noisy
-    for seg, stretch in ((32768, 2048), (131072, 4096)):
+    for seg, stretch in ((32768, 4096), (131072, 4096)):
         _scale(monkeypatch, seg, stretch, batch=300)
         monkeypatch.setenv("NOHUMAN_GZ_READER", "device")
         hyb = _run(tmp_path, "hyb", p)
@@ -138,7 +139,7 @@ def test_a_wrong_crc_in_a_piece_of_either_kind_fails_the_run(tmp_path, monkeypat
     from nohuman_amd import EngineError
     p = tmp_path / "r.fq.gz"
     p.write_bytes(gzip.compress(_fastq(6, 9000), 6))
-    _scale(monkeypatch, 16384, 2048, batch=100)
+    _scale(monkeypatch, 16384, 4096, batch=100)
     monkeypatch.delenv("NOHUMAN_GZ_READER", raising=False)
     monkeypatch.setenv("NOHUMAN_GZDEV_FAKE_CRC", "6")
     with pytest.raises(EngineError) as ei:
@@ -146,14 +147,18 @@ def test_a_wrong_crc_in_a_piece_of_either_kind_fails_the_run(tmp_path, monkeypat
     assert "crc error" in str(ei.value)
 
 
-def test_the_default_policy_turns_the_hybrid_on_for_gpu_gzip_outputs_only(tmp_path, monkeypatch, capfd):
+def test_the_hybrid_is_off_unless_asked_for(tmp_path, monkeypatch, capfd):
+    """measured and left off (profiles/r06_hybrid.txt): a run without NOHUMAN_GZ_HYBRID has no host lane, whatever its outputs"""
     p1, p2 = tmp_path / "r_1.fq.gz", tmp_path / "r_2.fq.gz"
     p1.write_bytes(gzip.compress(_fastq(7, 3000, b"/1"), 6))
     p2.write_bytes(gzip.compress(_fastq(8, 3000, b"/2"), 6))
     _scale(monkeypatch)
     monkeypatch.delenv("NOHUMAN_GZ_HYBRID")
     monkeypatch.setenv("NOHUMAN_GZ_READER", "device")
-    _run(tmp_path, "gz", p1, p2, out_codec=2)
-    assert "hybrid on (2 host workers per file)" in capfd.readouterr().err  # (8 threads: (8 - 4) / 2 files)
-    _run(tmp_path, "plain", p1, p2)
-    assert "hybrid off" in capfd.readouterr().err
+    for codec in (2, 0):
+        _run(tmp_path, "x", p1, p2, out_codec=codec)
+        err = capfd.readouterr().err
+        assert "hybrid on" not in err and not _host_pieces(err)
+    monkeypatch.setenv("NOHUMAN_GZ_HYBRID", "1")  # "1": the run's threads less four, shared between the files
+    _run(tmp_path, "y", p1, p2, out_codec=2)
+    assert "hybrid on (2 host workers per file)" in capfd.readouterr().err
