@@ -1420,9 +1420,16 @@ __global__ __launch_bounds__(WAVE * WAVES_PER_BLOCK, BIG ? 1 : (STD ? NH_MIN_WAV
     uint64_t prof[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     uint64_t tprev = PROF ? __builtin_readcyclecounter() : 0;
 
-    // speculative prefetch of the bases of the next two tiles (byte offset tags, loaded dwords)
-    uint32_t tag1 = 0, tag2 = 0;  // 1 + byte offset relative to the chunk's first base; 0 = nothing loaded
-    uint32_t w1 = 0, w2 = 0;
+    // speculative prefetch of the bases of the next NH_PF_DEPTH tiles (byte offset tags, loaded dwords): a FIFO, slot 0 = the
+    // next tile.  Depth 2 until round 5; a group is up to four tiles scanned back to back, so only a load issued four scans ahead
+    // has a whole probe phase to arrive (what k_classify_short does with its batches): profiles/r06_prefetch_depth.txt.
+#ifndef NH_PF_DEPTH
+#define NH_PF_DEPTH 2
+#endif
+    constexpr int PFD = NH_PF_DEPTH;
+    uint32_t tagf[PFD], wf[PFD];  // 1 + byte offset relative to the chunk's first base; 0 = nothing loaded
+#pragma unroll
+    for (int i = 0; i < PFD; i++) tagf[i] = 0, wf[i] = 0;
 
     // Two groups of tiles are in flight: the one being scanned / probed (parity `par`) and the
     // previous one, which is post-processed only after the probe phase of its successor.
@@ -1543,7 +1550,8 @@ __global__ __launch_bounds__(WAVE * WAVES_PER_BLOCK, BIG ? 1 : (STD ? NH_MIN_WAV
                 S.acc[CNT_BASES] += cb;
             }
         }
-        tag1 = tag2 = 0;  // tags are relative to the chunk
+#pragma unroll
+        for (int i = 0; i < PFD; i++) tagf[i] = 0;  // tags are relative to the chunk
         for (uint32_t fc = 0; fc < ncf; fc++) {
             NH_STAMP(8);
             const uint64_t f = cbeg + fc;
@@ -1609,16 +1617,21 @@ __global__ __launch_bounds__(WAVE * WAVES_PER_BLOCK, BIG ? 1 : (STD ? NH_MIN_WAV
                 for (uint32_t q0 = (m == 0 ? qbeg : 0u); q0 < nk; q0 += TQ) {
                     const uint64_t g0 = cbase + (m ? o1 : o0) + q0;
                     NH_STAMP(0);
-                    // two-deep prefetch FIFO: (tag1, w1) was loaded for the next tile, (tag2, w2)
-                    // for the one after it
+                    // prefetch FIFO: (tagf[0], wf[0]) was loaded for the next tile, (tagf[1], wf[1]) for the one after it, ...
                     const uint32_t gtag = (uint32_t)(g0 - cbase) + 1u;
-                    uint32_t w = w1;
-                    if (tag1 != gtag) {
-                        w = w2;
-                        if (tag2 != gtag) w = *tile_ptr(g0);
+                    uint32_t w = 0;
+                    {
+                        bool have = false;
+#pragma unroll
+                        for (int i = 0; i < PFD; i++)
+                            if (!have && tagf[i] == gtag) {
+                                w = wf[i];
+                                have = true;
+                            }
+                        if (!have) w = *tile_ptr(g0);
                     }
-                    tag1 = tag2;
-                    w1 = w2;
+#pragma unroll
+                    for (int i = 0; i + 1 < PFD; i++) tagf[i] = tagf[i + 1], wf[i] = wf[i + 1];
                     // the tile to be scanned two scans from now (a full group away, so its load has a whole probe phase
                     // to arrive): the scan order -- tiles of a sequence, then the next mate, then the next fragment of the
                     // chunk -- stepped twice from here.  (Round 5: the guess used to assume ONE tile per sequence once a
@@ -1626,13 +1639,13 @@ __global__ __launch_bounds__(WAVE * WAVES_PER_BLOCK, BIG ? 1 : (STD ? NH_MIN_WAV
                     // loaded and fetched it synchronously.)  Lengths of the sequences ahead come from the lanes of len_v; a
                     // sequence without k-mers there makes the guess wrong, which costs a load, never a result: the tag decides.
                     const bool seq_end = q0 + TQ >= nk;
-                    uint64_t ng0 = g0 + 2 * TQ;
+                    uint64_t ng0 = g0 + (uint32_t)PFD * TQ;
                     bool pf_on = true;
-                    if (q0 + 2 * TQ >= nk) {
+                    if (q0 + (uint32_t)PFD * TQ >= nk) {
                         uint32_t si = (uint32_t)oi + (uint32_t)m;  // sequence index within the chunk
                         uint32_t q2 = q0, nk2 = nk;
 #pragma unroll
-                        for (int hop = 0; hop < 2; hop++) {
+                        for (int hop = 0; hop < PFD; hop++) {
                             q2 += TQ;
                             if (q2 >= nk2) {
                                 q2 = 0;
@@ -1645,7 +1658,7 @@ __global__ __launch_bounds__(WAVE * WAVES_PER_BLOCK, BIG ? 1 : (STD ? NH_MIN_WAV
                         ng0 = cbase + __builtin_amdgcn_readlane(off_v, (int)(si < 63u ? si : 63u)) + q2;
                     }
                     const uint32_t *pf_ptr = tile_ptr(pf_on ? ng0 : g0);
-                    tag2 = pf_on ? (uint32_t)(ng0 - cbase) + 1u : 0u;
+                    tagf[PFD - 1] = pf_on ? (uint32_t)(ng0 - cbase) + 1u : 0u;
 
                     const uint32_t nl_left = (n - L + 1) - q0;
                     const uint32_t nlt = nl_left < (uint32_t)TL ? nl_left : (uint32_t)TL;
@@ -1658,7 +1671,7 @@ __global__ __launch_bounds__(WAVE * WAVES_PER_BLOCK, BIG ? 1 : (STD ? NH_MIN_WAV
                     int last_lane;
                     const uint32_t nruns =
                         scan_tile<STD, PROF>(ap, S, lane, w, (uint32_t)g0 & 3u, nlt, nqt, par, qn,
-                                             carry_min, ps, last_lane, pf_ptr, pf_on, w2, prof, tprev);
+                                             carry_min, ps, last_lane, pf_ptr, pf_on, wf[PFD - 1], prof, tprev);
                     if (lane == 0) {
                         uint4 d0, d1, d2;  // layout of SlotLds
                         d0.x = (uint32_t)f;
