@@ -2078,19 +2078,36 @@ private:
     // take() is the stream's next piece ON set k, in stream order: the set's decoded cell if it starts exactly where the
     // stream stands (the normal case), else a piece decoded now, from the stream's position to the end of ITS cell -- which
     // puts the stream back on the grid.
+    // (With a host lane -- the hybrid reader, below -- the grid ALTERNATES: even cells of a piece's size for the devices, odd cells
+    //  of host_cell_ bytes, a quarter of that, for the host's workers: a host cell must cost less time than the device cell
+    //  before it, or the chip waits for it.  host_cell_ == 0: the uniform grid of rounds 4-5.)
     uint64_t cell_bytes() const { return (uint64_t)n_slots_ * stretch_; }
-    uint64_t cell_of_pos() const { return ((pos_bit_ >> 3) - grid0_) / cell_bytes(); }
-    uint64_t cells() const { return (size_ - grid0_ + cell_bytes() - 1) / cell_bytes(); }
+    uint64_t pair_bytes() const { return cell_bytes() + host_cell_; }
+    uint64_t cell_lo(uint64_t c) const {
+        return host_cell_ ? grid0_ + (c / 2) * pair_bytes() + ((c & 1) ? cell_bytes() : 0) : grid0_ + c * cell_bytes();
+    }
+    uint64_t cell_hi(uint64_t c) const { return cell_lo(c) + (host_cell_ && (c & 1) ? host_cell_ : cell_bytes()); }
+    uint64_t cell_of_pos() const {
+        const uint64_t off = (pos_bit_ >> 3) - grid0_;
+        if (!host_cell_) return off / cell_bytes();
+        return 2 * (off / pair_bytes()) + (off % pair_bytes() >= cell_bytes() ? 1 : 0);
+    }
+    uint64_t cells() const {
+        const uint64_t total = size_ - grid0_;
+        if (!host_cell_) return (total + cell_bytes() - 1) / cell_bytes();
+        const uint64_t r = total % pair_bytes();
+        return 2 * (total / pair_bytes()) + (r > 0 ? 1 : 0) + (r > cell_bytes() ? 1 : 0);
+    }
     bool spec_ok() const { return !bgzf_ && stretch_ % ALIGN == 0 && !host_mode_; }
     void spec_decode(int k, uint64_t cell, hipStream_t stream) {
         DevSet &d = *sets_[(size_t)k];
         d.spec = PieceJob();
         d.spec_cell = cell;
         if (dev_set(d.device_) != hipSuccess) return;
-        d.spec.a_byte = grid0_ + cell * cell_bytes();
+        d.spec.a_byte = cell_lo(cell);
         if (d.spec.a_byte >= size_) return;
         d.spec.first_bit = NONE;
-        d.spec.n = n_slots_;
+        d.spec.n = (uint32_t)((cell_hi(cell) - cell_lo(cell)) / stretch_);
         if (phase_a(d, d.spec, stream, true) != 0) d.spec.valid = false;
     }
     long take(int k, bool use_spec, void *d_dst, size_t room, hipStream_t stream) {
@@ -2118,7 +2135,7 @@ private:
         d.spec.valid = false;
         for (;;) {
             if (ended_) return 0;
-            const uint64_t limit = grid0_ + (cell_of_pos() + 1) * cell_bytes();
+            const uint64_t limit = cell_hi(cell_of_pos());
             const long n = piece((uint8_t *)d_dst, room, stream, limit < size_ ? limit : 0);
             if (n != 0) return n;
         }
@@ -2134,15 +2151,27 @@ private:
     // boundary at or behind its cell that passes the host's block-header test, which is where the GPU's search starts the next
     // cell (a cell decoded ahead on the GPU whose first start is elsewhere is refused and decoded in order: correctness
     // never depends on the two searches agreeing).
-    bool host_ok(size_t room) const { return host_threads_ > 0 && spec_ok() && ratio_ * 1.1 * (double)cell_bytes() <= (double)room; }
+    bool host_ok(size_t room) const { return host_threads_ > 0 && host_cell_ > 0 && spec_ok() && ratio_ * 1.1 * (double)host_cell_ <= (double)room; }
+    // (before the first piece: the grid's shape is fixed for the file)
+    void set_host(unsigned threads) {
+        host_threads_ = threads;
+        host_cell_ = 0;
+        if (!threads || !spec_ok()) return;
+        uint64_t hc = cell_bytes() / 4;
+        if (const char *e = getenv("NOHUMAN_GZ_HYBRID_CELL")) hc = (uint64_t)atoll(e);  // tuning / test knob: bytes of gzip a host cell
+        hc = hc / stretch_ * stretch_;
+        if (hc < stretch_) hc = stretch_;
+        if (hc > cell_bytes()) hc = cell_bytes();
+        host_cell_ = hc;
+    }
     void host_decode_ahead(uint64_t cell) {
         hc_valid_ = false;
         if (!hc_) hc_.reset(new RangeGunzip());
-        const uint64_t lo = grid0_ + cell * cell_bytes();
+        const uint64_t lo = cell_lo(cell), hi = cell_hi(cell);
         if (lo >= size_) return;
         // (chunks of 4 MiB like the host reader's; the tests' tiny cells are cut into eight)
-        const size_t chunk = (size_t)std::min<uint64_t>((uint64_t)4u << 20, std::max<uint64_t>(cell_bytes() / 8, 4096));
-        if (hc_->start(base_, size_, lo, lo + cell_bytes(), host_threads_, chunk) != 0) return;
+        const size_t chunk = (size_t)std::min<uint64_t>((uint64_t)4u << 20, std::max<uint64_t>((hi - lo) / 8, 4096));
+        if (hc_->start(base_, size_, lo, hi, host_threads_, chunk) != 0) return;
         hc_->wait_speculated();
         hc_cell_ = cell;
         hc_valid_ = true;
@@ -2158,12 +2187,14 @@ private:
             use_spec = false;
             if (!hc_valid_) return fail("the host decoder could not be started");
             hc_valid_ = false;
-            if (!h_text_ || h_text_cap_ < room) {
+            // (page-locked room for the cell's text: eight times its gzip bytes, more where the file has been seen to inflate further)
+            const size_t want = (size_t)std::min<double>((double)room, std::max(8.0, ratio_ * 2.0) * (double)(cell_hi(cell) - cell_lo(cell)) + (double)(1u << 20));
+            if (!h_text_ || h_text_cap_ < want) {
                 if (h_text_) cache_free(s_->device_, h_text_cap_, h_text_, true);
                 h_text_cap_ = 0;
-                h_text_ = (uint8_t *)cache_alloc(s_->device_, room, true);
+                h_text_ = (uint8_t *)cache_alloc(s_->device_, want, true);
                 if (!h_text_) return fail("the host lane's page-locked text buffer cannot be had");
-                h_text_cap_ = room;
+                h_text_cap_ = want;
             }
             uint8_t window[WSIZE], wafter[WSIZE];
             GZ_TRY(hipMemcpyAsync(window, s_->d_win_[s_->win_], WSIZE, hipMemcpyDeviceToHost, stream));
@@ -2172,7 +2203,7 @@ private:
             bool stream_end = false;
             std::vector<GzSeg> segs;
             const auto t0 = std::chrono::steady_clock::now();
-            const long n = hc_->finish(pos_bit_, window, h_text_, room, &eb, &stream_end, wafter, segs);
+            const long n = hc_->finish(pos_bit_, window, h_text_, h_text_cap_, &eb, &stream_end, wafter, segs);
             if (n < 0) {
                 error_ = hc_->error() + " (" + path_ + ")";
                 hc_->close();
@@ -2298,6 +2329,7 @@ private:
     long fake_crc_ = 0;
     // the host lane of the hybrid reader (take_host)
     unsigned host_threads_ = 0;
+    uint64_t host_cell_ = 0;  // bytes of gzip of the grid's odd cells (0: no host lane, a uniform grid)
     std::unique_ptr<RangeGunzip> hc_;
     uint64_t hc_cell_ = 0;
     bool hc_valid_ = false;
@@ -2340,7 +2372,7 @@ long DevGunzip::take(int set, bool use_ahead, void *d_dst, size_t room, hipStrea
 bool DevGunzip::ended() const { return impl_->ended_; }
 const std::string &DevGunzip::error() const { return impl_->error_; }
 bool DevGunzip::integrity_failure() const { return impl_->integrity_; }
-void DevGunzip::set_host_threads(unsigned n) { impl_->host_threads_ = n; }
+void DevGunzip::set_host_threads(unsigned n) { impl_->set_host(n); }
 bool DevGunzip::host_ok(size_t room) const { return impl_->host_ok(room); }
 void DevGunzip::decode_ahead_host(uint64_t cell) { impl_->host_decode_ahead(cell); }
 long DevGunzip::take_host(bool use_ahead, void *d_dst, size_t room, hipStream_t stream) { return impl_->take_host(use_ahead, d_dst, room, stream); }
@@ -2921,20 +2953,41 @@ private:
         if (next_cell_ <= k) next_cell_ = k + 1;
         for (Lane &l : lanes_)
             if (l.state == 2 && l.cell < k) l.state = 0;  // (the stream is past it: a block longer than a cell -- tiny cells of the tests)
-        // (hybrid: while nobody holds the cell the stream stands in, one idle DEVICE lane is kept back for it -- load_next takes
-        //  it in order at once --, and the host lane gets a cell only while a cell's expected text fits its buffer)
-        const bool hybrid = lanes_.size() > n_dev_lanes_;
-        bool owned = false, kept = false;
-        for (const Lane &l : lanes_)
-            if (l.state != 0 && l.cell == k) owned = true;
+        if (lanes_.size() == n_dev_lanes_) {
+            for (Lane &l : lanes_)
+                if (l.state == 0 && next_cell_ < n) {
+                    l.cell = next_cell_++;
+                    l.state = 1;
+                }
+            cv_.notify_all();
+            return;
+        }
+        // The hybrid reader: the grid alternates (DevGunzip: even cells of a piece's size, odd cells a quarter of that): the odd
+        // cells are the host lane's, the even ones the devices' -- which take the odd ones too while the host lane is off (a file
+        // that inflates further than its buffer holds).  While nobody holds the cell the stream stands in, one idle DEVICE lane is
+        // kept back for it: load_next takes it in order at once.  Nobody runs more than eight cells ahead.
+        auto taken = [&](uint64_t c) {
+            for (const Lane &l : lanes_)
+                if (l.state != 0 && l.cell == c) return true;
+            return false;
+        };
+        const bool host_on = gz_.host_ok(room_ - head_);
+        const bool owned = taken(k);
+        bool kept = false;
         for (Lane &l : lanes_) {
-            if (l.state != 0 || next_cell_ >= n) continue;
-            if (l.host && !gz_.host_ok(room_ - head_)) continue;
-            if (hybrid && !owned && !l.host && !kept) {
+            if (l.state != 0 || (l.host && !host_on)) continue;
+            if (!owned && !l.host && !kept) {
                 kept = true;
                 continue;
             }
-            l.cell = next_cell_++;
+            uint64_t c = k + 1;
+            for (; c < n && c <= k + 8; c++) {
+                if (taken(c)) continue;
+                const bool odd = (c & 1) != 0;
+                if (l.host ? odd : (!odd || !host_on)) break;
+            }
+            if (c >= n || c > k + 8) continue;
+            l.cell = c;
             l.state = 1;
         }
         cv_.notify_all();
@@ -3000,6 +3053,7 @@ private:
             cv_.wait(lk, [&] { return lanes_[g].state != 1 || stop_ || done_; });
             if (stop_ || done_) return -2;
             lanes_[g].state = 3;  // the stream's own (not idle: no new cell until the piece is through)
+            lanes_[g].cell = k;
         }
         Lane &ln = lanes_[g];
         if (fail_at_ > 0 && piece_no_ == (uint64_t)fail_at_) return fail("test knob NOHUMAN_GZDEV_FAIL_AT");  // (the handover, provoked)
