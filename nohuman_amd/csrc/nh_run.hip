@@ -964,12 +964,12 @@ int run_engines(const std::vector<Engine *> &engines, const nh_run_args *a, nh_s
         const int n = atoi(e);
         while (G == 1 && (int)devs1.size() < n && n <= 4) devs1.push_back(devs1[0]), devs2.push_back(devs2[0]);
     }
-    // The hybrid reader (round 6, nh_gunzip.hip): some cells of each input's piece grid inflated by host workers beside the GPU's.
-    // OFF unless asked for (NOHUMAN_GZ_HYBRID=n: n workers per file; 1: the run's threads less four, shared between the files):
-    // built for the runs whose kept text is re-encoded on the GPU -- there the chip's codec kernels, inflate and deflate in turn,
-    // are what the run waits for while the host's cores idle -- and measured there: 28.8 -> 13.0 Mreads/s (profiles/r06_hybrid.txt).
-    // A cell takes six host workers 0.85 s + 0.4 s against the GPU's 0.28 s, the stream's pieces are taken in order, and a GPU lane
-    // holds ONE cell decoded ahead: the chip waits for the host's cell instead of being relieved by it.
+    // The hybrid reader (round 6, nh_gunzip.hip): the odd cells of each input's (then alternating) piece grid inflated by host workers
+    // beside the GPU's.  OFF unless asked for (NOHUMAN_GZ_HYBRID=n: n workers per file; 1: the run's threads less four, shared between
+    // the files): built for the runs whose kept text is re-encoded on the GPU -- there the chip's codec kernels, inflate and deflate in
+    // turn, are what the run waits for -- and measured there: 30.8 -> 24.7 Mreads/s on 40 M pairs (profiles/r06_hybrid.txt).  The pool's
+    // boxes give a process 16 CPUs' worth of time; the pipeline's own threads use half of it at that speed, and a dozen inflate
+    // workers on top get the whole process throttled, the threads that feed the GPU included.
     unsigned hybrid_threads = 0;
     if (const char *e = getenv("NOHUMAN_GZ_HYBRID")) {
         const int v = atoi(e);
