@@ -693,10 +693,10 @@ extern "C" int nh_debug_gunzip_ranges(const char *in, const char *out, uint32_t 
                     rc = nh::set_error(NH_EIO, "gzip: crc error");
                 a = m.out_pos;
             }
-            member(nh::crc32_fast(0, o.data() + a, o.size() - (size_t)a), o.size() - a, false, 0, 0);
+            if (o.size() > a) member(nh::crc32_fast(0, o.data() + a, o.size() - (size_t)a), o.size() - a, false, 0, 0);
             if (!rc && !nh::write_all(fout, o.data(), o.size())) rc = nh::set_error(NH_EIO, "write error on %s", out);
             if (o.size() >= window.size()) memcpy(window.data(), o.data() + o.size() - window.size(), window.size());
-            else {
+            else if (!o.empty()) {
                 memmove(window.data(), window.data() + o.size(), window.size() - o.size());
                 memcpy(window.data() + window.size() - o.size(), o.data(), o.size());
             }

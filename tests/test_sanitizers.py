@@ -3,7 +3,7 @@ AddressSanitizer is not available on the pool, and nh_run has some ten cooperati
 nh_inflate.cpp (speculative multi-threaded gzip decoder), nh_fastx.cpp (block reader with its read-ahead thread) and
 nh_codec.cpp (the host gzip encoder's worker pool) are built AS THEY ARE into tools/san_host.cpp with
 -fsanitize=address,undefined and again with -fsanitize=thread, and run over gzip streams of every shape the decoder's own tests
-use, at 1 / 4 / 8 threads.  The CPU oracle (test infrastructure) runs its own test file once under ASan + UBSan.
+use, at 1 / 4 / 8 threads; round 6: the same streams through RangeGunzip, the hybrid reader's host lane, cell by cell.  The CPU oracle (test infrastructure) runs its own test file once under ASan + UBSan.
 CPU only."""
 import gzip
 import os
@@ -97,6 +97,20 @@ def test_gzip_decoder_and_block_reader_under_sanitizers(binaries, corpus, kind):
             if kind == "tsan" and name in ("fastq_l1", "fastq_l9", "huffman_only", "fixed") and threads == 1:
                 continue  # (one thread: nothing to race; keeps the suite within its minute)
             _run(binaries[kind], ["gunzip", p, threads, chunk], kind)
+
+
+@pytest.mark.parametrize("kind", ["asan", "tsan"])
+def test_range_decoder_of_the_hybrid_reader_under_sanitizers(binaries, corpus, kind):
+    """RangeGunzip (round 6): a cell's chunks decoded ahead by a worker pool, stitched later from a position and window handed in --
+    a second way through the decoder's shared state (tails, jobs, pieces), with its own thread hand-overs"""
+    paths, _ = corpus
+    for name, p in paths.items():
+        if kind == "tsan" and name in ("fastq_l1", "fastq_l9", "huffman_only", "fixed", "zeros"):
+            continue
+        for threads, cell, chunk, every in ((4, 200_000, 40_000, 1), (8, 120_000, 9_000, 2)):
+            out = _run(binaries[kind], ["ranges", p, threads, cell, chunk, every], kind)
+            if name == "fastq_l6":
+                assert "ranges ok" in out and "zlib ok" in out
 
 
 @pytest.mark.parametrize("kind", ["asan", "tsan"])

@@ -5,6 +5,8 @@
 //   san_host gunzip file.gz threads chunk_bytes   ParallelGunzip against zlib byte for byte, then the block reader over the file
 //   san_host gzip file threads                    the host gzip encoder (make_encoder, the pool of block workers) on the file's
 //                                                 bytes, written in odd-sized pieces; zlib inflates the result back to the input
+//   san_host ranges file.gz threads cell chunk every   RangeGunzip (the hybrid reader's host lane, round 6): the file as a chain of cells,
+//                                                 every `every`-th by a fresh RangeGunzip decoded ahead and stitched, against zlib
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -82,8 +84,53 @@ static int gzip_mode(const char *path, unsigned threads) {
     return 0;
 }
 
+extern "C" int nh_debug_gunzip_ranges(const char *in, const char *out, uint32_t threads, uint64_t cell_bytes, uint64_t chunk_bytes,
+                                      uint32_t host_every, uint64_t *stats4);
+
+static int ranges_mode(const char *path, unsigned threads, uint64_t cell, uint64_t chunk, unsigned every) {
+    std::vector<uint8_t> ref;
+    bool ref_ok = true;
+    {
+        gzFile g = gzopen(path, "rb");
+        if (!g) return 2;
+        std::vector<uint8_t> buf(1 << 20);
+        for (;;) {
+            int n = gzread(g, buf.data(), (unsigned)buf.size());
+            if (n < 0) { ref_ok = false; break; }
+            if (n == 0) break;
+            ref.insert(ref.end(), buf.begin(), buf.begin() + n);
+        }
+        int err = 0;
+        gzerror(g, &err);
+        if (err != Z_OK && err != Z_STREAM_END) ref_ok = false;
+        gzclose(g);
+    }
+    const std::string out = std::string(path) + ".ranges.out";
+    uint64_t st[4] = {0, 0, 0, 0};
+    const int rc = nh_debug_gunzip_ranges(path, out.c_str(), threads, cell, chunk, every, st);
+    std::vector<uint8_t> got;
+    if (rc == 0) {
+        FILE *f = fopen(out.c_str(), "rb");
+        if (!f) return 1;
+        uint8_t buf[65536];
+        size_t n;
+        while ((n = fread(buf, 1, sizeof buf, f)) > 0) got.insert(got.end(), buf, buf + n);
+        fclose(f);
+    }
+    unlink(out.c_str());
+    if (rc == 0 && ref_ok && got != ref) {
+        printf("MISMATCH: %zu vs %zu bytes\n", got.size(), ref.size());
+        return 1;
+    }
+    printf("%zu bytes, ranges %s, zlib %s, %llu cells by RangeGunzip, %llu chunks accepted\n", got.size(), rc == 0 ? "ok" : nh_last_error(),
+           ref_ok ? "ok" : "error", (unsigned long long)st[0], (unsigned long long)st[1]);
+    return 0;
+}
+
 int main(int argc, char **argv) {
     if (argc >= 4 && !strcmp(argv[1], "gzip")) return gzip_mode(argv[2], (unsigned)atoi(argv[3]));
+    if (argc >= 7 && !strcmp(argv[1], "ranges"))
+        return ranges_mode(argv[2], (unsigned)atoi(argv[3]), (uint64_t)atoll(argv[4]), (uint64_t)atoll(argv[5]), (unsigned)atoi(argv[6]));
     if (argc < 5 || strcmp(argv[1], "gunzip")) return 2;
     const char *path = argv[2];
     const unsigned threads = (unsigned)atoi(argv[3]);
