@@ -275,7 +275,17 @@ static int parse_taxonomy(Engine *e, const void *taxo, size_t taxo_len) {
         if (i >= 1 && p >= i) return set_error(NH_EDB, "taxo.k2d: parent id %llu of node %llu is not below it", (unsigned long long)p, (unsigned long long)i);
         e->parent[i] = i == 0 ? 0u : (uint32_t)p;
         e->external[i] = rd64(n + 40);
+        // what the report writer (-r, nh_run.hip) walks on the host: the children's range and the two string offsets
+        const uint64_t first = rd64(n + 8), cnt = rd64(n + 16), name_off = rd64(n + 24), rank_off = rd64(n + 32);
+        if (cnt && (first <= i || first >= nc || cnt > nc - first))
+            return set_error(NH_EDB, "taxo.k2d: children [%llu, +%llu) of node %llu are not nodes behind it", (unsigned long long)first,
+                             (unsigned long long)cnt, (unsigned long long)i);
+        if ((nl && name_off >= nl) || (rl && rank_off >= rl) || (!nl && name_off) || (!rl && rank_off))
+            return set_error(NH_EDB, "taxo.k2d: name / rank offset of node %llu lies outside the string tables", (unsigned long long)i);
     }
+    // (the two string tables are read as C strings)
+    if ((nl && tb[32 + 56 * nc + nl - 1] != 0) || (rl && tb[32 + 56 * nc + nl + rl - 1] != 0))
+        return set_error(NH_EDB, "taxo.k2d: a string table does not end with a NUL byte");
     return NH_OK;
 }
 

@@ -118,6 +118,44 @@ def test_a_taxonomy_that_loops_is_refused(toy, toy_oracle):
     _still_works(toy, toy_oracle)
 
 
+def test_what_the_report_writer_walks_is_checked_too(toy, toy_oracle, tmp_path):
+    """-r / --kraken-report (nh_run.hip write_report) walks the children's ranges and reads names and ranks as C strings out of
+    taxo.k2d on the HOST: a range that leaves the node table or an offset that leaves its string table is NH_EDB at nh_open, not
+    a wild read when the report is written"""
+    from nohuman_amd import Engine, EngineError
+    ob, tb, hb, _, _ = toy
+    nc, nl, rl = struct.unpack_from("<3Q", tb, 8)
+    cases = []
+    for node, field, value in ((1, 1, nc), (1, 2, nc + 5), (2, 1, 1), (3, 3, nl), (3, 3, nl + 1000), (4, 4, rl), (4, 4, 1 << 40)):
+        bad = bytearray(tb)
+        if field == 2:
+            struct.pack_into("<Q", bad, 32 + 56 * node + 8, node + 1)  # a first child that exists ...
+        if field == 1 and value == 1:
+            struct.pack_into("<Q", bad, 32 + 56 * node + 16, 1)        # ... / a count, so that the range is looked at
+        struct.pack_into("<Q", bad, 32 + 56 * node + 8 * field, value)
+        cases.append(bytes(bad))
+    unterminated = bytearray(tb)
+    unterminated[32 + 56 * nc + nl - 1] = ord("x")
+    cases.append(bytes(unterminated))
+    for bad in cases:
+        with pytest.raises(EngineError) as ei:
+            Engine.from_images(ob, bad, hb)
+        assert ei.value.code == NH_EDB and "taxo.k2d" in ei.value.message
+    # and the good one still writes its report
+    reads = tmp_path / "r.fq"
+    _, _, _, genomes, _ = toy
+    g = genomes[sorted(genomes)[0]]
+    reads.write_bytes(b"".join(b"@r%d\n%s\n+\n%s\n" % (i, g[i * 7:i * 7 + 150], b"I" * 150) for i in range(40)))
+    db = tmp_path / "db"
+    db.mkdir()
+    (db / "opts.k2d").write_bytes(ob)
+    (db / "taxo.k2d").write_bytes(tb)
+    (db / "hash.k2d").write_bytes(hb)
+    with Engine.open(str(db)) as eng:
+        eng.run(str(reads), str(tmp_path / "o.fq"), report=str(tmp_path / "rep.txt"))
+    assert (tmp_path / "rep.txt").read_text().count("\n") >= 2
+
+
 def test_the_check_runs_at_hbm_speed_on_a_full_size_table():
     """1.43 G cells = 5.7 GB (BASELINE.json's table size): the pass is a streaming read, a few milliseconds."""
     from nohuman_amd import Engine
