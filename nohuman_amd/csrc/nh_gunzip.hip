@@ -1557,7 +1557,7 @@ public:
                   (!bgzf_ || host_malloc((void **)&d.h_start_, (size_t)n_slots_ * 8, hipHostMallocDefault) == hipSuccess);
         if (ok) ok = hipMemset(d.d_win_[0], 0, WSIZE) == hipSuccess;  // (the input buffer's tail is zeroed with every piece's upload)
         if (ok)
-            ok = hipFuncSetAttribute((const void *)k_inflate3, hipFuncAttributeMaxDynamicSharedMemorySize, (int)inflate_lds()) == hipSuccess &&
+            ok = hipFuncSetAttribute((const void *)k_inflate3, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(Lds3)) == hipSuccess &&
                  hipFuncSetAttribute((const void *)k_scan_local, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(2 * WSIZE)) == hipSuccess &&
                  hipFuncSetAttribute((const void *)k_scan_groups, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(2 * WSIZE)) == hipSuccess;
         for (auto &e : d.ev_)
@@ -1691,13 +1691,7 @@ private:
     static constexpr size_t SEARCH3_LDS = sizeof(Lds3) > 64 * CLROW ? sizeof(Lds3) : 64 * CLROW;
     typedef void (*InflateFn)(const uint32_t *, uint64_t, uint32_t, ChunkDesc *, uint16_t *, uint32_t, uint32_t);
     InflateFn inflate_kernel() const { return k_inflate3; }
-    // (tuning knob NOHUMAN_GZDEV_LDS=bytes: a larger request per one-wave workgroup leaves fewer decoder waves on a CU -- room for the
-    //  gzip ENCODER's waves beside them, which do not fit next to five decoder waves a SIMD: profiles/r06_e2e.txt)
-    size_t inflate_lds() const {
-        const char *e = getenv("NOHUMAN_GZDEV_LDS");  // (per piece, not per chunk)
-        const size_t pad = e ? (size_t)atol(e) : 0;
-        return pad > sizeof(Lds3) && pad <= 65536 ? pad : sizeof(Lds3);
-    }
+    size_t inflate_lds() const { return sizeof(Lds3); }
 
     long fail(const std::string &m, bool integrity = false) {
         if (error_.empty()) {
