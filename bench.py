@@ -1204,8 +1204,9 @@ def e2e_multi_run(spec):
     if spec["fake_devices"]:  # NOHUMAN_BENCH_ONE_GPU: N logical devices on the one GPU (nh_internal.h)
         env["NOHUMAN_FAKE_DEVICES"] = str(spec["devices"])
     t = time.perf_counter()
+    # (bounded: this leg has never met a real multi-GPU node -- a child that hangs there must not cost the scaling line more than minutes)
     p = subprocess.run([sys.executable, os.path.abspath(__file__), "--multi-child", sp], env=env, capture_output=True, text=True,
-                       timeout=3600)
+                       timeout=float(os.environ.get("NOHUMAN_BENCH_MULTI_TIMEOUT", "300")))
     t_child = time.perf_counter() - t
     lines = [ln for ln in p.stdout.splitlines() if ln.startswith('{"multi_child"')]
     if p.returncode != 0 or not lines:
