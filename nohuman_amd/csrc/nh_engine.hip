@@ -939,7 +939,9 @@ int classify_device(Engine *e, const void *d_bases, const void *d_seq_off, uint6
     const unsigned slot = e->launch_seq.fetch_add(1) % LAUNCH_SLOTS;
     std::lock_guard<std::mutex> slot_lock(e->slot_mu[slot]);
 #ifndef NH_NO_SLOT_WAIT  // (-DNH_NO_SLOT_WAIT: rounds 1-5's behaviour, to show that tests/test_gpu_threads.py sees the difference)
-    if (e->slot_used[slot] && e->slot_stream[slot] != stream) {  // (the same stream orders its launches by itself)
+    // (also when the slot's last launch went to this very stream handle: the runtime drops a wait for an event of the same
+    //  stream itself, and a handle can be a NEW stream that took a destroyed one's place)
+    if (e->slot_used[slot]) {
         const hipError_t we = hipStreamWaitEvent(stream, e->slot_ev[slot], 0);
         if (we != hipSuccess) return set_error(NH_EDEVICE, "classify launch (slot wait): %s", hipGetErrorString(we));
     }
@@ -966,7 +968,6 @@ int classify_device(Engine *e, const void *d_bases, const void *d_seq_off, uint6
     if (he == hipSuccess && n_frag) {
         he = hipEventRecord(e->slot_ev[slot], stream);
         e->slot_used[slot] = true;
-        e->slot_stream[slot] = stream;
     }
     if (he != hipSuccess) return set_error(NH_EDEVICE, "classify launch: %s", hipGetErrorString(he));
     return NH_OK;

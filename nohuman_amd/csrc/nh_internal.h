@@ -74,7 +74,6 @@ struct Engine {
     // in flight -- what every caller in this repo does -- the event has long fired; more than that are ORDERED, not
     // undefined (rounds 1-5 documented "not supported" and nothing detected it).  slot_mu orders the hosts' enqueues.
     hipEvent_t slot_ev[LAUNCH_SLOTS] = {};
-    hipStream_t slot_stream[LAUNCH_SLOTS] = {};
     bool slot_used[LAUNCH_SLOTS] = {};
     std::mutex slot_mu[LAUNCH_SLOTS];
     LaunchKnobs knobs;
