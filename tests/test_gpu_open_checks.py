@@ -153,7 +153,8 @@ def test_what_the_report_writer_walks_is_checked_too(toy, toy_oracle, tmp_path):
     (db / "hash.k2d").write_bytes(hb)
     with Engine.open(str(db)) as eng:
         eng.run(str(reads), str(tmp_path / "o.fq"), report=str(tmp_path / "rep.txt"))
-    assert (tmp_path / "rep.txt").read_text().count("\n") >= 2
+    rep = (tmp_path / "rep.txt").read_text()
+    assert rep.count("\n") >= 1 and "taxon1" in rep  # (reads cut from the segment every genome shares: the root's clade)
 
 
 def test_the_check_runs_at_hbm_speed_on_a_full_size_table():
