@@ -967,9 +967,9 @@ int run_engines(const std::vector<Engine *> &engines, const nh_run_args *a, nh_s
     // The hybrid reader (round 6, nh_gunzip.hip): the odd cells of each input's (then alternating) piece grid inflated by host workers
     // beside the GPU's.  OFF unless asked for (NOHUMAN_GZ_HYBRID=n: n workers per file; 1: the run's threads less four, shared between
     // the files): built for the runs whose kept text is re-encoded on the GPU -- there the chip's codec kernels, inflate and deflate in
-    // turn, are what the run waits for -- and measured there: 30.8 -> 24.7 Mreads/s on 40 M pairs (profiles/r06_hybrid.txt).  The pool's
-    // boxes give a process 16 CPUs' worth of time; the pipeline's own threads use half of it at that speed, and a dozen inflate
-    // workers on top get the whole process throttled, the threads that feed the GPU included.
+    // turn, are what the run waits for -- and measured there: 30.8 -> 24.7 Mreads/s on 40 M pairs (profiles/r06_hybrid.txt): a host
+    // piece's in-order part (stitching, CRC, copy, upload: 0.2 s) holds the file's stream up five times a file, and pieces decoded
+    // ahead lose the in-order reader's staged input.  Correct and covered; what would make it pay is written down there.
     unsigned hybrid_threads = 0;
     if (const char *e = getenv("NOHUMAN_GZ_HYBRID")) {
         const int v = atoi(e);
