@@ -2173,8 +2173,21 @@ private:
         const size_t chunk = (size_t)std::min<uint64_t>((uint64_t)4u << 20, std::max<uint64_t>((hi - lo) / 8, 4096));
         if (hc_->start(base_, size_, lo, hi, host_threads_, chunk) != 0) return;
         hc_->wait_speculated();
+        // still ahead of the stream: the chunks' byte-decoded tails to their places in the page-locked buffer, CRC'd (RangeGunzip::prepare)
+        if (!sets_.empty() && dev_set(sets_[0]->device_) == hipSuccess && host_text_room(cell)) hc_->prepare(h_text_, h_text_cap_);
         hc_cell_ = cell;
         hc_valid_ = true;
+    }
+    // page-locked room for a host cell's text: eight times its gzip bytes, more where the file has been seen to inflate further
+    bool host_text_room(uint64_t cell) {
+        const size_t want = (size_t)(std::max(8.0, ratio_ * 2.0) * (double)(cell_hi(cell) - cell_lo(cell)) + (double)(1u << 20));
+        if (h_text_ && h_text_cap_ >= want) return true;
+        if (h_text_) cache_free(sets_[0]->device_, h_text_cap_, h_text_, true);
+        h_text_cap_ = 0;
+        h_text_ = (uint8_t *)cache_alloc(sets_[0]->device_, want, true);
+        if (!h_text_) return false;
+        h_text_cap_ = want;
+        return true;
     }
     long take_host(bool use_spec, void *d_dst, size_t room, hipStream_t stream) {
         if (!error_.empty()) return -1;
@@ -2187,15 +2200,7 @@ private:
             use_spec = false;
             if (!hc_valid_) return fail("the host decoder could not be started");
             hc_valid_ = false;
-            // (page-locked room for the cell's text: eight times its gzip bytes, more where the file has been seen to inflate further)
-            const size_t want = (size_t)std::min<double>((double)room, std::max(8.0, ratio_ * 2.0) * (double)(cell_hi(cell) - cell_lo(cell)) + (double)(1u << 20));
-            if (!h_text_ || h_text_cap_ < want) {
-                if (h_text_) cache_free(s_->device_, h_text_cap_, h_text_, true);
-                h_text_cap_ = 0;
-                h_text_ = (uint8_t *)cache_alloc(s_->device_, want, true);
-                if (!h_text_) return fail("the host lane's page-locked text buffer cannot be had");
-                h_text_cap_ = want;
-            }
+            if (!host_text_room(cell)) return fail("the host lane's page-locked text buffer cannot be had");
             uint8_t window[WSIZE], wafter[WSIZE];
             GZ_TRY(hipMemcpyAsync(window, s_->d_win_[s_->win_], WSIZE, hipMemcpyDeviceToHost, stream));
             GZ_TRY(hipStreamSynchronize(stream));
@@ -2210,6 +2215,7 @@ private:
                 return -1;
             }
             hc_->close();
+            if ((size_t)n > room) return fail("a host cell's text does not fit the piece's buffer");
             if (n > 0) GZ_TRY(hipMemcpyAsync(d_dst, h_text_, (size_t)n, hipMemcpyHostToDevice, stream));
             GZ_TRY(hipMemcpyAsync(s_->d_win_[s_->win_ ^ 1], wafter, WSIZE, hipMemcpyHostToDevice, stream));
             GZ_TRY(hipStreamSynchronize(stream));
