@@ -1637,9 +1637,10 @@ public:
             fprintf(stderr, "[nohuman trace] gzip reader, %s: pieces by device (device:pieces)%s\n", path_.c_str(), per.c_str());
         }
         if (trace_ && host_pieces_)
-            fprintf(stderr, "[nohuman trace] gzip reader, %s: %llu pieces inflated by the host's cores (%u workers; stitching, marker replacement and upload %.3f s)\n",
-                    path_.c_str(), (unsigned long long)host_pieces_, host_threads_, host_s_);
+            fprintf(stderr, "[nohuman trace] gzip reader, %s: %llu pieces inflated by the host's cores (%u workers; %llu with only their chunks' heads left in stream order; in-order part and upload %.3f s)\n",
+                    path_.c_str(), (unsigned long long)host_pieces_, host_threads_, (unsigned long long)host_fast_, host_s_);
         host_pieces_ = 0;
+        host_fast_ = 0;
         host_s_ = 0;
         if (hc_) hc_->close();
         hc_.reset();
@@ -1820,7 +1821,9 @@ private:
         const double copy_s = std::chrono::duration<double>(std::chrono::steady_clock::now() - c0).count();
         GZA_TRY(hipMemcpyAsync(d.d_in_, src, avail, hipMemcpyHostToDevice, stream));
         GZA_TRY(hipMemsetAsync(d.d_in_ + avail, 0, 1024, stream));  // (what a kernel reads beyond the valid bits is zeros)
-        if (!spec && sets_.size() == 1 && stage_ahead_ && !j.at_eof) {
+        // (not with a host lane: there the ONE set also decodes cells ahead, on its lane's thread, and stages their bytes through h_in_
+        //  -- the very buffer this helper may be filling; found by the soak as "invalid deflate data" in the piece behind a host piece)
+        if (!spec && sets_.size() == 1 && stage_ahead_ && !host_cell_ && !j.at_eof) {
             // where the next piece is expected: at the end of this one's last stretch (it starts at the first block boundary at
             // or behind it: up to a block further on, which the buffer's slack covers)
             pf_.start = (j.a_byte + (uint64_t)n_str * stretch_) / ALIGN * ALIGN;
@@ -2174,7 +2177,8 @@ private:
         if (hc_->start(base_, size_, lo, hi, host_threads_, chunk) != 0) return;
         hc_->wait_speculated();
         // still ahead of the stream: the chunks' byte-decoded tails to their places in the page-locked buffer, CRC'd (RangeGunzip::prepare)
-        if (!sets_.empty() && dev_set(sets_[0]->device_) == hipSuccess && host_text_room(cell)) hc_->prepare(h_text_, h_text_cap_);
+        static const bool no_prepare = getenv("NOHUMAN_GZ_HYBRID_PREPARE") && getenv("NOHUMAN_GZ_HYBRID_PREPARE")[0] == '0';  // (A/B and debugging aid)
+        if (!no_prepare && !sets_.empty() && dev_set(sets_[0]->device_) == hipSuccess && host_text_room(cell)) hc_->prepare(h_text_, h_text_cap_);
         hc_cell_ = cell;
         hc_valid_ = true;
     }
@@ -2214,6 +2218,15 @@ private:
                 hc_->close();
                 return -1;
             }
+            if (debug_) {
+                uint64_t sa = 0, sr = 0, sg = 0;
+                hc_->stats(&sa, &sr, &sg);
+                fprintf(stderr, "[gzdev] host piece: cell %llu [%llu, %llu), the stream at bit %llu, text %ld at %llu, ends at bit %llu%s; chunks accepted %llu rejected %llu, %llu bytes decoded in order%s\n",
+                        (unsigned long long)cell, (unsigned long long)cell_lo(cell), (unsigned long long)cell_hi(cell), (unsigned long long)pos_bit_, n,
+                        (unsigned long long)st_.text_bytes, (unsigned long long)eb, stream_end ? " (end of stream)" : "", (unsigned long long)sa, (unsigned long long)sr,
+                        (unsigned long long)sg, hc_->finished_from_prepared() ? ", prepared" : "");
+            }
+            if (hc_->finished_from_prepared()) host_fast_++;
             hc_->close();
             if ((size_t)n > room) return fail("a host cell's text does not fit the piece's buffer");
             if (n > 0) GZ_TRY(hipMemcpyAsync(d_dst, h_text_, (size_t)n, hipMemcpyHostToDevice, stream));
@@ -2341,7 +2354,7 @@ private:
     bool hc_valid_ = false;
     uint8_t *h_text_ = nullptr;  // page-locked: a host cell's text on its way to the device
     size_t h_text_cap_ = 0;
-    uint64_t host_pieces_ = 0;
+    uint64_t host_pieces_ = 0, host_fast_ = 0;
     double host_s_ = 0;
     bool integrity_ = false;  // the error is one of the END-TO-END checks on the decode: a member's CRC-32 / ISIZE, the stream's end
     double open_s_ = 0;
