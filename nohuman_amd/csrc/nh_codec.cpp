@@ -616,10 +616,9 @@ extern "C" int nh_gunzip_file(const char *in, const char *out, uint32_t threads,
 // RangeGunzip whose chunks are all decoded before the stream's position and window at the cell are handed to it; every
 // `host_every`-th cell that way, the cells between by the sequential decoder (standing in for the GPU's pieces, which end at the
 // first block boundary behind their cell too).  The members' CRC-32 / ISIZE are checked here from the stretches the ranges report.
-// stats5: {cells by RangeGunzip, chunks accepted, chunks rejected, bytes decoded in order, cells whose in-order part was the heads
-// only (RangeGunzip::prepare on every second cell)}.  Needs no GPU.
+// stats4: {cells by RangeGunzip, chunks accepted, chunks rejected, bytes decoded in order}.  Needs no GPU.
 extern "C" int nh_debug_gunzip_ranges(const char *in, const char *out, uint32_t threads, uint64_t cell_bytes, uint64_t chunk_bytes,
-                                      uint32_t host_every, uint64_t *stats5) {
+                                      uint32_t host_every, uint64_t *stats4) {
     if (!in || !out || !cell_bytes) return nh::set_error(NH_EINVAL, "nh_debug_gunzip_ranges: bad argument");
     int fd = ::open(in, O_RDONLY | O_CLOEXEC);
     if (fd < 0) return nh::set_error(NH_EIO, "cannot open %s", in);
@@ -641,7 +640,7 @@ extern "C" int nh_debug_gunzip_ranges(const char *in, const char *out, uint32_t 
     uint64_t P = body ? (uint64_t)(body - base) * 8 : 0;
     std::vector<uint8_t> window(32768, 0), wafter(32768);
     uint32_t run_crc = 0;
-    uint64_t run_len = 0, n_host = 0, acc = 0, rej = 0, gap = 0, n_fast = 0;
+    uint64_t run_len = 0, n_host = 0, acc = 0, rej = 0, gap = 0;
     bool ended = false;
     if (!host_every) host_every = 1;
     auto member = [&](uint32_t crc, uint64_t len, bool end, uint32_t want_crc, uint32_t want_isize) {
@@ -663,7 +662,6 @@ extern "C" int nh_debug_gunzip_ranges(const char *in, const char *out, uint32_t 
             // (deflate expands 1032 : 1 at most; the buffer is not touched beyond what is written)
             const size_t cap = (size_t)std::min<uint64_t>((std::min<uint64_t>(hi, size) - lo + 65536) * 1040, (uint64_t)1 << 33);
             std::unique_ptr<uint8_t[]> text(new uint8_t[cap]);
-            if ((n_host & 1) == 0) rg.prepare(text.get(), cap);  // (every second cell: the tails done ahead, the heads in order; the others all in order)
             std::vector<nh::GzSeg> segs;
             const long n = rg.finish(P, window.data(), text.get(), cap, &end_bit, &ended, wafter.data(), segs);
             if (n < 0) {
@@ -673,7 +671,6 @@ extern "C" int nh_debug_gunzip_ranges(const char *in, const char *out, uint32_t 
             uint64_t a = 0, r = 0, g = 0;
             rg.stats(&a, &r, &g);
             acc += a, rej += r, gap += g, n_host++;
-            n_fast += rg.finished_from_prepared() ? 1 : 0;
             uint64_t sum = 0;
             for (const nh::GzSeg &sg : segs) {
                 if (!member(sg.crc, sg.len, sg.member_end, sg.want_crc, sg.want_isize)) rc = nh::set_error(NH_EIO, "gzip: crc error");
@@ -710,7 +707,7 @@ extern "C" int nh_debug_gunzip_ranges(const char *in, const char *out, uint32_t 
     if (!rc && run_len) rc = nh::set_error(NH_EIO, "gzip: unexpected end of file");
     if (fout >= 0 && ::close(fout) != 0 && rc == NH_OK) rc = nh::set_error(NH_EIO, "write error on %s", out);
     munmap((void *)base, size);
-    if (stats5) stats5[0] = n_host, stats5[1] = acc, stats5[2] = rej, stats5[3] = gap, stats5[4] = n_fast;
+    if (stats4) stats4[0] = n_host, stats4[1] = acc, stats4[2] = rej, stats4[3] = gap;
     return rc;
 }
 

@@ -1637,10 +1637,9 @@ public:
             fprintf(stderr, "[nohuman trace] gzip reader, %s: pieces by device (device:pieces)%s\n", path_.c_str(), per.c_str());
         }
         if (trace_ && host_pieces_)
-            fprintf(stderr, "[nohuman trace] gzip reader, %s: %llu pieces inflated by the host's cores (%u workers; %llu with only their chunks' heads left in stream order; in-order part and upload %.3f s)\n",
-                    path_.c_str(), (unsigned long long)host_pieces_, host_threads_, (unsigned long long)host_fast_, host_s_);
+            fprintf(stderr, "[nohuman trace] gzip reader, %s: %llu pieces inflated by the host's cores (%u workers; stitching, marker replacement and upload %.3f s)\n",
+                    path_.c_str(), (unsigned long long)host_pieces_, host_threads_, host_s_);
         host_pieces_ = 0;
-        host_fast_ = 0;
         host_s_ = 0;
         if (hc_) hc_->close();
         hc_.reset();
@@ -2176,22 +2175,8 @@ private:
         const size_t chunk = (size_t)std::min<uint64_t>((uint64_t)4u << 20, std::max<uint64_t>((hi - lo) / 8, 4096));
         if (hc_->start(base_, size_, lo, hi, host_threads_, chunk) != 0) return;
         hc_->wait_speculated();
-        // still ahead of the stream: the chunks' byte-decoded tails to their places in the page-locked buffer, CRC'd (RangeGunzip::prepare)
-        static const bool no_prepare = getenv("NOHUMAN_GZ_HYBRID_PREPARE") && getenv("NOHUMAN_GZ_HYBRID_PREPARE")[0] == '0';  // (A/B and debugging aid)
-        if (!no_prepare && !sets_.empty() && dev_set(sets_[0]->device_) == hipSuccess && host_text_room(cell)) hc_->prepare(h_text_, h_text_cap_);
         hc_cell_ = cell;
         hc_valid_ = true;
-    }
-    // page-locked room for a host cell's text: eight times its gzip bytes, more where the file has been seen to inflate further
-    bool host_text_room(uint64_t cell) {
-        const size_t want = (size_t)(std::max(8.0, ratio_ * 2.0) * (double)(cell_hi(cell) - cell_lo(cell)) + (double)(1u << 20));
-        if (h_text_ && h_text_cap_ >= want) return true;
-        if (h_text_) cache_free(sets_[0]->device_, h_text_cap_, h_text_, true);
-        h_text_cap_ = 0;
-        h_text_ = (uint8_t *)cache_alloc(sets_[0]->device_, want, true);
-        if (!h_text_) return false;
-        h_text_cap_ = want;
-        return true;
     }
     long take_host(bool use_spec, void *d_dst, size_t room, hipStream_t stream) {
         if (!error_.empty()) return -1;
@@ -2204,7 +2189,15 @@ private:
             use_spec = false;
             if (!hc_valid_) return fail("the host decoder could not be started");
             hc_valid_ = false;
-            if (!host_text_room(cell)) return fail("the host lane's page-locked text buffer cannot be had");
+            // (page-locked room for the cell's text: eight times its gzip bytes, more where the file has been seen to inflate further)
+            const size_t want = (size_t)std::min<double>((double)room, std::max(8.0, ratio_ * 2.0) * (double)(cell_hi(cell) - cell_lo(cell)) + (double)(1u << 20));
+            if (!h_text_ || h_text_cap_ < want) {
+                if (h_text_) cache_free(s_->device_, h_text_cap_, h_text_, true);
+                h_text_cap_ = 0;
+                h_text_ = (uint8_t *)cache_alloc(s_->device_, want, true);
+                if (!h_text_) return fail("the host lane's page-locked text buffer cannot be had");
+                h_text_cap_ = want;
+            }
             uint8_t window[WSIZE], wafter[WSIZE];
             GZ_TRY(hipMemcpyAsync(window, s_->d_win_[s_->win_], WSIZE, hipMemcpyDeviceToHost, stream));
             GZ_TRY(hipStreamSynchronize(stream));
@@ -2221,14 +2214,12 @@ private:
             if (debug_) {
                 uint64_t sa = 0, sr = 0, sg = 0;
                 hc_->stats(&sa, &sr, &sg);
-                fprintf(stderr, "[gzdev] host piece: cell %llu [%llu, %llu), the stream at bit %llu, text %ld at %llu, ends at bit %llu%s; chunks accepted %llu rejected %llu, %llu bytes decoded in order%s\n",
+                fprintf(stderr, "[gzdev] host piece: cell %llu [%llu, %llu), the stream at bit %llu, text %ld at %llu, ends at bit %llu%s; chunks accepted %llu rejected %llu, %llu bytes decoded in order\n",
                         (unsigned long long)cell, (unsigned long long)cell_lo(cell), (unsigned long long)cell_hi(cell), (unsigned long long)pos_bit_, n,
                         (unsigned long long)st_.text_bytes, (unsigned long long)eb, stream_end ? " (end of stream)" : "", (unsigned long long)sa, (unsigned long long)sr,
-                        (unsigned long long)sg, hc_->finished_from_prepared() ? ", prepared" : "");
+                        (unsigned long long)sg);
             }
-            if (hc_->finished_from_prepared()) host_fast_++;
             hc_->close();
-            if ((size_t)n > room) return fail("a host cell's text does not fit the piece's buffer");
             if (n > 0) GZ_TRY(hipMemcpyAsync(d_dst, h_text_, (size_t)n, hipMemcpyHostToDevice, stream));
             GZ_TRY(hipMemcpyAsync(s_->d_win_[s_->win_ ^ 1], wafter, WSIZE, hipMemcpyHostToDevice, stream));
             GZ_TRY(hipStreamSynchronize(stream));
@@ -2354,7 +2345,7 @@ private:
     bool hc_valid_ = false;
     uint8_t *h_text_ = nullptr;  // page-locked: a host cell's text on its way to the device
     size_t h_text_cap_ = 0;
-    uint64_t host_pieces_ = 0, host_fast_ = 0;
+    uint64_t host_pieces_ = 0;
     double host_s_ = 0;
     bool integrity_ = false;  // the error is one of the END-TO-END checks on the decode: a member's CRC-32 / ISIZE, the stream's end
     double open_s_ = 0;

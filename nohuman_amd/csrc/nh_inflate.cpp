@@ -934,24 +934,7 @@ struct Chunk {
     size_t read_off = 0;  // consumer: bytes already handed out
     bool verified = false;
     size_t out_off = 0;   // range mode: where the chunk's text goes in the caller's buffer
-    // range mode, prepared ahead (GunzipImpl::prepare_range): per member stretch of the chunk's output the CRC-32 and length of the
-    // part that lies in the byte-decoded tail -- all of the chunk but its 16-bit head, which needs the window
-    std::vector<std::pair<size_t, uint32_t>> tail_crc;
 };
-
-// the chunk's output as stretches by gzip member: f(begin, end, is_member_end, member index)
-template <class F>
-void for_segs(const Chunk &c, F f) {
-    const size_t total = c.dec.total();
-    size_t pos = 0, mi = 0;
-    while (pos < total || mi < c.dec.members.size()) {
-        const bool me = mi < c.dec.members.size();
-        const size_t e = me ? (size_t)c.dec.members[mi].out_pos : total;
-        f(pos, e, me, mi);
-        pos = e;
-        if (me) mi++;
-    }
-}
 
 // the chunk's output bytes [from, to) as one or two contiguous ranges, applied to f(ptr, n); the
 // 16-bit part has been narrowed in place by resolve_chunk()
@@ -1119,8 +1102,6 @@ public:
         cur_len_ = 0;
         accepted_ = rejected_ = gap_bytes_ = 0;
         out_total_ = 0;
-        prepared_ = false;
-        pre_dst_ = nullptr;
         for (unsigned i = 0; i < threads_; i++) workers_.emplace_back([this] { worker(); });
         dispatch();
         return 0;
@@ -1143,14 +1124,6 @@ public:
         if (!range_ || failed_) return -1;
         P_ = from_bit;
         memcpy(window_, window, WSIZE);
-        used_prepared_ = false;
-        if (dst == pre_dst_ && finish_prepared(segs)) {  // (everything but the chunks' heads was done ahead: prepare_range)
-            *end_bit = P_;
-            *stream_end = ended_;
-            memcpy(window_after, window_, WSIZE);
-            return (long)out_total_;
-        }
-        prepared_ = false;
         range_dst_ = dst;
         range_cap_ = cap;
         out_total_ = 0;
@@ -1176,87 +1149,6 @@ public:
         *stream_end = ended_;
         memcpy(window_after, window_, WSIZE);
         return (long)out_total_;
-    }
-
-    // Range mode, still AHEAD of the stream (after wait_speculated(), same thread): if the chunks chain -- each starts exactly where
-    // the one before ended, which is the rule, not luck -- everything that does not need the window is done now, on the workers:
-    // every chunk's byte-decoded tail (all but its first 32 KiB or so) is copied to its place in the caller's buffer and its
-    // CRC-32 taken per member stretch.  finish_range() then only has to replace the markers of the chunks' heads: milliseconds
-    // instead of the cell's whole text through resolve + CRC + copy in stream order.  (The first form of the hybrid reader did
-    // all of it in order: 0.2 s a cell during which the stream stood still, profiles/r06_hybrid.txt.)
-    void prepare_range(uint8_t *dst, size_t cap) {
-        prepared_ = false;
-        if (!range_ || failed_ || inflight_.empty()) return;
-        size_t off = 0;
-        for (size_t i = 0; i < inflight_.size(); i++) {
-            Chunk &c = *inflight_[i];
-            if (!c.found || (c.dec.stop != STOP_BOUNDARY && c.dec.stop != STOP_STREAM_END)) return;
-            if (i && c.dec.start_bit != inflight_[i - 1]->dec.end_bit) return;
-            if (i + 1 < inflight_.size() && c.dec.stop != STOP_BOUNDARY) return;
-            c.out_off = off;
-            off += c.dec.total();
-        }
-        if (off > cap) return;
-        pre_dst_ = dst;
-        pre_total_ = off;
-        {
-            std::lock_guard<std::mutex> lk(mu_);
-            pre_pending_ = inflight_.size();
-            for (auto &c : inflight_) jobs_.push_back({c.get(), 2});
-        }
-        cv_work_.notify_all();
-        {
-            std::unique_lock<std::mutex> lk(mu_);
-            cv_done_.wait(lk, [&] { return pre_pending_ == 0; });
-        }
-        prepared_ = true;
-    }
-    void pre_chunk(Chunk &c) {  // (a worker) the tail's bytes to their place, its CRCs by member stretch
-        const size_t n16 = c.dec.n16;
-        if (c.dec.n8) memcpy(pre_dst_ + c.out_off + n16, c.dec.out8.data(), c.dec.n8);
-        c.tail_crc.clear();
-        for_segs(c, [&](size_t a, size_t b, bool, size_t) {
-            const size_t ta = a > n16 ? a : n16;
-            if (b > ta) c.tail_crc.push_back({b - ta, crc32_fast(0, c.dec.out8.data() + (ta - n16), b - ta)});
-            else c.tail_crc.push_back({0, 0});
-        });
-    }
-    // the in-order part of a prepared range: true when it was used (the stream stands exactly at the first chunk's start)
-    bool finish_prepared(std::vector<GzSeg> &segs) {
-        if (!prepared_ || inflight_.empty() || P_ != inflight_.front()->dec.start_bit) return false;
-        segs.clear();
-        for (auto &cp : inflight_) {
-            Chunk &c = *cp;
-            memcpy(c.window_before, window_, WSIZE);
-            const size_t n16 = c.dec.n16;
-            const uint16_t *s16 = c.dec.out16.data();
-            uint8_t *d = pre_dst_ + c.out_off;
-            for (size_t i = 0; i < n16; i++) {
-                const uint16_t v = s16[i];
-                const uint8_t from_window = window_[v & 0x7fffu];
-                d[i] = v & 0x8000u ? from_window : (uint8_t)v;
-            }
-            size_t k = 0;
-            for_segs(c, [&](size_t a, size_t b, bool me, size_t mi) {
-                const size_t he = b < n16 ? b : n16;
-                uint32_t crc = a < he ? crc32_fast(0, d + a, he - a) : 0;
-                const std::pair<size_t, uint32_t> &t = c.tail_crc[k++];
-                if (t.first) crc = a < he ? (uint32_t)crc32_combine(crc, t.second, (z_off_t)t.first) : t.second;
-                segs.push_back({(uint64_t)(b - a), crc, me, me ? c.dec.members[mi].crc : 0u, me ? c.dec.members[mi].isize : 0u});
-            });
-            advance_window(c);
-            P_ = c.dec.end_bit;
-            if (c.dec.stop == STOP_STREAM_END) ended_ = true;
-            accepted_++;
-        }
-        out_total_ = pre_total_;
-        while (!inflight_.empty()) {
-            spare_.push_back(std::move(inflight_.front()));
-            inflight_.pop_front();
-        }
-        prepared_ = false;
-        used_prepared_ = true;
-        return true;
     }
 
     long read(uint8_t *dst, size_t cap) {
@@ -1313,7 +1205,7 @@ public:
 private:
     struct Job {
         Chunk *c;
-        int kind;  // 0 speculative decode, 1 resolve, 2 range mode: a chunk's tail copied and CRC'd ahead (pre_chunk)
+        int kind;  // 0 speculative decode, 1 resolve
     };
     // what a successor needs to continue from a finished chunk whose own start was certain
     struct TailInfo {
@@ -1336,8 +1228,6 @@ private:
             const auto j0 = std::chrono::steady_clock::now();
             if (j.kind == 0)
                 speculate(*j.c);
-            else if (j.kind == 2)
-                pre_chunk(*j.c);
             else {
                 resolve_chunk(*j.c);
                 if (range_dst_) copy_out(*j.c);
@@ -1353,9 +1243,7 @@ private:
             }
             {
                 std::lock_guard<std::mutex> lk(mu_);
-                if (j.kind == 2) {
-                    pre_pending_--;
-                } else if (j.kind == 0) {
+                if (j.kind == 0) {
                     j.c->spec_done = true;
                     if (tail) {
                         tails_[j.c->index] = tail;
@@ -1688,12 +1576,6 @@ private:
     uint64_t lo_ = 0, hi_ = 0;
     uint8_t *range_dst_ = nullptr;
     size_t range_cap_ = 0, out_total_ = 0;
-    bool prepared_ = false;  // prepare_range() did the tails of every chunk ahead, into pre_dst_
-public:
-    bool used_prepared_ = false;  // the last finish_range() only had the heads left to do
-private:
-    uint8_t *pre_dst_ = nullptr;
-    size_t pre_total_ = 0, pre_pending_ = 0;
     size_t size_ = 0, chunk_ = 0, n_chunks_ = 0, max_ahead_ = 0;
     unsigned threads_ = 1;
     bool force_chain_ = false;
@@ -1726,8 +1608,6 @@ int RangeGunzip::start(const uint8_t *base, size_t size, uint64_t lo_byte, uint6
     return impl_->open_range(base, size, lo_byte, hi_byte, threads, chunk_bytes);
 }
 void RangeGunzip::wait_speculated() { impl_->wait_speculated(); }
-void RangeGunzip::prepare(uint8_t *dst, size_t cap) { impl_->prepare_range(dst, cap); }
-bool RangeGunzip::finished_from_prepared() const { return impl_->used_prepared_; }
 long RangeGunzip::finish(uint64_t from_bit, const uint8_t *window, uint8_t *dst, size_t cap, uint64_t *end_bit, bool *stream_end,
                          uint8_t *window_after, std::vector<GzSeg> &segs) {
     return impl_->finish_range(from_bit, window, dst, cap, end_bit, stream_end, window_after, segs);

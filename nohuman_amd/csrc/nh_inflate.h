@@ -88,11 +88,6 @@ public:
     RangeGunzip &operator=(const RangeGunzip &) = delete;
     int start(const uint8_t *base, size_t size, uint64_t lo_byte, uint64_t hi_byte, unsigned threads, size_t chunk_bytes);
     void wait_speculated();  // every chunk has been tried (needs neither the stream's position nor its window)
-    // Still ahead of the stream (optional, after wait_speculated()): if the chunks chain, their byte-decoded tails -- all of the text
-    // but the chunks' first 32 KiB or so -- go to their places in dst and are CRC'd now, on the workers; finish() with the SAME dst then
-    // only replaces the markers of the heads (a few milliseconds in stream order instead of the range's whole text).
-    void prepare(uint8_t *dst, size_t cap);
-    bool finished_from_prepared() const;  // the last finish() found the range prepared and the stream at its first chunk
     // -1: error(); else the bytes of text written to dst
     long finish(uint64_t from_bit, const uint8_t *window, uint8_t *dst, size_t cap, uint64_t *end_bit, bool *stream_end,
                 uint8_t *window_after, std::vector<GzSeg> &segs);
