@@ -27,7 +27,7 @@ for d in ("pmc1", "pmc2", "pmc3", "pmc4", "pmc5"):
     acc = collections.defaultdict(float); n = 0
     for f in glob.glob(out + "/%s/*counter_collection.csv" % d):
         for r in csv.DictReader(open(f)):
-            if "k_deflateILi" in r["Kernel_Name"]:
+            if "k_deflateILi" in r["Kernel_Name"] or "k_deflate<" in r["Kernel_Name"]:  # (mangled or demangled, by rocprofv3 version)
                 acc[r["Counter_Name"]] += float(r["Counter_Value"])
                 n += 1
     disp = n / max(1, len(acc))
