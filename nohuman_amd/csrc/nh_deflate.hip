@@ -50,6 +50,11 @@ constexpr uint32_t BLOCK_IN = 32768;           // input bytes after which a bloc
 constexpr uint32_t TOK_CAP = BLOCK_IN + 512;   // tokens a block can hold (one per byte at worst, plus the last step)
 constexpr uint32_t OB_WORDS = 136;             // staging row of the bit writer
 constexpr uint32_t PRIOR_BYTES = NLIT + NDIST; // code lengths handed from chunk to chunk: the match finder's prices
+// The phase timers of NOHUMAN_GZIP_PROF keep a dozen scalars alive across the step loop, in a kernel that spills scalar registers
+// already: they are compiled in by -DNH_DFL_PROF=1 only (make ab-dflprof -> tools/ab_engine_dflprof.so, NOHUMAN_ENGINE_LIB)
+#ifndef NH_DFL_PROF
+#define NH_DFL_PROF 0
+#endif
 
 struct DeflateArgs {
     const uint8_t *in;      // the text; readable up to n + 64
@@ -257,6 +262,7 @@ struct __attribute__((aligned(16))) RegionLds {
 template <int WAYS>
 __device__ void finish_block(RegionLds<WAYS> &S, BitOut &bo, const uint32_t *tok, uint32_t ntok, const uint8_t *src,
                              uint32_t from, uint32_t to, int lane, unsigned long long *prof) {
+    if (!NH_DFL_PROF) prof = nullptr;
     const unsigned long long f0 = prof ? __builtin_amdgcn_s_memtime() : 0ull;
     const PackedCounts lfreq{S.lfreq2}, dfreq{S.dfreq2};
     if (lane == 0) lfreq.bump(256);
@@ -407,9 +413,10 @@ __global__ __launch_bounds__(64) void k_deflate(DeflateArgs a) {
     uint32_t carry = 0, ntok = 0, blk_from = 0;
     const uint64_t lt_mask = (1ull << lane) - 1ull;
     Bytes16 next16 = load16(src + lane);
-    unsigned long long t_match = 0, t_parse = 0, t_block = 0, t_all = __builtin_amdgcn_s_memtime();
+    unsigned long long *const prof = NH_DFL_PROF ? a.prof : nullptr;
+    unsigned long long t_match = 0, t_parse = 0, t_block = 0, t_all = prof ? __builtin_amdgcn_s_memtime() : 0ull;
     for (uint32_t s = 0; s < n; s += 64) {
-        const unsigned long long c0 = a.prof ? __builtin_amdgcn_s_memtime() : 0ull;
+        const unsigned long long c0 = prof ? __builtin_amdgcn_s_memtime() : 0ull;
         const uint32_t p = s + (uint32_t)lane;
         const bool inside = p < n;
         const bool any = carry < s + 64u;
@@ -426,7 +433,7 @@ __global__ __launch_bounds__(64) void k_deflate(DeflateArgs a) {
             L = find_match<WAYS>(src, p, n, cur16, &S.bucket[WAYS * hash_bucket(h)], costs, D, gain);
         }
         __syncthreads();
-        const unsigned long long c1 = a.prof ? __builtin_amdgcn_s_memtime() : 0ull;
+        const unsigned long long c1 = prof ? __builtin_amdgcn_s_memtime() : 0ull;
         if (hashed) S.bucket[WAYS * hash_bucket(h) + ((p >> 6) % WAYS)] = make_entry(p);
         if (any) {
             // lazy rule: a longer match one position on wins over a short one here
@@ -481,27 +488,27 @@ __global__ __launch_bounds__(64) void k_deflate(DeflateArgs a) {
             ntok += (uint32_t)__popcll(sel);
         }
         __syncthreads();
-        const unsigned long long c2 = a.prof ? __builtin_amdgcn_s_memtime() : 0ull;
+        const unsigned long long c2 = prof ? __builtin_amdgcn_s_memtime() : 0ull;
         t_match += c1 - c0;
         t_parse += c2 - c1;
         if (carry - blk_from >= BLOCK_IN || s + 64u >= n) {
             const uint32_t to = carry < n ? carry : n;
             __threadfence_block();
-            finish_block<WAYS>(S, bo, tok, ntok, src, blk_from, to, lane, a.prof);
+            finish_block<WAYS>(S, bo, tok, ntok, src, blk_from, to, lane, prof);
             for (int i = lane; i < NLIT / 2; i += 64) S.lfreq2[i] = 0;
             if (lane < NDIST / 2) S.dfreq2[lane] = 0;
             __syncthreads();
             blk_from = to;
             ntok = 0;
-            if (a.prof) t_block += __builtin_amdgcn_s_memtime() - c2;
+            if (prof) t_block += __builtin_amdgcn_s_memtime() - c2;
         }
     }
-    if (a.prof && lane == 0) {
-        atomicAdd(&a.prof[0], t_match);
-        atomicAdd(&a.prof[1], t_parse);
-        atomicAdd(&a.prof[2], t_block);
-        atomicAdd(&a.prof[3], __builtin_amdgcn_s_memtime() - t_all);
-        atomicAdd(&a.prof[4], 1ull);
+    if (prof && lane == 0) {
+        atomicAdd(&prof[0], t_match);
+        atomicAdd(&prof[1], t_parse);
+        atomicAdd(&prof[2], t_block);
+        atomicAdd(&prof[3], __builtin_amdgcn_s_memtime() - t_all);
+        atomicAdd(&prof[4], 1ull);
     }
     // the region ends on a byte boundary: an empty stored block (BFINAL 0, BTYPE 0, padding, LEN 0, NLEN 0xFFFF)
     {
@@ -680,7 +687,9 @@ struct DeflateDev {  // device side of one encoder: buffers for chunks in flight
         for (const char *c = "ACGTN"; *c; c++) prior[1][(int)*c] = 2;
         if ((e = hipMemcpy(d_prior + 2 * dfl::PRIOR_BYTES, prior, sizeof prior, hipMemcpyHostToDevice)) != hipSuccess) return fail(e, "prior copy");
         if ((e = hipMemcpy(d_prior, prior[1], dfl::PRIOR_BYTES, hipMemcpyHostToDevice)) != hipSuccess) return fail(e, "prior copy");
-        if (getenv("NOHUMAN_GZIP_PROF")) {
+        if (getenv("NOHUMAN_GZIP_PROF") && !NH_DFL_PROF)
+            fprintf(stderr, "[gzip prof] this build has no phase timers: make -C nohuman_amd/csrc ab-dflprof, NOHUMAN_ENGINE_LIB=tools/ab_engine_dflprof.so\n");
+        if (getenv("NOHUMAN_GZIP_PROF") && NH_DFL_PROF) {
             if ((e = dev_malloc((void **)&d_prof, 64)) != hipSuccess) return fail(e, "prof");
             (void)hipMemset(d_prof, 0, 64);
         }
