@@ -240,8 +240,10 @@ struct __attribute__((aligned(16))) RegionLds {
     uint32_t lfreq2[NLIT / 2];  // PackedCounts
     uint32_t dfreq2[NDIST / 2];
     uint32_t clfreq[32];
-    uint8_t llen[NLIT];   // lengths of the last block built: the codes' lengths while coding, the prices while matching
+    uint8_t llen[NLIT];   // lengths of the last block built: the codes' lengths while coding
     uint8_t dlen[NDIST];
+    uint8_t lprice[NLIT]; // what the match finder prices with: the same lengths, an absent symbol at its penalty (CostsT<true>)
+    uint8_t dprice[NDIST];
     uint8_t cllen[32];
     uint16_t lcode[NLIT];
     uint16_t dcode[NDIST];
@@ -252,6 +254,7 @@ struct __attribute__((aligned(16))) RegionLds {
             uint8_t all[NLIT + NDIST];     // afterwards: hlit + hdist lengths in a row
             uint16_t items[NLIT + NDIST];  // and their run-length form
         } hdr;
+        uint32_t crct[256];                // before the first block: the byte table of the region's CRC-32
     } u;
     uint16_t cl_a[32], cl_sym[32];        // the code-length code is built while hdr is live
     uint32_t ob[OB_WORDS];
@@ -372,22 +375,33 @@ __global__ __launch_bounds__(64) void k_deflate(DeflateArgs a) {
     for (int i = lane; i < NLIT; i += 64) {
         if (i < NLIT / 2) S.lfreq2[i] = 0;
         S.llen[i] = a.prior[i];
+        S.lprice[i] = price_of_litlen((uint32_t)i, a.prior[i]);
     }
     if (lane < NDIST) {
         if (lane < NDIST / 2) S.dfreq2[lane] = 0;
         S.dlen[lane] = a.prior[NLIT + lane];
+        S.dprice[lane] = price_of_dist(a.prior[NLIT + lane]);
+    }
+    // the CRC's table: entry b = eight shifts of b (RFC 1952's polynomial), four entries a lane
+    for (uint32_t i = (uint32_t)lane; i < 256u; i += 64u) {
+        uint32_t c = i;
+#pragma unroll
+        for (int k = 0; k < 8; k++) c = (c >> 1) ^ (CRC_POLY & (0u - (c & 1u)));
+        S.u.crct[i] = c;
     }
     const PackedCounts lfreq{S.lfreq2}, dfreq{S.dfreq2};
     for (uint32_t i = (uint32_t)lane; i < OB_WORDS; i += 64) S.ob[i] = 0;
     __syncthreads();
-    // CRC-32 of the region's text: a slice per lane, bit by bit (0.7 % of the region's time; it also brings the
-    // text into the L2 before the match finder asks for it), the slices joined by one multiplication each
+    // CRC-32 of the region's text: a slice per lane, a byte a look-up in the table above (bit by bit it was 40 vector
+    // instructions per 64 bytes of text, 7 % of the kernel's; it also brings the text into the L2 before the match finder
+    // asks for it), the slices joined by one multiplication each
     {
         const uint32_t slice = (((n + 63u) >> 6) + 15u) & ~15u;
         const uint32_t start = (uint32_t)lane * slice;
         const uint32_t len = start >= n ? 0u : (n - start < slice ? n - start : slice);
         uint32_t crc = 0xFFFFFFFFu;
         const uint8_t *sp = src + start;
+        const uint32_t *T = S.u.crct;
         uint32_t i = 0;
         for (; i + 16u <= len; i += 16u) {
             const uint4 v = *(const uint4 *)(sp + i);  // (region bases and slices are multiples of 16)
@@ -395,14 +409,11 @@ __global__ __launch_bounds__(64) void k_deflate(DeflateArgs a) {
 #pragma unroll
             for (int q = 0; q < 4; q++) {
                 crc ^= w[q];
-#pragma unroll 8
-                for (int k = 0; k < 32; k++) crc = (crc >> 1) ^ (CRC_POLY & (0u - (crc & 1u)));
+#pragma unroll
+                for (int k = 0; k < 4; k++) crc = T[crc & 0xFFu] ^ (crc >> 8);
             }
         }
-        for (; i < len; i++) {
-            crc ^= sp[i];
-            for (int k = 0; k < 8; k++) crc = (crc >> 1) ^ (CRC_POLY & (0u - (crc & 1u)));
-        }
+        for (; i < len; i++) crc = T[(crc ^ sp[i]) & 0xFFu] ^ (crc >> 8);
         crc = len ? ~crc : 0u;
         uint32_t t = len ? gf2_mul(crc, gf2_xpow8((uint64_t)(n - (start + len)))) : 0u;
 #pragma unroll
@@ -428,7 +439,7 @@ __global__ __launch_bounds__(64) void k_deflate(DeflateArgs a) {
         const uint32_t h = hash_at(cur16.lo);
         uint32_t L = 0, D = 0;
         if (any && inside && p >= carry) {
-            const Costs costs{S.llen, S.dlen};
+            const CostsT<true> costs{S.lprice, S.dprice};
             int gain = 0;
             L = find_match<WAYS>(src, p, n, cur16, &S.bucket[WAYS * hash_bucket(h)], costs, D, gain);
         }
@@ -497,6 +508,8 @@ __global__ __launch_bounds__(64) void k_deflate(DeflateArgs a) {
             finish_block<WAYS>(S, bo, tok, ntok, src, blk_from, to, lane, prof);
             for (int i = lane; i < NLIT / 2; i += 64) S.lfreq2[i] = 0;
             if (lane < NDIST / 2) S.dfreq2[lane] = 0;
+            for (int i = lane; i < NLIT; i += 64) S.lprice[i] = price_of_litlen((uint32_t)i, S.llen[i]);  // (built even when the block went out stored)
+            if (lane < NDIST) S.dprice[lane] = price_of_dist(S.dlen[lane]);
             __syncthreads();
             blk_from = to;
             ntok = 0;

@@ -296,28 +296,41 @@ constexpr uint32_t SCAN_CAP = NH_SCAN_CAP;  // match lengths are measured up to 
 
 // what a match costs and what it saves, in bits, under the code lengths of the previous block (lit_cost: 288 + 32
 // entries, 0 = the symbol did not occur there)
-struct Costs {
-    const uint8_t *llen;  // literal / length lengths
-    const uint8_t *dlen;
-};
 NH_HD inline uint32_t cost_or(uint32_t len_bits, uint32_t absent) { return len_bits ? len_bits : absent; }
+constexpr uint32_t ABSENT_LIT = 12u, ABSENT_LEN = 10u, ABSENT_DIST = 8u;  // what a symbol the previous block did not use is priced at
+// PRICED = false: the two rows are code lengths (0 = absent), priced on every look-up.  PRICED = true: the rows hold prices already
+// (price_of() of every entry, refreshed when a block's codes are built): the device's form -- three look-ups in four are literals,
+// and a compare + select per look-up is a sixth of the match finder's pricing instructions.
+template <bool PRICED>
+struct CostsT {
+    const uint8_t *llen;  // literal / length lengths (or prices)
+    const uint8_t *dlen;
+    NH_HD uint32_t lit(uint32_t b) const { return PRICED ? (uint32_t)llen[b] : cost_or(llen[b], ABSENT_LIT); }
+    NH_HD uint32_t len(uint32_t sym) const { return PRICED ? (uint32_t)llen[sym] : cost_or(llen[sym], ABSENT_LEN); }
+    NH_HD uint32_t dist(uint32_t dsym) const { return PRICED ? (uint32_t)dlen[dsym] : cost_or(dlen[dsym], ABSENT_DIST); }
+};
+using Costs = CostsT<false>;
+NH_HD inline uint8_t price_of_litlen(uint32_t sym, uint32_t len_bits) { return (uint8_t)cost_or(len_bits, sym < 256u ? ABSENT_LIT : ABSENT_LEN); }
+NH_HD inline uint8_t price_of_dist(uint32_t len_bits) { return (uint8_t)cost_or(len_bits, ABSENT_DIST); }
 // prices of the first eight literals at a position as eight running sums, one per byte of the result
-NH_HD inline uint64_t literal_prices8(const Costs &c, uint64_t cur8) {
+template <typename C>
+NH_HD inline uint64_t literal_prices8(const C &c, uint64_t cur8) {
     uint64_t packed = 0;
     uint32_t acc = 0;
     for (uint32_t j = 0; j < 8; j++) {
-        acc += cost_or(c.llen[(cur8 >> (8u * j)) & 0xFFu], 12u);
+        acc += c.lit((uint32_t)(cur8 >> (8u * j)) & 0xFFu);
         packed |= (uint64_t)acc << (8u * j);
     }
     return packed;
 }
 // bits saved by coding `len` bytes as a match at `dist` instead of literals (the literals behind the eighth are
 // priced like the first eight on average)
-NH_HD inline int match_gain(const Costs &c, uint64_t lit8, uint32_t len, uint32_t dist) {
+template <typename C>
+NH_HD inline int match_gain(const C &c, uint64_t lit8, uint32_t len, uint32_t dist) {
     uint32_t sym, eb, ev, dsym, deb, dev;
     len_symbol(len - 3u, sym, eb, ev);
     dist_symbol(dist - 1u, dsym, deb, dev);
-    const int cost = (int)(cost_or(c.llen[sym], 10u) + eb + cost_or(c.dlen[dsym], 8u) + deb);
+    const int cost = (int)(c.len(sym) + eb + c.dist(dsym) + deb);
     const uint32_t lit = len <= 8u ? (uint32_t)(lit8 >> (8u * (len - 1u))) & 0xFFu : ((uint32_t)(lit8 >> 56) * len) >> 3;
     return (int)lit - cost;
 }
@@ -330,9 +343,9 @@ NH_HD inline int match_gain(const Costs &c, uint64_t lit8, uint32_t len, uint32_
 // unconditional -- issued back to back, waited for once: on a GPU the rounds' latency is what a step costs.  The
 // longest far candidate (the nearest among equals) and the run are priced under `costs`; the one that saves more
 // bits wins.  Returns the length (0: none worth taking, else 3..SCAN_CAP, SCAN_CAP meaning "at least").
-template <int WAYS, typename EntryPtr>
+template <int WAYS, typename EntryPtr, typename C>
 NH_HD inline uint32_t find_match(const uint8_t *src, uint32_t p, uint32_t n, const Bytes16 &cur16, EntryPtr entries,
-                                 const Costs &costs, uint32_t &dist_out, int &gain_out) {
+                                 const C &costs, uint32_t &dist_out, int &gain_out) {
     constexpr int NC = 1 + WAYS;
     const uint32_t room = n - p;
     const uint32_t cap = room < SCAN_CAP ? room : SCAN_CAP;
