@@ -539,7 +539,12 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(5, 8))) void
                             uint32_t e = S.lit[wlo & ((1u << ROOT3) - 1u)];
                             if (e == 0u) {
                                 uint32_t l2;
-                                const uint32_t sy = slow_symbol(w, S.lcount, S.lsym, l2);
+                                // (the walk's fifteen single-bit extractions of w are loop invariants to the compiler, which
+                                //  moved them in front of the token walk: fifteen vector instructions a WINDOW for a branch a
+                                //  FASTQ stream takes once in thousands of tokens.  An opaque copy keeps them in here.)
+                                uint64_t wq = w;
+                                asm volatile("" : "+v"(wq));
+                                const uint32_t sy = slow_symbol(wq, S.lcount, S.lsym, l2);
                                 if (l2 != 0u && sy < 286u) e = lit_entry3(sy, l2);
                             }
                             if (e != 0u) {
