@@ -363,7 +363,7 @@ __device__ void finish_block(RegionLds<WAYS> &S, BitOut &bo, const uint32_t *tok
 }
 
 template <int WAYS>
-__global__ __launch_bounds__(64) void k_deflate(DeflateArgs a) {
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3))) void k_deflate(DeflateArgs a) {
     __shared__ RegionLds<WAYS> S;
     const int lane = (int)threadIdx.x;
     const uint32_t r = blockIdx.x;
@@ -424,6 +424,10 @@ __global__ __launch_bounds__(64) void k_deflate(DeflateArgs a) {
     uint32_t carry = 0, ntok = 0, blk_from = 0;
     const uint64_t lt_mask = (1ull << lane) - 1ull;
     Bytes16 next16 = load16(src + lane);
+    // the candidates of the step to come: the bucket read and the first round's gathers of step s + 1 are issued before step
+    // s's parse (below), the compare half runs at the top of step s + 1
+    MatchProbe<1 + WAYS> pr;
+    match_probe<WAYS>(src, (uint32_t)lane, n, &S.bucket[WAYS * hash_bucket(hash_at(next16.lo))], pr);
     unsigned long long *const prof = NH_DFL_PROF ? a.prof : nullptr;
     unsigned long long t_match = 0, t_parse = 0, t_block = 0, t_all = prof ? __builtin_amdgcn_s_memtime() : 0ull;
     for (uint32_t s = 0; s < n; s += 64) {
@@ -441,11 +445,14 @@ __global__ __launch_bounds__(64) void k_deflate(DeflateArgs a) {
         if (any && inside && p >= carry) {
             const CostsT<true> costs{S.lprice, S.dprice};
             int gain = 0;
-            L = find_match<WAYS>(src, p, n, cur16, &S.bucket[WAYS * hash_bucket(h)], costs, D, gain);
+            L = match_finish<WAYS>(src, p, n, cur16, pr, costs, D, gain);
         }
         __syncthreads();
         const unsigned long long c1 = prof ? __builtin_amdgcn_s_memtime() : 0ull;
         if (hashed) S.bucket[WAYS * hash_bucket(h) + ((p >> 6) % WAYS)] = make_entry(p);
+        // (LDS operations of one wave execute in order: the next step's bucket reads see this step's entries, as they did
+        //  when they were issued at the top of that step)
+        if (s + 64u < n) match_probe<WAYS>(src, p + 64u, n, &S.bucket[WAYS * hash_bucket(hash_at(next16.lo))], pr);
         if (any) {
             // lazy rule: a longer match one position on wins over a short one here
             const uint32_t nx = (uint32_t)__shfl_down((int)L, 1);

@@ -343,24 +343,39 @@ NH_HD inline int match_gain(const C &c, uint64_t lit8, uint32_t len, uint32_t di
 // unconditional -- issued back to back, waited for once: on a GPU the rounds' latency is what a step costs.  The
 // longest far candidate (the nearest among equals) and the run are priced under `costs`; the one that saves more
 // bits wins.  Returns the length (0: none worth taking, else 3..SCAN_CAP, SCAN_CAP meaning "at least").
-template <int WAYS, typename EntryPtr, typename C>
-NH_HD inline uint32_t find_match(const uint8_t *src, uint32_t p, uint32_t n, const Bytes16 &cur16, EntryPtr entries,
-                                 const C &costs, uint32_t &dist_out, int &gain_out) {
+// The two halves of it: match_probe() reads the bucket and issues the first round's loads (it needs the position and the
+// bucket only), match_finish() does everything that looks at the bytes.  The kernel runs the probe of the NEXT step before this
+// step's parse, so that the gathers are in flight while the scalar walk along the tokens runs; find_match() = one after the other.
+template <int NC>
+struct MatchProbe {
+    uint32_t d[NC];   // candidate distances: [0] the run (1), then the bucket's ways; 0 = none
+    Bytes16 x[NC];    // the sixteen bytes at each candidate (at the position itself where there is none)
+};
+template <int WAYS, typename EntryPtr>
+NH_HD inline void match_probe(const uint8_t *src, uint32_t p, uint32_t n, EntryPtr entries, MatchProbe<1 + WAYS> &pr) {
+    constexpr int NC = 1 + WAYS;
+    const bool live = p < n && n - p >= MIN_MATCH;  // (a position at which match_finish() gives up before it looks: no candidates)
+    const uint32_t room = live ? n - p : 0u;
+    // (every address below is the region's base -- uniform -- plus a 32-bit offset that cannot be negative: d <= p.  Written so,
+    //  the compiler keeps the base in scalar registers and the loads cost one subtraction each instead of a 64-bit one)
+    pr.d[0] = live && p >= 1u ? 1u : 0u;
+    for (int k = 0; k < WAYS; k++) {
+        const uint32_t c = entries[k];
+        const bool ok = room >= HASH_BYTES && c < p && p - c <= WINDOW && p - c > 1u;
+        pr.d[1 + k] = ok ? p - c : 0u;
+    }
+    for (int k = 0; k < NC; k++) pr.x[k] = load16(src + (p - pr.d[k]));  // (distance 0 reads the position itself: readable up to n + 64)
+}
+template <int WAYS, typename C>
+NH_HD inline uint32_t match_finish(const uint8_t *src, uint32_t p, uint32_t n, const Bytes16 &cur16, MatchProbe<1 + WAYS> &pr,
+                                   const C &costs, uint32_t &dist_out, int &gain_out) {
     constexpr int NC = 1 + WAYS;
     const uint32_t room = n - p;
     const uint32_t cap = room < SCAN_CAP ? room : SCAN_CAP;
     if (cap < MIN_MATCH) return 0;
-    // (every address below is the region's base -- uniform -- plus a 32-bit offset that cannot be negative: d <= p.  Written so,
-    //  the compiler keeps the base in scalar registers and the loads cost one subtraction each instead of a 64-bit one)
-    uint32_t d[NC], len[NC];
-    d[0] = p >= 1u ? 1u : 0u;
-    for (int k = 0; k < WAYS; k++) {
-        const uint32_t c = entries[k];
-        const bool ok = room >= HASH_BYTES && c < p && p - c <= WINDOW && p - c > 1u;
-        d[1 + k] = ok ? p - c : 0u;
-    }
-    Bytes16 x[NC];
-    for (int k = 0; k < NC; k++) x[k] = load16(src + (p - d[k]));  // (distance 0 reads the position itself)
+    uint32_t len[NC];
+    const uint32_t *d = pr.d;
+    Bytes16 *x = pr.x;
     for (int k = 0; k < NC; k++) len[k] = d[k] == 0u ? 0u : equal_bytes16(x[k], cur16);
     if (cap > 16u) {
         bool any = false;
@@ -406,6 +421,13 @@ NH_HD inline uint32_t find_match(const uint8_t *src, uint32_t p, uint32_t n, con
     dist_out = bdist;
     gain_out = bgain;
     return best;
+}
+template <int WAYS, typename EntryPtr, typename C>
+NH_HD inline uint32_t find_match(const uint8_t *src, uint32_t p, uint32_t n, const Bytes16 &cur16, EntryPtr entries,
+                                 const C &costs, uint32_t &dist_out, int &gain_out) {
+    MatchProbe<1 + WAYS> pr;
+    match_probe<WAYS>(src, p, n, entries, pr);
+    return match_finish<WAYS>(src, p, n, cur16, pr, costs, dist_out, gain_out);
 }
 
 // ---- CRC-32 of the text (the gzip member's check value), computed where the text is ---------------------------
