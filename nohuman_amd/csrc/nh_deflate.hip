@@ -71,18 +71,21 @@ struct DeflateArgs {
     unsigned long long *prof;  // NULL, or 8 counters the waves add their phase times to (NOHUMAN_GZIP_PROF)
 };
 
-__device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v, int lane) {
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-        const uint32_t t = (uint32_t)__shfl_up((int)v, o);
-        if (lane >= o) v += t;
-    }
-    return v;
+// Inclusive prefix sum over the wave by data-parallel primitives (DPP): four shifts inside the rows of sixteen lanes, then row 0's
+// and rows 0-1's totals broadcast into the rows above (row_bcast:15 / :31, gfx9) -- six vector instructions and no LDS traffic,
+// where the __shfl_up form was six ds_bpermute round trips (the bit writer runs one of these per 64 tokens).
+__device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v, int) {
+    int x = (int)v;
+    x += __builtin_amdgcn_update_dpp(0, x, 0x111, 0xF, 0xF, false);  // row_shr:1
+    x += __builtin_amdgcn_update_dpp(0, x, 0x112, 0xF, 0xF, false);  // row_shr:2
+    x += __builtin_amdgcn_update_dpp(0, x, 0x114, 0xF, 0xF, false);  // row_shr:4
+    x += __builtin_amdgcn_update_dpp(0, x, 0x118, 0xF, 0xF, false);  // row_shr:8
+    x += __builtin_amdgcn_update_dpp(0, x, 0x142, 0xA, 0xF, false);  // row_bcast:15 into rows 1 and 3
+    x += __builtin_amdgcn_update_dpp(0, x, 0x143, 0xC, 0xF, false);  // row_bcast:31 into rows 2 and 3
+    return (uint32_t)x;
 }
 __device__ __forceinline__ uint32_t wave_sum(uint32_t v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += (uint32_t)__shfl_xor((int)v, o);
-    return v;
+    return (uint32_t)__builtin_amdgcn_readlane((int)wave_incl_scan(v, 0), 63);
 }
 __device__ __forceinline__ uint32_t readlane_u(uint32_t v, uint32_t l) {
     return (uint32_t)__builtin_amdgcn_readlane((int)v, (int)__builtin_amdgcn_readfirstlane((int)l));
@@ -154,19 +157,38 @@ __device__ void build_tree_wave(const Counts &freq, int nsym, int maxbits, uint8
             }
     used = used < 2 ? 2 : used;
     __syncthreads();
-    // rank sort by (count, symbol): every lane counts the smaller pairs for its symbols (broadcast reads)
-    for (int s = lane; s < NLIT; s += 64) {
+    // rank sort by (count, symbol): a lane holds the keys count << 9 | symbol of its (up to five) symbols in registers; every
+    // USED symbol's key goes round by v_readlane and each lane counts the smaller ones.  (The first version read all nsym counts
+    // from LDS for every lane: 1430 dependent-latency iterations for the literal code, a fifth of what a block's end cost;
+    // FASTQ text uses about a hundred of the 286 symbols.)
+    constexpr int SLOTS = (NLIT + 63) / 64;
+    uint32_t key[SLOTS], rank[SLOTS];
+#pragma unroll
+    for (int k = 0; k < SLOTS; k++) {
+        const int s = lane + 64 * k;
         if (s < nsym) lens[s] = 0;
         const uint32_t f = s < nsym ? freq.get(s) : 0u;
-        if (!f) continue;
-        uint32_t r = 0;
-        for (int j = 0; j < nsym; j++) {
-            const uint32_t g = freq.get(j);
-            r += g != 0u && (g < f || (g == f && j < s));
-        }
-        ta[r] = (uint16_t)f;
-        tsym[r] = (uint16_t)s;
+        key[k] = f ? (f << 9) | (uint32_t)s : 0xFFFFFFFFu;
+        rank[k] = 0;
     }
+#pragma unroll
+    for (int k = 0; k < SLOTS; k++) {
+        if (64 * k >= nsym) break;
+        uint64_t m = __ballot(key[k] != 0xFFFFFFFFu);
+        while (m) {
+            const uint32_t l = (uint32_t)__builtin_ctzll(m);
+            m &= m - 1;
+            const uint32_t g = readlane_u(key[k], l);
+#pragma unroll
+            for (int q = 0; q < SLOTS; q++) rank[q] += g < key[q];
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < SLOTS; k++)
+        if (key[k] != 0xFFFFFFFFu) {
+            ta[rank[k]] = (uint16_t)(key[k] >> 9);
+            tsym[rank[k]] = (uint16_t)(key[k] & 511u);
+        }
     __syncthreads();
     const int n = (int)used;
     if (lane == 0) huff_depths_sorted(ta, n);  // ta[i] = depth of the i-th rarest symbol
@@ -271,7 +293,9 @@ __device__ void finish_block(RegionLds<WAYS> &S, BitOut &bo, const uint32_t *tok
     if (lane == 0) lfreq.bump(256);
     __syncthreads();
     build_tree_wave(lfreq, NLIT_USED, MAXBITS, S.llen, S.lcode, S.u.tree.a, S.u.tree.ssym, lane);
+    const unsigned long long f1 = prof ? __builtin_amdgcn_s_memtime() : 0ull;
     build_tree_wave(dfreq, NDIST_USED, MAXBITS, S.dlen, S.dcode, S.u.tree.a, S.u.tree.ssym, lane);
+    const unsigned long long f2 = prof ? __builtin_amdgcn_s_memtime() : 0ull;
     {
         // hlit / hdist: one past the last used symbol; the two rows of lengths in a row, then their run-length form
         uint32_t top_l = 0, top_d = 0;
@@ -295,8 +319,16 @@ __device__ void finish_block(RegionLds<WAYS> &S, BitOut &bo, const uint32_t *tok
         }
     }
     __syncthreads();
+    const unsigned long long f3 = prof ? __builtin_amdgcn_s_memtime() : 0ull;
     build_tree_wave(PlainCounts{S.clfreq}, NCL, MAXBITS_CL, S.cllen, S.clcode, S.cl_a, S.cl_sym, lane);
-    if (prof && lane == 0) atomicAdd(&prof[5], __builtin_amdgcn_s_memtime() - f0);
+    if (prof && lane == 0) {
+        const unsigned long long f4 = __builtin_amdgcn_s_memtime();
+        atomicAdd(&prof[5], f4 - f0);
+        atomicAdd(&prof[6], f1 - f0);
+        atomicAdd(&prof[7], f2 - f1);
+        atomicAdd(&prof[8], f3 - f2);
+        atomicAdd(&prof[9], f4 - f3);
+    }
     const int hlit = S.misc[0], hdist = S.misc[1], ni = S.misc[2];
     int hclen = NCL;
     while (hclen > 4 && S.cllen[cl_order(hclen - 1)] == 0) hclen--;
@@ -710,8 +742,8 @@ struct DeflateDev {  // device side of one encoder: buffers for chunks in flight
         if (getenv("NOHUMAN_GZIP_PROF") && !NH_DFL_PROF)
             fprintf(stderr, "[gzip prof] this build has no phase timers: make -C nohuman_amd/csrc ab-dflprof, NOHUMAN_ENGINE_LIB=tools/ab_engine_dflprof.so\n");
         if (getenv("NOHUMAN_GZIP_PROF") && NH_DFL_PROF) {
-            if ((e = dev_malloc((void **)&d_prof, 64)) != hipSuccess) return fail(e, "prof");
-            (void)hipMemset(d_prof, 0, 64);
+            if ((e = dev_malloc((void **)&d_prof, 128)) != hipSuccess) return fail(e, "prof");
+            (void)hipMemset(d_prof, 0, 128);
         }
         return NH_OK;
     }
@@ -739,11 +771,13 @@ struct DeflateDev {  // device side of one encoder: buffers for chunks in flight
         if (d_tok) (void)hipFree(d_tok);
         if (d_prior) (void)hipFree(d_prior);
         if (d_prof) {
-            unsigned long long h[8] = {};
-            (void)hipMemcpy(h, d_prof, 64, hipMemcpyDeviceToHost);
+            unsigned long long h[16] = {};
+            (void)hipMemcpy(h, d_prof, 128, hipMemcpyDeviceToHost);
             if (h[4])
-                fprintf(stderr, "[gzip prof] %llu regions: per region (cycles) match %.0f  insert+parse+tokens %.0f  blocks %.0f (codes %.0f)  all %.0f\n",
-                        h[4], (double)h[0] / h[4], (double)h[1] / h[4], (double)h[2] / h[4], (double)h[5] / h[4], (double)h[3] / h[4]);
+                fprintf(stderr, "[gzip prof] %llu regions: per region (cycles) match %.0f  insert+parse+tokens %.0f  blocks %.0f (codes %.0f: literal %.0f distance %.0f "
+                                "header rows + run lengths %.0f code-length code %.0f)  all %.0f\n",
+                        h[4], (double)h[0] / h[4], (double)h[1] / h[4], (double)h[2] / h[4], (double)h[5] / h[4], (double)h[6] / h[4], (double)h[7] / h[4],
+                        (double)h[8] / h[4], (double)h[9] / h[4], (double)h[3] / h[4]);
             (void)hipFree(d_prof);
         }
         if (stream) (void)hipStreamDestroy(stream);
