@@ -4,10 +4,11 @@
 // `nohuman reads.fq.gz` run spends most of its time on once the classifier is a GPU kernel.  Here the text is cut
 // into regions of 64 KiB and ONE WAVE compresses a region:
 //
-//   match finding   64 consecutive positions per step, a lane each: hash of 5 bytes -> an 8-way bucket of earlier
-//                   positions (16 bits each, in LDS), plus distance 1 (runs); compared in lockstep rounds of 16 bytes,
-//                   the longest is taken if it saves bits under the PREVIOUS block's code lengths (find_match,
-//                   nh_deflate_core.h).
+//   match finding   64 consecutive positions per step, a lane each: hash of 5 bytes -> a 4-way bucket (6 / 8 by
+//                   NOHUMAN_GZIP_WAYS) of earlier positions (16 bits each, in LDS), plus distance 1 (runs); compared in
+//                   lockstep rounds of 16 bytes, the longest is taken if it saves bits under the PREVIOUS block's code
+//                   lengths (match_probe + match_finish, nh_deflate_core.h: the bucket read and the first round of
+//                   gathers of step s + 1 are issued before step s's parse).
 //   parse           lazy rule by a lane shift, then the chain of tokens through the step with v_readlane; a match
 //                   that reached the scan cap is extended by the whole wave at once (8 bytes a lane).
 //   block           every 32 KiB of input: symbol counts (LDS atomics) -> rank sort by the wave -> code lengths
@@ -18,7 +19,7 @@
 //                   regions' streams concatenate; a small kernel packs them for one D2H copy.
 //
 // The host side (GpuGzipEncoder, a StreamEncoder of nh_codec.h) stages the writer's spans in page-locked chunks,
-// keeps two chunks in flight, joins the regions' CRC-32s (computed by the same waves) and writes header, streams and
+// keeps two chunks in flight, joins the regions' CRC-32s (computed by the same waves, a byte-table look-up a byte) and writes header, streams and
 // trailer: one ordinary gzip member.  Parity target is the decompressed content (compression.rs:282-288), checked
 // by zlib and by this repo's own reader in tests/test_gpu_deflate.py.
 #include <errno.h>
