@@ -530,9 +530,24 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(5, 8))) void
                 uint64_t real = 0;
                 GZ_STAMP(1);
                 GZ_COUNT(6, 1);
-                // the walk along the real chain: one v_readlane a token
-                while (pos < 64u && span < SPAN3) {
-                    uint32_t inf = (uint32_t)__builtin_amdgcn_readlane((int)info, (int)pos);
+                // the walk along the real chain: one v_readlane a token.  The inner loop takes decoded literals and matches only
+                // (one test for everything else: bit 8 "not decoded yet", bit 7 = kinds 2 and 3), so that the compiler's loop is
+                // the dozen scalar instructions it looks like; the rare tokens are dealt with outside and the walk resumes.
+                for (;;) {
+                    uint32_t inf = 0;
+                    bool special = false;
+                    while (pos < 64u && span < SPAN3) {
+                        inf = (uint32_t)__builtin_amdgcn_readlane((int)info, (int)pos);
+                        if (inf & 0x180u) {
+                            special = true;
+                            break;
+                        }
+                        tpos = wlane(tpos, span, pos);
+                        real |= 1ull << pos;
+                        span += (inf >> 9) & 0x1FFu;
+                        pos += inf & 63u;
+                    }
+                    if (!special) break;  // the window's bits or the span's symbols are used up
                     if (inf & 0x100u) {  // a code longer than a root table: the canonical walk, in the token's own lane
                         GZ_COUNT(10, 1);
                         if ((uint32_t)lane == pos) {
@@ -573,6 +588,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(5, 8))) void
                         pos += inf & 63u;
                         break;
                     }
+                    // a token the slow path decoded: taken like the inner loop takes its own
                     tpos = wlane(tpos, span, pos);
                     real |= 1ull << pos;
                     span += (inf >> 9) & 0x1FFu;
