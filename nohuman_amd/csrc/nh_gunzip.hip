@@ -626,11 +626,15 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(5, 8))) void
                 // the chunk (markers).  All of the window's far matches of up to 64 symbols are loaded NOW -- one coalesced
                 // load each, past the L1 (sc1: the lines were written by this wave) -- and waited for once.
                 uint64_t mfar = __ballot(act && !isl && (tok & 0xFFFFu) > RING_DMAX3 && (tok >> 16) <= 64u);
-                uint16_t fv[4] = {0, 0, 0, 0};
                 uint64_t mf_done = 0;
                 if (mfar) {
+                    // (their place in the order does not matter: they read nothing this window writes and nobody else writes where
+                    //  they write; a later match of the ring that copies FROM one finds it written.  So they leave the in-order loop
+                    //  below -- six matches in ten on FASTQ text are of this kind.)
                     __builtin_amdgcn_s_waitcnt(0x0F70);  // what was flushed is in HBM
                     uint64_t m2 = mfar;
+                    uint16_t fv[4] = {0, 0, 0, 0};
+                    uint32_t fP[4] = {0, 0, 0, 0}, fL[4] = {0, 0, 0, 0};
 #pragma unroll
                     for (int g = 0; g < 4; g++) {
                         if (!m2) break;
@@ -644,23 +648,23 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(5, 8))) void
                         uint16_t v = (uint16_t)(0x8000u | (uint32_t)(sp + (int32_t)WSIZE));
                         if ((uint32_t)lane < L && sp >= 0) v = __hip_atomic_load(&o[sp], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                         fv[g] = v;
+                        fP[g] = Pj;
+                        fL[g] = L;
                     }
+#pragma unroll
+                    for (int g = 0; g < 4; g++)
+                        if ((uint32_t)lane < fL[g]) S.ring[(fP[g] + (uint32_t)lane) & M3] = fv[g];  // (fL = 0: not one of them)
                 }
-                // then the matches in order: the ring's own (one read, one write; with D < L the pattern repeats: lane % D),
-                // the far ones from their registers, long ones 64 symbols at a time
-                uint64_t mm = mall;
-                int fg = 0;
+                // then the other matches in order: the ring's own (one read, one write; with D < L the pattern repeats: lane % D),
+                // long ones (and the fifth far one of a window) 64 symbols at a time
+                uint64_t mm = mall & ~mf_done;
                 while (mm) {
                     const uint32_t j = (uint32_t)__builtin_ctzll(mm);
                     mm &= mm - 1;
                     const uint32_t t = (uint32_t)__builtin_amdgcn_readlane((int)tok, (int)j);
                     const uint32_t Pj = op + (uint32_t)__builtin_amdgcn_readlane((int)tpos, (int)j);
                     const uint32_t L = t >> 16, D = t & 0xFFFFu;
-                    if ((mf_done >> j) & 1ull) {
-                        const uint16_t v = fg == 0 ? fv[0] : fg == 1 ? fv[1] : fg == 2 ? fv[2] : fv[3];
-                        fg++;
-                        if ((uint32_t)lane < L) S.ring[(Pj + (uint32_t)lane) & M3] = v;
-                    } else if (L <= 64u && D <= RING_DMAX3) {
+                    if (L <= 64u && D <= RING_DMAX3) {
                         uint32_t from = (uint32_t)lane;
                         if (D < 64u) {
                             const uint32_t iv = (uint32_t)__builtin_amdgcn_readlane((int)inv, (int)D);
