@@ -1462,6 +1462,51 @@ def e2e_leg(cx, args, eng):
         shutil.rmtree(tmp, ignore_errors=True)
 
 
+def make_ont_input(cx, tmp, n_member, members, threads):
+    """ONE gzip FASTQ file of `members` x `n_member` ONT-like reads (length lognormal(8.8, 0.85) in [200, 200000]) under tmp:
+    (path, text bytes of a member, xxh3-64 of a member's text, N50).  Used by e2e_ont_leg and tools/ont_trace.py."""
+    import shutil
+    np, torch = cx.np, cx.torch
+    from nohuman_amd import _lib
+    dev = cx.dev
+    g = torch.Generator(device=dev)
+    g.manual_seed(4)
+    lens = torch.exp(torch.randn(n_member, generator=g, device=dev, dtype=torch.float64) * 0.85 + 8.8).clamp(200, 200000).to(torch.int64)
+    total = int(lens.sum().item())
+    acgt = torch.tensor([65, 67, 71, 84], dtype=torch.uint8, device=dev)
+    seq = acgt[torch.randint(0, 4, (total,), generator=g, device=dev)].cpu().numpy()
+    lens_h = lens.cpu().numpy()
+    srt = np.sort(lens_h)[::-1]
+    n50 = int(srt[np.searchsorted(np.cumsum(srt), total / 2)])
+    plain = os.path.join(tmp, "ont.fq")
+    with open(plain, "wb") as fo:
+        off = 0
+        rows = []
+        for i in range(n_member):
+            ln = int(lens_h[i])
+            rows.append(b"@ont.%d runid=nh ch=%d\n" % (i, i % 512))
+            rows.append(seq[off:off + ln].tobytes())
+            rows.append(b"\n+\n" + b"5" * ln + b"\n")
+            off += ln
+            if len(rows) >= 3000:
+                fo.write(b"".join(rows))
+                rows = []
+        fo.write(b"".join(rows))
+    del seq
+    text_len = os.path.getsize(plain)
+    member_hash = _hash_file_ranges(plain, [(0, text_len)])[0]
+    if _lib.lib().nh_compress_file(os.fsencode(plain), os.fsencode(plain + ".gz"), 2, threads) != 0:
+        raise RuntimeError("nh_compress_file failed")
+    os.remove(plain)
+    fin = os.path.join(tmp, "ont_all.fq.gz")
+    with open(fin, "wb") as out:
+        for _ in range(members):
+            with open(plain + ".gz", "rb") as src:
+                shutil.copyfileobj(src, out, 16 << 20)
+    os.remove(plain + ".gz")
+    return fin, text_len, member_hash, n50
+
+
 def e2e_ont_leg(cx, args, eng):
     """configs[3] end to end, scaled: ONE gzip FASTQ file of ONT-like reads (length lognormal(8.8, 0.85) in [200, 200000],
     N50 ~ 10 kb) through nh_run, gzip in -> gzip out (the reference's default for a gzip input, main.rs:238-245) and the input
@@ -1479,42 +1524,7 @@ def e2e_ont_leg(cx, args, eng):
     tmp = tempfile.mkdtemp(prefix="nh_bench_ont_", dir=base)
     try:
         t0 = time.time()
-        dev = cx.dev
-        g = torch.Generator(device=dev)
-        g.manual_seed(4)
-        lens = torch.exp(torch.randn(n_member, generator=g, device=dev, dtype=torch.float64) * 0.85 + 8.8).clamp(200, 200000).to(torch.int64)
-        total = int(lens.sum().item())
-        acgt = torch.tensor([65, 67, 71, 84], dtype=torch.uint8, device=dev)
-        seq = acgt[torch.randint(0, 4, (total,), generator=g, device=dev)].cpu().numpy()
-        lens_h = lens.cpu().numpy()
-        srt = np.sort(lens_h)[::-1]
-        n50 = int(srt[np.searchsorted(np.cumsum(srt), total / 2)])
-        plain = os.path.join(tmp, "ont.fq")
-        with open(plain, "wb") as fo:
-            off = 0
-            rows = []
-            for i in range(n_member):
-                ln = int(lens_h[i])
-                rows.append(b"@ont.%d runid=nh ch=%d\n" % (i, i % 512))
-                rows.append(seq[off:off + ln].tobytes())
-                rows.append(b"\n+\n" + b"5" * ln + b"\n")
-                off += ln
-                if len(rows) >= 3000:
-                    fo.write(b"".join(rows))
-                    rows = []
-            fo.write(b"".join(rows))
-        del seq
-        text_len = os.path.getsize(plain)
-        member_hash = _hash_file_ranges(plain, [(0, text_len)])[0]
-        if _lib.lib().nh_compress_file(os.fsencode(plain), os.fsencode(plain + ".gz"), 2, threads) != 0:
-            raise RuntimeError("nh_compress_file failed")
-        os.remove(plain)
-        fin = os.path.join(tmp, "ont_all.fq.gz")
-        with open(fin, "wb") as out:
-            for _ in range(members):
-                with open(plain + ".gz", "rb") as src:
-                    shutil.copyfileobj(src, out, 16 << 20)
-        os.remove(plain + ".gz")
+        fin, text_len, member_hash, n50 = make_ont_input(cx, tmp, n_member, members, threads)
         t_setup = time.time() - t0
         gout = os.path.join(tmp, "o.fq.gz")
         best = None

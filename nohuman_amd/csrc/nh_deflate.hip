@@ -654,7 +654,16 @@ void host_free(void *q) {
 }
 
 struct DeflateDev {  // device side of one encoder: buffers for chunks in flight
-    static constexpr size_t CHUNK = 128u << 20;
+    // Text per kernel launch: 128 MiB = 2048 regions, a wave each.  The chip holds 3072 of this kernel's waves, and 192 MiB chunks do
+    // make the encoder ALONE faster (34.2 -> 39.1 GB/s of kernels) -- but a run with two output files has two encoders' chunks in flight
+    // already and pays for the coarser pipeline (20 M pairs gzip -> gzip: 1.395 s at 128, 1.475 at 192, 1.512 at 256), and the one-file
+    // long-read run gains 2-4 %, inside its noise (profiles/r06_gzip_summary.txt).  NOHUMAN_GZIP_CHUNK_MB: 64 .. 512.
+    static size_t chunk_bytes_now() {  // (read when an encoder is set up: a test may ask for small chunks)
+        const char *e = getenv("NOHUMAN_GZIP_CHUNK_MB");
+        const long mb = e ? atol(e) : 128;
+        return (size_t)(mb < 64 ? 64 : mb > 512 ? 512 : mb) << 20;
+    }
+    size_t chunk = 0;  // this encoder's
     static uint32_t region_bytes() {  // NOHUMAN_GZIP_REGION: tuning (bytes of text a wave compresses)
         static const uint32_t r = [] {
             const char *e = getenv("NOHUMAN_GZIP_REGION");
@@ -704,12 +713,13 @@ struct DeflateDev {  // device side of one encoder: buffers for chunks in flight
         if ((e = hipStreamCreateWithFlags(&stream, hipStreamNonBlocking)) != hipSuccess) return fail(e, "stream");
         if ((e = hipStreamCreateWithFlags(&copy_stream, hipStreamNonBlocking)) != hipSuccess) return fail(e, "stream");
         if ((e = hipStreamCreateWithFlags(&out_stream, hipStreamNonBlocking)) != hipSuccess) return fail(e, "stream");
-        max_regions = (uint32_t)((CHUNK + REGION - 1) / REGION);
+        chunk = chunk_bytes_now();
+        max_regions = (uint32_t)((chunk + REGION - 1) / REGION);
         slot_stride = REGION + 256;
         for (Buf &b : buf) {
-            if (!(b.h_in = (uint8_t *)host_alloc(CHUNK + 64))) return set_error(NH_EOOM, "gzip encoder: no memory for the staging buffers");
-            if ((e = dev_malloc((void **)&b.d_in, CHUNK + 256)) != hipSuccess) return fail(e, "device input");
-            if ((e = hipMemset(b.d_in, 0, CHUNK + 256)) != hipSuccess) return fail(e, "memset");
+            if (!(b.h_in = (uint8_t *)host_alloc(chunk + 64))) return set_error(NH_EOOM, "gzip encoder: no memory for the staging buffers");
+            if ((e = dev_malloc((void **)&b.d_in, chunk + 256)) != hipSuccess) return fail(e, "device input");
+            if ((e = hipMemset(b.d_in, 0, chunk + 256)) != hipSuccess) return fail(e, "memset");
             if ((e = dev_malloc((void **)&b.d_slots, (size_t)max_regions * slot_stride)) != hipSuccess) return fail(e, "slots");
             if ((e = dev_malloc((void **)&b.d_sizes, max_regions * sizeof(uint32_t))) != hipSuccess) return fail(e, "sizes");
             if ((e = dev_malloc((void **)&b.d_crcs, max_regions * sizeof(uint32_t))) != hipSuccess) return fail(e, "crcs");
@@ -1023,7 +1033,7 @@ public:
         if (n && dev_set(dev_.device) != hipSuccess) rc_ = set_error(NH_EDEVICE, "gzip encoder: hipSetDevice failed");
         while (n && rc_ == NH_OK) {
             DeflateDev::Buf &b = dev_.buf[cur_];
-            const size_t room = DeflateDev::CHUNK - b.fill;
+            const size_t room = dev_.chunk - b.fill;
             const size_t take = n < room ? n : room;
             // a long span of text that is on this GPU already (the batch the classifier worked on) is copied
             // there; everything else is staged in page-locked memory and uploaded in one piece
@@ -1037,7 +1047,7 @@ public:
             total_ += take;
             c += take;
             n -= take;
-            if (rc_ == NH_OK && b.fill == DeflateDev::CHUNK) rotate();
+            if (rc_ == NH_OK && b.fill == dev_.chunk) rotate();
         }
         return rc_;
     }

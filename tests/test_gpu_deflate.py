@@ -87,8 +87,10 @@ def test_runs_long_matches_and_every_byte_value(tmp_path):
     check(geo + bytes(rng.permutation(np.frombuffer(geo, dtype=np.uint8))), str(tmp_path / "b.gz"))
 
 
-def test_several_chunks(tmp_path):
-    """More than one 64 MiB chunk: two buffers in flight, the prices handed from chunk to chunk."""
+def test_several_chunks(tmp_path, monkeypatch):
+    """More than one chunk (64 MiB here, 128 MiB by default: NOHUMAN_GZIP_CHUNK_MB is read when an encoder is set up): two
+    buffers in flight, the prices handed from chunk to chunk."""
+    monkeypatch.setenv("NOHUMAN_GZIP_CHUNK_MB", "64")
     unit = fastq_text(20000, 11)
     data = unit * (150_000_000 // len(unit))
     size = check(data, str(tmp_path / "a.gz"))
