@@ -947,6 +947,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(5, 8))) void
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     Lds3 &S = *(Lds3 *)smem;  // the wave-wide parse's tables and the lanes' own (64 x CLROW bytes) share the space: never live together
     __shared__ uint64_t cand_list[128];
+    __shared__ uint32_t pre_list[128];
     const uint32_t tbl = (uint32_t)threadIdx.x * CLROW;
     const int lane = (int)threadIdx.x;
     const uint32_t c = blockIdx.x;
@@ -974,11 +975,21 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(5, 8))) void
         }
         LDS_ORDER();
     };
-    for (uint64_t b0 = from; b0 < to && found == NONE; b0 += 64) {
-        const uint64_t b = b0 + (uint64_t)lane;
-        const uint64_t w = bits_at(bytes, b), w2 = bits_at(bytes + 7, b);  // w2: bits 56.. of the window
-        bool pre = b < to && (w & 7) == 4 && ((w >> 3) & 31) <= 29 && ((w >> 8) & 31) <= 29;
-        if (__ballot(pre)) {  // (seven of eight positions fail the first three bits)
+    // Two sieves in front of evaluate().  The cheap one (three header bits, HLIT, HDIST: 13 bits of one load) runs on every bit
+    // position, 64 a round, and passes one in nine; what passes is LISTED, and the dear one -- the Kraft sum of the code-length
+    // code's up to nineteen lengths, 150 vector instructions -- runs on full waves of listed positions instead of on every round
+    // of 64 positions with at most a handful of live lanes (it did: some lane passes the cheap sieve in nearly every round).
+    // Order is kept throughout (lists are filled by ballot compaction, emptied from the front), so the first plausible start wins
+    // as before.
+    const uint64_t base0 = (uint64_t)c * stretch_bits;  // (listed positions as 32-bit offsets from here: a stretch is 2^18 bits)
+    uint32_t np = 0;
+    auto kraft = [&](uint32_t count) {  // the first `count` listed positions
+        LDS_ORDER();
+        const bool live = (uint32_t)lane < count;
+        const uint64_t b = base0 + (live ? pre_list[lane] : 0u);
+        bool ok = false;
+        if (live) {
+            const uint64_t w = bits_at(bytes, b), w2 = bits_at(bytes + 7, b);  // w2: bits 56.. of the window
             const int ncl = (int)((w >> 13) & 15) + 4;
             int left = 128, any = 0;
             for (int i = 0; i < 19; i++) {
@@ -989,22 +1000,41 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(5, 8))) void
                     any = 1;
                 }
             }
-            pre = pre && any && left == 0;
-            const uint64_t m = __ballot(pre);
-            if (m) {
-                if (pre) cand_list[nc + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u))] = b;
-                nc += (uint32_t)__popcll(m);
-                if (nc >= 64u) {
-                    evaluate(64u);
-                    LDS_ORDER();
-                    const uint64_t keep = (uint32_t)lane + 64u < nc ? cand_list[64 + lane] : NONE;
-                    LDS_ORDER();
-                    cand_list[lane] = keep;
-                    nc -= 64u;
-                }
+            ok = any && left == 0;
+        }
+        const uint64_t m = __ballot(ok);
+        if (m) {
+            if (ok) cand_list[nc + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u))] = b;
+            nc += (uint32_t)__popcll(m);
+            if (nc >= 64u) {
+                evaluate(64u);
+                LDS_ORDER();
+                const uint64_t keep = (uint32_t)lane + 64u < nc ? cand_list[64 + lane] : NONE;
+                LDS_ORDER();
+                cand_list[lane] = keep;
+                nc -= 64u;
+            }
+        }
+        LDS_ORDER();
+    };
+    for (uint64_t b0 = from; b0 < to && found == NONE; b0 += 64) {
+        const uint64_t b = b0 + (uint64_t)lane;
+        const uint64_t w = bits_at(bytes, b);
+        const bool pre = b < to && (w & 7) == 4 && ((w >> 3) & 31) <= 29 && ((w >> 8) & 31) <= 29;
+        const uint64_t m = __ballot(pre);  // (seven of eight positions fail the first three bits)
+        if (m) {
+            if (pre) pre_list[np + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u))] = (uint32_t)(b - base0);
+            np += (uint32_t)__popcll(m);
+            if (np >= 64u) {
+                kraft(64u);
+                const uint32_t keep = (uint32_t)lane + 64u < np ? pre_list[64 + lane] : 0u;
+                LDS_ORDER();
+                pre_list[lane] = keep;
+                np -= 64u;
             }
         }
     }
+    if (found == NONE && np) kraft(np);
     if (found == NONE && nc) evaluate(nc);
     if (lane == 0) start[c] = found;
 }
