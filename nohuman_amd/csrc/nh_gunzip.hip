@@ -942,7 +942,7 @@ __device__ __forceinline__ bool plausible_block3(Lds3 &S, const uint32_t *in, ui
     return true;
 }
 
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(5, 8))) void k_search3(const uint32_t *in, uint64_t valid_bits, uint64_t stretch_bits, uint64_t first_bit,
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8))) void k_search3(const uint32_t *in, uint64_t valid_bits, uint64_t stretch_bits, uint64_t first_bit,
                                                 uint64_t *start) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     Lds3 &S = *(Lds3 *)smem;  // the wave-wide parse's tables and the lanes' own (64 x CLROW bytes) share the space: never live together
@@ -961,81 +961,80 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(5, 8))) void
     if (to + 160 > valid_bits) to = valid_bits > 160 ? valid_bits - 160 : 0;
     const uint8_t *bytes = (const uint8_t *)in;
     uint64_t found = NONE;
-    uint32_t nc = 0;
-    auto evaluate = [&](uint32_t count) {  // the first `count` candidates of the list, in order
-        LDS_ORDER();
-        const uint64_t mine = (uint32_t)lane < count ? cand_list[lane] : NONE;
-        const bool ok = mine != NONE && lane_header_ok(bytes, mine, valid_bits, tbl);
-        uint64_t m = __ballot(ok);
-        while (m && found == NONE) {
-            const uint32_t j = (uint32_t)__builtin_ctzll(m);
-            const uint64_t cb = cand_list[j];
-            if (plausible_block3(S, in, cb, valid_bits, lane)) found = cb;
-            m &= m - 1;
-        }
-        LDS_ORDER();
-    };
-    // Two sieves in front of evaluate().  The cheap one (three header bits, HLIT, HDIST: 13 bits of one load) runs on every bit
-    // position, 64 a round, and passes one in nine; what passes is LISTED, and the dear one -- the Kraft sum of the code-length
-    // code's up to nineteen lengths, 150 vector instructions -- runs on full waves of listed positions instead of on every round
-    // of 64 positions with at most a handful of live lanes (it did: some lane passes the cheap sieve in nearly every round).
-    // Order is kept throughout (lists are filled by ballot compaction, emptied from the front), so the first plausible start wins
-    // as before.
+    uint32_t nc = 0, np = 0;
+    // Two sieves in front of the candidates' evaluation.  The cheap one (three header bits, HLIT, HDIST: 13 bits of one load) runs on
+    // every bit position, 64 a round, and passes one in nine; what passes is LISTED, and the dear one -- the Kraft sum of the
+    // code-length code's up to nineteen lengths, 150 vector instructions -- runs on full waves of listed positions instead of on
+    // every round of 64 positions with at most a handful of live lanes (it did: some lane passes the cheap sieve in nearly every
+    // round).  What passes both is listed again and evaluated (the header parsed per lane, the block's first tokens walked by the
+    // wave) 64 at a time.  Order is kept throughout -- lists are filled by ballot compaction and emptied from the front -- so the
+    // first plausible start wins as before.  ONE loop with one site for each stage (the stages are large: inlined twice they
+    // spilled); once the stretch is scanned the rounds go on until the lists are empty.
     const uint64_t base0 = (uint64_t)c * stretch_bits;  // (listed positions as 32-bit offsets from here: a stretch is 2^18 bits)
-    uint32_t np = 0;
-    auto kraft = [&](uint32_t count) {  // the first `count` listed positions
-        LDS_ORDER();
-        const bool live = (uint32_t)lane < count;
-        const uint64_t b = base0 + (live ? pre_list[lane] : 0u);
-        bool ok = false;
-        if (live) {
-            const uint64_t w = bits_at(bytes, b), w2 = bits_at(bytes + 7, b);  // w2: bits 56.. of the window
-            const int ncl = (int)((w >> 13) & 15) + 4;
-            int left = 128, any = 0;
-            for (int i = 0; i < 19; i++) {
-                const unsigned at = 17 + 3 * (unsigned)i;
-                const unsigned l = i < ncl ? (at + 3 <= 56 ? (unsigned)(w >> at) & 7 : (unsigned)(w2 >> (at - 56)) & 7) : 0u;
-                if (l) {
-                    left -= 128 >> l;
-                    any = 1;
+    for (uint64_t b0 = from; found == NONE; b0 += 64) {
+        const bool scanning = b0 < to;
+        if (scanning) {
+            const uint64_t b = b0 + (uint64_t)lane;
+            const uint64_t w = bits_at(bytes, b);
+            const bool pre = b < to && (w & 7) == 4 && ((w >> 3) & 31) <= 29 && ((w >> 8) & 31) <= 29;
+            const uint64_t m = __ballot(pre);  // (seven of eight positions fail the first three bits)
+            if (m) {
+                if (pre) pre_list[np + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u))] = (uint32_t)(b - base0);
+                np += (uint32_t)__popcll(m);
+            }
+        }
+        if (np >= 64u || (!scanning && np)) {  // the dear sieve on the first 64 (or the last few) listed positions
+            const uint32_t count = np < 64u ? np : 64u;
+            LDS_ORDER();
+            const bool live = (uint32_t)lane < count;
+            const uint64_t b = base0 + (live ? pre_list[lane] : 0u);
+            bool ok = false;
+            if (live) {
+                const uint64_t w = bits_at(bytes, b), w2 = bits_at(bytes + 7, b);  // w2: bits 56.. of the window
+                const int ncl = (int)((w >> 13) & 15) + 4;
+                int left = 128, any = 0;
+                for (int i = 0; i < 19; i++) {
+                    const unsigned at = 17 + 3 * (unsigned)i;
+                    const unsigned l = i < ncl ? (at + 3 <= 56 ? (unsigned)(w >> at) & 7 : (unsigned)(w2 >> (at - 56)) & 7) : 0u;
+                    if (l) {
+                        left -= 128 >> l;
+                        any = 1;
+                    }
                 }
+                ok = any && left == 0;
             }
-            ok = any && left == 0;
-        }
-        const uint64_t m = __ballot(ok);
-        if (m) {
-            if (ok) cand_list[nc + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u))] = b;
-            nc += (uint32_t)__popcll(m);
-            if (nc >= 64u) {
-                evaluate(64u);
-                LDS_ORDER();
-                const uint64_t keep = (uint32_t)lane + 64u < nc ? cand_list[64 + lane] : NONE;
-                LDS_ORDER();
-                cand_list[lane] = keep;
-                nc -= 64u;
+            const uint64_t m = __ballot(ok);
+            if (m) {
+                if (ok) cand_list[nc + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u))] = b;
+                nc += (uint32_t)__popcll(m);
             }
+            const uint32_t keep = (uint32_t)lane + count < np ? pre_list[count + lane] : 0u;
+            LDS_ORDER();
+            pre_list[lane] = keep;
+            np -= count;
+            LDS_ORDER();
         }
-        LDS_ORDER();
-    };
-    for (uint64_t b0 = from; b0 < to && found == NONE; b0 += 64) {
-        const uint64_t b = b0 + (uint64_t)lane;
-        const uint64_t w = bits_at(bytes, b);
-        const bool pre = b < to && (w & 7) == 4 && ((w >> 3) & 31) <= 29 && ((w >> 8) & 31) <= 29;
-        const uint64_t m = __ballot(pre);  // (seven of eight positions fail the first three bits)
-        if (m) {
-            if (pre) pre_list[np + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u))] = (uint32_t)(b - base0);
-            np += (uint32_t)__popcll(m);
-            if (np >= 64u) {
-                kraft(64u);
-                const uint32_t keep = (uint32_t)lane + 64u < np ? pre_list[64 + lane] : 0u;
-                LDS_ORDER();
-                pre_list[lane] = keep;
-                np -= 64u;
+        if (nc >= 64u || (!scanning && np == 0 && nc)) {  // the first 64 (or the last few) candidates, in order
+            const uint32_t count = nc < 64u ? nc : 64u;
+            LDS_ORDER();
+            const uint64_t mine = (uint32_t)lane < count ? cand_list[lane] : NONE;
+            const bool ok = mine != NONE && lane_header_ok(bytes, mine, valid_bits, tbl);
+            uint64_t m = __ballot(ok);
+            while (m && found == NONE) {
+                const uint32_t j = (uint32_t)__builtin_ctzll(m);
+                const uint64_t cb = cand_list[j];
+                if (plausible_block3(S, in, cb, valid_bits, lane)) found = cb;
+                m &= m - 1;
             }
+            LDS_ORDER();
+            const uint64_t keep = (uint32_t)lane + count < nc ? cand_list[count + lane] : NONE;
+            LDS_ORDER();
+            cand_list[lane] = keep;
+            nc -= count;
+            LDS_ORDER();
         }
+        if (!scanning && np == 0 && nc == 0) break;
     }
-    if (found == NONE && np) kraft(np);
-    if (found == NONE && nc) evaluate(nc);
     if (lane == 0) start[c] = found;
 }
 
